@@ -1,0 +1,64 @@
+"""Thin loader for the REFERENCE's own compiled E-step built by oracle/build_ref.py.
+TEST INFRASTRUCTURE ONLY (checker + CPU baseline).  Never imported by svae_amd/.
+
+Wraps the functions imported at /root/reference/svae/lds/lds_inference.py:18-24 exactly as
+`cython_natural_lds_estep_general` (lds_inference.py:232-237) composes them; the only change is
+materialising Python-3 `map` objects (cython_lds_inference.pyx:23,208 were written for Python 2).
+"""
+import glob
+import importlib.util
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_mods = {}
+
+
+def available():
+    return bool(glob.glob(os.path.join(_HERE, "_ref", "cython_lds_inference*.so")))
+
+
+def _load(name):
+    if name not in _mods:
+        paths = glob.glob(os.path.join(_HERE, "_ref", name + "*.so"))
+        if not paths:
+            raise ImportError("oracle/_ref/%s*.so not built; run python oracle/build_ref.py" % name)
+        spec = importlib.util.spec_from_file_location(name, paths[0])
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        _mods[name] = mod
+    return _mods[name]
+
+
+def filter_forward(init_params, pair_params, node_params):
+    """cython_lds_inference.pyx:28-90.  init_params must be the 3-tuple (J, h, logZ)."""
+    m = _load("cython_lds_inference")
+    (messages, lognorm), aux = m.natural_filter_forward_general(init_params, pair_params, node_params)
+    return messages, lognorm, aux
+
+
+def smoother(forward_messages, pair_params):
+    """cython_lds_inference.pyx:149-210."""
+    m = _load("cython_lds_inference")
+    (E_init, E_pair, E_node), aux = m.natural_smoother_general(forward_messages, pair_params)
+    return (tuple(E_init), tuple(E_pair), tuple(E_node)), aux
+
+
+def estep(natparam, node_params):
+    """cython_natural_lds_estep_general, lds_inference.py:232-237 -> (lognorm, stats)."""
+    init_params, pair_params = natparam
+    init_params = (init_params[0], init_params[1], sum(init_params[2:]))
+    messages, lognorm, _ = filter_forward(init_params, pair_params, node_params)
+    stats, _ = smoother(messages, pair_params)
+    return lognorm, stats
+
+
+def hmm_logZ(natparam):
+    """cython_hmm_inference.pyx:93-121."""
+    m = _load("cython_hmm_inference")
+    return m.hmm_logZ(natparam)
+
+
+def hmm_logZ_grad(g, aux):
+    """cython_hmm_inference.pyx:126-166; at g=1 this is the HMM E-step (hmm_inference.py:65)."""
+    m = _load("cython_hmm_inference")
+    return m.hmm_logZ_grad(g, aux)
