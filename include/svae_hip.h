@@ -1,0 +1,119 @@
+/* svae_hip.h -- C ABI of libsvae_hip.so: the MI355X (gfx950) structured E-step of mattjj/svae.
+ *
+ * Every entry point replaces one function at the reference's Python->Cython boundary
+ * (/root/reference/svae/lds/lds_inference.py:18-24) or one hot loop of svae/models/gmm.py, batched
+ * over independent sequences / data points.  Plain pointers and sizes only; no torch types.
+ *
+ * Conventions (identical to the reference's API level):
+ *   - all arrays are float64, C-order, time-major, and hold NATURAL parameters:
+ *       Gaussian potentials are (-1/2 J, h); pair potentials are
+ *       (J11 = -1/2 A'Q^-1 A, J12 = A'Q^-1, J22 = -1/2 Q^-1, logZ)        [gaussian.py:130-143]
+ *   - every pointer is a DEVICE pointer owned by the caller; calls are asynchronous on `stream`
+ *     (a hipStream_t, passed as void*); nothing is allocated internally.
+ *   - return value: 0 = launched, <0 = bad argument number -k (nothing launched).
+ *   - numerical failures (non-positive pivot = potentials not positive definite; the reference
+ *     silently ignores LAPACK `info`, cython_gaussian_grads.pxd:54-76) are reported through the
+ *     device-side `info` word: 0 = ok, k>0 = 1 + index of the first offending sequence/point.
+ */
+#ifndef SVAE_HIP_H
+#define SVAE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVAE_HIP_ABI_VERSION 1
+#define SVAE_LDS_MAX_N 15   /* register/DPP path: one 16-lane row per sequence, n+1 <= 16 */
+
+/* Library/ABI version (host only, no GPU needed). */
+int svae_hip_abi_version(void);
+
+/* Bytes of scratch `svae_lds_estep_f64` / `svae_lds_sample_f64` need for (B, T, n).
+ * Holds the per-step backward kernels (G_t, c_t, P_t^-1) written by the forward filter. */
+size_t svae_lds_workspace_bytes(int B, int T, int n);
+
+/* Batched LDS E-step = filter + RTS smoother + expected sufficient statistics + log-normalizer.
+ *
+ * Replaces, for B independent sequences sharing (init, pair) parameters,
+ *   cython_natural_lds_estep_general(natparam, node_params) -> (lognorm, expected_stats)
+ *     /root/reference/svae/lds/lds_inference.py:232-237, i.e.
+ *   natural_filter_forward_general  /root/reference/svae/lds/cython_lds_inference.pyx:28-90
+ *   natural_smoother_general        /root/reference/svae/lds/cython_lds_inference.pyx:149-195
+ *   _compute_stats                  /root/reference/svae/lds/cython_lds_inference.pyx:197-210
+ *
+ *  in : init_J (n,n), init_h (n), init_logZ (1)           = init_params (sum of trailing logZ terms)
+ *       J11, J12, J22: (n,n) if !inhomog, else (T-1,n,n) per sequence-independent step;
+ *       logZ_pair: (1) if !inhomog else (T-1)
+ *       pair_batched != 0 (inhomog only): J11/J12/J22 are (B,T-1,n,n), logZ_pair (B,T-1)
+ *         (the SLDS case, slds_svae.py:92-103, where pair params depend on each sequence's
+ *          discrete-state marginals)
+ *       node_J (B,T,n) diagonal of -1/2 precision, node_h (B,T,n), node_logZ (B,T) or NULL (=0)
+ *  out: lognorm (B)
+ *       E_init  (B, n*n + n)      = [E[x0 x0'] (n,n) | E[x0] (n)]   (the two trailing 1's of the
+ *                                    reference tuple are implied)
+ *       E_pair  (B, 3, n, n)      = [sum_t E[x_t x_t'], sum_t E[x_t x_{t+1}'], sum_t E[x_{t+1}x_{t+1}']]
+ *                                    t = 0..T-2 (4th entry of the reference tuple is T-1)
+ *                                    if inhomog: (B, T-1, 3, n, n) per-step blocks (no sum)
+ *       E_node_diagxx (B,T,n) = diag E[x_t x_t'],   E_node_x (B,T,n) = E[x_t]
+ *       info (1) int32, must be zeroed by the caller (or by a previous successful call)
+ */
+int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched,
+                       const double* init_J, const double* init_h, const double* init_logZ,
+                       const double* J11, const double* J12, const double* J22,
+                       const double* logZ_pair,
+                       const double* node_J, const double* node_h, const double* node_logZ,
+                       double* lognorm, double* E_init, double* E_pair,
+                       double* E_node_diagxx, double* E_node_x,
+                       int32_t* info, void* workspace, size_t ws_bytes, void* stream);
+
+/* Deterministic sum over the batch of the per-sequence global statistics (the quantity that is
+ * all-reduced across GPUs for the natural-gradient step, svae.py:33-34):
+ *   out (n*n + n + 3*n*n + 2) = [sum_b E_init | sum_b E_pair | sum_b lognorm | B]
+ * Homogeneous E_pair layout only. */
+int svae_lds_reduce_stats_f64(int B, int n, const double* E_init, const double* E_pair,
+                              const double* lognorm, double* out, void* stream);
+
+/* Backward sampling given the forward messages held in `workspace` by the LAST call of
+ * svae_lds_estep_f64 with the same (B,T,n) [natural_sample_backward,
+ * /root/reference/svae/lds/cython_lds_inference.pyx:310-355].
+ *   eps     (B,T,S,n) standard-normal draws (the reference draws them inside, :333; passing them
+ *           in makes the op deterministic and parity-testable)
+ *   samples (B,T,S,n)
+ */
+int svae_lds_sample_f64(int B, int T, int n, int S, const double* eps, double* samples,
+                        const void* workspace, size_t ws_bytes, void* stream);
+
+/* GMM mean-field fixed point + global statistics for one minibatch of T points
+ * [local_meanfield, /root/reference/svae/models/gmm.py:62-88; meanfield_fixed_point :90-110;
+ *  gaussian_meanfield :112-117; label_meanfield :119-124].
+ *
+ *  in : label_global (K)             = dirichlet.expectedstats(dirichlet natparam)
+ *       gaussian_globals (K,N+2,N+2) = niw.expectedstats(niw natparams), dense-packed
+ *       node_J (T,N) diagonal -1/2 precision, node_h (T,N)      (the recognition potentials)
+ *       label_init (T,K)  initial responsibilities (reference: normalize(rand(T,K)), gmm.py:126-128)
+ *       tol, max_iter     (reference: 1e-3, 100); the stop rule is on the batch-total KL
+ *  out: label_stats (T,K) responsibilities at the fixed point (after the final extra pass, :74-77)
+ *       gaussian_stats (T,N+2,N+2) dense-packed E[t(x_t)]
+ *       label_natparam (T,K), gaussian_natparam (T,N+2,N+2)
+ *       dirichlet_stats (K), niw_stats (K,N+2,N+2)      (sums over points, :80-81)
+ *       kl (1) = label_kl + gaussian_kl (:86),  iters (1) number of fixed-point iterations run
+ *       assign (T) int32 argmax_k label_stats
+ *  Limits: N <= 8, K <= 64.  Single workgroup (the minibatch total KL is a block reduction).
+ */
+int svae_gmm_meanfield_f64(int T, int N, int K,
+                           const double* label_global, const double* gaussian_globals,
+                           const double* node_J, const double* node_h, const double* label_init,
+                           double tol, int max_iter,
+                           double* label_stats, double* gaussian_stats,
+                           double* label_natparam, double* gaussian_natparam,
+                           double* dirichlet_stats, double* niw_stats,
+                           double* kl, int32_t* iters, int32_t* assign,
+                           int32_t* info, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVAE_HIP_H */

@@ -1,0 +1,29 @@
+// lds_args.hpp -- launch arguments shared by the C-ABI dispatcher and the per-n kernel units.
+#pragma once
+#include <stdint.h>
+
+namespace svae {
+
+struct LdsArgs {
+  int B, T;
+  const double* __restrict__ init_J;
+  const double* __restrict__ init_h;
+  const double* __restrict__ init_logZ;
+  const double* __restrict__ J11;
+  const double* __restrict__ J12;
+  const double* __restrict__ J22;
+  const double* __restrict__ logZ_pair;
+  const double* __restrict__ node_J;
+  const double* __restrict__ node_h;
+  const double* __restrict__ node_logZ;
+  double* __restrict__ lognorm;
+  double* __restrict__ E_init;
+  double* __restrict__ E_pair;
+  double* __restrict__ E_node_diagxx;
+  double* __restrict__ E_node_x;
+  int32_t* __restrict__ info;
+  double* __restrict__ ws;
+  long pair_seq_stride;  // doubles between consecutive sequences' pair blocks (0 = shared)
+};
+
+}  // namespace svae

@@ -1,0 +1,118 @@
+// lds_estep.hip -- C ABI (include/svae_hip.h) of the batched LDS E-step: argument checks, dispatch
+// on the latent dimension to the per-n kernels (lds_estep_n.hip), and the deterministic batch
+// reduction of the global statistics.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/svae_hip.h"
+#include "lds_args.hpp"
+
+extern "C" {
+#define SVAE_DECL(NN) int svae_lds_launch_n##NN(const svae::LdsArgs*, int, void*);
+SVAE_DECL(1) SVAE_DECL(2) SVAE_DECL(3) SVAE_DECL(4) SVAE_DECL(5) SVAE_DECL(6) SVAE_DECL(7)
+SVAE_DECL(8) SVAE_DECL(9) SVAE_DECL(10) SVAE_DECL(11) SVAE_DECL(12) SVAE_DECL(13) SVAE_DECL(14)
+SVAE_DECL(15)
+#undef SVAE_DECL
+}
+
+namespace svae {
+
+// ---- deterministic batch reduction of the global statistics ------------------------------------
+// out = [sum_b E_init (n^2+n) | sum_b E_pair (3 n^2) | sum_b lognorm | B]; one workgroup, fixed
+// summation order (pairwise tree over a strided per-thread partial) => bit-reproducible.
+__global__ __launch_bounds__(256) void lds_reduce_stats_kernel(int B, int n, const double* E_init,
+                                                               const double* E_pair,
+                                                               const double* lognorm, double* out) {
+  const int ni = n * n + n, np = 3 * n * n, tot = ni + np + 1;
+  __shared__ double red[256];
+  for (int j = blockIdx.x; j < tot; j += gridDim.x) {
+    double acc = 0.0;
+    for (int b = threadIdx.x; b < B; b += 256) {
+      double v = (j < ni) ? E_init[(long)b * ni + j]
+                 : (j < ni + np) ? E_pair[(long)b * np + (j - ni)] : lognorm[b];
+      acc += v;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[j] = red[0];
+    __syncthreads();
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[tot] = (double)B;
+}
+
+}  // namespace svae
+
+extern "C" {
+
+int svae_hip_abi_version(void) { return SVAE_HIP_ABI_VERSION; }
+
+size_t svae_lds_workspace_bytes(int B, int T, int n) {
+  if (B <= 0 || T <= 0 || n <= 0 || n > SVAE_LDS_MAX_N) return 0;
+  return (size_t)B * (size_t)T * (size_t)((2 * n + 1) * n) * sizeof(double);
+}
+
+int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched,
+                       const double* init_J, const double* init_h, const double* init_logZ,
+                       const double* J11, const double* J12, const double* J22,
+                       const double* logZ_pair,
+                       const double* node_J, const double* node_h, const double* node_logZ,
+                       double* lognorm, double* E_init, double* E_pair,
+                       double* E_node_diagxx, double* E_node_x,
+                       int32_t* info, void* workspace, size_t ws_bytes, void* stream) {
+  if (B < 0) return -1;
+  if (T < 1) return -2;
+  if (n < 1 || n > SVAE_LDS_MAX_N) return -3;
+  if (pair_batched && !inhomog) return -5;
+  if (!init_J) return -6;
+  if (!init_h) return -7;
+  if (!init_logZ) return -8;
+  if (T > 1 && (!J11 || !J12 || !J22 || !logZ_pair)) return -9;
+  if (!node_J) return -13;
+  if (!node_h) return -14;
+  if (!lognorm) return -16;
+  if (!E_init) return -17;
+  if (T > 1 && !E_pair) return -18;
+  if (!E_node_diagxx) return -19;
+  if (!E_node_x) return -20;
+  if (!info) return -21;
+  if (!workspace || ws_bytes < svae_lds_workspace_bytes(B, T, n)) return -22;
+  if (B == 0) return 0;
+
+  svae::LdsArgs a;
+  a.B = B; a.T = T;
+  a.init_J = init_J; a.init_h = init_h; a.init_logZ = init_logZ;
+  a.J11 = J11; a.J12 = J12; a.J22 = J22; a.logZ_pair = logZ_pair;
+  a.node_J = node_J; a.node_h = node_h; a.node_logZ = node_logZ;
+  a.lognorm = lognorm; a.E_init = E_init; a.E_pair = E_pair;
+  a.E_node_diagxx = E_node_diagxx; a.E_node_x = E_node_x;
+  a.info = info; a.ws = (double*)workspace;
+  a.pair_seq_stride = pair_batched ? (long)(T - 1) * n * n : 0;
+  switch (n) {
+#define SVAE_CASE(NN) case NN: return svae_lds_launch_n##NN(&a, inhomog, stream);
+    SVAE_CASE(1) SVAE_CASE(2) SVAE_CASE(3) SVAE_CASE(4) SVAE_CASE(5) SVAE_CASE(6) SVAE_CASE(7)
+    SVAE_CASE(8) SVAE_CASE(9) SVAE_CASE(10) SVAE_CASE(11) SVAE_CASE(12) SVAE_CASE(13)
+    SVAE_CASE(14) SVAE_CASE(15)
+#undef SVAE_CASE
+  }
+  return -3;
+}
+
+int svae_lds_reduce_stats_f64(int B, int n, const double* E_init, const double* E_pair,
+                              const double* lognorm, double* out, void* stream) {
+  if (B < 0) return -1;
+  if (n < 1 || n > SVAE_LDS_MAX_N) return -2;
+  if (!E_init) return -3;
+  if (!E_pair) return -4;
+  if (!lognorm) return -5;
+  if (!out) return -6;
+  const int tot = 4 * n * n + n + 1;
+  hipLaunchKernelGGL(svae::lds_reduce_stats_kernel, dim3(tot < 256 ? tot : 256), dim3(256), 0,
+                     (hipStream_t)stream, B, n, E_init, E_pair, lognorm, out);
+  return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+}  // extern "C"

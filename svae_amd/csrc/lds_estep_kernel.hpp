@@ -1,0 +1,304 @@
+// lds_estep_kernel.hpp -- batched natural-parameter LDS E-step for MI355X (gfx950, wave64, fp64).
+//
+// What it replaces (reference = mattjj/svae, /root/reference):
+//   natural_filter_forward_general   svae/lds/cython_lds_inference.pyx:28-90
+//     _natural_condition_diag        svae/lds/cython_gaussian_grads.pxd:125-144
+//     _natural_predict               svae/lds/cython_gaussian_grads.pxd:38-82
+//     _natural_lognorm               svae/lds/cython_gaussian_grads.pxd:167-188
+//   natural_smoother_general         svae/lds/cython_lds_inference.pyx:149-195
+//     _rts_backward_step             svae/lds/cython_gaussian_grads.pxd:240-296
+//     _info_to_mean                  svae/lds/cython_gaussian_grads.pxd:208-220
+//   _compute_stats                   svae/lds/cython_lds_inference.pyx:197-210
+//
+// This is NOT a translation of those LAPACK call sequences.  Mapping to the hardware:
+//   * one DPP row (16 lanes) per sequence, 4 sequences per wavefront, one wavefront per workgroup;
+//     lane c holds column c of every n x n block, one VGPR pair per block row (n <= 15);
+//   * every small dense product is "broadcast lane k of my row" x "my column": a v_mov_b64_dpp
+//     row_newbcast + v_fma_f64 -- no LDS traffic, no SGPR round trips, no cross-row shuffles;
+//   * the forward pass inverts P_t = J_filt,t + J11 by in-place Gauss-Jordan (pivots = the LDL'
+//     diagonal, so log|P_t| comes for free; reciprocal = v_rcp_f64 + 2 Newton steps, no sqrt/div);
+//   * the backward pass runs in MOMENT form on homogeneous coordinates x~ = [x;1]:
+//         S~_t = G~_t S~_{t+1} G~_t' + diag(P_t^-1, 0),   G~_t = [[-P_t^-1 J12, P_t^-1 h_filt,t],[0,1]]
+//         E[x~_{t+1} x~_t'] = S~_{t+1} G~_t'
+//     i.e. two (n+1)^3 products per step and NO factorisation on the backward critical path (the
+//     reference's information-form RTS step does 2 Cholesky + potri + 3 triangular solves per step).
+//     S~ carries E[x x'], E[x] and 1 together, so means, second moments and cross moments fall out
+//     of the same two products; sums of PSD terms only (no cancelling subtractions);
+//   * forward -> backward hand-off (G~_t', P_t^-1: (2n+1) n doubles per step) goes through an HBM
+//     workspace written and re-read by the SAME lanes (no inter-workgroup communication).
+//
+// Algorithmic HBM bytes per sequence: 8*[T(2n+1) + 2Tn + 4n^2 + n + 1];
+// workspace traffic on top of that is 2 * 8 * T * (2n+1) * n (write + read).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+#include "../../include/svae_hip.h"
+#include "dpp.hpp"
+#include "lds_args.hpp"
+
+namespace svae {
+
+
+// doubles of workspace per (sequence, time step): rows 0..N-1 = G~' rows (-J12' P^-1), row N = c =
+// P^-1 h_filt, rows N+1..2N = P^-1.  Each row is N doubles (lane c < N).
+template <int N>
+constexpr int ws_step_doubles() { return (2 * N + 1) * N; }
+
+// Opaque register barrier: stops LLVM from hoisting loop-invariant DPP broadcasts of the constant
+// pair-parameter tiles out of the time loop (that would need N*N extra VGPR pairs).
+__device__ __forceinline__ void opaque(double& x) { asm volatile("" : "+v"(x)); }
+
+template <int N, bool INHOMOG>
+__global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
+  static_assert(N >= 1 && N <= SVAE_LDS_MAX_N, "n+1 lanes must fit a 16-lane DPP row");
+  const int lane = threadIdx.x;
+  const int c = lane & 15;
+  const int brow = blockIdx.x * 4 + (lane >> 4);
+  const bool valid = brow < a.B;
+  const int b = valid ? brow : a.B - 1;   // surplus rows recompute the last sequence, stores masked
+  const bool col = c < N;
+  const bool st = valid && col;
+  const int cc = col ? c : 0;
+  const int T = a.T;
+
+  // ---- pair parameters (info form: J = -2 natJ, J12 = -natJ12), column c per lane -------------
+  double J11c[N], J12c[N], J12T[N], J22c[N];
+  const double* pJ11 = a.J11 + (long)b * a.pair_seq_stride;
+  const double* pJ12 = a.J12 + (long)b * a.pair_seq_stride;
+  const double* pJ22 = a.J22 + (long)b * a.pair_seq_stride;
+  auto load_pair = [&](int t) {
+    const long o = INHOMOG ? (long)t * N * N : 0;
+    static_for<0, N>([&](auto i) {
+      J11c[i] = col ? -2.0 * pJ11[o + i * N + cc] : 0.0;
+      J12c[i] = col ? -pJ12[o + i * N + cc] : 0.0;
+      J12T[i] = col ? -pJ12[o + cc * N + i] : 0.0;
+      J22c[i] = col ? -2.0 * pJ22[o + i * N + cc] : 0.0;
+    });
+  };
+  if (!INHOMOG) load_pair(0);
+
+  // ---- forward filter --------------------------------------------------------------------------
+  double Jp[N], hp;
+  static_for<0, N>([&](auto i) { Jp[i] = col ? -2.0 * a.init_J[i * N + cc] : 0.0; });
+  hp = col ? a.init_h[cc] : 0.0;
+
+  const double* nJ = a.node_J + ((long)b * T) * N + cc;
+  const double* nh = a.node_h + ((long)b * T) * N + cc;
+  double* wsb = a.ws + ((long)b * T) * ws_step_doubles<N>() + cc;
+
+  double qacc = 0.0;       // per-lane partial of sum_t h_filt' P^-1 h_filt
+  double ldM = 1.0;        // log|P_t| accumulated as mantissa product ...
+  int ldE = 0;             // ... and exponent sum (one log at the very end)
+  bool bad = false;
+
+  double Jo_n = col ? -2.0 * nJ[0] : 0.0;
+  double ho_n = col ? nh[0] : 0.0;
+
+  for (int t = 0; t < T; ++t) {
+    const bool last = (t == T - 1);
+    const double Jo = Jo_n, ho = ho_n;
+    if (!last) {
+      Jo_n = col ? -2.0 * nJ[(long)(t + 1) * N] : 0.0;
+      ho_n = col ? nh[(long)(t + 1) * N] : 0.0;
+    }
+    if (INHOMOG) { if (!last) load_pair(t); }
+    else static_for<0, N>([&](auto i) { opaque(J12T[i]); });
+
+    // P = J_pred + diag(J_node) [+ J11 unless last]   (condition, then the predict-step pivot block)
+    double P[N];
+    const double s11 = last ? 0.0 : 1.0;
+    static_for<0, N>([&](auto i) {
+      P[i] = __builtin_fma(s11, J11c[i], Jp[i]);
+      if (c == i) P[i] += Jo;
+    });
+    const double hf = hp + ho;
+
+    // in-place Gauss-Jordan inverse (SPD => no pivoting); pivots are the LDL' diagonal
+    static_for<0, N>([&](auto k) {
+      const double p = bcast<k>(P[k]);
+      bad |= !(p > 0.0);
+      const double rinv = rcp_nr(p);
+      ldM *= __builtin_amdgcn_frexp_mant(p);
+      ldE += __builtin_amdgcn_frexp_exp(p);
+      double r = P[k] * rinv;
+      r = (c == k) ? rinv : r;
+      static_for<0, N>([&](auto i) {
+        if constexpr (i != k) {
+          const double m = bcast<k>(P[i]);
+          const double acc = (c == k) ? 0.0 : P[i];
+          P[i] = __builtin_fma(-m, r, acc);
+        }
+      });
+      P[k] = r;
+    });
+    {
+      const int e = __builtin_amdgcn_frexp_exp(ldM);
+      ldM = __builtin_amdgcn_frexp_mant(ldM);
+      ldE += e;
+    }
+
+    // c_t = P^-1 h_filt  (row layout: lane c holds c_t[c]); P^-1 symmetric
+    double cv = 0.0;
+    static_for<0, N>([&](auto k) { cv = __builtin_fma(bcast<k>(hf), P[k], cv); });
+    qacc = __builtin_fma(hf, cv, qacc);
+
+    double* w = wsb + (long)t * ws_step_doubles<N>();
+    if (st) {
+      w[N * N] = cv;
+      static_for<0, N>([&](auto i) { w[(N + 1 + i) * N] = P[i]; });
+    }
+
+    if (!last) {
+      // XT_i = row i of J12' P^-1 ;  G~' rows are -XT_i
+      double XT[N];
+      static_for<0, N>([&](auto i) {
+        double acc = 0.0;
+        static_for<0, N>([&](auto k) { acc = __builtin_fma(bcast<k>(J12T[i]), P[k], acc); });
+        XT[i] = acc;
+      });
+      if (st) static_for<0, N>([&](auto i) { w[i * N] = -XT[i]; });
+      // J_pred' = J22 - J12' P^-1 J12 ;  h_pred' = -J12' P^-1 h_filt
+      static_for<0, N>([&](auto i) {
+        double acc = J22c[i];
+        static_for<0, N>([&](auto k) { acc = __builtin_fma(-bcast<k>(XT[i]), J12c[k], acc); });
+        Jp[i] = acc;
+      });
+      double acc = 0.0;
+      static_for<0, N>([&](auto k) { acc = __builtin_fma(-bcast<k>(cv), J12c[k], acc); });
+      hp = acc;
+    } else {
+      if (st) static_for<0, N>([&](auto i) { w[i * N] = 0.0; });
+    }
+  }
+
+  // ---- log-normaliser --------------------------------------------------------------------------
+  {
+    double z = 0.0;
+    if (a.node_logZ) {
+      for (int t = c; t < T; t += 16) z += a.node_logZ[(long)b * T + t];
+    }
+    if (INHOMOG) {
+      const double* lz = a.logZ_pair + (a.pair_seq_stride ? (long)b * (T - 1) : 0);
+      for (int t = c; t < T - 1; t += 16) z += lz[t];
+    }
+    double total = row_sum16(__builtin_fma(0.5, qacc, z));
+    total += a.init_logZ[0];
+    if (!INHOMOG) total += (double)(T - 1) * a.logZ_pair[0];
+    total -= 0.5 * (::log(ldM) + (double)ldE * 0.6931471805599453094);
+    if (valid && c == 0) a.lognorm[b] = total;
+    if (bad && valid && c == 0) {   // rare path: keep the smallest failing index (+1); 0 = ok
+      int old = *(volatile int32_t*)a.info;
+      while (old == 0 || old > b + 1) {
+        const int seen = atomicCAS(a.info, old, b + 1);
+        if (seen == old) break;
+        old = seen;
+      }
+    }
+  }
+
+  // ---- backward pass in moment form on homogeneous coordinates ---------------------------------
+  // S[i] = row i of S~ (i = 0..N), lane c = column c (c = 0..N).  Start from S~_T := e_N e_N' so
+  // that the generic step at t = T-1 (where G = 0, c = mu_{T-1}) yields [[Sigma+mu mu', mu],[mu',1]].
+  double S[N + 1];
+  static_for<0, N + 1>([&](auto i) { S[i] = 0.0; });
+  S[N] = (c == N) ? 1.0 : 0.0;
+  double sumA[N], sumC[N], sumW[N];
+  static_for<0, N>([&](auto i) { sumA[i] = 0.0; sumC[i] = 0.0; sumW[i] = 0.0; });
+
+  double* oEx = a.E_node_x + ((long)b * T) * N + cc;
+  double* oExx = a.E_node_diagxx + ((long)b * T) * N + cc;
+  double* oPair = INHOMOG ? a.E_pair + ((long)b * (T - 1)) * 3 * N * N + cc : nullptr;
+
+  double GT[N + 1], Pi[N];
+  auto load_step = [&](int t, double (&g)[N + 1], double (&pi)[N]) {
+    const double* w = wsb + (long)t * ws_step_doubles<N>();
+    static_for<0, N>([&](auto k) { g[k] = col ? w[k * N] : 0.0; });
+    g[N] = col ? w[N * N] : ((c == N) ? 1.0 : 0.0);
+    static_for<0, N>([&](auto i) { pi[i] = col ? w[(N + 1 + i) * N] : 0.0; });
+  };
+  load_step(T - 1, GT, Pi);
+
+  for (int t = T - 1; t >= 0; --t) {
+    double GTn[N + 1], Pin[N];
+    if (t > 0) load_step(t - 1, GTn, Pin);
+
+    // W~ = S~_{t+1} G~'   (W[i][c] = E[x~_{t+1,i} x~_{t,c}])
+    double W[N + 1];
+    static_for<0, N + 1>([&](auto i) {
+      double acc = 0.0;
+      static_for<0, N + 1>([&](auto k) { acc = __builtin_fma(bcast<k>(S[i]), GT[k], acc); });
+      W[i] = acc;
+    });
+    // S~_t = G~ W~ + diag(P^-1, 0), computed through its transpose (S~ symmetric):
+    //   S~[c][i] = sum_k G~[c][k] W~[k][i] = sum_k GT[k](lane c) * W[k](lane i)
+    static_for<0, N + 1>([&](auto i) {
+      double acc = 0.0;
+      if constexpr (i < N) acc = Pi[i];
+      static_for<0, N + 1>([&](auto k) { acc = __builtin_fma(GT[k], bcast<i>(W[k]), acc); });
+      S[i] = acc;
+    });
+
+    if (INHOMOG) {
+      // per-step pair blocks: [E x_t x_t' | E x_t x_{t+1}' | E x_{t+1} x_{t+1}'] for pair index t;
+      // S~_t completes pair t (first block) and pair t-1 (third block); W~ (t < T-1) is pair t.
+      if (st) {
+        if (t < T - 1) {
+          double* o = oPair + (long)t * 3 * N * N;
+          static_for<0, N>([&](auto i) { o[i * N] = S[i]; });
+          // E[x_t x_{t+1}'][a][bb] = W[bb][a]: lane c = a... stored transposed
+          double* o2 = a.E_pair + (((long)b * (T - 1) + t) * 3 + 1) * N * N + (long)cc * N;
+          static_for<0, N>([&](auto i) { o2[i] = W[i]; });
+        }
+        if (t > 0) {
+          double* o = oPair + ((long)(t - 1) * 3 + 2) * N * N;
+          static_for<0, N>([&](auto i) { o[i * N] = S[i]; });
+        }
+      }
+    } else {
+      if (t < T - 1) static_for<0, N>([&](auto i) { sumA[i] += S[i]; sumW[i] += W[i]; });
+      if (t > 0) static_for<0, N>([&](auto i) { sumC[i] += S[i]; });
+    }
+
+    // node statistics: E[x_t] = row N of S~, diag E[x_t x_t']
+    double dg = 0.0;
+    static_for<0, N>([&](auto i) { dg = (c == i) ? S[i] : dg; });
+    if (st) {
+      oEx[(long)t * N] = S[N];
+      oExx[(long)t * N] = dg;
+    }
+    if (t > 0) {
+      static_for<0, N + 1>([&](auto k) { GT[k] = GTn[k]; });
+      static_for<0, N>([&](auto i) { Pi[i] = Pin[i]; });
+    }
+  }
+
+  // ---- global statistics -----------------------------------------------------------------------
+  if (st) {
+    double* ei = a.E_init + (long)b * (N * N + N);
+    static_for<0, N>([&](auto i) { ei[i * N + cc] = S[i]; });   // E[x0 x0']
+    ei[N * N + cc] = S[N];                                      // E[x0]
+    if (!INHOMOG) {
+      double* ep = a.E_pair + (long)b * 3 * N * N;
+      static_for<0, N>([&](auto i) {
+        ep[i * N + cc] = sumA[i];                 // sum_t E[x_t x_t']
+        ep[N * N + cc * N + i] = sumW[i];         // sum_t E[x_t x_{t+1}'] = (sum_t W_t)'
+        ep[2 * N * N + i * N + cc] = sumC[i];     // sum_t E[x_{t+1} x_{t+1}']
+      });
+    }
+  }
+}
+
+
+template <int N>
+static int launch_estep(const LdsArgs& a, bool inhomog, hipStream_t stream) {
+  dim3 grid((a.B + 3) / 4), block(64);
+  if (inhomog)
+    hipLaunchKernelGGL((lds_estep_kernel<N, true>), grid, block, 0, stream, a);
+  else
+    hipLaunchKernelGGL((lds_estep_kernel<N, false>), grid, block, 0, stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+}  // namespace svae

@@ -1,0 +1,13 @@
+// lds_estep_n.hip -- one translation unit per latent dimension (compiled with -DSVAE_N=<n>), so
+// that `make -j` builds the 15 specialisations of the E-step kernel in parallel.
+#include "lds_estep_kernel.hpp"
+
+#ifndef SVAE_N
+#error "compile with -DSVAE_N=<latent dim>"
+#endif
+#define SVAE_CAT_(a, b) a##b
+#define SVAE_CAT(a, b) SVAE_CAT_(a, b)
+
+extern "C" int SVAE_CAT(svae_lds_launch_n, SVAE_N)(const svae::LdsArgs* a, int inhomog, void* stream) {
+  return svae::launch_estep<SVAE_N>(*a, inhomog != 0, (hipStream_t)stream);
+}
