@@ -1,0 +1,206 @@
+#!/usr/bin/env python
+"""bench.py -- E-step sequences/sec of the LDS forward-backward smoother (T=200, n=10) on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
+torch.distributed.run with one rank per GPU.  One JSON line on rank 0.
+
+A "step" is one pass of the hot path over one batch of synthetic sequences resident in HBM:
+  svae_lds_estep_f64 (filter + smoother + expected statistics + log-normaliser, per sequence)
+  -> svae_lds_reduce_stats_f64 (deterministic batch sum of the global statistics)
+  -> [N > 1] one RCCL all-reduce (sum, fp64) of the packed 4n^2+n+2 global statistics.
+Workload = BASELINE.json configs[1]: 512 sequences x T=200, n=10 per GPU (weak scaling: N=8 is
+configs[2], 4096 sequences sharded 8 x 512 with the stat all-reduce).
+
+Extra JSON objects: `roofline` (dominant kernel vs HBM peak, duration measured live with events
+on the launch stream) and, at N=1 on rank 0, `cpu_baseline` (the reference's own compiled E-step,
+oracle/_ref, timed on this box's host cores on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+T_STEPS, N_LATENT, SEQS_PER_GPU = 200, 10, 512
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+
+
+def algorithmic_bytes_per_seq(T, n):
+    """read node_J,node_h,node_logZ + write E_node (diag, x) + per-sequence
+    E_init, E_pair sums, lognorm."""
+    return 8 * (T * (2 * n + 1) + 2 * T * n + (n * n + n) + 3 * n * n + 1)
+
+
+def _cpu_worker(args):
+    """Times the reference's compiled E-step on a slice of sequences (one process = one core)."""
+    os.environ["OMP_NUM_THREADS"] = os.environ["OPENBLAS_NUM_THREADS"] = "1"
+    natparam, node_J, node_h = args
+    from oracle import ref
+    T = node_h.shape[1]
+    z = np.zeros(T)
+    t0 = time.perf_counter()
+    for b in range(node_h.shape[0]):
+        ref.estep(natparam, (node_J[b], node_h[b], z))
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(natparam, node_J, node_h, budget_s=12.0):
+    """Reference CPU path on a bounded sample: 1 core, then all host cores (process pool)."""
+    from oracle import lds_numpy, ref
+    kind = "reference" if ref.available() else "port"
+    T = node_h.shape[1]
+    if kind == "port":
+        est = lambda b: lds_numpy.natural_lds_estep_general(natparam, (node_J[b], node_h[b], np.zeros(T)))
+        nb = 64
+        t0 = time.perf_counter()
+        for b in range(nb):
+            est(b)
+        dt = time.perf_counter() - t0
+        return {"value": nb / dt, "unit": "sequences/s", "cores": 1, "kind": kind,
+                "sample": "%d sequences T=%d n=%d, NumPy restatement, 1 core" % (nb, T, node_h.shape[2])}
+    _cpu_worker((natparam, node_J[:8], node_h[:8]))                       # warm-up / page-in
+    n1 = min(node_h.shape[0], 512)
+    dt1 = _cpu_worker((natparam, node_J[:n1], node_h[:n1]))
+    one_core = n1 / dt1
+    cores = os.cpu_count() or 1
+    value, used, sample = one_core, 1, "%d sequences on 1 core" % n1
+    if cores > 1:
+        import multiprocessing as mp
+        per = max(64, int(min(budget_s * one_core, 4096) // cores))
+        reps = -(-per // node_h.shape[0])
+        J = np.concatenate([node_J] * reps)[:per] if reps > 1 else node_J[:per]
+        h = np.concatenate([node_h] * reps)[:per] if reps > 1 else node_h[:per]
+        try:
+            with mp.get_context("fork").Pool(cores) as pool:
+                t0 = time.perf_counter()
+                pool.map(_cpu_worker, [(natparam, J, h)] * cores)
+                wall = time.perf_counter() - t0
+            allc = per * cores / wall
+            if allc > value:
+                value, used = allc, cores
+                sample = "%d sequences per core on %d cores (process pool)" % (per, cores)
+        except Exception as e:  # pragma: no cover
+            sample += " (pool failed: %r)" % (e,)
+    return {"value": value, "unit": "sequences/s", "cores": used, "kind": kind,
+            "one_core_value": one_core, "host_cores": cores,
+            "sample": "reference compiled E-step (oracle/_ref), T=%d n=%d: %s"
+                      % (T, node_h.shape[2], sample)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--seqs-per-gpu", type=int, default=SEQS_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from svae_amd.lds.lds_inference import LDSEStepPlan
+    from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials
+    from svae_amd.parallel import allreduce_global_stats
+
+    B, T, n = args.seqs_per_gpu, T_STEPS, N_LATENT
+    init, pair = rand_lds_natparam(n, np.random.default_rng(0))       # replicated global params
+    node_J, node_h = rand_node_potentials((B, T, n), np.random.default_rng(1000 + rank))  # this rank's shard
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev).contiguous()
+    d_init = [t(init[0]), t(init[1]), t(init[2]).reshape(1)]
+    d_pair = [t(pair[0]), t(pair[1]), t(pair[2]), t(pair[3]).reshape(1)]
+    d_J, d_h = t(node_J), t(node_h)
+    plan = LDSEStepPlan(B, T, n, dev)
+
+    def step():
+        plan.launch(d_init[0], d_init[1], d_init[2], d_pair[0], d_pair[1], d_pair[2], d_pair[3],
+                    d_J, d_h, None)
+        packed = plan.reduce()
+        if world > 1:
+            allreduce_global_stats(packed)
+        return packed
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+
+    def timed_step(i):
+        ev[i][0].record()
+        plan.launch(d_init[0], d_init[1], d_init[2], d_pair[0], d_pair[1], d_pair[2], d_pair[3],
+                    d_J, d_h, None)
+        ev[i][1].record()
+        packed = plan.reduce()
+        if world > 1:
+            allreduce_global_stats(packed)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        timed_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    plan.check_info()
+    if world > 1:
+        el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
+    if rank == 0:
+        total_seqs = B * world * args.steps
+        bytes_launch = B * algorithmic_bytes_per_seq(T, n)
+        achieved = bytes_launch / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "E-step sequences/sec (LDS fwd-bwd smoother, T=200 n=10)",
+            "value": total_seqs / elapsed, "unit": "sequences/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "LDS-SVAE E-step, latent dim %d, T=%d, %d sequences per GPU "
+                                   "(BASELINE configs[1]; x8 GPUs = configs[2])" % (n, T, B),
+                       "sequences_per_gpu": B, "T": T, "n": n, "global_sequences": B * world,
+                       "parallelism": "dp%d" % world,
+                       "step": "estep kernel + batch stat reduce" + (" + RCCL all-reduce" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "svae::lds_estep_kernel<10,false>", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": bytes_launch,
+                         "kernel_sequences_per_s": B / (kern_ms * 1e-3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline((init, pair), node_J, node_h)
+                out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+            except Exception as e:  # never lose the GPU line to a baseline hiccup
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -241,5 +241,5 @@ def dense_estep(natparam, node_params):
     M = Sigma + np.outer(mu, mu)
     Ex = mu.reshape(T, n)
     ExxT = np.stack([M[sl(t), sl(t)] for t in range(T)])
-    ExxnT = np.stack([M[sl(t), sl(t + 1)] for t in range(T - 1)])
+    ExxnT = np.stack([M[sl(t), sl(t + 1)] for t in range(T - 1)]) if T > 1 else np.zeros((0, n, n))
     return lognorm, Ex, ExxT, ExxnT

@@ -1,0 +1,70 @@
+"""ctypes binding of libsvae_hip.so (C ABI declared in include/svae_hip.h).
+
+The library must be loaded AFTER torch so that its DT_NEEDED ``libamdhip64.so.7`` resolves to the
+HIP runtime torch already mapped (one runtime per process: torch's streams and device pointers are
+handed straight to the kernels).  Missing library => ImportError; there is no fallback path.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede CDLL: shares torch's HIP runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsvae_hip.so")
+
+ABI_VERSION = 1
+LDS_MAX_N = 15
+
+_c_double_p = ctypes.c_void_p   # raw device pointers travel as integers
+_c_int_p = ctypes.c_void_p
+
+# name -> (restype, argtypes).  Must list every symbol of include/svae_hip.h (tests check this).
+SIGNATURES = {
+    "svae_hip_abi_version": (ctypes.c_int, []),
+    "svae_lds_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
+    "svae_lds_estep_f64": (ctypes.c_int, [ctypes.c_int] * 5 + [_c_double_p] * 15
+                           + [_c_int_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "svae_lds_reduce_stats_f64": (ctypes.c_int, [ctypes.c_int] * 2 + [_c_double_p] * 4
+                                  + [ctypes.c_void_p]),
+    "svae_lds_sample_f64": (ctypes.c_int, [ctypes.c_int] * 4 + [_c_double_p] * 2
+                            + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "svae_gmm_meanfield_f64": (ctypes.c_int, [ctypes.c_int] * 3 + [_c_double_p] * 5
+                               + [ctypes.c_double, ctypes.c_int] + [_c_double_p] * 7
+                               + [_c_int_p] * 3 + [ctypes.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises ImportError if the library is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise ImportError(
+                "svae_amd: %s not found -- build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `make -C svae_amd/csrc -j8` (there is no CPU fallback)" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError => stale library: fail loudly
+            fn.restype, fn.argtypes = res, args
+        if lib.svae_hip_abi_version() != ABI_VERSION:
+            raise ImportError("svae_amd: libsvae_hip.so ABI %d != expected %d"
+                              % (lib.svae_hip_abi_version(), ABI_VERSION))
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed: rc=%d (%s)" % (
+            what, rc, "bad argument #%d" % -rc if -100 < rc < 0 else "launch error"))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def current_stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,354 @@
+// gmm_meanfield.hip -- GMM-SVAE local mean field (responsibility updates) for MI355X (gfx950, fp64).
+//
+// What it replaces (reference = mattjj/svae, /root/reference):
+//   local_meanfield        svae/models/gmm.py:62-88
+//   meanfield_fixed_point  svae/models/gmm.py:90-110   (block coordinate ascent, <= max_iter sweeps)
+//   gaussian_meanfield     svae/models/gmm.py:112-117  -> gaussian.expectedstats / logZ
+//                                                         (svae/distributions/gaussian.py:11-25)
+//   label_meanfield        svae/models/gmm.py:119-124  -> categorical softmax / logsumexp
+//                                                         (svae/distributions/categorical.py:6-9)
+//
+// Mapping to the hardware.  A minibatch is a few hundred to a few thousand points with N ~ 2 and
+// K ~ 5..15: < 1 MB of state, so the whole fixed point runs as ONE launch of ONE workgroup (no
+// host round trip per sweep -- the reference's loop is a host loop): one point per lane, the N x N
+// solve/inverse/Cholesky in registers, the K global potentials G_k fetched with wave-uniform
+// (scalar) loads, the batch-total KL the stopping rule needs reduced through LDS in a fixed order
+// (bit-reproducible run to run).  It is launch-latency bound by construction.
+//
+// Dense packing (gaussian.py:39-57): a (N+2)x(N+2) block holds A in [:N,:N], b in [:N,N], c at
+// [N,N], d at [N+1,N+1]; every other entry is zero.  G_k is required to have that sparsity (it is
+// the output of niw.expectedstats, niw.py:25), node potentials have A diagonal.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+#include "../../include/svae_hip.h"
+
+namespace svae {
+
+struct GmmArgs {
+  int T, K, max_iter;
+  double tol;
+  const double* __restrict__ label_global;      // (K)
+  const double* __restrict__ gaussian_globals;  // (K, D, D), D = N + 2
+  const double* __restrict__ node_J;            // (T, N)
+  const double* __restrict__ node_h;            // (T, N)
+  const double* __restrict__ label_init;        // (T, K)
+  double* label_stats;                          // (T, K)   (iterated in place)
+  double* gaussian_stats;                       // (T, D, D)
+  double* label_natparam;                       // (T, K)
+  double* gaussian_natparam;                    // (T, D, D)
+  double* dirichlet_stats;                      // (K)
+  double* niw_stats;                            // (K, D, D)
+  double* kl;
+  int32_t* iters;
+  int32_t* assign;
+  int32_t* info;
+};
+
+// threads per (single) workgroup: more registers per lane for larger N
+template <int N> constexpr int gmm_block() { return N <= 3 ? 1024 : (N <= 5 ? 512 : 256); }
+
+// fixed-order block reduction (every thread returns the total)
+template <int GMM_BLOCK>
+__device__ __forceinline__ double block_sum(double v, double* red) {
+  const int tid = threadIdx.x;
+  red[tid] = v;
+  __syncthreads();
+  for (int s = GMM_BLOCK / 2; s > 0; s >>= 1) {
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  const double out = red[0];
+  __syncthreads();
+  return out;
+}
+
+// Per-point Gaussian factor update: eta = node + sum_k r_k G_k  ->  (Ex, ExxT, logZ, <node,stats>).
+template <int N>
+struct PointGauss {
+  double A[N][N];   // -1/2 J block of eta
+  double h[N];
+  double ab;        // eta[N,N] + eta[N+1,N+1]
+  double Ex[N];
+  double ExxT[N][N];
+  double logZ;
+  bool ok;
+};
+
+template <int N>
+__device__ __forceinline__ void gauss_update(PointGauss<N>& g) {
+  // J = -2 A (SPD); Cholesky J = L L', Sigma = J^-1, Ex = Sigma h   [gaussian.py:11-25]
+  double L[N][N];
+  g.ok = true;
+  double sumlog = 0.0;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    double d = -2.0 * g.A[j][j];
+#pragma unroll
+    for (int m = 0; m < j; ++m) d -= L[j][m] * L[j][m];
+    g.ok = g.ok && (d > 0.0);
+    const double l = sqrt(d);
+    L[j][j] = l;
+    sumlog += log(l);
+    const double inv = 1.0 / l;
+#pragma unroll
+    for (int i = j + 1; i < N; ++i) {
+      double s = -2.0 * g.A[i][j];
+#pragma unroll
+      for (int m = 0; m < j; ++m) s -= L[i][m] * L[j][m];
+      L[i][j] = s * inv;
+    }
+  }
+  // Linv (lower), Sigma = Linv' Linv
+  double Li[N][N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    Li[j][j] = 1.0 / L[j][j];
+#pragma unroll
+    for (int i = j + 1; i < N; ++i) {
+      double s = 0.0;
+#pragma unroll
+      for (int m = j; m < i; ++m) s -= L[i][m] * Li[m][j];
+      Li[i][j] = s / L[i][i];
+    }
+  }
+  double v[N];   // v = Linv h
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    double s = 0.0;
+#pragma unroll
+    for (int m = 0; m <= i; ++m) s += Li[i][m] * g.h[m];
+    v[i] = s;
+  }
+  double vv = 0.0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) vv += v[i] * v[i];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    double s = 0.0;
+#pragma unroll
+    for (int m = i; m < N; ++m) s += Li[m][i] * v[m];
+    g.Ex[i] = s;
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      double s = 0.0;
+#pragma unroll
+      for (int m = i; m < N; ++m) s += Li[m][i] * Li[m][j];
+      s += g.Ex[i] * g.Ex[j];
+      g.ExxT[i][j] = s;
+      g.ExxT[j][i] = s;
+    }
+  g.logZ = 0.5 * vv - sumlog + g.ab;
+}
+
+template <int N>
+__global__ __launch_bounds__(gmm_block<N>()) void gmm_meanfield_kernel(const GmmArgs a) {
+  constexpr int D = N + 2;
+  constexpr int GMM_BLOCK = gmm_block<N>();
+  __shared__ double red[GMM_BLOCK];
+  const int tid = threadIdx.x;
+  const int T = a.T, K = a.K;
+
+  // one sweep over this thread's points; FINAL = the extra differentiable pass of gmm.py:74-77
+  // (no linear correction term, writes every output).  Returns the thread's KL partial.
+  auto sweep = [&](bool first, bool final_pass) -> double {
+    double klpart = 0.0;
+    for (int t = tid; t < T; t += GMM_BLOCK) {
+      const double* rin = first ? a.label_init + (long)t * K : a.label_stats + (long)t * K;
+      PointGauss<N> g;
+      // eta = pack_dense(node) + sum_k r_k G_k          [gmm.py:113-114]
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) g.A[i][j] = 0.0;
+        g.h[i] = 0.0;
+      }
+      double cN = 0.0, dN = 0.0;   // eta[N,N], eta[N+1,N+1]
+      for (int k = 0; k < K; ++k) {
+        const double r = rin[k];
+        const double* G = a.gaussian_globals + (long)k * D * D;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+#pragma unroll
+          for (int j = 0; j < N; ++j) g.A[i][j] = __builtin_fma(r, G[i * D + j], g.A[i][j]);
+          g.h[i] = __builtin_fma(r, G[i * D + N], g.h[i]);
+        }
+        cN = __builtin_fma(r, G[N * D + N], cN);
+        dN = __builtin_fma(r, G[(N + 1) * D + N + 1], dN);
+      }
+      g.ab = cN + dN;
+      double nJ[N], nh[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        nJ[i] = a.node_J[(long)t * N + i];
+        nh[i] = a.node_h[(long)t * N + i];
+        g.A[i][i] += nJ[i];
+        g.h[i] += nh[i];
+      }
+      gauss_update<N>(g);
+      if (!g.ok) {
+        int old = *(volatile int32_t*)a.info;
+        while (old == 0 || old > t + 1) {
+          const int seen = atomicCAS(a.info, old, t + 1);
+          if (seen == old) break;
+          old = seen;
+        }
+      }
+      // gaussian_kl_t = <node, stats> - logZ(eta)        [gmm.py:116]
+      double nodedot = 0.0;
+#pragma unroll
+      for (int i = 0; i < N; ++i) nodedot += nJ[i] * g.ExxT[i][i] + nh[i] * g.Ex[i];
+      double klt = nodedot - g.logZ;
+
+      // label update: l_k = <stats, G_k>, natparam = l + label_global, r = softmax   [gmm.py:119-124]
+      double mx = -1.0 / 0.0;
+      for (int k = 0; k < K; ++k) {
+        const double* G = a.gaussian_globals + (long)k * D * D;
+        double l = G[N * D + N] + G[(N + 1) * D + N + 1];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+#pragma unroll
+          for (int j = 0; j < N; ++j) l = __builtin_fma(g.ExxT[i][j], G[i * D + j], l);
+          l = __builtin_fma(g.Ex[i], G[i * D + N], l);
+        }
+        const double np_ = l + a.label_global[k];
+        a.label_natparam[(long)t * K + k] = np_;   // scratch between the two k-loops
+        mx = np_ > mx ? np_ : mx;
+      }
+      double se = 0.0;
+      for (int k = 0; k < K; ++k) se += exp(a.label_natparam[(long)t * K + k] - mx);
+      const double lse = mx + log(se);
+      const double inv = 1.0 / se;
+      double lab = 0.0, lin = 0.0;
+      int best = 0;
+      double bestv = -1.0;
+      for (int k = 0; k < K; ++k) {
+        const double np_ = a.label_natparam[(long)t * K + k];
+        const double l = np_ - a.label_global[k];
+        const double rnew = exp(np_ - mx) * inv;
+        const double rold = rin[k];
+        lab = __builtin_fma(rnew, l, lab);
+        lin = __builtin_fma(rold - rnew, l, lin);     // <eta - sum_k rnew_k G_k - node, stats>, gmm.py:99-102
+        if (rnew > bestv) { bestv = rnew; best = k; }
+        a.label_stats[(long)t * K + k] = rnew;
+      }
+      klt += lab - lse;
+      if (!final_pass) klt += lin;
+      klpart += klt;
+
+      if (final_pass) {
+        a.assign[t] = best;
+        double* gs = a.gaussian_stats + (long)t * D * D;
+        double* gn = a.gaussian_natparam + (long)t * D * D;
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+          for (int j = 0; j < D; ++j) {
+            double sv = 0.0, nv = 0.0;
+            if (i < N && j < N) { sv = g.ExxT[i < N ? i : 0][j < N ? j : 0]; nv = g.A[i < N ? i : 0][j < N ? j : 0]; }
+            else if (i < N && j == N) { sv = g.Ex[i < N ? i : 0]; nv = g.h[i < N ? i : 0]; }
+            else if (i == j) { sv = 1.0; }
+            gs[i * D + j] = sv;
+            gn[i * D + j] = nv;
+          }
+        gn[N * D + N] = cN;
+        gn[(N + 1) * D + N + 1] = dN;
+      }
+    }
+    return klpart;
+  };
+
+  // ---- fixed point [gmm.py:90-110] -------------------------------------------------------------
+  double kl_prev = 1.0 / 0.0;
+  int it = 0;
+  for (int i = 0; i < a.max_iter; ++i) {
+    it = i + 1;
+    const double kl = block_sum<GMM_BLOCK>(sweep(i == 0, false), red);
+    const bool stop = fabs(kl - kl_prev) < a.tol;
+    kl_prev = kl;
+    if (stop) break;
+  }
+  // label_stats now holds the fixed point (or label_init if max_iter == 0)
+  if (a.max_iter == 0) {
+    for (int j = tid; j < T * K; j += GMM_BLOCK) a.label_stats[j] = a.label_init[j];
+    __syncthreads();
+  }
+  // ---- final pass + outputs [gmm.py:74-86] -----------------------------------------------------
+  // (reads r from label_stats and overwrites it point by point, by the same thread)
+  const double kl = block_sum<GMM_BLOCK>(sweep(false, true), red);
+  if (tid == 0) { a.kl[0] = kl; a.iters[0] = it; }
+  __syncthreads();
+  __threadfence_block();
+
+  // ---- global statistics: dirichlet_stats = sum_t r_t ; niw_stats_k = sum_t r_tk stats_t -------
+  for (int j = tid; j < K * (1 + D * D); j += GMM_BLOCK) {
+    if (j < K) {
+      double s = 0.0;
+      for (int t = 0; t < T; ++t) s += a.label_stats[(long)t * K + j];
+      a.dirichlet_stats[j] = s;
+    } else {
+      const int k = (j - K) / (D * D), e = (j - K) % (D * D);
+      double s = 0.0;
+      for (int t = 0; t < T; ++t)
+        s = __builtin_fma(a.label_stats[(long)t * K + k], a.gaussian_stats[(long)t * D * D + e], s);
+      a.niw_stats[(long)k * D * D + e] = s;
+    }
+  }
+}
+
+template <int N>
+static int launch_gmm(const GmmArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL((gmm_meanfield_kernel<N>), dim3(1), dim3(gmm_block<N>()), 0, s, a);
+  return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+}  // namespace svae
+
+extern "C" int svae_gmm_meanfield_f64(int T, int N, int K,
+                                      const double* label_global, const double* gaussian_globals,
+                                      const double* node_J, const double* node_h,
+                                      const double* label_init, double tol, int max_iter,
+                                      double* label_stats, double* gaussian_stats,
+                                      double* label_natparam, double* gaussian_natparam,
+                                      double* dirichlet_stats, double* niw_stats,
+                                      double* kl, int32_t* iters, int32_t* assign,
+                                      int32_t* info, void* stream) {
+  if (T < 0) return -1;
+  if (N < 1 || N > 8) return -2;
+  if (K < 1 || K > 64) return -3;
+  if (!label_global) return -4;
+  if (!gaussian_globals) return -5;
+  if (T > 0 && !node_J) return -6;
+  if (T > 0 && !node_h) return -7;
+  if (T > 0 && !label_init) return -8;
+  if (!(tol >= 0.0)) return -9;
+  if (max_iter < 0) return -10;
+  if (T > 0 && (!label_stats || !gaussian_stats || !label_natparam || !gaussian_natparam)) return -11;
+  if (!dirichlet_stats || !niw_stats || !kl || !iters) return -15;
+  if (T > 0 && !assign) return -19;
+  if (!info) return -20;
+  svae::GmmArgs a;
+  a.T = T; a.K = K; a.max_iter = max_iter; a.tol = tol;
+  a.label_global = label_global; a.gaussian_globals = gaussian_globals;
+  a.node_J = node_J; a.node_h = node_h; a.label_init = label_init;
+  a.label_stats = label_stats; a.gaussian_stats = gaussian_stats;
+  a.label_natparam = label_natparam; a.gaussian_natparam = gaussian_natparam;
+  a.dirichlet_stats = dirichlet_stats; a.niw_stats = niw_stats;
+  a.kl = kl; a.iters = iters; a.assign = assign; a.info = info;
+  hipStream_t s = (hipStream_t)stream;
+  switch (N) {
+    case 1: return svae::launch_gmm<1>(a, s);
+    case 2: return svae::launch_gmm<2>(a, s);
+    case 3: return svae::launch_gmm<3>(a, s);
+    case 4: return svae::launch_gmm<4>(a, s);
+    case 5: return svae::launch_gmm<5>(a, s);
+    case 6: return svae::launch_gmm<6>(a, s);
+    case 7: return svae::launch_gmm<7>(a, s);
+    case 8: return svae::launch_gmm<8>(a, s);
+  }
+  return -2;
+}

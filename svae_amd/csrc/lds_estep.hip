@@ -116,3 +116,10 @@ int svae_lds_reduce_stats_f64(int B, int n, const double* E_init, const double* 
 }
 
 }  // extern "C"
+
+extern "C" int svae_lds_sample_f64(int B, int T, int n, int S, const double* eps, double* samples,
+                                   const void* workspace, size_t ws_bytes, void* stream) {
+  (void)B; (void)T; (void)n; (void)S; (void)eps; (void)samples; (void)workspace; (void)ws_bytes;
+  (void)stream;
+  return -100;  // not implemented yet ("next" row 1)
+}

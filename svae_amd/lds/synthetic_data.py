@@ -1,0 +1,41 @@
+"""Synthetic LDS models and recognition potentials for tests and benchmarks.
+
+Mirrors the reference's generator /root/reference/svae/lds/synthetic_data.py:8-28 (`rand_lds`:
+A = randn scaled to spectral radius < 1 via /(max|eig| + 0.1), Sigma_states = B B', Sigma_init =
+rand_psd, mu_init = randn) and the conversions of svae/lds/gaussian.py:110-114,130-143
+(`mean_to_natural`, `pair_mean_to_natural`); node potentials mimic the recognition head
+`gaussian_info` (svae/nnet.py:43-47): J = -1/2 softplus(z), h ~ N(0,1)  (SURVEY.md section 8d).
+Host-side NumPy only (this is input construction, not the hot path).
+"""
+import numpy as np
+
+
+def rand_lds_natparam(n, rng):
+    """-> (init_params, pair_params) in natural form for a random stable LDS."""
+    A = rng.standard_normal((n, n))
+    A /= np.max(np.abs(np.linalg.eigvals(A))) + 0.1
+    Bm = rng.standard_normal((n, n))
+    sigma_states = Bm @ Bm.T
+    S0 = rng.standard_normal((n, n))
+    sigma_init = S0 @ S0.T
+    mu_init = rng.standard_normal(n)
+    # mean_to_natural, gaussian.py:110-114
+    J0 = -0.5 * np.linalg.inv(sigma_init)
+    h0 = np.linalg.solve(sigma_init, mu_init)
+    logZ0 = -0.5 * mu_init @ h0 - 0.5 * np.linalg.slogdet(sigma_init)[1]
+    # pair_mean_to_natural, gaussian.py:130-143
+    temp = np.linalg.solve(sigma_states, A)
+    J11 = -0.5 * A.T @ temp
+    J12 = temp.T
+    J22 = -0.5 * np.linalg.inv(sigma_states)
+    logZ = -0.5 * np.linalg.slogdet(sigma_states)[1]
+    return (J0, h0, logZ0), (J11, J12, J22, logZ)
+
+
+def rand_node_potentials(shape, rng, with_logZ=False):
+    """shape = (T, n) or (B, T, n) -> (J diag, h[, logZ]) like nnet.gaussian_info (nnet.py:43-47)."""
+    J = -0.5 * np.log1p(np.exp(rng.standard_normal(shape)))
+    h = rng.standard_normal(shape)
+    if with_logZ:
+        return J, h, 0.1 * rng.standard_normal(shape[:-1])
+    return J, h

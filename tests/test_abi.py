@@ -1,0 +1,63 @@
+"""CPU tests of the drop-in boundary: libsvae_hip.so loads without a GPU, exports every symbol
+include/svae_hip.h declares, and rejects bad arguments before touching the device."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "svae_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(svae_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_the_expected_entry_points():
+    syms = _header_symbols()
+    for s in ("svae_lds_estep_f64", "svae_lds_workspace_bytes", "svae_lds_reduce_stats_f64",
+              "svae_lds_sample_f64", "svae_gmm_meanfield_f64", "svae_hip_abi_version"):
+        assert s in syms
+
+
+def test_library_loads_and_exports_every_header_symbol():
+    from svae_amd import _lib
+    lib = _lib.load()                       # raises if not built: no fallback
+    assert sorted(_lib.SIGNATURES) == _header_symbols()
+    for s in _header_symbols():
+        assert hasattr(lib, s), s
+    assert lib.svae_hip_abi_version() == _lib.ABI_VERSION
+
+
+def test_workspace_size_formula():
+    from svae_amd import _lib
+    lib = _lib.load()
+    assert lib.svae_lds_workspace_bytes(512, 200, 10) == 512 * 200 * (2 * 10 + 1) * 10 * 8
+    assert lib.svae_lds_workspace_bytes(1, 1, 16) == 0     # n > 15: outside the register path
+    assert lib.svae_lds_workspace_bytes(0, 5, 3) == 0
+
+
+def test_bad_arguments_are_rejected_on_the_host():
+    """Argument errors return -k before any HIP call (safe without a GPU)."""
+    from svae_amd import _lib
+    lib = _lib.load()
+    null = None
+    args = [null] * 15 + [null, null, 0, null]
+    assert lib.svae_lds_estep_f64(4, 0, 3, 0, 0, *args) == -2          # T < 1
+    assert lib.svae_lds_estep_f64(4, 5, 16, 0, 0, *args) == -3         # n too large
+    assert lib.svae_lds_estep_f64(4, 5, 3, 0, 1, *args) == -5          # batched pair w/o inhomog
+    assert lib.svae_lds_estep_f64(4, 5, 3, 0, 0, *args) == -6          # NULL init_J
+    assert lib.svae_gmm_meanfield_f64(10, 9, 3, *([null] * 5), 1e-3, 100,
+                                      *([null] * 7), null, null, null, null) == -2
+    assert lib.svae_gmm_meanfield_f64(10, 2, 65, *([null] * 5), 1e-3, 100,
+                                      *([null] * 7), null, null, null, null) == -3
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from svae_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError):
+        _lib.load()

@@ -1,0 +1,142 @@
+"""CPU tests: the oracle (NumPy restatement) against the committed golden vectors generated from
+the reference itself, against the live reference build when present, and against a brute-force
+dense solve."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import expfam_numpy as ef
+from oracle import gmm_numpy, lds_numpy, ref
+
+LDS_CASES = ["lds_T5_n3", "lds_T20_n10", "lds_T200_n10", "lds_T1_n4", "lds_T2_n15",
+             "lds_T12_n4_inhomog"]
+GMM_CASES = ["gmm_K5_N2_T100", "gmm_K15_N2_T50", "gmm_K4_N3_T33"]
+
+
+def _lds_inputs(g, b):
+    init = (g["init_J"], g["init_h"], float(g["init_logZ"]))
+    lz = g["logZ_pair"]
+    pair = (g["J11"], g["J12"], g["J22"], float(lz) if lz.ndim == 0 else lz)
+    T = g["node_h"].shape[1]
+    node = (g["node_J"][b], g["node_h"][b], g["node_logZ"][b] if "node_logZ" in g else np.zeros(T))
+    return (init, pair), node
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    scale = np.maximum(np.abs(b), 1e-3 * max(np.max(np.abs(b)), 1e-300))
+    return float(np.max(np.abs(a - b) / scale)) if a.size else 0.0
+
+
+@pytest.mark.parametrize("case", LDS_CASES)
+def test_lds_oracle_matches_golden(case, golden_dir):
+    g = np.load(os.path.join(golden_dir, case + ".npz"))
+    for b in range(g["node_h"].shape[0]):
+        natparam, node = _lds_inputs(g, b)
+        lognorm, (Ei, Ep, En) = lds_numpy.natural_lds_estep_general(natparam, node)
+        assert abs(lognorm - g["lognorm"][b]) <= 1e-9 * max(1.0, abs(g["lognorm"][b]))
+        assert _rel(Ei[0], g["ExxT0"][b]) < 1e-8 and _rel(Ei[1], g["Ex0"][b]) < 1e-8
+        for i, k in enumerate(("Epair_xx", "Epair_xxn", "Epair_xnxn")):
+            assert _rel(Ep[i], g[k][b]) < 1e-8, k
+        assert _rel(En[0], g["Enode_diagxx"][b]) < 1e-8 and _rel(En[1], g["Enode_x"][b]) < 1e-8
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("case", LDS_CASES)
+def test_reference_build_reproduces_golden(case, golden_dir):
+    g = np.load(os.path.join(golden_dir, case + ".npz"))
+    natparam, node = _lds_inputs(g, 0)
+    lognorm, (Ei, Ep, En) = ref.estep(natparam, node)
+    assert lognorm == pytest.approx(float(g["lognorm"][0]), rel=1e-12)
+    assert _rel(En[1], g["Enode_x"][0]) < 1e-10
+    assert _rel(np.asarray(Ep[1]), g["Epair_xxn"][0]) < 1e-10
+
+
+def test_lds_oracle_matches_dense_bruteforce():
+    from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials
+    rng = np.random.default_rng(11)
+    for T, n in [(1, 2), (4, 3), (7, 5)]:
+        natparam = rand_lds_natparam(n, rng)
+        node = rand_node_potentials((T, n), rng, with_logZ=True)
+        lognorm, (Ei, Ep, En) = lds_numpy.natural_lds_estep_general(natparam, node)
+        ln_d, Ex, ExxT, ExxnT = lds_numpy.dense_estep(natparam, node)
+        assert lognorm == pytest.approx(ln_d, rel=1e-10, abs=1e-10)
+        assert _rel(En[1], Ex) < 1e-9 and _rel(Ei[0], ExxT[0]) < 1e-9
+        assert _rel(En[0], np.stack([np.diag(x) for x in ExxT])) < 1e-9
+        if T > 1:
+            assert _rel(Ep[0], ExxT[:-1].sum(0)) < 1e-9 and _rel(Ep[1], ExxnT.sum(0)) < 1e-9
+            assert _rel(Ep[2], ExxT[1:].sum(0)) < 1e-9
+
+
+def test_lds_node_param_validation():
+    # lds_inference.py:65-82 raises ValueError on malformed node potentials
+    with pytest.raises(ValueError):
+        lds_numpy._canonical_node_params((np.zeros((3, 2)), np.zeros((4, 2))))
+    with pytest.raises(ValueError):
+        lds_numpy._canonical_node_params((np.zeros((3,)), np.zeros((3, 2))))
+
+
+@pytest.mark.parametrize("case", GMM_CASES)
+def test_gmm_oracle_matches_golden(case, golden_dir):
+    g = np.load(os.path.join(golden_dir, case + ".npz"))
+    (ls, gs), (ds, ns), (ln, gn), kl, iters = gmm_numpy.local_meanfield(
+        g["label_global"], g["gaussian_globals"], (g["node_J"], g["node_h"]), g["label_init"])
+    assert np.array_equal(ls.argmax(1), g["label_stats"].argmax(1))          # bit-exact labels
+    for got, key in ((ls, "label_stats"), (gs, "gaussian_stats"), (ds, "dirichlet_stats"),
+                     (ns, "niw_stats"), (ln, "label_natparam"), (gn, "gaussian_natparam")):
+        np.testing.assert_allclose(got, g[key], rtol=1e-12, atol=1e-12, err_msg=key)
+    assert kl == pytest.approx(float(g["kl"]), rel=1e-12)
+    assert 1 <= iters <= 100
+
+
+def test_expfam_matches_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "expfam.npz"))
+    np.testing.assert_allclose(ef.dirichlet_expectedstats(g["dir_nat"]), g["dir_es"], rtol=1e-13)
+    assert ef.dirichlet_logZ(g["dir_nat"]) == pytest.approx(float(g["dir_logZ"]), rel=1e-13)
+    np.testing.assert_allclose(ef.niw_expectedstats(g["niw_nat"]), g["niw_es"], rtol=1e-12, atol=1e-14)
+    assert ef.niw_logZ(g["niw_nat"]) == pytest.approx(float(g["niw_logZ"]), rel=1e-12)
+    nat = tuple(g["mniw_nat%d" % i] for i in range(4))
+    for i, x in enumerate(ef.mniw_expectedstats(nat)):
+        np.testing.assert_allclose(x, g["mniw_es%d" % i], rtol=1e-12, atol=1e-14)
+    assert ef.mniw_logZ(nat) == pytest.approx(float(g["mniw_logZ"]), rel=1e-12)
+
+
+def test_expfam_identities():
+    # the reference's own tests (tests/test_gaussian.py:19-40, tests/test_niw.py:21-42,
+    # tests/test_dirichlet.py:15-25): pack/unpack round trips and E[stats] = grad logZ, the latter
+    # by central differences here (autograd is not available).
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((3, 6, 6))
+    A, b, c, d = ef.unpack_dense(x)
+    y = ef.pack_dense(A, b, c, d)
+    np.testing.assert_array_equal(ef.unpack_dense(y)[0], A)
+    np.testing.assert_array_equal(ef.unpack_dense(y)[1], b)
+
+    def numgrad(f, x, eps=1e-6):
+        g = np.zeros_like(x)
+        for idx in np.ndindex(*x.shape):
+            xp, xm = x.copy(), x.copy()
+            xp[idx] += eps
+            xm[idx] -= eps
+            g[idx] = (f(xp) - f(xm)) / (2 * eps)
+        return g
+
+    a = rng.random(4) * 2
+    np.testing.assert_allclose(ef.dirichlet_expectedstats(a), numgrad(ef.dirichlet_logZ, a),
+                               rtol=1e-6, atol=1e-7)
+    n = 2
+    M = rng.standard_normal((n, n))
+    S = M @ M.T + n * np.eye(n)
+    nat = ef.niw_standard_to_natural(S, rng.standard_normal(n), np.array(1.5), np.array(n + 2.5))
+    rt = ef.niw_standard_to_natural(*ef.niw_natural_to_standard(nat))
+    np.testing.assert_allclose(rt, nat, rtol=1e-12, atol=1e-12)
+    es = ef.niw_expectedstats(nat, fudge=0.0)
+    gnum = numgrad(lambda z: ef.niw_logZ(z), nat)
+    # only the packed slots are free parameters; A enters symmetrically
+    An, bn, cn, dn = ef.unpack_dense(gnum)
+    Ae, be, ce, de = ef.unpack_dense(es)
+    np.testing.assert_allclose((An + An.T) / 2, Ae, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(bn, be, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose([cn, dn], [ce, de], rtol=1e-5, atol=1e-6)
