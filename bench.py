@@ -38,60 +38,16 @@ def algorithmic_bytes_per_seq(T, n):
     return 8 * (T * (2 * n + 1) + 2 * T * n + (n * n + n) + 3 * n * n + 1)
 
 
-def _cpu_worker(args):
-    """Times the reference's compiled E-step on a slice of sequences (one process = one core)."""
-    os.environ["OMP_NUM_THREADS"] = os.environ["OPENBLAS_NUM_THREADS"] = "1"
-    natparam, node_J, node_h = args
-    from oracle import ref
-    T = node_h.shape[1]
-    z = np.zeros(T)
-    t0 = time.perf_counter()
-    for b in range(node_h.shape[0]):
-        ref.estep(natparam, (node_J[b], node_h[b], z))
-    return time.perf_counter() - t0
-
-
-def cpu_baseline(natparam, node_J, node_h, budget_s=12.0):
-    """Reference CPU path on a bounded sample: 1 core, then all host cores (process pool)."""
-    from oracle import lds_numpy, ref
-    kind = "reference" if ref.available() else "port"
-    T = node_h.shape[1]
-    if kind == "port":
-        est = lambda b: lds_numpy.natural_lds_estep_general(natparam, (node_J[b], node_h[b], np.zeros(T)))
-        nb = 64
-        t0 = time.perf_counter()
-        for b in range(nb):
-            est(b)
-        dt = time.perf_counter() - t0
-        return {"value": nb / dt, "unit": "sequences/s", "cores": 1, "kind": kind,
-                "sample": "%d sequences T=%d n=%d, NumPy restatement, 1 core" % (nb, T, node_h.shape[2])}
-    _cpu_worker((natparam, node_J[:8], node_h[:8]))                       # warm-up / page-in
-    n1 = min(node_h.shape[0], 512)
-    dt1 = _cpu_worker((natparam, node_J[:n1], node_h[:n1]))
-    one_core = n1 / dt1
-    cores = os.cpu_count() or 1
-    value, used, sample = one_core, 1, "%d sequences on 1 core" % n1
-    if cores > 1:
-        import multiprocessing as mp
-        per = max(64, int(min(budget_s * one_core, 4096) // cores))
-        reps = -(-per // node_h.shape[0])
-        J = np.concatenate([node_J] * reps)[:per] if reps > 1 else node_J[:per]
-        h = np.concatenate([node_h] * reps)[:per] if reps > 1 else node_h[:per]
-        try:
-            with mp.get_context("fork").Pool(cores) as pool:
-                t0 = time.perf_counter()
-                pool.map(_cpu_worker, [(natparam, J, h)] * cores)
-                wall = time.perf_counter() - t0
-            allc = per * cores / wall
-            if allc > value:
-                value, used = allc, cores
-                sample = "%d sequences per core on %d cores (process pool)" % (per, cores)
-        except Exception as e:  # pragma: no cover
-            sample += " (pool failed: %r)" % (e,)
-    return {"value": value, "unit": "sequences/s", "cores": used, "kind": kind,
-            "one_core_value": one_core, "host_cores": cores,
-            "sample": "reference compiled E-step (oracle/_ref), T=%d n=%d: %s"
-                      % (T, node_h.shape[2], sample)}
+def cpu_baseline(B, T, n, budget_s=10.0):
+    """Reference CPU path on a bounded sample of the same workload, in a SEPARATE process (a forked
+    pool must not inherit an initialised HIP runtime): see oracle/cpu_baseline.py."""
+    import subprocess
+    r = subprocess.run([sys.executable, "-m", "oracle.cpu_baseline", "--B", str(B), "--T", str(T),
+                        "--n", str(n), "--budget", str(budget_s)], cwd=ROOT, capture_output=True,
+                       text=True, timeout=20 * budget_s + 120)
+    if r.returncode != 0:
+        raise RuntimeError(r.stderr[-400:])
+    return json.loads(r.stdout.strip().splitlines()[-1])
 
 
 def main():
@@ -193,7 +149,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline((init, pair), node_J, node_h)
+                out["cpu_baseline"] = cpu_baseline(B, T, n)
                 out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
             except Exception as e:  # never lose the GPU line to a baseline hiccup
                 out["cpu_baseline"] = {"error": repr(e)}

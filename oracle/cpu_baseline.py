@@ -1,0 +1,92 @@
+"""Time the reference's CPU E-step on this box's host cores.  TEST/BENCH INFRASTRUCTURE ONLY.
+
+Run by bench.py's `cpu_baseline` leg as a separate process (never forked from a process that has
+initialised the HIP runtime):  python -m oracle.cpu_baseline --B 512 --T 200 --n 10
+
+Times `cython_natural_lds_estep_general` (svae/lds/lds_inference.py:232-237) = the reference's own
+compiled filter + smoother built by oracle/build_ref.py ("reference"), or, when oracle/_ref is
+absent, the NumPy restatement ("port"), per sequence, on a BOUNDED sample of the bench workload
+(same generator and seeds as bench.py rank 0): first on 1 core, then on all host cores with a
+process pool (BLAS pinned to 1 thread per process).  Prints one JSON object.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+os.environ.setdefault("OMP_NUM_THREADS", "1")
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+os.environ.setdefault("MKL_NUM_THREADS", "1")
+
+import numpy as np  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+_G = {}
+
+
+def _estep_fn():
+    from oracle import lds_numpy, ref
+    if ref.available():
+        return "reference", ref.estep
+    return "port", lds_numpy.natural_lds_estep_general
+
+
+def _worker(count):
+    """E-step `count` sequences (cycling through the sample); returns elapsed seconds."""
+    natparam, node_J, node_h = _G["data"]
+    _, est = _estep_fn()
+    T = node_h.shape[1]
+    z = np.zeros(T)
+    B = node_h.shape[0]
+    t0 = time.perf_counter()
+    for i in range(count):
+        b = i % B
+        est(natparam, (node_J[b], node_h[b], z))
+    return time.perf_counter() - t0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--B", type=int, default=512)
+    ap.add_argument("--T", type=int, default=200)
+    ap.add_argument("--n", type=int, default=10)
+    ap.add_argument("--budget", type=float, default=10.0, help="seconds of wall time per leg")
+    a = ap.parse_args()
+    from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials
+    natparam = rand_lds_natparam(a.n, np.random.default_rng(0))
+    node_J, node_h = rand_node_potentials((a.B, a.T, a.n), np.random.default_rng(1000))
+    _G["data"] = (natparam, node_J, node_h)
+    kind, _ = _estep_fn()
+
+    _worker(8)                                        # warm-up / page-in
+    probe = _worker(32) / 32.0                        # seconds per sequence
+    n1 = int(max(32, min(a.B, a.budget / probe)))
+    dt1 = _worker(n1)
+    one_core = n1 / dt1
+    cores = os.cpu_count() or 1
+    out = {"value": one_core, "unit": "sequences/s", "cores": 1, "kind": kind,
+           "one_core_value": one_core, "host_cores": cores,
+           "sample": "%d of the %d bench sequences (T=%d, n=%d), 1 core" % (n1, a.B, a.T, a.n)}
+    if cores > 1:
+        import multiprocessing as mp
+        per = int(max(32, min(a.B, a.budget * one_core)))
+        with mp.get_context("fork").Pool(cores) as pool:      # no GPU runtime in this process
+            pool.map(_worker, [4] * cores)
+            t0 = time.perf_counter()
+            pool.map(_worker, [per] * cores)
+            wall = time.perf_counter() - t0
+        allc = per * cores / wall
+        out["all_cores_value"] = allc
+        if allc > one_core:
+            out.update(value=allc, cores=cores,
+                       sample="%d sequences per process x %d processes (one per host core), drawn "
+                              "from the %d bench sequences (T=%d, n=%d)" % (per, cores, a.B, a.T, a.n))
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,94 @@
+"""GMM-SVAE local inference on MI355X; mirrors /root/reference/svae/models/gmm.py.
+
+  local_meanfield(global_natparam, node_potentials) -> (local_stats, prior_stats, natparam, kl)
+                                                                        (gmm.py:62-88)
+  run_inference(prior_natparam, global_natparam, nn_potentials, num_samples)   (gmm.py:12-16)
+
+The fixed point (gmm.py:90-110) and the final pass run in ONE kernel launch of libsvae_hip.so
+(svae_gmm_meanfield_f64); the two global->local maps (dirichlet / niw expectedstats, gmm.py:67-68)
+are O(K N^2) torch ops.  Difference to the reference, by design: `initialize_meanfield`
+(gmm.py:126-128) draws from the global NumPy RNG inside the loop; here the initial
+responsibilities are an argument (`label_init`, default: drawn from a torch generator), so results
+are reproducible and parity-testable.  No CPU fallback.
+"""
+import torch
+
+from .. import _lib
+from ..distributions import expfam
+
+GMM_MAX_N, GMM_MAX_K = 8, 64
+
+
+def _dev64(x, device):
+    t = x.detach() if isinstance(x, torch.Tensor) else torch.as_tensor(x)
+    return t.to(device=device, dtype=torch.float64).contiguous()
+
+
+def initialize_meanfield(T, K, device, generator=None):
+    """normalize(rand(T, K)), gmm.py:126-128."""
+    r = torch.rand(T, K, dtype=torch.float64, device=device, generator=generator)
+    return r / r.sum(-1, keepdim=True)
+
+
+def meanfield_from_globals(label_global, gaussian_globals, node_potentials, label_init,
+                           tol=1e-3, max_iter=100, check=True):
+    """The kernel call: everything after gmm.py:68.  Returns a dict of device tensors."""
+    lib = _lib.load()
+    dev = gaussian_globals.device if isinstance(gaussian_globals, torch.Tensor) and \
+        gaussian_globals.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    lg, gg = _dev64(label_global, dev), _dev64(gaussian_globals, dev)
+    nJ, nh = _dev64(node_potentials[0], dev), _dev64(node_potentials[1], dev)
+    if nJ.dim() != 2 or nJ.shape != nh.shape:
+        raise ValueError("node potentials must be (J diag (T,N), h (T,N))")
+    T, N = nh.shape
+    K = lg.shape[0]
+    D = N + 2
+    if tuple(gg.shape) != (K, D, D):
+        raise ValueError("gaussian_globals must be (K, N+2, N+2)")
+    if not (1 <= N <= GMM_MAX_N and 1 <= K <= GMM_MAX_K):
+        raise ValueError("GMM kernel limits: N <= %d, K <= %d" % (GMM_MAX_N, GMM_MAX_K))
+    li = _dev64(label_init, dev)
+    if tuple(li.shape) != (T, K):
+        raise ValueError("label_init must be (T, K)")
+    f64 = dict(dtype=torch.float64, device=dev)
+    out = dict(label_stats=torch.empty(T, K, **f64), gaussian_stats=torch.empty(T, D, D, **f64),
+               label_natparam=torch.empty(T, K, **f64), gaussian_natparam=torch.empty(T, D, D, **f64),
+               dirichlet_stats=torch.empty(K, **f64), niw_stats=torch.empty(K, D, D, **f64),
+               kl=torch.empty(1, **f64), iters=torch.zeros(1, dtype=torch.int32, device=dev),
+               assign=torch.empty(T, dtype=torch.int32, device=dev),
+               info=torch.zeros(1, dtype=torch.int32, device=dev))
+    p = _lib.ptr
+    rc = lib.svae_gmm_meanfield_f64(
+        T, N, K, p(lg), p(gg), p(nJ), p(nh), p(li), float(tol), int(max_iter),
+        p(out["label_stats"]), p(out["gaussian_stats"]), p(out["label_natparam"]),
+        p(out["gaussian_natparam"]), p(out["dirichlet_stats"]), p(out["niw_stats"]),
+        p(out["kl"]), p(out["iters"]), p(out["assign"]), p(out["info"]), _lib.current_stream(dev))
+    _lib.check(rc, "svae_gmm_meanfield_f64")
+    if check:
+        v = int(out["info"].item())
+        if v != 0:
+            raise FloatingPointError("GMM mean field: point %d has a non positive definite "
+                                     "Gaussian factor" % (v - 1))
+    return out
+
+
+def local_meanfield(global_natparam, node_potentials, label_init=None, tol=1e-3, max_iter=100,
+                    generator=None):
+    """gmm.py:62-88 -> (local_stats, prior_stats, natparam, kl)."""
+    dirichlet_natparam, niw_natparams = global_natparam
+    dev = torch.device("cuda", torch.cuda.current_device())
+    for x in (niw_natparams, node_potentials[0]):
+        if isinstance(x, torch.Tensor) and x.is_cuda:
+            dev = x.device
+    dn, nn_ = _dev64(dirichlet_natparam, dev), _dev64(niw_natparams, dev)
+    label_global = expfam.dirichlet_expectedstats(dn)          # gmm.py:67
+    gaussian_globals = expfam.niw_expectedstats(nn_)           # gmm.py:68
+    T = node_potentials[1].shape[0]
+    if label_init is None:
+        label_init = initialize_meanfield(T, dn.shape[0], dev, generator)
+    o = meanfield_from_globals(label_global, gaussian_globals, node_potentials, label_init,
+                               tol, max_iter)
+    local_stats = o["label_stats"], o["gaussian_stats"]
+    prior_stats = o["dirichlet_stats"], o["niw_stats"]
+    natparam = o["label_natparam"], o["gaussian_natparam"]
+    return local_stats, prior_stats, natparam, o["kl"][0]

@@ -1,0 +1,94 @@
+"""GPU parity tests of the GMM mean-field kernel against the golden vectors produced by the
+reference's own svae/models/gmm.py and against the NumPy oracle.  Assignments (argmax of the
+responsibilities) must be bit-exact; real-valued outputs within 1e-9 relative."""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import expfam_numpy as ef, gmm_numpy  # noqa: E402  (checker only)
+
+GMM_CASES = ["gmm_K5_N2_T100", "gmm_K15_N2_T50", "gmm_K4_N3_T33"]
+
+
+def _np(x):
+    return x.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("case", GMM_CASES)
+def test_golden_local_meanfield(case, golden_dir):
+    from svae_amd.models.gmm import local_meanfield
+    g = np.load(os.path.join(golden_dir, case + ".npz"))
+    (ls, gs), (ds, ns), (ln, gn), kl = local_meanfield(
+        (g["dirichlet_natparam"], g["niw_natparam"]), (g["node_J"], g["node_h"]),
+        label_init=g["label_init"])
+    assert np.array_equal(_np(ls).argmax(1), g["label_stats"].argmax(1))       # bit-exact labels
+    for got, key in ((ls, "label_stats"), (gs, "gaussian_stats"), (ds, "dirichlet_stats"),
+                     (ns, "niw_stats"), (ln, "label_natparam"), (gn, "gaussian_natparam")):
+        np.testing.assert_allclose(_np(got), g[key], rtol=1e-9, atol=1e-10, err_msg=key)
+    assert float(kl) == pytest.approx(float(g["kl"]), rel=1e-10)
+
+
+def test_global_maps_match_golden(golden_dir):
+    from svae_amd.distributions import expfam
+    g = np.load(os.path.join(golden_dir, "expfam.npz"))
+    t = lambda x: torch.as_tensor(x, dtype=torch.float64, device="cuda:0")
+    np.testing.assert_allclose(_np(expfam.dirichlet_expectedstats(t(g["dir_nat"]))), g["dir_es"], rtol=1e-12)
+    np.testing.assert_allclose(_np(expfam.niw_expectedstats(t(g["niw_nat"]))), g["niw_es"],
+                               rtol=1e-10, atol=1e-12)
+    nat = tuple(t(g["mniw_nat%d" % i]) for i in range(4))
+    for i, x in enumerate(expfam.mniw_expectedstats(nat)):
+        np.testing.assert_allclose(_np(x), g["mniw_es%d" % i], rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("T,N,K", [(1000, 2, 5), (500, 2, 15), (3000, 2, 8), (257, 4, 6),
+                                   (64, 8, 3), (1, 2, 5), (7, 1, 1)])
+def test_against_oracle(T, N, K):
+    """BASELINE configs[0] (K=5, 2-D, 1k points), the shipped script's shape (K=15, 500 points), more
+    points than lanes (3000 > 1024), and the corners N=1..8, T=1, K=1."""
+    from svae_amd.models.gmm import meanfield_from_globals
+    from svae_amd.lds.synthetic_data import rand_node_potentials
+    rng = np.random.default_rng(T + N + K)
+    niw = []
+    for _ in range(K):
+        m = rng.standard_normal(N) * 2
+        niw.append(ef.niw_standard_to_natural((N + 10.) * np.eye(N), m, np.array(10.), np.array(N + 10.)))
+    lg = ef.dirichlet_expectedstats(rng.random(K) + 0.5)
+    gg = ef.niw_expectedstats(np.stack(niw))
+    node = rand_node_potentials((T, N), rng)
+    init = rng.random((T, K))
+    init /= init.sum(-1, keepdims=True)
+    o = meanfield_from_globals(lg, gg, node, init)
+    (ls, gs), (ds, ns), (ln, gn), kl, iters = gmm_numpy.local_meanfield(lg, gg, node, init)
+    assert int(o["iters"].item()) == iters
+    assert np.array_equal(_np(o["assign"]), ls.argmax(1))
+    assert np.array_equal(_np(o["label_stats"]).argmax(1), ls.argmax(1))
+    np.testing.assert_allclose(_np(o["label_stats"]), ls, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(_np(o["gaussian_stats"]), gs, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(_np(o["niw_stats"]), ns, rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(_np(o["dirichlet_stats"]), ds, rtol=1e-10)
+    np.testing.assert_allclose(_np(o["gaussian_natparam"]), gn, rtol=1e-10, atol=1e-12)
+    assert float(o["kl"].item()) == pytest.approx(kl, rel=1e-9)
+
+
+def test_max_iter_and_determinism():
+    from svae_amd.models.gmm import meanfield_from_globals
+    from svae_amd.lds.synthetic_data import rand_node_potentials
+    rng = np.random.default_rng(5)
+    K, N, T = 5, 2, 400
+    niw = np.stack([ef.niw_standard_to_natural(12. * np.eye(N), rng.standard_normal(N), np.array(10.),
+                                               np.array(12.)) for _ in range(K)])
+    lg, gg = ef.dirichlet_expectedstats(np.ones(K)), ef.niw_expectedstats(niw)
+    node = rand_node_potentials((T, N), rng)
+    init = rng.random((T, K)); init /= init.sum(-1, keepdims=True)
+    a = meanfield_from_globals(lg, gg, node, init, max_iter=3)
+    b = meanfield_from_globals(lg, gg, node, init, max_iter=3)
+    assert int(a["iters"].item()) == 3
+    for k in ("label_stats", "niw_stats", "kl"):
+        assert torch.equal(a[k], b[k])                      # bit-reproducible run to run
+    ls, it = gmm_numpy.meanfield_fixed_point(lg, gg, ef.pack_dense(*node), init, max_iter=3,
+                                             return_iters=True)
+    assert it == 3
