@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  (must precede CDLL: shares torch's HIP runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsvae_hip.so")
+LIB_PATH = os.environ.get("SVAE_AMD_LIB", os.path.join(_HERE, "libsvae_hip.so"))  # env: experiments only
 
 ABI_VERSION = 1
 LDS_MAX_N = 15

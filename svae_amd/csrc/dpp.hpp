@@ -1,14 +1,32 @@
 // dpp.hpp -- CDNA4 (gfx950) cross-lane primitives used by the SVAE message-passing kernels.
 //
 // Layout convention ("row tile"): a wavefront is 4 DPP rows of 16 lanes.  One row owns one
-// sequence (or one data point group); lane c of the row holds COLUMN c of every small matrix, one
-// VGPR pair per matrix row.  `bcast<K>(x)` returns lane K of the caller's row to all 16 lanes of
-// that row in one DP-ALU DPP move (v_mov_b64_dpp row_newbcast:K) -- no LDS, no SGPR round trip, no
-// cross-row traffic, so the 4 rows of a wave run 4 independent problems in lock-step.
+// sequence; lane c of the row holds COLUMN c of every small matrix, one VGPR pair per matrix row.
+// Every small dense product is then  acc[c] += M[i][k] * B[k][c]  with M[i][k] = "lane k of my row,
+// register i": on gfx90a+ that broadcast is a DPP operand modifier (row_newbcast:k) that the DP-ALU
+// accepts directly on v_fmac_f64, i.e. ONE instruction per multiply-accumulate, no LDS, no SGPR
+// round trip, no cross-row traffic; the 4 rows of a wave run 4 independent problems in lock-step.
+//
+// hipcc (ROCm 7.2) cannot emit that form: clang's update_dpp builtin is 32-bit only, and LLVM's
+// GCNDPPCombine does not fold a v_mov_b64_dpp into v_fmac_f64 (tied accumulator), which leaves
+// mov+fma pairs plus an s_nop per pair.  So the multiply-accumulate is inline asm, and the two
+// hazards the compiler would otherwise pad are handled here by construction:
+//   (H1) VALU write of a VGPR -> DPP read of it needs 2 wait states;
+//   (H2) VALU write of EXEC (v_cmpx) -> DPP op needs 5 wait states (gfx9 hipcc emits v_cmp +
+//        s_and_saveexec, never v_cmpx; tools/audit_dpp_hazards.py checks the .s for both).
+// All DPP asm statements are `volatile`, so they keep their source order relative to each other;
+// `dpp_fence` (an s_nop 1 that "rewrites" its operands) separates compiler-produced values from
+// their first DPP read, and the kernels order the statements so that an asm-produced register is
+// never DPP-read within the next two instructions.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 namespace svae {
+
+#ifndef SVAE_FUSED_DPP
+#define SVAE_FUSED_DPP 1   // 0: compiler-only path (v_mov_b64_dpp + v_fma_f64), for A/B and debugging
+#endif
 
 // llvm.amdgcn.update.dpp is type-generic in LLVM but clang's builtin is int-only in ROCm 7.2;
 // binding the intrinsic by its IR name gives the f64 form (lowers to v_mov_b64_dpp on gfx950).
@@ -17,10 +35,56 @@ extern "C" __device__ double __svae_update_dpp_f64(double, double, int, int, int
 
 constexpr int DPP_ROW_NEWBCAST0 = 0x150;  // row_newbcast:0 .. row_newbcast:15 (gfx90a+)
 
+// lane K of the caller's 16-lane row, broadcast to the row (compiler-scheduled; hazards padded
+// by hipcc).  Only for values produced by ordinary (non-asm) code.
 template <int K>
 __device__ __forceinline__ double bcast(double x) {
   static_assert(K >= 0 && K < 16, "row_newbcast lane out of range");
   return __svae_update_dpp_f64(0.0, x, DPP_ROW_NEWBCAST0 + K, 0xf, 0xf, true);
+}
+
+// acc + bcast_K(src) * b   in one DP-ALU DPP instruction.
+template <int K>
+__device__ __forceinline__ void mac_bc(double& acc, double src, double b) {
+  static_assert(K >= 0 && K < 16, "row_newbcast lane out of range");
+#if SVAE_FUSED_DPP
+  asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+               : "+v"(acc)
+               : "v"(src), "v"(b), "n"(K));
+#else
+  acc = __builtin_fma(bcast<K>(src), b, acc);
+#endif
+}
+
+// bcast_K(src) of a register that may have been written by the immediately preceding asm
+// statements: carries its own two wait states (H1).
+template <int K>
+__device__ __forceinline__ double bcast_fenced(double src) {
+#if SVAE_FUSED_DPP
+  double out;
+  asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
+               : "=v"(out)
+               : "v"(src), "n"(K));
+  return out;
+#else
+  return bcast<K>(src);
+#endif
+}
+
+// Order every earlier producer of x[0..M) before every later DPP read of them, with >= 2 wait
+// states in between.  The empty statements emit no code; they only pin program order.
+template <int M>
+__device__ __forceinline__ void dpp_fence(double (&x)[M]) {
+#if SVAE_FUSED_DPP
+#pragma unroll
+  for (int i = 0; i < M - 1; ++i) asm volatile("" : "+v"(x[i]));
+  asm volatile("s_nop 1" : "+v"(x[M - 1]));
+#endif
+}
+__device__ __forceinline__ void dpp_fence(double& x) {
+#if SVAE_FUSED_DPP
+  asm volatile("s_nop 1" : "+v"(x));
+#endif
 }
 
 // compile-time loop: f(std::integral_constant<int, I>) for I in [B, E)

@@ -24,6 +24,7 @@ struct LdsArgs {
   int32_t* __restrict__ info;
   double* __restrict__ ws;
   long pair_seq_stride;  // doubles between consecutive sequences' pair blocks (0 = shared)
+  int rows_per_wave;     // sequences per wavefront: 4 (throughput) .. 1 (latency, small batches)
 };
 
 }  // namespace svae

@@ -3,15 +3,21 @@
 // reduction of the global statistics.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/svae_hip.h"
 #include "lds_args.hpp"
 
 extern "C" {
-#define SVAE_DECL(NN) int svae_lds_launch_n##NN(const svae::LdsArgs*, int, void*);
+#define SVAE_DECL_(NN) int svae_lds_launch_n##NN(const svae::LdsArgs*, int, void*);
+#define SVAE_DECL(NN) SVAE_DECL_(NN)
+#ifdef SVAE_ONLY_N   /* experimental single-n builds (tools/build_variant.sh) */
+SVAE_DECL(SVAE_ONLY_N)
+#else
 SVAE_DECL(1) SVAE_DECL(2) SVAE_DECL(3) SVAE_DECL(4) SVAE_DECL(5) SVAE_DECL(6) SVAE_DECL(7)
 SVAE_DECL(8) SVAE_DECL(9) SVAE_DECL(10) SVAE_DECL(11) SVAE_DECL(12) SVAE_DECL(13) SVAE_DECL(14)
 SVAE_DECL(15)
+#endif
 #undef SVAE_DECL
 }
 
@@ -47,6 +53,19 @@ __global__ __launch_bounds__(256) void lds_reduce_stats_kernel(int B, int n, con
 }  // namespace svae
 
 extern "C" {
+
+// Sequences per wavefront.  4 fills every DPP row (best throughput once the batch covers the chip);
+// override with SVAE_LDS_ROWS_PER_WAVE=1|2|4 (experiments).
+static int svae_lds_rows_per_wave(int B) {
+  (void)B;
+  static int cached = 0;
+  if (!cached) {
+    const char* e = getenv("SVAE_LDS_ROWS_PER_WAVE");
+    int v = e ? atoi(e) : 4;
+    cached = (v == 1 || v == 2 || v == 4) ? v : 4;
+  }
+  return cached;
+}
 
 int svae_hip_abi_version(void) { return SVAE_HIP_ABI_VERSION; }
 
@@ -91,11 +110,17 @@ int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched,
   a.E_node_diagxx = E_node_diagxx; a.E_node_x = E_node_x;
   a.info = info; a.ws = (double*)workspace;
   a.pair_seq_stride = pair_batched ? (long)(T - 1) * n * n : 0;
+  a.rows_per_wave = svae_lds_rows_per_wave(B);
   switch (n) {
-#define SVAE_CASE(NN) case NN: return svae_lds_launch_n##NN(&a, inhomog, stream);
+#define SVAE_CASE_(NN) case NN: return svae_lds_launch_n##NN(&a, inhomog, stream);
+#define SVAE_CASE(NN) SVAE_CASE_(NN)
+#ifdef SVAE_ONLY_N
+    SVAE_CASE(SVAE_ONLY_N)
+#else
     SVAE_CASE(1) SVAE_CASE(2) SVAE_CASE(3) SVAE_CASE(4) SVAE_CASE(5) SVAE_CASE(6) SVAE_CASE(7)
     SVAE_CASE(8) SVAE_CASE(9) SVAE_CASE(10) SVAE_CASE(11) SVAE_CASE(12) SVAE_CASE(13)
     SVAE_CASE(14) SVAE_CASE(15)
+#endif
 #undef SVAE_CASE
   }
   return -3;

@@ -46,16 +46,41 @@ namespace svae {
 template <int N>
 constexpr int ws_step_doubles() { return (2 * N + 1) * N; }
 
-// Opaque register barrier: stops LLVM from hoisting loop-invariant DPP broadcasts of the constant
-// pair-parameter tiles out of the time loop (that would need N*N extra VGPR pairs).
-__device__ __forceinline__ void opaque(double& x) { asm volatile("" : "+v"(x)); }
+// rows i0, i0+1, .. i0+IL-1 of  OUT[i] (+)= sum_k bcast_k(SRC[i]) * Bt[k]   (k = 0..KN-1), the IL
+// accumulation chains interleaved so that consecutive instructions are independent.
+template <int IL, int I0, int KN, int MS, int MB, int MO>
+__device__ __forceinline__ void rows_src_bcast(double (&out)[MO], const double (&src)[MS],
+                                               const double (&bt)[MB]) {
+  static_for<0, KN>([&](auto k) {
+    static_for<0, IL>([&](auto j) {
+      if constexpr (I0 + j < MO && I0 + j < MS) mac_bc<k>(out[I0 + j], src[I0 + j], bt[k]);
+    });
+  });
+}
+
+// rows i0.. of  OUT[i] (+)= sum_k Gt[k] * bcast_i(W[k])   (the transposed product of the backward step)
+template <int IL, int I0, int KN, int MW, int MG, int MO>
+__device__ __forceinline__ void rows_lane_bcast(double (&out)[MO], const double (&w)[MW],
+                                                const double (&gt)[MG]) {
+  static_for<0, KN>([&](auto k) {
+    static_for<0, IL>([&](auto j) {
+      if constexpr (I0 + j < MO) mac_bc<I0 + j>(out[I0 + j], w[k], gt[k]);
+    });
+  });
+}
+
+#ifndef SVAE_IL
+#define SVAE_IL 2     // independent accumulation chains interleaved per DPP product stage
+#endif
 
 template <int N, bool INHOMOG>
 __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
   static_assert(N >= 1 && N <= SVAE_LDS_MAX_N, "n+1 lanes must fit a 16-lane DPP row");
+  constexpr int IL = SVAE_IL;
   const int lane = threadIdx.x;
   const int c = lane & 15;
-  const int brow = blockIdx.x * 4 + (lane >> 4);
+  if ((lane >> 4) >= a.rows_per_wave) return;       // latency mode: fewer sequences per wave
+  const int brow = blockIdx.x * a.rows_per_wave + (lane >> 4);
   const bool valid = brow < a.B;
   const int b = valid ? brow : a.B - 1;   // surplus rows recompute the last sequence, stores masked
   const bool col = c < N;
@@ -77,7 +102,7 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
       J22c[i] = col ? -2.0 * pJ22[o + i * N + cc] : 0.0;
     });
   };
-  if (!INHOMOG) load_pair(0);
+  if (!INHOMOG) { load_pair(0); dpp_fence(J12T); }
 
   // ---- forward filter --------------------------------------------------------------------------
   double Jp[N], hp;
@@ -103,8 +128,7 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
       Jo_n = col ? -2.0 * nJ[(long)(t + 1) * N] : 0.0;
       ho_n = col ? nh[(long)(t + 1) * N] : 0.0;
     }
-    if (INHOMOG) { if (!last) load_pair(t); }
-    else static_for<0, N>([&](auto i) { opaque(J12T[i]); });
+    if (INHOMOG && !last) { load_pair(t); dpp_fence(J12T); }
 
     // P = J_pred + diag(J_node) [+ J11 unless last]   (condition, then the predict-step pivot block)
     double P[N];
@@ -113,24 +137,36 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
       P[i] = __builtin_fma(s11, J11c[i], Jp[i]);
       if (c == i) P[i] += Jo;
     });
-    const double hf = hp + ho;
+    double hf = hp + ho;
+    dpp_fence(P);
+    dpp_fence(hf);
 
-    // in-place Gauss-Jordan inverse (SPD => no pivoting); pivots are the LDL' diagonal
+    // In-place Gauss-Jordan inverse (SPD => no pivoting); pivots are the LDL' diagonal.  Row k+1 is
+    // updated first so that the next pivot's reciprocal chain overlaps the remaining row updates.
+    double p = bcast_fenced<0>(P[0]);
     static_for<0, N>([&](auto k) {
-      const double p = bcast<k>(P[k]);
       bad |= !(p > 0.0);
       const double rinv = rcp_nr(p);
       ldM *= __builtin_amdgcn_frexp_mant(p);
       ldE += __builtin_amdgcn_frexp_exp(p);
       double r = P[k] * rinv;
       r = (c == k) ? rinv : r;
+      const double nr = -r;
+      auto update = [&](auto i) {
+        // lane k: its column becomes the inverse's column, 0 - m * (1/p); other lanes: P_i - m r
+        double acc = (c == k) ? 0.0 : P[i];
+        mac_bc<k>(acc, P[i], nr);
+        P[i] = acc;
+      };
+      if constexpr (k + 1 < N) update(std::integral_constant<int, k + 1>{});
+      int cnt = 0;
       static_for<0, N>([&](auto i) {
-        if constexpr (i != k) {
-          const double m = bcast<k>(P[i]);
-          const double acc = (c == k) ? 0.0 : P[i];
-          P[i] = __builtin_fma(-m, r, acc);
+        if constexpr (i != k && i != k + 1) {
+          update(i);
+          if constexpr (k + 1 < N) { if (++cnt == 1) p = bcast_fenced<k + 1>(P[k + 1]); }
         }
       });
+      if constexpr (k + 1 < N && N == 2) p = bcast_fenced<k + 1>(P[k + 1]);
       P[k] = r;
     });
     {
@@ -138,10 +174,11 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
       ldM = __builtin_amdgcn_frexp_mant(ldM);
       ldE += e;
     }
+    dpp_fence(P);   // P[k] rows were written by plain moves/muls
 
     // c_t = P^-1 h_filt  (row layout: lane c holds c_t[c]); P^-1 symmetric
     double cv = 0.0;
-    static_for<0, N>([&](auto k) { cv = __builtin_fma(bcast<k>(hf), P[k], cv); });
+    static_for<0, N>([&](auto k) { mac_bc<k>(cv, hf, P[k]); });
     qacc = __builtin_fma(hf, cv, qacc);
 
     double* w = wsb + (long)t * ws_step_doubles<N>();
@@ -153,21 +190,16 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
     if (!last) {
       // XT_i = row i of J12' P^-1 ;  G~' rows are -XT_i
       double XT[N];
-      static_for<0, N>([&](auto i) {
-        double acc = 0.0;
-        static_for<0, N>([&](auto k) { acc = __builtin_fma(bcast<k>(J12T[i]), P[k], acc); });
-        XT[i] = acc;
-      });
+      static_for<0, N>([&](auto i) { XT[i] = 0.0; });
+      static_for<0, (N + IL - 1) / IL>([&](auto g) { rows_src_bcast<IL, g * IL, N>(XT, J12T, P); });
       if (st) static_for<0, N>([&](auto i) { w[i * N] = -XT[i]; });
-      // J_pred' = J22 - J12' P^-1 J12 ;  h_pred' = -J12' P^-1 h_filt
-      static_for<0, N>([&](auto i) {
-        double acc = J22c[i];
-        static_for<0, N>([&](auto k) { acc = __builtin_fma(-bcast<k>(XT[i]), J12c[k], acc); });
-        Jp[i] = acc;
-      });
-      double acc = 0.0;
-      static_for<0, N>([&](auto k) { acc = __builtin_fma(-bcast<k>(cv), J12c[k], acc); });
-      hp = acc;
+      // J_pred' = J22 - J12' P^-1 J12 ;  h_pred' = -J12' P^-1 h_filt   (accumulate +, negate once)
+      double Sc[N + 1], Sr[N + 1];
+      static_for<0, N>([&](auto i) { Sc[i] = 0.0; Sr[i] = XT[i]; });
+      Sc[N] = 0.0; Sr[N] = cv;
+      static_for<0, (N + 1 + IL - 1) / IL>([&](auto g) { rows_src_bcast<IL, g * IL, N>(Sc, Sr, J12c); });
+      static_for<0, N>([&](auto i) { Jp[i] = J22c[i] - Sc[i]; });
+      hp = -Sc[N];
     } else {
       if (st) static_for<0, N>([&](auto i) { w[i * N] = 0.0; });
     }
@@ -204,6 +236,7 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
   double S[N + 1];
   static_for<0, N + 1>([&](auto i) { S[i] = 0.0; });
   S[N] = (c == N) ? 1.0 : 0.0;
+  dpp_fence(S);
   double sumA[N], sumC[N], sumW[N];
   static_for<0, N>([&](auto i) { sumA[i] = 0.0; sumC[i] = 0.0; sumW[i] = 0.0; });
 
@@ -226,19 +259,13 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
 
     // W~ = S~_{t+1} G~'   (W[i][c] = E[x~_{t+1,i} x~_{t,c}])
     double W[N + 1];
-    static_for<0, N + 1>([&](auto i) {
-      double acc = 0.0;
-      static_for<0, N + 1>([&](auto k) { acc = __builtin_fma(bcast<k>(S[i]), GT[k], acc); });
-      W[i] = acc;
-    });
+    static_for<0, N + 1>([&](auto i) { W[i] = 0.0; });
+    static_for<0, (N + 1 + IL - 1) / IL>([&](auto g) { rows_src_bcast<IL, g * IL, N + 1>(W, S, GT); });
     // S~_t = G~ W~ + diag(P^-1, 0), computed through its transpose (S~ symmetric):
     //   S~[c][i] = sum_k G~[c][k] W~[k][i] = sum_k GT[k](lane c) * W[k](lane i)
-    static_for<0, N + 1>([&](auto i) {
-      double acc = 0.0;
-      if constexpr (i < N) acc = Pi[i];
-      static_for<0, N + 1>([&](auto k) { acc = __builtin_fma(GT[k], bcast<i>(W[k]), acc); });
-      S[i] = acc;
-    });
+    static_for<0, N>([&](auto i) { S[i] = Pi[i]; });
+    S[N] = 0.0;
+    static_for<0, (N + 1 + IL - 1) / IL>([&](auto g) { rows_lane_bcast<IL, g * IL, N + 1>(S, W, GT); });
 
     if (INHOMOG) {
       // per-step pair blocks: [E x_t x_t' | E x_t x_{t+1}' | E x_{t+1} x_{t+1}'] for pair index t;
@@ -247,7 +274,6 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
         if (t < T - 1) {
           double* o = oPair + (long)t * 3 * N * N;
           static_for<0, N>([&](auto i) { o[i * N] = S[i]; });
-          // E[x_t x_{t+1}'][a][bb] = W[bb][a]: lane c = a... stored transposed
           double* o2 = a.E_pair + (((long)b * (T - 1) + t) * 3 + 1) * N * N + (long)cc * N;
           static_for<0, N>([&](auto i) { o2[i] = W[i]; });
         }
@@ -290,10 +316,9 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
   }
 }
 
-
 template <int N>
 static int launch_estep(const LdsArgs& a, bool inhomog, hipStream_t stream) {
-  dim3 grid((a.B + 3) / 4), block(64);
+  dim3 grid((a.B + a.rows_per_wave - 1) / a.rows_per_wave), block(64);
   if (inhomog)
     hipLaunchKernelGGL((lds_estep_kernel<N, true>), grid, block, 0, stream, a);
   else
