@@ -43,16 +43,26 @@ __device__ __forceinline__ double bcast(double x) {
   return __svae_update_dpp_f64(0.0, x, DPP_ROW_NEWBCAST0 + K, 0xf, 0xf, true);
 }
 
-// acc + bcast_K(src) * b   in one DP-ALU DPP instruction.
-template <int K>
+// acc (+/-)= bcast_K(src) * b   in one DP-ALU DPP instruction.  FENCED: the statement carries its
+// own two wait states (src may have been written by the immediately preceding instruction).
+template <int K, bool NEG = false, bool FENCED = false>
 __device__ __forceinline__ void mac_bc(double& acc, double src, double b) {
   static_assert(K >= 0 && K < 16, "row_newbcast lane out of range");
 #if SVAE_FUSED_DPP
-  asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
-               : "+v"(acc)
-               : "v"(src), "v"(b), "n"(K));
+  if constexpr (NEG && FENCED)
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc) : "v"(src), "v"(b), "n"(K));
+  else if constexpr (NEG)
+    asm volatile("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc) : "v"(src), "v"(b), "n"(K));
+  else if constexpr (FENCED)
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc) : "v"(src), "v"(b), "n"(K));
+  else
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc) : "v"(src), "v"(b), "n"(K));
 #else
-  acc = __builtin_fma(bcast<K>(src), b, acc);
+  acc = __builtin_fma(bcast<K>(src), NEG ? -b : b, acc);
 #endif
 }
 

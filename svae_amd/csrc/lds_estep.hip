@@ -94,7 +94,7 @@ int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched,
   if (!node_h) return -14;
   if (!lognorm) return -16;
   if (!E_init) return -17;
-  if (T > 1 && !E_pair) return -18;
+  if (!E_pair) return -18;
   if (!E_node_diagxx) return -19;
   if (!E_node_x) return -20;
   if (!info) return -21;

@@ -70,7 +70,7 @@ __device__ __forceinline__ void rows_lane_bcast(double (&out)[MO], const double 
 }
 
 #ifndef SVAE_IL
-#define SVAE_IL 2     // independent accumulation chains interleaved per DPP product stage
+#define SVAE_IL 4     // independent accumulation chains interleaved per DPP product stage
 #endif
 
 template <int N, bool INHOMOG>
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
   constexpr int IL = SVAE_IL;
   const int lane = threadIdx.x;
   const int c = lane & 15;
-  if ((lane >> 4) >= a.rows_per_wave) return;       // latency mode: fewer sequences per wave
+  if ((lane >> 4) >= a.rows_per_wave) return;       // experiments: fewer sequences per wave
   const int brow = blockIdx.x * a.rows_per_wave + (lane >> 4);
   const bool valid = brow < a.B;
   const int b = valid ? brow : a.B - 1;   // surplus rows recompute the last sequence, stores masked
@@ -88,25 +88,39 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
   const int cc = col ? c : 0;
   const int T = a.T;
 
+  // identity tile: E[i][c] = (c == i).  Per-lane selects are done arithmetically with it (x*E, exact)
+  // instead of v_cndmask: on gfx950 v_cndmask throughput is shared by the whole CU (measured:
+  // tools/ubench/valu_rates.hip), which throttles the kernel as soon as >1 wave runs per CU.
+  double E[N];
+  static_for<0, N>([&](auto i) { E[i] = (c == i) ? 1.0 : 0.0; });
+
   // ---- pair parameters (info form: J = -2 natJ, J12 = -natJ12), column c per lane -------------
-  double J11c[N], J12c[N], J12T[N], J22c[N];
+  //   NJ12T[i][c] = -J12[c][i]   (so that G~' rows = -J12' P^-1 come out of the product directly)
+  //   J12c[k][c]  =  J12[k][c]
+  //   Cc[i][c]    =  J22[i][c] + J11[i][c]   (next step's pivot block without the node diagonal)
+  double NJ12T[N], J12c[N], Cc[N], J22c[N];
   const double* pJ11 = a.J11 + (long)b * a.pair_seq_stride;
   const double* pJ12 = a.J12 + (long)b * a.pair_seq_stride;
   const double* pJ22 = a.J22 + (long)b * a.pair_seq_stride;
-  auto load_pair = [&](int t) {
+  auto load_pair = [&](int t, bool with_next_J11) {   // pair t (and J11 of pair t+1)
     const long o = INHOMOG ? (long)t * N * N : 0;
+    const long o1 = INHOMOG ? (long)(t + 1) * N * N : 0;
     static_for<0, N>([&](auto i) {
-      J11c[i] = col ? -2.0 * pJ11[o + i * N + cc] : 0.0;
       J12c[i] = col ? -pJ12[o + i * N + cc] : 0.0;
-      J12T[i] = col ? -pJ12[o + cc * N + i] : 0.0;
+      NJ12T[i] = col ? pJ12[o + cc * N + i] : 0.0;
       J22c[i] = col ? -2.0 * pJ22[o + i * N + cc] : 0.0;
+      Cc[i] = J22c[i] + ((col && with_next_J11) ? -2.0 * pJ11[o1 + i * N + cc] : 0.0);
     });
   };
-  if (!INHOMOG) { load_pair(0); dpp_fence(J12T); }
+  if (!INHOMOG && T > 1) { load_pair(0, true); dpp_fence(NJ12T); }
 
   // ---- forward filter --------------------------------------------------------------------------
-  double Jp[N], hp;
-  static_for<0, N>([&](auto i) { Jp[i] = col ? -2.0 * a.init_J[i * N + cc] : 0.0; });
+  // A = pivot block of the current step without the node diagonal: J_pred + J11 (J_pred at t = T-1)
+  double A[N], hp;
+  static_for<0, N>([&](auto i) {
+    A[i] = col ? -2.0 * a.init_J[i * N + cc] : 0.0;
+    if (T > 1) A[i] += col ? -2.0 * pJ11[i * N + cc] : 0.0;
+  });
   hp = col ? a.init_h[cc] : 0.0;
 
   const double* nJ = a.node_J + ((long)b * T) * N + cc;
@@ -116,7 +130,7 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
   double qacc = 0.0;       // per-lane partial of sum_t h_filt' P^-1 h_filt
   double ldM = 1.0;        // log|P_t| accumulated as mantissa product ...
   int ldE = 0;             // ... and exponent sum (one log at the very end)
-  bool bad = false;
+  double pmin = 1.0;       // smallest pivot seen (<= 0 => not positive definite)
 
   double Jo_n = col ? -2.0 * nJ[0] : 0.0;
   double ho_n = col ? nh[0] : 0.0;
@@ -128,15 +142,11 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
       Jo_n = col ? -2.0 * nJ[(long)(t + 1) * N] : 0.0;
       ho_n = col ? nh[(long)(t + 1) * N] : 0.0;
     }
-    if (INHOMOG && !last) { load_pair(t); dpp_fence(J12T); }
+    if (INHOMOG && !last) { load_pair(t, t + 1 < T - 1); dpp_fence(NJ12T); }
 
-    // P = J_pred + diag(J_node) [+ J11 unless last]   (condition, then the predict-step pivot block)
+    // condition on the node potential: P = A + diag(J_node), h_filt = h_pred + h_node
     double P[N];
-    const double s11 = last ? 0.0 : 1.0;
-    static_for<0, N>([&](auto i) {
-      P[i] = __builtin_fma(s11, J11c[i], Jp[i]);
-      if (c == i) P[i] += Jo;
-    });
+    static_for<0, N>([&](auto i) { P[i] = __builtin_fma(Jo, E[i], A[i]); });
     double hf = hp + ho;
     dpp_fence(P);
     dpp_fence(hf);
@@ -144,41 +154,47 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
     // In-place Gauss-Jordan inverse (SPD => no pivoting); pivots are the LDL' diagonal.  Row k+1 is
     // updated first so that the next pivot's reciprocal chain overlaps the remaining row updates.
     double p = bcast_fenced<0>(P[0]);
+    double pprod = 1.0;
     static_for<0, N>([&](auto k) {
-      bad |= !(p > 0.0);
+      pmin = fmin(pmin, p);
+      pprod *= p;
       const double rinv = rcp_nr(p);
-      ldM *= __builtin_amdgcn_frexp_mant(p);
-      ldE += __builtin_amdgcn_frexp_exp(p);
-      double r = P[k] * rinv;
-      r = (c == k) ? rinv : r;
-      const double nr = -r;
-      auto update = [&](auto i) {
-        // lane k: its column becomes the inverse's column, 0 - m * (1/p); other lanes: P_i - m r
-        double acc = (c == k) ? 0.0 : P[i];
-        mac_bc<k>(acc, P[i], nr);
+      // scaled pivot row; lane k gets 1/p (the inverse's diagonal entry)
+      const double r = __builtin_fma(E[k], 1.0 - p, P[k]) * rinv;
+      auto update = [&](auto i, auto fenced) {
+        // lane k: its column becomes the inverse's column, 0 - m/p; other lanes: P_i - m r
+        double acc = __builtin_fma(-P[i], E[k], P[i]);
+        mac_bc<k, true, decltype(fenced)::value>(acc, P[i], r);
         P[i] = acc;
       };
-      if constexpr (k + 1 < N) update(std::integral_constant<int, k + 1>{});
-      int cnt = 0;
+      if constexpr (k + 1 < N) update(std::integral_constant<int, k + 1>{}, std::true_type{});
       static_for<0, N>([&](auto i) {
         if constexpr (i != k && i != k + 1) {
-          update(i);
-          if constexpr (k + 1 < N) { if (++cnt == 1) p = bcast_fenced<k + 1>(P[k + 1]); }
+          if constexpr (k + 1 >= N && i == 0) update(i, std::true_type{});
+          else update(i, std::false_type{});
         }
       });
-      if constexpr (k + 1 < N && N == 2) p = bcast_fenced<k + 1>(P[k + 1]);
+      if constexpr (k + 1 < N) p = bcast_fenced<k + 1>(P[k + 1]);
       P[k] = r;
+      if constexpr (k == N / 2 || k == N - 1) {      // keep the running product in range
+        ldE += __builtin_amdgcn_frexp_exp(pprod);
+        ldM *= __builtin_amdgcn_frexp_mant(pprod);
+        pprod = 1.0;
+      }
     });
     {
       const int e = __builtin_amdgcn_frexp_exp(ldM);
       ldM = __builtin_amdgcn_frexp_mant(ldM);
       ldE += e;
     }
-    dpp_fence(P);   // P[k] rows were written by plain moves/muls
+    dpp_fence(P);   // rows P[k] were last written by plain multiplies
 
-    // c_t = P^-1 h_filt  (row layout: lane c holds c_t[c]); P^-1 symmetric
-    double cv = 0.0;
-    static_for<0, N>([&](auto k) { mac_bc<k>(cv, hf, P[k]); });
+    // c_t = P^-1 h_filt  (row layout: lane c holds c_t[c]); P^-1 symmetric.  Two partial sums.
+    double cv = 0.0, cv1 = 0.0;
+    static_for<0, N>([&](auto k) {
+      if constexpr (k % 2 == 0) mac_bc<k>(cv, hf, P[k]); else mac_bc<k>(cv1, hf, P[k]);
+    });
+    cv += cv1;
     qacc = __builtin_fma(hf, cv, qacc);
 
     double* w = wsb + (long)t * ws_step_doubles<N>();
@@ -188,18 +204,26 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
     }
 
     if (!last) {
-      // XT_i = row i of J12' P^-1 ;  G~' rows are -XT_i
-      double XT[N];
-      static_for<0, N>([&](auto i) { XT[i] = 0.0; });
-      static_for<0, (N + IL - 1) / IL>([&](auto g) { rows_src_bcast<IL, g * IL, N>(XT, J12T, P); });
-      if (st) static_for<0, N>([&](auto i) { w[i * N] = -XT[i]; });
-      // J_pred' = J22 - J12' P^-1 J12 ;  h_pred' = -J12' P^-1 h_filt   (accumulate +, negate once)
-      double Sc[N + 1], Sr[N + 1];
-      static_for<0, N>([&](auto i) { Sc[i] = 0.0; Sr[i] = XT[i]; });
-      Sc[N] = 0.0; Sr[N] = cv;
-      static_for<0, (N + 1 + IL - 1) / IL>([&](auto g) { rows_src_bcast<IL, g * IL, N>(Sc, Sr, J12c); });
-      static_for<0, N>([&](auto i) { Jp[i] = J22c[i] - Sc[i]; });
-      hp = -Sc[N];
+      // G~' rows:  XTn_i = -(row i of J12' P^-1)
+      double XTn[N + 1];
+      static_for<0, N>([&](auto i) { XTn[i] = 0.0; });
+      static_for<0, (N + IL - 1) / IL>([&](auto g) { rows_src_bcast<IL, g * IL, N>(XTn, NJ12T, P); });
+      if (st) static_for<0, N>([&](auto i) { w[i * N] = XTn[i]; });
+      // next pivot block  A' = (J22 + J11) - J12' P^-1 J12   and   -h_pred' = c_t' J12   (row N)
+      double An[N + 1];
+      const bool next_last = (t + 1 == T - 1);
+      if (!INHOMOG && next_last) {
+        asm volatile("; next step is the last: its pivot block has no J11 term");   // keep this a branch
+        static_for<0, N>([&](auto i) { An[i] = J22c[i]; });
+      } else {
+        static_for<0, N>([&](auto i) { An[i] = Cc[i]; });
+      }
+      An[N] = 0.0;
+      XTn[N] = cv;
+      dpp_fence(XTn[N]);
+      static_for<0, (N + 1 + IL - 1) / IL>([&](auto g) { rows_src_bcast<IL, g * IL, N>(An, XTn, J12c); });
+      static_for<0, N>([&](auto i) { A[i] = An[i]; });
+      hp = -An[N];
     } else {
       if (st) static_for<0, N>([&](auto i) { w[i * N] = 0.0; });
     }
@@ -217,9 +241,10 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
     }
     double total = row_sum16(__builtin_fma(0.5, qacc, z));
     total += a.init_logZ[0];
-    if (!INHOMOG) total += (double)(T - 1) * a.logZ_pair[0];
+    if (!INHOMOG && T > 1) total += (double)(T - 1) * a.logZ_pair[0];
     total -= 0.5 * (::log(ldM) + (double)ldE * 0.6931471805599453094);
     if (valid && c == 0) a.lognorm[b] = total;
+    const bool bad = !(pmin > 0.0) || !(total == total);
     if (bad && valid && c == 0) {   // rare path: keep the smallest failing index (+1); 0 = ok
       int old = *(volatile int32_t*)a.info;
       while (old == 0 || old > b + 1) {
@@ -237,24 +262,22 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
   static_for<0, N + 1>([&](auto i) { S[i] = 0.0; });
   S[N] = (c == N) ? 1.0 : 0.0;
   dpp_fence(S);
-  double sumA[N], sumC[N], sumW[N];
-  static_for<0, N>([&](auto i) { sumA[i] = 0.0; sumC[i] = 0.0; sumW[i] = 0.0; });
+  double sumA[N], sumW[N], Slast[N];
+  static_for<0, N>([&](auto i) { sumA[i] = 0.0; sumW[i] = 0.0; Slast[i] = 0.0; });
 
   double* oEx = a.E_node_x + ((long)b * T) * N + cc;
   double* oExx = a.E_node_diagxx + ((long)b * T) * N + cc;
   double* oPair = INHOMOG ? a.E_pair + ((long)b * (T - 1)) * 3 * N * N + cc : nullptr;
 
-  double GT[N + 1], Pi[N];
   auto load_step = [&](int t, double (&g)[N + 1], double (&pi)[N]) {
     const double* w = wsb + (long)t * ws_step_doubles<N>();
     static_for<0, N>([&](auto k) { g[k] = col ? w[k * N] : 0.0; });
     g[N] = col ? w[N * N] : ((c == N) ? 1.0 : 0.0);
     static_for<0, N>([&](auto i) { pi[i] = col ? w[(N + 1 + i) * N] : 0.0; });
   };
-  load_step(T - 1, GT, Pi);
 
-  for (int t = T - 1; t >= 0; --t) {
-    double GTn[N + 1], Pin[N];
+  // one backward step: consumes (GT, Pi) of step t, prefetches step t-1 into (GTn, Pin)
+  auto step = [&](int t, double (&GT)[N + 1], double (&Pi)[N], double (&GTn)[N + 1], double (&Pin)[N]) {
     if (t > 0) load_step(t - 1, GTn, Pin);
 
     // W~ = S~_{t+1} G~'   (W[i][c] = E[x~_{t+1,i} x~_{t,c}])
@@ -284,20 +307,29 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
       }
     } else {
       if (t < T - 1) static_for<0, N>([&](auto i) { sumA[i] += S[i]; sumW[i] += W[i]; });
-      if (t > 0) static_for<0, N>([&](auto i) { sumC[i] += S[i]; });
+      else static_for<0, N>([&](auto i) { Slast[i] = S[i]; });
     }
 
-    // node statistics: E[x_t] = row N of S~, diag E[x_t x_t']
-    double dg = 0.0;
-    static_for<0, N>([&](auto i) { dg = (c == i) ? S[i] : dg; });
+    // node statistics: E[x_t] = row N of S~, diag E[x_t x_t'] = sum_i E[i] * S[i]
+    double dg = 0.0, dg1 = 0.0;
+    static_for<0, N>([&](auto i) {
+      if constexpr (i % 2 == 0) dg = __builtin_fma(E[i], S[i], dg); else dg1 = __builtin_fma(E[i], S[i], dg1);
+    });
     if (st) {
       oEx[(long)t * N] = S[N];
-      oExx[(long)t * N] = dg;
+      oExx[(long)t * N] = dg + dg1;
     }
-    if (t > 0) {
-      static_for<0, N + 1>([&](auto k) { GT[k] = GTn[k]; });
-      static_for<0, N>([&](auto i) { Pi[i] = Pin[i]; });
+  };
+
+  {
+    double GTa[N + 1], Pia[N], GTb[N + 1], Pib[N];
+    load_step(T - 1, GTa, Pia);
+    int t = T - 1;
+    for (; t >= 1; t -= 2) {          // two steps per trip: the prefetch buffers ping-pong
+      step(t, GTa, Pia, GTb, Pib);
+      step(t - 1, GTb, Pib, GTa, Pia);
     }
+    if (t == 0) step(0, GTa, Pia, GTb, Pib);
   }
 
   // ---- global statistics -----------------------------------------------------------------------
@@ -308,9 +340,9 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
     if (!INHOMOG) {
       double* ep = a.E_pair + (long)b * 3 * N * N;
       static_for<0, N>([&](auto i) {
-        ep[i * N + cc] = sumA[i];                 // sum_t E[x_t x_t']
-        ep[N * N + cc * N + i] = sumW[i];         // sum_t E[x_t x_{t+1}'] = (sum_t W_t)'
-        ep[2 * N * N + i * N + cc] = sumC[i];     // sum_t E[x_{t+1} x_{t+1}']
+        ep[i * N + cc] = sumA[i];                               // sum_{t<T-1} E[x_t x_t']
+        ep[N * N + cc * N + i] = sumW[i];                       // sum_t E[x_t x_{t+1}'] = (sum_t W_t)'
+        ep[2 * N * N + i * N + cc] = (sumA[i] - S[i]) + Slast[i];   // sum_{t>=1} E[x_t x_t']
       });
     }
   }

@@ -1,0 +1,40 @@
+"""CPU tests of the native build: the kernels cross-compile for gfx950 without a GPU, and the
+generated ISA is free of the DPP hazards hipcc cannot pad around the inline-asm multiply-accumulates
+(svae_amd/csrc/dpp.hpp, tools/audit_dpp_hazards.py)."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import audit_dpp_hazards  # noqa: E402
+
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def test_audit_tool_detects_a_planted_hazard(tmp_path):
+    s = tmp_path / "x.s"
+    s.write_text("f:\n\ts_nop 4\n\tv_fma_f64 v[2:3], v[4:5], v[6:7], v[8:9]\n"
+                 "\tv_fmac_f64_dpp v[10:11], v[2:3], v[6:7] row_newbcast:1 row_mask:0xf bank_mask:0xf\n")
+    n, probs = audit_dpp_hazards.audit(str(s))
+    assert n == 1 and len(probs) == 1 and "H1" in probs[0]
+    s.write_text("f:\n\ts_nop 4\n\tv_fma_f64 v[2:3], v[4:5], v[6:7], v[8:9]\n\ts_nop 1\n"
+                 "\tv_fmac_f64_dpp v[10:11], v[2:3], v[6:7] row_newbcast:1 row_mask:0xf bank_mask:0xf\n")
+    assert audit_dpp_hazards.audit(str(s))[1] == []
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+@pytest.mark.parametrize("n", [2, 10, 15])
+def test_estep_kernel_isa_has_no_dpp_hazards(n, tmp_path):
+    out = tmp_path / ("n%d.s" % n)
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-DSVAE_N=%d" % n,
+                    "--cuda-device-only", "-S", os.path.join(ROOT, "svae_amd/csrc/lds_estep_n.hip"),
+                    "-o", str(out)], check=True, capture_output=True)
+    ndpp, probs = audit_dpp_hazards.audit(str(out))
+    assert ndpp > 50 * n, "fused v_fmac_f64_dpp path not generated"
+    assert probs == [], "\n".join(probs[:10])
+    txt = out.read_text()
+    assert "scratch_" not in txt and "buffer_store_dword" not in txt      # no register spills
