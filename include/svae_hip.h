@@ -31,8 +31,9 @@ extern "C" {
 /* Library/ABI version (host only, no GPU needed). */
 int svae_hip_abi_version(void);
 
-/* Bytes of scratch `svae_lds_estep_f64` / `svae_lds_sample_f64` need for (B, T, n).
- * Holds the per-step backward kernels (G_t, c_t, P_t^-1) written by the forward filter. */
+/* Bytes of scratch `svae_lds_estep_f64` / `svae_lds_sample_f64` need for (B, T, n): the per-step
+ * backward kernels (G_t, c_t, P_t^-1: (2n+1)n doubles) written by the forward filter, followed by
+ * the factor region (unit LDL' factor + pivots of P_t: n*n+n doubles) the sampler reads. */
 size_t svae_lds_workspace_bytes(int B, int T, int n);
 
 /* Batched LDS E-step = filter + RTS smoother + expected sufficient statistics + log-normalizer.
@@ -50,6 +51,8 @@ size_t svae_lds_workspace_bytes(int B, int T, int n);
  *       pair_batched != 0 (inhomog only): J11/J12/J22 are (B,T-1,n,n), logZ_pair (B,T-1)
  *         (the SLDS case, slds_svae.py:92-103, where pair params depend on each sequence's
  *          discrete-state marginals)
+ *       keep_factor != 0: also write the factor region of the workspace so that
+ *         svae_lds_sample_f64 can follow (costs ~2% of the E-step)
  *       node_J (B,T,n) diagonal of -1/2 precision, node_h (B,T,n), node_logZ (B,T) or NULL (=0)
  *  out: lognorm (B)
  *       E_init  (B, n*n + n)      = [E[x0 x0'] (n,n) | E[x0] (n)]   (the two trailing 1's of the
@@ -60,7 +63,7 @@ size_t svae_lds_workspace_bytes(int B, int T, int n);
  *       E_node_diagxx (B,T,n) = diag E[x_t x_t'],   E_node_x (B,T,n) = E[x_t]
  *       info (1) int32, must be zeroed by the caller (or by a previous successful call)
  */
-int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched,
+int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int keep_factor,
                        const double* init_J, const double* init_h, const double* init_logZ,
                        const double* J11, const double* J12, const double* J22,
                        const double* logZ_pair,
@@ -77,7 +80,7 @@ int svae_lds_reduce_stats_f64(int B, int n, const double* E_init, const double* 
                               const double* lognorm, double* out, void* stream);
 
 /* Backward sampling given the forward messages held in `workspace` by the LAST call of
- * svae_lds_estep_f64 with the same (B,T,n) [natural_sample_backward,
+ * svae_lds_estep_f64 with the same (B,T,n) and keep_factor != 0 [natural_sample_backward,
  * /root/reference/svae/lds/cython_lds_inference.pyx:310-355].
  *   eps     (B,T,S,n) standard-normal draws (the reference draws them inside, :333; passing them
  *           in makes the op deterministic and parity-testable)

@@ -62,3 +62,21 @@ def hmm_logZ_grad(g, aux):
     """cython_hmm_inference.pyx:126-166; at g=1 this is the HMM E-step (hmm_inference.py:65)."""
     m = _load("cython_hmm_inference")
     return m.hmm_logZ_grad(g, aux)
+
+
+def sample_backward(natparam, node_params, num_samples, seed):
+    """cython_natural_lds_sample (lds_inference.py:260-264): filter + natural_sample_backward
+    (cython_lds_inference.pyx:310-355).  The compiled sampler draws `flipud(randn(T,S,N))` from the
+    global NumPy RNG (:333); we seed it and return, next to the samples (T,S,N), the noise it used,
+    re-indexed so that eps[t] is the draw applied at time t."""
+    import numpy as np
+    m = _load("cython_lds_inference")
+    init_params, pair_params = natparam
+    init_params = (init_params[0], init_params[1], sum(init_params[2:]))
+    messages, _, _ = filter_forward(init_params, pair_params, node_params)
+    T, N = np.asarray(node_params[1]).shape
+    np.random.seed(seed)
+    samples, _ = m.natural_sample_backward(messages, pair_params, num_samples)
+    np.random.seed(seed)
+    eps = np.random.randn(T, num_samples, N)[::-1].copy()
+    return np.asarray(samples), eps

@@ -23,8 +23,17 @@ struct LdsArgs {
   double* __restrict__ E_node_x;
   int32_t* __restrict__ info;
   double* __restrict__ ws;
+  double* __restrict__ ws2;   // factor region for the sampler (nullptr: not kept)
   long pair_seq_stride;  // doubles between consecutive sequences' pair blocks (0 = shared)
   int rows_per_wave;     // sequences per wavefront: 4 (throughput) .. 1 (latency, small batches)
+};
+
+struct SampleArgs {
+  int B, T, S;
+  const double* __restrict__ eps;     // (B, T, S, n)
+  double* __restrict__ samples;       // (B, T, S, n)
+  const double* __restrict__ ws;      // main region (G~' rows, c, P^-1)
+  const double* __restrict__ ws2;     // factor region
 };
 
 }  // namespace svae

@@ -9,7 +9,8 @@
 #include "lds_args.hpp"
 
 extern "C" {
-#define SVAE_DECL_(NN) int svae_lds_launch_n##NN(const svae::LdsArgs*, int, void*);
+#define SVAE_DECL_(NN) int svae_lds_launch_n##NN(const svae::LdsArgs*, int, void*); \
+  int svae_lds_sample_n##NN(const svae::SampleArgs*, void*);
 #define SVAE_DECL(NN) SVAE_DECL_(NN)
 #ifdef SVAE_ONLY_N   /* experimental single-n builds (tools/build_variant.sh) */
 SVAE_DECL(SVAE_ONLY_N)
@@ -69,12 +70,15 @@ static int svae_lds_rows_per_wave(int B) {
 
 int svae_hip_abi_version(void) { return SVAE_HIP_ABI_VERSION; }
 
+static size_t main_ws_doubles(int B, int T, int n) { return (size_t)B * T * ((2 * n + 1) * n); }
+static size_t factor_ws_doubles(int B, int T, int n) { return (size_t)B * T * (n * n + n); }
+
 size_t svae_lds_workspace_bytes(int B, int T, int n) {
   if (B <= 0 || T <= 0 || n <= 0 || n > SVAE_LDS_MAX_N) return 0;
-  return (size_t)B * (size_t)T * (size_t)((2 * n + 1) * n) * sizeof(double);
+  return (main_ws_doubles(B, T, n) + factor_ws_doubles(B, T, n)) * sizeof(double);
 }
 
-int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched,
+int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int keep_factor,
                        const double* init_J, const double* init_h, const double* init_logZ,
                        const double* J11, const double* J12, const double* J22,
                        const double* logZ_pair,
@@ -109,6 +113,7 @@ int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched,
   a.lognorm = lognorm; a.E_init = E_init; a.E_pair = E_pair;
   a.E_node_diagxx = E_node_diagxx; a.E_node_x = E_node_x;
   a.info = info; a.ws = (double*)workspace;
+  a.ws2 = keep_factor ? (double*)workspace + main_ws_doubles(B, T, n) : nullptr;
   a.pair_seq_stride = pair_batched ? (long)(T - 1) * n * n : 0;
   a.rows_per_wave = svae_lds_rows_per_wave(B);
   switch (n) {
@@ -122,6 +127,7 @@ int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched,
     SVAE_CASE(14) SVAE_CASE(15)
 #endif
 #undef SVAE_CASE
+#undef SVAE_CASE_
   }
   return -3;
 }
@@ -144,7 +150,30 @@ int svae_lds_reduce_stats_f64(int B, int n, const double* E_init, const double* 
 
 extern "C" int svae_lds_sample_f64(int B, int T, int n, int S, const double* eps, double* samples,
                                    const void* workspace, size_t ws_bytes, void* stream) {
-  (void)B; (void)T; (void)n; (void)S; (void)eps; (void)samples; (void)workspace; (void)ws_bytes;
-  (void)stream;
-  return -100;  // not implemented yet ("next" row 1)
+  if (B < 0) return -1;
+  if (T < 1) return -2;
+  if (n < 1 || n > SVAE_LDS_MAX_N) return -3;
+  if (S < 1) return -4;
+  if (!eps) return -5;
+  if (!samples) return -6;
+  if (!workspace || ws_bytes < svae_lds_workspace_bytes(B, T, n)) return -7;
+  if (B == 0) return 0;
+  svae::SampleArgs a;
+  a.B = B; a.T = T; a.S = S; a.eps = eps; a.samples = samples;
+  a.ws = (const double*)workspace;
+  a.ws2 = (const double*)workspace + main_ws_doubles(B, T, n);
+  switch (n) {
+#define SVAE_CASE_(NN) case NN: return svae_lds_sample_n##NN(&a, stream);
+#define SVAE_CASE(NN) SVAE_CASE_(NN)
+#ifdef SVAE_ONLY_N
+    SVAE_CASE(SVAE_ONLY_N)
+#else
+    SVAE_CASE(1) SVAE_CASE(2) SVAE_CASE(3) SVAE_CASE(4) SVAE_CASE(5) SVAE_CASE(6) SVAE_CASE(7)
+    SVAE_CASE(8) SVAE_CASE(9) SVAE_CASE(10) SVAE_CASE(11) SVAE_CASE(12) SVAE_CASE(13)
+    SVAE_CASE(14) SVAE_CASE(15)
+#endif
+#undef SVAE_CASE
+#undef SVAE_CASE_
+  }
+  return -3;
 }

@@ -73,7 +73,7 @@ __device__ __forceinline__ void rows_lane_bcast(double (&out)[MO], const double 
 #define SVAE_IL 4     // independent accumulation chains interleaved per DPP product stage
 #endif
 
-template <int N, bool INHOMOG>
+template <int N, bool INHOMOG, bool CHOL>
 __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
   static_assert(N >= 1 && N <= SVAE_LDS_MAX_N, "n+1 lanes must fit a 16-lane DPP row");
   constexpr int IL = SVAE_IL;
@@ -126,6 +126,9 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
   const double* nJ = a.node_J + ((long)b * T) * N + cc;
   const double* nh = a.node_h + ((long)b * T) * N + cc;
   double* wsb = a.ws + ((long)b * T) * ws_step_doubles<N>() + cc;
+  // CHOL: also keep the unit-upper factor rows (the scaled pivot rows) and the pivots of P_t for the
+  // backward sampler (svae_lds_sample_f64): N*N + N doubles per step in the second workspace region.
+  double* ws2b = CHOL ? a.ws2 + ((long)b * T) * (N * N + N) + cc : nullptr;
 
   double qacc = 0.0;       // per-lane partial of sum_t h_filt' P^-1 h_filt
   double ldM = 1.0;        // log|P_t| accumulated as mantissa product ...
@@ -155,12 +158,18 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
     // updated first so that the next pivot's reciprocal chain overlaps the remaining row updates.
     double p = bcast_fenced<0>(P[0]);
     double pprod = 1.0;
+    double pv = 0.0;                                   // CHOL: lane k <- pivot k
+    double* w2 = CHOL ? ws2b + (long)t * (N * N + N) : nullptr;
     static_for<0, N>([&](auto k) {
       pmin = fmin(pmin, p);
       pprod *= p;
       const double rinv = rcp_nr(p);
       // scaled pivot row; lane k gets 1/p (the inverse's diagonal entry)
       const double r = __builtin_fma(E[k], 1.0 - p, P[k]) * rinv;
+      if constexpr (CHOL) {
+        pv = __builtin_fma(E[k], p, pv);
+        if (st) w2[k * N] = r;       // lanes j > k hold L_unit[j][k] (P = L D L')
+      }
       auto update = [&](auto i, auto fenced) {
         // lane k: its column becomes the inverse's column, 0 - m/p; other lanes: P_i - m r
         double acc = __builtin_fma(-P[i], E[k], P[i]);
@@ -187,6 +196,7 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
       ldM = __builtin_amdgcn_frexp_mant(ldM);
       ldE += e;
     }
+    if constexpr (CHOL) { if (st) w2[N * N] = pv; }
     dpp_fence(P);   // rows P[k] were last written by plain multiplies
 
     // c_t = P^-1 h_filt  (row layout: lane c holds c_t[c]); P^-1 symmetric.  Two partial sums.
@@ -351,10 +361,91 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
 template <int N>
 static int launch_estep(const LdsArgs& a, bool inhomog, hipStream_t stream) {
   dim3 grid((a.B + a.rows_per_wave - 1) / a.rows_per_wave), block(64);
-  if (inhomog)
-    hipLaunchKernelGGL((lds_estep_kernel<N, true>), grid, block, 0, stream, a);
+  const bool chol = a.ws2 != nullptr;
+  if (inhomog && chol)
+    hipLaunchKernelGGL((lds_estep_kernel<N, true, true>), grid, block, 0, stream, a);
+  else if (inhomog)
+    hipLaunchKernelGGL((lds_estep_kernel<N, true, false>), grid, block, 0, stream, a);
+  else if (chol)
+    hipLaunchKernelGGL((lds_estep_kernel<N, false, true>), grid, block, 0, stream, a);
   else
-    hipLaunchKernelGGL((lds_estep_kernel<N, false>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((lds_estep_kernel<N, false, false>), grid, block, 0, stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+// ---- backward sampler ---------------------------------------------------------------------------
+// natural_sample_backward (svae/lds/cython_lds_inference.pyx:310-355; _natural_sample
+// cython_gaussian_grads.pxd:431-454, _natural_condition_on :489-508):
+//   x_{T-1} ~ N(J_f^-1 h_f, J_f^-1),   x_t | x_{t+1} ~ N(P_t^-1 (h_f,t - J12 x_{t+1}), P_t^-1),
+//   noise = chol(P_t)^-T eps_t   (the reference's dtrtrs 'L','T'), so that equal eps give equal samples.
+// From the forward pass: mean = c_t + G_t x_{t+1} (G~' rows in the main workspace) and P_t = L D L'
+// (unit factor rows + pivots in the second region): noise = L^-T D^-1/2 eps by back substitution.
+// Layout: one DPP row per sequence as in the E-step, but lanes are SAMPLES (16 per pass) and the
+// vector index lives in the register number: every coefficient is then a row_newbcast operand, so
+// one v_fmac_f64_dpp advances 16 samples of 4 sequences.
+
+template <int N>
+__global__ __launch_bounds__(64) void lds_sample_kernel(const SampleArgs a) {
+  const int lane = threadIdx.x;
+  const int c = lane & 15;
+  const int brow = blockIdx.x * 4 + (lane >> 4);
+  const bool valid = brow < a.B;
+  const int b = valid ? brow : a.B - 1;
+  const bool col = c < N;
+  const int cc = col ? c : 0;
+  const int T = a.T, S = a.S;
+  const double* wsb = a.ws + ((long)b * T) * ws_step_doubles<N>() + cc;
+  const double* ws2b = a.ws2 + ((long)b * T) * (N * N + N) + cc;
+
+  for (int s0 = 0; s0 < S; s0 += 16) {
+    const int s = s0 + c;                      // this lane's sample
+    const bool sv = valid && s < S;
+    const int ss = s < S ? s : S - 1;
+    double Xn[N];
+    static_for<0, N>([&](auto k) { Xn[k] = 0.0; });
+    double one = 1.0;
+    for (int t = T - 1; t >= 0; --t) {
+      const double* w = wsb + (long)t * ws_step_doubles<N>();
+      const double* w2 = ws2b + (long)t * (N * N + N);
+      double GT[N + 1], R[N];
+      static_for<0, N>([&](auto k) { GT[k] = col ? w[k * N] : 0.0; });
+      GT[N] = col ? w[N * N] : 0.0;
+      static_for<0, N>([&](auto k) { R[k] = col ? w2[k * N] : 0.0; });
+      const double pv = col ? w2[N * N] : 1.0;
+      double dis = 1.0 / sqrt(pv);             // lane k: D_k^-1/2
+      const double* e = a.eps + (((long)b * T + t) * S + ss) * N;
+      double Y[N];
+      static_for<0, N>([&](auto k) { Y[k] = e[k]; });
+      dpp_fence(GT);
+      dpp_fence(R);
+      dpp_fence(dis);
+      // y = D^-1/2 eps, then back substitution with the unit upper factor L'
+      static_for<0, N>([&](auto k) {
+        double acc = 0.0;
+        mac_bc<k>(acc, dis, Y[k]);
+        Y[k] = acc;
+      });
+      static_for<1, N>([&](auto jj) {
+        constexpr int j = N - jj;              // j = N-1 .. 1
+        static_for<0, j>([&](auto k) { mac_bc<j, true>(Y[k], R[k], Y[j]); });
+      });
+      // x_t = noise + c_t + G_t x_{t+1};   G[k][j] = GT[j] at lane k
+      static_for<0, N>([&](auto k) { mac_bc<k>(Y[k], GT[N], one); });
+      static_for<0, N>([&](auto j) {
+        static_for<0, N>([&](auto k) { mac_bc<k>(Y[k], GT[j], Xn[j]); });
+      });
+      if (sv) {
+        double* o = a.samples + (((long)b * T + t) * S + s) * N;
+        static_for<0, N>([&](auto k) { o[k] = Y[k]; });
+      }
+      static_for<0, N>([&](auto k) { Xn[k] = Y[k]; });
+    }
+  }
+}
+
+template <int N>
+static int launch_sample(const SampleArgs& a, hipStream_t stream) {
+  hipLaunchKernelGGL((lds_sample_kernel<N>), dim3((a.B + 3) / 4), dim3(64), 0, stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 

@@ -11,3 +11,7 @@
 extern "C" int SVAE_CAT(svae_lds_launch_n, SVAE_N)(const svae::LdsArgs* a, int inhomog, void* stream) {
   return svae::launch_estep<SVAE_N>(*a, inhomog != 0, (hipStream_t)stream);
 }
+
+extern "C" int SVAE_CAT(svae_lds_sample_n, SVAE_N)(const svae::SampleArgs* a, void* stream) {
+  return svae::launch_sample<SVAE_N>(*a, (hipStream_t)stream);
+}

@@ -18,7 +18,7 @@ import torch
 from .. import _lib
 
 __all__ = ["LDSEStepPlan", "natural_lds_estep_general", "cython_natural_lds_estep_general",
-           "reduce_stats"]
+           "natural_lds_inference_general", "cython_natural_lds_inference_general", "reduce_stats"]
 
 
 def _as_dev(x, device):
@@ -65,17 +65,36 @@ class LDSEStepPlan(object):
         self.reduced = torch.empty(4 * n * n + n + 2, **f64)
 
     def launch(self, init_J, init_h, init_logZ, J11, J12, J22, logZ_pair, node_J, node_h,
-               node_logZ=None, pair_batched=False):
+               node_logZ=None, pair_batched=False, keep_factor=False):
         """Raw launch on the current stream.  All arguments: contiguous float64 device tensors."""
         p = _lib.ptr
         rc = self.lib.svae_lds_estep_f64(
-            self.B, self.T, self.n, int(self.inhomog), int(pair_batched),
+            self.B, self.T, self.n, int(self.inhomog), int(pair_batched), int(keep_factor),
             p(init_J), p(init_h), p(init_logZ), p(J11), p(J12), p(J22), p(logZ_pair),
             p(node_J), p(node_h), p(node_logZ),
             p(self.lognorm), p(self.E_init), p(self.E_pair), p(self.E_node_diagxx),
             p(self.E_node_x), p(self.info), p(self.ws), self.ws_bytes,
             _lib.current_stream(self.device))
         _lib.check(rc, "svae_lds_estep_f64")
+        self.has_factor = bool(keep_factor)
+
+    def sample(self, eps, out=None):
+        """Backward sampling from the messages of the last `launch(..., keep_factor=True)`.
+        eps: (B,T,S,n) standard-normal draws -> samples (B,T,S,n)
+        [natural_sample_backward, cython_lds_inference.pyx:310-355]."""
+        if not getattr(self, "has_factor", False):
+            raise RuntimeError("sample() needs a preceding launch(..., keep_factor=True)")
+        if eps.dim() != 4 or eps.shape[0] != self.B or eps.shape[1] != self.T or eps.shape[3] != self.n:
+            raise ValueError("eps must be (B,T,S,n)")
+        eps = eps.to(device=self.device, dtype=torch.float64).contiguous()
+        S = eps.shape[2]
+        if out is None:
+            out = torch.empty_like(eps)
+        p = _lib.ptr
+        rc = self.lib.svae_lds_sample_f64(self.B, self.T, self.n, S, p(eps), p(out), p(self.ws),
+                                          self.ws_bytes, _lib.current_stream(self.device))
+        _lib.check(rc, "svae_lds_sample_f64")
+        return out
 
     def reduce(self):
         """Deterministic batch sums [sum E_init | sum E_pair | sum lognorm | B] (homogeneous)."""
@@ -96,7 +115,7 @@ class LDSEStepPlan(object):
                                      "(potentials not positive definite)" % (v - 1))
 
 
-def natural_lds_estep_general(natparam, node_params, plan=None, check=True):
+def natural_lds_estep_general(natparam, node_params, plan=None, check=True, keep_factor=False):
     """E-step = filter + smoother (lds_inference.py:223-237).
 
     natparam = (init_params, pair_params); init_params = (-1/2 J0, h0, logZ...) and
@@ -150,7 +169,7 @@ def natural_lds_estep_general(natparam, node_params, plan=None, check=True):
     elif (plan.B, plan.T, plan.n, plan.inhomog) != (B, T, n, inhomog):
         raise ValueError("plan shape mismatch")
     plan.launch(init_J, init_h, init_logZ, J11, J12, J22, logZ_pair, node_J, node_h, node_logZ,
-                pair_batched)
+                pair_batched, keep_factor)
     if check:
         plan.check_info()
 
@@ -173,6 +192,39 @@ def natural_lds_estep_general(natparam, node_params, plan=None, check=True):
 
 
 cython_natural_lds_estep_general = natural_lds_estep_general
+
+
+def natural_lds_inference_general(natparam, node_params, num_samples=None, eps=None, plan=None,
+                                  generator=None):
+    """E-step + backward sampling: (samples, expected_stats, lognorm), mirroring
+    `cython_natural_lds_inference_general` (lds_inference.py:196-202).  samples: (T,S,n), or (T,n) when
+    num_samples is None as in the Python path (:109-124); batched nodes add a leading B axis.
+    The reference draws its noise from the global NumPy RNG inside the sampler
+    (cython_lds_inference.pyx:333); here `eps` (B,T,S,n) / (T,S,n) may be passed in, else it is drawn
+    from `generator` on the device."""
+    batched = (node_params[1].ndim if hasattr(node_params[1], "ndim") else torch.as_tensor(node_params[1]).dim()) == 3
+    S = 1 if num_samples is None else int(num_samples)
+    if plan is None:
+        nh = torch.as_tensor(node_params[1])
+        B, T, n = (nh.shape if batched else (1,) + tuple(nh.shape))
+        inhomog = torch.as_tensor(natparam[1][0]).dim() >= 3
+        plan = LDSEStepPlan(B, T, n, "cuda", inhomog)
+    lognorm, stats = natural_lds_estep_general(natparam, node_params, plan=plan, keep_factor=True)
+    if eps is None:
+        eps = torch.randn(plan.B, plan.T, S, plan.n, dtype=torch.float64, device=plan.device,
+                          generator=generator)
+    else:
+        eps = torch.as_tensor(eps, dtype=torch.float64)
+        eps = eps if batched else eps[None]
+    samples = plan.sample(eps)
+    if num_samples is None:
+        samples = samples[:, :, 0]
+    if not batched:
+        samples = samples[0]
+    return samples, stats, lognorm
+
+
+cython_natural_lds_inference_general = natural_lds_inference_general
 
 
 def reduce_stats(plan):

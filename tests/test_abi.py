@@ -34,7 +34,7 @@ def test_library_loads_and_exports_every_header_symbol():
 def test_workspace_size_formula():
     from svae_amd import _lib
     lib = _lib.load()
-    assert lib.svae_lds_workspace_bytes(512, 200, 10) == 512 * 200 * (2 * 10 + 1) * 10 * 8
+    assert lib.svae_lds_workspace_bytes(512, 200, 10) == 512 * 200 * ((2 * 10 + 1) * 10 + 10 * 10 + 10) * 8
     assert lib.svae_lds_workspace_bytes(1, 1, 16) == 0     # n > 15: outside the register path
     assert lib.svae_lds_workspace_bytes(0, 5, 3) == 0
 
@@ -45,10 +45,11 @@ def test_bad_arguments_are_rejected_on_the_host():
     lib = _lib.load()
     null = None
     args = [null] * 15 + [null, null, 0, null]
-    assert lib.svae_lds_estep_f64(4, 0, 3, 0, 0, *args) == -2          # T < 1
-    assert lib.svae_lds_estep_f64(4, 5, 16, 0, 0, *args) == -3         # n too large
-    assert lib.svae_lds_estep_f64(4, 5, 3, 0, 1, *args) == -5          # batched pair w/o inhomog
-    assert lib.svae_lds_estep_f64(4, 5, 3, 0, 0, *args) == -6          # NULL init_J
+    assert lib.svae_lds_estep_f64(4, 0, 3, 0, 0, 0, *args) == -2       # T < 1
+    assert lib.svae_lds_estep_f64(4, 5, 16, 0, 0, 0, *args) == -3      # n too large
+    assert lib.svae_lds_estep_f64(4, 5, 3, 0, 1, 0, *args) == -5       # batched pair w/o inhomog
+    assert lib.svae_lds_estep_f64(4, 5, 3, 0, 0, 0, *args) == -6       # NULL init_J
+    assert lib.svae_lds_sample_f64(4, 5, 3, 0, null, null, null, 0, null) == -4    # S < 1
     assert lib.svae_gmm_meanfield_f64(10, 9, 3, *([null] * 5), 1e-3, 100,
                                       *([null] * 7), null, null, null, null) == -2
     assert lib.svae_gmm_meanfield_f64(10, 2, 65, *([null] * 5), 1e-3, 100,
