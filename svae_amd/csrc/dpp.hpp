@@ -45,9 +45,13 @@ __device__ __forceinline__ double bcast(double x) {
 
 // acc (+/-)= bcast_K(src) * b   in one DP-ALU DPP instruction.  FENCED: the statement carries its
 // own two wait states (src may have been written by the immediately preceding instruction).
-template <int K, bool NEG = false, bool FENCED = false>
+#ifndef SVAE_DPP_ALWAYS_FENCED
+#define SVAE_DPP_ALWAYS_FENCED 0   // 1: every DPP statement carries its own wait states (used where
+#endif                             // register pressure makes the compiler shuffle VGPR<->AGPR)
+template <int K, bool NEG = false, bool FENCED_ = false>
 __device__ __forceinline__ void mac_bc(double& acc, double src, double b) {
   static_assert(K >= 0 && K < 16, "row_newbcast lane out of range");
+  constexpr bool FENCED = FENCED_ || SVAE_DPP_ALWAYS_FENCED;
 #if SVAE_FUSED_DPP
   if constexpr (NEG && FENCED)
     asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"

@@ -4,6 +4,12 @@
 
 namespace svae {
 
+// Workspace layout per (sequence, step), in doubles: N rows of H = [P^-1 J12 | c] (N+1 entries, row
+// stride padded to even => 16-byte aligned rows), then N rows of P^-1 (stride padded to even).
+constexpr int ws_h_stride(int n) { return (n + 1) + ((n + 1) & 1); }
+constexpr int ws_p_stride(int n) { return n + (n & 1); }
+constexpr int ws_step_doubles(int n) { return n * (ws_h_stride(n) + ws_p_stride(n)); }
+
 struct LdsArgs {
   int B, T;
   const double* __restrict__ init_J;

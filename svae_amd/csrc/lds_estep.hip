@@ -70,7 +70,7 @@ static int svae_lds_rows_per_wave(int B) {
 
 int svae_hip_abi_version(void) { return SVAE_HIP_ABI_VERSION; }
 
-static size_t main_ws_doubles(int B, int T, int n) { return (size_t)B * T * ((2 * n + 1) * n); }
+static size_t main_ws_doubles(int B, int T, int n) { return (size_t)B * T * svae::ws_step_doubles(n); }
 static size_t factor_ws_doubles(int B, int T, int n) { return (size_t)B * T * (n * n + n); }
 
 size_t svae_lds_workspace_bytes(int B, int T, int n) {

@@ -24,11 +24,14 @@
 //     reference's information-form RTS step does 2 Cholesky + potri + 3 triangular solves per step).
 //     S~ carries E[x x'], E[x] and 1 together, so means, second moments and cross moments fall out
 //     of the same two products; sums of PSD terms only (no cancelling subtractions);
-//   * forward -> backward hand-off (G~_t', P_t^-1: (2n+1) n doubles per step) goes through an HBM
-//     workspace written and re-read by the SAME lanes (no inter-workgroup communication).
+//   * J12 and h_filt ride through the elimination as extra right-hand-side columns (h in lane n), so
+//     G_t = -P^-1 J12 and c_t = P^-1 h_filt have solve-quality accuracy (not inverse-times-matrix);
+//   * forward -> backward hand-off ([P^-1 J12 | c] and P^-1 per step) goes through an HBM workspace
+//     written and re-read by the SAME wave (no inter-workgroup communication); the backward half
+//     reads it row-wise with 16-byte loads (the transposition G -> G' is done by the addressing).
 //
 // Algorithmic HBM bytes per sequence: 8*[T(2n+1) + 2Tn + 4n^2 + n + 1];
-// workspace traffic on top of that is 2 * 8 * T * (2n+1) * n (write + read).
+// workspace traffic on top of that is 2 * 8 * T * ws_step_doubles(n) (write + read).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -40,31 +43,26 @@
 
 namespace svae {
 
-
-// doubles of workspace per (sequence, time step): rows 0..N-1 = G~' rows (-J12' P^-1), row N = c =
-// P^-1 h_filt, rows N+1..2N = P^-1.  Each row is N doubles (lane c < N).
-template <int N>
-constexpr int ws_step_doubles() { return (2 * N + 1) * N; }
-
-// rows i0, i0+1, .. i0+IL-1 of  OUT[i] (+)= sum_k bcast_k(SRC[i]) * Bt[k]   (k = 0..KN-1), the IL
-// accumulation chains interleaved so that consecutive instructions are independent.
-template <int IL, int I0, int KN, int MS, int MB, int MO>
+// rows i0, i0+1, .. i0+IL-1 of  OUT[i] += sum_k (+/-) bcast_k(SRC[i]) * Bt[k]   (k = 0..KN-1; the
+// first NEGK terms are subtracted), the IL accumulation chains interleaved so that consecutive
+// instructions are independent.
+template <int IL, int I0, int KN, int NEGK, int MS, int MB, int MO>
 __device__ __forceinline__ void rows_src_bcast(double (&out)[MO], const double (&src)[MS],
                                                const double (&bt)[MB]) {
   static_for<0, KN>([&](auto k) {
     static_for<0, IL>([&](auto j) {
-      if constexpr (I0 + j < MO && I0 + j < MS) mac_bc<k>(out[I0 + j], src[I0 + j], bt[k]);
+      if constexpr (I0 + j < MO && I0 + j < MS) mac_bc<k, (k < NEGK)>(out[I0 + j], src[I0 + j], bt[k]);
     });
   });
 }
 
-// rows i0.. of  OUT[i] (+)= sum_k Gt[k] * bcast_i(W[k])   (the transposed product of the backward step)
-template <int IL, int I0, int KN, int MW, int MG, int MO>
+// rows i0.. of  OUT[i] += sum_k (+/-) Gt[k] * bcast_i(W[k])   (the transposed product of the backward step)
+template <int IL, int I0, int KN, int NEGK, int MW, int MG, int MO>
 __device__ __forceinline__ void rows_lane_bcast(double (&out)[MO], const double (&w)[MW],
                                                 const double (&gt)[MG]) {
   static_for<0, KN>([&](auto k) {
     static_for<0, IL>([&](auto j) {
-      if constexpr (I0 + j < MO) mac_bc<I0 + j>(out[I0 + j], w[k], gt[k]);
+      if constexpr (I0 + j < MO) mac_bc<I0 + j, (k < NEGK)>(out[I0 + j], w[k], gt[k]);
     });
   });
 }
@@ -73,10 +71,26 @@ __device__ __forceinline__ void rows_lane_bcast(double (&out)[MO], const double 
 #define SVAE_IL 4     // independent accumulation chains interleaved per DPP product stage
 #endif
 
+// contiguous row of CNT doubles at a 16-byte aligned address -> registers (8- or 16-byte loads)
+template <int CNT, int M>
+__device__ __forceinline__ void load_row(const double* __restrict__ p, double (&r)[M]) {
+  static_for<0, CNT / 2>([&](auto j) {
+    const double2 v = reinterpret_cast<const double2*>(p)[j];
+    r[2 * j] = v.x;
+    if constexpr (2 * j + 1 < M) r[2 * j + 1] = v.y;
+  });
+  if constexpr (CNT % 2 == 1) r[CNT - 1] = p[CNT - 1];
+}
+
 template <int N, bool INHOMOG, bool CHOL>
 __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
   static_assert(N >= 1 && N <= SVAE_LDS_MAX_N, "n+1 lanes must fit a 16-lane DPP row");
   constexpr int IL = SVAE_IL;
+  constexpr int HS = ws_h_stride(N), PS = ws_p_stride(N), WS = ws_step_doubles(N);
+  // Above n = 10 the register tiles no longer fit 256 VGPRs: keep fewer constants resident (reload
+  // J12/J22 from L2 when needed) and do not double-buffer the backward loads.  (AGPR spill moves are
+  // VALU writes, i.e. DPP hazards the compiler cannot see around the inline asm: avoid them.)
+  constexpr bool LOWREG = N > 10;
   const int lane = threadIdx.x;
   const int c = lane & 15;
   if ((lane >> 4) >= a.rows_per_wave) return;       // experiments: fewer sequences per wave
@@ -85,20 +99,21 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
   const int b = valid ? brow : a.B - 1;   // surplus rows recompute the last sequence, stores masked
   const bool col = c < N;
   const bool st = valid && col;
+  const bool sth = valid && c <= N;
   const int cc = col ? c : 0;
   const int T = a.T;
 
-  // identity tile: E[i][c] = (c == i).  Per-lane selects are done arithmetically with it (x*E, exact)
-  // instead of v_cndmask: on gfx950 v_cndmask throughput is shared by the whole CU (measured:
-  // tools/ubench/valu_rates.hip), which throttles the kernel as soon as >1 wave runs per CU.
+  // identity tile: E[i][c] = (c == i), EN[c] = (c == N).  Per-lane selects are done arithmetically
+  // with it (x*E, exact) instead of v_cndmask: on gfx950 v_cndmask throughput is shared by the whole
+  // CU (measured: tools/ubench/valu_rates.hip), which throttles the kernel once >1 wave runs per CU.
   double E[N];
   static_for<0, N>([&](auto i) { E[i] = (c == i) ? 1.0 : 0.0; });
+  const double EN = (c == N) ? 1.0 : 0.0;
 
   // ---- pair parameters (info form: J = -2 natJ, J12 = -natJ12), column c per lane -------------
-  //   NJ12T[i][c] = -J12[c][i]   (so that G~' rows = -J12' P^-1 come out of the product directly)
-  //   J12c[k][c]  =  J12[k][c]
+  //   NJ12T[i][c] = -J12[c][i]      J12c[k][c] = J12[k][c]      (lanes >= N: 0)
   //   Cc[i][c]    =  J22[i][c] + J11[i][c]   (next step's pivot block without the node diagonal)
-  double NJ12T[N], J12c[N], Cc[N], J22c[N];
+  double NJ12T[N], J12c[LOWREG ? 1 : N], Cc[N], J22c[LOWREG ? 1 : N];
   const double* pJ11 = a.J11 + (long)b * a.pair_seq_stride;
   const double* pJ12 = a.J12 + (long)b * a.pair_seq_stride;
   const double* pJ22 = a.J22 + (long)b * a.pair_seq_stride;
@@ -106,31 +121,34 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
     const long o = INHOMOG ? (long)t * N * N : 0;
     const long o1 = INHOMOG ? (long)(t + 1) * N * N : 0;
     static_for<0, N>([&](auto i) {
-      J12c[i] = col ? -pJ12[o + i * N + cc] : 0.0;
       NJ12T[i] = col ? pJ12[o + cc * N + i] : 0.0;
-      J22c[i] = col ? -2.0 * pJ22[o + i * N + cc] : 0.0;
-      Cc[i] = J22c[i] + ((col && with_next_J11) ? -2.0 * pJ11[o1 + i * N + cc] : 0.0);
+      const double j22 = col ? -2.0 * pJ22[o + i * N + cc] : 0.0;
+      if constexpr (!LOWREG) {
+        J12c[i] = col ? -pJ12[o + i * N + cc] : 0.0;
+        J22c[i] = j22;
+      }
+      Cc[i] = j22 + ((col && with_next_J11) ? -2.0 * pJ11[o1 + i * N + cc] : 0.0);
     });
   };
   if (!INHOMOG && T > 1) { load_pair(0, true); dpp_fence(NJ12T); }
 
   // ---- forward filter --------------------------------------------------------------------------
-  // A = pivot block of the current step without the node diagonal: J_pred + J11 (J_pred at t = T-1)
-  double A[N], hp;
+  // An: lanes < N = pivot block of the current step without the node diagonal (J_pred + J11; J_pred
+  // alone at t = T-1); lane N = h_pred (column layout: register i holds component i).
+  double An[N];
   static_for<0, N>([&](auto i) {
-    A[i] = col ? -2.0 * a.init_J[i * N + cc] : 0.0;
-    if (T > 1) A[i] += col ? -2.0 * pJ11[i * N + cc] : 0.0;
+    An[i] = col ? -2.0 * a.init_J[i * N + cc] : ((c == N) ? a.init_h[i] : 0.0);
+    if (T > 1) An[i] += col ? -2.0 * pJ11[i * N + cc] : 0.0;
   });
-  hp = col ? a.init_h[cc] : 0.0;
 
   const double* nJ = a.node_J + ((long)b * T) * N + cc;
   const double* nh = a.node_h + ((long)b * T) * N + cc;
-  double* wsb = a.ws + ((long)b * T) * ws_step_doubles<N>() + cc;
+  double* wsb = a.ws + ((long)b * T) * WS;
   // CHOL: also keep the unit-upper factor rows (the scaled pivot rows) and the pivots of P_t for the
   // backward sampler (svae_lds_sample_f64): N*N + N doubles per step in the second workspace region.
   double* ws2b = CHOL ? a.ws2 + ((long)b * T) * (N * N + N) + cc : nullptr;
 
-  double qacc = 0.0;       // per-lane partial of sum_t h_filt' P^-1 h_filt
+  double qacc = 0.0;       // lane N: sum_t h_filt' P^-1 h_filt (other lanes: unused partials)
   double ldM = 1.0;        // log|P_t| accumulated as mantissa product ...
   int ldE = 0;             // ... and exponent sum (one log at the very end)
   double pmin = 1.0;       // smallest pivot seen (<= 0 => not positive definite)
@@ -140,22 +158,35 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
 
   for (int t = 0; t < T; ++t) {
     const bool last = (t == T - 1);
-    const double Jo = Jo_n, ho = ho_n;
+    const double Jo = Jo_n;
+    double ho = ho_n;
     if (!last) {
       Jo_n = col ? -2.0 * nJ[(long)(t + 1) * N] : 0.0;
       ho_n = col ? nh[(long)(t + 1) * N] : 0.0;
     }
     if (INHOMOG && !last) { load_pair(t, t + 1 < T - 1); dpp_fence(NJ12T); }
 
-    // condition on the node potential: P = A + diag(J_node), h_filt = h_pred + h_node
-    double P[N];
-    static_for<0, N>([&](auto i) { P[i] = __builtin_fma(Jo, E[i], A[i]); });
-    double hf = hp + ho;
+    // condition on the node potential: P = A + diag(J_node); right-hand sides X = [J12 | h_filt]
+    // (h_filt = h_pred + h_node lands in lane N, register i <- lane i of the row-layout h_node)
+    double P[N], X[N];
+    static_for<0, N>([&](auto i) { P[i] = __builtin_fma(Jo, E[i], An[i]); });
+    if (last) {
+      asm volatile("; last step: no pair potential, G = 0");   // keep this a branch
+      static_for<0, N>([&](auto i) { X[i] = EN * An[i]; });
+    } else {
+      if constexpr (LOWREG) {
+        const long o = INHOMOG ? (long)t * N * N : 0;
+        static_for<0, N>([&](auto i) { X[i] = __builtin_fma(EN, An[i], col ? -pJ12[o + i * N + cc] : 0.0); });
+      } else {
+        static_for<0, N>([&](auto i) { X[i] = __builtin_fma(EN, An[i], J12c[i]); });
+      }
+    }
+    dpp_fence(ho);
+    static_for<0, N>([&](auto i) { mac_bc<i>(X[i], ho, EN); });
     dpp_fence(P);
-    dpp_fence(hf);
 
-    // In-place Gauss-Jordan inverse (SPD => no pivoting); pivots are the LDL' diagonal.  Row k+1 is
-    // updated first so that the next pivot's reciprocal chain overlaps the remaining row updates.
+    // In-place Gauss-Jordan (SPD => no pivoting): P -> P^-1, X -> P^-1 X; pivots = LDL' diagonal.
+    // Row k+1 is updated first so the next pivot's reciprocal chain overlaps the other row updates.
     double p = bcast_fenced<0>(P[0]);
     double pprod = 1.0;
     double pv = 0.0;                                   // CHOL: lane k <- pivot k
@@ -164,16 +195,20 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
       pmin = fmin(pmin, p);
       pprod *= p;
       const double rinv = rcp_nr(p);
-      // scaled pivot row; lane k gets 1/p (the inverse's diagonal entry)
+      // scaled pivot rows; lane k of r gets 1/p (the inverse's diagonal entry)
       const double r = __builtin_fma(E[k], 1.0 - p, P[k]) * rinv;
+      const double rx = X[k] * rinv;
+      qacc = __builtin_fma(X[k], rx, qacc);            // lane N: z_k^2 / d_k  (h' P^-1 h = sum_k)
       if constexpr (CHOL) {
         pv = __builtin_fma(E[k], p, pv);
         if (st) w2[k * N] = r;       // lanes j > k hold L_unit[j][k] (P = L D L')
       }
       auto update = [&](auto i, auto fenced) {
         // lane k: its column becomes the inverse's column, 0 - m/p; other lanes: P_i - m r
-        double acc = __builtin_fma(-P[i], E[k], P[i]);
-        mac_bc<k, true, decltype(fenced)::value>(acc, P[i], r);
+        const double old = P[i];
+        double acc = __builtin_fma(-old, E[k], old);
+        mac_bc<k, true, decltype(fenced)::value>(acc, old, r);
+        mac_bc<k, true>(X[i], old, rx);
         P[i] = acc;
       };
       if constexpr (k + 1 < N) update(std::integral_constant<int, k + 1>{}, std::true_type{});
@@ -185,6 +220,7 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
       });
       if constexpr (k + 1 < N) p = bcast_fenced<k + 1>(P[k + 1]);
       P[k] = r;
+      X[k] = rx;
       if constexpr (k == N / 2 || k == N - 1) {      // keep the running product in range
         ldE += __builtin_amdgcn_frexp_exp(pprod);
         ldM *= __builtin_amdgcn_frexp_mant(pprod);
@@ -197,45 +233,24 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
       ldE += e;
     }
     if constexpr (CHOL) { if (st) w2[N * N] = pv; }
-    dpp_fence(P);   // rows P[k] were last written by plain multiplies
 
-    // c_t = P^-1 h_filt  (row layout: lane c holds c_t[c]); P^-1 symmetric.  Two partial sums.
-    double cv = 0.0, cv1 = 0.0;
-    static_for<0, N>([&](auto k) {
-      if constexpr (k % 2 == 0) mac_bc<k>(cv, hf, P[k]); else mac_bc<k>(cv1, hf, P[k]);
-    });
-    cv += cv1;
-    qacc = __builtin_fma(hf, cv, qacc);
-
-    double* w = wsb + (long)t * ws_step_doubles<N>();
-    if (st) {
-      w[N * N] = cv;
-      static_for<0, N>([&](auto i) { w[(N + 1 + i) * N] = P[i]; });
-    }
+    // hand-off to the backward half: row i of [P^-1 J12 | c] (lanes 0..N) and of P^-1 (lanes < N)
+    double* w = wsb + (long)t * WS;
+    if (sth) static_for<0, N>([&](auto i) { w[i * HS + c] = X[i]; });
+    if (st) static_for<0, N>([&](auto i) { w[N * HS + i * PS + c] = P[i]; });
 
     if (!last) {
-      // G~' rows:  XTn_i = -(row i of J12' P^-1)
-      double XTn[N + 1];
-      static_for<0, N>([&](auto i) { XTn[i] = 0.0; });
-      static_for<0, (N + IL - 1) / IL>([&](auto g) { rows_src_bcast<IL, g * IL, N>(XTn, NJ12T, P); });
-      if (st) static_for<0, N>([&](auto i) { w[i * N] = XTn[i]; });
-      // next pivot block  A' = (J22 + J11) - J12' P^-1 J12   and   -h_pred' = c_t' J12   (row N)
-      double An[N + 1];
+      // next pivot block  A' = (J22 + J11) - J12' P^-1 J12  (lanes < N),  h_pred' = -J12' c  (lane N)
       const bool next_last = (t + 1 == T - 1);
       if (!INHOMOG && next_last) {
-        asm volatile("; next step is the last: its pivot block has no J11 term");   // keep this a branch
-        static_for<0, N>([&](auto i) { An[i] = J22c[i]; });
+        asm volatile("; next step is the last: its pivot block has no J11 term");   // keep a branch
+        if constexpr (LOWREG) static_for<0, N>([&](auto i) { An[i] = col ? -2.0 * pJ22[i * N + cc] : 0.0; });
+        else static_for<0, N>([&](auto i) { An[i] = J22c[i]; });
       } else {
         static_for<0, N>([&](auto i) { An[i] = Cc[i]; });
       }
-      An[N] = 0.0;
-      XTn[N] = cv;
-      dpp_fence(XTn[N]);
-      static_for<0, (N + 1 + IL - 1) / IL>([&](auto g) { rows_src_bcast<IL, g * IL, N>(An, XTn, J12c); });
-      static_for<0, N>([&](auto i) { A[i] = An[i]; });
-      hp = -An[N];
-    } else {
-      if (st) static_for<0, N>([&](auto i) { w[i * N] = 0.0; });
+      asm volatile("s_nop 1");   // block entry: two wait states before the first DPP read (audit rule)
+      static_for<0, (N + IL - 1) / IL>([&](auto g) { rows_src_bcast<IL, g * IL, N, 0>(An, NJ12T, X); });
     }
   }
 
@@ -249,7 +264,7 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
       const double* lz = a.logZ_pair + (a.pair_seq_stride ? (long)b * (T - 1) : 0);
       for (int t = c; t < T - 1; t += 16) z += lz[t];
     }
-    double total = row_sum16(__builtin_fma(0.5, qacc, z));
+    double total = row_sum16(__builtin_fma(0.5, qacc * EN, z));
     total += a.init_logZ[0];
     if (!INHOMOG && T > 1) total += (double)(T - 1) * a.logZ_pair[0];
     total -= 0.5 * (::log(ldM) + (double)ldE * 0.6931471805599453094);
@@ -268,37 +283,47 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
   // ---- backward pass in moment form on homogeneous coordinates ---------------------------------
   // S[i] = row i of S~ (i = 0..N), lane c = column c (c = 0..N).  Start from S~_T := e_N e_N' so
   // that the generic step at t = T-1 (where G = 0, c = mu_{T-1}) yields [[Sigma+mu mu', mu],[mu',1]].
+  // With H = [P^-1 J12 | c]:  G~' row k = -H[.][k] (k < N),  row N = c';  lane N: (0,..,0,1).
   double S[N + 1];
   static_for<0, N + 1>([&](auto i) { S[i] = 0.0; });
-  S[N] = (c == N) ? 1.0 : 0.0;
+  S[N] = EN;
   dpp_fence(S);
-  double sumA[N], sumW[N], Slast[N];
-  static_for<0, N>([&](auto i) { sumA[i] = 0.0; sumW[i] = 0.0; Slast[i] = 0.0; });
+  double sumA[N], sumW[N], Slast[LOWREG ? 1 : N];   // LOWREG: S~_{T-1} waits in its output slot
+  static_for<0, N>([&](auto i) { sumA[i] = 0.0; sumW[i] = 0.0; });
+  if constexpr (!LOWREG) static_for<0, N>([&](auto i) { Slast[i] = 0.0; });
 
   double* oEx = a.E_node_x + ((long)b * T) * N + cc;
   double* oExx = a.E_node_diagxx + ((long)b * T) * N + cc;
   double* oPair = INHOMOG ? a.E_pair + ((long)b * (T - 1)) * 3 * N * N + cc : nullptr;
 
-  auto load_step = [&](int t, double (&g)[N + 1], double (&pi)[N]) {
-    const double* w = wsb + (long)t * ws_step_doubles<N>();
-    static_for<0, N>([&](auto k) { g[k] = col ? w[k * N] : 0.0; });
-    g[N] = col ? w[N * N] : ((c == N) ? 1.0 : 0.0);
-    static_for<0, N>([&](auto i) { pi[i] = col ? w[(N + 1 + i) * N] : 0.0; });
+  // lane c < N reads ROW c of H (-> H[k] = H[c][k], the transposition G -> G') and row c of the
+  // symmetric P^-1, both contiguous and 16-byte aligned.
+  auto load_step = [&](int t, double (&h)[N + 1], double (&pi)[N]) {
+    const double* w = wsb + (long)t * WS;
+    if (col) {
+      load_row<N + 1>(w + cc * HS, h);
+      load_row<N>(w + N * HS + cc * PS, pi);
+    } else {
+      static_for<0, N>([&](auto k) { h[k] = 0.0; pi[k] = 0.0; });
+      h[N] = EN;
+    }
   };
 
-  // one backward step: consumes (GT, Pi) of step t, prefetches step t-1 into (GTn, Pin)
-  auto step = [&](int t, double (&GT)[N + 1], double (&Pi)[N], double (&GTn)[N + 1], double (&Pin)[N]) {
-    if (t > 0) load_step(t - 1, GTn, Pin);
+  // one backward step: consumes (H, Pi) of step t, prefetches step t-1 into (Hn, Pin)
+  auto step = [&](int tt, double (&H)[N + 1], double (&Pi)[N], double (&Hn)[N + 1], double (&Pin)[N]) {
+    const int t = tt < 0 ? -1 - tt : tt;
+    if (tt > 0) load_step(t - 1, Hn, Pin);
+    dpp_fence(H);   // not a DPP source, but keeps the loads' consumers behind this point
 
     // W~ = S~_{t+1} G~'   (W[i][c] = E[x~_{t+1,i} x~_{t,c}])
     double W[N + 1];
     static_for<0, N + 1>([&](auto i) { W[i] = 0.0; });
-    static_for<0, (N + 1 + IL - 1) / IL>([&](auto g) { rows_src_bcast<IL, g * IL, N + 1>(W, S, GT); });
+    static_for<0, (N + 1 + IL - 1) / IL>([&](auto g) { rows_src_bcast<IL, g * IL, N + 1, N>(W, S, H); });
     // S~_t = G~ W~ + diag(P^-1, 0), computed through its transpose (S~ symmetric):
-    //   S~[c][i] = sum_k G~[c][k] W~[k][i] = sum_k GT[k](lane c) * W[k](lane i)
+    //   S~[c][i] = sum_k G~[c][k] W~[k][i] = sum_k G~'[k](lane c) * W[k](lane i)
     static_for<0, N>([&](auto i) { S[i] = Pi[i]; });
     S[N] = 0.0;
-    static_for<0, (N + 1 + IL - 1) / IL>([&](auto g) { rows_lane_bcast<IL, g * IL, N + 1>(S, W, GT); });
+    static_for<0, (N + 1 + IL - 1) / IL>([&](auto g) { rows_lane_bcast<IL, g * IL, N + 1, N>(S, W, H); });
 
     if (INHOMOG) {
       // per-step pair blocks: [E x_t x_t' | E x_t x_{t+1}' | E x_{t+1} x_{t+1}'] for pair index t;
@@ -317,7 +342,10 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
       }
     } else {
       if (t < T - 1) static_for<0, N>([&](auto i) { sumA[i] += S[i]; sumW[i] += W[i]; });
-      else static_for<0, N>([&](auto i) { Slast[i] = S[i]; });
+      else {
+        if constexpr (LOWREG) { if (st) static_for<0, N>([&](auto i) { a.E_pair[(long)b * 3 * N * N + 2 * N * N + i * N + cc] = S[i]; }); }
+        else static_for<0, N>([&](auto i) { Slast[i] = S[i]; });
+      }
     }
 
     // node statistics: E[x_t] = row N of S~, diag E[x_t x_t'] = sum_i E[i] * S[i]
@@ -331,15 +359,21 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
     }
   };
 
-  {
-    double GTa[N + 1], Pia[N], GTb[N + 1], Pib[N];
-    load_step(T - 1, GTa, Pia);
+  if constexpr (LOWREG) {
+    double Ha[N + 1], Pia[N];
+    for (int t = T - 1; t >= 0; --t) {
+      load_step(t, Ha, Pia);
+      step(-1 - t, Ha, Pia, Ha, Pia);   // negative: "no prefetch" (see step)
+    }
+  } else {
+    double Ha[N + 1], Pia[N], Hb[N + 1], Pib[N];
+    load_step(T - 1, Ha, Pia);
     int t = T - 1;
     for (; t >= 1; t -= 2) {          // two steps per trip: the prefetch buffers ping-pong
-      step(t, GTa, Pia, GTb, Pib);
-      step(t - 1, GTb, Pib, GTa, Pia);
+      step(t, Ha, Pia, Hb, Pib);
+      step(t - 1, Hb, Pib, Ha, Pia);
     }
-    if (t == 0) step(0, GTa, Pia, GTb, Pib);
+    if (t == 0) step(0, Ha, Pia, Hb, Pib);
   }
 
   // ---- global statistics -----------------------------------------------------------------------
@@ -352,7 +386,8 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
       static_for<0, N>([&](auto i) {
         ep[i * N + cc] = sumA[i];                               // sum_{t<T-1} E[x_t x_t']
         ep[N * N + cc * N + i] = sumW[i];                       // sum_t E[x_t x_{t+1}'] = (sum_t W_t)'
-        ep[2 * N * N + i * N + cc] = (sumA[i] - S[i]) + Slast[i];   // sum_{t>=1} E[x_t x_t']
+        const double sl = LOWREG ? ep[2 * N * N + i * N + cc] : Slast[LOWREG ? 0 : (int)i];
+        ep[2 * N * N + i * N + cc] = (sumA[i] - S[i]) + sl;      // sum_{t>=1} E[x_t x_t']
       });
     }
   }
@@ -378,14 +413,14 @@ static int launch_estep(const LdsArgs& a, bool inhomog, hipStream_t stream) {
 // cython_gaussian_grads.pxd:431-454, _natural_condition_on :489-508):
 //   x_{T-1} ~ N(J_f^-1 h_f, J_f^-1),   x_t | x_{t+1} ~ N(P_t^-1 (h_f,t - J12 x_{t+1}), P_t^-1),
 //   noise = chol(P_t)^-T eps_t   (the reference's dtrtrs 'L','T'), so that equal eps give equal samples.
-// From the forward pass: mean = c_t + G_t x_{t+1} (G~' rows in the main workspace) and P_t = L D L'
-// (unit factor rows + pivots in the second region): noise = L^-T D^-1/2 eps by back substitution.
-// Layout: one DPP row per sequence as in the E-step, but lanes are SAMPLES (16 per pass) and the
-// vector index lives in the register number: every coefficient is then a row_newbcast operand, so
-// one v_fmac_f64_dpp advances 16 samples of 4 sequences.
-
+// From the forward pass: mean = c_t - (P^-1 J12) x_{t+1} (H rows in the main workspace) and
+// P_t = L D L' (unit factor rows + pivots in the second region): noise = L^-T D^-1/2 eps by back
+// substitution.  Layout: one DPP row per sequence as in the E-step, but lanes are SAMPLES (16 per
+// pass) and the vector index lives in the register number: every coefficient is then a
+// row_newbcast operand, so one v_fmac_f64_dpp advances 16 samples of 4 sequences.
 template <int N>
 __global__ __launch_bounds__(64) void lds_sample_kernel(const SampleArgs a) {
+  constexpr int HS = ws_h_stride(N), WS = ws_step_doubles(N);
   const int lane = threadIdx.x;
   const int c = lane & 15;
   const int brow = blockIdx.x * 4 + (lane >> 4);
@@ -394,7 +429,7 @@ __global__ __launch_bounds__(64) void lds_sample_kernel(const SampleArgs a) {
   const bool col = c < N;
   const int cc = col ? c : 0;
   const int T = a.T, S = a.S;
-  const double* wsb = a.ws + ((long)b * T) * ws_step_doubles<N>() + cc;
+  const double* wsb = a.ws + ((long)b * T) * WS;
   const double* ws2b = a.ws2 + ((long)b * T) * (N * N + N) + cc;
 
   for (int s0 = 0; s0 < S; s0 += 16) {
@@ -405,18 +440,17 @@ __global__ __launch_bounds__(64) void lds_sample_kernel(const SampleArgs a) {
     static_for<0, N>([&](auto k) { Xn[k] = 0.0; });
     double one = 1.0;
     for (int t = T - 1; t >= 0; --t) {
-      const double* w = wsb + (long)t * ws_step_doubles<N>();
       const double* w2 = ws2b + (long)t * (N * N + N);
-      double GT[N + 1], R[N];
-      static_for<0, N>([&](auto k) { GT[k] = col ? w[k * N] : 0.0; });
-      GT[N] = col ? w[N * N] : 0.0;
+      double H[N + 1], R[N];
+      if (col) load_row<N + 1>(wsb + (long)t * WS + cc * HS, H);       // H[j] = H[c][j]
+      else static_for<0, N + 1>([&](auto k) { H[k] = 0.0; });
       static_for<0, N>([&](auto k) { R[k] = col ? w2[k * N] : 0.0; });
       const double pv = col ? w2[N * N] : 1.0;
       double dis = 1.0 / sqrt(pv);             // lane k: D_k^-1/2
       const double* e = a.eps + (((long)b * T + t) * S + ss) * N;
       double Y[N];
       static_for<0, N>([&](auto k) { Y[k] = e[k]; });
-      dpp_fence(GT);
+      dpp_fence(H);
       dpp_fence(R);
       dpp_fence(dis);
       // y = D^-1/2 eps, then back substitution with the unit upper factor L'
@@ -429,10 +463,10 @@ __global__ __launch_bounds__(64) void lds_sample_kernel(const SampleArgs a) {
         constexpr int j = N - jj;              // j = N-1 .. 1
         static_for<0, j>([&](auto k) { mac_bc<j, true>(Y[k], R[k], Y[j]); });
       });
-      // x_t = noise + c_t + G_t x_{t+1};   G[k][j] = GT[j] at lane k
-      static_for<0, N>([&](auto k) { mac_bc<k>(Y[k], GT[N], one); });
+      // x_t = noise + c_t - (P^-1 J12) x_{t+1}:  coefficient [k][j] = H[j] at lane k
+      static_for<0, N>([&](auto k) { mac_bc<k>(Y[k], H[N], one); });
       static_for<0, N>([&](auto j) {
-        static_for<0, N>([&](auto k) { mac_bc<k>(Y[k], GT[j], Xn[j]); });
+        static_for<0, N>([&](auto k) { mac_bc<k, true>(Y[k], H[j], Xn[j]); });
       });
       if (sv) {
         double* o = a.samples + (((long)b * T + t) * S + s) * N;

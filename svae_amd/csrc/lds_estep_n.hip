@@ -1,5 +1,10 @@
 // lds_estep_n.hip -- one translation unit per latent dimension (compiled with -DSVAE_N=<n>), so
 // that `make -j` builds the 15 specialisations of the E-step kernel in parallel.
+#if defined(SVAE_N) && SVAE_N > 13
+// n = 14, 15: the tiles exceed 256 VGPRs and hipcc moves values through AGPRs (VALU writes the DPP
+// hazard bookkeeping in dpp.hpp cannot see): make every DPP statement self-fenced (slower, safe).
+#define SVAE_DPP_ALWAYS_FENCED 1
+#endif
 #include "lds_estep_kernel.hpp"
 
 #ifndef SVAE_N

@@ -34,7 +34,10 @@ def test_library_loads_and_exports_every_header_symbol():
 def test_workspace_size_formula():
     from svae_amd import _lib
     lib = _lib.load()
-    assert lib.svae_lds_workspace_bytes(512, 200, 10) == 512 * 200 * ((2 * 10 + 1) * 10 + 10 * 10 + 10) * 8
+    # main region: n rows of [P^-1 J12 | c] (stride even(n+1)) + n rows of P^-1 (stride even(n));
+    # factor region: n*n + n
+    assert lib.svae_lds_workspace_bytes(512, 200, 10) == 512 * 200 * (10 * (12 + 10) + 10 * 10 + 10) * 8
+    assert lib.svae_lds_workspace_bytes(3, 7, 5) == 3 * 7 * (5 * (6 + 6) + 5 * 5 + 5) * 8
     assert lib.svae_lds_workspace_bytes(1, 1, 16) == 0     # n > 15: outside the register path
     assert lib.svae_lds_workspace_bytes(0, 5, 3) == 0
 
