@@ -97,3 +97,38 @@ def mniw_expectedstats(natparam, fudge=1e-8):
     ar = torch.arange(m, dtype=S.dtype, device=S.device)
     E_logdet = torch.digamma((nu - ar) / 2.).sum() + m * math.log(2.) - torch.linalg.slogdet(S)[1]
     return (-0.5 * E_AT_Sigmainv_A, E_Sigmainv_A.transpose(-1, -2), -0.5 * E_Sigmainv, 0.5 * E_logdet)
+
+
+# --- log-normalisers (for the global KL terms; svae/models/gmm.py:44-58, svae/models/lds.py:16-30) ---
+
+def dirichlet_logZ(natparam):
+    """dirichlet.py:9-11."""
+    alpha = natparam + 1
+    return (torch.lgamma(alpha).sum(-1) - torch.lgamma(alpha.sum(-1))).sum()
+
+
+def niw_logZ(natparam):
+    """niw.py:27-31 (dense-packed natparam, possibly stacked)."""
+    S, m, kappa, nu = niw_natural_to_standard(natparam)
+    d = m.shape[-1]
+    return (d * nu / 2. * math.log(2.) + torch.special.multigammaln(nu / 2., d)
+            - nu / 2. * torch.linalg.slogdet(S)[1] - d / 2. * torch.log(kappa)).sum()
+
+
+def mniw_logZ(natparam):
+    """mniw.py:13-17."""
+    nu, S, _, K = mniw_natural_to_standard(natparam)
+    n = S.shape[0]
+    nu = torch.as_tensor(nu, dtype=S.dtype, device=S.device)
+    return n * nu / 2. * math.log(2.) + torch.special.multigammaln(nu / 2., n) \
+        - nu / 2. * torch.linalg.slogdet(S)[1] + n / 2. * torch.linalg.slogdet(K)[1]
+
+
+def gaussian_natural_sample(natparam, eps):
+    """gaussian.py:27-33: x = J^-1 h + L^-T eps, dense-packed natparam (...,N+2,N+2), eps (...,S,N)."""
+    neghalfJ, h, _, _ = unpack_dense(natparam)
+    J = -2 * neghalfJ
+    L = torch.linalg.cholesky(J)
+    noise = torch.linalg.solve_triangular(L.transpose(-1, -2), eps.transpose(-1, -2), upper=True)
+    mean = torch.linalg.solve(J, h.unsqueeze(-1))[..., 0]
+    return mean.unsqueeze(-2) + noise.transpose(-1, -2)

