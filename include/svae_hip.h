@@ -72,6 +72,12 @@ int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int k
                        double* E_node_diagxx, double* E_node_x,
                        int32_t* info, void* workspace, size_t ws_bytes, void* stream);
 
+/* Kernel selection for svae_lds_estep_f64: batches with B <= max_b run the small-batch variant (one
+ * sequence per wavefront, product stages split across the four DPP rows), larger ones the packed
+ * kernel (four sequences per wavefront).  Default 1023 (or env SVAE_LDS_SPLIT_MAX_B); 0 = never.
+ * Both give the same results up to rounding.  Returns the previous value.  Host only. */
+int svae_lds_set_split_max_b(int max_b);
+
 /* Deterministic sum over the batch of the per-sequence global statistics (the quantity that is
  * all-reduced across GPUs for the natural-gradient step, svae.py:33-34):
  *   out (n*n + n + 3*n*n + 2) = [sum_b E_init | sum_b E_pair | sum_b lognorm | B]

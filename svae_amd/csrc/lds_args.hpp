@@ -9,6 +9,11 @@ namespace svae {
 constexpr int ws_h_stride(int n) { return (n + 1) + ((n + 1) & 1); }
 constexpr int ws_p_stride(int n) { return n + (n & 1); }
 constexpr int ws_step_doubles(int n) { return n * (ws_h_stride(n) + ws_p_stride(n)); }
+// Per sequence, ahead of the T step blocks: a constant page [e_n (H stride) | zeros (P stride)] that
+// the lanes >= n read instead of a hand-off row (keeps every hot-loop load unconditional: a
+// conditional load makes hipcc wait for it at the join, which defeats the prefetch).
+constexpr int ws_zpage_doubles(int n) { return ws_h_stride(n) + ws_p_stride(n); }
+constexpr long ws_seq_doubles(int n, int T) { return ws_zpage_doubles(n) + (long)T * ws_step_doubles(n); }
 
 struct LdsArgs {
   int B, T;
@@ -32,6 +37,8 @@ struct LdsArgs {
   double* __restrict__ ws2;   // factor region for the sampler (nullptr: not kept)
   long pair_seq_stride;  // doubles between consecutive sequences' pair blocks (0 = shared)
   int rows_per_wave;     // sequences per wavefront: 4 (throughput) .. 1 (latency, small batches)
+  int debug_flags;       // timing ablations only (env SVAE_LDS_DEBUG_FLAGS): 1 = skip backward half,
+                         // 2 = skip the Schur/product stage of the forward half.  Results are wrong.
 };
 
 struct SampleArgs {

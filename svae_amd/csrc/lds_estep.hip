@@ -10,6 +10,7 @@
 
 extern "C" {
 #define SVAE_DECL_(NN) int svae_lds_launch_n##NN(const svae::LdsArgs*, int, void*); \
+  int svae_lds_launch_split_n##NN(const svae::LdsArgs*, int, void*);           \
   int svae_lds_sample_n##NN(const svae::SampleArgs*, void*);
 #define SVAE_DECL(NN) SVAE_DECL_(NN)
 #ifdef SVAE_ONLY_N   /* experimental single-n builds (tools/build_variant.sh) */
@@ -68,9 +69,29 @@ static int svae_lds_rows_per_wave(int B) {
   return cached;
 }
 
+// Batches up to this size run the latency variant (one sequence per wavefront, product stages split
+// across the DPP rows: lds_estep_split.hpp); larger ones the packed kernel (four sequences per
+// wavefront).  Measured crossover on MI355X (T=200, n=10): B ~ 1024 (one wavefront per SIMD).
+// Override: SVAE_LDS_SPLIT_MAX_B (0 = never).
+static int g_split_max_b = -1;
+static int svae_lds_split_max_b(void) {
+  if (g_split_max_b < 0) {
+    const char* e = getenv("SVAE_LDS_SPLIT_MAX_B");
+    g_split_max_b = e ? atoi(e) : 1023;
+    if (g_split_max_b < 0) g_split_max_b = 0;
+  }
+  return g_split_max_b;
+}
+
+int svae_lds_set_split_max_b(int max_b) {
+  const int old = svae_lds_split_max_b();
+  g_split_max_b = max_b < 0 ? 0 : max_b;
+  return old;
+}
+
 int svae_hip_abi_version(void) { return SVAE_HIP_ABI_VERSION; }
 
-static size_t main_ws_doubles(int B, int T, int n) { return (size_t)B * T * svae::ws_step_doubles(n); }
+static size_t main_ws_doubles(int B, int T, int n) { return (size_t)B * svae::ws_seq_doubles(n, T); }
 static size_t factor_ws_doubles(int B, int T, int n) { return (size_t)B * T * (n * n + n); }
 
 size_t svae_lds_workspace_bytes(int B, int T, int n) {
@@ -116,8 +137,11 @@ int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int k
   a.ws2 = keep_factor ? (double*)workspace + main_ws_doubles(B, T, n) : nullptr;
   a.pair_seq_stride = pair_batched ? (long)(T - 1) * n * n : 0;
   a.rows_per_wave = svae_lds_rows_per_wave(B);
+  const bool split = B <= svae_lds_split_max_b();
+  { const char* e = getenv("SVAE_LDS_DEBUG_FLAGS"); a.debug_flags = e ? atoi(e) : 0; }
   switch (n) {
-#define SVAE_CASE_(NN) case NN: return svae_lds_launch_n##NN(&a, inhomog, stream);
+#define SVAE_CASE_(NN) case NN: return split ? svae_lds_launch_split_n##NN(&a, inhomog, stream) \
+                                             : svae_lds_launch_n##NN(&a, inhomog, stream);
 #define SVAE_CASE(NN) SVAE_CASE_(NN)
 #ifdef SVAE_ONLY_N
     SVAE_CASE(SVAE_ONLY_N)

@@ -67,6 +67,101 @@ __device__ __forceinline__ void rows_lane_bcast(double (&out)[MO], const double 
   });
 }
 
+// ---- in-place Gauss-Jordan on [P | X] ------------------------------------------------------------
+// P (SPD, column layout) -> P^-1, X -> P^-1 X; pivots = LDL' diagonal (no pivoting needed).  Per pivot k:
+// scaled pivot rows r, rx; every other row i: lane k of P[i] becomes the inverse's column (0 - m/p),
+// the other lanes P[i] - m r, and X[i] -= m rx, with m = P[i][k] broadcast from lane k (DPP).
+// Software pipelining by hand (hipcc would otherwise put the whole reciprocal chain of pivot k+1
+// behind the row updates of pivot k, stalling ~100 cycles per pivot): row k+1 is updated first, its
+// pivot is broadcast, and v_rcp_f64 + the two Newton steps are issued as asm statements BETWEEN the
+// remaining row updates.
+__device__ __forceinline__ double asm_rcp(double p) {
+  double r;
+  asm volatile("v_rcp_f64 %0, %1\n\ts_nop 0" : "=v"(r) : "v"(p));   // trans result: 1 wait state
+  return r;
+}
+__device__ __forceinline__ double asm_fnma1(double a, double b) {        // 1 - a*b
+  double r;
+  asm volatile("v_fma_f64 %0, -%1, %2, 1.0" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double asm_fma(double a, double b, double c) { // a*b + c
+  double r;
+  asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+template <int N, bool CHOL, class StoreR>
+__device__ __forceinline__ void gauss_jordan(double (&P)[N], double (&X)[N], const double (&E)[N],
+                                             double& qacc, double& pmin, double& ldM, int& ldE,
+                                             double& pv, StoreR&& store_r) {
+  double p = bcast_fenced<0>(P[0]);
+  double rinv = rcp_nr(p);
+  double pprod = 1.0;
+  static_for<0, N>([&](auto k) {
+    pmin = fmin(pmin, p);
+    pprod *= p;
+    // scaled pivot rows; lane k of r gets 1/p (the inverse's diagonal entry)
+    const double r = __builtin_fma(E[k], 1.0 - p, P[k]) * rinv;
+    const double rx = X[k] * rinv;
+    qacc = __builtin_fma(X[k], rx, qacc);            // lane N: z_k^2 / d_k  (h' P^-1 h = sum_k)
+    if constexpr (CHOL) {
+      pv = __builtin_fma(E[k], p, pv);
+      store_r(k, r);                                 // lanes j > k hold L_unit[j][k] (P = L D L')
+    }
+    auto update = [&](auto i, auto fenced) {
+      const double old = P[i];
+      double acc = __builtin_fma(-old, E[k], old);
+      mac_bc<k, true, decltype(fenced)::value>(acc, old, r);
+      mac_bc<k, true>(X[i], old, rx);
+      P[i] = acc;
+    };
+    if constexpr (k + 1 < N) {
+      update(std::integral_constant<int, k + 1>{}, std::true_type{});
+      const double pn = bcast_fenced<k + 1>(P[k + 1]);
+      // reciprocal chain of the NEXT pivot, one step after every other remaining row update
+      double t0 = 0.0, e0 = 0.0, t1 = 0.0, e1 = 0.0, rn = 0.0;
+      constexpr int REM = N - 2;                       // row updates still to come
+      auto chain = [&](auto s) {
+        if constexpr (s == 0) t0 = asm_rcp(pn);
+        else if constexpr (s == 1) e0 = asm_fnma1(pn, t0);
+        else if constexpr (s == 2) t1 = asm_fma(t0, e0, t0);
+        else if constexpr (s == 3) e1 = asm_fnma1(pn, t1);
+        else if constexpr (s == 4) rn = asm_fma(t1, e1, t1);
+      };
+      if constexpr (REM == 0) static_for<0, 5>(chain);
+      static_for<0, N>([&](auto i) {
+        if constexpr (i != k && i != k + 1) {
+          constexpr int pos = i - (i > k ? 1 : 0) - (i > k + 1 ? 1 : 0);     // 0 .. REM-1
+          update(i, std::false_type{});
+          // spread the 5 chain steps over the REM gaps (all remaining ones after the last update)
+          constexpr int lo = pos * 5 / REM, hi = (pos + 1) * 5 / REM;
+          static_for<lo, hi>(chain);
+        }
+      });
+      p = pn;
+      rinv = rn;
+    } else {
+      static_for<0, N>([&](auto i) {
+        if constexpr (i != k) {
+          if constexpr (i == 0 || (k == 0 && i == 1)) update(i, std::true_type{});
+          else update(i, std::false_type{});
+        }
+      });
+    }
+    P[k] = r;
+    X[k] = rx;
+    if constexpr (k == N / 2 || k == N - 1) {      // keep the running product in range
+      ldE += __builtin_amdgcn_frexp_exp(pprod);
+      ldM *= __builtin_amdgcn_frexp_mant(pprod);
+      pprod = 1.0;
+    }
+  });
+  const int e = __builtin_amdgcn_frexp_exp(ldM);
+  ldM = __builtin_amdgcn_frexp_mant(ldM);
+  ldE += e;
+}
+
 #ifndef SVAE_IL
 #define SVAE_IL 4     // independent accumulation chains interleaved per DPP product stage
 #endif
@@ -109,6 +204,8 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
   double E[N];
   static_for<0, N>([&](auto i) { E[i] = (c == i) ? 1.0 : 0.0; });
   const double EN = (c == N) ? 1.0 : 0.0;
+  double Em2[N];                           // -2 E: node precision diagonal from the natural parameter
+  static_for<0, N>([&](auto i) { Em2[i] = (c == i) ? -2.0 : 0.0; });
 
   // ---- pair parameters (info form: J = -2 natJ, J12 = -natJ12), column c per lane -------------
   //   NJ12T[i][c] = -J12[c][i]      J12c[k][c] = J12[k][c]      (lanes >= N: 0)
@@ -120,14 +217,16 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
   auto load_pair = [&](int t, bool with_next_J11) {   // pair t (and J11 of pair t+1)
     const long o = INHOMOG ? (long)t * N * N : 0;
     const long o1 = INHOMOG ? (long)(t + 1) * N * N : 0;
-    static_for<0, N>([&](auto i) {
-      NJ12T[i] = col ? pJ12[o + cc * N + i] : 0.0;
-      const double j22 = col ? -2.0 * pJ22[o + i * N + cc] : 0.0;
+    static_for<0, N>([&](auto i) {      // unconditional loads, selected afterwards
+      const double r12t = pJ12[o + cc * N + i], r22 = pJ22[o + i * N + cc], r12 = pJ12[o + i * N + cc];
+      const double r11 = with_next_J11 ? pJ11[o1 + i * N + cc] : 0.0;
+      NJ12T[i] = col ? r12t : 0.0;
+      const double j22 = col ? -2.0 * r22 : 0.0;
       if constexpr (!LOWREG) {
-        J12c[i] = col ? -pJ12[o + i * N + cc] : 0.0;
+        J12c[i] = col ? -r12 : 0.0;
         J22c[i] = j22;
       }
-      Cc[i] = j22 + ((col && with_next_J11) ? -2.0 * pJ11[o1 + i * N + cc] : 0.0);
+      Cc[i] = col ? -2.0 * (r22 + r11) : 0.0;
     });
   };
   if (!INHOMOG && T > 1) { load_pair(0, true); dpp_fence(NJ12T); }
@@ -137,13 +236,16 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
   // alone at t = T-1); lane N = h_pred (column layout: register i holds component i).
   double An[N];
   static_for<0, N>([&](auto i) {
-    An[i] = col ? -2.0 * a.init_J[i * N + cc] : ((c == N) ? a.init_h[i] : 0.0);
-    if (T > 1) An[i] += col ? -2.0 * pJ11[i * N + cc] : 0.0;
+    const double ij = a.init_J[i * N + cc], ih = a.init_h[i], j11 = T > 1 ? pJ11[i * N + cc] : 0.0;
+    An[i] = col ? -2.0 * (ij + j11) : ((c == N) ? ih : 0.0);
   });
 
   const double* nJ = a.node_J + ((long)b * T) * N + cc;
   const double* nh = a.node_h + ((long)b * T) * N + cc;
-  double* wsb = a.ws + ((long)b * T) * WS;
+  double* zpage = a.ws + (long)b * ws_seq_doubles(N, T);   // [e_N | 0] rows for the lanes >= N
+  double* wsb = zpage + ws_zpage_doubles(N);
+  if (c < HS) zpage[c] = EN;
+  if (c < PS) zpage[HS + c] = 0.0;
   // CHOL: also keep the unit-upper factor rows (the scaled pivot rows) and the pivots of P_t for the
   // backward sampler (svae_lds_sample_f64): N*N + N doubles per step in the second workspace region.
   double* ws2b = CHOL ? a.ws2 + ((long)b * T) * (N * N + N) + cc : nullptr;
@@ -153,30 +255,39 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
   int ldE = 0;             // ... and exponent sum (one log at the very end)
   double pmin = 1.0;       // smallest pivot seen (<= 0 => not positive definite)
 
-  double Jo_n = col ? -2.0 * nJ[0] : 0.0;
-  double ho_n = col ? nh[0] : 0.0;
+  // prefetched RAW (no arithmetic on a prefetched value before its step: the multiply would make
+  // the wave wait for the load -- and, vmcnt being in-order, for the previous step's stores)
+  double Jo_n = nJ[0];             // unconditional loads (lanes >= N read a valid dummy element)
+  double ho_n = nh[0];
 
+#ifdef SVAE_PHASE_TIMING
+  long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define TICK(i) { const long long now_ = __builtin_readcyclecounter(); tm[i] += now_ - tlast_; tlast_ = now_; }
+  long long tlast_ = __builtin_readcyclecounter();
+#else
+#define TICK(i)
+#endif
   for (int t = 0; t < T; ++t) {
     const bool last = (t == T - 1);
     const double Jo = Jo_n;
     double ho = ho_n;
     if (!last) {
-      Jo_n = col ? -2.0 * nJ[(long)(t + 1) * N] : 0.0;
-      ho_n = col ? nh[(long)(t + 1) * N] : 0.0;
+      Jo_n = nJ[(long)(t + 1) * N];
+      ho_n = nh[(long)(t + 1) * N];
     }
     if (INHOMOG && !last) { load_pair(t, t + 1 < T - 1); dpp_fence(NJ12T); }
 
     // condition on the node potential: P = A + diag(J_node); right-hand sides X = [J12 | h_filt]
     // (h_filt = h_pred + h_node lands in lane N, register i <- lane i of the row-layout h_node)
     double P[N], X[N];
-    static_for<0, N>([&](auto i) { P[i] = __builtin_fma(Jo, E[i], An[i]); });
+    static_for<0, N>([&](auto i) { P[i] = __builtin_fma(Jo, Em2[i], An[i]); });   // + diag(-2 natJ)
     if (last) {
       asm volatile("; last step: no pair potential, G = 0");   // keep this a branch
       static_for<0, N>([&](auto i) { X[i] = EN * An[i]; });
     } else {
       if constexpr (LOWREG) {
         const long o = INHOMOG ? (long)t * N * N : 0;
-        static_for<0, N>([&](auto i) { X[i] = __builtin_fma(EN, An[i], col ? -pJ12[o + i * N + cc] : 0.0); });
+        static_for<0, N>([&](auto i) { const double r = pJ12[o + i * N + cc]; X[i] = __builtin_fma(EN, An[i], col ? -r : 0.0); });
       } else {
         static_for<0, N>([&](auto i) { X[i] = __builtin_fma(EN, An[i], J12c[i]); });
       }
@@ -184,67 +295,28 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
     dpp_fence(ho);
     static_for<0, N>([&](auto i) { mac_bc<i>(X[i], ho, EN); });
     dpp_fence(P);
+    TICK(0)
 
-    // In-place Gauss-Jordan (SPD => no pivoting): P -> P^-1, X -> P^-1 X; pivots = LDL' diagonal.
-    // Row k+1 is updated first so the next pivot's reciprocal chain overlaps the other row updates.
-    double p = bcast_fenced<0>(P[0]);
-    double pprod = 1.0;
+    // in-place Gauss-Jordan: P -> P^-1, X -> P^-1 X (gauss_jordan above)
     double pv = 0.0;                                   // CHOL: lane k <- pivot k
     double* w2 = CHOL ? ws2b + (long)t * (N * N + N) : nullptr;
-    static_for<0, N>([&](auto k) {
-      pmin = fmin(pmin, p);
-      pprod *= p;
-      const double rinv = rcp_nr(p);
-      // scaled pivot rows; lane k of r gets 1/p (the inverse's diagonal entry)
-      const double r = __builtin_fma(E[k], 1.0 - p, P[k]) * rinv;
-      const double rx = X[k] * rinv;
-      qacc = __builtin_fma(X[k], rx, qacc);            // lane N: z_k^2 / d_k  (h' P^-1 h = sum_k)
-      if constexpr (CHOL) {
-        pv = __builtin_fma(E[k], p, pv);
-        if (st) w2[k * N] = r;       // lanes j > k hold L_unit[j][k] (P = L D L')
-      }
-      auto update = [&](auto i, auto fenced) {
-        // lane k: its column becomes the inverse's column, 0 - m/p; other lanes: P_i - m r
-        const double old = P[i];
-        double acc = __builtin_fma(-old, E[k], old);
-        mac_bc<k, true, decltype(fenced)::value>(acc, old, r);
-        mac_bc<k, true>(X[i], old, rx);
-        P[i] = acc;
-      };
-      if constexpr (k + 1 < N) update(std::integral_constant<int, k + 1>{}, std::true_type{});
-      static_for<0, N>([&](auto i) {
-        if constexpr (i != k && i != k + 1) {
-          if constexpr (k + 1 >= N && i == 0) update(i, std::true_type{});
-          else update(i, std::false_type{});
-        }
-      });
-      if constexpr (k + 1 < N) p = bcast_fenced<k + 1>(P[k + 1]);
-      P[k] = r;
-      X[k] = rx;
-      if constexpr (k == N / 2 || k == N - 1) {      // keep the running product in range
-        ldE += __builtin_amdgcn_frexp_exp(pprod);
-        ldM *= __builtin_amdgcn_frexp_mant(pprod);
-        pprod = 1.0;
-      }
-    });
-    {
-      const int e = __builtin_amdgcn_frexp_exp(ldM);
-      ldM = __builtin_amdgcn_frexp_mant(ldM);
-      ldE += e;
-    }
+    gauss_jordan<N, CHOL>(P, X, E, qacc, pmin, ldM, ldE, pv,
+                          [&](auto kk, double r) { if (st) w2[kk * N] = r; });
     if constexpr (CHOL) { if (st) w2[N * N] = pv; }
+    TICK(1)
 
     // hand-off to the backward half: row i of [P^-1 J12 | c] (lanes 0..N) and of P^-1 (lanes < N)
     double* w = wsb + (long)t * WS;
     if (sth) static_for<0, N>([&](auto i) { w[i * HS + c] = X[i]; });
     if (st) static_for<0, N>([&](auto i) { w[N * HS + i * PS + c] = P[i]; });
+    TICK(2)
 
-    if (!last) {
+    if (!last && !(a.debug_flags & 2)) {
       // next pivot block  A' = (J22 + J11) - J12' P^-1 J12  (lanes < N),  h_pred' = -J12' c  (lane N)
       const bool next_last = (t + 1 == T - 1);
       if (!INHOMOG && next_last) {
         asm volatile("; next step is the last: its pivot block has no J11 term");   // keep a branch
-        if constexpr (LOWREG) static_for<0, N>([&](auto i) { An[i] = col ? -2.0 * pJ22[i * N + cc] : 0.0; });
+        if constexpr (LOWREG) static_for<0, N>([&](auto i) { const double r = pJ22[i * N + cc]; An[i] = col ? -2.0 * r : 0.0; });
         else static_for<0, N>([&](auto i) { An[i] = J22c[i]; });
       } else {
         static_for<0, N>([&](auto i) { An[i] = Cc[i]; });
@@ -252,6 +324,7 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
       asm volatile("s_nop 1");   // block entry: two wait states before the first DPP read (audit rule)
       static_for<0, (N + IL - 1) / IL>([&](auto g) { rows_src_bcast<IL, g * IL, N, 0>(An, NJ12T, X); });
     }
+    TICK(3)
   }
 
   // ---- log-normaliser --------------------------------------------------------------------------
@@ -280,6 +353,11 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
     }
   }
 
+#ifdef SVAE_PHASE_TIMING
+  if (valid && c == 0) { for (int q = 0; q < 4; ++q) a.E_init[(long)b * (N * N + N) + q] = (double)tm[q]; }
+  return;
+#endif
+  if (a.debug_flags & 1) return;
   // ---- backward pass in moment form on homogeneous coordinates ---------------------------------
   // S[i] = row i of S~ (i = 0..N), lane c = column c (c = 0..N).  Start from S~_T := e_N e_N' so
   // that the generic step at t = T-1 (where G = 0, c = mu_{T-1}) yields [[Sigma+mu mu', mu],[mu',1]].
@@ -298,15 +376,17 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
 
   // lane c < N reads ROW c of H (-> H[k] = H[c][k], the transposition G -> G') and row c of the
   // symmetric P^-1, both contiguous and 16-byte aligned.
-  auto load_step = [&](int t, double (&h)[N + 1], double (&pi)[N]) {
-    const double* w = wsb + (long)t * WS;
-    if (col) {
-      load_row<N + 1>(w + cc * HS, h);
-      load_row<N>(w + N * HS + cc * PS, pi);
-    } else {
-      static_for<0, N>([&](auto k) { h[k] = 0.0; pi[k] = 0.0; });
-      h[N] = EN;
-    }
+  // lanes >= N read the constant page ([e_N | 0], stride 0) instead: no branch around the loads
+  const double* hrow0 = col ? wsb + cc * HS : zpage;
+  const double* prow0 = col ? wsb + N * HS + cc * PS : zpage + HS;
+  const long tstride = col ? WS : 0;
+  const double* hp_ = hrow0 + (long)(T - 1) * tstride;     // walking pointers: steps T-1, T-2, ..
+  const double* pp_ = prow0 + (long)(T - 1) * tstride;
+  auto load_step = [&](int, double (&h)[N + 1], double (&pi)[N]) {
+    load_row<N + 1>(hp_, h);
+    load_row<N>(pp_, pi);
+    hp_ -= tstride;
+    pp_ -= tstride;
   };
 
   // one backward step: consumes (H, Pi) of step t, prefetches step t-1 into (Hn, Pin)
@@ -429,7 +509,7 @@ __global__ __launch_bounds__(64) void lds_sample_kernel(const SampleArgs a) {
   const bool col = c < N;
   const int cc = col ? c : 0;
   const int T = a.T, S = a.S;
-  const double* wsb = a.ws + ((long)b * T) * WS;
+  const double* wsb = a.ws + (long)b * ws_seq_doubles(N, T) + ws_zpage_doubles(N);
   const double* ws2b = a.ws2 + ((long)b * T) * (N * N + N) + cc;
 
   for (int s0 = 0; s0 < S; s0 += 16) {

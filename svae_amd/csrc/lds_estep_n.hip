@@ -6,6 +6,7 @@
 #define SVAE_DPP_ALWAYS_FENCED 1
 #endif
 #include "lds_estep_kernel.hpp"
+#include "lds_estep_split.hpp"
 
 #ifndef SVAE_N
 #error "compile with -DSVAE_N=<latent dim>"
@@ -19,4 +20,8 @@ extern "C" int SVAE_CAT(svae_lds_launch_n, SVAE_N)(const svae::LdsArgs* a, int i
 
 extern "C" int SVAE_CAT(svae_lds_sample_n, SVAE_N)(const svae::SampleArgs* a, void* stream) {
   return svae::launch_sample<SVAE_N>(*a, (hipStream_t)stream);
+}
+
+extern "C" int SVAE_CAT(svae_lds_launch_split_n, SVAE_N)(const svae::LdsArgs* a, int inhomog, void* stream) {
+  return svae::launch_estep_split<SVAE_N>(*a, inhomog != 0, (hipStream_t)stream);
 }

@@ -17,7 +17,8 @@ def _header_symbols():
 
 def test_header_declares_the_expected_entry_points():
     syms = _header_symbols()
-    for s in ("svae_lds_estep_f64", "svae_lds_workspace_bytes", "svae_lds_reduce_stats_f64",
+    for s in ("svae_lds_estep_f64", "svae_lds_workspace_bytes", "svae_lds_set_split_max_b",
+              "svae_lds_reduce_stats_f64",
               "svae_lds_sample_f64", "svae_gmm_meanfield_f64", "svae_hip_abi_version"):
         assert s in syms
 
@@ -36,8 +37,9 @@ def test_workspace_size_formula():
     lib = _lib.load()
     # main region: n rows of [P^-1 J12 | c] (stride even(n+1)) + n rows of P^-1 (stride even(n));
     # factor region: n*n + n
-    assert lib.svae_lds_workspace_bytes(512, 200, 10) == 512 * 200 * (10 * (12 + 10) + 10 * 10 + 10) * 8
-    assert lib.svae_lds_workspace_bytes(3, 7, 5) == 3 * 7 * (5 * (6 + 6) + 5 * 5 + 5) * 8
+    # plus one constant page (12 + 10 doubles) per sequence
+    assert lib.svae_lds_workspace_bytes(512, 200, 10) == 512 * (22 + 200 * (10 * (12 + 10) + 10 * 10 + 10)) * 8
+    assert lib.svae_lds_workspace_bytes(3, 7, 5) == 3 * (12 + 7 * (5 * (6 + 6) + 5 * 5 + 5)) * 8
     assert lib.svae_lds_workspace_bytes(1, 1, 16) == 0     # n > 15: outside the register path
     assert lib.svae_lds_workspace_bytes(0, 5, 3) == 0
 

@@ -18,6 +18,17 @@ from oracle import lds_numpy, ref  # noqa: E402  (checker only)
 LDS_CASES = ["lds_T5_n3", "lds_T20_n10", "lds_T200_n10", "lds_T1_n4", "lds_T2_n15"]
 
 
+@pytest.fixture(params=["split", "packed"], autouse=True)
+def kernel_variant(request):
+    """Run every test through both E-step kernels: the small-batch variant (one sequence per
+    wavefront) and the packed one (four per wavefront)."""
+    from svae_amd import _lib
+    lib = _lib.load()
+    old = lib.svae_lds_set_split_max_b(1 << 30 if request.param == "split" else 0)
+    yield request.param
+    lib.svae_lds_set_split_max_b(old)
+
+
 def _rel(a, b):
     a = a.detach().cpu().numpy() if hasattr(a, "detach") else np.asarray(a, float)
     b = np.asarray(b, float)
