@@ -204,13 +204,11 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
   double E[N];
   static_for<0, N>([&](auto i) { E[i] = (c == i) ? 1.0 : 0.0; });
   const double EN = (c == N) ? 1.0 : 0.0;
-  double Em2[N];                           // -2 E: node precision diagonal from the natural parameter
-  static_for<0, N>([&](auto i) { Em2[i] = (c == i) ? -2.0 : 0.0; });
 
   // ---- pair parameters (info form: J = -2 natJ, J12 = -natJ12), column c per lane -------------
   //   NJ12T[i][c] = -J12[c][i]      J12c[k][c] = J12[k][c]      (lanes >= N: 0)
   //   Cc[i][c]    =  J22[i][c] + J11[i][c]   (next step's pivot block without the node diagonal)
-  double NJ12T[N], J12c[LOWREG ? 1 : N], Cc[N], J22c[LOWREG ? 1 : N];
+  double NJ12T[N], J12c[LOWREG ? 1 : N], Cc[N];   // (J22 alone is re-read from L2 for the one step that needs it)
   const double* pJ11 = a.J11 + (long)b * a.pair_seq_stride;
   const double* pJ12 = a.J12 + (long)b * a.pair_seq_stride;
   const double* pJ22 = a.J22 + (long)b * a.pair_seq_stride;
@@ -221,11 +219,7 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
       const double r12t = pJ12[o + cc * N + i], r22 = pJ22[o + i * N + cc], r12 = pJ12[o + i * N + cc];
       const double r11 = with_next_J11 ? pJ11[o1 + i * N + cc] : 0.0;
       NJ12T[i] = col ? r12t : 0.0;
-      const double j22 = col ? -2.0 * r22 : 0.0;
-      if constexpr (!LOWREG) {
-        J12c[i] = col ? -r12 : 0.0;
-        J22c[i] = j22;
-      }
+      if constexpr (!LOWREG) J12c[i] = col ? -r12 : 0.0;
       Cc[i] = col ? -2.0 * (r22 + r11) : 0.0;
     });
   };
@@ -269,7 +263,7 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
 #endif
   for (int t = 0; t < T; ++t) {
     const bool last = (t == T - 1);
-    const double Jo = Jo_n;
+    const double Jo = -2.0 * Jo_n;     // scaled one step AFTER its load was issued (see below)
     double ho = ho_n;
     if (!last) {
       Jo_n = nJ[(long)(t + 1) * N];
@@ -280,7 +274,7 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
     // condition on the node potential: P = A + diag(J_node); right-hand sides X = [J12 | h_filt]
     // (h_filt = h_pred + h_node lands in lane N, register i <- lane i of the row-layout h_node)
     double P[N], X[N];
-    static_for<0, N>([&](auto i) { P[i] = __builtin_fma(Jo, Em2[i], An[i]); });   // + diag(-2 natJ)
+    static_for<0, N>([&](auto i) { P[i] = __builtin_fma(Jo, E[i], An[i]); });
     if (last) {
       asm volatile("; last step: no pair potential, G = 0");   // keep this a branch
       static_for<0, N>([&](auto i) { X[i] = EN * An[i]; });
@@ -316,8 +310,7 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
       const bool next_last = (t + 1 == T - 1);
       if (!INHOMOG && next_last) {
         asm volatile("; next step is the last: its pivot block has no J11 term");   // keep a branch
-        if constexpr (LOWREG) static_for<0, N>([&](auto i) { const double r = pJ22[i * N + cc]; An[i] = col ? -2.0 * r : 0.0; });
-        else static_for<0, N>([&](auto i) { An[i] = J22c[i]; });
+        static_for<0, N>([&](auto i) { const double r = pJ22[i * N + cc]; An[i] = col ? -2.0 * r : 0.0; });
       } else {
         static_for<0, N>([&](auto i) { An[i] = Cc[i]; });
       }

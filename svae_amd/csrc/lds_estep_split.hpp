@@ -55,8 +55,6 @@ __global__ __launch_bounds__(64) void lds_estep_split_kernel(const LdsArgs a) {
   double E[N];
   static_for<0, N>([&](auto i) { E[i] = (c == i) ? 1.0 : 0.0; });
   const double EN = (c == N) ? 1.0 : 0.0;
-  double Em2[N];                           // -2 E: node precision diagonal from the natural parameter
-  static_for<0, N>([&](auto i) { Em2[i] = (c == i) ? -2.0 : 0.0; });
   double ED[J1];                          // ED[j][c] = (c == 4j+g): picks S[i][i] in slot layout
   static_for<0, J1>([&](auto j) { ED[j] = (c == 4 * j + g && c < N) ? 1.0 : 0.0; });
 
@@ -107,7 +105,7 @@ __global__ __launch_bounds__(64) void lds_estep_split_kernel(const LdsArgs a) {
 
   for (int t = 0; t < T; ++t) {
     const bool last = (t == T - 1);
-    const double Jo = Jo_n;
+    const double Jo = -2.0 * Jo_n;     // scaled one step AFTER its load was issued (see below)
     double ho = ho_n;
     if (!last) {
       Jo_n = nJ[(long)(t + 1) * N];
@@ -116,7 +114,7 @@ __global__ __launch_bounds__(64) void lds_estep_split_kernel(const LdsArgs a) {
     if (INHOMOG && !last) { load_pair(t, t + 1 < T - 1); dpp_fence(NJ12T); }
 
     double P[N], X[N];
-    static_for<0, N>([&](auto i) { P[i] = __builtin_fma(Jo, Em2[i], An[i]); });   // + diag(-2 natJ)
+    static_for<0, N>([&](auto i) { P[i] = __builtin_fma(Jo, E[i], An[i]); });
     if (last) {
       asm volatile("; last step: no pair potential, G = 0");
       static_for<0, N>([&](auto i) { X[i] = EN * An[i]; });
