@@ -125,6 +125,21 @@ def main():
         elapsed = float(el.item())
 
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
+    # which E-step kernel the library dispatched to (include/svae_hip.h: svae_lds_set_split_max_b)
+    from svae_amd import _lib
+    lib = _lib.load()
+    split_max = lib.svae_lds_set_split_max_b(0)
+    lib.svae_lds_set_split_max_b(split_max)
+    kernel = ("svae::lds_estep_split_kernel<%d,false,false>" if B <= split_max
+              else "svae::lds_estep_kernel<%d,false,false>") % n
+    # HBM traffic of that kernel from the committed rocprofv3 PMC passes (separate runs of this
+    # same command, see profiles/run_profile.sh); only quoted when the workload matches.
+    traffic, traffic_src = None, None
+    prof = os.path.join(ROOT, "profiles", "r1_final" if B == 512 else "r1_final_b%d" % B, "pmc_hbm.json")
+    if os.path.isfile(prof):
+        p = json.load(open(prof))
+        if kernel.split("<")[0] in p.get("kernel", ""):
+            traffic, traffic_src = p["hbm_bytes_per_launch_corrected"], os.path.relpath(prof, ROOT)
     if rank == 0:
         total_seqs = B * world * args.steps
         bytes_launch = B * algorithmic_bytes_per_seq(T, n)
@@ -142,8 +157,10 @@ def main():
                        "parallelism": "dp%d" % world,
                        "step": "estep kernel + batch stat reduce" + (" + RCCL all-reduce" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": "svae::lds_estep_kernel<10,false>", "kernel_ms": kern_ms,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "traffic_unit": "bytes per launch (rocprofv3 PMC, 2*FETCH_SIZE+WRITE_SIZE)",
+                         "traffic_source": traffic_src,
+                         "kernel": kernel, "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": bytes_launch,
                          "kernel_sequences_per_s": B / (kern_ms * 1e-3)},
         }
