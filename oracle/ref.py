@@ -80,3 +80,39 @@ def sample_backward(natparam, node_params, num_samples, seed):
     np.random.seed(seed)
     eps = np.random.randn(T, num_samples, N)[::-1].copy()
     return np.asarray(samples), eps
+
+
+def estep_vjp(natparam, node_params, g_lognorm, g_E_node, g_samples=None, seed=0):
+    """Composite reverse-mode derivative w.r.t. node_params, wired exactly as the reference wires its
+    autograd primitives (svae/lds/lds_inference.py:26-39):
+        natural_filter_grad            cython_lds_inference.pyx:92-145   (argnum 2 = node_params)
+        natural_smoother_general_grad  cython_lds_inference.pyx:236-306  (argnum 0 = messages)
+        natural_sample_backward_grad   cython_lds_inference.pyx:357-409  (argnum 0 = messages)
+    g_E_node = (g_diagExxT (T,n), g_Ex (T,n)); cotangents of E_init / E_pair are zero (the model code
+    never differentiates the global statistics: svae.py:21 stores them in `saved.stats`).
+    Returns (g_node_J, g_node_h, g_node_logZ) and, if sampling, the eps used (re-indexed by time)."""
+    import numpy as np
+    m = _load("cython_lds_inference")
+    init_params, pair_params = natparam
+    init_params = (init_params[0], init_params[1], sum(init_params[2:]))
+    (messages, lognorm), aux_f = m.natural_filter_forward_general(init_params, pair_params, node_params)
+    T, n = np.asarray(node_params[1]).shape
+    (E_init, E_pair, E_node), aux_s = m.natural_smoother_general(messages, pair_params)
+    g_stats = ((np.zeros((n, n)), np.zeros(n), 0., 0.),
+               (np.zeros((n, n)), np.zeros((n, n)), np.zeros((n, n)), 0.),
+               (np.array(g_E_node[0], dtype=float, copy=True), np.array(g_E_node[1], dtype=float, copy=True),
+                np.zeros(T)))   # copies: _compute_stats_grad (:212-234) accumulates into its inputs
+    (gJp, ghp), (gJf, ghf) = m.natural_smoother_general_grad(g_stats, aux_s)
+    gJp, ghp, gJf, ghf = [np.array(x, dtype=float, copy=True) for x in (gJp, ghp, gJf, ghf)]
+    eps = None
+    if g_samples is not None:
+        S = g_samples.shape[1]
+        np.random.seed(seed)
+        samples, aux_x = m.natural_sample_backward(messages, pair_params, S)
+        np.random.seed(seed)
+        eps = np.random.randn(T, S, n)[::-1].copy()
+        (aJp, ahp), (aJf, ahf) = m.natural_sample_backward_grad(np.array(g_samples, dtype=float, copy=True), aux_x)
+        gJp += aJp; ghp += ahp; gJf += aJf; ghf += ahf
+    g = (((gJp, ghp), (gJf, ghf)), float(g_lognorm))
+    gJ, gh, gz = m.natural_filter_grad(g, aux_f)
+    return (np.asarray(gJ), np.asarray(gh), np.asarray(gz)), eps
