@@ -33,7 +33,8 @@ int svae_hip_abi_version(void);
 
 /* Bytes of scratch `svae_lds_estep_f64` / `svae_lds_sample_f64` need for (B, T, n): the per-step
  * backward kernels (G_t, c_t, P_t^-1: (2n+1)n doubles) written by the forward filter, followed by
- * the factor region (unit LDL' factor + pivots of P_t: n*n+n doubles) the sampler reads. */
+ * the factor region (unit LDL' factor + pivots of P_t: n*n+n doubles) the sampler reads and the
+ * cross-moment region (W~_t) the VJP reads. */
 size_t svae_lds_workspace_bytes(int B, int T, int n);
 
 /* Batched LDS E-step = filter + RTS smoother + expected sufficient statistics + log-normalizer.
@@ -51,8 +52,9 @@ size_t svae_lds_workspace_bytes(int B, int T, int n);
  *       pair_batched != 0 (inhomog only): J11/J12/J22 are (B,T-1,n,n), logZ_pair (B,T-1)
  *         (the SLDS case, slds_svae.py:92-103, where pair params depend on each sequence's
  *          discrete-state marginals)
- *       keep_factor != 0: also write the factor region of the workspace so that
- *         svae_lds_sample_f64 can follow (costs ~2% of the E-step)
+ *       keep: bit 0 = also write the factor region of the workspace so that svae_lds_sample_f64 can
+ *         follow; bit 1 = also write the cross-moment region so that svae_lds_estep_vjp_f64 can
+ *         follow (each costs a few % of the E-step)
  *       node_J (B,T,n) diagonal of -1/2 precision, node_h (B,T,n), node_logZ (B,T) or NULL (=0)
  *  out: lognorm (B)
  *       E_init  (B, n*n + n)      = [E[x0 x0'] (n,n) | E[x0] (n)]   (the two trailing 1's of the
@@ -63,7 +65,7 @@ size_t svae_lds_workspace_bytes(int B, int T, int n);
  *       E_node_diagxx (B,T,n) = diag E[x_t x_t'],   E_node_x (B,T,n) = E[x_t]
  *       info (1) int32, must be zeroed by the caller (or by a previous successful call)
  */
-int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int keep_factor,
+int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int keep,
                        const double* init_J, const double* init_h, const double* init_logZ,
                        const double* J11, const double* J12, const double* J22,
                        const double* logZ_pair,
@@ -94,6 +96,31 @@ int svae_lds_reduce_stats_f64(int B, int n, const double* E_init, const double* 
  */
 int svae_lds_sample_f64(int B, int T, int n, int S, const double* eps, double* samples,
                         const void* workspace, size_t ws_bytes, void* stream);
+
+/* Bytes of scratch svae_lds_estep_vjp_f64 needs in addition to the E-step workspace. */
+size_t svae_lds_vjp_workspace_bytes(int B, int T, int n);
+
+/* Reverse-mode derivative (vector-Jacobian product) of the E-step [+ sampler] w.r.t. the node
+ * potentials, for the LAST svae_lds_estep_f64 call on `workspace` with keep = 3 (and, if g_samples
+ * is given, the svae_lds_sample_f64 call that followed).  One entry point for what the reference
+ * wires as three autograd primitives (/root/reference/svae/lds/lds_inference.py:26-39):
+ *   natural_filter_grad            /root/reference/svae/lds/cython_lds_inference.pyx:92-145
+ *   natural_smoother_general_grad  /root/reference/svae/lds/cython_lds_inference.pyx:236-306
+ *   natural_sample_backward_grad   /root/reference/svae/lds/cython_lds_inference.pyx:357-409
+ *  in : J12 (n,n) natural pair parameter (homogeneous pair parameters only)
+ *       g_lognorm (B); g_E_node_diagxx, g_E_node_x (B,T,n) or NULL; g_samples (B,T,S,n) or NULL with
+ *       the eps (B,T,S,n) and samples (B,T,S,n) of the sampler call (S <= 16)
+ *       (cotangents of E_init / E_pair are taken as zero: the model code never differentiates the
+ *        global statistics, /root/reference/svae/svae.py:21)
+ *  out: g_node_J (B,T,n), g_node_h (B,T,n)   [g_node_logZ[b,t] = g_lognorm[b]: trivial, left to the caller]
+ */
+int svae_lds_estep_vjp_f64(int B, int T, int n, int S, const double* J12,
+                           const double* g_lognorm, const double* g_E_node_diagxx,
+                           const double* g_E_node_x, const double* g_samples,
+                           const double* eps, const double* samples,
+                           double* g_node_J, double* g_node_h,
+                           const void* workspace, size_t ws_bytes,
+                           void* vjp_workspace, size_t vjp_ws_bytes, void* stream);
 
 /* GMM mean-field fixed point + global statistics for one minibatch of T points
  * [local_meanfield, /root/reference/svae/models/gmm.py:62-88; meanfield_fixed_point :90-110;

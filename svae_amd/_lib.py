@@ -27,6 +27,10 @@ SIGNATURES = {
                            + [_c_int_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "svae_lds_reduce_stats_f64": (ctypes.c_int, [ctypes.c_int] * 2 + [_c_double_p] * 4
                                   + [ctypes.c_void_p]),
+    "svae_lds_vjp_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
+    "svae_lds_estep_vjp_f64": (ctypes.c_int, [ctypes.c_int] * 4 + [_c_double_p] * 9
+                               + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
+                                  ctypes.c_void_p]),
     "svae_lds_sample_f64": (ctypes.c_int, [ctypes.c_int] * 4 + [_c_double_p] * 2
                             + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "svae_gmm_meanfield_f64": (ctypes.c_int, [ctypes.c_int] * 3 + [_c_double_p] * 5

@@ -35,6 +35,7 @@ struct LdsArgs {
   int32_t* __restrict__ info;
   double* __restrict__ ws;
   double* __restrict__ ws2;   // factor region for the sampler (nullptr: not kept)
+  double* __restrict__ ws3;   // cross-moment region for the VJP: W~_t, (n+1) rows x ws_h_stride per step
   long pair_seq_stride;  // doubles between consecutive sequences' pair blocks (0 = shared)
   int rows_per_wave;     // sequences per wavefront: 4 (throughput) .. 1 (latency, small batches)
   int debug_flags;       // timing ablations only (env SVAE_LDS_DEBUG_FLAGS): 1 = skip backward half,
@@ -48,5 +49,24 @@ struct SampleArgs {
   const double* __restrict__ ws;      // main region (G~' rows, c, P^-1)
   const double* __restrict__ ws2;     // factor region
 };
+
+// reverse-mode sweeps (lds_vjp_kernel.hpp)
+struct VjpArgs {
+  int B, T, S;
+  const double* __restrict__ J12;        // (n,n) natural pair parameter (homogeneous)
+  const double* __restrict__ g_lognorm;  // (B)
+  const double* __restrict__ g_diagxx;   // (B,T,n) or nullptr
+  const double* __restrict__ g_x;        // (B,T,n) or nullptr
+  const double* __restrict__ g_samples;  // (B,T,S,n) or nullptr
+  const double* __restrict__ eps;        // (B,T,S,n)   (with g_samples)
+  const double* __restrict__ samples;    // (B,T,S,n)   (with g_samples)
+  double* __restrict__ g_node_J;         // (B,T,n)
+  double* __restrict__ g_node_h;         // (B,T,n)
+  const double* __restrict__ ws;         // E-step main region
+  const double* __restrict__ ws2;        // factor region
+  const double* __restrict__ ws3;        // cross-moment region
+  double* __restrict__ adj;              // VJP scratch: per (b,t) n rows x (ws_h_stride + 2 ws_p_stride)
+};
+constexpr int vjp_step_doubles(int n) { return n * (ws_h_stride(n) + 2 * ws_p_stride(n)); }
 
 }  // namespace svae

@@ -11,7 +11,8 @@
 extern "C" {
 #define SVAE_DECL_(NN) int svae_lds_launch_n##NN(const svae::LdsArgs*, int, void*); \
   int svae_lds_launch_split_n##NN(const svae::LdsArgs*, int, void*);           \
-  int svae_lds_sample_n##NN(const svae::SampleArgs*, void*);
+  int svae_lds_sample_n##NN(const svae::SampleArgs*, void*);                   \
+  int svae_lds_vjp_n##NN(const svae::VjpArgs*, void*);
 #define SVAE_DECL(NN) SVAE_DECL_(NN)
 #ifdef SVAE_ONLY_N   /* experimental single-n builds (tools/build_variant.sh) */
 SVAE_DECL(SVAE_ONLY_N)
@@ -93,13 +94,14 @@ int svae_hip_abi_version(void) { return SVAE_HIP_ABI_VERSION; }
 
 static size_t main_ws_doubles(int B, int T, int n) { return (size_t)B * svae::ws_seq_doubles(n, T); }
 static size_t factor_ws_doubles(int B, int T, int n) { return (size_t)B * T * (n * n + n); }
+static size_t cross_ws_doubles(int B, int T, int n) { return (size_t)B * T * (n + 1) * svae::ws_h_stride(n); }
 
 size_t svae_lds_workspace_bytes(int B, int T, int n) {
   if (B <= 0 || T <= 0 || n <= 0 || n > SVAE_LDS_MAX_N) return 0;
-  return (main_ws_doubles(B, T, n) + factor_ws_doubles(B, T, n)) * sizeof(double);
+  return (main_ws_doubles(B, T, n) + factor_ws_doubles(B, T, n) + cross_ws_doubles(B, T, n)) * sizeof(double);
 }
 
-int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int keep_factor,
+int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int keep,
                        const double* init_J, const double* init_h, const double* init_logZ,
                        const double* J11, const double* J12, const double* J22,
                        const double* logZ_pair,
@@ -134,7 +136,8 @@ int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int k
   a.lognorm = lognorm; a.E_init = E_init; a.E_pair = E_pair;
   a.E_node_diagxx = E_node_diagxx; a.E_node_x = E_node_x;
   a.info = info; a.ws = (double*)workspace;
-  a.ws2 = keep_factor ? (double*)workspace + main_ws_doubles(B, T, n) : nullptr;
+  a.ws2 = (keep & 1) ? (double*)workspace + main_ws_doubles(B, T, n) : nullptr;
+  a.ws3 = (keep & 2) ? (double*)workspace + main_ws_doubles(B, T, n) + factor_ws_doubles(B, T, n) : nullptr;
   a.pair_seq_stride = pair_batched ? (long)(T - 1) * n * n : 0;
   a.rows_per_wave = svae_lds_rows_per_wave(B);
   const bool split = B <= svae_lds_split_max_b();
@@ -188,6 +191,55 @@ extern "C" int svae_lds_sample_f64(int B, int T, int n, int S, const double* eps
   a.ws2 = (const double*)workspace + main_ws_doubles(B, T, n);
   switch (n) {
 #define SVAE_CASE_(NN) case NN: return svae_lds_sample_n##NN(&a, stream);
+#define SVAE_CASE(NN) SVAE_CASE_(NN)
+#ifdef SVAE_ONLY_N
+    SVAE_CASE(SVAE_ONLY_N)
+#else
+    SVAE_CASE(1) SVAE_CASE(2) SVAE_CASE(3) SVAE_CASE(4) SVAE_CASE(5) SVAE_CASE(6) SVAE_CASE(7)
+    SVAE_CASE(8) SVAE_CASE(9) SVAE_CASE(10) SVAE_CASE(11) SVAE_CASE(12) SVAE_CASE(13)
+    SVAE_CASE(14) SVAE_CASE(15)
+#endif
+#undef SVAE_CASE
+#undef SVAE_CASE_
+  }
+  return -3;
+}
+
+extern "C" size_t svae_lds_vjp_workspace_bytes(int B, int T, int n) {
+  if (B <= 0 || T <= 0 || n <= 0 || n > SVAE_LDS_MAX_N) return 0;
+  return (size_t)B * T * svae::vjp_step_doubles(n) * sizeof(double);
+}
+
+extern "C" int svae_lds_estep_vjp_f64(int B, int T, int n, int S, const double* J12,
+                                      const double* g_lognorm, const double* g_E_node_diagxx,
+                                      const double* g_E_node_x, const double* g_samples,
+                                      const double* eps, const double* samples,
+                                      double* g_node_J, double* g_node_h,
+                                      const void* workspace, size_t ws_bytes,
+                                      void* vjp_workspace, size_t vjp_ws_bytes, void* stream) {
+  if (B < 0) return -1;
+  if (T < 1) return -2;
+  if (n < 1 || n > SVAE_LDS_MAX_N) return -3;
+  if (g_samples && (S < 1 || S > 16)) return -4;
+  if (T > 1 && !J12) return -5;
+  if (!g_lognorm) return -6;
+  if (g_samples && (!eps || !samples)) return -10;
+  if (!g_node_J) return -12;
+  if (!g_node_h) return -13;
+  if (!workspace || ws_bytes < svae_lds_workspace_bytes(B, T, n)) return -14;
+  if (!vjp_workspace || vjp_ws_bytes < svae_lds_vjp_workspace_bytes(B, T, n)) return -16;
+  if (B == 0) return 0;
+  svae::VjpArgs a;
+  a.B = B; a.T = T; a.S = g_samples ? S : 0;
+  a.J12 = J12; a.g_lognorm = g_lognorm; a.g_diagxx = g_E_node_diagxx; a.g_x = g_E_node_x;
+  a.g_samples = g_samples; a.eps = eps; a.samples = samples;
+  a.g_node_J = g_node_J; a.g_node_h = g_node_h;
+  a.ws = (const double*)workspace;
+  a.ws2 = a.ws + main_ws_doubles(B, T, n);
+  a.ws3 = a.ws2 + factor_ws_doubles(B, T, n);
+  a.adj = (double*)vjp_workspace;
+  switch (n) {
+#define SVAE_CASE_(NN) case NN: return svae_lds_vjp_n##NN(&a, stream);
 #define SVAE_CASE(NN) SVAE_CASE_(NN)
 #ifdef SVAE_ONLY_N
     SVAE_CASE(SVAE_ONLY_N)

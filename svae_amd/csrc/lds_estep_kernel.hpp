@@ -392,6 +392,10 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
     double W[N + 1];
     static_for<0, N + 1>([&](auto i) { W[i] = 0.0; });
     static_for<0, (N + 1 + IL - 1) / IL>([&](auto g) { rows_src_bcast<IL, g * IL, N + 1, N>(W, S, H); });
+    if (a.ws3) {   // VJP mode: keep W~_t (rows 0..N, lanes 0..N)
+      double* w3 = a.ws3 + ((long)b * T + t) * (N + 1) * HS + c;
+      if (sth) static_for<0, N + 1>([&](auto i) { w3[i * HS] = W[i]; });
+    }
     // S~_t = G~ W~ + diag(P^-1, 0), computed through its transpose (S~ symmetric):
     //   S~[c][i] = sum_k G~[c][k] W~[k][i] = sum_k G~'[k](lane c) * W[k](lane i)
     static_for<0, N>([&](auto i) { S[i] = Pi[i]; });

@@ -238,6 +238,10 @@ __global__ __launch_bounds__(64) void lds_estep_split_kernel(const LdsArgs a) {
     });
     double WR[N + 1];
     all_gather_rows<J1, N + 1, RS>(tab, g, c, W, WR);
+    if (a.ws3) {   // VJP mode: keep W~_t (replicated after the gather: DPP row 0 stores it)
+      double* w3 = a.ws3 + ((long)b * T + t) * (N + 1) * HS + c;
+      if (g == 0 && c <= N) static_for<0, N + 1>([&](auto i) { w3[i * HS] = WR[i]; });
+    }
     // S~_t[i] = P^-1[i] + G~[i] W~ = Pi + sum_k -/+ bcast_k(Gc[j]) WR[k]
     static_for<0, J1>([&](auto j) { S[j] = Pi[j]; });
     asm volatile("s_nop 1");

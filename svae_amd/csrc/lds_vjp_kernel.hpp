@@ -1,0 +1,271 @@
+// lds_vjp_kernel.hpp -- reverse-mode (VJP) sweeps of the LDS E-step [+ backward sampler] on MI355X.
+//
+// What it replaces (reference = mattjj/svae, /root/reference), composed exactly as the reference wires
+// its autograd primitives (svae/lds/lds_inference.py:26-39):
+//   natural_filter_grad            svae/lds/cython_lds_inference.pyx:92-145   (+ pxd:84-120,146-162,190-204)
+//   natural_smoother_general_grad  svae/lds/cython_lds_inference.pyx:236-306  (+ pxd:222-238,298-426)
+//   natural_sample_backward_grad   svae/lds/cython_lds_inference.pyx:357-409  (+ pxd:456-487,510-528)
+//   and the linear-algebra VJP helpers of svae/cython_linalg_grads.pxd:10-118.
+// Not a translation: it differentiates THIS library's forward algorithm (lds_estep_kernel.hpp), whose
+// per-step state is (P^-1, H = [P^-1 J12 | c]), the moment recursion S~_t = G~ S~_{t+1} G~' + diag(P^-1,0)
+// and the sampler x_t = c - (P^-1 J12) x_{t+1} + chol(P)^-T eps.  Adjoint algebra (prototype with a
+// finite-difference and reference check: tools/proto/vjp_proto.py), S^ = adjoint of S~ kept symmetric:
+//   sweep 1, t = 0 .. T-1 (reverse of the smoother / sampler recursions):
+//     S^ += direct cotangents (E[x_t] in row/column N, diag E[x x'] on the diagonal)
+//     G^ = 2 S^ W~_t'                      -> Xbar_t = -G^[:n,:n],  cbar_t = G^[:n,n]
+//     Pinvbar_t = S^[:n,:n];               S^ <- G~' S^ G~
+//     xhat_t = g_x_t - X_{t-1}' xhat_{t-1}; cbar_t += sum_s xhat; Xbar_t -= sum_s xhat x_{t+1}'
+//     Pbar_t(direct) = -U Lh U',  U = chol(P)^-T,  Lh = lower-half(sum_s eps_s (U' xhat_s)')
+//   sweep 2, t = T-1 .. 0 (reverse of the filter recursion):
+//     [Xbar | cbar]_t -= J12 [Abar | hbar]_{t+1}
+//     Bbar = P^-1 [Xbar | cbar];   hfbar = Bbar[:,n] + g c
+//     Pbar = -P^-1 Pinvbar P^-1 - Bbar H' - 1/2 g (c c' + P^-1) + Pbar(direct)
+//     g_node_J_t = -2 diag(Pbar);  g_node_h_t = hfbar;  [Abar | hbar]_t = [Pbar | hfbar]
+// Layout: as the packed E-step kernel (one DPP row per sequence, lane = column, fused DPP FMAs);
+// every statement of this unit is self-fenced (SVAE_DPP_ALWAYS_FENCED, dpp.hpp): the kernels are
+// register-heavy and correctness comes first here.
+#pragma once
+#include "lds_estep_kernel.hpp"
+
+namespace svae {
+
+// OUT[i] += sum_{k<KN} (+/-) bcast_k(A[i]) * B[k]   for i in [0, IN)      (OUT = A B)
+template <int IN, int KN, bool NEG, int MA, int MB, int MO>
+__device__ __forceinline__ void mm_ab(double (&out)[MO], const double (&A)[MA], const double (&Bt)[MB]) {
+  static_for<0, KN>([&](auto k) {
+    static_for<0, IN>([&](auto i) { mac_bc<k, NEG>(out[i], A[i], Bt[k]); });
+  });
+}
+// OUT[i] += sum_{k<KN} (+/-) bcast_i(A[k]) * B[k]   for i in [0, IN)      (OUT = A' B)
+template <int IN, int KN, bool NEG, int MA, int MB, int MO>
+__device__ __forceinline__ void mm_atb(double (&out)[MO], const double (&A)[MA], const double (&Bt)[MB]) {
+  static_for<0, KN>([&](auto k) {
+    static_for<0, IN>([&](auto i) { mac_bc<i, NEG>(out[i], A[k], Bt[k]); });
+  });
+}
+
+// transpose an N-row column-layout tile inside its DPP row through LDS (tab: 256 doubles per row)
+template <int N>
+__device__ __forceinline__ void transpose_tile(double* tab, int c, const double (&a)[N], double (&at)[N]) {
+  __builtin_amdgcn_wave_barrier();
+  static_for<0, N>([&](auto i) { tab[c * 16 + i] = a[i]; });
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  static_for<0, N>([&](auto i) { at[i] = tab[i * 16 + c]; });
+  __builtin_amdgcn_wave_barrier();
+}
+
+// ---- sweep 1: smoother + sampler adjoints, forward in time ----------------------------------------
+template <int N, bool SAMP>
+__global__ __launch_bounds__(64) void lds_vjp_sweep1_kernel(const VjpArgs a) {
+  constexpr int HS = ws_h_stride(N), PS = ws_p_stride(N), WS = ws_step_doubles(N);
+  constexpr int AS = vjp_step_doubles(N);
+  __shared__ double tabs[4 * 256];
+  const int lane = threadIdx.x;
+  const int c = lane & 15;
+  double* tab = tabs + (lane >> 4) * 256;
+  const int brow = blockIdx.x * 4 + (lane >> 4);
+  const bool valid = brow < a.B;
+  const int b = valid ? brow : a.B - 1;
+  const bool col = c < N, colN = c <= N;
+  const int T = a.T, S = a.S;
+  double E[N];
+  static_for<0, N>([&](auto i) { E[i] = (c == i) ? 1.0 : 0.0; });
+  const double EN = (c == N) ? 1.0 : 0.0;
+  const double sg = col ? -1.0 : (c == N ? 1.0 : 0.0);        // G~ row k = H row k * sg
+  double mU[SAMP ? N : 1];                                    // (c > j) + 1/2 (c == j)
+  if constexpr (SAMP) static_for<0, N>([&](auto j) { mU[j] = (c > j) ? 1.0 : ((c == j) ? 0.5 : 0.0); });
+
+  const double* wsb = a.ws + (long)b * ws_seq_doubles(N, T) + ws_zpage_doubles(N);
+  double Sh[N + 1];
+  static_for<0, N + 1>([&](auto i) { Sh[i] = 0.0; });
+  double HcPrev[SAMP ? N : 1], xh[SAMP ? N : 1];
+  if constexpr (SAMP) static_for<0, N>([&](auto k) { HcPrev[k] = 0.0; xh[k] = 0.0; });
+  const bool sv = c < S;                                      // this lane carries a sample
+  const int ss = sv ? c : 0;
+
+  for (int t = 0; t < T; ++t) {
+    const double* w = wsb + (long)t * WS;
+    const double* w3 = a.ws3 + ((long)b * T + t) * (N + 1) * HS;
+    double* ad = a.adj + ((long)b * T + t) * AS;
+    double Hc[N], WT[N + 1], Gc[N + 1];
+    static_for<0, N>([&](auto k) { const double v = w[k * HS + (colN ? c : 0)]; Hc[k] = colN ? v : 0.0; });
+    {
+      double tmp[N + 1];
+      load_row<N + 1>(w3 + (colN ? c : 0) * HS, tmp);
+      static_for<0, N + 1>([&](auto k) { WT[k] = colN ? 2.0 * tmp[k] : 0.0; });      // 2 W~'
+    }
+    static_for<0, N>([&](auto k) { Gc[k] = Hc[k] * sg; });
+    Gc[N] = EN;
+
+    // direct cotangents, symmetrised
+    const double gx = (a.g_x && col) ? 0.5 * a.g_x[((long)b * T + t) * N + c] : 0.0;
+    const double gd = (a.g_diagxx && col) ? a.g_diagxx[((long)b * T + t) * N + c] : 0.0;
+    Sh[N] += gx;
+    static_for<0, N>([&](auto i) {
+      mac_bc<i>(Sh[i], gx, EN);
+      Sh[i] = __builtin_fma(gd, E[i], Sh[i]);
+    });
+
+    // G^ rows i < N:  2 S^ W~'   (lanes 0..N)
+    double Gb[N];
+    static_for<0, N>([&](auto i) { Gb[i] = 0.0; });
+    mm_ab<N, N + 1, false>(Gb, Sh, WT);
+    if (valid && col) static_for<0, N>([&](auto i) { ad[N * HS + i * PS + c] = Sh[i]; });   // Pinvbar
+
+    // S^ <- G~' (S^ G~)
+    {
+      double M[N + 1], Sn[N + 1];
+      static_for<0, N + 1>([&](auto i) { M[i] = 0.0; Sn[i] = 0.0; });
+      mm_ab<N + 1, N + 1, false>(M, Sh, Gc);
+      mm_atb<N + 1, N + 1, false>(Sn, Gc, M);
+      static_for<0, N + 1>([&](auto i) { Sh[i] = Sn[i]; });
+    }
+
+    if constexpr (SAMP) {
+      // xhat_t = g_samples_t - X_{t-1}' xhat_{t-1}   (register k, lane = sample)
+      double xn[N];
+      const double* gs = a.g_samples + (((long)b * T + t) * S + ss) * N;
+      static_for<0, N>([&](auto k) { const double v = gs[k]; xn[k] = sv ? v : 0.0; });
+      static_for<0, N>([&](auto j) {
+        static_for<0, N>([&](auto k) { mac_bc<k, true>(xn[k], HcPrev[j], xh[j]); });
+      });
+      static_for<0, N>([&](auto k) { xh[k] = xn[k]; HcPrev[k] = Hc[k]; });
+      // cbar_t += sum_s xhat (lane N);  Xbar_t -= sum_s xhat x_{t+1}'  (i.e. G^[:, :n] += ...)
+      static_for<0, 16>([&](auto s) {
+        if (s < S) {
+          double v = EN;
+          if (t + 1 < T) {
+            const double x1 = a.samples[(((long)b * T + t + 1) * S + s) * N + (col ? c : 0)];
+            v += col ? x1 : 0.0;
+          }
+          static_for<0, N>([&](auto i) { mac_bc<s>(Gb[i], xh[i], v); });
+        }
+      });
+      // noise adjoint:  Pbar_t(direct) = -U (Lh U')  with  U = L^-T D^-1/2,  Lh from E' = sum_s eps_s z_s'
+      const double* w2 = a.ws2 + ((long)b * T + t) * (N * N + N);
+      double R[N], U[N];
+      static_for<0, N>([&](auto k) { const double v = w2[k * N + (col ? c : 0)]; R[k] = col ? v : 0.0; });
+      const double pvv = w2[N * N + (col ? c : 0)];
+      const double dis = col ? 1.0 / sqrt(pvv) : 0.0;
+      static_for<0, N>([&](auto k) { U[k] = E[k] * dis; });
+      static_for<1, N>([&](auto jj) {
+        constexpr int j = N - jj;
+        static_for<0, j>([&](auto k) { mac_bc<j, true>(U[k], R[k], U[j]); });
+      });
+      double z[N], ET[N];
+      static_for<0, N>([&](auto j) { z[j] = 0.0; ET[j] = 0.0; });
+      static_for<0, N>([&](auto i) {
+        static_for<0, N>([&](auto j) { mac_bc<j>(z[j], U[i], xh[i]); });        // z = U' xhat
+      });
+      static_for<0, 16>([&](auto s) {
+        if (s < S) {
+          const double e1 = a.eps[(((long)b * T + t) * S + s) * N + (col ? c : 0)];
+          const double ev = col ? e1 : 0.0;
+          static_for<0, N>([&](auto j) { mac_bc<s>(ET[j], z[j], ev); });         // ET[j][c] = E[c][j]
+        }
+      });
+      double LhT[N], K[N], KT[N], Pex[N];
+      static_for<0, N>([&](auto j) { LhT[j] = ET[j] * mU[j]; K[j] = 0.0; Pex[j] = 0.0; });
+      mm_ab<N, N, false>(K, U, LhT);              // K = U Lh'
+      transpose_tile<N>(tab, c, K, KT);           // KT = Lh U'
+      mm_ab<N, N, true>(Pex, U, KT);              // Pex = -U Lh U'
+      if (valid && col) static_for<0, N>([&](auto i) { ad[N * HS + N * PS + i * PS + c] = Pex[i]; });
+    }
+    if (valid && colN) static_for<0, N>([&](auto i) { ad[i * HS + c] = Gb[i]; });
+  }
+}
+
+// ---- sweep 2: filter adjoint, backward in time -----------------------------------------------------
+template <int N, bool SAMP>
+__global__ __launch_bounds__(64) void lds_vjp_sweep2_kernel(const VjpArgs a) {
+  constexpr int HS = ws_h_stride(N), PS = ws_p_stride(N), WS = ws_step_doubles(N);
+  constexpr int AS = vjp_step_doubles(N);
+  const int lane = threadIdx.x;
+  const int c = lane & 15;
+  const int brow = blockIdx.x * 4 + (lane >> 4);
+  const bool valid = brow < a.B;
+  const int b = valid ? brow : a.B - 1;
+  const bool col = c < N, colN = c <= N;
+  const int T = a.T;
+  double E[N];
+  static_for<0, N>([&](auto i) { E[i] = (c == i) ? 1.0 : 0.0; });
+  const double EN = (c == N) ? 1.0 : 0.0;
+  const double sg = col ? -1.0 : (c == N ? 1.0 : 0.0);
+  double J12c[N];                                             // info form: J12 = -natJ12
+  static_for<0, N>([&](auto i) { const double v = a.J12[i * N + (col ? c : 0)]; J12c[i] = col ? -v : 0.0; });
+  const double g = a.g_lognorm[b];
+
+  const double* wsb = a.ws + (long)b * ws_seq_doubles(N, T) + ws_zpage_doubles(N);
+  double Ab[N];                                               // [Abar | hbar] of step t+1
+  static_for<0, N>([&](auto i) { Ab[i] = 0.0; });
+
+  for (int t = T - 1; t >= 0; --t) {
+    const double* w = wsb + (long)t * WS;
+    const double* ad = a.adj + ((long)b * T + t) * AS;
+    double Pi[N], Hc[N], HT[N + 1], Xc[N];
+    static_for<0, N>([&](auto i) {
+      const double v = w[N * HS + i * PS + (col ? c : 0)];
+      Pi[i] = col ? v : 0.0;
+      const double h = w[i * HS + (colN ? c : 0)];
+      Hc[i] = colN ? h : 0.0;
+      const double gb = ad[i * HS + (colN ? c : 0)];
+      Xc[i] = colN ? gb * sg : 0.0;                            // [Xbar | cbar] = [-G^ | G^[:,n]]
+    });
+    {
+      double tmp[N + 1];
+      load_row<N + 1>(w + (col ? c : 0) * HS, tmp);
+      static_for<0, N + 1>([&](auto k) { HT[k] = col ? tmp[k] : 0.0; });    // H' (lane c: row c of H)
+    }
+    // [Xbar | cbar] -= J12 [Abar | hbar]_{t+1}
+    if (t < T - 1) mm_ab<N, N, true>(Xc, J12c, Ab);
+    // Bbar = P^-1 [Xbar | cbar]
+    double Bb[N], T1[N], Pb[N];
+    static_for<0, N>([&](auto i) { Bb[i] = 0.0; T1[i] = 0.0; Pb[i] = 0.0; });
+    mm_ab<N, N, false>(Bb, Pi, Xc);
+    // Pbar = -P^-1 (Pinvbar P^-1) - Bbar H' - 1/2 g (c c' + P^-1) [+ direct]
+    {
+      double Pib[N];
+      static_for<0, N>([&](auto i) { const double v = ad[N * HS + i * PS + (col ? c : 0)]; Pib[i] = col ? v : 0.0; });
+      mm_ab<N, N, false>(T1, Pib, Pi);
+    }
+    mm_ab<N, N, true>(Pb, Pi, T1);
+    mm_ab<N, N + 1, true>(Pb, Bb, HT);
+    double cvs = -0.5 * g * HT[N];
+    static_for<0, N>([&](auto i) {
+      mac_bc<i>(Pb[i], cvs, HT[N]);
+      Pb[i] = __builtin_fma(-0.5 * g, Pi[i], Pb[i]);
+    });
+    if constexpr (SAMP) {
+      static_for<0, N>([&](auto i) { const double v = ad[N * HS + N * PS + i * PS + (col ? c : 0)]; Pb[i] += col ? v : 0.0; });
+    }
+    // outputs and the adjoint handed to step t-1:  Ab = [Pbar | Bbar[:,n] + g c]
+    double gJ = 0.0, gh = 0.0;
+    static_for<0, N>([&](auto i) {
+      const double hfb = __builtin_fma(g, Hc[i], Bb[i]);      // lane N: hfbar_i
+      Ab[i] = __builtin_fma(EN, hfb - Pb[i], Pb[i]);
+      gJ = __builtin_fma(E[i], Pb[i], gJ);
+    });
+    static_for<0, N>([&](auto i) { mac_bc<N>(gh, Ab[i], E[i]); });
+    if (valid && col) {
+      a.g_node_J[((long)b * T + t) * N + c] = -2.0 * gJ;
+      a.g_node_h[((long)b * T + t) * N + c] = gh;
+    }
+  }
+}
+
+template <int N>
+static int launch_vjp(const VjpArgs& a, hipStream_t stream) {
+  dim3 grid((a.B + 3) / 4), block(64);
+  if (a.g_samples) {
+    hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, true>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((lds_vjp_sweep2_kernel<N, true>), grid, block, 0, stream, a);
+  } else {
+    hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, false>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((lds_vjp_sweep2_kernel<N, false>), grid, block, 0, stream, a);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+}  // namespace svae

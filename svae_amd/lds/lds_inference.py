@@ -18,7 +18,8 @@ import torch
 from .. import _lib
 
 __all__ = ["LDSEStepPlan", "natural_lds_estep_general", "cython_natural_lds_estep_general",
-           "natural_lds_inference_general", "cython_natural_lds_inference_general", "reduce_stats"]
+           "natural_lds_inference_general", "cython_natural_lds_inference_general", "reduce_stats",
+           "lds_inference_differentiable"]
 
 
 def _as_dev(x, device):
@@ -65,11 +66,12 @@ class LDSEStepPlan(object):
         self.reduced = torch.empty(4 * n * n + n + 2, **f64)
 
     def launch(self, init_J, init_h, init_logZ, J11, J12, J22, logZ_pair, node_J, node_h,
-               node_logZ=None, pair_batched=False, keep_factor=False):
+               node_logZ=None, pair_batched=False, keep_factor=False, keep_cross=False):
         """Raw launch on the current stream.  All arguments: contiguous float64 device tensors."""
         p = _lib.ptr
         rc = self.lib.svae_lds_estep_f64(
-            self.B, self.T, self.n, int(self.inhomog), int(pair_batched), int(keep_factor),
+            self.B, self.T, self.n, int(self.inhomog), int(pair_batched),
+            int(bool(keep_factor)) | (2 if keep_cross else 0),
             p(init_J), p(init_h), p(init_logZ), p(J11), p(J12), p(J22), p(logZ_pair),
             p(node_J), p(node_h), p(node_logZ),
             p(self.lognorm), p(self.E_init), p(self.E_pair), p(self.E_node_diagxx),
@@ -77,6 +79,8 @@ class LDSEStepPlan(object):
             _lib.current_stream(self.device))
         _lib.check(rc, "svae_lds_estep_f64")
         self.has_factor = bool(keep_factor)
+        self.has_cross = bool(keep_cross)
+        self._J12 = J12
 
     def sample(self, eps, out=None):
         """Backward sampling from the messages of the last `launch(..., keep_factor=True)`.
@@ -95,6 +99,35 @@ class LDSEStepPlan(object):
                                           self.ws_bytes, _lib.current_stream(self.device))
         _lib.check(rc, "svae_lds_sample_f64")
         return out
+
+    def vjp(self, g_lognorm, g_E_node_diagxx=None, g_E_node_x=None, g_samples=None, eps=None,
+            samples=None):
+        """Vector-Jacobian product w.r.t. the node potentials of the last
+        `launch(..., keep_factor=True, keep_cross=True)` [+ `sample`]: returns (g_node_J, g_node_h)
+        (B,T,n) each; g_node_logZ[b,t] = g_lognorm[b].  Replaces the reference's natural_filter_grad /
+        natural_smoother_general_grad / natural_sample_backward_grad
+        (cython_lds_inference.pyx:92-145, 236-306, 357-409)."""
+        if not (getattr(self, "has_cross", False) and getattr(self, "has_factor", False)):
+            raise RuntimeError("vjp() needs a preceding launch(..., keep_factor=True, keep_cross=True)")
+        if self.inhomog:
+            raise NotImplementedError("VJP for time-inhomogeneous pair parameters")
+        f64 = dict(dtype=torch.float64, device=self.device)
+        c = lambda x: None if x is None else x.to(**f64).contiguous()
+        g_lognorm, g_E_node_diagxx, g_E_node_x = c(g_lognorm), c(g_E_node_diagxx), c(g_E_node_x)
+        g_samples, eps, samples = c(g_samples), c(eps), c(samples)
+        S = 0 if g_samples is None else g_samples.shape[2]
+        if not hasattr(self, "vjp_ws"):
+            self.vjp_ws_bytes = int(self.lib.svae_lds_vjp_workspace_bytes(max(self.B, 1), self.T, self.n))
+            self.vjp_ws = torch.empty(self.vjp_ws_bytes // 8, **f64)
+        gJ = torch.empty(self.B, self.T, self.n, **f64)
+        gh = torch.empty(self.B, self.T, self.n, **f64)
+        p = _lib.ptr
+        rc = self.lib.svae_lds_estep_vjp_f64(
+            self.B, self.T, self.n, S, p(self._J12), p(g_lognorm), p(g_E_node_diagxx), p(g_E_node_x),
+            p(g_samples), p(eps), p(samples), p(gJ), p(gh), p(self.ws), self.ws_bytes,
+            p(self.vjp_ws), self.vjp_ws_bytes, _lib.current_stream(self.device))
+        _lib.check(rc, "svae_lds_estep_vjp_f64")
+        return gJ, gh
 
     def reduce(self):
         """Deterministic batch sums [sum E_init | sum E_pair | sum lognorm | B] (homogeneous)."""
@@ -239,3 +272,54 @@ def reduce_stats(plan):
     Ep = (r[o:o + nn].reshape(n, n), r[o + nn:o + 2 * nn].reshape(n, n),
           r[o + 2 * nn:o + 3 * nn].reshape(n, n), float(B * (T - 1)))
     return Ei, Ep, r[o + 3 * nn]
+
+
+class _LDSInference(torch.autograd.Function):
+    """Differentiable (w.r.t. the node potentials) E-step + sampler, the torch counterpart of the
+    reference's three autograd primitives (lds_inference.py:26-39).  Forward: one E-step launch
+    (+ sampler); backward: the two VJP sweeps.  The global statistics (E_init, E_pair) are returned
+    non-differentiable, as in the reference's use (svae.py:21 `saved.stats`)."""
+
+    @staticmethod
+    def forward(ctx, node_J, node_h, node_logZ, eps, plan, params):
+        init_J, init_h, init_logZ, J11, J12, J22, logZ_pair = params
+        plan.launch(init_J, init_h, init_logZ, J11, J12, J22, logZ_pair, node_J, node_h, node_logZ,
+                    False, True, True)
+        samples = plan.sample(eps) if eps is not None else torch.zeros(0, dtype=torch.float64, device=plan.device)
+        ctx.plan, ctx.has_logZ, ctx.has_samples = plan, node_logZ is not None, eps is not None
+        ctx.save_for_backward(eps if eps is not None else samples, samples)
+        ctx.mark_non_differentiable(plan.E_init, plan.E_pair)
+        return (plan.lognorm.clone(), plan.E_node_diagxx.clone(), plan.E_node_x.clone(), samples,
+                plan.E_init, plan.E_pair)
+
+    @staticmethod
+    def backward(ctx, g_lognorm, g_dxx, g_x, g_samples, _gi, _gp):
+        plan = ctx.plan
+        eps, samples = ctx.saved_tensors
+        zero = lambda g, like: torch.zeros_like(like) if g is None else g
+        g_lognorm = zero(g_lognorm, plan.lognorm)
+        gs = g_samples if (ctx.has_samples and g_samples is not None) else None
+        gJ, gh = plan.vjp(g_lognorm, g_dxx, g_x, gs, eps if gs is not None else None,
+                          samples if gs is not None else None)
+        gz = g_lognorm[:, None].expand(plan.B, plan.T).clone() if ctx.has_logZ else None
+        return gJ, gh, gz, None, None, None
+
+
+def lds_inference_differentiable(natparam, node_params, eps=None, plan=None):
+    """(lognorm (B), (E_node_diagxx, E_node_x) (B,T,n), samples (B,T,S,n) | None, (E_init, E_pair)):
+    differentiable w.r.t. node_params = (J (B,T,n), h (B,T,n)[, logZ (B,T)]) through torch autograd."""
+    init_params, pair_params = natparam
+    node_J, node_h = node_params[0], node_params[1]
+    node_logZ = node_params[2] if len(node_params) == 3 else None
+    dev = node_h.device
+    B, T, n = node_h.shape
+    if plan is None:
+        plan = LDSEStepPlan(B, T, n, dev)
+    init_J, init_h, init_logZ = _canonical_init_params(init_params, dev)
+    J11, J12, J22 = (_as_dev(x, dev) for x in pair_params[:3])
+    logZ_pair = _as_dev(pair_params[3], dev).reshape(-1)
+    params = (init_J, init_h, init_logZ, J11, J12, J22, logZ_pair)
+    cont = lambda x: None if x is None else x.to(torch.float64).contiguous()
+    out = _LDSInference.apply(cont(node_J), cont(node_h), cont(node_logZ), cont(eps), plan, params)
+    lognorm, dxx, ex, samples, E_init, E_pair = out
+    return lognorm, (dxx, ex), (samples if eps is not None else None), (E_init, E_pair)

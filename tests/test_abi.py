@@ -19,7 +19,8 @@ def test_header_declares_the_expected_entry_points():
     syms = _header_symbols()
     for s in ("svae_lds_estep_f64", "svae_lds_workspace_bytes", "svae_lds_set_split_max_b",
               "svae_lds_reduce_stats_f64",
-              "svae_lds_sample_f64", "svae_gmm_meanfield_f64", "svae_hip_abi_version"):
+              "svae_lds_sample_f64", "svae_lds_estep_vjp_f64", "svae_lds_vjp_workspace_bytes",
+              "svae_gmm_meanfield_f64", "svae_hip_abi_version"):
         assert s in syms
 
 
@@ -38,8 +39,10 @@ def test_workspace_size_formula():
     # main region: n rows of [P^-1 J12 | c] (stride even(n+1)) + n rows of P^-1 (stride even(n));
     # factor region: n*n + n
     # plus one constant page (12 + 10 doubles) per sequence
-    assert lib.svae_lds_workspace_bytes(512, 200, 10) == 512 * (22 + 200 * (10 * (12 + 10) + 10 * 10 + 10)) * 8
-    assert lib.svae_lds_workspace_bytes(3, 7, 5) == 3 * (12 + 7 * (5 * (6 + 6) + 5 * 5 + 5)) * 8
+    # and the cross-moment region ((n+1) rows of stride even(n+1)) per step
+    assert lib.svae_lds_workspace_bytes(512, 200, 10) == 512 * (22 + 200 * (10 * (12 + 10) + 10 * 10 + 10 + 11 * 12)) * 8
+    assert lib.svae_lds_workspace_bytes(3, 7, 5) == 3 * (12 + 7 * (5 * (6 + 6) + 5 * 5 + 5 + 6 * 6)) * 8
+    assert lib.svae_lds_vjp_workspace_bytes(3, 7, 5) == 3 * 7 * 5 * (6 + 2 * 6) * 8
     assert lib.svae_lds_workspace_bytes(1, 1, 16) == 0     # n > 15: outside the register path
     assert lib.svae_lds_workspace_bytes(0, 5, 3) == 0
 

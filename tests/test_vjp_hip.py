@@ -1,0 +1,91 @@
+"""GPU parity tests of the reverse-mode sweeps (svae_lds_estep_vjp_f64) against the reference's own
+compiled VJPs (natural_filter_grad / natural_smoother_general_grad / natural_sample_backward_grad,
+composed as lds_inference.py:26-39 wires them; oracle/ref.estep_vjp) and against central finite
+differences of the HIP forward itself."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import ref  # noqa: E402  (checker only)
+
+
+def _rel(a, b):
+    a = a.detach().cpu().numpy() if hasattr(a, "detach") else np.asarray(a, float)
+    b = np.asarray(b, float)
+    scale = np.maximum(np.abs(b), 1e-3 * max(np.max(np.abs(b)), 1e-300))
+    return float(np.max(np.abs(a - b) / scale))
+
+
+def _setup(n, T, B, S, seed):
+    from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials
+    rng = np.random.default_rng(seed)
+    init, pair = rand_lds_natparam(n, rng)
+    node = rand_node_potentials((B, T, n), rng, with_logZ=True)
+    g = dict(ln=rng.standard_normal(B), dxx=rng.standard_normal((B, T, n)), x=rng.standard_normal((B, T, n)),
+             s=rng.standard_normal((B, T, S, n)))
+    return init, pair, node, g
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("n,T,B,S", [(3, 6, 2, 2), (10, 25, 5, 1), (10, 40, 3, 4), (15, 5, 1, 3), (1, 4, 2, 1)])
+@pytest.mark.parametrize("with_samples", [False, True])
+def test_vjp_against_reference_compiled_vjps(n, T, B, S, with_samples):
+    from svae_amd.lds.lds_inference import lds_inference_differentiable
+    init, pair, node, g = _setup(n, T, B, S, 31 * n + T)
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev)
+    want, eps = [], np.zeros((B, T, S, n))
+    for b in range(B):
+        (gJ, gh, gz), e = ref.estep_vjp((init, pair), tuple(x[b] for x in node), g["ln"][b],
+                                        (g["dxx"][b], g["x"][b]), g["s"][b] if with_samples else None,
+                                        seed=100 + b)
+        want.append((gJ, gh, gz))
+        if with_samples:
+            eps[b] = e
+    nJ, nh, nz = (t(x).requires_grad_(True) for x in node)
+    lognorm, (dxx, ex), samples, _ = lds_inference_differentiable(
+        (tuple(t(x) for x in init), tuple(t(x) for x in pair)), (nJ, nh, nz),
+        eps=t(eps) if with_samples else None)
+    loss = (t(g["ln"]) * lognorm).sum() + (t(g["dxx"]) * dxx).sum() + (t(g["x"]) * ex).sum()
+    if with_samples:
+        loss = loss + (t(g["s"]) * samples).sum()
+    loss.backward()
+    for b in range(B):
+        assert _rel(nJ.grad[b], want[b][0]) < 1e-6, "g_node_J"
+        assert _rel(nh.grad[b], want[b][1]) < 1e-6, "g_node_h"
+        assert _rel(nz.grad[b], want[b][2]) < 1e-12, "g_node_logZ"
+
+
+def test_vjp_against_finite_differences_of_the_hip_forward():
+    """Independent of any reference: d/d(node) of a random linear functional of the HIP outputs."""
+    from svae_amd.lds.lds_inference import lds_inference_differentiable
+    n, T, B, S = 4, 6, 2, 2
+    init, pair, node, g = _setup(n, T, B, S, 5)
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev)
+    natparam = (tuple(t(x) for x in init), tuple(t(x) for x in pair))
+    eps = t(np.random.default_rng(9).standard_normal((B, T, S, n)))
+
+    def f(nJ, nh):
+        lognorm, (dxx, ex), samples, _ = lds_inference_differentiable(natparam, (nJ, nh), eps=eps)
+        return (t(g["ln"]) * lognorm).sum() + (t(g["dxx"]) * dxx).sum() + (t(g["x"]) * ex).sum() \
+            + (t(g["s"]) * samples).sum()
+
+    nJ, nh = t(node[0]).requires_grad_(True), t(node[1]).requires_grad_(True)
+    f(nJ, nh).backward()
+    h = 1e-6
+    rng = np.random.default_rng(1)
+    for _ in range(12):
+        b, tt, i = rng.integers(B), rng.integers(T), rng.integers(n)
+        for which, grad in ((0, nJ.grad), (1, nh.grad)):
+            d = torch.zeros(B, T, n, dtype=torch.float64, device=dev)
+            d[b, tt, i] = h
+            args = [t(node[0]), t(node[1])]
+            args[which] = args[which] + d
+            fp = float(f(*args))
+            args[which] = args[which] - 2 * d
+            fm = float(f(*args))
+            num = (fp - fm) / (2 * h)
+            assert abs(float(grad[b, tt, i]) - num) < 2e-5 * max(1.0, abs(num))
