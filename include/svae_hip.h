@@ -132,6 +132,8 @@ int svae_lds_estep_vjp_f64(int B, int T, int n, int S, const double* J12,
  *       label_init (T,K)  initial responsibilities (reference: normalize(rand(T,K)), gmm.py:126-128)
  *       tol, max_iter     (reference: 1e-3, 100); the stop rule is on the batch-total KL
  *  out: label_stats (T,K) responsibilities at the fixed point (after the final extra pass, :74-77)
+ *       label_fixed (T,K) or NULL: the fixed point itself, i.e. what that final pass started from
+ *         (:71; callers that keep the final pass on an autograd tape re-run it from here)
  *       gaussian_stats (T,N+2,N+2) dense-packed E[t(x_t)]
  *       label_natparam (T,K), gaussian_natparam (T,N+2,N+2)
  *       dirichlet_stats (K), niw_stats (K,N+2,N+2)      (sums over points, :80-81)
@@ -143,7 +145,7 @@ int svae_gmm_meanfield_f64(int T, int N, int K,
                            const double* label_global, const double* gaussian_globals,
                            const double* node_J, const double* node_h, const double* label_init,
                            double tol, int max_iter,
-                           double* label_stats, double* gaussian_stats,
+                           double* label_stats, double* label_fixed, double* gaussian_stats,
                            double* label_natparam, double* gaussian_natparam,
                            double* dirichlet_stats, double* niw_stats,
                            double* kl, int32_t* iters, int32_t* assign,

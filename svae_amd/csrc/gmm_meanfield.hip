@@ -35,6 +35,7 @@ struct GmmArgs {
   const double* __restrict__ node_h;            // (T, N)
   const double* __restrict__ label_init;        // (T, K)
   double* label_stats;                          // (T, K)   (iterated in place)
+  double* label_fixed;                          // (T, K) or nullptr: the fixed point itself
   double* gaussian_stats;                       // (T, D, D)
   double* label_natparam;                       // (T, K)
   double* gaussian_natparam;                    // (T, D, D)
@@ -277,6 +278,10 @@ __global__ __launch_bounds__(gmm_block<N>()) void gmm_meanfield_kernel(const Gmm
     for (int j = tid; j < T * K; j += GMM_BLOCK) a.label_stats[j] = a.label_init[j];
     __syncthreads();
   }
+  if (a.label_fixed) {   // the responsibilities the final pass starts from (gmm.py:71)
+    for (int t = tid; t < T; t += GMM_BLOCK)
+      for (int k = 0; k < K; ++k) a.label_fixed[(long)t * K + k] = a.label_stats[(long)t * K + k];
+  }
   // ---- final pass + outputs [gmm.py:74-86] -----------------------------------------------------
   // (reads r from label_stats and overwrites it point by point, by the same thread)
   const double kl = block_sum<GMM_BLOCK>(sweep(false, true), red);
@@ -312,7 +317,8 @@ extern "C" int svae_gmm_meanfield_f64(int T, int N, int K,
                                       const double* label_global, const double* gaussian_globals,
                                       const double* node_J, const double* node_h,
                                       const double* label_init, double tol, int max_iter,
-                                      double* label_stats, double* gaussian_stats,
+                                      double* label_stats, double* label_fixed,
+                                      double* gaussian_stats,
                                       double* label_natparam, double* gaussian_natparam,
                                       double* dirichlet_stats, double* niw_stats,
                                       double* kl, int32_t* iters, int32_t* assign,
@@ -335,7 +341,7 @@ extern "C" int svae_gmm_meanfield_f64(int T, int N, int K,
   a.T = T; a.K = K; a.max_iter = max_iter; a.tol = tol;
   a.label_global = label_global; a.gaussian_globals = gaussian_globals;
   a.node_J = node_J; a.node_h = node_h; a.label_init = label_init;
-  a.label_stats = label_stats; a.gaussian_stats = gaussian_stats;
+  a.label_stats = label_stats; a.label_fixed = label_fixed; a.gaussian_stats = gaussian_stats;
   a.label_natparam = label_natparam; a.gaussian_natparam = gaussian_natparam;
   a.dirichlet_stats = dirichlet_stats; a.niw_stats = niw_stats;
   a.kl = kl; a.iters = iters; a.assign = assign; a.info = info;

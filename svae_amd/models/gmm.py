@@ -51,7 +51,8 @@ def meanfield_from_globals(label_global, gaussian_globals, node_potentials, labe
     if tuple(li.shape) != (T, K):
         raise ValueError("label_init must be (T, K)")
     f64 = dict(dtype=torch.float64, device=dev)
-    out = dict(label_stats=torch.empty(T, K, **f64), gaussian_stats=torch.empty(T, D, D, **f64),
+    out = dict(label_stats=torch.empty(T, K, **f64), label_fixed=torch.empty(T, K, **f64),
+               gaussian_stats=torch.empty(T, D, D, **f64),
                label_natparam=torch.empty(T, K, **f64), gaussian_natparam=torch.empty(T, D, D, **f64),
                dirichlet_stats=torch.empty(K, **f64), niw_stats=torch.empty(K, D, D, **f64),
                kl=torch.empty(1, **f64), iters=torch.zeros(1, dtype=torch.int32, device=dev),
@@ -60,7 +61,7 @@ def meanfield_from_globals(label_global, gaussian_globals, node_potentials, labe
     p = _lib.ptr
     rc = lib.svae_gmm_meanfield_f64(
         T, N, K, p(lg), p(gg), p(nJ), p(nh), p(li), float(tol), int(max_iter),
-        p(out["label_stats"]), p(out["gaussian_stats"]), p(out["label_natparam"]),
+        p(out["label_stats"]), p(out["label_fixed"]), p(out["gaussian_stats"]), p(out["label_natparam"]),
         p(out["gaussian_natparam"]), p(out["dirichlet_stats"]), p(out["niw_stats"]),
         p(out["kl"]), p(out["iters"]), p(out["assign"]), p(out["info"]), _lib.current_stream(dev))
     _lib.check(rc, "svae_gmm_meanfield_f64")
@@ -116,3 +117,54 @@ def run_inference(prior_natparam, global_natparam, nn_potentials, num_samples, l
         eps = torch.randn(T, num_samples, N, dtype=torch.float64, device=gn.device, generator=generator)
     samples = expfam.gaussian_natural_sample(gn, _dev64(eps, gn.device))
     return samples, stats, prior_kl(global_natparam, prior_natparam), local_kl
+
+
+# --- differentiable call surface (what make_gradfun drives) ------------------------------------------
+
+def _final_pass_torch(label_global, gaussian_globals, node_dense, label_stats):
+    """gmm.py:74-86 in torch: the ONE pass after the fixed point that the reference keeps on the
+    autograd tape (`gaussian_meanfield` + `label_meanfield` on the boxed node potentials).  The fixed
+    point itself (gmm.py:71, <= 100 sweeps, not differentiated: `getval`) runs in the HIP kernel."""
+    N = node_dense.shape[-1] - 2
+    gaussian_natparam = node_dense + torch.tensordot(label_stats, gaussian_globals, dims=([1], [0]))
+    neghalfJ, h = gaussian_natparam[..., :N, :N], gaussian_natparam[..., :N, N]
+    J = -2 * neghalfJ
+    L = torch.linalg.cholesky(J)
+    Ex = torch.cholesky_solve(h.unsqueeze(-1), L)[..., 0]
+    ExxT = torch.cholesky_inverse(L) + Ex.unsqueeze(-1) * Ex.unsqueeze(-2)
+    ones = torch.ones(Ex.shape[0], dtype=Ex.dtype, device=Ex.device)
+    gaussian_stats = expfam.pack_dense(ExxT, Ex, ones, ones)
+    logZ = 0.5 * (h * Ex).sum() - torch.log(torch.diagonal(L, dim1=-1, dim2=-2)).sum() \
+        + (gaussian_natparam[..., N, N] + gaussian_natparam[..., N + 1, N + 1]).sum()
+    gaussian_kl = (node_dense * gaussian_stats).sum() - logZ
+    node_l = torch.tensordot(gaussian_stats, gaussian_globals, dims=([1, 2], [1, 2]))
+    label_natparam = node_l + label_global
+    label_stats_new = torch.softmax(label_natparam, dim=-1)
+    label_kl = (label_stats_new * node_l).sum() - torch.logsumexp(label_natparam, dim=-1).sum()
+    return (label_stats_new, gaussian_stats), (label_natparam, gaussian_natparam), label_kl + gaussian_kl
+
+
+def run_inference_differentiable(prior_natparam, global_natparam, nn_potentials, num_samples,
+                                 label_init=None, eps=None, generator=None):
+    """run_inference (gmm.py:12-16) with gradients w.r.t. nn_potentials flowing into `samples` and
+    `local_kl`, exactly the two quantities the reference differentiates (svae.py:21-24); statistics
+    are returned detached (`unbox(stats)`, gmm.py:16)."""
+    dev = nn_potentials[1].device
+    g = [_dev64(x, dev) for x in global_natparam]
+    label_global = expfam.dirichlet_expectedstats(g[0])
+    gaussian_globals = expfam.niw_expectedstats(g[1])
+    nJ, nh = nn_potentials[0].to(torch.float64), nn_potentials[1].to(torch.float64)
+    T, N = nh.shape
+    if label_init is None:
+        label_init = initialize_meanfield(T, g[0].shape[0], dev, generator)
+    o = meanfield_from_globals(label_global, gaussian_globals, (nJ.detach(), nh.detach()), label_init)
+    label_fixed = o["label_fixed"]          # the fixed point the final pass starts from (gmm.py:71)
+    node_dense = expfam.pack_dense(nJ, nh)
+    (label_stats, gaussian_stats), (label_natparam, gaussian_natparam), local_kl = \
+        _final_pass_torch(label_global, gaussian_globals, node_dense, label_fixed.detach())
+    if eps is None:
+        eps = torch.randn(T, num_samples, N, dtype=torch.float64, device=dev, generator=generator)
+    samples = expfam.gaussian_natural_sample(gaussian_natparam, _dev64(eps, dev))
+    dirichlet_stats = label_stats.detach().sum(0)
+    niw_stats = torch.tensordot(label_stats.detach(), gaussian_stats.detach(), dims=([0], [0]))
+    return samples, (dirichlet_stats, niw_stats), prior_kl(global_natparam, prior_natparam), local_kl

@@ -103,3 +103,43 @@ def run_inference(prior_natparam, global_natparam, nn_potentials, num_samples, e
     if not batched:
         samples = samples[0]
     return samples, (niw_stats, mniw_stats), global_kl, local_kl
+
+
+def run_inference_differentiable(prior_natparam, global_natparam, nn_potentials, num_samples,
+                                 eps=None, plan=None, generator=None, group=None):
+    """run_inference with gradients w.r.t. nn_potentials = (J (B,T,n), h (B,T,n)[, logZ (B,T)]) flowing
+    into `samples` and `local_kl` through the HIP VJP kernels (the reference differentiates exactly
+    these two, svae.py:21-24; the statistics go to `saved.stats` undifferentiated)."""
+    from ..lds.lds_inference import lds_inference_differentiable
+    dev = nn_potentials[1].device
+    g = (_dev64(global_natparam[0], dev), tuple(_dev64(x, dev) for x in global_natparam[1]))
+    p = (_dev64(prior_natparam[0], dev), tuple(_dev64(x, dev) for x in prior_natparam[1]))
+    local_natparam, global_es = local_natparam_from_global(g)
+    node = tuple(x.to(torch.float64) for x in nn_potentials)
+    batched = node[1].dim() == 3
+    nodeb = node if batched else tuple(x[None] for x in node)
+    B, T, n = nodeb[1].shape
+    S = 1 if num_samples is None else int(num_samples)
+    if eps is None:
+        eps = torch.randn(B, T, S, n, dtype=torch.float64, device=dev, generator=generator)
+    else:
+        eps = _dev64(eps, dev)
+        eps = eps if batched else eps[None]
+    if plan is None:
+        plan = LDSEStepPlan(B, T, n, dev)
+    lognorm, (dxx, ex), samples, _ = lds_inference_differentiable(local_natparam, nodeb, eps=eps, plan=plan)
+    local_kl = (nodeb[0] * dxx).sum() + (nodeb[1] * ex).sum() - lognorm.sum()
+    if len(nodeb) == 3:
+        local_kl = local_kl + nodeb[2].sum()
+    packed = plan.reduce().clone()
+    allreduce_global_stats(packed, group)
+    nn_ = n * n
+    cnt = packed[-1]
+    o = nn_ + n
+    niw_stats = expfam.pack_dense(packed[:nn_].reshape(n, n), packed[nn_:o], cnt, cnt)
+    mniw_stats = (packed[o:o + nn_].reshape(n, n), packed[o + nn_:o + 2 * nn_].reshape(n, n),
+                  packed[o + 2 * nn_:o + 3 * nn_].reshape(n, n), cnt * (T - 1))
+    global_kl = lds_prior_kl(g, p, global_es)
+    if not batched:
+        samples = samples[0]
+    return samples, (niw_stats, mniw_stats), global_kl, local_kl

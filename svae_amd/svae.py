@@ -1,0 +1,94 @@
+"""make_gradfun: the SVAE training-step contract of the reference, on torch.
+
+Mirrors /root/reference/svae/svae.py:10-39 (same argument names and order, same returned tuple):
+the Monte-Carlo ELBO estimator `mc_elbo` (:19-24), its gradient w.r.t. (loglike_params,
+recogn_params) by reverse-mode AD (autograd there, torch here; the structured E-step in between is
+the HIP kernels with their own VJP kernels), and the closed-form NATURAL gradient of the PGM
+parameters from the expected statistics the E-step left in `saved.stats` (:33-34).
+
+  gradfun = make_gradfun(run_inference, recognize, loglike, pgm_prior, data,
+                         batch_size, num_samples, natgrad_scale=1., callback=callback)
+  grad = gradfun((pgm_params, loglike_params, recogn_params), i)
+       = (pgm_natgrad [same nested structure as pgm_prior], loglike_grad, recogn_grad)
+
+`recognize(recogn_params, batch) -> nn_potentials` and `loglike(loglike_params, samples, batch) ->
+scalar` are the user's torch functions (the reference's svae/nnet.py is out of scope: stock PyTorch);
+`run_inference` is svae_amd.models.{lds,gmm}.run_inference_differentiable or anything with the
+same signature.  `functools.partial` replaces toolz.curry.
+"""
+import torch
+
+callback = lambda i, val, params, grad: print("{}: {}".format(i, val))
+
+
+def _leaves(struct):
+    if isinstance(struct, (tuple, list)):
+        out = []
+        for s in struct:
+            out += _leaves(s)
+        return out
+    return [struct]
+
+
+def flat(struct):
+    """autograd.util.flatten(struct)[0] (svae.py:8): concatenation of the raveled leaves."""
+    return torch.cat([torch.as_tensor(x, dtype=torch.float64).reshape(-1) for x in _leaves(struct)])
+
+
+def unflat_like(vec, struct):
+    pos = [0]
+
+    def build(s):
+        if isinstance(s, (tuple, list)):
+            return tuple(build(x) for x in s)
+        t = torch.as_tensor(s)
+        n = t.numel()
+        out = vec[pos[0]:pos[0] + n].reshape(t.shape)
+        pos[0] += n
+        return out
+    return build(struct)
+
+
+def split_into_batches(data, batch_size):
+    """util.py:120-123 without the permutation's global RNG: chunks of `batch_size` rows."""
+    k = data.shape[0] // batch_size
+    return [data[i * batch_size:(i + 1) * batch_size] for i in range(k)], k
+
+
+def make_gradfun(run_inference, recognize, loglike, pgm_prior, data, batch_size, num_samples,
+                 natgrad_scale=1., callback=callback):
+    num_datapoints = data.shape[0]
+    data_batches, num_batches = split_into_batches(data, batch_size)
+    get_batch = lambda i: data_batches[i % num_batches]
+    saved = lambda: None
+
+    def mc_elbo(pgm_params, loglike_params, recogn_params, i):
+        nn_potentials = recognize(recogn_params, get_batch(i))
+        samples, saved.stats, global_kl, local_kl = \
+            run_inference(pgm_prior, pgm_params, nn_potentials, num_samples)
+        return (num_batches * loglike(loglike_params, samples, get_batch(i))
+                - global_kl - num_batches * local_kl) / num_datapoints
+
+    def gradfun(params, i):
+        pgm_params, loglike_params, recogn_params = params
+        leaves = [p for p in _leaves((loglike_params, recogn_params))]
+        for p in leaves:
+            if p.grad is not None:
+                p.grad = None
+        val = -mc_elbo(pgm_params, loglike_params, recogn_params, i)
+        grads = torch.autograd.grad(val, leaves, allow_unused=True)
+        grads = [torch.zeros_like(p) if g is None else g for g, p in zip(grads, leaves)]
+        nl = len(_leaves(loglike_params))
+        loglike_grad = unflat_like(torch.cat([g.reshape(-1) for g in grads[:nl]]) if nl else torch.zeros(0), loglike_params)
+        recogn_grad = unflat_like(torch.cat([g.reshape(-1) for g in grads[nl:]]), recogn_params)
+        # this expression drops the same term the reference's does (svae.py:31-32)
+        dev = flat(saved.stats).device
+        pgm_natgrad = -natgrad_scale / num_datapoints * \
+            (flat(pgm_prior).to(dev) + num_batches * flat(saved.stats) - flat(pgm_params).to(dev))
+        grad = unflat_like(pgm_natgrad, pgm_prior), loglike_grad, recogn_grad
+        if callback:
+            callback(i, float(val), params, grad)
+        return grad
+
+    gradfun.mc_elbo = mc_elbo
+    return gradfun

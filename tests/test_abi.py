@@ -59,9 +59,9 @@ def test_bad_arguments_are_rejected_on_the_host():
     assert lib.svae_lds_estep_f64(4, 5, 3, 0, 0, 0, *args) == -6       # NULL init_J
     assert lib.svae_lds_sample_f64(4, 5, 3, 0, null, null, null, 0, null) == -4    # S < 1
     assert lib.svae_gmm_meanfield_f64(10, 9, 3, *([null] * 5), 1e-3, 100,
-                                      *([null] * 7), null, null, null, null) == -2
+                                      *([null] * 8), null, null, null, null) == -2
     assert lib.svae_gmm_meanfield_f64(10, 2, 65, *([null] * 5), 1e-3, 100,
-                                      *([null] * 7), null, null, null, null) == -3
+                                      *([null] * 8), null, null, null, null) == -3
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
