@@ -122,6 +122,23 @@ int svae_lds_estep_vjp_f64(int B, int T, int n, int S, const double* J12,
                            const void* workspace, size_t ws_bytes,
                            void* vjp_workspace, size_t vjp_ws_bytes, void* stream);
 
+/* Batched HMM E-step: log-normaliser and expected statistics of B chains with K <= 16 states
+ * [hmm_logZ  /root/reference/svae/hmm/cython_hmm_inference.pyx:93-121 and hmm_logZ_grad :126-166 at
+ *  g = 1, i.e. `hmm_estep_slow = vgrad(hmm_logZ)` /root/reference/svae/hmm/hmm_inference.py:65; the
+ *  reference's hmm_estep (:21-41) delegates to the un-vendored pyhsmm].
+ *  in : init_params (K) log initial potentials; pair_params (K,K) log transition potentials [j][k] =
+ *       j -> k, or (B,K,K) if pair_batched; node_params (B,T,K) log node potentials
+ *  out: logZ (B); E_init (B,K) = E[z_0]; E_trans (B,K,K) = sum_t E[z_t = j, z_{t+1} = k];
+ *       E_states (B,T,K) = E[z_t]
+ *  workspace: svae_hmm_workspace_bytes(B,T,K)
+ */
+size_t svae_hmm_workspace_bytes(int B, int T, int K);
+int svae_hmm_estep_f64(int B, int T, int K, int pair_batched,
+                       const double* init_params, const double* pair_params,
+                       const double* node_params,
+                       double* logZ, double* E_init, double* E_trans, double* E_states,
+                       void* workspace, size_t ws_bytes, void* stream);
+
 /* GMM mean-field fixed point + global statistics for one minibatch of T points
  * [local_meanfield, /root/reference/svae/models/gmm.py:62-88; meanfield_fixed_point :90-110;
  *  gaussian_meanfield :112-117; label_meanfield :119-124].

@@ -1,0 +1,181 @@
+// hmm_estep.hip -- batched HMM E-step (forward-backward + expected statistics) for MI355X (gfx950).
+//
+// What it replaces (reference = mattjj/svae, /root/reference):
+//   hmm_logZ        svae/hmm/cython_hmm_inference.pyx:93-121   (log-space forward pass)
+//   hmm_logZ_grad   svae/hmm/cython_hmm_inference.pyx:126-166  (its reverse pass at g = 1 IS the
+//                   E-step: expected initial state, transition counts, state marginals;
+//                   `hmm_estep_slow = vgrad(hmm_logZ)`, svae/hmm/hmm_inference.py:65)
+//   hmm_estep       svae/hmm/hmm_inference.py:21-41, which delegates to the un-vendored pyhsmm
+//                   messages (parity pinned on hmm_logZ / hmm_logZ_grad).
+// Used by the SLDS-SVAE coordinate ascent (svae/models/slds_svae.py:108-115, 159-175).
+//
+// Mapping: one DPP row (16 lanes) per sequence, 4 sequences per wavefront, lane k = discrete state k
+// (K <= 16).  The matrix-vector products alpha' P and P (e . beta) are row_newbcast FMAs like the
+// LDS kernels.  Scaled (not log-space) recursions: per step the node log-potentials are shifted by
+// their maximum and exponentiated ONCE per lane (the reference does K logsumexp's of K terms per
+// step), alpha is renormalised to sum 1, and log Z accumulates the scales as mantissa/exponent
+// pairs (one log per sequence).  Forward quantities needed by the backward pass (alpha_t, e_t/c_t)
+// go through a caller-owned workspace of 32 doubles per (sequence, step).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/svae_hip.h"
+#include "dpp.hpp"
+
+namespace svae {
+
+struct HmmArgs {
+  int B, T, K;
+  long pair_stride;                       // doubles between sequences' pair params (0 = shared)
+  const double* __restrict__ init_params; // (K)      log pi_0 (unnormalised ok)
+  const double* __restrict__ pair_params; // (K,K) or (B,K,K)   log P[j][k]  (j -> k)
+  const double* __restrict__ node_params; // (B,T,K)  log-likelihood potentials
+  double* __restrict__ logZ;              // (B)
+  double* __restrict__ E_init;            // (B,K)
+  double* __restrict__ E_trans;           // (B,K,K)
+  double* __restrict__ E_states;          // (B,T,K)
+  double* __restrict__ ws;                // (B,T,32)
+};
+
+template <int K>
+__global__ __launch_bounds__(64) void hmm_estep_kernel(const HmmArgs a) {
+  const int lane = threadIdx.x;
+  const int c = lane & 15;
+  const int brow = blockIdx.x * 4 + (lane >> 4);
+  const bool valid = brow < a.B;
+  const int b = valid ? brow : a.B - 1;
+  const bool col = c < K;
+  const int cc = col ? c : 0;
+  const int T = a.T;
+  const double NEG_BIG = -1.0e300;
+
+  // transition matrix in both layouts, shifted by its maximum (the shift goes into logZ)
+  const double* pp = a.pair_params + (long)b * a.pair_stride;
+  double lp[K], lpT[K];
+  static_for<0, K>([&](auto j) {
+    const double v = pp[j * K + cc], vt = pp[cc * K + j];
+    lp[j] = col ? v : NEG_BIG;            // lp[j][c] = log P[j][c]
+    lpT[j] = col ? vt : NEG_BIG;          // lpT[k][c] = log P[c][k]
+  });
+  double pmax = NEG_BIG;
+  static_for<0, K>([&](auto j) { pmax = fmax(pmax, lp[j]); });
+  static_for<0, 4>([&](auto s) { pmax = fmax(pmax, __shfl_xor(pmax, 1 << s, 16)); });
+  double P[K], PT[K];
+  static_for<0, K>([&](auto j) { P[j] = col ? exp(lp[j] - pmax) : 0.0; PT[j] = col ? exp(lpT[j] - pmax) : 0.0; });
+
+  const double* node = a.node_params + ((long)b * T) * K + cc;
+  double* wsb = a.ws + ((long)b * T) * 32 + c;
+  double one = 1.0;
+
+  // ---- forward ------------------------------------------------------------------------------------
+  double lzM = 1.0;            // product of scales (mantissa) ...
+  long lzE = 0;                // ... exponent
+  double lzS = 0.0;            // sum of the subtracted maxima
+  double alpha = 0.0;
+  double nd_n = node[0];
+  for (int t = 0; t < T; ++t) {
+    double nd = col ? nd_n : NEG_BIG;
+    if (t + 1 < T) nd_n = node[(long)(t + 1) * K];
+    if (t == 0) nd += col ? a.init_params[cc] : 0.0;
+    // m = max_k node[k]  (broadcast-and-max over the row)
+    double m = NEG_BIG;
+    dpp_fence(nd);
+    static_for<0, K>([&](auto k) { m = fmax(m, bcast_fenced<k>(nd)); });
+    const double e = col ? exp(nd - m) : 0.0;
+    double pred;
+    if (t == 0) {
+      pred = col ? 1.0 : 0.0;
+    } else {
+      pred = 0.0;
+      dpp_fence(alpha);
+      static_for<0, K>([&](auto j) { mac_bc<j, false, true>(pred, alpha, P[j]); });   // sum_j alpha[j] P[j][k]
+    }
+    double al = pred * e;
+    double cs = 0.0;
+    dpp_fence(al);
+    static_for<0, K>([&](auto k) { mac_bc<k, false, true>(cs, al, one); });            // c_t = sum_k
+    const double rc = 1.0 / cs;
+    alpha = al * rc;
+    if (valid) { wsb[(long)t * 32] = alpha; wsb[(long)t * 32 + 16] = e * rc; }
+    lzM *= __builtin_amdgcn_frexp_mant(cs);
+    lzE += __builtin_amdgcn_frexp_exp(cs);
+    lzS += m + (t > 0 ? pmax : 0.0);
+    if ((t & 15) == 15) { lzE += __builtin_amdgcn_frexp_exp(lzM); lzM = __builtin_amdgcn_frexp_mant(lzM); }
+  }
+  if (valid && c == 0) a.logZ[b] = lzS + ::log(lzM) + (double)lzE * 0.6931471805599453094;
+
+  // ---- backward + statistics ----------------------------------------------------------------------
+  double beta = col ? 1.0 : 0.0;
+  double acc[K];
+  static_for<0, K>([&](auto j) { acc[j] = 0.0; });
+  double* oS = a.E_states + ((long)b * T) * K + cc;
+  {
+    const double gam = alpha * beta;      // t = T-1
+    if (valid && col) oS[(long)(T - 1) * K] = gam;
+    if (T == 1 && valid && col) a.E_init[(long)b * K + c] = gam;
+  }
+  for (int t = T - 2; t >= 0; --t) {
+    const double u = wsb[(long)(t + 1) * 32 + 16];     // e_{t+1} / c_{t+1}
+    const double al = wsb[(long)t * 32];
+    double w = u * beta;
+    double al_f = al;
+    dpp_fence(w);
+    dpp_fence(al_f);
+    double bn = 0.0;
+    static_for<0, K>([&](auto k) { mac_bc<k, false, true>(bn, w, PT[k]); });            // beta_t[j] = sum_k P[j][k] w[k]
+    static_for<0, K>([&](auto j) { mac_bc<j, false, true>(acc[j], al_f, w); });         // xi sums (without P)
+    beta = bn;
+    const double gam = al * beta;
+    if (valid && col) oS[(long)t * K] = gam;
+    if (t == 0 && valid && col) a.E_init[(long)b * K + c] = gam;
+  }
+  if (valid && col) {
+    static_for<0, K>([&](auto j) { a.E_trans[(long)b * K * K + j * K + c] = acc[j] * P[j]; });
+  }
+}
+
+template <int K>
+static int launch_hmm(const HmmArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL((hmm_estep_kernel<K>), dim3((a.B + 3) / 4), dim3(64), 0, s, a);
+  return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+}  // namespace svae
+
+extern "C" size_t svae_hmm_workspace_bytes(int B, int T, int K) {
+  if (B <= 0 || T <= 0 || K <= 0 || K > 16) return 0;
+  return (size_t)B * T * 32 * sizeof(double);
+}
+
+extern "C" int svae_hmm_estep_f64(int B, int T, int K, int pair_batched,
+                                  const double* init_params, const double* pair_params,
+                                  const double* node_params,
+                                  double* logZ, double* E_init, double* E_trans, double* E_states,
+                                  void* workspace, size_t ws_bytes, void* stream) {
+  if (B < 0) return -1;
+  if (T < 1) return -2;
+  if (K < 1 || K > 16) return -3;
+  if (!init_params) return -5;
+  if (!pair_params) return -6;
+  if (!node_params) return -7;
+  if (!logZ) return -8;
+  if (!E_init) return -9;
+  if (!E_trans) return -10;
+  if (!E_states) return -11;
+  if (!workspace || ws_bytes < svae_hmm_workspace_bytes(B, T, K)) return -12;
+  if (B == 0) return 0;
+  svae::HmmArgs a;
+  a.B = B; a.T = T; a.K = K; a.pair_stride = pair_batched ? (long)K * K : 0;
+  a.init_params = init_params; a.pair_params = pair_params; a.node_params = node_params;
+  a.logZ = logZ; a.E_init = E_init; a.E_trans = E_trans; a.E_states = E_states;
+  a.ws = (double*)workspace;
+  hipStream_t s = (hipStream_t)stream;
+  switch (K) {
+#define SVAE_CASE(KK) case KK: return svae::launch_hmm<KK>(a, s);
+    SVAE_CASE(1) SVAE_CASE(2) SVAE_CASE(3) SVAE_CASE(4) SVAE_CASE(5) SVAE_CASE(6) SVAE_CASE(7)
+    SVAE_CASE(8) SVAE_CASE(9) SVAE_CASE(10) SVAE_CASE(11) SVAE_CASE(12) SVAE_CASE(13)
+    SVAE_CASE(14) SVAE_CASE(15) SVAE_CASE(16)
+#undef SVAE_CASE
+  }
+  return -3;
+}

@@ -1,0 +1,60 @@
+"""GPU parity tests of the HMM E-step kernel against the reference's compiled hmm_logZ /
+hmm_logZ_grad (oracle/_ref, built from svae/hmm/cython_hmm_inference.pyx) and the NumPy oracle."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import hmm_numpy, ref  # noqa: E402  (checker only)
+
+
+def _np(x):
+    return x.detach().cpu().numpy()
+
+
+def _problem(B, T, K, rng, scale=1.0):
+    init = np.log(rng.dirichlet(np.ones(K)))
+    pair = np.log(rng.dirichlet(np.ones(K), size=K)) + 0.3 * rng.standard_normal((K, K))   # unnormalised
+    node = scale * rng.standard_normal((B, T, K))
+    return init, pair, node
+
+
+@pytest.mark.parametrize("B,T,K,scale", [(5, 7, 3, 1.0), (9, 50, 8, 3.0), (2, 500, 8, 50.0), (3, 1, 4, 1.0),
+                                         (4, 33, 16, 1.0), (1, 12, 1, 2.0)])
+def test_hmm_estep_against_oracle_and_reference(B, T, K, scale):
+    from svae_amd.hmm.hmm_inference import hmm_estep
+    rng = np.random.default_rng(B * 100 + T + K)
+    init, pair, node = _problem(B, T, K, rng, scale)
+    logZ, (Ei, Et, Es) = hmm_estep((init, pair, node))
+    for b in range(B):
+        lz, (oi, ot, os_) = hmm_numpy.hmm_estep((init, pair, node[b]))
+        assert float(logZ[b]) == pytest.approx(lz, rel=1e-10, abs=1e-10)
+        np.testing.assert_allclose(_np(Ei[b]), oi, rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(_np(Et[b]), ot, rtol=1e-8, atol=1e-11)
+        np.testing.assert_allclose(_np(Es[b]), os_, rtol=1e-8, atol=1e-12)
+        if ref.available():
+            rz, aux = ref.hmm_logZ((init, pair, node[b]))
+            gi, gp, gn = ref.hmm_logZ_grad(1.0, aux)
+            assert float(logZ[b]) == pytest.approx(rz, rel=1e-10, abs=1e-10)
+            np.testing.assert_allclose(_np(Et[b]), gp, rtol=1e-8, atol=1e-11)
+            np.testing.assert_allclose(_np(Es[b]), gn, rtol=1e-8, atol=1e-12)
+            np.testing.assert_allclose(_np(Ei[b]), gi, rtol=1e-8, atol=1e-12)
+    # properties: marginals sum to one, transition counts to T-1
+    assert float((Es.sum(-1) - 1).abs().max()) < 1e-12
+    assert float((Et.sum((-1, -2)) - (T - 1)).abs().max()) < 1e-10 * max(1, T)
+
+
+def test_hmm_batched_pair_params_and_unbatched_call():
+    from svae_amd.hmm.hmm_inference import hmm_estep, hmm_logZ
+    rng = np.random.default_rng(3)
+    B, T, K = 3, 9, 4
+    init, _, node = _problem(B, T, K, rng)
+    pairs = np.stack([_problem(1, 1, K, rng)[1] for _ in range(B)])
+    logZ, (Ei, Et, Es) = hmm_estep((init, pairs, node))
+    for b in range(B):
+        lz, (oi, ot, os_) = hmm_numpy.hmm_estep((init, pairs[b], node[b]))
+        assert float(logZ[b]) == pytest.approx(lz, rel=1e-10)
+        np.testing.assert_allclose(_np(Et[b]), ot, rtol=1e-8, atol=1e-11)
+    lz1 = hmm_logZ((init, pairs[0], node[0]))
+    assert lz1.dim() == 0 and float(lz1) == pytest.approx(float(logZ[0]), rel=1e-13)
