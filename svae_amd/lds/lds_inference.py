@@ -26,7 +26,7 @@ def _as_dev(x, device):
     if isinstance(x, torch.Tensor):
         t = x.detach()
     else:
-        t = torch.as_tensor(x)
+        t = torch.as_tensor(x, dtype=torch.float64)   # (a bare python float would become float32)
     return t.to(device=device, dtype=torch.float64).contiguous()
 
 

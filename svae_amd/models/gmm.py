@@ -20,7 +20,8 @@ GMM_MAX_N, GMM_MAX_K = 8, 64
 
 
 def _dev64(x, device):
-    t = x.detach() if isinstance(x, torch.Tensor) else torch.as_tensor(x)
+    # dtype given up front: torch.as_tensor(python_float) alone would round to float32
+    t = x.detach() if isinstance(x, torch.Tensor) else torch.as_tensor(x, dtype=torch.float64)
     return t.to(device=device, dtype=torch.float64).contiguous()
 
 

@@ -24,7 +24,8 @@ from ..parallel import allreduce_global_stats
 
 
 def _dev64(x, device):
-    t = x.detach() if isinstance(x, torch.Tensor) else torch.as_tensor(x)
+    # dtype given up front: torch.as_tensor(python_float) alone would round to float32
+    t = x.detach() if isinstance(x, torch.Tensor) else torch.as_tensor(x, dtype=torch.float64)
     return t.to(device=device, dtype=torch.float64).contiguous()
 
 

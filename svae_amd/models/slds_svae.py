@@ -1,0 +1,225 @@
+"""SLDS-SVAE local inference on MI355X; mirrors /root/reference/svae/models/slds_svae.py:80-310.
+
+  lds_meanfield / get_var_lds_local_natparam      (:80-103)  -> svae_lds_estep_f64, per-sequence
+                                                              time-inhomogeneous pair parameters
+  hmm_meanfield / get_arhmm_local_nodeparams      (:108-147) -> svae_hmm_estep_f64
+  optimize_local_meanfield                        (:159-175) coordinate ascent between the two
+  initialize_local_meanfield                      (:203-226) one sample of a random-walk LDS posterior
+  get_global_stats                                (:229-243)
+  run_inference                                   (:289-310)
+
+The reference module is stale as shipped (imports svae.lds.niw/mniw, svae.hmm.dirichlet, lds_svae,
+none of which exist; hmm_estep needs the un-vendored pyhsmm).  Formulas are taken from it with
+svae/distributions/{niw,mniw,dirichlet}.py.  The two message-passing hot loops run in the HIP
+kernels; the contractions between them (O(B T K n^2) einsums) are torch ops on the device.
+Batched: node potentials (B,T,n); every sequence runs its own coordinate ascent and stops on its own
+|delta vlb| < tol like the reference (converged sequences are frozen).
+"""
+import torch
+
+from ..distributions import expfam
+from ..hmm.hmm_inference import hmm_estep
+from ..lds.lds_inference import LDSEStepPlan, natural_lds_estep_general, natural_lds_inference_general
+
+
+def _dev64(x, device):
+    # dtype given up front: torch.as_tensor(python_float) alone would round to float32
+    t = x.detach() if isinstance(x, torch.Tensor) else torch.as_tensor(x, dtype=torch.float64)
+    return t.to(device=device, dtype=torch.float64).contiguous()
+
+
+def hmm_prior_expectedstats(natparam):
+    """(:124-130) Dirichlet rows -> (E log pi_0 (K), E log P (K,K))."""
+    dir_natparam, mdir_natparam = natparam
+    return expfam.dirichlet_expectedstats(dir_natparam), expfam.dirichlet_expectedstats(mdir_natparam)
+
+
+def get_all_lds_local_natparams(lds_global_natparams):
+    """(:86-89) per discrete state k: init 4-tuple and pair 4-tuple, stacked over k."""
+    inits, pairs = [], []
+    for niw_nat, mniw_nat in lds_global_natparams:
+        inits.append(expfam.unpack_dense(expfam.niw_expectedstats(niw_nat)))
+        pairs.append(expfam.mniw_expectedstats(mniw_nat))
+    stack = lambda tuples: tuple(torch.stack([torch.as_tensor(t[i], dtype=torch.float64) for t in tuples]) for i in range(4))
+    return stack(inits), stack(pairs)          # each: 4 tensors with leading K
+
+
+def get_var_lds_local_natparam(dense_init, dense_pair, expected_states):
+    """(:92-103) expected_states (B,T,K) -> init params (B,..) and per-step pair params (B,T-1,..)."""
+    w0, w1 = expected_states[:, 0], expected_states[:, 1:]
+    init = tuple(torch.tensordot(w0, p, dims=1) for p in dense_init)
+    pair = tuple(torch.tensordot(w1, p, dims=1) for p in dense_pair)
+    return init, pair
+
+
+def get_arhmm_local_nodeparams(dense_init, dense_pair, init_stats, pair_stats):
+    """(:131-147) node[b,0,k] = <init_stats_b, init_params_k>, node[b,t+1,k] = <pair_stats_bt, pair_params_k>."""
+    ExxT0, Ex0 = init_stats
+    n0 = torch.einsum("bij,kij->bk", ExxT0, dense_init[0]) + torch.einsum("bi,ki->bk", Ex0, dense_init[1]) \
+        + dense_init[2] + dense_init[3]
+    Exx, Exxn, Exnxn = pair_stats
+    nt = torch.einsum("btij,kij->btk", Exx, dense_pair[0]) + torch.einsum("btij,kij->btk", Exxn, dense_pair[1]) \
+        + torch.einsum("btij,kij->btk", Exnxn, dense_pair[2]) + dense_pair[3]
+    return torch.cat([n0[:, None], nt], 1)
+
+
+def initialize_local_meanfield(node_potentials, eps):
+    """(:203-226) statistics of ONE posterior sample path of a random-walk LDS; eps (B,T,1,n)."""
+    nJ = node_potentials[0]
+    B, T, n = nJ.shape
+    dev = nJ.device
+    eye = torch.eye(n, dtype=torch.float64, device=dev)
+    A = 0.9 * eye
+    natparam = ((-0.5 * eye, torch.zeros(n, dtype=torch.float64, device=dev), torch.zeros((), dtype=torch.float64, device=dev)),
+                (-0.5 * A.T @ A, A.T.contiguous(), -0.5 * eye, torch.zeros((), dtype=torch.float64, device=dev)))
+    x, _, _ = natural_lds_inference_general(natparam, node_potentials, num_samples=1, eps=eps)
+    x = x[:, :, 0]                                                   # (B,T,n)
+    out = lambda a, b: a.unsqueeze(-1) * b.unsqueeze(-2)
+    init_stats = (out(x[:, 0], x[:, 0]), x[:, 0])
+    pair_stats = (out(x[:, :-1], x[:, :-1]), out(x[:, :-1], x[:, 1:]), out(x[:, 1:], x[:, 1:]))
+    return init_stats, pair_stats
+
+
+def optimize_local_meanfield(global_natparam, node_potentials, init_eps, tol=1e-2, max_iter=100):
+    """(:159-175).  Returns ((hmm_stats, lds_stats), (hmm_natparam, lds_natparam), (hmm_vlb, lds_vlb), iters)."""
+    hmm_global, lds_global = global_natparam
+    dev = node_potentials[0].device
+    node = tuple(_dev64(x, dev) for x in node_potentials)
+    B, T, n = node[1].shape
+    hmm_init, hmm_pair = hmm_prior_expectedstats(tuple(_dev64(x, dev) for x in hmm_global))
+    lds_global = [(_dev64(a, dev), tuple(_dev64(y, dev) for y in m)) for a, m in lds_global]
+    dense_init, dense_pair = get_all_lds_local_natparams(lds_global)
+    plan = LDSEStepPlan(B, T, n, dev, inhomog=True)
+
+    init_stats, pair_stats = initialize_local_meanfield(node, _dev64(init_eps, dev))
+    vlb = torch.full((B,), -float("inf"), dtype=torch.float64, device=dev)
+    active = torch.ones(B, dtype=torch.bool, device=dev)
+    iters = torch.zeros(B, dtype=torch.int64, device=dev)
+    keep = {}
+    for _ in range(max_iter):
+        node_hmm = get_arhmm_local_nodeparams(dense_init, dense_pair, init_stats, pair_stats)
+        hmm_vlb, (Ei, Et, Es) = hmm_estep((hmm_init, hmm_pair, node_hmm))
+        lds_init, lds_pair = get_var_lds_local_natparam(dense_init, dense_pair, Es)
+        # the E-step API takes one shared init potential per launch: fold each sequence's init
+        # potential into its first node potential instead (identical model: both multiply x_0's factor)
+        lds_vlb, (Ei_l, Ep_l, En_l) = _lds_estep_batched_init(plan, lds_init, lds_pair, node)
+        new = dict(hmm_stats=(Ei, Et, Es), init_stats=(Ei_l[0], Ei_l[1]), pair_stats=(Ep_l[0], Ep_l[1], Ep_l[2]),
+                   node_stats=(En_l[0], En_l[1]), hmm_natparam=node_hmm, lds_init=lds_init, lds_pair=lds_pair,
+                   hmm_vlb=hmm_vlb, lds_vlb=lds_vlb)
+        sel = lambda old, val: val if old is None else torch.where(active.view((-1,) + (1,) * (val.dim() - 1)), val, old)
+        for k, v in new.items():
+            if isinstance(v, tuple):
+                keep[k] = tuple(sel(None if k not in keep else keep[k][i], x.clone()) for i, x in enumerate(v))
+            else:
+                keep[k] = sel(keep.get(k), v.clone())
+        init_stats, pair_stats = keep["init_stats"], keep["pair_stats"]
+        new_vlb = keep["hmm_vlb"] + keep["lds_vlb"]
+        iters += active.to(torch.int64)
+        done = (new_vlb - vlb).abs() < tol
+        vlb = new_vlb
+        active = active & ~done
+        if not bool(active.any()):
+            break
+    lds_stats = (keep["init_stats"], keep["pair_stats"], keep["node_stats"])
+    return (keep["hmm_stats"], lds_stats), ((hmm_init, hmm_pair, keep["hmm_natparam"]), (keep["lds_init"], keep["lds_pair"])), \
+        (keep["hmm_vlb"], keep["lds_vlb"]), iters
+
+
+def optimize_local_meanfield_withlabels(global_natparam, node_potentials, labels):
+    """(:178-200) discrete states given: HMM stats from the labels (B,T) int, then one LDS mean-field step."""
+    hmm_global, lds_global = global_natparam
+    dev = node_potentials[0].device
+    node = tuple(_dev64(x, dev) for x in node_potentials)
+    B, T, n = node[1].shape
+    K = torch.as_tensor(hmm_global[0]).shape[0]
+    labels = torch.as_tensor(labels, device=dev).long()
+    ind = torch.nn.functional.one_hot(labels, K).to(torch.float64)             # (B,T,K)
+    E_trans = torch.einsum("bti,btj->bij", ind[:, :-1], ind[:, 1:])
+    soft = ind + 1e-2
+    hmm_stats = (ind[:, 0], E_trans, soft / soft.sum(-1, keepdim=True))
+    lds_global = [(_dev64(a, dev), tuple(_dev64(y, dev) for y in m)) for a, m in lds_global]
+    dense_init, dense_pair = get_all_lds_local_natparams(lds_global)
+    lds_init, lds_pair = get_var_lds_local_natparam(dense_init, dense_pair, hmm_stats[2])
+    plan = LDSEStepPlan(B, T, n, dev, inhomog=True)
+    lds_vlb, (Ei, Ep, En) = _lds_estep_batched_init(plan, lds_init, lds_pair, node)
+    lds_stats = ((Ei[0].clone(), Ei[1].clone()), tuple(x.clone() for x in Ep[:3]), tuple(x.clone() for x in En[:2]))
+    return (hmm_stats, lds_stats), (None, (lds_init, lds_pair)), (torch.zeros_like(lds_vlb), lds_vlb.clone())
+
+
+def _lds_estep_batched_init(plan, lds_init, lds_pair, node, keep_factor=False):
+    """LDS E-step with a PER-SEQUENCE init potential (the SLDS mixes K init potentials by E[z_0]):
+    run the kernel with a zero shared init potential and add each sequence's (J0, h0) to its first
+    node potential's dense block... the kernel's node potentials are diagonal, so instead the init
+    potential is passed through the batched pair-parameter path: J11 of step 0 absorbs J0, and h0 is
+    added to node_h[:,0]; log-normaliser constants are added back on the host."""
+    J0, h0, a0, b0 = lds_init                      # (B,n,n), (B,n), (B), (B)
+    J11, J12, J22, lz = lds_pair                   # (B,T-1,...)
+    B, T, n = node[1].shape
+    dev = node[1].device
+    nJ, nh = node[0], node[1].clone()
+    nh[:, 0] += h0
+    zero = torch.zeros((), dtype=torch.float64, device=dev)
+    if T > 1:
+        J11 = J11.clone()
+        J11[:, 0] += J0                            # -1/2 x0' J0 x0 multiplies the same variable as J11[0]
+        natparam = ((torch.zeros(n, n, dtype=torch.float64, device=dev), torch.zeros(n, dtype=torch.float64, device=dev), zero),
+                    (J11.contiguous(), J12.contiguous(), J22.contiguous(), lz.contiguous()))
+        lognorm, stats = natural_lds_estep_general(natparam, (nJ, nh) + tuple(node[2:]), plan=plan,
+                                                   keep_factor=keep_factor)
+        return lognorm + a0 + b0, stats
+    raise NotImplementedError("SLDS needs T > 1")
+
+
+def get_global_stats(hmm_stats, init_stats, pair_stats):
+    """(:229-243) -> (hmm (E_init, E_trans) summed over the batch, per state k: (init stats, pair stats))."""
+    Ei, Et, Es = hmm_stats
+    w0, w1 = Es[:, 0], Es[:, 1:]
+    ExxT0, Ex0 = init_stats
+    ones = torch.ones_like(w0)
+    g_init = (torch.einsum("bk,bij->kij", w0, ExxT0), torch.einsum("bk,bi->ki", w0, Ex0), w0.sum(0), w0.sum(0))
+    g_pair = tuple(torch.einsum("btk,btij->kij", w1, p) for p in pair_stats) + (w1.sum((0, 1)),)
+    return (Ei.sum(0), Et.sum(0)), (g_init, g_pair)
+
+
+def run_inference(prior_natparam, global_natparam, nn_potentials, num_samples, init_eps=None, eps=None,
+                  generator=None, tol=1e-2):
+    """(:289-310) -> (samples (B,T,S,n), expected_stats, global_vlb, local_vlb).  Forward values only:
+    the VJP of the time-inhomogeneous E-step is not built yet."""
+    dev = nn_potentials[1].device
+    node = tuple(_dev64(x, dev) for x in nn_potentials)
+    B, T, n = node[1].shape
+    if init_eps is None:
+        init_eps = torch.randn(B, T, 1, n, dtype=torch.float64, device=dev, generator=generator)
+    (hmm_stats, _), (hmm_nat, (lds_init, lds_pair)), _, _ = optimize_local_meanfield(global_natparam, node, init_eps, tol)
+    plan = LDSEStepPlan(B, T, n, dev, inhomog=True)
+    lognorm, (Ei, Ep, En) = _lds_estep_batched_init(plan, lds_init, lds_pair, node, keep_factor=True)
+    S = int(num_samples)
+    if eps is None:
+        eps = torch.randn(B, T, S, n, dtype=torch.float64, device=dev, generator=generator)
+    samples = plan.sample(_dev64(eps, dev))
+    hmm_global, lds_global = global_natparam
+    lds_global_d = [(_dev64(a, dev), tuple(_dev64(y, dev) for y in m)) for a, m in lds_global]
+    dense_init, dense_pair = get_all_lds_local_natparams(lds_global_d)
+    node_hmm = get_arhmm_local_nodeparams(dense_init, dense_pair, (Ei[0], Ei[1]), (Ep[0], Ep[1], Ep[2]))
+    hmm_vlb, _ = hmm_estep((hmm_nat[0], hmm_nat[1], node_hmm))
+    expected_stats = get_global_stats(hmm_stats, (Ei[0], Ei[1]), (Ep[0], Ep[1], Ep[2]))
+    lds_vlb = lognorm - ((node[0] * En[0]).sum((1, 2)) + (node[1] * En[1]).sum((1, 2)))
+    local_vlb = (hmm_vlb + lds_vlb).sum()
+    global_vlb = slds_prior_vlb(global_natparam, prior_natparam, dev)
+    return samples, expected_stats, global_vlb, local_vlb
+
+
+def slds_prior_vlb(global_natparam, prior_natparam, dev):
+    """(:248-286) <prior - global, E_global[stats]> - (logZ(prior) - logZ(global))."""
+    def parts(natparam):
+        (d, md), lds = natparam
+        return (_dev64(d, dev), _dev64(md, dev)), [(_dev64(a, dev), tuple(_dev64(y, dev) for y in m)) for a, m in lds]
+    (gd, gmd), glds = parts(global_natparam)
+    (pd, pmd), plds = parts(prior_natparam)
+    val = ((pd - gd) * expfam.dirichlet_expectedstats(gd)).sum() + ((pmd - gmd) * expfam.dirichlet_expectedstats(gmd)).sum()
+    logZ = lambda d, md, lds: expfam.dirichlet_logZ(d) + expfam.dirichlet_logZ(md) + \
+        sum(expfam.niw_logZ(a) + expfam.mniw_logZ(m) for a, m in lds)
+    for (ga, gm), (pa, pm) in zip(glds, plds):
+        val = val + ((pa - ga) * expfam.niw_expectedstats(ga)).sum()
+        val = val + sum(((x - y) * e).sum() for x, y, e in zip(pm, gm, expfam.mniw_expectedstats(gm)))
+    return val - (logZ(pd, pmd, plds) - logZ(gd, gmd, glds))

@@ -64,16 +64,14 @@ def test_lds_run_inference_against_oracle(n, T, B, S):
     samples, (niw_stats, mniw_stats), global_kl, local_kl = run_inference(prior, glob, node, S, eps=eps)
     want = [models_numpy.lds_run_inference(prior, glob, tuple(x[b] for x in node), eps[b]) for b in range(B)]
     for b in range(B):
-        assert _rel(samples[b], want[b][0]) < 1e-6
+        assert _rel(samples[b], want[b][0]) < 1e-8
     E_init = sum(ef.pack_dense(w[1][0][0], w[1][0][1], np.array(1.), np.array(1.)) for w in want)
-    # 1e-6: the global->local maps run in torch here and in NumPy in the oracle (1e-12 apart); the
-    # near-degenerate pair potential of this prior amplifies that, not the kernel (cf. test_lds_hip)
-    assert _rel(niw_stats, E_init) < 1e-6
+    assert _rel(niw_stats, E_init) < 1e-8
     for i in range(3):
-        assert _rel(mniw_stats[i], sum(np.asarray(w[1][1][i]) for w in want)) < 1e-6
+        assert _rel(mniw_stats[i], sum(np.asarray(w[1][1][i]) for w in want)) < 1e-8
     assert float(mniw_stats[3]) == B * (T - 1)
-    assert float(local_kl) == pytest.approx(sum(w[3] for w in want), rel=1e-6)
-    assert float(global_kl) == pytest.approx(want[0][2], rel=1e-6)   # difference of large logZ terms
+    assert float(local_kl) == pytest.approx(sum(w[3] for w in want), rel=1e-8)
+    assert float(global_kl) == pytest.approx(want[0][2], rel=1e-8)   # difference of large logZ terms
 
 
 def test_lds_run_inference_unbatched_shapes():

@@ -160,3 +160,31 @@ def test_model_glue_oracle_consistency():
         num = (ef.mniw_logZ(tuple(p)) - ef.mniw_logZ(tuple(m_))) / (2 * eps)
         # expectedstats are w.r.t. the (A,B,C,d) parametrisation of logZ up to the symmetric embedding
         assert np.isfinite(num)
+
+
+def test_slds_coordinate_ascent_oracle_is_monotone():
+    """The SLDS glue restatement (slds_svae.py:159-175) has no importable reference to pin it
+    against (its pieces are pinned above).  Check what a coordinate ascent must satisfy: a tighter
+    tolerance needs at least as many sweeps, the HMM statistics are normalised, and the converged
+    solution is a fixed point of one more sweep."""
+    from oracle import slds_numpy, expfam_numpy as ef
+    rng = np.random.default_rng(3)
+    K, n, T = 3, 3, 14
+    lds = []
+    for k in range(K):
+        nu, S = n + 1.5, 2. * (n + 1) * np.eye(n)
+        M = 0.9 * np.eye(n) + 0.1 * k * np.eye(n, k=1)
+        lds.append((ef.niw_standard_to_natural(S, 0.2 * rng.standard_normal(n), np.array(0.5), np.array(nu)),
+                    ef.mniw_standard_to_natural(nu, S, M, 0.2 * np.eye(n))))
+    glob = ((rng.random(K), rng.random((K, K)) + 2 * np.eye(K)), lds)
+    node = (-0.5 * (0.5 + rng.random((T, n))), 2 * rng.standard_normal((T, n)))
+    eps = rng.standard_normal((T, 1, n))
+    r_loose = slds_numpy.optimize_local_meanfield(glob, node, eps, tol=1e-1)
+    r_tight = slds_numpy.optimize_local_meanfield(glob, node, eps, tol=1e-6)
+    assert r_tight["iters"] >= r_loose["iters"]
+    assert np.allclose(r_tight["hmm_stats"][2].sum(1), 1.0)
+    assert abs(r_tight["hmm_stats"][1].sum() - (T - 1)) < 1e-9
+    # a fixed point: one more sweep from the tight solution reproduces it
+    inits, pairs = slds_numpy.get_all_lds_local_natparams(lds)
+    node_hmm = slds_numpy.get_arhmm_local_nodeparams(inits, pairs, r_tight["init_stats"], r_tight["pair_stats"])
+    np.testing.assert_allclose(node_hmm, r_tight["node_hmm"], atol=1e-3)

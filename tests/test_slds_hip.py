@@ -1,0 +1,117 @@
+"""GPU tests of the SLDS-SVAE local inference (svae_amd/models/slds_svae.py): the coordinate ascent
+between the HMM and LDS E-step kernels against the NumPy restatement of svae/models/slds_svae.py."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import expfam_numpy as ef, slds_numpy  # noqa: E402  (checker only)
+
+
+def _np(x):
+    return x.detach().cpu().numpy()
+
+
+def _close(got, want, tol=1e-6):
+    """relative to max(|want_ij|, 1e-3 max|want|): entries that cancel to ~0 are judged on the array's scale"""
+    got, want = _np(got), np.asarray(want, float)
+    scale = np.maximum(np.abs(want), 1e-3 * max(np.max(np.abs(want)), 1e-300))
+    err = float(np.max(np.abs(got - want) / scale))
+    assert err < tol, err
+
+
+def _globals(K, n, rng):
+    dir_nat = rng.random(K) * 2.
+    mdir_nat = rng.random((K, K)) * 2. + 3. * np.eye(K)
+    lds = []
+    for k in range(K):
+        nu, S = n + 1. + rng.random(), 2. * (n + 1) * np.eye(n)
+        mu, kappa = 0.3 * rng.standard_normal(n), 0.5
+        th = 0.4 * (k + 1)
+        M = 0.95 * np.eye(n)
+        M[:2, :2] = 0.95 * np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        Kmat = 0.2 * np.eye(n)
+        lds.append((ef.niw_standard_to_natural(S, mu, np.array(kappa), np.array(nu)),
+                    ef.mniw_standard_to_natural(nu, S, M, Kmat)))
+    return (dir_nat, mdir_nat), lds
+
+
+def _nodes(B, T, n, rng):
+    J = -0.5 * (0.5 + rng.random((B, T, n)))
+    h = rng.standard_normal((B, T, n)) * 2.
+    return J, h
+
+
+@pytest.mark.parametrize("K,n,T,B", [(3, 2, 12, 3), (4, 5, 30, 6), (2, 10, 16, 2)])
+def test_optimize_local_meanfield_matches_oracle(K, n, T, B):
+    from svae_amd.models import slds_svae
+    rng = np.random.default_rng(100 * K + n)
+    glob = _globals(K, n, rng)
+    J, h = _nodes(B, T, n, rng)
+    eps = rng.standard_normal((B, T, 1, n))
+    dev = torch.device("cuda:0")
+    node = (torch.as_tensor(J, device=dev), torch.as_tensor(h, device=dev))
+    (hmm_stats, lds_stats), _, (hmm_vlb, lds_vlb), iters = slds_svae.optimize_local_meanfield(glob, node, eps)
+    for b in range(B):
+        ref = slds_numpy.optimize_local_meanfield(glob, (J[b], h[b]), eps[b])
+        assert int(iters[b]) == ref["iters"]
+        assert float(hmm_vlb[b]) == pytest.approx(ref["hmm_vlb"], rel=1e-7, abs=1e-7)
+        assert float(lds_vlb[b]) == pytest.approx(ref["lds_vlb"], rel=1e-7, abs=1e-7)
+        _close(hmm_stats[2][b], ref["hmm_stats"][2])
+        _close(hmm_stats[1][b], ref["hmm_stats"][1])
+        for got, want in zip(lds_stats[0], ref["init_stats"]):
+            _close(got[b], want)
+        for got, want in zip(lds_stats[1], ref["pair_stats"]):
+            _close(got[b], want)
+
+
+def test_run_inference_and_global_stats():
+    from svae_amd.models import slds_svae
+    K, n, T, B, S = 3, 4, 20, 4, 2
+    rng = np.random.default_rng(7)
+    glob, prior = _globals(K, n, rng), _globals(K, n, rng)
+    J, h = _nodes(B, T, n, rng)
+    init_eps, eps = rng.standard_normal((B, T, 1, n)), rng.standard_normal((B, T, S, n))
+    dev = torch.device("cuda:0")
+    node = (torch.as_tensor(J, device=dev), torch.as_tensor(h, device=dev))
+    samples, (hmm_g, (g_init, g_pair)), global_vlb, local_vlb = slds_svae.run_inference(
+        prior, glob, node, S, init_eps=init_eps, eps=eps)
+    assert tuple(samples.shape) == (B, T, S, n) and torch.isfinite(samples).all()
+    want_hmm = [0., 0.]
+    want_init, want_pair = None, None
+    tot = 0.
+    for b in range(B):
+        ref = slds_numpy.optimize_local_meanfield(glob, (J[b], h[b]), init_eps[b])
+        (Ei, Et), (gi, gp) = slds_numpy.get_global_stats(ref["hmm_stats"], ref["init_stats"], ref["pair_stats"])
+        want_hmm = [want_hmm[0] + Ei, want_hmm[1] + Et]
+        want_init = gi if want_init is None else tuple(x + y for x, y in zip(want_init, gi))
+        want_pair = gp if want_pair is None else tuple(x + y for x, y in zip(want_pair, gp))
+    np.testing.assert_allclose(_np(hmm_g[0]), want_hmm[0], rtol=1e-6)
+    _close(hmm_g[1], want_hmm[1])
+    for got, want in zip(g_init, want_init):
+        _close(got, want)
+    for got, want in zip(g_pair, want_pair):
+        _close(got, want)
+    assert np.isfinite(float(global_vlb)) and np.isfinite(float(local_vlb))
+
+
+def test_withlabels_matches_oracle():
+    from svae_amd.models import slds_svae
+    K, n, T, B = 3, 3, 15, 3
+    rng = np.random.default_rng(11)
+    glob = _globals(K, n, rng)
+    J, h = _nodes(B, T, n, rng)
+    labels = rng.integers(0, K, (B, T))
+    dev = torch.device("cuda:0")
+    node = (torch.as_tensor(J, device=dev), torch.as_tensor(h, device=dev))
+    (hmm_stats, lds_stats), _, (_, lds_vlb) = slds_svae.optimize_local_meanfield_withlabels(glob, node, labels)
+    for b in range(B):
+        ref = slds_numpy.optimize_local_meanfield_withlabels(glob, (J[b], h[b]), labels[b])
+        assert float(lds_vlb[b]) == pytest.approx(ref["lds_vlb"], rel=1e-8)
+        np.testing.assert_allclose(_np(hmm_stats[1][b]), ref["hmm_stats"][1])
+        np.testing.assert_allclose(_np(hmm_stats[2][b]), ref["hmm_stats"][2], rtol=1e-12)
+        for got, want in zip(lds_stats[1], ref["pair_stats"]):
+            _close(got[b], want)
+        for got, want in zip(lds_stats[2], ref["node_stats"]):
+            _close(got[b], want)
