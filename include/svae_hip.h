@@ -27,6 +27,7 @@ extern "C" {
 
 #define SVAE_HIP_ABI_VERSION 1
 #define SVAE_LDS_MAX_N 15   /* register/DPP path: one 16-lane row per sequence, n+1 <= 16 */
+#define SVAE_LDS_TILE_MAX_N 64   /* 16 <= n <= 64: LDS-tiled MFMA path (E-step only: keep must be 0) */
 
 /* Library/ABI version (host only, no GPU needed). */
 int svae_hip_abi_version(void);

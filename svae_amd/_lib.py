@@ -13,7 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVAE_AMD_LIB", os.path.join(_HERE, "libsvae_hip.so"))  # env: experiments only
 
 ABI_VERSION = 1
-LDS_MAX_N = 15
+LDS_MAX_N = 15        # register/DPP path (E-step, sampler, VJP)
+LDS_TILE_MAX_N = 64   # LDS-tiled MFMA path (E-step only)
 
 _c_double_p = ctypes.c_void_p   # raw device pointers travel as integers
 _c_int_p = ctypes.c_void_p

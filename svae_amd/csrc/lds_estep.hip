@@ -22,6 +22,9 @@ SVAE_DECL(8) SVAE_DECL(9) SVAE_DECL(10) SVAE_DECL(11) SVAE_DECL(12) SVAE_DECL(13
 SVAE_DECL(15)
 #endif
 #undef SVAE_DECL
+/* 16 <= n <= SVAE_LDS_TILE_MAX_N: LDS-tiled MFMA path (lds_estep_tile.hip) */
+int svae_lds_launch_tile(const svae::LdsArgs*, int n, int inhomog, void* stream);
+size_t svae_lds_tile_step_doubles(int n);
 }
 
 namespace svae {
@@ -97,7 +100,8 @@ static size_t factor_ws_doubles(int B, int T, int n) { return (size_t)B * T * (n
 static size_t cross_ws_doubles(int B, int T, int n) { return (size_t)B * T * (n + 1) * svae::ws_h_stride(n); }
 
 size_t svae_lds_workspace_bytes(int B, int T, int n) {
-  if (B <= 0 || T <= 0 || n <= 0 || n > SVAE_LDS_MAX_N) return 0;
+  if (B <= 0 || T <= 0 || n <= 0 || n > SVAE_LDS_TILE_MAX_N) return 0;
+  if (n > SVAE_LDS_MAX_N) return (size_t)B * T * svae_lds_tile_step_doubles(n) * sizeof(double);
   return (main_ws_doubles(B, T, n) + factor_ws_doubles(B, T, n) + cross_ws_doubles(B, T, n)) * sizeof(double);
 }
 
@@ -111,7 +115,8 @@ int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int k
                        int32_t* info, void* workspace, size_t ws_bytes, void* stream) {
   if (B < 0) return -1;
   if (T < 1) return -2;
-  if (n < 1 || n > SVAE_LDS_MAX_N) return -3;
+  if (n < 1 || n > SVAE_LDS_TILE_MAX_N) return -3;
+  if (n > SVAE_LDS_MAX_N && keep) return -23;   /* sampler / VJP hand-off: register path only */
   if (pair_batched && !inhomog) return -5;
   if (!init_J) return -6;
   if (!init_h) return -7;
@@ -139,6 +144,10 @@ int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int k
   a.ws2 = (keep & 1) ? (double*)workspace + main_ws_doubles(B, T, n) : nullptr;
   a.ws3 = (keep & 2) ? (double*)workspace + main_ws_doubles(B, T, n) + factor_ws_doubles(B, T, n) : nullptr;
   a.pair_seq_stride = pair_batched ? (long)(T - 1) * n * n : 0;
+  if (n > SVAE_LDS_MAX_N) {
+    a.ws2 = a.ws3 = nullptr; a.rows_per_wave = 1; a.debug_flags = 0;
+    return svae_lds_launch_tile(&a, n, inhomog, stream);
+  }
   a.rows_per_wave = svae_lds_rows_per_wave(B);
   const bool split = B <= svae_lds_split_max_b();
   { const char* e = getenv("SVAE_LDS_DEBUG_FLAGS"); a.debug_flags = e ? atoi(e) : 0; }
@@ -162,7 +171,7 @@ int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int k
 int svae_lds_reduce_stats_f64(int B, int n, const double* E_init, const double* E_pair,
                               const double* lognorm, double* out, void* stream) {
   if (B < 0) return -1;
-  if (n < 1 || n > SVAE_LDS_MAX_N) return -2;
+  if (n < 1 || n > SVAE_LDS_TILE_MAX_N) return -2;
   if (!E_init) return -3;
   if (!E_pair) return -4;
   if (!lognorm) return -5;

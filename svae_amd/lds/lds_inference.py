@@ -43,9 +43,9 @@ class LDSEStepPlan(object):
     allocation, no host<->device copy and no synchronisation."""
 
     def __init__(self, B, T, n, device="cuda", inhomog=False):
-        if not (1 <= n <= _lib.LDS_MAX_N):
-            raise ValueError("latent dimension n=%d outside the register path (1..%d)"
-                             % (n, _lib.LDS_MAX_N))
+        if not (1 <= n <= _lib.LDS_TILE_MAX_N):
+            raise ValueError("latent dimension n=%d outside the supported range (1..%d)"
+                             % (n, _lib.LDS_TILE_MAX_N))
         if T < 1 or B < 0:
             raise ValueError("need T >= 1 and B >= 0")
         self.lib = _lib.load()

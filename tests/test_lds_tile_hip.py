@@ -1,0 +1,141 @@
+"""GPU parity tests of the LDS-tiled MFMA E-step (16 <= n <= 64, svae_amd/csrc/lds_estep_tile.hip)
+against the NumPy oracle and the reference's own compiled path (oracle/_ref)."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import lds_longdouble, lds_numpy, ref  # noqa: E402  (checkers only)
+from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials  # noqa: E402
+
+
+def _rel(a, b):
+    a = a.detach().cpu().numpy() if hasattr(a, "detach") else np.asarray(a, float)
+    b = np.asarray(b, float)
+    scale = np.maximum(np.abs(b), 1e-3 * max(np.max(np.abs(b)), 1e-300))
+    return float(np.max(np.abs(a - b) / scale)) if b.size else 0.0
+
+
+def _run(natparam, node):
+    from svae_amd.lds.lds_inference import natural_lds_estep_general
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev)
+    nat = (tuple(t(x) for x in natparam[0]), tuple(t(x) for x in natparam[1]))
+    return natural_lds_estep_general(nat, tuple(t(x) for x in node))
+
+
+def _check(got, want, tol):
+    lognorm, (Ei, Ep, En) = got
+    wl, (wi, wp, wn) = want
+    assert _rel(lognorm, wl) < tol
+    assert _rel(Ei[0], wi[0]) < tol and _rel(Ei[1], wi[1]) < tol
+    for k in range(3):
+        assert _rel(Ep[k], wp[k]) < tol, k
+    assert _rel(En[0], wn[0]) < tol and _rel(En[1], wn[1]) < tol
+
+
+@pytest.mark.parametrize("n,T", [(16, 6), (17, 5), (24, 9), (32, 7), (40, 4), (48, 5), (63, 4), (64, 6), (16, 1), (33, 2)])
+def test_tile_estep_matches_oracle(n, T):
+    rng = np.random.default_rng(1000 * n + T)
+    natparam = rand_lds_natparam(n, rng)
+    node = rand_node_potentials((T, n), rng, with_logZ=True)
+    want = lds_numpy.natural_lds_estep_general(natparam, node)
+    _check(_run(natparam, node), want, 1e-7)   # cond(state noise) grows like n^2 for these random models
+
+
+@pytest.mark.parametrize("n,T,B", [(16, 30, 5), (32, 20, 3), (64, 12, 3)])
+def test_tile_estep_batched_matches_compiled_reference(n, T, B):
+    if not ref.available():
+        pytest.skip("oracle/_ref not built")
+    rng = np.random.default_rng(n + T)
+    natparam = rand_lds_natparam(n, rng)
+    node = rand_node_potentials((B, T, n), rng)
+    lognorm, (Ei, Ep, En) = _run(natparam, node)
+    for b in range(B):
+        want = ref.estep(natparam, (node[0][b], node[1][b], np.zeros(T)))
+        got = (lognorm[b], (tuple(x[b] for x in Ei), tuple(x[b] for x in Ep), tuple(x[b] for x in En)))
+        _check(got, want, 1e-7)
+
+
+@pytest.mark.parametrize("n,T,B", [(20, 6, 2), (64, 5, 2)])
+def test_tile_estep_inhomogeneous_batched_pairs(n, T, B):
+    rng = np.random.default_rng(5 * n + T)
+    init = rand_lds_natparam(n, rng)[0]
+    pairs = [[rand_lds_natparam(n, rng)[1] for _ in range(T - 1)] for _ in range(B)]
+    stack = lambda i: np.stack([np.stack([p[i] for p in row]) for row in pairs])
+    pair = tuple(stack(i) for i in range(4))                     # (B,T-1,n,n) x3, (B,T-1)
+    node = rand_node_potentials((B, T, n), rng)
+    lognorm, (Ei, Ep, En) = _run((init, pair), node)
+    for b in range(B):
+        want = lds_numpy.natural_lds_estep_general((init, tuple(x[b] for x in pair)), (node[0][b], node[1][b]))
+        got = (lognorm[b], (tuple(x[b] for x in Ei), tuple(x[b] for x in Ep), tuple(x[b] for x in En)))
+        _check(got, want, 1e-7)
+
+
+def test_tile_estep_flags_indefinite_potentials():
+    from svae_amd.lds.lds_inference import natural_lds_estep_general
+    n, T = 32, 4
+    rng = np.random.default_rng(0)
+    natparam = rand_lds_natparam(n, rng)
+    J, h = rand_node_potentials((2, T, n), rng)
+    J[1, 2] = +50.0                      # makes the filtered precision indefinite
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev)
+    nat = (tuple(t(x) for x in natparam[0]), tuple(t(x) for x in natparam[1]))
+    with pytest.raises(Exception):
+        natural_lds_estep_general(nat, (t(J), t(h)))
+
+
+def test_tile_estep_config4_properties():
+    """BASELINE configs[4] shape (n=64, T=1000), a few sequences: size-independent properties --
+    permutation equivariance over the batch, marginal consistency E[x x'] - E[x]E[x]' >= 0 on the
+    diagonal, and agreement of the pair sums with the per-step node statistics."""
+    n, T, B = 64, 1000, 4
+    rng = np.random.default_rng(64)
+    natparam = rand_lds_natparam(n, rng)
+    node = rand_node_potentials((B, T, n), rng)
+    lognorm, (Ei, Ep, En) = _run(natparam, node)
+    perm = np.array([2, 0, 3, 1])
+    lognorm2, (Ei2, Ep2, En2) = _run(natparam, (node[0][perm], node[1][perm]))
+    assert torch.equal(lognorm[perm], lognorm2) and torch.equal(En[1][perm], En2[1])
+    var = En[0] - En[1] ** 2
+    assert float(var.min()) > 0
+    # diag of sum_{t<T-1} E[x_t x_t'] equals the sum of the node statistics over the same steps
+    d0 = torch.diagonal(Ep[0], dim1=-2, dim2=-1)
+    assert _rel(d0, En[0][:, :-1].sum(1).cpu().numpy()) < 1e-10
+    d2 = torch.diagonal(Ep[2], dim1=-2, dim2=-1)
+    assert _rel(d2, En[0][:, 1:].sum(1).cpu().numpy()) < 1e-10
+    # Parity at full size.  This random model is ill-conditioned (cond of the state noise ~ n^2) and
+    # the reference's own fp64 path is off by ~1e-5 here; the arbiter is the same model evaluated in
+    # extended precision (oracle/lds_longdouble.py).
+    want = lds_longdouble.estep(natparam, (node[0][0], node[1][0]))
+    got = (lognorm[0], (tuple(x[0] for x in Ei), tuple(x[0] for x in Ep), tuple(x[0] for x in En)))
+    errs = [_rel(got[0], want[0]), _rel(Ei[0][0], want[1][0][0]), _rel(Ep[1][0], want[1][1][1]), _rel(En[1][0], want[1][2][1])]
+    print("n=64 T=1000 kernel vs extended precision:", errs)
+    _check(got, want, 5e-6)      # north_star: 1e-5
+    if ref.available():
+        r = ref.estep(natparam, (node[0][0], node[1][0], np.zeros(T)))
+        print("reference vs extended precision:", _rel(r[1][0][0], want[1][0][0]), _rel(r[1][1][1], want[1][1][1]))
+        _check(got, r, 1e-3)
+
+
+def _wellcond_natparam(n, rng):
+    """Rotation-like dynamics (spectral radius 0.97) with isotropic-ish state noise: cond ~ 10."""
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    A = 0.97 * Q
+    S = 0.3 * np.eye(n) + 0.02 * (lambda B: B @ B.T)(rng.standard_normal((n, n))) / n
+    Si = np.linalg.inv(S)
+    J0, h0 = -0.5 * np.eye(n), rng.standard_normal(n)
+    return (J0, h0, 0.), (-0.5 * A.T @ Si @ A, A.T @ Si, -0.5 * Si, -0.5 * np.linalg.slogdet(S)[1])
+
+
+@pytest.mark.parametrize("n,T", [(64, 1000), (32, 500)])
+def test_tile_estep_full_size_well_conditioned(n, T):
+    rng = np.random.default_rng(n)
+    natparam = _wellcond_natparam(n, rng)
+    node = rand_node_potentials((2, T, n), rng)
+    lognorm, (Ei, Ep, En) = _run(natparam, node)
+    want = lds_longdouble.estep(natparam, (node[0][1], node[1][1]))
+    got = (lognorm[1], (tuple(x[1] for x in Ei), tuple(x[1] for x in Ep), tuple(x[1] for x in En)))
+    _check(got, want, 1e-10)
