@@ -38,6 +38,13 @@ int svae_hip_abi_version(void);
  * cross-moment region (W~_t) the VJP reads. */
 size_t svae_lds_workspace_bytes(int B, int T, int n);
 
+/* Same, exact for the tiled path (n > SVAE_LDS_MAX_N), whose workspace also holds the pair
+ * parameters re-packed in MFMA fragment order: 2 slots when they are homogeneous (what
+ * svae_lds_workspace_bytes assumes), T-1 slots per parameter set when they are per-step
+ * (`inhomog`), one set per sequence when `pair_batched`.  Equal to svae_lds_workspace_bytes for
+ * n <= SVAE_LDS_MAX_N. */
+size_t svae_lds_workspace_bytes_ex(int B, int T, int n, int inhomog, int pair_batched);
+
 /* Batched LDS E-step = filter + RTS smoother + expected sufficient statistics + log-normalizer.
  *
  * Replaces, for B independent sequences sharing (init, pair) parameters,

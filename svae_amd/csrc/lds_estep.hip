@@ -25,6 +25,7 @@ SVAE_DECL(15)
 /* 16 <= n <= SVAE_LDS_TILE_MAX_N: LDS-tiled MFMA path (lds_estep_tile.hip) */
 int svae_lds_launch_tile(const svae::LdsArgs*, int n, int inhomog, void* stream);
 size_t svae_lds_tile_step_doubles(int n);
+size_t svae_lds_tile_packed_doubles(int B, int T, int n, int inhomog, int pair_batched);
 }
 
 namespace svae {
@@ -99,9 +100,16 @@ static size_t main_ws_doubles(int B, int T, int n) { return (size_t)B * svae::ws
 static size_t factor_ws_doubles(int B, int T, int n) { return (size_t)B * T * (n * n + n); }
 static size_t cross_ws_doubles(int B, int T, int n) { return (size_t)B * T * (n + 1) * svae::ws_h_stride(n); }
 
+size_t svae_lds_workspace_bytes_ex(int B, int T, int n, int inhomog, int pair_batched) {
+  if (B <= 0 || T <= 0 || n <= 0 || n > SVAE_LDS_TILE_MAX_N) return 0;
+  if (n <= SVAE_LDS_MAX_N) return svae_lds_workspace_bytes(B, T, n);
+  return ((size_t)B * T * svae_lds_tile_step_doubles(n) +
+          svae_lds_tile_packed_doubles(B, T, n, inhomog, pair_batched)) * sizeof(double);
+}
+
 size_t svae_lds_workspace_bytes(int B, int T, int n) {
   if (B <= 0 || T <= 0 || n <= 0 || n > SVAE_LDS_TILE_MAX_N) return 0;
-  if (n > SVAE_LDS_MAX_N) return (size_t)B * T * svae_lds_tile_step_doubles(n) * sizeof(double);
+  if (n > SVAE_LDS_MAX_N) return svae_lds_workspace_bytes_ex(B, T, n, 0, 0);
   return (main_ws_doubles(B, T, n) + factor_ws_doubles(B, T, n) + cross_ws_doubles(B, T, n)) * sizeof(double);
 }
 
@@ -130,7 +138,7 @@ int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int k
   if (!E_node_diagxx) return -19;
   if (!E_node_x) return -20;
   if (!info) return -21;
-  if (!workspace || ws_bytes < svae_lds_workspace_bytes(B, T, n)) return -22;
+  if (!workspace || ws_bytes < svae_lds_workspace_bytes_ex(B, T, n, inhomog, pair_batched)) return -22;
   if (B == 0) return 0;
 
   svae::LdsArgs a;

@@ -68,7 +68,7 @@ struct TileCfg {
   static constexpr int WSTEP = 2 * NP * NP + NP;   // hand-off per step: X, P^-1 (row-major NP x NP), c
   static constexpr int LDU = 18;                // pivot-factor tile U = L^-1, row stride
   static constexpr int UBUF = 16 * LDU + 16;    // U and D^-1; double-buffered
-  static constexpr int LDS_DOUBLES = NP * LDM + 3 * NP + 16 + 2 * UBUF;
+  static constexpr int LDS_DOUBLES = NP * LDM + 3 * NP + 16 + 2 * UBUF + 2;
 };
 
 // 16x16 SPD tile A = L D L'  ->  U = L^-1 (unit lower triangular) and D^-1, by the calling wavefront
@@ -77,23 +77,23 @@ struct TileCfg {
 // into lane p, so that lanes c < i of row i end as U[i][c].  Accumulates log det as mantissa/exponent.
 __device__ __forceinline__ void factor_pivot_tile(const double* tile, int ld, double* U, int ldu,
                                                   double* dinv, int r16, int kq,
-                                                  const double (&E)[16], double& pmin, double& ldM,
-                                                  int& ldE) {
+                                                  double& pmin, double& ldM, int& ldE) {
   double A[16];
   static_for<0, 16>([&](auto r) { A[r] = tile[r * ld + r16]; });
   dpp_fence(A);
   double dv = 0.0;
   static_for<0, 16>([&](auto p) {
+    const double Ep = (r16 == p) ? 1.0 : 0.0;       // per-lane selects done arithmetically (x * Ep, exact)
     const double pv = bcast_fenced<p>(A[p]);
     pmin = fmin(pmin, pv);
     ldM *= __builtin_amdgcn_frexp_mant(pv);
     ldE += __builtin_amdgcn_frexp_exp(pv);
     const double rinv = rcp_nr(pv);
-    dv = __builtin_fma(E[p], rinv, dv);
-    const double r = __builtin_fma(E[p], 1.0 - pv, A[p]) * rinv;     // lane p: 1/pivot
+    dv = __builtin_fma(Ep, rinv, dv);
+    const double r = __builtin_fma(Ep, 1.0 - pv, A[p]) * rinv;       // lane p: 1/pivot
     static_for<p + 1, 16>([&](auto i) {
       const double old = A[i];
-      double acc = __builtin_fma(-old, E[p], old);                    // lane p of the row -> 0
+      double acc = __builtin_fma(-old, Ep, old);                      // lane p of the row -> 0
       mac_bc<p, true, true>(acc, old, r);                             // row_i -= A[i][p] * r
       A[i] = acc;
     });
@@ -101,13 +101,15 @@ __device__ __forceinline__ void factor_pivot_tile(const double* tile, int ld, do
   ldE += __builtin_amdgcn_frexp_exp(ldM);
   ldM = __builtin_amdgcn_frexp_mant(ldM);
   if (kq == 0) {
-    static_for<0, 16>([&](auto r) { U[r * ldu + r16] = r16 < r ? A[r] : E[r]; });
+    static_for<0, 16>([&](auto r) { U[r * ldu + r16] = r16 < r ? A[r] : (r16 == r ? 1.0 : 0.0); });
     dinv[r16] = dv;
   }
 }
 
 template <int NB, bool INHOMOG>
-__global__ __launch_bounds__(256, 2) void lds_estep_tile_kernel(const LdsArgs a, const int n) {
+__global__ __launch_bounds__(256, 2) void lds_estep_tile_kernel(const LdsArgs a, const int n,
+                                                                const double* __restrict__ pk_base,
+                                                                const int pk_batched) {
   using Cfg = TileCfg<NB>;
   constexpr int NP = Cfg::NP, NTC = Cfg::NTC, LDM = Cfg::LDM, WSTEP = Cfg::WSTEP;
   extern __shared__ double smem[];
@@ -131,16 +133,23 @@ __global__ __launch_bounds__(256, 2) void lds_estep_tile_kernel(const LdsArgs a,
   const double* nodeJ = a.node_J + (long)b * T * n;
   const double* nodeh = a.node_h + (long)b * T * n;
   double* wsb = a.ws + (long)b * T * WSTEP;
+  // packed pair parameters: per set, (INHOMOG ? T-1 : 2) slots of [pA | pC | pR] (3 NP^2 doubles)
+  const double* packed = pk_base + (pk_batched ? (long)b * (T - 1) * (3 * NP * NP) : 0);
   auto pair_at = [&](const double* p, int t) { return INHOMOG ? p + (long)t * nn : p; };
 
-  double E[16];
-  static_for<0, 16>([&](auto i) { E[i] = (r16 == i) ? 1.0 : 0.0; });
   double ldM = 1.0, pmin = 1.0e300, qacc = 0.0;
   int ldE = 0;
+#ifdef SVAE_TILE_TIMING   // per-phase cycle counts of wave 0 (tools/tile_timing.py); results are not written
+  long long tm[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast_ = __builtin_readcyclecounter();
+#define TICK(i) { const long long now_ = __builtin_readcyclecounter(); tm[i] += now_ - tlast_; tlast_ = now_; }
+#else
+#define TICK(i)
+#endif
 
   // B/C fragments by tile column jt of the panel; jt == 2 NB is the h column (one physical column:
   // lanes r16 > 0 see zeros and do not store)
-  const double e0 = E[0];
+  const double e0 = (r16 == 0) ? 1.0 : 0.0;
   auto ld_b = [&](int row0, int jt) -> d4 {
     if (jt < 2 * NB) return frag_b(M, LDM, row0, 16 * jt, r16, kq);
     const double* p = M + (row0 + kq) * LDM + 2 * NP;
@@ -161,22 +170,21 @@ __global__ __launch_bounds__(256, 2) void lds_estep_tile_kernel(const LdsArgs a,
     for (int qq = 0; qq < 4; ++qq) v[qq] *= dinv[4 * qq + kq];
     return mma16(frag_b(U, LDU, 0, 0, r16, kq), v, d4{0.0, 0.0, 0.0, 0.0});
   };
-  // tiles of block column kc that the elimination of block pivot kc left for later:
-  //   A[i][kc] <- -A[i][kc] A_kk^-1 (computed transposed: A_kk^-1 A[i][kc]')   and   A[kc][kc] <- A_kk^-1
-  auto deferred_column = [&](int kc, const double* U, const double* dinv, int w0, int nw) {
-    for (int q = w0; q < NB; q += nw) {
-      if (q == NB - 1) {
-        d4 v = frag_b(U, LDU, 0, 0, r16, kq);
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) v[qq] *= dinv[4 * qq + kq];
-        store_c(M, LDM, 16 * kc, 16 * kc, r16, kq, mma16(frag_b(U, LDU, 0, 0, r16, kq), v, d4{0.0, 0.0, 0.0, 0.0}));
-      } else {
-        const int i = q + (q >= kc ? 1 : 0);
-        const d4 rt = apply_pivot(U, dinv, frag_a(M, LDM, 16 * i, 16 * kc, r16, kq));   // (A[i][kc] W)'
-        double* p = M + (16 * i + r16) * LDM + 16 * kc + kq;
-        p[0] = -rt[0]; p[4] = -rt[1]; p[8] = -rt[2]; p[12] = -rt[3];
-      }
-    }
+  // ---- roles ------------------------------------------------------------------------------------
+  // Schur product: tile row si per wavefront (WPR wavefronts share a row when NB <= 2), tile columns
+  // sj0, sj0 + WPR, ... <= NB (column NB is the h column)
+  constexpr int WPR = NB <= 2 ? 4 / NB : 1;
+  constexpr int SCOLS = (NB + 1 + WPR - 1) / WPR;
+  constexpr int RL = (NP * NP + 255) / 256;      // doubles per thread of an NP x NP copy
+  constexpr int RL4 = (NP * NP / 4 + 255) / 256; // 4-double chunks per thread of an NP x NP copy
+  int* flag = (int*)(ubuf + 2 * UBUF);           // look-ahead hand-shake (see below)
+  if (tid == 0) *flag = 0;
+
+  // clamped, branch-free global reads of an n x n matrix padded to NP x NP
+  auto gl = [&](const double* p, int row, int col) -> double {
+    const int rr = row < n ? row : n - 1, cc = col < n ? col : n - 1;
+    const double v = p[rr * n + cc];
+    return (row < n && col < n) ? v : 0.0;
   };
 
   // ---- step 0: P = -2 (init_J + J11) + diag(-2 node_J[0]),  R = J12,  h = init_h + node_h[0] -----
@@ -199,39 +207,122 @@ __global__ __launch_bounds__(256, 2) void lds_estep_tile_kernel(const LdsArgs a,
   }
   __syncthreads();
 
+  // The forward half is instantiated per wavefront index W (wave-uniform switch below): every tile
+  // coordinate is then a compile-time constant and every LDS access is base + immediate.
+  auto forward = [&](auto wc) {
+  constexpr int W = decltype(wc)::value;
+  constexpr bool schur_on = W < NB * WPR;
+  constexpr int si = W % NB, sj0 = W / NB;
+  // Operands taken from the pair parameters come pre-packed (tile_pack_pairs_kernel below) in the
+  // exact register order, so each is one coalesced 32-byte load per lane at base + immediate:
+  //   sA = -(J12') tiles of row si (A operands of the Schur product), sC = its C input
+  //   -2 (J22 + J11') (identity on the padding), rl = this thread's share of the next J12.
+  // They are requested inside the last block pivot of a step and consumed after the hand-off: the
+  // L2 latency hides behind the elimination.
+  d4 sA[NB], sC[SCOLS], rl[RL4];
+  auto load_operands = [&](const double* pk) {
+    if constexpr (schur_on) {
+#pragma unroll
+      for (int kk = 0; kk < NB; ++kk) sA[kk] = *(const d4*)(pk + ((si * NB + kk) * 64 + lane) * 4);
+#pragma unroll
+      for (int s2 = 0; s2 < SCOLS; ++s2) {
+        const int j = sj0 + s2 * WPR;
+        sC[s2] = d4{0.0, 0.0, 0.0, 0.0};
+        if (j < NB) sC[s2] = *(const d4*)(pk + NP * NP + ((si * NB + j) * 64 + lane) * 4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < RL4; ++u) {
+      const int c4 = tid + 256 * u;
+      rl[u] = d4{0.0, 0.0, 0.0, 0.0};
+      if (c4 * 4 < NP * NP) rl[u] = *(const d4*)(pk + 2 * NP * NP + c4 * 4);
+    }
+  };
   for (int t = 0; t < T; ++t) {
     const bool last = (t == T - 1);
-    // ---- in-place block Gauss-Jordan ---------------------------------------------------------------
-    for (int k = 0; k < NB; ++k) {
-      double* U = ubuf + (k & 1) * UBUF;
-      double* dinv = U + 16 * LDU;
-      if (wave == 0) {
-        factor_pivot_tile(M + (16 * k) * LDM + 16 * k, LDM, U, LDU, dinv, r16, kq, E, pmin, ldM, ldE);
-      } else if (k > 0) {
-        const double* Up = ubuf + ((k - 1) & 1) * UBUF;
-        deferred_column(k - 1, Up, Up + 16 * LDU, wave - 1, 3);
+    const bool next_last = (t + 1 == T - 1);
+    TICK(0)
+    // ---- in-place block Gauss-Jordan with look-ahead -----------------------------------------------
+    // Per block pivot k:  (P1) all wavefronts scale the pivot row with U_k;  (P2) wavefronts 1..3 own
+    // the other tile rows (eliminate, then rewrite their pivot-column tile) while wavefront 0 updates
+    // the NEXT pivot tile first and factors it, so that the serial DPP factorisation overlaps the MFMA
+    // work.  The owner of row k+1 must not overwrite tile (k+1,k) before wavefront 0 has read it: an
+    // LDS flag carries that one dependency (LDS operations of a wavefront execute in order).
+    if constexpr (W == 0) factor_pivot_tile(M, LDM, ubuf, LDU, ubuf + 16 * LDU, r16, kq, pmin, ldM, ldE);
+    TICK(1)
+    static_for<0, NB>([&](auto kc) {
+      constexpr int k = kc;
+      const double* U = ubuf + (k & 1) * UBUF;
+      const double* dinv = U + 16 * LDU;
+      const int gen = t * NB + k + 1;
+      __syncthreads();
+      TICK(2)
+      {  // (P1) pivot row:  A[k][j] <- A_kk^-1 A[k][j]   (j != k)
+        constexpr int NT1 = (2 * NB + 3) / 4;
+        d4 fb[NT1];
+#pragma unroll
+        for (int s2 = 0; s2 < NT1; ++s2) {
+          const int q = W + 4 * s2;
+          if (q < 2 * NB) fb[s2] = ld_b(16 * k, q + (q >= k ? 1 : 0));
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < NT1; ++s2) {
+          const int q = W + 4 * s2;
+          if (q < 2 * NB) st_c(16 * k, q + (q >= k ? 1 : 0), apply_pivot(U, dinv, fb[s2]));
+        }
       }
       __syncthreads();
-      // pivot row:  A[k][j] <- A_kk^-1 A[k][j]   (j != k)
-      for (int q = wave; q < NTC - 1; q += 4) {
-        const int j = q + (q >= k ? 1 : 0);
-        st_c(16 * k, j, apply_pivot(U, dinv, ld_b(16 * k, j)));
+      TICK(3)
+      if constexpr (k == NB - 1) { if (!last) load_operands(packed + (long)(INHOMOG ? t : (next_last ? 1 : 0)) * (3 * NP * NP)); }
+      if constexpr (W == 0) {
+        {  // A[k][k] <- A_kk^-1 = U' D^-1 U
+          d4 v = frag_b(U, LDU, 0, 0, r16, kq);
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) v[qq] *= dinv[4 * qq + kq];
+          store_c(M, LDM, 16 * k, 16 * k, r16, kq, mma16(frag_b(U, LDU, 0, 0, r16, kq), v, d4{0.0, 0.0, 0.0, 0.0}));
+        }
+        if constexpr (k + 1 < NB) {
+          const d4 fa = frag_a(M, LDM, 16 * (k + 1), 16 * k, r16, kq);
+          const d4 c = mma16(-fa, ld_b(16 * k, k + 1), ld_b(16 * (k + 1), k + 1));
+          __hip_atomic_store(flag, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // (k+1,k) has been read
+          st_c(16 * (k + 1), k + 1, c);
+          double* Un = ubuf + ((k + 1) & 1) * UBUF;
+          factor_pivot_tile(M + (16 * (k + 1)) * LDM + 16 * (k + 1), LDM, Un, LDU, Un + 16 * LDU, r16, kq,
+                            pmin, ldM, ldE);
+        }
+      } else {
+        static_for<0, (NB - 1 - (W - 1) + 2) / 3>([&](auto rc) {
+          constexpr int r = W - 1 + 3 * decltype(rc)::value;
+          constexpr int i = r + (r >= k ? 1 : 0);
+          constexpr int skipn = (i == k + 1) ? 2 : 1;         // row k+1: tile (k+1,k+1) belongs to wave 0
+          constexpr int cnt = 2 * NB + 1 - skipn;
+          const d4 fa = frag_a(M, LDM, 16 * i, 16 * k, r16, kq);
+          const d4 nfa = -fa;
+          auto jmap = [&](int jq) { return jq + (jq >= k ? skipn : 0); };
+          d4 cc = ld_b(16 * i, jmap(0)), bb = ld_b(16 * k, jmap(0));
+#pragma unroll
+          for (int jq = 0; jq < 2 * NB; ++jq) {
+            if (jq < cnt) {
+              d4 cn = cc, bn = bb;
+              if (jq + 1 < cnt) { cn = ld_b(16 * i, jmap(jq + 1)); bn = ld_b(16 * k, jmap(jq + 1)); }
+              st_c(16 * i, jmap(jq), mma16(nfa, bb, cc));
+              cc = cn; bb = bn;
+            }
+          }
+          // pivot-column tile:  A[i][k] <- -A[i][k] A_kk^-1, computed transposed as A_kk^-1 A[i][k]'
+          const d4 rt = apply_pivot(U, dinv, fa);
+          if constexpr (i == k + 1) {
+            while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < gen)
+              __builtin_amdgcn_s_sleep(1);
+          }
+          double* p = M + (16 * i + r16) * LDM + 16 * k + kq;
+          p[0] = -rt[0]; p[4] = -rt[1]; p[8] = -rt[2]; p[12] = -rt[3];
+        });
       }
-      __syncthreads();
-      // elimination:  A[i][j] -= A[i][k] * A[k][j]   (i != k, j != k); column k itself is deferred
-      for (int q = wave; q < (NB - 1) * (NTC - 1); q += 4) {
-        const int iq = q / (NTC - 1), jq = q % (NTC - 1);
-        const int i = iq + (iq >= k ? 1 : 0), j = jq + (jq >= k ? 1 : 0);
-        const d4 fa = frag_a(M, LDM, 16 * i, 16 * k, r16, kq);
-        st_c(16 * i, j, mma16(-fa, ld_b(16 * k, j), ld_b(16 * i, j)));
-      }
-      __syncthreads();
-    }
-    {
-      const double* Up = ubuf + ((NB - 1) & 1) * UBUF;
-      deferred_column(NB - 1, Up, Up + 16 * LDU, wave, 4);
-    }
+      TICK(4)
+    });
     __syncthreads();
+    TICK(5)
 
     // ---- hand-off to the backward half: X, P^-1 (row-major NP x NP), c --------------------------
     double* w = wsb + (long)t * WSTEP;
@@ -246,56 +337,51 @@ __global__ __launch_bounds__(256, 2) void lds_estep_tile_kernel(const LdsArgs a,
       qacc = __builtin_fma(hvec[tid], cv, qacc);            // h' P^-1 h
     }
     __syncthreads();
+    TICK(6)
 
     if (!last) {
-      // ---- Schur step:  P' = -2 (J22 + J11') - J12' X   (tile (i,j), j < NB);   h' = J12' c (j == NB) --
-      const bool next_last = (t + 1 == T - 1);
-      const double* pJ12 = pair_at(J12, t);
-      const double* pJ22 = pair_at(J22, t);
-      const double* pJ11n = next_last ? nullptr : pair_at(J11, t + 1);
-      for (int q = wave; q < NB * (NB + 1); q += 4) {
-        const int i = q % NB, j = q / NB;
-        d4 c = {0.0, 0.0, 0.0, 0.0};
-        if (j < NB) {
-          const int col = 16 * j + r16;
+      // ---- Schur step:  P' = -2 (J22 + J11') + diag(-2 node_J') - J12' X   (tile (si,j), j < NB);
+      //                   h' = node_h' + J12' c                              (j == NB) ------------
+      if (schur_on) {
+        d4 fb[NB];
 #pragma unroll
-          for (int qq = 0; qq < 4; ++qq) {
-            const int row = 16 * i + 4 * qq + kq;
-            double v = (row == col) ? 1.0 : 0.0;
-            if (row < n && col < n) {
-              v = -2.0 * pJ22[row * n + col];
-              if (pJ11n) v -= 2.0 * pJ11n[row * n + col];
+        for (int kk = 0; kk < NB; ++kk) fb[kk] = ld_b(16 * kk, NB + sj0);
+#pragma unroll
+        for (int s2 = 0; s2 < SCOLS; ++s2) {
+          const int j = sj0 + s2 * WPR;
+          if (j <= NB) {
+            d4 fn[NB];
+            const int jn = j + WPR;
+#pragma unroll
+            for (int kk = 0; kk < NB; ++kk) fn[kk] = fb[kk];
+            if (s2 + 1 < SCOLS && jn <= NB) {
+#pragma unroll
+              for (int kk = 0; kk < NB; ++kk) fn[kk] = ld_b(16 * kk, NB + jn);
             }
-            c[qq] = v;
-          }
-        }
-        for (int kk = 0; kk < NB; ++kk) {
-          // A operand = -(J12')[tile i][tile kk]:  lane holds -J12[16 kk + 4 kb + kq][16 i + r16]
-          d4 fa;
-          const int col = 16 * i + r16;
+            d4 c = sC[s2];
 #pragma unroll
-          for (int kb = 0; kb < 4; ++kb) {
-            const int row = 16 * kk + 4 * kb + kq;
-            fa[kb] = (row < n && col < n) ? -pJ12[row * n + col] : 0.0;
-          }
-          c = mma16(fa, ld_b(16 * kk, NB + j), c);
-        }
-        if (j < NB) {
-          store_c(M, LDM, 16 * i, 16 * j, r16, kq, c);
-        } else if (r16 == 0) {
+            for (int kk = 0; kk < NB; ++kk) c = mma16(sA[kk], fb[kk], c);
+            if (j < NB) {
+              store_c(M, LDM, 16 * si, 16 * j, r16, kq, c);
+            } else if (r16 == 0) {
 #pragma unroll
-          for (int qq = 0; qq < 4; ++qq) {
-            const int row = 16 * i + 4 * qq + kq;
-            mv0[row] = row < n ? nodeh[(long)(t + 1) * n + row] - c[qq] : 0.0;   // c = -J12' c_t
+              for (int qq = 0; qq < 4; ++qq) {
+                const int row = 16 * si + 4 * qq + kq;
+                mv0[row] = row < n ? nodeh[(long)(t + 1) * n + row] - c[qq] : 0.0;   // c = -J12' c_t
+              }
+            }
+#pragma unroll
+            for (int kk = 0; kk < NB; ++kk) fb[kk] = fn[kk];
           }
         }
       }
       __syncthreads();
-      // ---- next step's right-hand sides and node diagonal ---------------------------------------
-      const double* pJ12n = next_last ? nullptr : pair_at(J12, t + 1);
-      for (int idx = tid; idx < NP * NP; idx += 256) {
-        const int row = idx / NP, col = idx % NP;
-        M[row * LDM + NP + col] = (pJ12n && row < n && col < n) ? pJ12n[row * n + col] : 0.0;
+      TICK(7)
+      // ---- next step's right-hand sides ------------------------------------------------------------
+#pragma unroll
+      for (int u = 0; u < RL4; ++u) {
+        const int c4 = tid + 256 * u;
+        if (c4 * 4 < NP * NP) *(d4*)(M + ((c4 * 4) / NP) * LDM + NP + ((c4 * 4) % NP)) = rl[u];
       }
       if (tid < NP) {
         const double hv = mv0[tid];
@@ -304,7 +390,15 @@ __global__ __launch_bounds__(256, 2) void lds_estep_tile_kernel(const LdsArgs a,
         if (tid < n) M[tid * LDM + tid] -= 2.0 * nodeJ[(long)(t + 1) * n + tid];
       }
       __syncthreads();
+      TICK(8)
     }
+  }
+  };
+  switch (wave) {
+    case 0: forward(std::integral_constant<int, 0>{}); break;
+    case 1: forward(std::integral_constant<int, 1>{}); break;
+    case 2: forward(std::integral_constant<int, 2>{}); break;
+    default: forward(std::integral_constant<int, 3>{}); break;
   }
 
   // ---- log-normaliser --------------------------------------------------------------------------
@@ -337,40 +431,71 @@ __global__ __launch_bounds__(256, 2) void lds_estep_tile_kernel(const LdsArgs a,
     }
   }
 
+#ifdef SVAE_TILE_FWD_ONLY   // register-pressure experiments
+  return;
+#endif
   // ---- backward pass (moment form) -------------------------------------------------------------
+  // Per step: (B0) the prefetched X_t, c_t go to LDS; (B1) W = Sigma_{t+1} X_t' for this wavefront's tile
+  // column (kept in registers) and m_t = c_t + X_t m_{t+1}; (B2) Sigma_t = P_t^-1 + X_t W tile by tile,
+  // straight into LDS, with the statistics accumulated from the same registers.
   for (int idx = tid; idx < NP * NP; idx += 256) M[(idx / NP) * LDM + (idx % NP)] = 0.0;   // Sigma_T := 0
   if (tid < NP) { mv0[tid] = 0.0; mv1[tid] = 0.0; }
   double* mold = mv0;
   double* mnew = mv1;
-  d4 cross[NB], sxx[NB], lastE[NB], firstE[NB];
+  d4 cross[NB], sxx[NB], prevE[NB];
 #pragma unroll
-  for (int i = 0; i < NB; ++i) {
-    cross[i] = d4{0.0, 0.0, 0.0, 0.0}; sxx[i] = cross[i]; lastE[i] = cross[i]; firstE[i] = cross[i];
-  }
+  for (int i = 0; i < NB; ++i) { cross[i] = d4{0.0, 0.0, 0.0, 0.0}; sxx[i] = cross[i]; prevE[i] = cross[i]; }
   const int j = wave;                       // this wavefront's tile column (waves >= NB only help copy)
   const int mycol = 16 * j + r16;
   double* oEx = a.E_node_x + (long)b * T * n;
   double* oExx = a.E_node_diagxx + (long)b * T * n;
+  double* oI = a.E_init + (long)b * (nn + n);
+  double* oPh = a.E_pair + (long)b * 3 * nn;            // homogeneous: the three sums
+  double xr[RL], cpre = 0.0;
+  {
+    const double* w = wsb + (long)(T - 1) * WSTEP;
+#pragma unroll
+    for (int u = 0; u < RL; ++u) { const int idx = tid + 256 * u; xr[u] = idx < NP * NP ? w[idx] : 0.0; }
+    if (tid < NP) cpre = w[2 * NP * NP + tid];
+  }
   __syncthreads();
 
   for (int t = T - 1; t >= 0; --t) {
+    TICK(9)
     const double* w = wsb + (long)t * WSTEP;
-    for (int idx = tid; idx < NP * NP; idx += 256) M[(idx / NP) * LDM + NP + (idx % NP)] = w[idx];
-    if (tid < NP) hvec[tid] = w[2 * NP * NP + tid];
+#pragma unroll
+    for (int u = 0; u < RL; ++u) {
+      const int idx = tid + 256 * u;
+      if (idx < NP * NP) M[(idx / NP) * LDM + NP + (idx % NP)] = xr[u];
+    }
+    if (tid < NP) hvec[tid] = cpre;
     __syncthreads();
-
+    if (t + 1 < T && tid < n) {          // node statistics of step t+1 (Sigma_{t+1} is complete now)
+      const double mm = mold[tid];
+      oEx[(long)(t + 1) * n + tid] = mm;
+      oExx[(long)(t + 1) * n + tid] = __builtin_fma(mm, mm, M[tid * LDM + tid]);
+    }
+    d4 pin[NB];                          // P_t^-1 tiles (i, j): consumed in B2
+    if (j < NB) {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const double* pi = w + NP * NP + (16 * i + kq) * NP + mycol;
+        pin[i] = d4{pi[0], pi[4 * NP], pi[8 * NP], pi[12 * NP]};
+      }
+    }
+    TICK(10)
     {  // m_t = c_t + X_t m_{t+1}
       const int row = tid >> 2, part = tid & 3;
       double s = 0.0;
       if (row < NP) {
-        const double* xr = M + row * LDM + NP;
-        for (int cc = part; cc < NP; cc += 4) s = __builtin_fma(xr[cc], mold[cc], s);
+        const double* xrow = M + row * LDM + NP;
+        for (int cc = part; cc < NP; cc += 4) s = __builtin_fma(xrow[cc], mold[cc], s);
       }
       s += __shfl_xor(s, 1, 64);
       s += __shfl_xor(s, 2, 64);
       if (row < NP && part == 0) mnew[row] = hvec[row] + s;
     }
-    d4 Wt[NB], Sn[NB];
+    d4 Wt[NB];
     if (j < NB) {
       d4 Bx[NB];
 #pragma unroll
@@ -382,85 +507,134 @@ __global__ __launch_bounds__(256, 2) void lds_estep_tile_kernel(const LdsArgs a,
         for (int l = 0; l < NB; ++l) c = mma16(frag_a(M, LDM, 16 * kk, 16 * l, r16, kq), Bx[l], c);
         Wt[kk] = c;                            // W[kk][j] = (Sigma_{t+1} X')  = Cov(x_{t+1}, x_t)
       }
-#pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        const double* pi = w + NP * NP + (16 * i + kq) * NP + mycol;
-        d4 c = {pi[0], pi[4 * NP], pi[8 * NP], pi[12 * NP]};
-#pragma unroll
-        for (int kk = 0; kk < NB; ++kk) c = mma16(frag_a(M, LDM, 16 * i, NP + 16 * kk, r16, kq), Wt[kk], c);
-        Sn[i] = c;                             // Sigma_t tile (i, j)
-      }
     }
     __syncthreads();
+    TICK(11)
 
+    if (t > 0) {                         // prefetch step t-1 (in flight during B2)
+      const double* wn = w - WSTEP;
+#pragma unroll
+      for (int u = 0; u < RL; ++u) { const int idx = tid + 256 * u; xr[u] = idx < NP * NP ? wn[idx] : 0.0; }
+      if (tid < NP) cpre = wn[2 * NP * NP + tid];
+    }
     if (j < NB) {
       const double mc = mnew[mycol];
       double* oP = INHOMOG && t < T - 1 ? a.E_pair + ((long)b * (T - 1) + t) * 3 * nn : nullptr;
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
-        store_c(M, LDM, 16 * i, 16 * j, r16, kq, Sn[i]);
+        d4 c = pin[i];
+#pragma unroll
+        for (int kk = 0; kk < NB; ++kk) c = mma16(frag_a(M, LDM, 16 * i, NP + 16 * kk, r16, kq), Wt[kk], c);
+        store_c(M, LDM, 16 * i, 16 * j, r16, kq, c);          // Sigma_t tile (i, j)
         d4 exx, ecr;
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
           const int row = 16 * i + 4 * qq + kq;
-          exx[qq] = __builtin_fma(mnew[row], mc, Sn[i][qq]);      // E[x_t x_t'](row, mycol)
+          exx[qq] = __builtin_fma(mnew[row], mc, c[qq]);          // E[x_t x_t'](row, mycol)
           ecr[qq] = __builtin_fma(mold[row], mc, Wt[i][qq]);      // E[x_{t+1} x_t'](row, mycol)
         }
-        if (INHOMOG) {
-          if (oP) {
+#ifndef SVAE_TILE_TIMING
 #pragma unroll
-            for (int qq = 0; qq < 4; ++qq) {
-              const int row = 16 * i + 4 * qq + kq;
-              if (row < n && mycol < n) {
-                oP[row * n + mycol] = exx[qq];
-                oP[nn + mycol * n + row] = ecr[qq];
-                oP[2 * nn + row * n + mycol] = lastE[i][qq];      // E[x_{t+1} x_{t+1}'] (previous step)
-              }
+        for (int qq = 0; qq < 4; ++qq) {
+          const int row = 16 * i + 4 * qq + kq;
+          const bool in = row < n && mycol < n;
+          if (INHOMOG) {
+            if (oP && in) {
+              oP[row * n + mycol] = exx[qq];
+              oP[nn + mycol * n + row] = ecr[qq];
+              oP[2 * nn + row * n + mycol] = prevE[i][qq];        // E[x_{t+1} x_{t+1}'] (previous step)
+            }
+          } else if (in) {
+            // sum_{t>=1} E[x_t x_t'] = sum_{t<=T-2} + last - first: the last term waits in its output slot
+            if (t == T - 1) oPh[2 * nn + row * n + mycol] = exx[qq];
+            if (t == 0) {
+              const double s0 = sxx[i][qq] + (T > 1 ? exx[qq] : 0.0);
+              oPh[row * n + mycol] = s0;
+              oPh[nn + mycol * n + row] = cross[i][qq] + ecr[qq];
+              oPh[2 * nn + row * n + mycol] = s0 + oPh[2 * nn + row * n + mycol] - exx[qq];
             }
           }
-          lastE[i] = exx;
-        } else {
-          if (t == T - 1) lastE[i] = exx; else sxx[i] += exx;
-          cross[i] += ecr;
+          if (t == 0 && in) oI[row * n + mycol] = exx[qq];
         }
-        if (t == 0) firstE[i] = exx;
+#endif
+        if (INHOMOG) prevE[i] = exx;
+        else if (t < T - 1) { sxx[i] += exx; cross[i] += ecr; }
       }
-    }
-    __syncthreads();
-    if (tid < n) {
-      const double mm = mnew[tid];
-      oEx[(long)t * n + tid] = mm;
-      oExx[(long)t * n + tid] = __builtin_fma(mm, mm, M[tid * LDM + tid]);
     }
     double* tmp = mold; mold = mnew; mnew = tmp;
+    __syncthreads();
+    TICK(9)
   }
+#ifdef SVAE_TILE_TIMING
+  if (tid == 0) { for (int q = 0; q < 12; ++q) a.E_init[(long)b * (nn + n) + q] = (double)tm[q]; }
+  return;
+#endif
+  if (tid < n) {                          // node statistics of step 0, E[x_0]
+    const double mm = mold[tid];
+    oEx[tid] = mm;
+    oExx[tid] = __builtin_fma(mm, mm, M[tid * LDM + tid]);
+    oI[nn + tid] = mm;
+  }
+}
 
-  // ---- E_init and the pair sums -----------------------------------------------------------------
-  if (j < NB) {
-    double* oI = a.E_init + (long)b * (nn + n);
-    double* oP = a.E_pair + (long)b * 3 * nn;
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-#pragma unroll
-      for (int qq = 0; qq < 4; ++qq) {
-        const int row = 16 * i + 4 * qq + kq;
-        if (row < n && mycol < n) {
-          oI[row * n + mycol] = firstE[i][qq];
-          if (!INHOMOG) {
-            oP[row * n + mycol] = sxx[i][qq];
-            oP[nn + mycol * n + row] = cross[i][qq];
-            oP[2 * nn + row * n + mycol] = sxx[i][qq] + lastE[i][qq] - firstE[i][qq];
-          }
-        }
-      }
+
+// Packs the pair parameters of one step (slot) into the register order of the main kernel:
+//   pA[((i NB + kk) 64 + lane) 4 + kb] = -J12[16 kk + 4 kb + kq][16 i + r16]       (A operand of -(J12'))
+//   pC[((i NB + j) 64 + lane) 4 + qq]  = -2 (J22 + w J11n)[16 i + 4 qq + kq][16 j + r16], identity on the padding
+//   pR[row NP + col]                   = J12n[row][col] (zero-padded; all zero when the next step is the last)
+// Homogeneous parameters: slot 0 = regular step, slot 1 = the step before the last one (no J11 term,
+// zero right-hand side).  Per-step parameters: slot t = transition t -> t+1 (t = 0 .. T-2).
+template <int NB>
+__global__ __launch_bounds__(256) void tile_pack_pairs_kernel(const double* __restrict__ J11,
+                                                              const double* __restrict__ J12,
+                                                              const double* __restrict__ J22,
+                                                              int n, int T, int inhomog, long set_stride,
+                                                              double* __restrict__ out) {
+  constexpr int NP = 16 * NB;
+  const int slot = blockIdx.x, set = blockIdx.y;
+  const int nslots = inhomog ? T - 1 : 2;
+  const long nn = (long)n * n;
+  const int t = inhomog ? slot : 0;
+  const bool next_last = inhomog ? (t + 1 == T - 1) : (slot == 1);
+  const double* j12 = J12 + set * set_stride + (long)t * nn;
+  const double* j22 = J22 + set * set_stride + (long)t * nn;
+  const double* j11n = J11 + set * set_stride + (long)(inhomog && !next_last ? t + 1 : t) * nn;
+  const double* j12n = J12 + set * set_stride + (long)(inhomog && !next_last ? t + 1 : t) * nn;
+  double* o = out + ((long)set * nslots + slot) * (3 * NP * NP);
+  for (int e = threadIdx.x; e < NP * NP; e += 256) {
+    const int qq = e & 3, lane = (e >> 2) & 63, tile = e >> 8;
+    const int r16 = lane & 15, kq = lane >> 4, ti = tile / NB, tj = tile % NB;
+    {  // pA: tile (i = ti, kk = tj), kb = qq
+      const int row = 16 * tj + 4 * qq + kq, col = 16 * ti + r16;
+      o[e] = (row < n && col < n) ? -j12[row * n + col] : 0.0;
+    }
+    {  // pC: tile (i = ti, j = tj)
+      const int row = 16 * ti + 4 * qq + kq, col = 16 * tj + r16;
+      double v = (row == col) ? 1.0 : 0.0;
+      if (row < n && col < n) v = -2.0 * j22[row * n + col] - (next_last ? 0.0 : 2.0 * j11n[row * n + col]);
+      o[NP * NP + e] = v;
+    }
+    {  // pR
+      const int row = e / NP, col = e % NP;
+      o[2 * NP * NP + e] = (!next_last && row < n && col < n) ? j12n[row * n + col] : 0.0;
     }
   }
-  if (tid < n) a.E_init[(long)b * (nn + n) + nn + tid] = mold[tid];    // mold == m_0 after the last swap
 }
 
 template <int NB>
 static int launch_tile(const LdsArgs& a, int n, int inhomog, hipStream_t s) {
+  constexpr int NP = 16 * NB;
   const size_t lds = TileCfg<NB>::LDS_DOUBLES * sizeof(double);
+  const int T = a.T;
+  // workspace: [hand-off region: B T WSTEP][packed pair parameters]
+  double* pk = a.ws + (size_t)a.B * T * TileCfg<NB>::WSTEP;
+  const int batched = a.pair_seq_stride != 0;
+  if (T > 1) {
+    const int nslots = inhomog ? T - 1 : 2;
+    hipLaunchKernelGGL((tile_pack_pairs_kernel<NB>), dim3(nslots, batched ? a.B : 1), dim3(256), 0, s,
+                       a.J11, a.J12, a.J22, n, T, inhomog, (long)a.pair_seq_stride, pk);
+    if (hipGetLastError() != hipSuccess) return -1000;
+  }
   auto go = [&](auto kern) {
     static bool attr_set = false;     // per instantiation
     if (!attr_set) {
@@ -468,9 +642,10 @@ static int launch_tile(const LdsArgs& a, int n, int inhomog, hipStream_t s) {
         return -1001;
       attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(a.B), dim3(256), lds, s, a, n);
+    hipLaunchKernelGGL(kern, dim3(a.B), dim3(256), lds, s, a, n, (const double*)pk, batched);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
   };
+  (void)NP;
   return inhomog ? go(lds_estep_tile_kernel<NB, true>) : go(lds_estep_tile_kernel<NB, false>);
 }
 
@@ -479,6 +654,14 @@ static int launch_tile(const LdsArgs& a, int n, int inhomog, hipStream_t s) {
 extern "C" size_t svae_lds_tile_step_doubles(int n) {
   const int NP = 16 * ((n + 15) / 16);
   return (size_t)2 * NP * NP + NP;
+}
+
+/* doubles of packed pair parameters behind the hand-off region */
+extern "C" size_t svae_lds_tile_packed_doubles(int B, int T, int n, int inhomog, int pair_batched) {
+  const int NP = 16 * ((n + 15) / 16);
+  if (T < 2) return 0;
+  const size_t nslots = inhomog ? (size_t)(T - 1) : 2;
+  return (pair_batched ? (size_t)B : 1) * nslots * 3 * NP * NP;
 }
 
 extern "C" int svae_lds_launch_tile(const svae::LdsArgs* a, int n, int inhomog, void* stream) {

@@ -42,7 +42,7 @@ class LDSEStepPlan(object):
     """Pre-allocated buffers for repeated E-steps of one shape (B, T, n): the launch itself does no
     allocation, no host<->device copy and no synchronisation."""
 
-    def __init__(self, B, T, n, device="cuda", inhomog=False):
+    def __init__(self, B, T, n, device="cuda", inhomog=False, pair_batched=False):
         if not (1 <= n <= _lib.LDS_TILE_MAX_N):
             raise ValueError("latent dimension n=%d outside the supported range (1..%d)"
                              % (n, _lib.LDS_TILE_MAX_N))
@@ -52,7 +52,9 @@ class LDSEStepPlan(object):
         self.B, self.T, self.n, self.inhomog = B, T, n, bool(inhomog)
         self.device = torch.device(device)
         f64 = dict(dtype=torch.float64, device=self.device)
-        self.ws_bytes = int(self.lib.svae_lds_workspace_bytes(max(B, 1), T, n))
+        # (n > 15: the workspace also holds the re-packed pair parameters, one set per sequence if batched)
+        self.ws_bytes = int(self.lib.svae_lds_workspace_bytes_ex(max(B, 1), T, n, int(self.inhomog),
+                                                                 int(bool(pair_batched))))
         self.ws = torch.empty(self.ws_bytes // 8, **f64)
         self.lognorm = torch.empty(B, **f64)
         self.E_init = torch.empty(B, n * n + n, **f64)
@@ -198,7 +200,7 @@ def natural_lds_estep_general(natparam, node_params, plan=None, check=True, keep
         raise ValueError("pair logZ must have one entry per step")
 
     if plan is None:
-        plan = LDSEStepPlan(B, T, n, dev, inhomog)
+        plan = LDSEStepPlan(B, T, n, dev, inhomog, pair_batched)
     elif (plan.B, plan.T, plan.n, plan.inhomog) != (B, T, n, inhomog):
         raise ValueError("plan shape mismatch")
     plan.launch(init_J, init_h, init_logZ, J11, J12, J22, logZ_pair, node_J, node_h, node_logZ,

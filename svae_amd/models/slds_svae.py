@@ -89,7 +89,7 @@ def optimize_local_meanfield(global_natparam, node_potentials, init_eps, tol=1e-
     hmm_init, hmm_pair = hmm_prior_expectedstats(tuple(_dev64(x, dev) for x in hmm_global))
     lds_global = [(_dev64(a, dev), tuple(_dev64(y, dev) for y in m)) for a, m in lds_global]
     dense_init, dense_pair = get_all_lds_local_natparams(lds_global)
-    plan = LDSEStepPlan(B, T, n, dev, inhomog=True)
+    plan = LDSEStepPlan(B, T, n, dev, inhomog=True, pair_batched=True)
 
     init_stats, pair_stats = initialize_local_meanfield(node, _dev64(init_eps, dev))
     vlb = torch.full((B,), -float("inf"), dtype=torch.float64, device=dev)
@@ -140,7 +140,7 @@ def optimize_local_meanfield_withlabels(global_natparam, node_potentials, labels
     lds_global = [(_dev64(a, dev), tuple(_dev64(y, dev) for y in m)) for a, m in lds_global]
     dense_init, dense_pair = get_all_lds_local_natparams(lds_global)
     lds_init, lds_pair = get_var_lds_local_natparam(dense_init, dense_pair, hmm_stats[2])
-    plan = LDSEStepPlan(B, T, n, dev, inhomog=True)
+    plan = LDSEStepPlan(B, T, n, dev, inhomog=True, pair_batched=True)
     lds_vlb, (Ei, Ep, En) = _lds_estep_batched_init(plan, lds_init, lds_pair, node)
     lds_stats = ((Ei[0].clone(), Ei[1].clone()), tuple(x.clone() for x in Ep[:3]), tuple(x.clone() for x in En[:2]))
     return (hmm_stats, lds_stats), (None, (lds_init, lds_pair)), (torch.zeros_like(lds_vlb), lds_vlb.clone())
@@ -191,7 +191,7 @@ def run_inference(prior_natparam, global_natparam, nn_potentials, num_samples, i
     if init_eps is None:
         init_eps = torch.randn(B, T, 1, n, dtype=torch.float64, device=dev, generator=generator)
     (hmm_stats, _), (hmm_nat, (lds_init, lds_pair)), _, _ = optimize_local_meanfield(global_natparam, node, init_eps, tol)
-    plan = LDSEStepPlan(B, T, n, dev, inhomog=True)
+    plan = LDSEStepPlan(B, T, n, dev, inhomog=True, pair_batched=True)
     lognorm, (Ei, Ep, En) = _lds_estep_batched_init(plan, lds_init, lds_pair, node, keep_factor=True)
     S = int(num_samples)
     if eps is None:

@@ -17,7 +17,7 @@ def _header_symbols():
 
 def test_header_declares_the_expected_entry_points():
     syms = _header_symbols()
-    for s in ("svae_lds_estep_f64", "svae_lds_workspace_bytes", "svae_lds_set_split_max_b",
+    for s in ("svae_lds_estep_f64", "svae_lds_workspace_bytes", "svae_lds_workspace_bytes_ex", "svae_lds_set_split_max_b",
               "svae_lds_reduce_stats_f64",
               "svae_lds_sample_f64", "svae_lds_estep_vjp_f64", "svae_lds_vjp_workspace_bytes",
               "svae_hmm_estep_f64", "svae_hmm_workspace_bytes",
@@ -44,7 +44,16 @@ def test_workspace_size_formula():
     assert lib.svae_lds_workspace_bytes(512, 200, 10) == 512 * (22 + 200 * (10 * (12 + 10) + 10 * 10 + 10 + 11 * 12)) * 8
     assert lib.svae_lds_workspace_bytes(3, 7, 5) == 3 * (12 + 7 * (5 * (6 + 6) + 5 * 5 + 5 + 6 * 6)) * 8
     assert lib.svae_lds_vjp_workspace_bytes(3, 7, 5) == 3 * 7 * 5 * (6 + 2 * 6) * 8
-    assert lib.svae_lds_workspace_bytes(1, 1, 16) == 0     # n > 15: outside the register path
+    # n > 15: tiled path, per step X and P^-1 (NP x NP, NP = n rounded up to 16) and c (NP)
+    # + the pair parameters re-packed in fragment order: 2 slots (homogeneous) or T-1 per set, 3 NP^2 each
+    assert lib.svae_lds_workspace_bytes(1, 1, 16) == (2 * 16 * 16 + 16) * 8
+    assert lib.svae_lds_workspace_bytes(2, 3, 40) == (2 * 3 * (2 * 48 * 48 + 48) + 2 * 3 * 48 * 48) * 8
+    assert lib.svae_lds_workspace_bytes_ex(2, 3, 40, 0, 0) == lib.svae_lds_workspace_bytes(2, 3, 40)
+    assert lib.svae_lds_workspace_bytes_ex(2, 3, 40, 1, 0) == (2 * 3 * (2 * 48 * 48 + 48) + 2 * 3 * 48 * 48) * 8
+    assert lib.svae_lds_workspace_bytes_ex(2, 5, 40, 1, 1) == (2 * 5 * (2 * 48 * 48 + 48) + 2 * 4 * 3 * 48 * 48) * 8
+    assert lib.svae_lds_workspace_bytes_ex(3, 7, 5, 1, 1) == lib.svae_lds_workspace_bytes(3, 7, 5)
+    assert lib.svae_lds_workspace_bytes(1, 1, 65) == 0     # n > 64: unsupported
+    assert lib.svae_lds_vjp_workspace_bytes(1, 1, 16) == 0  # VJP / sampler: register path only
     assert lib.svae_lds_workspace_bytes(0, 5, 3) == 0
 
 
@@ -55,7 +64,8 @@ def test_bad_arguments_are_rejected_on_the_host():
     null = None
     args = [null] * 15 + [null, null, 0, null]
     assert lib.svae_lds_estep_f64(4, 0, 3, 0, 0, 0, *args) == -2       # T < 1
-    assert lib.svae_lds_estep_f64(4, 5, 16, 0, 0, 0, *args) == -3      # n too large
+    assert lib.svae_lds_estep_f64(4, 5, 65, 0, 0, 0, *args) == -3      # n too large
+    assert lib.svae_lds_estep_f64(4, 5, 16, 0, 0, 1, *args) == -23     # tiled path keeps no sampler factors
     assert lib.svae_lds_estep_f64(4, 5, 3, 0, 1, 0, *args) == -5       # batched pair w/o inhomog
     assert lib.svae_lds_estep_f64(4, 5, 3, 0, 0, 0, *args) == -6       # NULL init_J
     assert lib.svae_lds_sample_f64(4, 5, 3, 0, null, null, null, 0, null) == -4    # S < 1

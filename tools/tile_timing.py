@@ -1,0 +1,21 @@
+"""Per-phase cycle counts of the tiled E-step (variants/tile_timing.so, built by
+tools/build_tile_variant.sh variants/tile_timing.so -DSVAE_TILE_TIMING).  Usage: n T B"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from svae_amd.lds.lds_inference import LDSEStepPlan
+from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials
+n, T, B = (int(x) for x in sys.argv[1:4])
+dev = torch.device("cuda:0")
+init, pair = rand_lds_natparam(n, np.random.default_rng(0))
+node = rand_node_potentials((B, T, n), np.random.default_rng(1))
+t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev).contiguous()
+plan = LDSEStepPlan(B, T, n, dev)
+args = [t(init[0]), t(init[1]), t(init[2]).reshape(1), t(pair[0]), t(pair[1]), t(pair[2]), t(pair[3]).reshape(1), t(node[0]), t(node[1]), None]
+for _ in range(2):
+    plan.launch(*args)
+torch.cuda.synchronize()
+tm = plan.E_init[:, :12].cpu().numpy().mean(0) / T
+names = ["misc", "factor|deferred", "wait factor", "pivot row", "eliminate", "hand-off", "schur", "reload", "B load", "B compute", "B accumulate", "B emit"]
+print("n=%d T=%d B=%d  cycles/step (wave 0, mean over sequences); total %.0f" % (n, T, B, tm.sum()))
+for nm, v in zip(names, tm):
+    print("  %-16s %8.0f  %5.1f%%" % (nm, v, 100 * v / tm.sum()))
