@@ -120,6 +120,24 @@ __device__ __forceinline__ double rcp_nr(double p) {
   return r;
 }
 
+// Ordered pieces of the reciprocal chain (v_rcp_f64 + two Newton steps) for hand-pipelined pivoting:
+// asm statements keep their place between the DPP row updates.
+__device__ __forceinline__ double asm_rcp(double p) {
+  double r;
+  asm volatile("v_rcp_f64 %0, %1\n\ts_nop 0" : "=v"(r) : "v"(p));   // trans result: 1 wait state
+  return r;
+}
+__device__ __forceinline__ double asm_fnma1(double a, double b) {        // 1 - a*b
+  double r;
+  asm volatile("v_fma_f64 %0, -%1, %2, 1.0" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double asm_fma(double a, double b, double c) { // a*b + c
+  double r;
+  asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 // Sum over the 16 lanes of a DPP row (result valid in every lane of the row).
 __device__ __forceinline__ double row_sum16(double x) {
   x += __shfl_xor(x, 1, 16);

@@ -75,22 +75,6 @@ __device__ __forceinline__ void rows_lane_bcast(double (&out)[MO], const double 
 // behind the row updates of pivot k, stalling ~100 cycles per pivot): row k+1 is updated first, its
 // pivot is broadcast, and v_rcp_f64 + the two Newton steps are issued as asm statements BETWEEN the
 // remaining row updates.
-__device__ __forceinline__ double asm_rcp(double p) {
-  double r;
-  asm volatile("v_rcp_f64 %0, %1\n\ts_nop 0" : "=v"(r) : "v"(p));   // trans result: 1 wait state
-  return r;
-}
-__device__ __forceinline__ double asm_fnma1(double a, double b) {        // 1 - a*b
-  double r;
-  asm volatile("v_fma_f64 %0, -%1, %2, 1.0" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ double asm_fma(double a, double b, double c) { // a*b + c
-  double r;
-  asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
-
 template <int N, bool CHOL, class StoreR>
 __device__ __forceinline__ void gauss_jordan(double (&P)[N], double (&X)[N], const double (&E)[N],
                                              double& qacc, double& pmin, double& ldM, int& ldE,

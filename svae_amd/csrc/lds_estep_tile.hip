@@ -23,7 +23,6 @@
 //             tile column j of W stays in registers (the MFMA C layout IS the B-operand layout)
 //             and feeds the second product directly.
 // Padding rows/columns (n < NP) carry an identity diagonal: pivots 1, log det unchanged.
-#define SVAE_DPP_ALWAYS_FENCED 1
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -82,21 +81,54 @@ __device__ __forceinline__ void factor_pivot_tile(const double* tile, int ld, do
   static_for<0, 16>([&](auto r) { A[r] = tile[r * ld + r16]; });
   dpp_fence(A);
   double dv = 0.0;
+  double pv = bcast_fenced<0>(A[0]);
+  double rinv = rcp_nr(pv);
+  double pprod = 1.0;
   static_for<0, 16>([&](auto p) {
     const double Ep = (r16 == p) ? 1.0 : 0.0;       // per-lane selects done arithmetically (x * Ep, exact)
-    const double pv = bcast_fenced<p>(A[p]);
     pmin = fmin(pmin, pv);
-    ldM *= __builtin_amdgcn_frexp_mant(pv);
-    ldE += __builtin_amdgcn_frexp_exp(pv);
-    const double rinv = rcp_nr(pv);
+    pprod *= pv;
     dv = __builtin_fma(Ep, rinv, dv);
     const double r = __builtin_fma(Ep, 1.0 - pv, A[p]) * rinv;       // lane p: 1/pivot
-    static_for<p + 1, 16>([&](auto i) {
-      const double old = A[i];
-      double acc = __builtin_fma(-old, Ep, old);                      // lane p of the row -> 0
-      mac_bc<p, true, true>(acc, old, r);                             // row_i -= A[i][p] * r
-      A[i] = acc;
-    });
+    // row updates in groups of four: the four lane-p clears first (independent), then the four DPP
+    // multiply-accumulates, so that no instruction waits for its predecessor's 8-cycle latency
+    auto update4 = [&](auto i0, auto cnt) {
+      constexpr int I0 = decltype(i0)::value, C = decltype(cnt)::value;
+      double olds[C], accs[C];
+      static_for<0, C>([&](auto j) { olds[j] = A[I0 + j]; accs[j] = __builtin_fma(-olds[j], Ep, olds[j]); });
+      static_for<0, C>([&](auto j) { mac_bc<p, true, false>(accs[j], olds[j], r); A[I0 + j] = accs[j]; });
+    };
+    if constexpr (p + 1 < 16) {
+      // software pipelining by hand: row p+1 first, broadcast its pivot, then the reciprocal chain of
+      // the NEXT pivot between the remaining row updates (cf. gauss_jordan, lds_estep_kernel.hpp)
+      update4(std::integral_constant<int, p + 1>{}, std::integral_constant<int, 1>{});
+      const double pn = bcast_fenced<p + 1>(A[p + 1]);
+      double t0 = 0.0, e0 = 0.0, t1 = 0.0, e1 = 0.0, rn = 0.0;
+      constexpr int REM = 14 - p;                      // row updates still to come
+      constexpr int NG = (REM + 3) / 4;                // ... in groups of four
+      auto chain = [&](auto s) {
+        if constexpr (s == 0) t0 = asm_rcp(pn);
+        else if constexpr (s == 1) e0 = asm_fnma1(pn, t0);
+        else if constexpr (s == 2) t1 = asm_fma(t0, e0, t0);
+        else if constexpr (s == 3) e1 = asm_fnma1(pn, t1);
+        else if constexpr (s == 4) rn = asm_fma(t1, e1, t1);
+      };
+      if constexpr (NG == 0) static_for<0, 5>(chain);
+      static_for<0, NG>([&](auto g) {
+        constexpr int i0 = p + 2 + 4 * g;
+        constexpr int c = (16 - i0) < 4 ? (16 - i0) : 4;
+        constexpr int lo = g * 5 / NG, hi = (g + 1) * 5 / NG;
+        static_for<lo, hi>(chain);                     // chain steps ahead of the group they overlap with
+        update4(std::integral_constant<int, i0>{}, std::integral_constant<int, c>{});
+      });
+      pv = pn;
+      rinv = rn;
+    }
+    if constexpr (p == 7 || p == 15) {             // keep the running product of pivots in range
+      ldE += __builtin_amdgcn_frexp_exp(pprod);
+      ldM *= __builtin_amdgcn_frexp_mant(pprod);
+      pprod = 1.0;
+    }
   });
   ldE += __builtin_amdgcn_frexp_exp(ldM);
   ldM = __builtin_amdgcn_frexp_mant(ldM);
@@ -242,6 +274,19 @@ __global__ __launch_bounds__(256, 2) void lds_estep_tile_kernel(const LdsArgs a,
     const bool last = (t == T - 1);
     const bool next_last = (t + 1 == T - 1);
     TICK(0)
+    // next step's node potentials: requested now, used after the Gauss-Jordan
+    // (unconditional, clamped addresses: a load under a branch is waited for at the join)
+    const long tn = (long)(last ? t : t + 1) * n;
+    const double njn = nodeJ[tn + (tid < n ? tid : n - 1)];
+    d4 nhn = {0.0, 0.0, 0.0, 0.0};
+    if constexpr (schur_on && (NB - sj0) % WPR == 0) {
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const int row = 16 * si + 4 * qq + kq;
+        nhn[qq] = nodeh[tn + (row < n ? row : n - 1)];
+      }
+    }
+
     // ---- in-place block Gauss-Jordan with look-ahead -----------------------------------------------
     // Per block pivot k:  (P1) all wavefronts scale the pivot row with U_k;  (P2) wavefronts 1..3 own
     // the other tile rows (eliminate, then rewrite their pivot-column tile) while wavefront 0 updates
@@ -367,7 +412,7 @@ __global__ __launch_bounds__(256, 2) void lds_estep_tile_kernel(const LdsArgs a,
 #pragma unroll
               for (int qq = 0; qq < 4; ++qq) {
                 const int row = 16 * si + 4 * qq + kq;
-                mv0[row] = row < n ? nodeh[(long)(t + 1) * n + row] - c[qq] : 0.0;   // c = -J12' c_t
+                mv0[row] = row < n ? nhn[qq] - c[qq] : 0.0;   // c = -J12' c_t
               }
             }
 #pragma unroll
@@ -387,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void lds_estep_tile_kernel(const LdsArgs a,
         const double hv = mv0[tid];
         hvec[tid] = hv;
         M[tid * LDM + 2 * NP] = hv;
-        if (tid < n) M[tid * LDM + tid] -= 2.0 * nodeJ[(long)(t + 1) * n + tid];
+        if (tid < n) M[tid * LDM + tid] -= 2.0 * njn;
       }
       __syncthreads();
       TICK(8)
