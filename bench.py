@@ -30,12 +30,21 @@ if ROOT not in sys.path:
 
 T_STEPS, N_LATENT, SEQS_PER_GPU = 200, 10, 512
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+FP64_MFMA_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x (16x16x4x2 flop / 64 clk, tools/ubench/mfma_f64.hip) x 2.4 GHz
+# --workload: the headline (BASELINE configs[1]/[2]) or BASELINE configs[4] (latent dim 64, T=1000; the
+# batch is not specified there: 512 sequences per GPU = two workgroups per CU)
+WORKLOADS = {"lds10": (200, 10, 512), "lds64": (1000, 64, 512)}
 
 
 def algorithmic_bytes_per_seq(T, n):
     """read node_J,node_h,node_logZ + write E_node (diag, x) + per-sequence
     E_init, E_pair sums, lognorm."""
     return 8 * (T * (2 * n + 1) + 2 * T * n + (n * n + n) + 3 * n * n + 1)
+
+
+def algorithmic_flops_per_seq(T, n):
+    """T (35/3) n^3 (filter: potrf + trsm + gemm; RTS: potrf, trsm, potri, gemms)."""
+    return T * (35.0 / 3.0) * n ** 3
 
 
 def cpu_baseline(B, T, n, budget_s=10.0):
@@ -55,7 +64,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--seqs-per-gpu", type=int, default=SEQS_PER_GPU)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="lds10")
+    ap.add_argument("--seqs-per-gpu", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -75,7 +85,8 @@ def main():
     from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials
     from svae_amd.parallel import allreduce_global_stats
 
-    B, T, n = args.seqs_per_gpu, T_STEPS, N_LATENT
+    T, n, B = WORKLOADS[args.workload]
+    B = args.seqs_per_gpu or B
     init, pair = rand_lds_natparam(n, np.random.default_rng(0))       # replicated global params
     node_J, node_h = rand_node_potentials((B, T, n), np.random.default_rng(1000 + rank))  # this rank's shard
     t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev).contiguous()
@@ -132,10 +143,13 @@ def main():
     lib.svae_lds_set_split_max_b(split_max)
     kernel = ("svae::lds_estep_split_kernel<%d,false,false>" if B <= split_max
               else "svae::lds_estep_kernel<%d,false,false>") % n
+    if n > _lib.LDS_MAX_N:
+        kernel = "svae::lds_estep_tile_kernel<%d,false>" % ((n + 15) // 16)
     # HBM traffic of that kernel from the committed rocprofv3 PMC passes (separate runs of this
     # same command, see profiles/run_profile.sh); only quoted when the workload matches.
     traffic, traffic_src = None, None
-    prof = os.path.join(ROOT, "profiles", "r1_final" if B == 512 else "r1_final_b%d" % B, "pmc_hbm.json")
+    prof = os.path.join(ROOT, "profiles", ("r1_final" if B == 512 else "r1_final_b%d" % B) if n == 10
+                        else "r1_tile_n%d_b%d" % (n, B), "pmc_hbm.json")
     if os.path.isfile(prof):
         p = json.load(open(prof))
         if kernel.split("<")[0] in p.get("kernel", ""):
@@ -144,25 +158,35 @@ def main():
         total_seqs = B * world * args.steps
         bytes_launch = B * algorithmic_bytes_per_seq(T, n)
         achieved = bytes_launch / (kern_ms * 1e-3) / 1e9
+        hbm = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+               "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+               "traffic_unit": "bytes per launch (rocprofv3 PMC, 2*FETCH_SIZE+WRITE_SIZE)",
+               "traffic_source": traffic_src,
+               "kernel": kernel, "kernel_ms": kern_ms,
+               "algorithmic_bytes_per_launch": bytes_launch,
+               "kernel_sequences_per_s": B / (kern_ms * 1e-3)}
+        if n > _lib.LDS_MAX_N:      # dense contraction: priced against the fp64 MFMA peak
+            flops_launch = B * algorithmic_flops_per_seq(T, n)
+            tf = flops_launch / (kern_ms * 1e-3) / 1e12
+            roof = dict(hbm, bound="mfma", achieved=tf, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=tf / FP64_MFMA_PEAK_TFLOPS, algorithmic_flops_per_launch=flops_launch,
+                        hbm_algorithmic_GBps=achieved)
+        else:
+            roof = hbm
         out = {
-            "metric": "E-step sequences/sec (LDS fwd-bwd smoother, T=200 n=10)",
+            "metric": "E-step sequences/sec (LDS fwd-bwd smoother, T=%d n=%d)" % (T, n),
             "value": total_seqs / elapsed, "unit": "sequences/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "LDS-SVAE E-step, latent dim %d, T=%d, %d sequences per GPU "
-                                   "(BASELINE configs[1]; x8 GPUs = configs[2])" % (n, T, B),
+                                   "(%s)" % (n, T, B, "BASELINE configs[1]; x8 GPUs = configs[2]" if n == 10
+                                                  else "BASELINE configs[4] shape; batch chosen here"),
                        "sequences_per_gpu": B, "T": T, "n": n, "global_sequences": B * world,
                        "parallelism": "dp%d" % world,
                        "step": "estep kernel + batch stat reduce" + (" + RCCL all-reduce" if world > 1 else "")},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "traffic_unit": "bytes per launch (rocprofv3 PMC, 2*FETCH_SIZE+WRITE_SIZE)",
-                         "traffic_source": traffic_src,
-                         "kernel": kernel, "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": bytes_launch,
-                         "kernel_sequences_per_s": B / (kern_ms * 1e-3)},
+            "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

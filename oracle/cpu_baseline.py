@@ -62,9 +62,10 @@ def main():
     _G["data"] = (natparam, node_J, node_h)
     kind, _ = _estep_fn()
 
-    _worker(8)                                        # warm-up / page-in
-    probe = _worker(32) / 32.0                        # seconds per sequence
-    n1 = int(max(32, min(a.B, a.budget / probe)))
+    lo = 32 if a.n * a.n * a.T < 100000 else 4        # smallest sample (big sequences cost ~0.1 s each)
+    _worker(max(1, lo // 4))                          # warm-up / page-in
+    probe = _worker(lo) / float(lo)                   # seconds per sequence
+    n1 = int(max(lo, min(a.B, a.budget / probe)))
     dt1 = _worker(n1)
     one_core = n1 / dt1
     cores = os.cpu_count() or 1
@@ -73,9 +74,10 @@ def main():
            "sample": "%d of the %d bench sequences (T=%d, n=%d), 1 core" % (n1, a.B, a.T, a.n)}
     if cores > 1:
         import multiprocessing as mp
-        per = int(max(32, min(a.B, a.budget * one_core)))
+        # (big sequences scale poorly over cores -- measured 6x on 256 -- so their all-core sample stays small)
+        per = lo if lo < 32 else int(max(lo, min(a.B, a.budget * one_core)))
         with mp.get_context("fork").Pool(cores) as pool:      # no GPU runtime in this process
-            pool.map(_worker, [4] * cores)
+            pool.map(_worker, [max(1, lo // 8)] * cores)
             t0 = time.perf_counter()
             pool.map(_worker, [per] * cores)
             wall = time.perf_counter() - t0

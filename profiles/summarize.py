@@ -1,0 +1,43 @@
+#!/usr/bin/env python
+"""Turn the raw rocprofv3 output of profiles/run_profile.sh (gpurun_out/prof_<tag>/) into the small
+summaries committed under profiles/<tag>/: kernel_stats.csv (copy of the --stats table) and
+pmc_hbm.json (HBM bytes per launch of the dominant kernel from the FETCH_SIZE / WRITE_SIZE passes,
+with the gfx950 correction of MI355X_MICROARCH.md: wide coalesced reads are counted at 1/2).
+Usage: python profiles/summarize.py <tag> [kernel-name-substring]"""
+import csv, json, os, shutil, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    tag = sys.argv[1]
+    sub = sys.argv[2] if len(sys.argv) > 2 else "lds_estep"
+    src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+    dst = os.path.join(ROOT, "profiles", tag)
+    os.makedirs(dst, exist_ok=True)
+    shutil.copy(os.path.join(src, "trace", "bench_kernel_stats.csv"), os.path.join(dst, "kernel_stats.csv"))
+    out = {}
+    disp = {}
+    for counter, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+        per = {}
+        name = None
+        with open(os.path.join(src, d, "bench_counter_collection.csv")) as f:
+            for row in csv.DictReader(f):
+                if row.get("Counter_Name") != counter or sub not in row.get("Kernel_Name", ""):
+                    continue
+                per[row["Dispatch_Id"]] = per.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+                name = row["Kernel_Name"]
+        vals = list(per.values())
+        out[counter + "_KB_per_launch_mean"] = sum(vals) / max(1, len(vals))
+        out[counter + "_launches"] = len(vals)
+        out["kernel"] = name
+    out["note"] = ("rocprofv3 --pmc, separate passes (profiles/run_profile.sh); gfx950: FETCH_SIZE counts wide "
+                   "coalesced reads at 1/2 (MI355X_MICROARCH.md, HBM) -> hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) KB")
+    out["hbm_bytes_per_launch_corrected"] = 1024.0 * (2 * out["FETCH_SIZE_KB_per_launch_mean"]
+                                                       + out["WRITE_SIZE_KB_per_launch_mean"])
+    json.dump(out, open(os.path.join(dst, "pmc_hbm.json"), "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
