@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void lds_estep_tile_kernel(const LdsArgs a,
                                                                 const double* __restrict__ pk_base,
                                                                 const int pk_batched) {
   using Cfg = TileCfg<NB>;
-  constexpr int NP = Cfg::NP, NTC = Cfg::NTC, LDM = Cfg::LDM, WSTEP = Cfg::WSTEP;
+  constexpr int NP = Cfg::NP, LDM = Cfg::LDM, WSTEP = Cfg::WSTEP;
   extern __shared__ double smem[];
   double* M = smem;
   double* hvec = M + NP * LDM;     // forward: h_filt of the step; backward: c_t
@@ -161,13 +161,11 @@ __global__ __launch_bounds__(256, 2) void lds_estep_tile_kernel(const LdsArgs a,
   const long nn = (long)n * n;
   const double* J11 = a.J11 + (long)b * a.pair_seq_stride;
   const double* J12 = a.J12 + (long)b * a.pair_seq_stride;
-  const double* J22 = a.J22 + (long)b * a.pair_seq_stride;
   const double* nodeJ = a.node_J + (long)b * T * n;
   const double* nodeh = a.node_h + (long)b * T * n;
   double* wsb = a.ws + (long)b * T * WSTEP;
   // packed pair parameters: per set, (INHOMOG ? T-1 : 2) slots of [pA | pC | pR] (3 NP^2 doubles)
   const double* packed = pk_base + (pk_batched ? (long)b * (T - 1) * (3 * NP * NP) : 0);
-  auto pair_at = [&](const double* p, int t) { return INHOMOG ? p + (long)t * nn : p; };
 
   double ldM = 1.0, pmin = 1.0e300, qacc = 0.0;
   int ldE = 0;
@@ -211,13 +209,6 @@ __global__ __launch_bounds__(256, 2) void lds_estep_tile_kernel(const LdsArgs a,
   constexpr int RL4 = (NP * NP / 4 + 255) / 256; // 4-double chunks per thread of an NP x NP copy
   int* flag = (int*)(ubuf + 2 * UBUF);           // look-ahead hand-shake (see below)
   if (tid == 0) *flag = 0;
-
-  // clamped, branch-free global reads of an n x n matrix padded to NP x NP
-  auto gl = [&](const double* p, int row, int col) -> double {
-    const int rr = row < n ? row : n - 1, cc = col < n ? col : n - 1;
-    const double v = p[rr * n + cc];
-    return (row < n && col < n) ? v : 0.0;
-  };
 
   // ---- step 0: P = -2 (init_J + J11) + diag(-2 node_J[0]),  R = J12,  h = init_h + node_h[0] -----
   for (int idx = tid; idx < NP * NP; idx += 256) {

@@ -115,3 +115,30 @@ def test_withlabels_matches_oracle():
             _close(got[b], want)
         for got, want in zip(lds_stats[2], ref["node_stats"]):
             _close(got[b], want)
+
+
+def test_config3_shape_properties():
+    """BASELINE configs[3] shape (K=8 states, latent dim 10, T=500), a slice of the batch:
+    size-independent properties of the converged local mean field plus parity of one sequence."""
+    from svae_amd.models import slds_svae
+    K, n, T, B = 8, 10, 500, 24
+    rng = np.random.default_rng(3)
+    glob = _globals(K, n, rng)
+    J, h = _nodes(B, T, n, rng)
+    eps = rng.standard_normal((B, T, 1, n))
+    dev = torch.device("cuda:0")
+    node = (torch.as_tensor(J, device=dev), torch.as_tensor(h, device=dev))
+    (hmm_stats, lds_stats), _, (hmm_vlb, lds_vlb), iters = slds_svae.optimize_local_meanfield(glob, node, eps)
+    Ei, Et, Es = hmm_stats
+    assert int(iters.max()) < 100
+    assert torch.allclose(Es.sum(-1), torch.ones_like(Es.sum(-1)), atol=1e-12)
+    assert torch.allclose(Et.sum((-1, -2)), torch.full((B,), T - 1., dtype=torch.float64, device=dev), atol=1e-9)
+    assert torch.allclose(Ei, Es[:, 0], atol=1e-12)
+    var = lds_stats[2][0] - lds_stats[2][1] ** 2
+    assert float(var.min()) > 0 and torch.isfinite(hmm_vlb + lds_vlb).all()
+    b = 5
+    ref = slds_numpy.optimize_local_meanfield(glob, (J[b], h[b]), eps[b])
+    assert int(iters[b]) == ref["iters"]
+    _close(Es[b], ref["hmm_stats"][2], 1e-5)
+    for got, want in zip(lds_stats[1], ref["pair_stats"]):
+        _close(got[b], want, 1e-5)

@@ -1,0 +1,53 @@
+"""Timing of the SLDS-SVAE local mean field (BASELINE configs[3]: K=8 discrete states, latent dim 10,
+2048 sequences x T=500).  Usage: python tools/bench_slds.py [B T n K]"""
+import os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import expfam_numpy as ef          # parameter construction only
+from svae_amd.models import slds_svae
+from svae_amd.hmm.hmm_inference import hmm_estep
+from svae_amd.lds.lds_inference import LDSEStepPlan
+
+
+def globals_(K, n, rng):
+    lds = []
+    for k in range(K):
+        nu, S = n + 1. + rng.random(), 2. * (n + 1) * np.eye(n)
+        th = 0.3 * (k + 1)
+        M = 0.95 * np.eye(n)
+        M[:2, :2] = 0.95 * np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        lds.append((ef.niw_standard_to_natural(S, 0.3 * rng.standard_normal(n), np.array(0.5), np.array(nu)),
+                    ef.mniw_standard_to_natural(nu, S, M, 0.2 * np.eye(n))))
+    return (rng.random(K) * 2., rng.random((K, K)) * 2. + 3. * np.eye(K)), lds
+
+
+def main():
+    B, T, n, K = (int(x) for x in sys.argv[1:5]) if len(sys.argv) > 4 else (2048, 500, 10, 8)
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(0)
+    glob = globals_(K, n, rng)
+    node = (torch.as_tensor(-0.5 * (0.5 + rng.random((B, T, n))), device=dev),
+            torch.as_tensor(2. * rng.standard_normal((B, T, n)), device=dev))
+    eps = torch.randn(B, T, 1, n, dtype=torch.float64, device=dev)
+    for rep in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        (hmm_stats, lds_stats), _, (hv, lv), iters = slds_svae.optimize_local_meanfield(glob, node, eps)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    it = int(iters.max())
+    print("SLDS local mean field B=%d T=%d n=%d K=%d: %.1f ms for %d sweeps (%.1f ms/sweep, %.0f sequence-sweeps/s); "
+          "iterations per sequence min/mean/max %d/%.1f/%d"
+          % (B, T, n, K, dt * 1e3, it, dt * 1e3 / it, B * it / dt, int(iters.min()), float(iters.double().mean()), it))
+    # the two kernels alone, same shapes
+    node_hmm = torch.randn(B, T, K, dtype=torch.float64, device=dev)
+    init = torch.zeros(K, dtype=torch.float64, device=dev); pair = torch.log_softmax(torch.randn(K, K, dtype=torch.float64, device=dev), -1)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    hmm_estep((init, pair, node_hmm)); torch.cuda.synchronize()
+    ev[0].record()
+    for _ in range(5): hmm_estep((init, pair, node_hmm))
+    ev[1].record(); torch.cuda.synchronize()
+    print("  HMM E-step kernel alone: %.3f ms per call" % (ev[0].elapsed_time(ev[1]) / 5))
+
+
+if __name__ == "__main__":
+    main()

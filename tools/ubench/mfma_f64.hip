@@ -33,17 +33,17 @@ void run(const char* name) {
   for (int waves : {1, 4, 8, 16}) {
     const int blocks = 256, threads = 64 * waves;
     long long* out; double* sink;
-    hipMalloc(&out, sizeof(long long) * blocks * waves);
-    hipMalloc(&sink, sizeof(double) * blocks * threads);
+    (void)hipMalloc(&out, sizeof(long long) * blocks * waves);
+    (void)hipMalloc(&sink, sizeof(double) * blocks * threads);
     k<CHAINS><<<blocks, threads>>>(out, sink, iters);
     k<CHAINS><<<blocks, threads>>>(out, sink, iters);
-    hipDeviceSynchronize();
+    (void)hipDeviceSynchronize();
     std::vector<long long> h(blocks * waves);
-    hipMemcpy(h.data(), out, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(h.data(), out, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
     std::sort(h.begin(), h.end());
     printf("%-22s waves/CU=%2d : %.1f cycles per MFMA per wave (median)\n", name, waves,
            (double)h[h.size() / 2] / (iters * 16.0 * CHAINS));
-    hipFree(out); hipFree(sink);
+    (void)hipFree(out); (void)hipFree(sink);
   }
 }
 
