@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void lds_estep_tile_kernel(const LdsArgs a,
   constexpr int WPR = NB <= 2 ? 4 / NB : 1;
   constexpr int SCOLS = (NB + 1 + WPR - 1) / WPR;
   constexpr int RL = (NP * NP + 255) / 256;      // doubles per thread of an NP x NP copy
-  constexpr int RL4 = (NP * NP / 4 + 255) / 256; // 4-double chunks per thread of an NP x NP copy
+  constexpr int RL4 = (NP * NP / 4 + 191) / 192; // 4-double chunks per thread of an NP x NP copy by 3 wavefronts
   int* flag = (int*)(ubuf + 2 * UBUF);           // look-ahead hand-shake (see below)
   if (tid == 0) *flag = 0;
 
@@ -254,37 +254,29 @@ __global__ __launch_bounds__(256, 2) void lds_estep_tile_kernel(const LdsArgs a,
         if (j < NB) sC[s2] = *(const d4*)(pk + NP * NP + ((si * NB + j) * 64 + lane) * 4);
       }
     }
+    if constexpr (W > 0) {
 #pragma unroll
-    for (int u = 0; u < RL4; ++u) {
-      const int c4 = tid + 256 * u;
-      rl[u] = d4{0.0, 0.0, 0.0, 0.0};
-      if (c4 * 4 < NP * NP) rl[u] = *(const d4*)(pk + 2 * NP * NP + c4 * 4);
+      for (int u = 0; u < RL4; ++u) {
+        const int c4 = tid - 64 + 192 * u;
+        rl[u] = d4{0.0, 0.0, 0.0, 0.0};
+        if (c4 * 4 < NP * NP) rl[u] = *(const d4*)(pk + 2 * NP * NP + c4 * 4);
+      }
     }
   };
+  if constexpr (W == 0) factor_pivot_tile(M, LDM, ubuf, LDU, ubuf + 16 * LDU, r16, kq, pmin, ldM, ldE);
   for (int t = 0; t < T; ++t) {
     const bool last = (t == T - 1);
     const bool next_last = (t + 1 == T - 1);
     TICK(0)
-    // next step's node potentials: requested now, used after the Gauss-Jordan
-    // (unconditional, clamped addresses: a load under a branch is waited for at the join)
-    const long tn = (long)(last ? t : t + 1) * n;
-    const double njn = nodeJ[tn + (tid < n ? tid : n - 1)];
+    double njn = 0.0;
     d4 nhn = {0.0, 0.0, 0.0, 0.0};
-    if constexpr (schur_on && (NB - sj0) % WPR == 0) {
-#pragma unroll
-      for (int qq = 0; qq < 4; ++qq) {
-        const int row = 16 * si + 4 * qq + kq;
-        nhn[qq] = nodeh[tn + (row < n ? row : n - 1)];
-      }
-    }
-
     // ---- in-place block Gauss-Jordan with look-ahead -----------------------------------------------
     // Per block pivot k:  (P1) all wavefronts scale the pivot row with U_k;  (P2) wavefronts 1..3 own
     // the other tile rows (eliminate, then rewrite their pivot-column tile) while wavefront 0 updates
     // the NEXT pivot tile first and factors it, so that the serial DPP factorisation overlaps the MFMA
     // work.  The owner of row k+1 must not overwrite tile (k+1,k) before wavefront 0 has read it: an
     // LDS flag carries that one dependency (LDS operations of a wavefront execute in order).
-    if constexpr (W == 0) factor_pivot_tile(M, LDM, ubuf, LDU, ubuf + 16 * LDU, r16, kq, pmin, ldM, ldE);
+    // (the first pivot tile of this step was factored during the previous step's reload phase)
     TICK(1)
     static_for<0, NB>([&](auto kc) {
       constexpr int k = kc;
@@ -309,14 +301,29 @@ __global__ __launch_bounds__(256, 2) void lds_estep_tile_kernel(const LdsArgs a,
       }
       __syncthreads();
       TICK(3)
-      if constexpr (k == NB - 1) { if (!last) load_operands(packed + (long)(INHOMOG ? t : (next_last ? 1 : 0)) * (3 * NP * NP)); }
-      if constexpr (W == 0) {
-        {  // A[k][k] <- A_kk^-1 = U' D^-1 U
-          d4 v = frag_b(U, LDU, 0, 0, r16, kq);
+      if constexpr (k == NB - 1) {
+        // operands of the Schur stage / next right-hand side / next node potentials: requested now,
+        // used after the hand-off (unconditional, clamped addresses: a load under a branch is waited
+        // for at the join)
+        if (!last) load_operands(packed + (long)(INHOMOG ? t : (next_last ? 1 : 0)) * (3 * NP * NP));
+        const long tn = (long)(last ? t : t + 1) * n;
+        njn = nodeJ[tn + (tid < n ? tid : n - 1)];
+        if constexpr (schur_on && (NB - sj0) % WPR == 0) {
 #pragma unroll
-          for (int qq = 0; qq < 4; ++qq) v[qq] *= dinv[4 * qq + kq];
-          store_c(M, LDM, 16 * k, 16 * k, r16, kq, mma16(frag_b(U, LDU, 0, 0, r16, kq), v, d4{0.0, 0.0, 0.0, 0.0}));
+          for (int qq = 0; qq < 4; ++qq) {
+            const int row = 16 * si + 4 * qq + kq;
+            nhn[qq] = nodeh[tn + (row < n ? row : n - 1)];
+          }
         }
+      }
+      auto inverse_tile = [&]() {   // A[k][k] <- A_kk^-1 = U' D^-1 U
+        d4 v = frag_b(U, LDU, 0, 0, r16, kq);
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) v[qq] *= dinv[4 * qq + kq];
+        store_c(M, LDM, 16 * k, 16 * k, r16, kq, mma16(frag_b(U, LDU, 0, 0, r16, kq), v, d4{0.0, 0.0, 0.0, 0.0}));
+      };
+      if constexpr (W == 0) {
+        if constexpr (k + 1 == NB) inverse_tile();      // (else: done by the owner of row k+1, one task short)
         if constexpr (k + 1 < NB) {
           const d4 fa = frag_a(M, LDM, 16 * (k + 1), 16 * k, r16, kq);
           const d4 c = mma16(-fa, ld_b(16 * k, k + 1), ld_b(16 * (k + 1), k + 1));
@@ -353,6 +360,7 @@ __global__ __launch_bounds__(256, 2) void lds_estep_tile_kernel(const LdsArgs a,
           }
           double* p = M + (16 * i + r16) * LDM + 16 * k + kq;
           p[0] = -rt[0]; p[4] = -rt[1]; p[8] = -rt[2]; p[12] = -rt[3];
+          if constexpr (i == k + 1) inverse_tile();
         });
       }
       TICK(4)
@@ -362,10 +370,10 @@ __global__ __launch_bounds__(256, 2) void lds_estep_tile_kernel(const LdsArgs a,
 
     // ---- hand-off to the backward half: X, P^-1 (row-major NP x NP), c --------------------------
     double* w = wsb + (long)t * WSTEP;
-    for (int idx = tid; idx < NP * NP; idx += 256) {
-      const int row = idx / NP, col = idx % NP;
-      w[idx] = M[row * LDM + NP + col];
-      w[NP * NP + idx] = M[row * LDM + col];
+    for (int c4 = tid; c4 * 4 < NP * NP; c4 += 256) {
+      const int row = (c4 * 4) / NP, col = (c4 * 4) % NP;
+      *(d4*)(w + c4 * 4) = *(const d4*)(M + row * LDM + NP + col);
+      *(d4*)(w + NP * NP + c4 * 4) = *(const d4*)(M + row * LDM + col);
     }
     if (tid < NP) {
       const double cv = M[tid * LDM + 2 * NP];
@@ -413,17 +421,23 @@ __global__ __launch_bounds__(256, 2) void lds_estep_tile_kernel(const LdsArgs a,
       }
       __syncthreads();
       TICK(7)
-      // ---- next step's right-hand sides ------------------------------------------------------------
-#pragma unroll
-      for (int u = 0; u < RL4; ++u) {
-        const int c4 = tid + 256 * u;
-        if (c4 * 4 < NP * NP) *(d4*)(M + ((c4 * 4) / NP) * LDM + NP + ((c4 * 4) % NP)) = rl[u];
-      }
-      if (tid < NP) {
-        const double hv = mv0[tid];
-        hvec[tid] = hv;
-        M[tid * LDM + 2 * NP] = hv;
+      // ---- next step: wavefront 0 adds the node diagonal and factors the first pivot tile while
+      //      wavefronts 1..3 write the right-hand sides -------------------------------------------------
+      if constexpr (W == 0) {
         if (tid < n) M[tid * LDM + tid] -= 2.0 * njn;
+        factor_pivot_tile(M, LDM, ubuf, LDU, ubuf + 16 * LDU, r16, kq, pmin, ldM, ldE);
+      } else {
+        const int t3 = tid - 64;
+#pragma unroll
+        for (int u = 0; u < RL4; ++u) {
+          const int c4 = t3 + 192 * u;
+          if (c4 * 4 < NP * NP) *(d4*)(M + ((c4 * 4) / NP) * LDM + NP + ((c4 * 4) % NP)) = rl[u];
+        }
+        if (t3 < NP) {
+          const double hv = mv0[t3];
+          hvec[t3] = hv;
+          M[t3 * LDM + 2 * NP] = hv;
+        }
       }
       __syncthreads();
       TICK(8)
@@ -602,7 +616,7 @@ __global__ __launch_bounds__(256, 2) void lds_estep_tile_kernel(const LdsArgs a,
     TICK(9)
   }
 #ifdef SVAE_TILE_TIMING
-  if (tid == 0) { for (int q = 0; q < 12; ++q) a.E_init[(long)b * (nn + n) + q] = (double)tm[q]; }
+  if (lane == 0 && wave < 2) { for (int q = 0; q < 12; ++q) a.E_init[(long)b * (nn + n) + 12 * wave + q] = (double)tm[q]; }
   return;
 #endif
   if (tid < n) {                          // node statistics of step 0, E[x_0]

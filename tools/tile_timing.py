@@ -14,8 +14,10 @@ args = [t(init[0]), t(init[1]), t(init[2]).reshape(1), t(pair[0]), t(pair[1]), t
 for _ in range(2):
     plan.launch(*args)
 torch.cuda.synchronize()
-tm = plan.E_init[:, :12].cpu().numpy().mean(0) / T
-names = ["misc", "factor|deferred", "wait factor", "pivot row", "eliminate", "hand-off", "schur", "reload", "B load", "B compute", "B accumulate", "B emit"]
-print("n=%d T=%d B=%d  cycles/step (wave 0, mean over sequences); total %.0f" % (n, T, B, tm.sum()))
-for nm, v in zip(names, tm):
-    print("  %-16s %8.0f  %5.1f%%" % (nm, v, 100 * v / tm.sum()))
+tm = plan.E_init[:, :24].cpu().numpy().mean(0).reshape(2, 12) / T
+names = ["step start", "first factor (w0)", "barrier before P1", "P1 pivot row + barrier", "P2 (w0: look-ahead+factor; w1: row)",
+         "barrier after GJ", "hand-off + barrier", "schur + barrier", "reload + barrier",
+         "B2 sigma/stats + barrier", "B0 stage + emit", "B1 W, matvec + barrier"]
+print("n=%d T=%d B=%d  cycles/step (mean over sequences); totals: wave0 %.0f  wave1 %.0f" % (n, T, B, tm[0].sum(), tm[1].sum()))
+for i, nm in enumerate(names):
+    print("  %-40s w0 %8.0f   w1 %8.0f" % (nm, tm[0, i], tm[1, i]))
