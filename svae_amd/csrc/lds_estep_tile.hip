@@ -43,6 +43,16 @@ __device__ __forceinline__ d4 mma16(const d4 a, const d4 b, d4 c) {
   return c;
 }
 
+// Two independent products sharing the A fragment, MFMAs interleaved (the second chain fills the
+// result latency of the first).
+__device__ __forceinline__ void mma16x2(const d4 a, const d4 b0, d4& c0, const d4 b1, d4& c1) {
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kb], b0[kb], c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kb], b1[kb], c1, 0, 0, 0);
+  }
+}
+
 // Fragment addressing (lane = 16 kq + r16).  For a row-major tile Tl at (row0, col0):
 //   frag_a: A operand of Tl   (lane holds Tl[r16][4 kb + kq])   == B operand of Tl'
 //   frag_b: B operand of Tl   (lane holds Tl[4 kb + kq][r16])   == A operand of Tl'  == C/D layout
@@ -205,7 +215,6 @@ __global__ __launch_bounds__(256, 2) void lds_estep_tile_kernel(const LdsArgs a,
   // sj0, sj0 + WPR, ... <= NB (column NB is the h column)
   constexpr int WPR = NB <= 2 ? 4 / NB : 1;
   constexpr int SCOLS = (NB + 1 + WPR - 1) / WPR;
-  constexpr int RL = (NP * NP + 255) / 256;      // doubles per thread of an NP x NP copy
   constexpr int RL4 = (NP * NP / 4 + 191) / 192; // 4-double chunks per thread of an NP x NP copy by 3 wavefronts
   int* flag = (int*)(ubuf + 2 * UBUF);           // look-ahead hand-shake (see below)
   if (tid == 0) *flag = 0;
@@ -285,18 +294,24 @@ __global__ __launch_bounds__(256, 2) void lds_estep_tile_kernel(const LdsArgs a,
       const int gen = t * NB + k + 1;
       __syncthreads();
       TICK(2)
-      {  // (P1) pivot row:  A[k][j] <- A_kk^-1 A[k][j]   (j != k)
+      {  // (P1) pivot row:  A[k][j] <- A_kk^-1 A[k][j] = U' D^-1 (U A[k][j])   (j != k), two tiles at a time
         constexpr int NT1 = (2 * NB + 3) / 4;
-        d4 fb[NT1];
+        static_assert(NT1 <= 2, "at most two pivot-row tiles per wavefront");
+        const int q0 = W, q1 = W + 4;
+        const int j0 = q0 + (q0 >= k ? 1 : 0), j1 = q1 + (q1 >= k ? 1 : 0);
+        const d4 z4 = {0.0, 0.0, 0.0, 0.0};
+        if (q1 < 2 * NB) {
+          const d4 fu = frag_a(U, LDU, 0, 0, r16, kq), fut = frag_b(U, LDU, 0, 0, r16, kq);
+          d4 v0 = z4, v1 = z4;
+          mma16x2(fu, ld_b(16 * k, j0), v0, ld_b(16 * k, j1), v1);
 #pragma unroll
-        for (int s2 = 0; s2 < NT1; ++s2) {
-          const int q = W + 4 * s2;
-          if (q < 2 * NB) fb[s2] = ld_b(16 * k, q + (q >= k ? 1 : 0));
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < NT1; ++s2) {
-          const int q = W + 4 * s2;
-          if (q < 2 * NB) st_c(16 * k, q + (q >= k ? 1 : 0), apply_pivot(U, dinv, fb[s2]));
+          for (int qq = 0; qq < 4; ++qq) { const double dq = dinv[4 * qq + kq]; v0[qq] *= dq; v1[qq] *= dq; }
+          d4 t0 = z4, t1 = z4;
+          mma16x2(fut, v0, t0, v1, t1);
+          st_c(16 * k, j0, t0);
+          st_c(16 * k, j1, t1);
+        } else if (q0 < 2 * NB) {
+          st_c(16 * k, j0, apply_pivot(U, dinv, ld_b(16 * k, j0)));
         }
       }
       __syncthreads();
@@ -342,16 +357,20 @@ __global__ __launch_bounds__(256, 2) void lds_estep_tile_kernel(const LdsArgs a,
           const d4 fa = frag_a(M, LDM, 16 * i, 16 * k, r16, kq);
           const d4 nfa = -fa;
           auto jmap = [&](int jq) { return jq + (jq >= k ? skipn : 0); };
-          d4 cc = ld_b(16 * i, jmap(0)), bb = ld_b(16 * k, jmap(0));
+          // software pipeline over the row's tiles: fragments of tile q+1 are requested, tile q runs on
+          // the MFMA pipe, tile q-1 is stored -- a store issued right behind its own MFMAs would stall
+          // the wavefront for the result latency with the pipe idle
+          d4 cq = ld_b(16 * i, jmap(0)), bq = ld_b(16 * k, jmap(0));
+          d4 rprev = cq;
 #pragma unroll
-          for (int jq = 0; jq < 2 * NB; ++jq) {
-            if (jq < cnt) {
-              d4 cn = cc, bn = bb;
-              if (jq + 1 < cnt) { cn = ld_b(16 * i, jmap(jq + 1)); bn = ld_b(16 * k, jmap(jq + 1)); }
-              st_c(16 * i, jmap(jq), mma16(nfa, bb, cc));
-              cc = cn; bb = bn;
-            }
+          for (int q = 0; q < cnt; ++q) {
+            d4 cn = cq, bn = bq;
+            if (q + 1 < cnt) { cn = ld_b(16 * i, jmap(q + 1)); bn = ld_b(16 * k, jmap(q + 1)); }
+            const d4 rq = mma16(nfa, bq, cq);
+            if (q > 0) st_c(16 * i, jmap(q - 1), rprev);
+            rprev = rq; cq = cn; bq = bn;
           }
+          st_c(16 * i, jmap(cnt - 1), rprev);
           // pivot-column tile:  A[i][k] <- -A[i][k] A_kk^-1, computed transposed as A_kk^-1 A[i][k]'
           const d4 rt = apply_pivot(U, dinv, fa);
           if constexpr (i == k + 1) {
@@ -495,28 +514,36 @@ __global__ __launch_bounds__(256, 2) void lds_estep_tile_kernel(const LdsArgs a,
   d4 cross[NB], sxx[NB], prevE[NB];
 #pragma unroll
   for (int i = 0; i < NB; ++i) { cross[i] = d4{0.0, 0.0, 0.0, 0.0}; sxx[i] = cross[i]; prevE[i] = cross[i]; }
-  const int j = wave;                       // this wavefront's tile column (waves >= NB only help copy)
-  const int mycol = 16 * j + r16;
   double* oEx = a.E_node_x + (long)b * T * n;
   double* oExx = a.E_node_diagxx + (long)b * T * n;
   double* oI = a.E_init + (long)b * (nn + n);
   double* oPh = a.E_pair + (long)b * 3 * nn;            // homogeneous: the three sums
-  double xr[RL], cpre = 0.0;
-  {
-    const double* w = wsb + (long)(T - 1) * WSTEP;
+  constexpr int RL4B = (NP * NP / 4 + 255) / 256;     // 4-double chunks per thread of an NP x NP copy
+  d4 xr[RL4B];
+  double cpre = 0.0;
+  auto prefetch_step = [&](const double* w) {       // X_t (row-major NP x NP) and c_t of one step
 #pragma unroll
-    for (int u = 0; u < RL; ++u) { const int idx = tid + 256 * u; xr[u] = idx < NP * NP ? w[idx] : 0.0; }
-    if (tid < NP) cpre = w[2 * NP * NP + tid];
-  }
+    for (int u = 0; u < RL4B; ++u) {
+      const int c4 = tid + 256 * u;
+      xr[u] = d4{0.0, 0.0, 0.0, 0.0};
+      if (c4 * 4 < NP * NP) xr[u] = *(const d4*)(w + c4 * 4);
+    }
+    cpre = w[2 * NP * NP + (tid < NP ? tid : 0)];
+  };
+  prefetch_step(wsb + (long)(T - 1) * WSTEP);
   __syncthreads();
 
+  // Like the forward half, instantiated per wavefront index (= tile column J of the wavefront).
+  auto backward = [&](auto jc) {
+  constexpr int J = decltype(jc)::value;
+  const int mycol = 16 * J + r16;
   for (int t = T - 1; t >= 0; --t) {
     TICK(9)
     const double* w = wsb + (long)t * WSTEP;
 #pragma unroll
-    for (int u = 0; u < RL; ++u) {
-      const int idx = tid + 256 * u;
-      if (idx < NP * NP) M[(idx / NP) * LDM + NP + (idx % NP)] = xr[u];
+    for (int u = 0; u < RL4B; ++u) {
+      const int c4 = tid + 256 * u;
+      if (c4 * 4 < NP * NP) *(d4*)(M + ((c4 * 4) / NP) * LDM + NP + ((c4 * 4) % NP)) = xr[u];
     }
     if (tid < NP) hvec[tid] = cpre;
     __syncthreads();
@@ -526,7 +553,7 @@ __global__ __launch_bounds__(256, 2) void lds_estep_tile_kernel(const LdsArgs a,
       oExx[(long)(t + 1) * n + tid] = __builtin_fma(mm, mm, M[tid * LDM + tid]);
     }
     d4 pin[NB];                          // P_t^-1 tiles (i, j): consumed in B2
-    if (j < NB) {
+    if constexpr (J < NB) {
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         const double* pi = w + NP * NP + (16 * i + kq) * NP + mycol;
@@ -546,10 +573,10 @@ __global__ __launch_bounds__(256, 2) void lds_estep_tile_kernel(const LdsArgs a,
       if (row < NP && part == 0) mnew[row] = hvec[row] + s;
     }
     d4 Wt[NB];
-    if (j < NB) {
+    if constexpr (J < NB) {
       d4 Bx[NB];
 #pragma unroll
-      for (int l = 0; l < NB; ++l) Bx[l] = frag_a(M, LDM, 16 * j, NP + 16 * l, r16, kq);   // (X_{jl})' as B
+      for (int l = 0; l < NB; ++l) Bx[l] = frag_a(M, LDM, 16 * J, NP + 16 * l, r16, kq);   // (X_{jl})' as B
 #pragma unroll
       for (int kk = 0; kk < NB; ++kk) {
         d4 c = {0.0, 0.0, 0.0, 0.0};
@@ -561,21 +588,24 @@ __global__ __launch_bounds__(256, 2) void lds_estep_tile_kernel(const LdsArgs a,
     __syncthreads();
     TICK(11)
 
-    if (t > 0) {                         // prefetch step t-1 (in flight during B2)
-      const double* wn = w - WSTEP;
-#pragma unroll
-      for (int u = 0; u < RL; ++u) { const int idx = tid + 256 * u; xr[u] = idx < NP * NP ? wn[idx] : 0.0; }
-      if (tid < NP) cpre = wn[2 * NP * NP + tid];
-    }
-    if (j < NB) {
+    prefetch_step(t > 0 ? w - WSTEP : w);        // step t-1, in flight during B2
+    if constexpr (J < NB) {
       const double mc = mnew[mycol];
       double* oP = INHOMOG && t < T - 1 ? a.E_pair + ((long)b * (T - 1) + t) * 3 * nn : nullptr;
+      d4 fx[NB];                           // A fragments of X tile row i, fetched one row ahead
+#pragma unroll
+      for (int kk = 0; kk < NB; ++kk) fx[kk] = frag_a(M, LDM, 0, NP + 16 * kk, r16, kq);
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
+        d4 fn[NB];
+#pragma unroll
+        for (int kk = 0; kk < NB; ++kk) fn[kk] = (i + 1 < NB) ? frag_a(M, LDM, 16 * (i + 1), NP + 16 * kk, r16, kq) : fx[kk];
         d4 c = pin[i];
 #pragma unroll
-        for (int kk = 0; kk < NB; ++kk) c = mma16(frag_a(M, LDM, 16 * i, NP + 16 * kk, r16, kq), Wt[kk], c);
-        store_c(M, LDM, 16 * i, 16 * j, r16, kq, c);          // Sigma_t tile (i, j)
+        for (int kk = 0; kk < NB; ++kk) c = mma16(fx[kk], Wt[kk], c);
+#pragma unroll
+        for (int kk = 0; kk < NB; ++kk) fx[kk] = fn[kk];
+        store_c(M, LDM, 16 * i, 16 * J, r16, kq, c);          // Sigma_t tile (i, j)
         d4 exx, ecr;
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
@@ -614,6 +644,13 @@ __global__ __launch_bounds__(256, 2) void lds_estep_tile_kernel(const LdsArgs a,
     double* tmp = mold; mold = mnew; mnew = tmp;
     __syncthreads();
     TICK(9)
+  }
+  };
+  switch (wave) {
+    case 0: backward(std::integral_constant<int, 0>{}); break;
+    case 1: backward(std::integral_constant<int, 1>{}); break;
+    case 2: backward(std::integral_constant<int, 2>{}); break;
+    default: backward(std::integral_constant<int, 3>{}); break;
   }
 #ifdef SVAE_TILE_TIMING
   if (lane == 0 && wave < 2) { for (int q = 0; q < 12; ++q) a.E_init[(long)b * (nn + n) + 12 * wave + q] = (double)tm[q]; }
