@@ -130,6 +130,24 @@ int svae_lds_estep_vjp_f64(int B, int T, int n, int S, const double* J12,
                            const void* workspace, size_t ws_bytes,
                            void* vjp_workspace, size_t vjp_ws_bytes, void* stream);
 
+/* The same with per-step pair parameters and cotangents of the remaining statistics -- what the
+ * SLDS-SVAE differentiates (/root/reference/svae/models/slds_svae.py:295-300: lds_stats feed
+ * get_hmm_vlb; _compute_stats_grad /root/reference/svae/lds/cython_lds_inference.pyx:212-234):
+ *   inhomog / pair_batched: J12 is (T-1,n,n) / (B,T-1,n,n) as in svae_lds_estep_f64
+ *   g_E_init (B, n*n+n) or NULL: cotangent of [E[x0 x0'] | E[x0]]
+ *   g_E_pair (B,T-1,3,n,n) or NULL (inhomog only): cotangent of the per-step pair statistics; needs
+ *     the forward outputs E_pair (B,T-1,3,n,n) and E_node_x (B,T,n) of the E-step call
+ * All other arguments as svae_lds_estep_vjp_f64 (which is this with inhomog = 0 and NULLs). */
+int svae_lds_estep_vjp_ex_f64(int B, int T, int n, int S, int inhomog, int pair_batched,
+                              const double* J12, const double* g_lognorm,
+                              const double* g_E_node_diagxx, const double* g_E_node_x,
+                              const double* g_E_init, const double* g_E_pair,
+                              const double* g_samples, const double* eps, const double* samples,
+                              const double* E_pair, const double* E_node_x,
+                              double* g_node_J, double* g_node_h,
+                              const void* workspace, size_t ws_bytes,
+                              void* vjp_workspace, size_t vjp_ws_bytes, void* stream);
+
 /* Batched HMM E-step: log-normaliser and expected statistics of B chains with K <= 16 states
  * [hmm_logZ  /root/reference/svae/hmm/cython_hmm_inference.pyx:93-121 and hmm_logZ_grad :126-166 at
  *  g = 1, i.e. `hmm_estep_slow = vgrad(hmm_logZ)` /root/reference/svae/hmm/hmm_inference.py:65; the

@@ -82,14 +82,16 @@ def sample_backward(natparam, node_params, num_samples, seed):
     return np.asarray(samples), eps
 
 
-def estep_vjp(natparam, node_params, g_lognorm, g_E_node, g_samples=None, seed=0):
+def estep_vjp(natparam, node_params, g_lognorm, g_E_node, g_samples=None, seed=0, g_E_init=None,
+              g_E_pair=None):
     """Composite reverse-mode derivative w.r.t. node_params, wired exactly as the reference wires its
     autograd primitives (svae/lds/lds_inference.py:26-39):
         natural_filter_grad            cython_lds_inference.pyx:92-145   (argnum 2 = node_params)
         natural_smoother_general_grad  cython_lds_inference.pyx:236-306  (argnum 0 = messages)
         natural_sample_backward_grad   cython_lds_inference.pyx:357-409  (argnum 0 = messages)
-    g_E_node = (g_diagExxT (T,n), g_Ex (T,n)); cotangents of E_init / E_pair are zero (the model code
-    never differentiates the global statistics: svae.py:21 stores them in `saved.stats`).
+    g_E_node = (g_diagExxT (T,n), g_Ex (T,n)); g_E_init = (g_ExxT0 (n,n), g_Ex0 (n)) and g_E_pair =
+    (g0, g1, g2), each (n,n) or per step (T-1,n,n), default to zero (the LDS model code never
+    differentiates them: svae.py:21 stores them in `saved.stats`; the SLDS does, slds_svae.py:300).
     Returns (g_node_J, g_node_h, g_node_logZ) and, if sampling, the eps used (re-indexed by time)."""
     import numpy as np
     m = _load("cython_lds_inference")
@@ -98,8 +100,11 @@ def estep_vjp(natparam, node_params, g_lognorm, g_E_node, g_samples=None, seed=0
     (messages, lognorm), aux_f = m.natural_filter_forward_general(init_params, pair_params, node_params)
     T, n = np.asarray(node_params[1]).shape
     (E_init, E_pair, E_node), aux_s = m.natural_smoother_general(messages, pair_params)
-    g_stats = ((np.zeros((n, n)), np.zeros(n), 0., 0.),
-               (np.zeros((n, n)), np.zeros((n, n)), np.zeros((n, n)), 0.),
+    cp = lambda x: np.array(x, dtype=float, copy=True)
+    gi = (np.zeros((n, n)), np.zeros(n)) if g_E_init is None else (cp(g_E_init[0]), cp(g_E_init[1]))
+    gp = (np.zeros((n, n)),) * 3 if g_E_pair is None else tuple(cp(x) for x in g_E_pair[:3])
+    g_stats = ((gi[0], gi[1], 0., 0.),
+               (cp(gp[0]), cp(gp[1]), cp(gp[2]), 0.),
                (np.array(g_E_node[0], dtype=float, copy=True), np.array(g_E_node[1], dtype=float, copy=True),
                 np.zeros(T)))   # copies: _compute_stats_grad (:212-234) accumulates into its inputs
     (gJp, ghp), (gJf, ghf) = m.natural_smoother_general_grad(g_stats, aux_s)

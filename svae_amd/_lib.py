@@ -33,6 +33,9 @@ SIGNATURES = {
     "svae_lds_estep_vjp_f64": (ctypes.c_int, [ctypes.c_int] * 4 + [_c_double_p] * 9
                                + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
                                   ctypes.c_void_p]),
+    "svae_lds_estep_vjp_ex_f64": (ctypes.c_int, [ctypes.c_int] * 6 + [_c_double_p] * 13
+                                  + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
+                                     ctypes.c_void_p]),
     "svae_lds_sample_f64": (ctypes.c_int, [ctypes.c_int] * 4 + [_c_double_p] * 2
                             + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "svae_hmm_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),

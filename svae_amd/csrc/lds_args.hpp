@@ -53,7 +53,13 @@ struct SampleArgs {
 // reverse-mode sweeps (lds_vjp_kernel.hpp)
 struct VjpArgs {
   int B, T, S;
-  const double* __restrict__ J12;        // (n,n) natural pair parameter (homogeneous)
+  const double* __restrict__ J12;        // natural pair parameter: (n,n), (T-1,n,n) or (B,T-1,n,n)
+  long pair_t_stride;                    // doubles between consecutive steps' J12 (0 = homogeneous)
+  long pair_seq_stride;                  // doubles between consecutive sequences' J12 blocks (0 = shared)
+  const double* __restrict__ g_E_init;   // (B, n*n+n) cotangent of (E[x_0 x_0'], E[x_0]) or nullptr
+  const double* __restrict__ g_E_pair;   // (B,T-1,3,n,n) cotangent of the per-step pair statistics or nullptr
+  const double* __restrict__ E_pair;     // (B,T-1,3,n,n) forward output (with g_E_pair: supplies S~_{t+1})
+  const double* __restrict__ E_node_x;   // (B,T,n)       forward output (with g_E_pair)
   const double* __restrict__ g_lognorm;  // (B)
   const double* __restrict__ g_diagxx;   // (B,T,n) or nullptr
   const double* __restrict__ g_x;        // (B,T,n) or nullptr

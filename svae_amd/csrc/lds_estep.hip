@@ -227,19 +227,23 @@ extern "C" size_t svae_lds_vjp_workspace_bytes(int B, int T, int n) {
   return (size_t)B * T * svae::vjp_step_doubles(n) * sizeof(double);
 }
 
-extern "C" int svae_lds_estep_vjp_f64(int B, int T, int n, int S, const double* J12,
-                                      const double* g_lognorm, const double* g_E_node_diagxx,
-                                      const double* g_E_node_x, const double* g_samples,
-                                      const double* eps, const double* samples,
-                                      double* g_node_J, double* g_node_h,
-                                      const void* workspace, size_t ws_bytes,
-                                      void* vjp_workspace, size_t vjp_ws_bytes, void* stream) {
+extern "C" int svae_lds_estep_vjp_ex_f64(int B, int T, int n, int S, int inhomog, int pair_batched,
+                                         const double* J12, const double* g_lognorm,
+                                         const double* g_E_node_diagxx, const double* g_E_node_x,
+                                         const double* g_E_init, const double* g_E_pair,
+                                         const double* g_samples, const double* eps,
+                                         const double* samples, const double* E_pair,
+                                         const double* E_node_x, double* g_node_J, double* g_node_h,
+                                         const void* workspace, size_t ws_bytes,
+                                         void* vjp_workspace, size_t vjp_ws_bytes, void* stream) {
   if (B < 0) return -1;
   if (T < 1) return -2;
   if (n < 1 || n > SVAE_LDS_MAX_N) return -3;
   if (g_samples && (S < 1 || S > 16)) return -4;
   if (T > 1 && !J12) return -5;
   if (!g_lognorm) return -6;
+  if (pair_batched && !inhomog) return -7;
+  if (g_E_pair && (!inhomog || !E_pair || !E_node_x)) return -8;   /* per-step statistics only */
   if (g_samples && (!eps || !samples)) return -10;
   if (!g_node_J) return -12;
   if (!g_node_h) return -13;
@@ -249,6 +253,9 @@ extern "C" int svae_lds_estep_vjp_f64(int B, int T, int n, int S, const double* 
   svae::VjpArgs a;
   a.B = B; a.T = T; a.S = g_samples ? S : 0;
   a.J12 = J12; a.g_lognorm = g_lognorm; a.g_diagxx = g_E_node_diagxx; a.g_x = g_E_node_x;
+  a.pair_t_stride = inhomog ? (long)n * n : 0;
+  a.pair_seq_stride = pair_batched ? (long)(T - 1) * n * n : 0;
+  a.g_E_init = g_E_init; a.g_E_pair = g_E_pair; a.E_pair = E_pair; a.E_node_x = E_node_x;
   a.g_samples = g_samples; a.eps = eps; a.samples = samples;
   a.g_node_J = g_node_J; a.g_node_h = g_node_h;
   a.ws = (const double*)workspace;
@@ -269,4 +276,18 @@ extern "C" int svae_lds_estep_vjp_f64(int B, int T, int n, int S, const double* 
 #undef SVAE_CASE_
   }
   return -3;
+}
+
+extern "C" int svae_lds_estep_vjp_f64(int B, int T, int n, int S, const double* J12,
+                                      const double* g_lognorm, const double* g_E_node_diagxx,
+                                      const double* g_E_node_x, const double* g_samples,
+                                      const double* eps, const double* samples,
+                                      double* g_node_J, double* g_node_h,
+                                      const void* workspace, size_t ws_bytes,
+                                      void* vjp_workspace, size_t vjp_ws_bytes, void* stream) {
+  const int rc = svae_lds_estep_vjp_ex_f64(B, T, n, S, 0, 0, J12, g_lognorm, g_E_node_diagxx, g_E_node_x,
+                                           nullptr, nullptr, g_samples, eps, samples, nullptr, nullptr,
+                                           g_node_J, g_node_h, workspace, ws_bytes, vjp_workspace,
+                                           vjp_ws_bytes, stream);
+  return rc == -12 ? -12 : rc;
 }

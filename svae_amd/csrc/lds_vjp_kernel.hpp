@@ -16,6 +16,10 @@
 //     Pinvbar_t = S^[:n,:n];               S^ <- G~' S^ G~
 //     xhat_t = g_x_t - X_{t-1}' xhat_{t-1}; cbar_t += sum_s xhat; Xbar_t -= sum_s xhat x_{t+1}'
 //     Pbar_t(direct) = -U Lh U',  U = chol(P)^-T,  Lh = lower-half(sum_s eps_s (U' xhat_s)')
+//     statistics cotangents (SLDS: hmm_vlb depends on E_init and on the per-step E_pair,
+//     svae/models/slds_svae.py:131-155,300):  Q_t = d/dE[x_t x_t'] goes into S^[:n,:n] symmetrised;
+//     Cb_t = d/dE[x_t x_{t+1}'] acts through W~_t = S~_{t+1} G~':  G^[:n] += Cb_t S~_{t+1}[:n],
+//     S^_{t+1} += sym([Cb_t' 0; 0 0] G~)   (S~_{t+1} is read back from the forward outputs)
 //   sweep 2, t = T-1 .. 0 (reverse of the filter recursion):
 //     [Xbar | cbar]_t -= J12 [Abar | hbar]_{t+1}
 //     Bbar = P^-1 [Xbar | cbar];   hfbar = Bbar[:,n] + g c
@@ -57,7 +61,7 @@ __device__ __forceinline__ void transpose_tile(double* tab, int c, const double 
 }
 
 // ---- sweep 1: smoother + sampler adjoints, forward in time ----------------------------------------
-template <int N, bool SAMP>
+template <int N, bool SAMP, bool STATC>
 __global__ __launch_bounds__(64) void lds_vjp_sweep1_kernel(const VjpArgs a) {
   constexpr int HS = ws_h_stride(N), PS = ws_p_stride(N), WS = ws_step_doubles(N);
   constexpr int AS = vjp_step_doubles(N);
@@ -108,10 +112,64 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep1_kernel(const VjpArgs a) {
       Sh[i] = __builtin_fma(gd, E[i], Sh[i]);
     });
 
+    double Cb[STATC ? N : 1], CbT[STATC ? N : 1];
+    bool cross = false;
+    if constexpr (STATC) {
+      // n x n cotangent of E[x_t x_t'] (first statistic of pair t, third of pair t-1, E_init at t = 0)
+      const long nn = (long)N * N;
+      const int cc = col ? c : 0;
+      static_for<0, N>([&](auto i) {
+        double q = 0.0;
+        if (a.g_E_pair && t < T - 1) {
+          const double* gp = a.g_E_pair + ((long)b * (T - 1) + t) * 3 * nn;
+          q += gp[i * N + cc] + gp[cc * N + i];
+        }
+        if (a.g_E_pair && t > 0) {
+          const double* gp = a.g_E_pair + ((long)b * (T - 1) + t - 1) * 3 * nn + 2 * nn;
+          q += gp[i * N + cc] + gp[cc * N + i];
+        }
+        if (a.g_E_init && t == 0) {
+          const double* gi = a.g_E_init + (long)b * (nn + N);
+          q += gi[i * N + cc] + gi[cc * N + i];
+        }
+        Sh[i] = __builtin_fma(0.5, col ? q : 0.0, Sh[i]);
+      });
+      if (a.g_E_init && t == 0) {
+        const double qx = col ? 0.5 * a.g_E_init[(long)b * (nn + N) + nn + c] : 0.0;
+        Sh[N] += qx;
+        static_for<0, N>([&](auto i) { mac_bc<i>(Sh[i], qx, EN); });
+      }
+      cross = a.g_E_pair && t < T - 1;
+      static_for<0, N>([&](auto i) { Cb[i] = 0.0; CbT[i] = 0.0; });
+      if (cross) {
+        const double* gc = a.g_E_pair + ((long)b * (T - 1) + t) * 3 * nn + nn;
+        static_for<0, N>([&](auto i) {
+          const double v = gc[i * N + cc], vt = gc[cc * N + i];
+          Cb[i] = col ? v : 0.0;                      // row i of Cb
+          CbT[i] = col ? vt : 0.0;                    // row i of Cb'
+        });
+      }
+    }
+
     // G^ rows i < N:  2 S^ W~'   (lanes 0..N)
     double Gb[N];
     static_for<0, N>([&](auto i) { Gb[i] = 0.0; });
     mm_ab<N, N + 1, false>(Gb, Sh, WT);
+    if constexpr (STATC) {
+      if (cross) {
+        // G^[i] += sum_k Cb[i][k] S~_{t+1}[k]:  S~_{t+1} rows from the forward outputs
+        const long nn = (long)N * N;
+        const double* e3 = a.E_pair + ((long)b * (T - 1) + t) * 3 * nn + 2 * nn;
+        const double* ex = a.E_node_x + ((long)b * T + t + 1) * N;
+        double Snx[N];
+        static_for<0, N>([&](auto k) {
+          const double v = e3[k * N + (col ? c : 0)], m = ex[k];
+          Snx[k] = col ? v : (c == N ? m : 0.0);
+        });
+        dpp_fence(Cb);
+        mm_ab<N, N, false>(Gb, Cb, Snx);
+      }
+    }
     if (valid && col) static_for<0, N>([&](auto i) { ad[N * HS + i * PS + c] = Sh[i]; });   // Pinvbar
 
     // S^ <- G~' (S^ G~)
@@ -121,6 +179,18 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep1_kernel(const VjpArgs a) {
       mm_ab<N + 1, N + 1, false>(M, Sh, Gc);
       mm_atb<N + 1, N + 1, false>(Sn, Gc, M);
       static_for<0, N + 1>([&](auto i) { Sh[i] = Sn[i]; });
+    }
+    if constexpr (STATC) {
+      if (cross) {                                  // S^_{t+1} += sym([Cb' 0; 0 0] G~)
+        double Mx[N], MxT[N + 1];
+        static_for<0, N>([&](auto i) { Mx[i] = 0.0; });
+        static_for<0, N + 1>([&](auto i) { MxT[i] = 0.0; });
+        dpp_fence(CbT);
+        mm_ab<N, N, false>(Mx, CbT, Gc);            // rows k < N of  Cb' G~[:n]
+        mm_atb<N + 1, N, false>(MxT, Gc, Cb);       // its transpose
+        static_for<0, N>([&](auto i) { Sh[i] = __builtin_fma(0.5, Mx[i], Sh[i]); });
+        static_for<0, N + 1>([&](auto i) { Sh[i] = __builtin_fma(0.5, MxT[i], Sh[i]); });
+      }
     }
 
     if constexpr (SAMP) {
@@ -194,7 +264,10 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep2_kernel(const VjpArgs a) {
   const double EN = (c == N) ? 1.0 : 0.0;
   const double sg = col ? -1.0 : (c == N ? 1.0 : 0.0);
   double J12c[N];                                             // info form: J12 = -natJ12
-  static_for<0, N>([&](auto i) { const double v = a.J12[i * N + (col ? c : 0)]; J12c[i] = col ? -v : 0.0; });
+  const double* pJ12 = a.J12 + (long)b * a.pair_seq_stride;
+  static_for<0, N>([&](auto i) { J12c[i] = 0.0; });
+  if (T > 1 && a.pair_t_stride == 0)
+    static_for<0, N>([&](auto i) { const double v = pJ12[i * N + (col ? c : 0)]; J12c[i] = col ? -v : 0.0; });
   const double g = a.g_lognorm[b];
 
   const double* wsb = a.ws + (long)b * ws_seq_doubles(N, T) + ws_zpage_doubles(N);
@@ -218,8 +291,15 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep2_kernel(const VjpArgs a) {
       load_row<N + 1>(w + (col ? c : 0) * HS, tmp);
       static_for<0, N + 1>([&](auto k) { HT[k] = col ? tmp[k] : 0.0; });    // H' (lane c: row c of H)
     }
-    // [Xbar | cbar] -= J12 [Abar | hbar]_{t+1}
-    if (t < T - 1) mm_ab<N, N, true>(Xc, J12c, Ab);
+    // [Xbar | cbar] -= J12_t [Abar | hbar]_{t+1}
+    if (t < T - 1) {
+      if (a.pair_t_stride != 0) {
+        const double* pj = pJ12 + (long)t * a.pair_t_stride;
+        static_for<0, N>([&](auto i) { const double v = pj[i * N + (col ? c : 0)]; J12c[i] = col ? -v : 0.0; });
+        dpp_fence(J12c);
+      }
+      mm_ab<N, N, true>(Xc, J12c, Ab);
+    }
     // Bbar = P^-1 [Xbar | cbar]
     double Bb[N], T1[N], Pb[N];
     static_for<0, N>([&](auto i) { Bb[i] = 0.0; T1[i] = 0.0; Pb[i] = 0.0; });
@@ -258,11 +338,14 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep2_kernel(const VjpArgs a) {
 template <int N>
 static int launch_vjp(const VjpArgs& a, hipStream_t stream) {
   dim3 grid((a.B + 3) / 4), block(64);
+  const bool statc = a.g_E_init || a.g_E_pair;
   if (a.g_samples) {
-    hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, true>), grid, block, 0, stream, a);
+    if (statc) hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, true, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, true, false>), grid, block, 0, stream, a);
     hipLaunchKernelGGL((lds_vjp_sweep2_kernel<N, true>), grid, block, 0, stream, a);
   } else {
-    hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, false>), grid, block, 0, stream, a);
+    if (statc) hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, false, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, false, false>), grid, block, 0, stream, a);
     hipLaunchKernelGGL((lds_vjp_sweep2_kernel<N, false>), grid, block, 0, stream, a);
   }
   return hipGetLastError() == hipSuccess ? 0 : -1000;

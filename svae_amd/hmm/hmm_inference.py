@@ -55,3 +55,26 @@ def hmm_estep(natparam, workspace=None):
 
 def hmm_logZ(natparam):
     return hmm_estep(natparam)[0]
+
+
+class _HMMLogZ(torch.autograd.Function):
+    """log Z of a batch of HMMs, differentiable w.r.t. the node log-potentials: the gradient is the
+    matrix of state marginals the same kernel launch returns (hmm_logZ_grad, cython_hmm_inference.pyx:
+    126-166, restricted to the node argument -- all the SLDS-SVAE differentiates, slds_svae.py:150-155)."""
+
+    @staticmethod
+    def forward(ctx, node_params, init_params, pair_params):
+        logZ, (_, _, E_states) = hmm_estep((init_params, pair_params, node_params))
+        ctx.save_for_backward(E_states)
+        return logZ
+
+    @staticmethod
+    def backward(ctx, g):
+        (E_states,) = ctx.saved_tensors
+        return g.reshape(g.shape + (1,) * (E_states.dim() - g.dim())) * E_states, None, None
+
+
+def hmm_logZ_differentiable(natparam):
+    """hmm_logZ with gradients flowing to node_params ((T,K) or (B,T,K))."""
+    init_params, pair_params, node_params = natparam
+    return _HMMLogZ.apply(node_params, init_params, pair_params)

@@ -83,6 +83,7 @@ class LDSEStepPlan(object):
         self.has_factor = bool(keep_factor)
         self.has_cross = bool(keep_cross)
         self._J12 = J12
+        self._pair_batched = bool(pair_batched)
 
     def sample(self, eps, out=None):
         """Backward sampling from the messages of the last `launch(..., keep_factor=True)`.
@@ -103,20 +104,23 @@ class LDSEStepPlan(object):
         return out
 
     def vjp(self, g_lognorm, g_E_node_diagxx=None, g_E_node_x=None, g_samples=None, eps=None,
-            samples=None):
+            samples=None, g_E_init=None, g_E_pair=None):
         """Vector-Jacobian product w.r.t. the node potentials of the last
         `launch(..., keep_factor=True, keep_cross=True)` [+ `sample`]: returns (g_node_J, g_node_h)
         (B,T,n) each; g_node_logZ[b,t] = g_lognorm[b].  Replaces the reference's natural_filter_grad /
         natural_smoother_general_grad / natural_sample_backward_grad
-        (cython_lds_inference.pyx:92-145, 236-306, 357-409)."""
+        (cython_lds_inference.pyx:92-145, 236-306, 357-409).  g_E_init (B, n*n+n) and, with per-step
+        pair parameters, g_E_pair (B,T-1,3,n,n) are the cotangents of the remaining statistics
+        (_compute_stats_grad, :212-234) -- what the SLDS-SVAE differentiates."""
         if not (getattr(self, "has_cross", False) and getattr(self, "has_factor", False)):
             raise RuntimeError("vjp() needs a preceding launch(..., keep_factor=True, keep_cross=True)")
-        if self.inhomog:
-            raise NotImplementedError("VJP for time-inhomogeneous pair parameters")
+        if g_E_pair is not None and not self.inhomog:
+            raise NotImplementedError("cotangents of the SUMMED pair statistics (homogeneous parameters)")
         f64 = dict(dtype=torch.float64, device=self.device)
         c = lambda x: None if x is None else x.to(**f64).contiguous()
         g_lognorm, g_E_node_diagxx, g_E_node_x = c(g_lognorm), c(g_E_node_diagxx), c(g_E_node_x)
         g_samples, eps, samples = c(g_samples), c(eps), c(samples)
+        g_E_init, g_E_pair = c(g_E_init), c(g_E_pair)
         S = 0 if g_samples is None else g_samples.shape[2]
         if not hasattr(self, "vjp_ws"):
             self.vjp_ws_bytes = int(self.lib.svae_lds_vjp_workspace_bytes(max(self.B, 1), self.T, self.n))
@@ -124,11 +128,12 @@ class LDSEStepPlan(object):
         gJ = torch.empty(self.B, self.T, self.n, **f64)
         gh = torch.empty(self.B, self.T, self.n, **f64)
         p = _lib.ptr
-        rc = self.lib.svae_lds_estep_vjp_f64(
-            self.B, self.T, self.n, S, p(self._J12), p(g_lognorm), p(g_E_node_diagxx), p(g_E_node_x),
-            p(g_samples), p(eps), p(samples), p(gJ), p(gh), p(self.ws), self.ws_bytes,
-            p(self.vjp_ws), self.vjp_ws_bytes, _lib.current_stream(self.device))
-        _lib.check(rc, "svae_lds_estep_vjp_f64")
+        rc = self.lib.svae_lds_estep_vjp_ex_f64(
+            self.B, self.T, self.n, S, int(self.inhomog), int(self._pair_batched),
+            p(self._J12), p(g_lognorm), p(g_E_node_diagxx), p(g_E_node_x), p(g_E_init), p(g_E_pair),
+            p(g_samples), p(eps), p(samples), p(self.E_pair), p(self.E_node_x), p(gJ), p(gh),
+            p(self.ws), self.ws_bytes, p(self.vjp_ws), self.vjp_ws_bytes, _lib.current_stream(self.device))
+        _lib.check(rc, "svae_lds_estep_vjp_ex_f64")
         return gJ, gh
 
     def reduce(self):
@@ -279,49 +284,59 @@ def reduce_stats(plan):
 class _LDSInference(torch.autograd.Function):
     """Differentiable (w.r.t. the node potentials) E-step + sampler, the torch counterpart of the
     reference's three autograd primitives (lds_inference.py:26-39).  Forward: one E-step launch
-    (+ sampler); backward: the two VJP sweeps.  The global statistics (E_init, E_pair) are returned
-    non-differentiable, as in the reference's use (svae.py:21 `saved.stats`)."""
+    (+ sampler); backward: the two VJP sweeps.  With homogeneous pair parameters the global
+    statistics (E_init, E_pair sums) are returned non-differentiable, as in the reference's use
+    (svae.py:21 `saved.stats`); with per-step pair parameters (the SLDS, slds_svae.py:295-300)
+    E_init and the per-step E_pair carry gradients too."""
 
     @staticmethod
-    def forward(ctx, node_J, node_h, node_logZ, eps, plan, params):
+    def forward(ctx, node_J, node_h, node_logZ, eps, plan, params, pair_batched):
         init_J, init_h, init_logZ, J11, J12, J22, logZ_pair = params
         plan.launch(init_J, init_h, init_logZ, J11, J12, J22, logZ_pair, node_J, node_h, node_logZ,
-                    False, True, True)
+                    pair_batched, True, True)
         samples = plan.sample(eps) if eps is not None else torch.zeros(0, dtype=torch.float64, device=plan.device)
         ctx.plan, ctx.has_logZ, ctx.has_samples = plan, node_logZ is not None, eps is not None
         ctx.save_for_backward(eps if eps is not None else samples, samples)
-        ctx.mark_non_differentiable(plan.E_init, plan.E_pair)
+        E_init, E_pair = plan.E_init.clone(), plan.E_pair.clone()
+        if not plan.inhomog:
+            ctx.mark_non_differentiable(E_init, E_pair)
         return (plan.lognorm.clone(), plan.E_node_diagxx.clone(), plan.E_node_x.clone(), samples,
-                plan.E_init, plan.E_pair)
+                E_init, E_pair)
 
     @staticmethod
-    def backward(ctx, g_lognorm, g_dxx, g_x, g_samples, _gi, _gp):
+    def backward(ctx, g_lognorm, g_dxx, g_x, g_samples, g_init, g_pair):
         plan = ctx.plan
         eps, samples = ctx.saved_tensors
         zero = lambda g, like: torch.zeros_like(like) if g is None else g
         g_lognorm = zero(g_lognorm, plan.lognorm)
         gs = g_samples if (ctx.has_samples and g_samples is not None) else None
+        if not plan.inhomog:
+            g_init = g_pair = None
         gJ, gh = plan.vjp(g_lognorm, g_dxx, g_x, gs, eps if gs is not None else None,
-                          samples if gs is not None else None)
+                          samples if gs is not None else None, g_init, g_pair)
         gz = g_lognorm[:, None].expand(plan.B, plan.T).clone() if ctx.has_logZ else None
-        return gJ, gh, gz, None, None, None
+        return gJ, gh, gz, None, None, None, None
 
 
 def lds_inference_differentiable(natparam, node_params, eps=None, plan=None):
     """(lognorm (B), (E_node_diagxx, E_node_x) (B,T,n), samples (B,T,S,n) | None, (E_init, E_pair)):
-    differentiable w.r.t. node_params = (J (B,T,n), h (B,T,n)[, logZ (B,T)]) through torch autograd."""
+    differentiable w.r.t. node_params = (J (B,T,n), h (B,T,n)[, logZ (B,T)]) through torch autograd.
+    Pair parameters (n,n), (T-1,n,n) or (B,T-1,n,n); in the per-step cases E_init (B, n*n+n) and
+    E_pair (B,T-1,3,n,n) are differentiable too."""
     init_params, pair_params = natparam
     node_J, node_h = node_params[0], node_params[1]
     node_logZ = node_params[2] if len(node_params) == 3 else None
     dev = node_h.device
     B, T, n = node_h.shape
-    if plan is None:
-        plan = LDSEStepPlan(B, T, n, dev)
     init_J, init_h, init_logZ = _canonical_init_params(init_params, dev)
     J11, J12, J22 = (_as_dev(x, dev) for x in pair_params[:3])
     logZ_pair = _as_dev(pair_params[3], dev).reshape(-1)
+    inhomog, pair_batched = J11.dim() >= 3, J11.dim() == 4
+    if plan is None:
+        plan = LDSEStepPlan(B, T, n, dev, inhomog, pair_batched)
     params = (init_J, init_h, init_logZ, J11, J12, J22, logZ_pair)
     cont = lambda x: None if x is None else x.to(torch.float64).contiguous()
-    out = _LDSInference.apply(cont(node_J), cont(node_h), cont(node_logZ), cont(eps), plan, params)
+    out = _LDSInference.apply(cont(node_J), cont(node_h), cont(node_logZ), cont(eps), plan, params,
+                              pair_batched)
     lognorm, dxx, ex, samples, E_init, E_pair = out
     return lognorm, (dxx, ex), (samples if eps is not None else None), (E_init, E_pair)

@@ -18,8 +18,9 @@ Batched: node potentials (B,T,n); every sequence runs its own coordinate ascent 
 import torch
 
 from ..distributions import expfam
-from ..hmm.hmm_inference import hmm_estep
-from ..lds.lds_inference import LDSEStepPlan, natural_lds_estep_general, natural_lds_inference_general
+from ..hmm.hmm_inference import hmm_estep, hmm_logZ_differentiable
+from ..lds.lds_inference import (LDSEStepPlan, lds_inference_differentiable, natural_lds_estep_general,
+                                     natural_lds_inference_general)
 
 
 def _dev64(x, device):
@@ -223,3 +224,56 @@ def slds_prior_vlb(global_natparam, prior_natparam, dev):
         val = val + ((pa - ga) * expfam.niw_expectedstats(ga)).sum()
         val = val + sum(((x - y) * e).sum() for x, y, e in zip(pm, gm, expfam.mniw_expectedstats(gm)))
     return val - (logZ(pd, pmd, plds) - logZ(gd, gmd, glds))
+
+
+def final_pass_differentiable(global_natparam, hmm_natparam, lds_natparam, nn_potentials, eps):
+    """The part of run_inference that depends on nn_potentials with gradients attached
+    (slds_svae.py:295-307, "recompute terms that depend on nn_potentials at optimum"): the LDS
+    E-step + sampler on the FIXED mean-field natural parameters, the HMM bound evaluated on its
+    statistics, and the local bound.  Returns (samples, (E_init, E_pair) per sequence, local_vlb)."""
+    dev = nn_potentials[1].device
+    nJ, nh = nn_potentials[0], nn_potentials[1]
+    B, T, n = nh.shape
+    (J0, h0, a0, b0), (J11, J12, J22, lz) = lds_natparam
+    # per-sequence init potential folded into pair 0 / node 0 (see _lds_estep_batched_init)
+    J11 = J11.clone()
+    J11[:, 0] += J0
+    first = torch.zeros_like(nh)
+    first[:, 0] = h0
+    nh_eff = nh + first
+    zero = torch.zeros((), dtype=torch.float64, device=dev)
+    natparam = ((torch.zeros(n, n, dtype=torch.float64, device=dev), torch.zeros(n, dtype=torch.float64, device=dev), zero),
+                (J11.contiguous(), J12.contiguous(), J22.contiguous(), lz.contiguous()))
+    lognorm, (dxx, ex), samples, (E_init, E_pair) = lds_inference_differentiable(natparam, (nJ, nh_eff), eps=eps)
+    lognorm = lognorm + a0 + b0
+    hmm_global, lds_global = global_natparam
+    lds_global_d = [(_dev64(a, dev), tuple(_dev64(y, dev) for y in m)) for a, m in lds_global]
+    dense_init, dense_pair = get_all_lds_local_natparams(lds_global_d)
+    init_stats = (E_init[:, :n * n].reshape(B, n, n), E_init[:, n * n:])
+    pair_stats = (E_pair[:, :, 0], E_pair[:, :, 1], E_pair[:, :, 2])
+    node_hmm = get_arhmm_local_nodeparams(dense_init, dense_pair, init_stats, pair_stats)
+    hmm_vlb = hmm_logZ_differentiable((hmm_natparam[0], hmm_natparam[1], node_hmm))
+    lds_vlb = lognorm - ((nJ * dxx).sum((1, 2)) + (nh * ex).sum((1, 2)))
+    return samples, (init_stats, pair_stats), (hmm_vlb + lds_vlb).sum()
+
+
+def run_inference_differentiable(prior_natparam, global_natparam, nn_potentials, num_samples, init_eps=None,
+                                 eps=None, generator=None, tol=1e-2):
+    """run_inference (slds_svae.py:289-310) with torch autograd attached to nn_potentials = (J, h),
+    each (B,T,n): the local mean field is optimised on detached values (the reference's `unbox`),
+    then the final pass is differentiated through the E-step / sampler VJP kernels and the HMM
+    kernel.  -> (samples (B,T,S,n), expected_stats, global_vlb, local_vlb)."""
+    dev = nn_potentials[1].device
+    node_d = tuple(_dev64(x, dev) for x in nn_potentials)
+    B, T, n = node_d[1].shape
+    if init_eps is None:
+        init_eps = torch.randn(B, T, 1, n, dtype=torch.float64, device=dev, generator=generator)
+    (hmm_stats, _), (hmm_nat, lds_nat), _, _ = optimize_local_meanfield(global_natparam, node_d, init_eps, tol)
+    if eps is None:
+        eps = torch.randn(B, T, int(num_samples), n, dtype=torch.float64, device=dev, generator=generator)
+    samples, (init_stats, pair_stats), local_vlb = final_pass_differentiable(
+        global_natparam, hmm_nat, lds_nat, (nn_potentials[0], nn_potentials[1]), _dev64(eps, dev))
+    expected_stats = get_global_stats(hmm_stats, tuple(x.detach() for x in init_stats),
+                                      tuple(x.detach() for x in pair_stats))
+    global_vlb = slds_prior_vlb(global_natparam, prior_natparam, dev)
+    return samples, expected_stats, global_vlb, local_vlb

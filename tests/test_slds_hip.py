@@ -142,3 +142,58 @@ def test_config3_shape_properties():
     _close(Es[b], ref["hmm_stats"][2], 1e-5)
     for got, want in zip(lds_stats[1], ref["pair_stats"]):
         _close(got[b], want, 1e-5)
+
+
+def test_final_pass_gradient_against_finite_differences():
+    """d(local_vlb + <g, samples>)/d(nn_potentials) through the VJP kernels (per-step pair parameters,
+    cotangents of E_init / E_pair from the HMM bound) against central differences of the forward."""
+    from svae_amd.models import slds_svae
+    K, n, T, B, S = 3, 3, 6, 2, 2
+    rng = np.random.default_rng(21)
+    glob = _globals(K, n, rng)
+    J, h = _nodes(B, T, n, rng)
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev)
+    node = (t(J), t(h))
+    (_, _), (hmm_nat, lds_nat), _, _ = slds_svae.optimize_local_meanfield(glob, node, t(rng.standard_normal((B, T, 1, n))))
+    eps = t(rng.standard_normal((B, T, S, n)))
+    gs = t(rng.standard_normal((B, T, S, n)))
+
+    def f(nJ, nh):
+        samples, _, local_vlb = slds_svae.final_pass_differentiable(glob, hmm_nat, lds_nat, (nJ, nh), eps)
+        return local_vlb + (gs * samples).sum()
+
+    nJ, nh = node[0].clone().requires_grad_(True), node[1].clone().requires_grad_(True)
+    f(nJ, nh).backward()
+    d = 1e-6
+    for name, x, grad in (("J", node[0], nJ.grad), ("h", node[1], nh.grad)):
+        fd = torch.zeros_like(x)
+        for idx in np.ndindex(*x.shape):
+            xp, xm = x.clone(), x.clone()
+            xp[idx] += d
+            xm[idx] -= d
+            args_p = (xp, node[1]) if name == "J" else (node[0], xp)
+            args_m = (xm, node[1]) if name == "J" else (node[0], xm)
+            fd[idx] = (f(*args_p) - f(*args_m)).detach() / (2 * d)
+        err = float((grad - fd).abs().max() / fd.abs().max())
+        assert err < 1e-6, (name, err)
+
+
+def test_run_inference_differentiable_matches_forward_values():
+    from svae_amd.models import slds_svae
+    K, n, T, B, S = 3, 4, 10, 3, 2
+    rng = np.random.default_rng(9)
+    glob, prior = _globals(K, n, rng), _globals(K, n, rng)
+    J, h = _nodes(B, T, n, rng)
+    init_eps, eps = rng.standard_normal((B, T, 1, n)), rng.standard_normal((B, T, S, n))
+    dev = torch.device("cuda:0")
+    node = (torch.as_tensor(J, device=dev), torch.as_tensor(h, device=dev))
+    s0, st0, g0, l0 = slds_svae.run_inference(prior, glob, node, S, init_eps=init_eps, eps=eps)
+    nd = tuple(x.clone().requires_grad_(True) for x in node)
+    s1, st1, g1, l1 = slds_svae.run_inference_differentiable(prior, glob, nd, S, init_eps=init_eps, eps=eps)
+    assert torch.allclose(s0, s1, rtol=1e-10, atol=1e-12)
+    assert float(l1.detach()) == pytest.approx(float(l0), rel=1e-10) and float(g1) == pytest.approx(float(g0), rel=1e-12)
+    for a, b in zip(st0[1][1], st1[1][1]):
+        assert torch.allclose(a, b, rtol=1e-9, atol=1e-10)
+    (l1 + s1.sum()).backward()
+    assert torch.isfinite(nd[0].grad).all() and torch.isfinite(nd[1].grad).all() and float(nd[1].grad.abs().max()) > 0

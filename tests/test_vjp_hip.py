@@ -89,3 +89,52 @@ def test_vjp_against_finite_differences_of_the_hip_forward():
             fm = float(f(*args))
             num = (fp - fm) / (2 * h)
             assert abs(float(grad[b, tt, i]) - num) < 2e-5 * max(1.0, abs(num))
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("n,T,B,S", [(3, 6, 2, 2), (10, 20, 3, 1), (8, 5, 2, 3), (4, 2, 2, 1)])
+@pytest.mark.parametrize("batched", [False, True])
+@pytest.mark.parametrize("with_samples", [False, True])
+def test_vjp_inhomogeneous_with_statistics_cotangents(n, T, B, S, batched, with_samples):
+    """Per-step (and per-sequence) pair parameters plus cotangents of E_init and the per-step E_pair --
+    what the SLDS-SVAE differentiates (slds_svae.py:295-300) -- against the reference's compiled
+    VJPs (its _compute_stats_grad, cython_lds_inference.pyx:212-234, takes those cotangents)."""
+    from svae_amd.lds.lds_inference import lds_inference_differentiable
+    from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials
+    rng = np.random.default_rng(7 * n + T + 100 * batched)
+    init = rand_lds_natparam(n, rng)[0]
+    sets = B if batched else 1
+    pairs = [[rand_lds_natparam(n, rng)[1] for _ in range(T - 1)] for _ in range(sets)]
+    stack = lambda i: np.stack([np.stack([p[i] for p in row]) for row in pairs])
+    pair_b = tuple(stack(i) for i in range(4))                      # (sets,T-1,n,n) x3, (sets,T-1)
+    pair = pair_b if batched else tuple(x[0] for x in pair_b)
+    node = rand_node_potentials((B, T, n), rng, with_logZ=True)
+    g = dict(ln=rng.standard_normal(B), dxx=rng.standard_normal((B, T, n)), x=rng.standard_normal((B, T, n)),
+             s=rng.standard_normal((B, T, S, n)), i=rng.standard_normal((B, n * n + n)),
+             p=rng.standard_normal((B, T - 1, 3, n, n)))
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev)
+    want, eps = [], np.zeros((B, T, S, n))
+    for b in range(B):
+        pb = tuple(x[b if batched else 0] for x in pair_b)
+        (gJ, gh, gz), e = ref.estep_vjp(
+            (init, pb), tuple(x[b] for x in node), g["ln"][b], (g["dxx"][b], g["x"][b]),
+            g["s"][b] if with_samples else None, seed=200 + b,
+            g_E_init=(g["i"][b, :n * n].reshape(n, n), g["i"][b, n * n:]),
+            g_E_pair=(g["p"][b, :, 0], g["p"][b, :, 1], g["p"][b, :, 2]))
+        want.append((gJ, gh, gz))
+        if with_samples:
+            eps[b] = e
+    nJ, nh, nz = (t(x).requires_grad_(True) for x in node)
+    lognorm, (dxx, ex), samples, (E_init, E_pair) = lds_inference_differentiable(
+        (tuple(t(x) for x in init), tuple(t(x) for x in pair)), (nJ, nh, nz),
+        eps=t(eps) if with_samples else None)
+    loss = (t(g["ln"]) * lognorm).sum() + (t(g["dxx"]) * dxx).sum() + (t(g["x"]) * ex).sum() \
+        + (t(g["i"]) * E_init).sum() + (t(g["p"]) * E_pair).sum()
+    if with_samples:
+        loss = loss + (t(g["s"]) * samples).sum()
+    loss.backward()
+    for b in range(B):
+        assert _rel(nJ.grad[b], want[b][0]) < 1e-6, "g_node_J"
+        assert _rel(nh.grad[b], want[b][1]) < 1e-6, "g_node_h"
+        assert _rel(nz.grad[b], want[b][2]) < 1e-12, "g_node_logZ"
