@@ -182,10 +182,22 @@ def get_global_stats(hmm_stats, init_stats, pair_stats):
     return (Ei.sum(0), Et.sum(0)), (g_init, g_pair)
 
 
+def global_stats_as_natparam(stats):
+    """Re-nest get_global_stats' stacked tensors like the global natural parameters
+    ((dirichlet (K), dirichlet rows (K,K)), [(niw dense (n+2,n+2), mniw 4-tuple)] * K), so that the
+    natural-gradient expression of make_gradfun (svae.py:33-34: prior + stats - params on the
+    flattened structures) lines up (the reference zips per-state tuples the same way, :240)."""
+    hmm, (g_init, g_pair) = stats
+    K = g_init[2].shape[0]
+    lds = [(expfam.pack_dense(g_init[0][k], g_init[1][k], g_init[2][k], g_init[3][k]),
+            tuple(p[k] for p in g_pair)) for k in range(K)]
+    return hmm, lds
+
+
 def run_inference(prior_natparam, global_natparam, nn_potentials, num_samples, init_eps=None, eps=None,
                   generator=None, tol=1e-2):
-    """(:289-310) -> (samples (B,T,S,n), expected_stats, global_vlb, local_vlb).  Forward values only:
-    the VJP of the time-inhomogeneous E-step is not built yet."""
+    """(:289-310) -> (samples (B,T,S,n), expected_stats, global_vlb, local_vlb); forward values only
+    (see run_inference_differentiable)."""
     dev = nn_potentials[1].device
     node = tuple(_dev64(x, dev) for x in nn_potentials)
     B, T, n = node[1].shape

@@ -197,3 +197,39 @@ def test_run_inference_differentiable_matches_forward_values():
         assert torch.allclose(a, b, rtol=1e-9, atol=1e-10)
     (l1 + s1.sum()).backward()
     assert torch.isfinite(nd[0].grad).all() and torch.isfinite(nd[1].grad).all() and float(nd[1].grad.abs().max()) > 0
+
+
+def test_make_gradfun_with_the_slds_model():
+    """One training-step gradient of an SLDS-SVAE through svae.make_gradfun: recognition net ->
+    run_inference_differentiable -> decoder; the PGM natural gradient lines up with the global
+    natural parameters' structure."""
+    from functools import partial
+    from svae_amd import svae
+    from svae_amd.models import slds_svae
+    K, n, T, B, S, p = 2, 3, 8, 4, 1, 5
+    rng = np.random.default_rng(4)
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev)
+    to_t = lambda s: tuple(to_t(x) for x in s) if isinstance(s, (tuple, list)) else t(s)
+    glob, prior = to_t(_globals(K, n, rng)), to_t(_globals(K, n, rng))
+    data = t(rng.standard_normal((2 * B, T, p)))
+    W_r = (t(0.3 * rng.standard_normal((p, n))).requires_grad_(True), t(0.3 * rng.standard_normal((p, n))).requires_grad_(True))
+    W_d = (t(0.3 * rng.standard_normal((n, p))).requires_grad_(True),)
+
+    def recognize(params, batch):            # (J diag <= 0, h)
+        return -0.5 * torch.nn.functional.softplus(batch @ params[0]) - 0.1, batch @ params[1]
+
+    def loglike(params, samples, batch):     # unit-variance Gaussian decoder, mean over samples
+        mean = samples @ params[0]
+        return -0.5 * ((batch[:, :, None, :] - mean) ** 2).sum() / samples.shape[2]
+
+    gen = torch.Generator(device=dev).manual_seed(0)
+    def run(prior_, glob_, pots, S_):
+        samples, stats, gv, lv = slds_svae.run_inference_differentiable(prior_, glob_, pots, S_, generator=gen)
+        return samples, slds_svae.global_stats_as_natparam(stats), -gv, -lv      # vlb -> kl sign of svae.py
+
+    gradfun = svae.make_gradfun(run, recognize, loglike, prior, data, B, S, callback=None)
+    natgrad, g_dec, g_rec = gradfun((glob, W_d, W_r), 0)
+    assert svae.flat(natgrad).shape == svae.flat(glob).shape
+    assert torch.isfinite(svae.flat(natgrad)).all()
+    assert all(torch.isfinite(g).all() and float(g.abs().max()) > 0 for g in g_rec + g_dec)
