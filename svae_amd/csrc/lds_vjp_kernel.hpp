@@ -25,9 +25,9 @@
 //     Bbar = P^-1 [Xbar | cbar];   hfbar = Bbar[:,n] + g c
 //     Pbar = -P^-1 Pinvbar P^-1 - Bbar H' - 1/2 g (c c' + P^-1) + Pbar(direct)
 //     g_node_J_t = -2 diag(Pbar);  g_node_h_t = hfbar;  [Abar | hbar]_t = [Pbar | hfbar]
-// Layout: as the packed E-step kernel (one DPP row per sequence, lane = column, fused DPP FMAs);
-// every statement of this unit is self-fenced (SVAE_DPP_ALWAYS_FENCED, dpp.hpp): the kernels are
-// register-heavy and correctness comes first here.
+// Layout: as the packed E-step kernel (one DPP row per sequence, lane = column, fused DPP FMAs).
+// Hazards: every product stage fences its DPP-read operand array once (mm_ab / mm_atb), the few
+// stand-alone broadcasts fence theirs; `make audit` checks the ISA of every latent dimension.
 #pragma once
 #include "lds_estep_kernel.hpp"
 
@@ -36,6 +36,7 @@ namespace svae {
 // OUT[i] += sum_{k<KN} (+/-) bcast_k(A[i]) * B[k]   for i in [0, IN)      (OUT = A B)
 template <int IN, int KN, bool NEG, int MA, int MB, int MO>
 __device__ __forceinline__ void mm_ab(double (&out)[MO], const double (&A)[MA], const double (&Bt)[MB]) {
+  dpp_fence(const_cast<double(&)[MA]>(A));     // A is the DPP-read operand: order its producers first
   static_for<0, KN>([&](auto k) {
     static_for<0, IN>([&](auto i) { mac_bc<k, NEG>(out[i], A[i], Bt[k]); });
   });
@@ -43,6 +44,7 @@ __device__ __forceinline__ void mm_ab(double (&out)[MO], const double (&A)[MA], 
 // OUT[i] += sum_{k<KN} (+/-) bcast_i(A[k]) * B[k]   for i in [0, IN)      (OUT = A' B)
 template <int IN, int KN, bool NEG, int MA, int MB, int MO>
 __device__ __forceinline__ void mm_atb(double (&out)[MO], const double (&A)[MA], const double (&Bt)[MB]) {
+  dpp_fence(const_cast<double(&)[MA]>(A));
   static_for<0, KN>([&](auto k) {
     static_for<0, IN>([&](auto i) { mac_bc<i, NEG>(out[i], A[k], Bt[k]); });
   });
@@ -104,9 +106,10 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep1_kernel(const VjpArgs a) {
     Gc[N] = EN;
 
     // direct cotangents, symmetrised
-    const double gx = (a.g_x && col) ? 0.5 * a.g_x[((long)b * T + t) * N + c] : 0.0;
+    double gx = (a.g_x && col) ? 0.5 * a.g_x[((long)b * T + t) * N + c] : 0.0;
     const double gd = (a.g_diagxx && col) ? a.g_diagxx[((long)b * T + t) * N + c] : 0.0;
     Sh[N] += gx;
+    dpp_fence(gx);
     static_for<0, N>([&](auto i) {
       mac_bc<i>(Sh[i], gx, EN);
       Sh[i] = __builtin_fma(gd, E[i], Sh[i]);
@@ -135,8 +138,9 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep1_kernel(const VjpArgs a) {
         Sh[i] = __builtin_fma(0.5, col ? q : 0.0, Sh[i]);
       });
       if (a.g_E_init && t == 0) {
-        const double qx = col ? 0.5 * a.g_E_init[(long)b * (nn + N) + nn + c] : 0.0;
+        double qx = col ? 0.5 * a.g_E_init[(long)b * (nn + N) + nn + c] : 0.0;
         Sh[N] += qx;
+        dpp_fence(qx);
         static_for<0, N>([&](auto i) { mac_bc<i>(Sh[i], qx, EN); });
       }
       cross = a.g_E_pair && t < T - 1;
@@ -198,10 +202,12 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep1_kernel(const VjpArgs a) {
       double xn[N];
       const double* gs = a.g_samples + (((long)b * T + t) * S + ss) * N;
       static_for<0, N>([&](auto k) { const double v = gs[k]; xn[k] = sv ? v : 0.0; });
+      dpp_fence(HcPrev);
       static_for<0, N>([&](auto j) {
         static_for<0, N>([&](auto k) { mac_bc<k, true>(xn[k], HcPrev[j], xh[j]); });
       });
       static_for<0, N>([&](auto k) { xh[k] = xn[k]; HcPrev[k] = Hc[k]; });
+      dpp_fence(xh);
       // cbar_t += sum_s xhat (lane N);  Xbar_t -= sum_s xhat x_{t+1}'  (i.e. G^[:, :n] += ...)
       static_for<0, 16>([&](auto s) {
         if (s < S) {
@@ -210,6 +216,7 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep1_kernel(const VjpArgs a) {
             const double x1 = a.samples[(((long)b * T + t + 1) * S + s) * N + (col ? c : 0)];
             v += col ? x1 : 0.0;
           }
+          asm volatile("s_nop 1");   // block entry after the branch: two wait states before the DPP reads (audit rule)
           static_for<0, N>([&](auto i) { mac_bc<s>(Gb[i], xh[i], v); });
         }
       });
@@ -220,19 +227,23 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep1_kernel(const VjpArgs a) {
       const double pvv = w2[N * N + (col ? c : 0)];
       const double dis = col ? 1.0 / sqrt(pvv) : 0.0;
       static_for<0, N>([&](auto k) { U[k] = E[k] * dis; });
+      dpp_fence(R);
       static_for<1, N>([&](auto jj) {
         constexpr int j = N - jj;
         static_for<0, j>([&](auto k) { mac_bc<j, true>(U[k], R[k], U[j]); });
       });
       double z[N], ET[N];
       static_for<0, N>([&](auto j) { z[j] = 0.0; ET[j] = 0.0; });
+      dpp_fence(U);
       static_for<0, N>([&](auto i) {
         static_for<0, N>([&](auto j) { mac_bc<j>(z[j], U[i], xh[i]); });        // z = U' xhat
       });
+      dpp_fence(z);
       static_for<0, 16>([&](auto s) {
         if (s < S) {
           const double e1 = a.eps[(((long)b * T + t) * S + s) * N + (col ? c : 0)];
           const double ev = col ? e1 : 0.0;
+          asm volatile("s_nop 1");   // block entry (audit rule)
           static_for<0, N>([&](auto j) { mac_bc<s>(ET[j], z[j], ev); });         // ET[j][c] = E[c][j]
         }
       });
@@ -313,6 +324,7 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep2_kernel(const VjpArgs a) {
     mm_ab<N, N, true>(Pb, Pi, T1);
     mm_ab<N, N + 1, true>(Pb, Bb, HT);
     double cvs = -0.5 * g * HT[N];
+    dpp_fence(cvs);
     static_for<0, N>([&](auto i) {
       mac_bc<i>(Pb[i], cvs, HT[N]);
       Pb[i] = __builtin_fma(-0.5 * g, Pi[i], Pb[i]);
@@ -327,6 +339,7 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep2_kernel(const VjpArgs a) {
       Ab[i] = __builtin_fma(EN, hfb - Pb[i], Pb[i]);
       gJ = __builtin_fma(E[i], Pb[i], gJ);
     });
+    dpp_fence(Ab);
     static_for<0, N>([&](auto i) { mac_bc<N>(gh, Ab[i], E[i]); });
     if (valid && col) {
       a.g_node_J[((long)b * T + t) * N + c] = -2.0 * gJ;

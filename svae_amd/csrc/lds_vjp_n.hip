@@ -1,6 +1,11 @@
 // lds_vjp_n.hip -- one translation unit per latent dimension (-DSVAE_N=<n>) for the VJP sweeps.
-// Register-heavy kernels: every DPP statement is self-fenced here (see dpp.hpp).
-#define SVAE_DPP_ALWAYS_FENCED 1
+// DPP hazards are handled per product stage (one fence on the DPP-read operand array, dpp.hpp /
+// lds_vjp_kernel.hpp) and checked on the generated ISA for every n by `make audit`;
+// -DSVAE_DPP_ALWAYS_FENCED=1 falls back to a self-fenced build (every DPP statement carries its own
+// wait states, about twice the instructions).
+#ifndef SVAE_DPP_ALWAYS_FENCED
+#define SVAE_DPP_ALWAYS_FENCED 0
+#endif
 #include "lds_vjp_kernel.hpp"
 
 #ifndef SVAE_N

@@ -1,0 +1,36 @@
+"""Timing of the training-step path of the LDS model at the headline shape: E-step (keeping the sampler /
+VJP hand-off), sampler, VJP.  Usage: python tools/bench_train_path.py [B T n S]"""
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from svae_amd.lds.lds_inference import LDSEStepPlan
+from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials
+
+
+def main():
+    B, T, n, S = (int(x) for x in sys.argv[1:5]) if len(sys.argv) > 4 else (512, 200, 10, 1)
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(0)
+    (J0, h0, z0), (J11, J12, J22, zp) = rand_lds_natparam(n, rng)
+    nJ, nh = rand_node_potentials((B, T, n), rng)
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev).contiguous()
+    args = [t(x) for x in (J0, h0, z0, J11, J12, J22, zp, nJ, nh)]
+    eps = torch.randn(B, T, S, n, dtype=torch.float64, device=dev)
+    g = [torch.randn(B, dtype=torch.float64, device=dev), torch.randn(B, T, n, dtype=torch.float64, device=dev),
+         torch.randn(B, T, n, dtype=torch.float64, device=dev), torch.randn(B, T, S, n, dtype=torch.float64, device=dev)]
+    plan = LDSEStepPlan(B, T, n, dev)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+    for rep in range(3):
+        ev[0].record(); plan.launch(*args)
+        ev[1].record(); plan.launch(*args, None, False, True, True)
+        ev[2].record(); smp = plan.sample(eps)
+        ev[3].record(); plan.vjp(g[0], g[1], g[2], g[3], eps, smp)
+        ev[4].record(); torch.cuda.synchronize()
+    ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(4)]
+    print("B=%d T=%d n=%d S=%d: E-step %.3f ms | E-step keeping factor+cross %.3f | sampler %.3f | VJP %.3f  "
+          "=> training path %.3f ms (%.0f seq/s)" % (B, T, n, S, ms[0], ms[1], ms[2], ms[3], sum(ms[1:]), B / sum(ms[1:]) * 1e3))
+
+
+if __name__ == "__main__":
+    main()
