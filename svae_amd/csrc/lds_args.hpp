@@ -71,8 +71,9 @@ struct VjpArgs {
   const double* __restrict__ ws;         // E-step main region
   const double* __restrict__ ws2;        // factor region
   const double* __restrict__ ws3;        // cross-moment region
-  double* __restrict__ adj;              // VJP scratch: per (b,t) n rows x (ws_h_stride + 2 ws_p_stride)
+  double* __restrict__ adj;              // VJP scratch: vjp_step_doubles(n) per (b,t)
 };
-constexpr int vjp_step_doubles(int n) { return n * (ws_h_stride(n) + 2 * ws_p_stride(n)); }
+// per (b,t): [G^ smoother share | G^ sampler share] (n rows x ws_h_stride each), [-P^-1 Pinvbar P^-1 | Pbar(direct)] (n x ws_p_stride each)
+constexpr int vjp_step_doubles(int n) { return n * (2 * ws_h_stride(n) + 2 * ws_p_stride(n)); }
 
 }  // namespace svae

@@ -63,7 +63,11 @@ __device__ __forceinline__ void transpose_tile(double* tab, int c, const double 
 }
 
 // ---- sweep 1: smoother + sampler adjoints, forward in time ----------------------------------------
-template <int N, bool SAMP, bool STATC>
+// The two adjoint chains of this sweep are independent (the S^ recursion of the smoother; the xhat
+// recursion + noise adjoint of the sampler): with samples they run as two ROLES in separate
+// workgroups (blockIdx.x & 1), each writing its own share of G^ -- the sweep is latency-bound on one
+// wavefront's instruction stream, and small batches leave most SIMDs idle.
+template <int N, bool SAMP, bool STATC, bool SPLIT>
 __global__ __launch_bounds__(64) void lds_vjp_sweep1_kernel(const VjpArgs a) {
   constexpr int HS = ws_h_stride(N), PS = ws_p_stride(N), WS = ws_step_doubles(N);
   constexpr int AS = vjp_step_doubles(N);
@@ -71,7 +75,11 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep1_kernel(const VjpArgs a) {
   const int lane = threadIdx.x;
   const int c = lane & 15;
   double* tab = tabs + (lane >> 4) * 256;
-  const int brow = blockIdx.x * 4 + (lane >> 4);
+  // SPLIT (small batches): role 0 = smoother adjoint, role 1 = sampler adjoint, in separate workgroups;
+  // otherwise one workgroup runs both bodies back to back
+  const bool do0 = !(SAMP && SPLIT) || (blockIdx.x & 1) == 0;
+  const bool do1 = SAMP && (!SPLIT || (blockIdx.x & 1) == 1);
+  const int brow = ((SAMP && SPLIT) ? (blockIdx.x >> 1) : blockIdx.x) * 4 + (lane >> 4);
   const bool valid = brow < a.B;
   const int b = valid ? brow : a.B - 1;
   const bool col = c < N, colN = c <= N;
@@ -91,12 +99,17 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep1_kernel(const VjpArgs a) {
   const bool sv = c < S;                                      // this lane carries a sample
   const int ss = sv ? c : 0;
 
+  const double cm = col ? 1.0 : 0.0;
   for (int t = 0; t < T; ++t) {
     const double* w = wsb + (long)t * WS;
     const double* w3 = a.ws3 + ((long)b * T + t) * (N + 1) * HS;
     double* ad = a.adj + ((long)b * T + t) * AS;
-    double Hc[N], WT[N + 1], Gc[N + 1];
+    double Hc[N];
     static_for<0, N>([&](auto k) { const double v = w[k * HS + (colN ? c : 0)]; Hc[k] = colN ? v : 0.0; });
+    double Gb[N];                              // G^ rows i < N (lanes 0..N); one share per role if SPLIT
+    static_for<0, N>([&](auto i) { Gb[i] = 0.0; });
+    if (do0) {
+    double WT[N + 1], Gc[N + 1];
     {
       double tmp[N + 1];
       load_row<N + 1>(w3 + (colN ? c : 0) * HS, tmp);
@@ -156,8 +169,6 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep1_kernel(const VjpArgs a) {
     }
 
     // G^ rows i < N:  2 S^ W~'   (lanes 0..N)
-    double Gb[N];
-    static_for<0, N>([&](auto i) { Gb[i] = 0.0; });
     mm_ab<N, N + 1, false>(Gb, Sh, WT);
     if constexpr (STATC) {
       if (cross) {
@@ -174,7 +185,20 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep1_kernel(const VjpArgs a) {
         mm_ab<N, N, false>(Gb, Cb, Snx);
       }
     }
-    if (valid && col) static_for<0, N>([&](auto i) { ad[N * HS + i * PS + c] = Sh[i]; });   // Pinvbar
+    {
+      // the part of Pbar_t that does not depend on the filter-adjoint recursion of sweep 2:
+      //   -P^-1 Pinvbar P^-1,   Pinvbar = S^[:n,:n] (before the propagation below)
+      double Pi[N], Pib[N], T1[N], Pbp[N];
+      static_for<0, N>([&](auto i) {
+        const double v = w[N * HS + i * PS + (col ? c : 0)];
+        Pi[i] = col ? v : 0.0;
+        Pib[i] = Sh[i] * cm;
+        T1[i] = 0.0; Pbp[i] = 0.0;
+      });
+      mm_ab<N, N, false>(T1, Pib, Pi);
+      mm_ab<N, N, true>(Pbp, Pi, T1);
+      if (valid && col) static_for<0, N>([&](auto i) { ad[2 * N * HS + i * PS + c] = Pbp[i]; });
+    }
 
     // S^ <- G~' (S^ G~)
     {
@@ -197,7 +221,11 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep1_kernel(const VjpArgs a) {
       }
     }
 
+    if (!do1) { if (valid && colN) static_for<0, N>([&](auto i) { ad[i * HS + c] = Gb[i]; }); }
+    }   // smoother adjoint
+
     if constexpr (SAMP) {
+      if (do1) {
       // xhat_t = g_samples_t - X_{t-1}' xhat_{t-1}   (register k, lane = sample)
       double xn[N];
       const double* gs = a.g_samples + (((long)b * T + t) * S + ss) * N;
@@ -252,14 +280,16 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep1_kernel(const VjpArgs a) {
       mm_ab<N, N, false>(K, U, LhT);              // K = U Lh'
       transpose_tile<N>(tab, c, K, KT);           // KT = Lh U'
       mm_ab<N, N, true>(Pex, U, KT);              // Pex = -U Lh U'
-      if (valid && col) static_for<0, N>([&](auto i) { ad[N * HS + N * PS + i * PS + c] = Pex[i]; });
+      if (valid && col) static_for<0, N>([&](auto i) { ad[2 * N * HS + N * PS + i * PS + c] = Pex[i]; });
+      // sampler share of G^ (SPLIT), or the total when this workgroup ran both bodies
+      if (valid && colN) static_for<0, N>([&](auto i) { ad[(SPLIT ? N * HS : 0) + i * HS + c] = Gb[i]; });
+      }   // sampler adjoint
     }
-    if (valid && colN) static_for<0, N>([&](auto i) { ad[i * HS + c] = Gb[i]; });
   }
 }
 
 // ---- sweep 2: filter adjoint, backward in time -----------------------------------------------------
-template <int N, bool SAMP>
+template <int N, bool SAMP, bool SPLIT>
 __global__ __launch_bounds__(64) void lds_vjp_sweep2_kernel(const VjpArgs a) {
   constexpr int HS = ws_h_stride(N), PS = ws_p_stride(N), WS = ws_step_doubles(N);
   constexpr int AS = vjp_step_doubles(N);
@@ -294,7 +324,8 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep2_kernel(const VjpArgs a) {
       Pi[i] = col ? v : 0.0;
       const double h = w[i * HS + (colN ? c : 0)];
       Hc[i] = colN ? h : 0.0;
-      const double gb = ad[i * HS + (colN ? c : 0)];
+      double gb = ad[i * HS + (colN ? c : 0)];
+      if constexpr (SAMP && SPLIT) gb += ad[N * HS + i * HS + (colN ? c : 0)];
       Xc[i] = colN ? gb * sg : 0.0;                            // [Xbar | cbar] = [-G^ | G^[:,n]]
     });
     {
@@ -312,16 +343,11 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep2_kernel(const VjpArgs a) {
       mm_ab<N, N, true>(Xc, J12c, Ab);
     }
     // Bbar = P^-1 [Xbar | cbar]
-    double Bb[N], T1[N], Pb[N];
-    static_for<0, N>([&](auto i) { Bb[i] = 0.0; T1[i] = 0.0; Pb[i] = 0.0; });
+    double Bb[N], Pb[N];
+    static_for<0, N>([&](auto i) { Bb[i] = 0.0; });
     mm_ab<N, N, false>(Bb, Pi, Xc);
-    // Pbar = -P^-1 (Pinvbar P^-1) - Bbar H' - 1/2 g (c c' + P^-1) [+ direct]
-    {
-      double Pib[N];
-      static_for<0, N>([&](auto i) { const double v = ad[N * HS + i * PS + (col ? c : 0)]; Pib[i] = col ? v : 0.0; });
-      mm_ab<N, N, false>(T1, Pib, Pi);
-    }
-    mm_ab<N, N, true>(Pb, Pi, T1);
+    // Pbar = [-P^-1 Pinvbar P^-1: from sweep 1] - Bbar H' - 1/2 g (c c' + P^-1) [+ direct]
+    static_for<0, N>([&](auto i) { const double v = ad[2 * N * HS + i * PS + (col ? c : 0)]; Pb[i] = col ? v : 0.0; });
     mm_ab<N, N + 1, true>(Pb, Bb, HT);
     double cvs = -0.5 * g * HT[N];
     dpp_fence(cvs);
@@ -330,7 +356,7 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep2_kernel(const VjpArgs a) {
       Pb[i] = __builtin_fma(-0.5 * g, Pi[i], Pb[i]);
     });
     if constexpr (SAMP) {
-      static_for<0, N>([&](auto i) { const double v = ad[N * HS + N * PS + i * PS + (col ? c : 0)]; Pb[i] += col ? v : 0.0; });
+      static_for<0, N>([&](auto i) { const double v = ad[2 * N * HS + N * PS + i * PS + (col ? c : 0)]; Pb[i] += col ? v : 0.0; });
     }
     // outputs and the adjoint handed to step t-1:  Ab = [Pbar | Bbar[:,n] + g c]
     double gJ = 0.0, gh = 0.0;
@@ -350,16 +376,20 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep2_kernel(const VjpArgs a) {
 
 template <int N>
 static int launch_vjp(const VjpArgs& a, hipStream_t stream) {
-  dim3 grid((a.B + 3) / 4), block(64);
+  dim3 grid((a.B + 3) / 4), grid2(2 * ((a.B + 3) / 4)), block(64);
   const bool statc = a.g_E_init || a.g_E_pair;
+  const bool split = a.B <= 2048;        // two roles while 2 wavefronts per 4 sequences still find idle SIMDs
   if (a.g_samples) {
-    if (statc) hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, true, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, true, false>), grid, block, 0, stream, a);
-    hipLaunchKernelGGL((lds_vjp_sweep2_kernel<N, true>), grid, block, 0, stream, a);
+    if (statc && split) hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, true, true, true>), grid2, block, 0, stream, a);
+    else if (statc) hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, true, true, false>), grid, block, 0, stream, a);
+    else if (split) hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, true, false, true>), grid2, block, 0, stream, a);
+    else hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, true, false, false>), grid, block, 0, stream, a);
+    if (split) hipLaunchKernelGGL((lds_vjp_sweep2_kernel<N, true, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((lds_vjp_sweep2_kernel<N, true, false>), grid, block, 0, stream, a);
   } else {
-    if (statc) hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, false, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, false, false>), grid, block, 0, stream, a);
-    hipLaunchKernelGGL((lds_vjp_sweep2_kernel<N, false>), grid, block, 0, stream, a);
+    if (statc) hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, false, true, false>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, false, false, false>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((lds_vjp_sweep2_kernel<N, false, false>), grid, block, 0, stream, a);
   }
   return hipGetLastError() == hipSuccess ? 0 : -1000;
 }

@@ -43,7 +43,7 @@ def test_workspace_size_formula():
     # and the cross-moment region ((n+1) rows of stride even(n+1)) per step
     assert lib.svae_lds_workspace_bytes(512, 200, 10) == 512 * (22 + 200 * (10 * (12 + 10) + 10 * 10 + 10 + 11 * 12)) * 8
     assert lib.svae_lds_workspace_bytes(3, 7, 5) == 3 * (12 + 7 * (5 * (6 + 6) + 5 * 5 + 5 + 6 * 6)) * 8
-    assert lib.svae_lds_vjp_workspace_bytes(3, 7, 5) == 3 * 7 * 5 * (6 + 2 * 6) * 8
+    assert lib.svae_lds_vjp_workspace_bytes(3, 7, 5) == 3 * 7 * 5 * (2 * 6 + 2 * 6) * 8
     # n > 15: tiled path, per step X and P^-1 (NP x NP, NP = n rounded up to 16) and c (NP)
     # + the pair parameters re-packed in fragment order: 2 slots (homogeneous) or T-1 per set, 3 NP^2 each
     assert lib.svae_lds_workspace_bytes(1, 1, 16) == (2 * 16 * 16 + 16) * 8
