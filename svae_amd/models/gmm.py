@@ -169,3 +169,32 @@ def run_inference_differentiable(prior_natparam, global_natparam, nn_potentials,
     dirichlet_stats = label_stats.detach().sum(0)
     niw_stats = torch.tensordot(label_stats.detach(), gaussian_stats.detach(), dims=([0], [0]))
     return samples, (dirichlet_stats, niw_stats), prior_kl(global_natparam, prior_natparam), local_kl
+
+
+def init_pgm_param(K, N, alpha, niw_conc=10., random_scale=0., generator=None, dtype=torch.float64, device="cpu"):
+    """(/root/reference/svae/models/gmm.py:33-42) -> (dirichlet natparam (K), NIW natparams (K, N+2, N+2)).
+    The reference draws from the global NumPy RNG; here from `generator`."""
+    kw = dict(dtype=dtype, device=device)
+    nu = torch.tensor(N + niw_conc, **kw)
+    S = (N + niw_conc) * torch.eye(N, **kw)
+    kappa = torch.tensor(float(niw_conc), **kw)
+    niws = []
+    for _ in range(K):
+        m = torch.zeros(N, **kw)
+        if random_scale:
+            m = m + random_scale * torch.randn(N, generator=generator, **kw)
+        niws.append(expfam.niw_standard_to_natural(S, m, kappa, nu))
+    dirichlet = alpha * (torch.rand(K, generator=generator, **kw) if random_scale else torch.ones(K, **kw))
+    return dirichlet, torch.stack(niws)
+
+
+def prior_logZ(gmm_natparam):
+    """(gmm.py:44-46)"""
+    dirichlet_natparam, niw_natparams = gmm_natparam
+    return expfam.dirichlet_logZ(dirichlet_natparam) + expfam.niw_logZ(niw_natparams).sum()
+
+
+def prior_expectedstats(gmm_natparam):
+    """(gmm.py:48-52)"""
+    dirichlet_natparam, niw_natparams = gmm_natparam
+    return expfam.dirichlet_expectedstats(dirichlet_natparam), expfam.niw_expectedstats(niw_natparams)

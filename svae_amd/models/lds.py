@@ -144,3 +144,18 @@ def run_inference_differentiable(prior_natparam, global_natparam, nn_potentials,
     if not batched:
         samples = samples[0]
     return samples, (niw_stats, mniw_stats), global_kl, local_kl
+
+
+def make_prior_natparam(n, random=False, scaling=1., dtype=torch.float64, device="cpu"):
+    """(/root/reference/svae/models/lds.py:57-67) -> (NIW natparam of the initial state, MNIW natparam
+    of the dynamics) for an n-dimensional LDS; the values of the reference (nu = n+1,
+    S = 2 scaling (n+1) I, mu = 0, kappa = 1/(2 scaling n), M = I, K = kappa I)."""
+    if random:
+        raise NotImplementedError
+    eye = torch.eye(n, dtype=dtype, device=device)
+    nu = torch.tensor(n + 1., dtype=dtype, device=device)
+    S = 2. * scaling * (n + 1) * eye
+    mu = torch.zeros(n, dtype=dtype, device=device)
+    kappa = torch.tensor(1. / (2. * scaling * n), dtype=dtype, device=device)
+    M, K = eye.clone(), 1. / (2. * scaling * n) * eye
+    return expfam.niw_standard_to_natural(S, mu, kappa, nu), expfam.mniw_standard_to_natural(nu, S, M, K)

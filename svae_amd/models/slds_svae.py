@@ -289,3 +289,42 @@ def run_inference_differentiable(prior_natparam, global_natparam, nn_potentials,
                                       tuple(x.detach() for x in pair_stats))
     global_vlb = slds_prior_vlb(global_natparam, prior_natparam, dev)
     return samples, expected_stats, global_vlb, local_vlb
+
+
+def make_hmm_global_natparam(num_states, alpha=1., sticky_bias=0., random=False, generator=None,
+                             dtype=torch.float64, device="cpu"):
+    """(slds_svae.py:38-50) -> (dirichlet natparam of the initial state (K), of the transition rows (K,K))."""
+    kw = dict(dtype=dtype, device=device)
+    row = lambda: alpha * torch.ones(num_states, **kw) if not random \
+        else alpha + torch.rand(num_states, generator=generator, **kw)
+    dir_natparam = row()
+    mdir_natparam = sticky_bias * torch.eye(num_states, **kw) + torch.stack([row() for _ in range(num_states)])
+    return dir_natparam, mdir_natparam
+
+
+def make_lds_global_natparams(num_states, state_dim, random=False, generator=None, dtype=torch.float64,
+                              device="cpu"):
+    """(slds_svae.py:56-75) -> [(NIW natparam, MNIW natparam)] per discrete state."""
+    kw = dict(dtype=dtype, device=device)
+    n = state_dim
+    eye = torch.eye(n, **kw)
+    r = lambda: float(torch.rand((), generator=generator, **kw))
+    out = []
+    for _ in range(num_states):
+        if not random:
+            nu, S, mu, kappa = n + 10., (n + 10.) * eye, torch.zeros(n, **kw), 10.
+            nu2, S2, M, K = n + 10., (n + 10.) * eye, torch.zeros(n, n, **kw), 10. * eye
+        else:
+            nu, S, mu, kappa = n + 4. + r(), (n + r()) * eye, torch.randn(n, generator=generator, **kw), r()
+            nu2, S2, M, K = n + 4. + r(), (n + r()) * eye, 1e-2 * torch.randn(n, n, generator=generator, **kw), (n + r()) * eye
+        t = lambda x: torch.as_tensor(x, **kw)
+        out.append((expfam.niw_standard_to_natural(S, mu, t(kappa), t(nu)),
+                    expfam.mniw_standard_to_natural(t(nu2), S2, M, K)))
+    return out
+
+
+def make_slds_global_natparam(num_states, state_dim, alpha=5., sticky_bias=0., random=False, generator=None,
+                              dtype=torch.float64, device="cpu"):
+    """(slds_svae.py:27-31)"""
+    return (make_hmm_global_natparam(num_states, alpha, sticky_bias, random, generator, dtype, device),
+            make_lds_global_natparams(num_states, state_dim, random, generator, dtype, device))

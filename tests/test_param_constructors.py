@@ -1,0 +1,57 @@
+"""CPU tests of the parameter constructors that sit on the data-format side of the hot path
+(models/lds.py:57-67, models/gmm.py:33-52, models/slds_svae.py:27-75 of the reference), against the
+NumPy restatement of the exponential-family maps."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle import expfam_numpy as ef
+
+
+def test_lds_make_prior_natparam_matches_the_reference_values():
+    from svae_amd.models.lds import make_prior_natparam, lds_prior_expectedstats
+    n = 4
+    niw, mniw = make_prior_natparam(n)
+    nu, S, mu, kappa = n + 1., 2. * (n + 1) * np.eye(n), np.zeros(n), 1. / (2. * n)
+    np.testing.assert_allclose(niw.numpy(), ef.niw_standard_to_natural(S, mu, np.array(kappa), np.array(nu)), rtol=1e-14)
+    want = ef.mniw_standard_to_natural(nu, S, np.eye(n), kappa * np.eye(n))
+    for a, b in zip(mniw, want):
+        np.testing.assert_allclose(np.asarray(a), b, rtol=1e-14)
+    # usable as a global parameter: its expected statistics are a valid LDS local natparam
+    init, pair = lds_prior_expectedstats((niw, mniw))
+    assert np.all(np.linalg.eigvalsh(-2 * np.asarray(pair[2])) > 0)
+
+
+def test_gmm_init_pgm_param_and_prior_terms():
+    from svae_amd.models import gmm
+    K, N = 3, 2
+    d, niws = gmm.init_pgm_param(K, N, alpha=0.5)
+    assert tuple(d.shape) == (K,) and tuple(niws.shape) == (K, N + 2, N + 2) and float(d[0]) == 0.5
+    want = ef.niw_standard_to_natural((N + 10.) * np.eye(N), np.zeros(N), np.array(10.), np.array(N + 10.))
+    np.testing.assert_allclose(niws[1].numpy(), want, rtol=1e-14)
+    es = gmm.prior_expectedstats((d, niws))
+    np.testing.assert_allclose(es[0].numpy(), ef.dirichlet_expectedstats(d.numpy()), rtol=1e-12)
+    np.testing.assert_allclose(es[1].numpy(), ef.niw_expectedstats(niws.numpy()), rtol=1e-10)
+    lz = ef.dirichlet_logZ(d.numpy()) + np.sum(ef.niw_logZ(niws.numpy()))
+    assert float(gmm.prior_logZ((d, niws))) == pytest.approx(float(lz), rel=1e-12)
+    g = torch.Generator().manual_seed(0)
+    d2, niws2 = gmm.init_pgm_param(K, N, alpha=0.5, random_scale=1.0, generator=g)
+    assert not torch.equal(niws2[0], niws2[1]) and float(d2.max()) <= 0.5
+
+
+def test_slds_global_natparam_constructors():
+    from svae_amd.models import slds_svae
+    K, n = 4, 3
+    (d, md), lds = slds_svae.make_slds_global_natparam(K, n, alpha=5., sticky_bias=2.)
+    assert tuple(d.shape) == (K,) and tuple(md.shape) == (K, K) and float(md[1, 1]) == 7. and float(md[0, 1]) == 5.
+    assert len(lds) == K
+    want_niw = ef.niw_standard_to_natural((n + 10.) * np.eye(n), np.zeros(n), np.array(10.), np.array(n + 10.))
+    np.testing.assert_allclose(lds[2][0].numpy(), want_niw, rtol=1e-14)
+    want = ef.mniw_standard_to_natural(n + 10., (n + 10.) * np.eye(n), np.zeros((n, n)), 10. * np.eye(n))
+    for a, b in zip(lds[0][1], want):
+        np.testing.assert_allclose(np.asarray(a), b, rtol=1e-14)
+    g = torch.Generator().manual_seed(1)
+    (_, _), lds_r = slds_svae.make_slds_global_natparam(K, n, random=True, generator=g)
+    init, pair = slds_svae.get_all_lds_local_natparams(lds_r)
+    assert tuple(pair[0].shape) == (K, n, n) and torch.isfinite(pair[0]).all()
