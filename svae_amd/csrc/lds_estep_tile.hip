@@ -30,6 +30,27 @@
 #include "dpp.hpp"
 #include "lds_args.hpp"
 
+#ifndef SVAE_TILE_EXP
+#define SVAE_TILE_EXP 0
+#endif
+#ifndef SVAE_TILE_SGB
+#define SVAE_TILE_SGB 5
+#endif
+
+// Scheduling hint: NM groups of {1 MFMA, NR LDS reads, NW LDS writes}.  An in-order wavefront stalls
+// on the next MFMA while the pipe is busy, so independent LDS work must sit BETWEEN the MFMAs in
+// program order to overlap with them (measured: -16 % on the elimination's tile updates).
+#define SVAE_SGB_(ID, NM, NR, NW)                                               \
+  _Pragma("unroll") for (int g_ = 0; g_ < (NM); ++g_) {                       \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, ID);                        \
+    if ((NR) > 0) __builtin_amdgcn_sched_group_barrier(0x100, (NR), ID);       \
+    if ((NW) > 0) __builtin_amdgcn_sched_group_barrier(0x200, (NW), ID);       \
+  }
+// SVAE_TILE_SGB: bit 0 = elimination row updates, bit 2 = backward Sigma update.  (bit 1, the Schur
+// stage, is wired but OFF: with it hipcc 7.2 produces wrong code for the per-step-parameter n = 64
+// instantiation -- caught by tests/test_lds_tile_hip.py; gain would be ~1 %.)
+#define SVAE_SGB(ID, NM, NR, NW) if constexpr (((SVAE_TILE_SGB) >> ((ID) - 1)) & 1) { SVAE_SGB_(ID, NM, NR, NW) }
+
 namespace svae {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -365,12 +386,22 @@ __global__ __launch_bounds__(256, 2) void lds_estep_tile_kernel(const LdsArgs a,
 #pragma unroll
           for (int q = 0; q < cnt; ++q) {
             d4 cn = cq, bn = bq;
+#if SVAE_TILE_EXP == 2     // timing experiment (wrong results): no accumulator loads
+            if (q + 1 < cnt) { bn = ld_b(16 * k, jmap(q + 1)); }
+#else
             if (q + 1 < cnt) { cn = ld_b(16 * i, jmap(q + 1)); bn = ld_b(16 * k, jmap(q + 1)); }
+#endif
             const d4 rq = mma16(nfa, bq, cq);
+#if SVAE_TILE_EXP != 1     // timing experiment (wrong results): no stores
             if (q > 0) st_c(16 * i, jmap(q - 1), rprev);
+#else
+            if (q > 0) asm volatile("" :: "v"(rprev));
+#endif
             rprev = rq; cq = cn; bq = bn;
+            SVAE_SGB(1, 4, 2, 1)
           }
           st_c(16 * i, jmap(cnt - 1), rprev);
+          TICK(1)     // (timing build: row updates of wavefronts 1..3 land in slot 1, the rest of P2 in slot 4)
           // pivot-column tile:  A[i][k] <- -A[i][k] A_kk^-1, computed transposed as A_kk^-1 A[i][k]'
           const d4 rt = apply_pivot(U, dinv, fa);
           if constexpr (i == k + 1) {
@@ -424,6 +455,7 @@ __global__ __launch_bounds__(256, 2) void lds_estep_tile_kernel(const LdsArgs a,
             d4 c = sC[s2];
 #pragma unroll
             for (int kk = 0; kk < NB; ++kk) c = mma16(sA[kk], fb[kk], c);
+            SVAE_SGB(2, 4 * NB, 1, 0)
             if (j < NB) {
               store_c(M, LDM, 16 * si, 16 * j, r16, kq, c);
             } else if (r16 == 0) {
@@ -603,6 +635,7 @@ __global__ __launch_bounds__(256, 2) void lds_estep_tile_kernel(const LdsArgs a,
         d4 c = pin[i];
 #pragma unroll
         for (int kk = 0; kk < NB; ++kk) c = mma16(fx[kk], Wt[kk], c);
+        SVAE_SGB(3, 4 * NB, 1, 0)
 #pragma unroll
         for (int kk = 0; kk < NB; ++kk) fx[kk] = fn[kk];
         store_c(M, LDM, 16 * i, 16 * J, r16, kq, c);          // Sigma_t tile (i, j)
