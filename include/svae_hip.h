@@ -1,8 +1,8 @@
 /* svae_hip.h -- C ABI of libsvae_hip.so: the MI355X (gfx950) structured E-step of mattjj/svae.
  *
  * Every entry point replaces one function at the reference's Python->Cython boundary
- * (/root/reference/svae/lds/lds_inference.py:18-24) or one hot loop of svae/models/gmm.py, batched
- * over independent sequences / data points.  Plain pointers and sizes only; no torch types.
+ * (/root/reference/svae/lds/lds_inference.py:18-24; svae/hmm/hmm_inference.py:11-13) or one hot loop
+ * of svae/models/gmm.py, batched over independent sequences / data points.  Plain pointers and sizes only; no torch types.
  *
  * Conventions (identical to the reference's API level):
  *   - all arrays are float64, C-order, time-major, and hold NATURAL parameters:
@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SVAE_HIP_ABI_VERSION 1
+#define SVAE_HIP_ABI_VERSION 2   /* 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
 #define SVAE_LDS_MAX_N 15   /* register/DPP path: one 16-lane row per sequence, n+1 <= 16 */
 #define SVAE_LDS_TILE_MAX_N 64   /* 16 <= n <= 64: LDS-tiled MFMA path (E-step only: keep must be 0) */
 

@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must precede CDLL: shares torch's HIP runtime)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVAE_AMD_LIB", os.path.join(_HERE, "libsvae_hip.so"))  # env: experiments only
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 LDS_MAX_N = 15        # register/DPP path (E-step, sampler, VJP)
 LDS_TILE_MAX_N = 64   # LDS-tiled MFMA path (E-step only)
 
