@@ -62,6 +62,22 @@ __device__ __forceinline__ void transpose_tile(double* tab, int c, const double 
   __builtin_amdgcn_wave_barrier();
 }
 
+// Cache warming (sweep 2, small batches): the sweep is serial in t and each step's operands (a few KB per sequence written
+// long ago by another kernel) come from HBM, ~2 us away; a one-step register prefetch cannot hide
+// that behind ~1 us of arithmetic.  Each DPP row instead touches one 128-byte line per lane of the
+// records of a step several iterations ahead; the values are folded into a dummy one iteration later
+// (by then, vmcnt being in-order, they have arrived) and the real loads find the lines in L2.
+template <int LINES>
+__device__ __forceinline__ double touch_lines(const double* rec, int c, long doubles) {
+  double s = 0.0;
+  static_for<0, (LINES + 15) / 16>([&](auto j) {
+    const long off = ((long)(c + 16 * j) * 16);
+    s += rec[off < doubles ? off : 0];
+  });
+  return s;
+}
+constexpr int VJP_AHEAD = 4;
+
 // ---- sweep 1: smoother + sampler adjoints, forward in time ----------------------------------------
 // The two adjoint chains of this sweep are independent (the S^ recursion of the smoother; the xhat
 // recursion + noise adjoint of the sampler): with samples they run as two ROLES in separate
@@ -315,9 +331,16 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep2_kernel(const VjpArgs a) {
   double Ab[N];                                               // [Abar | hbar] of step t+1
   static_for<0, N>([&](auto i) { Ab[i] = 0.0; });
 
+  double warm = 0.0, sink = 0.0;
   for (int t = T - 1; t >= 0; --t) {
     const double* w = wsb + (long)t * WS;
     const double* ad = a.adj + ((long)b * T + t) * AS;
+    sink += warm;                                              // last iteration's touches have landed
+    if (a.B <= 2048) {                                         // (large batches are bandwidth-bound: no extra traffic)
+      const int tw = t >= VJP_AHEAD ? t - VJP_AHEAD : 0;
+      warm = touch_lines<(WS + 15) / 16>(wsb + (long)tw * WS, c, WS)
+           + touch_lines<(AS + 15) / 16>(a.adj + ((long)b * T + tw) * AS, c, AS);
+    }
     double Pi[N], Hc[N], HT[N + 1], Xc[N];
     static_for<0, N>([&](auto i) {
       const double v = w[N * HS + i * PS + (col ? c : 0)];
@@ -367,6 +390,7 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep2_kernel(const VjpArgs a) {
     });
     dpp_fence(Ab);
     static_for<0, N>([&](auto i) { mac_bc<N>(gh, Ab[i], E[i]); });
+    if (sink == 1.2345e300) gJ += sink;                        // keeps the touches alive; never true
     if (valid && col) {
       a.g_node_J[((long)b * T + t) * N + c] = -2.0 * gJ;
       a.g_node_h[((long)b * T + t) * N + c] = gh;
