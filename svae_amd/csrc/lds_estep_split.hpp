@@ -225,9 +225,25 @@ __global__ __launch_bounds__(64) void lds_estep_split_kernel(const LdsArgs a) {
     });
   };
 
+#ifndef SVAE_WARM_AHEAD
+#define SVAE_WARM_AHEAD 4
+#endif
+  double warm = 0.0, sink = 0.0;
+  (void)warm; (void)sink;
   auto step = [&](int t, double (&H)[N + 1], double (&Gc)[J1], double (&Pi)[J1],
                   double (&Hn)[N + 1], double (&Gcn)[J1], double (&Pin)[J1]) {
     if (t > 0) load_step(t - 1, Hn, Gcn, Pin);      // prefetch: hides the L2/HBM latency
+#if SVAE_WARM_AHEAD > 0
+    // L2 warming: one 128-byte line per lane of the hand-off record SVAE_WARM_AHEAD steps ahead (the
+    // forward half wrote it ~T steps ago: HBM, further away than one step of arithmetic); the value
+    // is folded into a dummy one step later, when (vmcnt being in-order) it has long arrived
+    sink += warm;
+    {
+      const int tw = t > SVAE_WARM_AHEAD ? t - SVAE_WARM_AHEAD : 0;
+      const int lo = lane * 16 < WS ? lane * 16 : WS - 1;
+      warm = wsb[(long)tw * WS + lo];
+    }
+#endif
     dpp_fence(Gc);
 
     // W~[i] = S~[i] G~'  for my rows:  sum_k -/+ bcast_k(S[j]) H[k]
@@ -298,6 +314,9 @@ __global__ __launch_bounds__(64) void lds_estep_split_kernel(const LdsArgs a) {
     }
   });
   if (col && own_N) a.E_init[(long)b * (N * N + N) + N * N + c] = S[N / 4];
+#if SVAE_WARM_AHEAD > 0
+  if (sink == 1.2345e300) a.lognorm[b] = sink;        // keeps the touches alive; never true
+#endif
 }
 
 template <int N>
