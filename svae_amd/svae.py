@@ -87,7 +87,7 @@ def make_gradfun(run_inference, recognize, loglike, pgm_prior, data, batch_size,
             (flat(pgm_prior).to(dev) + num_batches * flat(saved.stats) - flat(pgm_params).to(dev))
         grad = unflat_like(pgm_natgrad, pgm_prior), loglike_grad, recogn_grad
         if callback:
-            callback(i, float(val), params, grad)
+            callback(i, float(val.detach()), params, grad)
         return grad
 
     gradfun.mc_elbo = mc_elbo

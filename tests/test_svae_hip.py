@@ -100,3 +100,17 @@ def test_make_gradfun_lds_against_finite_differences_and_natgrad_formula():
     expect = -10. / data.shape[0] * (flatnp(prior) + 2 * stats - flatnp(pgm))
     got = _np(flat(pgm_natgrad))
     assert np.max(np.abs(got - expect)) < 1e-6 * np.max(np.abs(expect))
+
+
+def test_example_training_loop_runs_and_improves():
+    """examples/lds_svae_synth.py: a few natural-gradient / SGD iterations through the HIP E-step,
+    sampler and VJP kernels; the Monte-Carlo ELBO estimate must stay finite and go up on average."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "lds_svae_synth.py")
+    spec = importlib.util.spec_from_file_location("lds_svae_synth", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    vals = mod.main(["--iters", "24", "--seqs", "64", "--T", "40", "--n", "4", "--p", "8", "--batch", "32", "--quiet"])
+    assert len(vals) == 24 and np.all(np.isfinite(vals))
+    assert np.mean(vals[-6:]) > np.mean(vals[:6])
