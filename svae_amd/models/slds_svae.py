@@ -96,7 +96,20 @@ def optimize_local_meanfield(global_natparam, node_potentials, init_eps, tol=1e-
     vlb = torch.full((B,), -float("inf"), dtype=torch.float64, device=dev)
     active = torch.ones(B, dtype=torch.bool, device=dev)
     iters = torch.zeros(B, dtype=torch.int64, device=dev)
-    keep = {}
+    # State of the ascent, one persistent buffer each; a sweep overwrites the rows of the sequences still
+    # active (converged ones are frozen, like the reference's per-sequence `break`).  The big ones --
+    # per-step pair statistics, 3 (T-1) n^2 doubles per sequence -- are only ever copied row-wise.
+    state = {}
+
+    def commit(name, val, all_active):
+        if name not in state:
+            state[name] = val.clone()
+        elif all_active:
+            state[name].copy_(val)
+        else:
+            idx = active.nonzero(as_tuple=True)[0]
+            state[name].index_copy_(0, idx, val.index_select(0, idx))
+
     for _ in range(max_iter):
         node_hmm = get_arhmm_local_nodeparams(dense_init, dense_pair, init_stats, pair_stats)
         hmm_vlb, (Ei, Et, Es) = hmm_estep((hmm_init, hmm_pair, node_hmm))
@@ -104,26 +117,25 @@ def optimize_local_meanfield(global_natparam, node_potentials, init_eps, tol=1e-
         # the E-step API takes one shared init potential per launch: fold each sequence's init
         # potential into its first node potential instead (identical model: both multiply x_0's factor)
         lds_vlb, (Ei_l, Ep_l, En_l) = _lds_estep_batched_init(plan, lds_init, lds_pair, node)
-        new = dict(hmm_stats=(Ei, Et, Es), init_stats=(Ei_l[0], Ei_l[1]), pair_stats=(Ep_l[0], Ep_l[1], Ep_l[2]),
-                   node_stats=(En_l[0], En_l[1]), hmm_natparam=node_hmm, lds_init=lds_init, lds_pair=lds_pair,
-                   hmm_vlb=hmm_vlb, lds_vlb=lds_vlb)
-        sel = lambda old, val: val if old is None else torch.where(active.view((-1,) + (1,) * (val.dim() - 1)), val, old)
-        for k, v in new.items():
-            if isinstance(v, tuple):
-                keep[k] = tuple(sel(None if k not in keep else keep[k][i], x.clone()) for i, x in enumerate(v))
-            else:
-                keep[k] = sel(keep.get(k), v.clone())
-        init_stats, pair_stats = keep["init_stats"], keep["pair_stats"]
-        new_vlb = keep["hmm_vlb"] + keep["lds_vlb"]
+        all_active = bool(active.all())
+        for name, val in (("Ei", Ei), ("Et", Et), ("Es", Es), ("node_hmm", node_hmm), ("E_init", plan.E_init),
+                          ("E_pair", plan.E_pair), ("dxx", En_l[0]), ("ex", En_l[1]), ("hmm_vlb", hmm_vlb),
+                          ("lds_vlb", lds_vlb)):
+            commit(name, val, all_active)
+        init_stats = (state["E_init"][:, :n * n].reshape(B, n, n), state["E_init"][:, n * n:])
+        pair_stats = tuple(state["E_pair"][:, :, i] for i in range(3))
+        new_vlb = state["hmm_vlb"] + state["lds_vlb"]
         iters += active.to(torch.int64)
         done = (new_vlb - vlb).abs() < tol
         vlb = new_vlb
         active = active & ~done
         if not bool(active.any()):
             break
-    lds_stats = (keep["init_stats"], keep["pair_stats"], keep["node_stats"])
-    return (keep["hmm_stats"], lds_stats), ((hmm_init, hmm_pair, keep["hmm_natparam"]), (keep["lds_init"], keep["lds_pair"])), \
-        (keep["hmm_vlb"], keep["lds_vlb"]), iters
+    # the natural parameters of the frozen solution (cheap to rebuild from the final HMM marginals)
+    lds_init, lds_pair = get_var_lds_local_natparam(dense_init, dense_pair, state["Es"])
+    lds_stats = (init_stats, pair_stats, (state["dxx"], state["ex"]))
+    return ((state["Ei"], state["Et"], state["Es"]), lds_stats), \
+        ((hmm_init, hmm_pair, state["node_hmm"]), (lds_init, lds_pair)), (state["hmm_vlb"], state["lds_vlb"]), iters
 
 
 def optimize_local_meanfield_withlabels(global_natparam, node_potentials, labels):
