@@ -58,7 +58,8 @@ def test_tile_estep_batched_matches_compiled_reference(n, T, B):
         _check(got, want, 1e-7)
 
 
-@pytest.mark.parametrize("n,T,B", [(20, 6, 2), (64, 5, 2), (48, 12, 2), (32, 9, 3), (64, 9, 2), (16, 7, 2), (64, 2, 1)])
+@pytest.mark.parametrize("n,T,B", [(20, 6, 2), (64, 5, 2), (48, 12, 2), (32, 9, 3), (64, 9, 2), (16, 7, 2), (64, 2, 1),
+                                   (64, 40, 3), (40, 33, 2)])
 def test_tile_estep_inhomogeneous_batched_pairs(n, T, B):
     rng = np.random.default_rng(5 * n + T)
     init = rand_lds_natparam(n, rng)[0]
