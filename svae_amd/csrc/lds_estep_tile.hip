@@ -30,9 +30,6 @@
 #include "dpp.hpp"
 #include "lds_args.hpp"
 
-#ifndef SVAE_TILE_EXP
-#define SVAE_TILE_EXP 0
-#endif
 #ifndef SVAE_TILE_SGB
 #define SVAE_TILE_SGB 5
 #endif
@@ -386,17 +383,9 @@ __global__ __launch_bounds__(256, 2) void lds_estep_tile_kernel(const LdsArgs a,
 #pragma unroll
           for (int q = 0; q < cnt; ++q) {
             d4 cn = cq, bn = bq;
-#if SVAE_TILE_EXP == 2     // timing experiment (wrong results): no accumulator loads
-            if (q + 1 < cnt) { bn = ld_b(16 * k, jmap(q + 1)); }
-#else
             if (q + 1 < cnt) { cn = ld_b(16 * i, jmap(q + 1)); bn = ld_b(16 * k, jmap(q + 1)); }
-#endif
             const d4 rq = mma16(nfa, bq, cq);
-#if SVAE_TILE_EXP != 1     // timing experiment (wrong results): no stores
             if (q > 0) st_c(16 * i, jmap(q - 1), rprev);
-#else
-            if (q > 0) asm volatile("" :: "v"(rprev));
-#endif
             rprev = rq; cq = cn; bq = bn;
             SVAE_SGB(1, 4, 2, 1)
           }
