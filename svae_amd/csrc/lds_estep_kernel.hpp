@@ -500,17 +500,25 @@ __global__ __launch_bounds__(64) void lds_sample_kernel(const SampleArgs a) {
     double Xn[N];
     static_for<0, N>([&](auto k) { Xn[k] = 0.0; });
     double one = 1.0;
-    for (int t = T - 1; t >= 0; --t) {
+    // operands of one step, fetched one step ahead (raw: no arithmetic before their step, and every
+    // load unconditional -- lanes >= N read row 0 and are masked when used)
+    double Hn[N + 1], Rn[N], Yn[N], pvn;
+    auto fetch = [&](int t) {
       const double* w2 = ws2b + (long)t * (N * N + N);
-      double H[N + 1], R[N];
-      if (col) load_row<N + 1>(wsb + (long)t * WS + cc * HS, H);       // H[j] = H[c][j]
-      else static_for<0, N + 1>([&](auto k) { H[k] = 0.0; });
-      static_for<0, N>([&](auto k) { R[k] = col ? w2[k * N] : 0.0; });
-      const double pv = col ? w2[N * N] : 1.0;
-      double dis = 1.0 / sqrt(pv);             // lane k: D_k^-1/2
+      load_row<N + 1>(wsb + (long)t * WS + cc * HS, Hn);                 // H[j] = H[c][j]
+      static_for<0, N>([&](auto k) { Rn[k] = w2[k * N]; });
+      pvn = w2[N * N];
       const double* e = a.eps + (((long)b * T + t) * S + ss) * N;
-      double Y[N];
-      static_for<0, N>([&](auto k) { Y[k] = e[k]; });
+      static_for<0, N>([&](auto k) { Yn[k] = e[k]; });
+    };
+    fetch(T - 1);
+    for (int t = T - 1; t >= 0; --t) {
+      double H[N + 1], R[N], Y[N];
+      static_for<0, N + 1>([&](auto k) { H[k] = col ? Hn[k] : 0.0; });
+      static_for<0, N>([&](auto k) { R[k] = col ? Rn[k] : 0.0; Y[k] = Yn[k]; });
+      const double pv = col ? pvn : 1.0;
+      if (t > 0) fetch(t - 1);
+      double dis = 1.0 / sqrt(pv);             // lane k: D_k^-1/2
       dpp_fence(H);
       dpp_fence(R);
       dpp_fence(dis);
