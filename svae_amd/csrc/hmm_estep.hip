@@ -114,9 +114,17 @@ __global__ __launch_bounds__(64) void hmm_estep_kernel(const HmmArgs a) {
     if (valid && col) oS[(long)(T - 1) * K] = gam;
     if (T == 1 && valid && col) a.E_init[(long)b * K + c] = gam;
   }
+  // (u, alpha) of a step are fetched one step ahead: the loop is serial in t and the forward pass
+  // wrote them ~T steps ago
+  double u_n = T > 1 ? wsb[(long)(T - 1) * 32 + 16] : 0.0, al_n = T > 1 ? wsb[(long)(T - 2) * 32] : 0.0;
   for (int t = T - 2; t >= 0; --t) {
-    const double u = wsb[(long)(t + 1) * 32 + 16];     // e_{t+1} / c_{t+1}
-    const double al = wsb[(long)t * 32];
+    const double u = u_n;                              // e_{t+1} / c_{t+1}
+    const double al = al_n;
+    {
+      const int tp = t > 0 ? t - 1 : 0;                // unconditional (clamped) prefetch of step t-1
+      u_n = wsb[(long)(tp + 1) * 32 + 16];
+      al_n = wsb[(long)tp * 32];
+    }
     double w = u * beta;
     double al_f = al;
     dpp_fence(w);
