@@ -17,7 +17,10 @@
 //             wavefront with the DPP elimination of the register path (pivots -> log det P), which
 //             leaves U = L^-1 and D^-1; the block row is then A_kk^-1 A_kj = U' D^-1 (U A_kj), two
 //             tile products (applying the explicit inverse tile instead costs 2 digits on
-//             ill-conditioned models).
+//             ill-conditioned models).  Look-ahead: while wavefronts 1..3 eliminate with block
+//             pivot k (one tile row each), wavefront 0 updates and factors pivot tile k+1; the
+//             first pivot tile of the next step is factored while the others reload the right-hand
+//             sides.  Pair-parameter operands come pre-packed in fragment order (tile_pack_pairs_kernel).
 //             Then the Schur step  P' = (J22 + J11) - J12' X,  h' = J12' c + node_h.
 //   backward  moment form:  W = Sigma_{t+1} X',  Sigma_t = P^-1 + X W,  m_t = c + X m_{t+1};
 //             tile column j of W stays in registers (the MFMA C layout IS the B-operand layout)
