@@ -123,6 +123,8 @@ __device__ __forceinline__ void factor_pivot_tile(const double* tile, int ld, do
     const double r = __builtin_fma(Ep, 1.0 - pv, A[p]) * rinv;       // lane p: 1/pivot
     // row updates in groups of four: the four lane-p clears first (independent), then the four DPP
     // multiply-accumulates, so that no instruction waits for its predecessor's 8-cycle latency
+    // (the exact two-instruction form: the single-FMA form of the register path, gauss_jordan in
+    // lds_estep_kernel.hpp, loses a factor 3 on ill-conditioned n = 64 models here and gains nothing)
     auto update4 = [&](auto i0, auto cnt) {
       constexpr int I0 = decltype(i0)::value, C = decltype(cnt)::value;
       double olds[C], accs[C];
