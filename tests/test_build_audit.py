@@ -39,3 +39,20 @@ def test_estep_kernel_isa_has_no_dpp_hazards(n, tmp_path):
     if n <= 10:                                   # the headline sizes must not spill at all
         txt = out.read_text()
         assert "scratch_" not in txt and "v_accvgpr" not in txt
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+@pytest.mark.parametrize("unit,n,min_dpp", [("lds_vjp_n.hip", 10, 3000), ("lds_estep_tile.hip", None, 2000),
+                                           ("hmm_estep.hip", None, 200)])
+def test_other_dpp_units_have_no_hazards(unit, n, min_dpp, tmp_path):
+    """The VJP sweeps (one fence per product stage), the pivot-tile factorisation of the tiled path
+    and the HMM kernel use the same inline-asm DPP forms: same audit."""
+    out = tmp_path / (unit + ".s")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S",
+           os.path.join(ROOT, "svae_amd/csrc", unit), "-o", str(out)]
+    if n is not None:
+        cmd.insert(4, "-DSVAE_N=%d" % n)
+    subprocess.run(cmd, check=True, capture_output=True)
+    ndpp, probs = audit_dpp_hazards.audit(str(out))
+    assert ndpp > min_dpp, ndpp
+    assert probs == [], "\n".join(probs[:10])
