@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="lds10")
     ap.add_argument("--seqs-per-gpu", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel", choices=["auto", "twoend", "split", "packed"], default="auto",
+                    help="A/B measurements: force one of the E-step kernels (n <= 15)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -85,6 +87,11 @@ def main():
     from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials
     from svae_amd.parallel import allreduce_global_stats
 
+    from svae_amd import _lib
+    lib = _lib.load()
+    if args.kernel != "auto":
+        lib.svae_lds_set_twoend(1 if args.kernel == "twoend" else 0)
+        lib.svae_lds_set_split_max_b(1 << 30 if args.kernel == "split" else (0 if args.kernel == "packed" else 1023))
     T, n, B = WORKLOADS[args.workload]
     B = args.seqs_per_gpu or B
     init, pair = rand_lds_natparam(n, np.random.default_rng(0))       # replicated global params
@@ -137,12 +144,14 @@ def main():
 
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
     # which E-step kernel the library dispatched to (include/svae_hip.h: svae_lds_set_split_max_b)
-    from svae_amd import _lib
-    lib = _lib.load()
     split_max = lib.svae_lds_set_split_max_b(0)
     lib.svae_lds_set_split_max_b(split_max)
+    twoend = lib.svae_lds_set_twoend(1)
+    lib.svae_lds_set_twoend(twoend)
     kernel = ("svae::lds_estep_split_kernel<%d,false,false>" if B <= split_max
               else "svae::lds_estep_kernel<%d,false,false>") % n
+    if twoend and n <= 10 and T >= 4:
+        kernel = "svae::lds_estep_twoend_kernel<%d,false>" % n
     if n > _lib.LDS_MAX_N:
         kernel = "svae::lds_estep_tile_kernel<%d,false>" % ((n + 15) // 16)
     # HBM traffic of that kernel from the committed rocprofv3 PMC passes (separate runs of this

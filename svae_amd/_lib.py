@@ -25,6 +25,7 @@ SIGNATURES = {
     "svae_lds_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
     "svae_lds_workspace_bytes_ex": (ctypes.c_size_t, [ctypes.c_int] * 5),
     "svae_lds_set_split_max_b": (ctypes.c_int, [ctypes.c_int]),
+    "svae_lds_set_twoend": (ctypes.c_int, [ctypes.c_int]),
     "svae_lds_estep_f64": (ctypes.c_int, [ctypes.c_int] * 6 + [_c_double_p] * 15
                            + [_c_int_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "svae_lds_reduce_stats_f64": (ctypes.c_int, [ctypes.c_int] * 2 + [_c_double_p] * 4

@@ -15,6 +15,19 @@ constexpr int ws_step_doubles(int n) { return n * (ws_h_stride(n) + ws_p_stride(
 constexpr int ws_zpage_doubles(int n) { return ws_h_stride(n) + ws_p_stride(n); }
 constexpr long ws_seq_doubles(int n, int T) { return ws_zpage_doubles(n) + (long)T * ws_step_doubles(n); }
 
+// ---- workspace geometry of the two-ended kernel (lds_estep_twoend.hpp) -------------------------------
+// per chain (2 per sequence): a constant page, then one record per local step 0 .. T/2
+constexpr int te_row_doubles(int n) { return 2 * n + 2; }           // [P^-1 row (n) | X row (n) | c_i | pad]
+constexpr int te_step_doubles(int n) { return n * te_row_doubles(n); }
+constexpr int te_page_doubles(int n) { return 2 * (n + 2); }        // [e_n (n+2) | zeros (n+2)]
+constexpr int te_elims(int T) { return T / 2; }                     // eliminations per chain
+constexpr long te_chain_doubles(int n, int T) {
+  return te_page_doubles(n) + (long)(te_elims(T) + 1) * te_step_doubles(n);
+}
+constexpr long te_seq_doubles(int n, int T) { return 2 * te_chain_doubles(n, T); }
+constexpr int TE_MAX_N = 10;
+constexpr int TE_MIN_T = 4;
+
 struct LdsArgs {
   int B, T;
   const double* __restrict__ init_J;
@@ -37,9 +50,6 @@ struct LdsArgs {
   double* __restrict__ ws2;   // factor region for the sampler (nullptr: not kept)
   double* __restrict__ ws3;   // cross-moment region for the VJP: W~_t, (n+1) rows x ws_h_stride per step
   long pair_seq_stride;  // doubles between consecutive sequences' pair blocks (0 = shared)
-  int rows_per_wave;     // sequences per wavefront: 4 (throughput) .. 1 (latency, small batches)
-  int debug_flags;       // timing ablations only (env SVAE_LDS_DEBUG_FLAGS): 1 = skip backward half,
-                         // 2 = skip the Schur/product stage of the forward half.  Results are wrong.
 };
 
 struct SampleArgs {

@@ -11,6 +11,7 @@
 extern "C" {
 #define SVAE_DECL_(NN) int svae_lds_launch_n##NN(const svae::LdsArgs*, int, void*); \
   int svae_lds_launch_split_n##NN(const svae::LdsArgs*, int, void*);           \
+  int svae_lds_launch_twoend_n##NN(const svae::LdsArgs*, int, void*);          \
   int svae_lds_sample_n##NN(const svae::SampleArgs*, void*);                   \
   int svae_lds_vjp_n##NN(const svae::VjpArgs*, void*);
 #define SVAE_DECL(NN) SVAE_DECL_(NN)
@@ -61,42 +62,36 @@ __global__ __launch_bounds__(256) void lds_reduce_stats_kernel(int B, int n, con
 
 extern "C" {
 
-// Sequences per wavefront.  4 fills every DPP row (best throughput once the batch covers the chip);
-// override with SVAE_LDS_ROWS_PER_WAVE=1|2|4 (experiments).
-static int svae_lds_rows_per_wave(int B) {
-  (void)B;
-  static int cached = 0;
-  if (!cached) {
-    const char* e = getenv("SVAE_LDS_ROWS_PER_WAVE");
-    int v = e ? atoi(e) : 4;
-    cached = (v == 1 || v == 2 || v == 4) ? v : 4;
-  }
-  return cached;
-}
-
-// Batches up to this size run the latency variant (one sequence per wavefront, product stages split
-// across the DPP rows: lds_estep_split.hpp); larger ones the packed kernel (four sequences per
-// wavefront).  Measured crossover on MI355X (T=200, n=10): B ~ 1024 (one wavefront per SIMD).
-// Override: SVAE_LDS_SPLIT_MAX_B (0 = never).
-static int g_split_max_b = -1;
-static int svae_lds_split_max_b(void) {
-  if (g_split_max_b < 0) {
-    const char* e = getenv("SVAE_LDS_SPLIT_MAX_B");
-    g_split_max_b = e ? atoi(e) : 1023;
-    if (g_split_max_b < 0) g_split_max_b = 0;
-  }
-  return g_split_max_b;
-}
+// Kernel selection for keep == 0 (no sampler / VJP hand-off), n <= 10, T >= 4: the two-ended kernel
+// (lds_estep_twoend.hpp: one sequence per wavefront, both elimination chains in one instruction
+// stream).  Otherwise batches up to g_split_max_b run the one-directional latency variant (one sequence
+// per wavefront, product stages split across the DPP rows: lds_estep_split.hpp), larger ones the
+// packed kernel (four sequences per wavefront).  Measured crossover split/packed on MI355X
+// (T=200, n=10): B ~ 1024 (one wavefront per SIMD).  svae_lds_set_split_max_b / svae_lds_set_twoend
+// exist for A/B measurements and for the tests that run every kernel.
+static int g_split_max_b = 1023;
+static int g_twoend = 1;
 
 int svae_lds_set_split_max_b(int max_b) {
-  const int old = svae_lds_split_max_b();
+  const int old = g_split_max_b;
   g_split_max_b = max_b < 0 ? 0 : max_b;
+  return old;
+}
+
+int svae_lds_set_twoend(int on) {
+  const int old = g_twoend;
+  g_twoend = on ? 1 : 0;
   return old;
 }
 
 int svae_hip_abi_version(void) { return SVAE_HIP_ABI_VERSION; }
 
-static size_t main_ws_doubles(int B, int T, int n) { return (size_t)B * svae::ws_seq_doubles(n, T); }
+// main region: the larger of the one-directional layout (lds_args.hpp) and the two-ended one
+static size_t main_ws_doubles(int B, int T, int n) {
+  const long one = svae::ws_seq_doubles(n, T);
+  const long two = n <= svae::TE_MAX_N ? svae::te_seq_doubles(n, T) : 0;
+  return (size_t)B * (size_t)(one > two ? one : two);
+}
 static size_t factor_ws_doubles(int B, int T, int n) { return (size_t)B * T * (n * n + n); }
 static size_t cross_ws_doubles(int B, int T, int n) { return (size_t)B * T * (n + 1) * svae::ws_h_stride(n); }
 
@@ -153,12 +148,24 @@ int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int k
   a.ws3 = (keep & 2) ? (double*)workspace + main_ws_doubles(B, T, n) + factor_ws_doubles(B, T, n) : nullptr;
   a.pair_seq_stride = pair_batched ? (long)(T - 1) * n * n : 0;
   if (n > SVAE_LDS_MAX_N) {
-    a.ws2 = a.ws3 = nullptr; a.rows_per_wave = 1; a.debug_flags = 0;
+    a.ws2 = a.ws3 = nullptr;
     return svae_lds_launch_tile(&a, n, inhomog, stream);
   }
-  a.rows_per_wave = svae_lds_rows_per_wave(B);
-  const bool split = B <= svae_lds_split_max_b();
-  { const char* e = getenv("SVAE_LDS_DEBUG_FLAGS"); a.debug_flags = e ? atoi(e) : 0; }
+  const bool split = B <= g_split_max_b;
+  if (g_twoend && !keep && n <= svae::TE_MAX_N && T >= svae::TE_MIN_T) {
+    switch (n) {
+#define SVAE_CASE_(NN) case NN: return svae_lds_launch_twoend_n##NN(&a, inhomog, stream);
+#define SVAE_CASE(NN) SVAE_CASE_(NN)
+#ifdef SVAE_ONLY_N
+      SVAE_CASE(SVAE_ONLY_N)
+#else
+      SVAE_CASE(1) SVAE_CASE(2) SVAE_CASE(3) SVAE_CASE(4) SVAE_CASE(5) SVAE_CASE(6) SVAE_CASE(7)
+      SVAE_CASE(8) SVAE_CASE(9) SVAE_CASE(10)
+#endif
+#undef SVAE_CASE
+#undef SVAE_CASE_
+    }
+  }
   switch (n) {
 #define SVAE_CASE_(NN) case NN: return split ? svae_lds_launch_split_n##NN(&a, inhomog, stream) \
                                              : svae_lds_launch_n##NN(&a, inhomog, stream);

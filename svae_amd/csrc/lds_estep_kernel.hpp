@@ -190,8 +190,7 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
   constexpr bool LOWREG = N > 10;
   const int lane = threadIdx.x;
   const int c = lane & 15;
-  if ((lane >> 4) >= a.rows_per_wave) return;       // experiments: fewer sequences per wave
-  const int brow = blockIdx.x * a.rows_per_wave + (lane >> 4);
+  const int brow = blockIdx.x * 4 + (lane >> 4);
   const bool valid = brow < a.B;
   const int b = valid ? brow : a.B - 1;   // surplus rows recompute the last sequence, stores masked
   const bool col = c < N;
@@ -307,7 +306,7 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
     if (st) static_for<0, N>([&](auto i) { w[N * HS + i * PS + c] = P[i]; });
     TICK(2)
 
-    if (!last && !(a.debug_flags & 2)) {
+    if (!last) {
       // next pivot block  A' = (J22 + J11) - J12' P^-1 J12  (lanes < N),  h_pred' = -J12' c  (lane N)
       const bool next_last = (t + 1 == T - 1);
       if (!INHOMOG && next_last) {
@@ -352,7 +351,6 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
   if (valid && c == 0) { for (int q = 0; q < 4; ++q) a.E_init[(long)b * (N * N + N) + q] = (double)tm[q]; }
   return;
 #endif
-  if (a.debug_flags & 1) return;
   // ---- backward pass in moment form on homogeneous coordinates ---------------------------------
   // S[i] = row i of S~ (i = 0..N), lane c = column c (c = 0..N).  Start from S~_T := e_N e_N' so
   // that the generic step at t = T-1 (where G = 0, c = mu_{T-1}) yields [[Sigma+mu mu', mu],[mu',1]].
@@ -474,7 +472,7 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
 
 template <int N>
 static int launch_estep(const LdsArgs& a, bool inhomog, hipStream_t stream) {
-  dim3 grid((a.B + a.rows_per_wave - 1) / a.rows_per_wave), block(64);
+  dim3 grid((a.B + 3) / 4), block(64);
   const bool chol = a.ws2 != nullptr;
   if (inhomog && chol)
     hipLaunchKernelGGL((lds_estep_kernel<N, true, true>), grid, block, 0, stream, a);

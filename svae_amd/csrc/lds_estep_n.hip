@@ -7,6 +7,7 @@
 #endif
 #include "lds_estep_kernel.hpp"
 #include "lds_estep_split.hpp"
+#include "lds_estep_twoend.hpp"
 
 #ifndef SVAE_N
 #error "compile with -DSVAE_N=<latent dim>"
@@ -24,4 +25,8 @@ extern "C" int SVAE_CAT(svae_lds_sample_n, SVAE_N)(const svae::SampleArgs* a, vo
 
 extern "C" int SVAE_CAT(svae_lds_launch_split_n, SVAE_N)(const svae::LdsArgs* a, int inhomog, void* stream) {
   return svae::launch_estep_split<SVAE_N>(*a, inhomog != 0, (hipStream_t)stream);
+}
+
+extern "C" int SVAE_CAT(svae_lds_launch_twoend_n, SVAE_N)(const svae::LdsArgs* a, int inhomog, void* stream) {
+  return svae::launch_estep_twoend<SVAE_N>(*a, inhomog != 0, (hipStream_t)stream);
 }

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(64) void lds_estep_split_kernel(const LdsArgs a) {
     if (g == 0 && c <= N) static_for<0, N>([&](auto i) { w[i * HS + c] = X[i]; });
     if (g == 0 && col) static_for<0, N>([&](auto i) { w[N * HS + i * PS + c] = P[i]; });
 
-    if (!last && !(a.debug_flags & 2)) {
+    if (!last) {
       // next pivot block, slot layout:  An_D[j] = C[j] + sum_k bcast_k(NJ12T[j]) X[k];  lane N: h_pred'
       double AnD[J];
       const bool next_last = (t + 1 == T - 1);
@@ -185,7 +185,6 @@ __global__ __launch_bounds__(64) void lds_estep_split_kernel(const LdsArgs a) {
     }
   }
 
-  if (a.debug_flags & 1) return;
   // ---- backward pass: S~ in slot layout (row i = 4j+g in DPP row g), W~ gathered per step ---------
   double S[J1];
   static_for<0, J1>([&](auto j) { S[j] = (4 * j + g == N) ? EN : 0.0; });
