@@ -67,7 +67,7 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="lds10")
     ap.add_argument("--seqs-per-gpu", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--kernel", choices=["auto", "twoend", "split", "packed"], default="auto",
+    ap.add_argument("--kernel", choices=["auto", "twoend", "twoend_full", "split", "packed"], default="auto",
                     help="A/B measurements: force one of the E-step kernels (n <= 15)")
     args = ap.parse_args()
 
@@ -90,7 +90,7 @@ def main():
     from svae_amd import _lib
     lib = _lib.load()
     if args.kernel != "auto":
-        lib.svae_lds_set_twoend(1 if args.kernel == "twoend" else 0)
+        lib.svae_lds_set_twoend({"twoend": 1, "twoend_full": 2}.get(args.kernel, 0))
         lib.svae_lds_set_split_max_b(1 << 30 if args.kernel == "split" else (0 if args.kernel == "packed" else 1023))
     T, n, B = WORKLOADS[args.workload]
     B = args.seqs_per_gpu or B
@@ -151,7 +151,7 @@ def main():
     kernel = ("svae::lds_estep_split_kernel<%d,false,false>" if B <= split_max
               else "svae::lds_estep_kernel<%d,false,false>") % n
     if twoend and n <= 10 and T >= 4:
-        kernel = "svae::lds_estep_twoend_kernel<%d,false>" % n
+        kernel = "svae::lds_estep_twoend_kernel<%d,false,%s>" % (n, "true" if twoend == 1 else "false")
     if n > _lib.LDS_MAX_N:
         kernel = "svae::lds_estep_tile_kernel<%d,false>" % ((n + 15) // 16)
     # HBM traffic of that kernel from the committed rocprofv3 PMC passes (separate runs of this

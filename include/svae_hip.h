@@ -84,13 +84,14 @@ int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int k
 
 /* Kernel selection for svae_lds_estep_f64 (n <= SVAE_LDS_MAX_N).  With keep == 0, n <= 10 and T >= 4
  * the two-ended kernel runs (block elimination from both ends of the chain, meeting in the middle:
- * half the serial depth; svae_lds_set_twoend(0) turns it off).  Otherwise batches with B <= max_b run
+ * half the serial depth; svae_lds_set_twoend: 1 = with the lean hand-off record (default), 2 = with the
+ * full record, 0 = off).  Otherwise batches with B <= max_b run
  * the one-directional small-batch variant (one sequence per wavefront, product stages split across
  * the four DPP rows), larger ones the packed kernel (four sequences per wavefront); default 1023,
  * 0 = never.  All three give the same results up to rounding.  Each setter returns the previous
  * value.  Host only (no environment variables are read). */
 int svae_lds_set_split_max_b(int max_b);
-int svae_lds_set_twoend(int on);
+int svae_lds_set_twoend(int mode);
 
 /* Deterministic sum over the batch of the per-sequence global statistics (the quantity that is
  * all-reduced across GPUs for the natural-gradient step, svae.py:33-34):

@@ -19,7 +19,8 @@ constexpr long ws_seq_doubles(int n, int T) { return ws_zpage_doubles(n) + (long
 // per chain (2 per sequence): a constant page, then one record per local step 0 .. T/2
 constexpr int te_row_doubles(int n) { return 2 * n + 2; }           // [P^-1 row (n) | X row (n) | c_i | pad]
 constexpr int te_step_doubles(int n) { return n * te_row_doubles(n); }
-constexpr int te_page_doubles(int n) { return 2 * (n + 2); }        // [e_n (n+2) | zeros (n+2)]
+constexpr int te_lean_step_doubles(int n) { return (n * (n + 1) / 2 + n + 3) & ~1; }   // lean record: [tril P^-1 | c | 0 | trash]
+constexpr int te_page_doubles(int n) { return 2 * (n + 2) + 2; }    // [e_n (n+2) | zeros (n+2) | trash (2)]
 constexpr int te_elims(int T) { return T / 2; }                     // eliminations per chain
 constexpr long te_chain_doubles(int n, int T) {
   return te_page_doubles(n) + (long)(te_elims(T) + 1) * te_step_doubles(n);

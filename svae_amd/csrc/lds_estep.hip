@@ -11,7 +11,7 @@
 extern "C" {
 #define SVAE_DECL_(NN) int svae_lds_launch_n##NN(const svae::LdsArgs*, int, void*); \
   int svae_lds_launch_split_n##NN(const svae::LdsArgs*, int, void*);           \
-  int svae_lds_launch_twoend_n##NN(const svae::LdsArgs*, int, void*);          \
+  int svae_lds_launch_twoend_n##NN(const svae::LdsArgs*, int, int, void*);          \
   int svae_lds_sample_n##NN(const svae::SampleArgs*, void*);                   \
   int svae_lds_vjp_n##NN(const svae::VjpArgs*, void*);
 #define SVAE_DECL(NN) SVAE_DECL_(NN)
@@ -78,9 +78,9 @@ int svae_lds_set_split_max_b(int max_b) {
   return old;
 }
 
-int svae_lds_set_twoend(int on) {
+int svae_lds_set_twoend(int mode) {
   const int old = g_twoend;
-  g_twoend = on ? 1 : 0;
+  g_twoend = (mode == 1 || mode == 2) ? mode : 0;
   return old;
 }
 
@@ -154,7 +154,7 @@ int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int k
   const bool split = B <= g_split_max_b;
   if (g_twoend && !keep && n <= svae::TE_MAX_N && T >= svae::TE_MIN_T) {
     switch (n) {
-#define SVAE_CASE_(NN) case NN: return svae_lds_launch_twoend_n##NN(&a, inhomog, stream);
+#define SVAE_CASE_(NN) case NN: return svae_lds_launch_twoend_n##NN(&a, inhomog, g_twoend == 1, stream);
 #define SVAE_CASE(NN) SVAE_CASE_(NN)
 #ifdef SVAE_ONLY_N
       SVAE_CASE(SVAE_ONLY_N)

@@ -27,6 +27,6 @@ extern "C" int SVAE_CAT(svae_lds_launch_split_n, SVAE_N)(const svae::LdsArgs* a,
   return svae::launch_estep_split<SVAE_N>(*a, inhomog != 0, (hipStream_t)stream);
 }
 
-extern "C" int SVAE_CAT(svae_lds_launch_twoend_n, SVAE_N)(const svae::LdsArgs* a, int inhomog, void* stream) {
-  return svae::launch_estep_twoend<SVAE_N>(*a, inhomog != 0, (hipStream_t)stream);
+extern "C" int SVAE_CAT(svae_lds_launch_twoend_n, SVAE_N)(const svae::LdsArgs* a, int inhomog, int lean, void* stream) {
+  return svae::launch_estep_twoend<SVAE_N>(*a, inhomog != 0, lean != 0, (hipStream_t)stream);
 }

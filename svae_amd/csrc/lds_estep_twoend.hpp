@@ -45,6 +45,23 @@ __device__ __forceinline__ void pair_split(double x, double& even_row, double& o
   odd_row = __hiloint2double(rh[1], rl[1]);
 }
 
+// Loads / stores the compiler's memory-counter bookkeeping does not see (see the forward loop: hipcc
+// merges the counter state of the loop entry with the back edge's and would wait for the previous
+// step's hand-off stores before touching a value prefetched a whole step earlier).
+__device__ __forceinline__ double asm_load(const double* p) {
+  double r;
+  asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
+  return r;
+}
+__device__ __forceinline__ void asm_store(double* p, double v) {
+  asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(p), "v"(v) : "memory");
+}
+// wait until at most CNT vector-memory operations issued after the loads of (x, y) are outstanding
+template <int CNT>
+__device__ __forceinline__ void asm_wait_loaded(double& x, double& y) {
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(x), "+v"(y) : "n"(CNT));
+}
+
 __device__ __forceinline__ double asm_sub(double a, double b) {        // a - b, kept in program order
   double r;
   asm volatile("v_add_f64 %0, %1, -%2" : "=v"(r) : "v"(a), "v"(b));
@@ -114,15 +131,22 @@ __device__ __forceinline__ void gauss_jordan_1r(double (&M)[N], const double (&E
 #define TE_TICK(i)
 #endif
 
-template <int N, bool INHOMOG>
+// LEAN hand-off (the default): per (chain, step) only the lower triangle of P^-1 and c = P^-1 h_filt
+// (te_lean_step_doubles: 68 doubles at n = 10 instead of 220); the smoother rebuilds G = -P^-1 J12 with one
+// split product per step and transposes it through 3 KB of LDS.  Algorithmic HBM bytes x ~4 instead of x 11.
+template <int N, bool INHOMOG, bool LEAN>
 __global__ __launch_bounds__(64) void lds_estep_twoend_kernel(const LdsArgs a) {
   static_assert(N >= 1 && N <= TE_MAX_N && N + ((N - 1) >> 1) <= 14,
                 "the right-hand-side columns must fit lanes N..14 of two DPP rows");
-  constexpr int RW = te_row_doubles(N), WS = te_step_doubles(N), ZP = te_page_doubles(N);
+  constexpr int RW = te_row_doubles(N), ZP = te_page_doubles(N);
+  constexpr int WS = LEAN ? te_lean_step_doubles(N) : te_step_doubles(N);
+  constexpr int TRI = N * (N + 1) / 2;    // LEAN record: [lower triangle | c (N) | 0.0 | trash | pad]
+  constexpr int LZERO = TRI + N, LTRASH = TRI + N + 1;
   constexpr int J = (N + 1) / 2;          // slots holding rows 0..N-1 (row i = 2j + gl)
   constexpr int J1 = (N + 2) / 2;         // slots holding rows 0..N
   constexpr int HL = 15;                  // lane of the h column
-  __shared__ double tab[2 * 16 * 16];     // final transpose of chain B's cross-moment sums
+  constexpr int RSL = (N + 3) & ~1;       // LDS row stride of the transposition tile (even, >= N + 1)
+  __shared__ double tab[2 * 16 * 16];     // [chain][row 0..15][RSL]: G~ rows for the transposed read
 
   const int lane = threadIdx.x;
   const int c = lane & 15;
@@ -157,21 +181,21 @@ __global__ __launch_bounds__(64) void lds_estep_twoend_kernel(const LdsArgs a) {
   //   NJ12c[k]: lanes < N: nat J12'[k][c] (= -J12'[k][c]); other lanes 0
   //   Cc[j] (row i = 2j+gl): lanes < N: info-form J22'(pair l) + J11'(pair l+1); other lanes 0
   double EX[N], NJ12c[N], Cc[J];
-  auto load_pair = [&](int l) {
+  auto load_pair = [&](int l, bool with_cc) {
     const long o = pair_off(l), o1 = pair_off(l + 1);
     static_for<0, N>([&](auto i) {
       const double rx = q12[o + i * si + xx * sc], rc = q12[o + i * si + cc * sc];
       EX[i] = xok ? -rx : E[i];
       NJ12c[i] = col ? rc : 0.0;
     });
-    static_for<0, J>([&](auto j) {
+    if (with_cc) static_for<0, J>([&](auto j) {
       const int i = 2 * j + gl;
       const int ii = i < N ? i : 0;
       const double r22 = q22[o + ii * N + cc], r11 = q11[o1 + ii * N + cc];
       Cc[j] = (col && i < N) ? -2.0 * (r22 + r11) : 0.0;
     });
   };
-  if (!INHOMOG) load_pair(0);
+  if (!INHOMOG) load_pair(0, true);
 
   // ---- elimination (filter) phase -------------------------------------------------------------------
   // An (replicated over the chain's two DPP rows): lanes < N = pivot block of the next node without its
@@ -191,23 +215,41 @@ __global__ __launch_bounds__(64) void lds_estep_twoend_kernel(const LdsArgs a) {
   const double* nhb = a.node_h + ((long)b * T) * N + cc;
   auto node_off = [&](int s) -> long { return (long)(dir ? T - 1 - s : s) * N; };
 
-  double* zpage = a.ws + ((long)b * 2 + dir) * te_chain_doubles(N, T);   // [e_N | zeros]
+  // chain workspace: constant page [e_N (N+2) | zeros (N+2) | trash (2)], then the records
+  double* wsb = a.ws + (long)b * te_seq_doubles(N, T);            // uniform: this sequence's two chains
+  const unsigned choff = (unsigned)(dir * te_chain_doubles(N, T)) + ZP;   // per lane: its chain's records
+  double* zpage = wsb + (long)dir * te_chain_doubles(N, T);
   double* rec0 = zpage + ZP;
+  double* trash = zpage + 2 * (N + 2);
   if (gl == 0) {
     if (c < N + 2) zpage[c] = EN;
     if (c < N + 2) zpage[N + 2 + c] = 0.0;
   }
-  // hand-off store of register i: one instruction, per-lane destination inside row i of the record
+  // hand-off store of register i: ONE unconditional instruction (a conditional one would make hipcc
+  // wait for the previous step's stores at the loop head); lanes with nothing to hand over write the
+  // record's trash / pad entry.
+  //   full:  row i of the record = [P^-1 row | X row | c_i | pad]:       base + i * RW + stoff
+  //   LEAN:  [lower triangle | c | 0.0 | trash]: lane c <= i -> tri(i) + c, lane 15 -> TRI + i
   const bool stp = (gl == 0 && col) || xok || (gl == 0 && c == HL);
-  const int stoff = col ? c : (c == HL ? 2 * N : N + xx);
+  const int stoff = !stp ? 2 * N + 1 : (col ? c : (c == HL ? 2 * N : N + xx));
+  unsigned loff[LEAN ? N : 1];
+  if constexpr (LEAN) {
+    static_for<0, N>([&](auto i) {
+      loff[i] = 8u * (choff + ((gl == 0 && c <= i) ? i * (i + 1) / 2 + c : ((gl == 0 && c == HL) ? TRI + i : LTRASH)));   // bytes
+    });
+    for (int q = lane; q < 2 * 16 * 16; q += 64) tab[q] = 0.0;     // rows of the transposition tile never written
+    for (int r = gl * 16 + c; r <= e; r += 32) rec0[(long)r * WS + LZERO] = 0.0;   // the records' zero entry
+  }
 
   double qacc = 0.0;        // lane 15: sum_t h' P^-1 h
   double ldM = 1.0;         // per lane c < N: running product of -1/p_c (log|P| = -sum log|.|)
   int ldE = 0;
   double vworst = -1.0;     // max over steps of -1/p_c (>= 0 <=> some pivot was not positive)
 
-  double Jo_n = nJb[node_off(0)];
-  double ho_n = nhb[node_off(0)];
+  // node potentials are prefetched one step ahead by hand (asm_load / asm_wait_loaded): exactly the N
+  // hand-off stores of a step are issued between a prefetch and its use
+  double Jo_n = asm_load(nJb + node_off(0));
+  double ho_n = asm_load(nhb + node_off(0));
   double Mp[N];             // partner chain's An at the hand-over point
   static_for<0, N>([&](auto i) { Mp[i] = 0.0; });
   // ... and this chain's log-normaliser accumulators at that point: with even T the partner's last
@@ -218,18 +260,29 @@ __global__ __launch_bounds__(64) void lds_estep_twoend_kernel(const LdsArgs a) {
     static_for<0, N>([&](auto i) { Mp[i] = __shfl_xor(An[i], 32); });
     qacc_s = qacc; ldM_s = ldM; ldE_s = ldE;
   };
+  auto hand_off = [&](int s, const double (&M)[N], double vfull) {
+    if constexpr (LEAN) {
+      char* w = reinterpret_cast<char*>(wsb + (long)s * WS);     // uniform base + 32-bit lane offset
+      static_for<0, N>([&](auto i) { *reinterpret_cast<double*>(w + loff[i]) = M[i] * vfull; });
+    } else {
+      double* w = rec0 + (long)s * WS + stoff;
+      static_for<0, N>([&](auto i) { w[i * RW] = M[i] * vfull; });
+    }
+  };
 
+  static_for<0, N>([&](auto i) { asm_store(trash, 0.0); });     // the first step's wait counts N stores too
 #ifdef SVAE_PHASE_TIMING
   long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tlast_ = __builtin_readcyclecounter();
 #endif
   for (int s = 0; s < e; ++s) {
     if (s == jx) take_partner();
+    if (INHOMOG) asm_wait_loaded<0>(Jo_n, ho_n); else asm_wait_loaded<N>(Jo_n, ho_n);
     const double JoX = col ? -2.0 * Jo_n : 1.0;
     double ho = ho_n;
-    Jo_n = nJb[node_off(s + 1)];           // s + 1 <= e: the meeting node's potentials included
-    ho_n = nhb[node_off(s + 1)];
-    if (INHOMOG) load_pair(s);
+    Jo_n = asm_load(nJb + node_off(s + 1));     // s + 1 <= e: the meeting node's potentials included
+    ho_n = asm_load(nhb + node_off(s + 1));
+    if (INHOMOG) load_pair(s, true);
 
     // condition on the node potential; right-hand sides ride in the upper lanes
     double M[N], Bt[N];
@@ -262,8 +315,7 @@ __global__ __launch_bounds__(64) void lds_estep_twoend_kernel(const LdsArgs a) {
       ldE += __builtin_amdgcn_frexp_exp(ldM);
       ldM = __builtin_amdgcn_frexp_mant(ldM);
     }
-    double* w = rec0 + (long)s * WS + stoff;
-    if (stp) static_for<0, N>([&](auto i) { w[i * RW] = M[i] * vfull; });
+    hand_off(s, M, vfull);
 
     dpp_fence(AnD);
     static_for<0, J>([&](auto j) {
@@ -281,6 +333,7 @@ __global__ __launch_bounds__(64) void lds_estep_twoend_kernel(const LdsArgs a) {
   double qacc_m = 0.0, vfull_m = col ? 0.0 : 1.0;
   {
     const long o = pair_off(e - 1), o1 = pair_off(e);
+    asm_wait_loaded<0>(Jo_n, ho_n);
     const double JoX = col ? -2.0 * Jo_n : 1.0;
     double ho = ho_n;
     double M[N];
@@ -293,8 +346,7 @@ __global__ __launch_bounds__(64) void lds_estep_twoend_kernel(const LdsArgs a) {
     static_for<0, N>([&](auto i) { mac_bc<i>(M[i], ho, EH); });
     dpp_fence(M);
     gauss_jordan_1r<N>(M, E, qacc_m, vfull_m);
-    double* w = rec0 + (long)e * WS + stoff;
-    if (stp) static_for<0, N>([&](auto i) { w[i * RW] = M[i] * vfull_m; });
+    hand_off(e, M, vfull_m);
   }
 
   // ---- log-normaliser --------------------------------------------------------------------------------
@@ -334,62 +386,119 @@ __global__ __launch_bounds__(64) void lds_estep_twoend_kernel(const LdsArgs a) {
       }
     }
   }
-#ifdef SVAE_PHASE_TIMING
   TE_TICK(4)
-#endif
 
   // ---- smoother phase: moment form on homogeneous coordinates, local steps e, e-1, .., 0 ---------------
   // S~ in slot layout (row i = 2j+gl of the (N+1) x (N+1) tile, lane = column); starts from e_N e_N' so that
   // the generic step at the meeting record (G = 0, c = mu) yields [[Sigma + mu mu', mu], [mu', 1]].
   double ED[J1];                          // ED[j][c] = (c == 2j+gl): picks S[i][i] in slot layout
   static_for<0, J1>([&](auto j) { ED[j] = (c == 2 * j + gl && c < N) ? 1.0 : 0.0; });
+  const double CN = (gl == (N & 1)) ? EN : 0.0;     // row N of G~ = e_N (slot N/2 of DPP row N & 1)
   double S[J1];
-  static_for<0, J1>([&](auto j) { S[j] = (2 * j + gl == N) ? EN : 0.0; });
+  static_for<0, J1>([&](auto j) { S[j] = (j == N / 2) ? CN : 0.0; });
   dpp_fence(S);
   double sumS[J], sumW[J], Stop[J];
   static_for<0, J>([&](auto j) { sumS[j] = 0.0; sumW[j] = 0.0; Stop[j] = 0.0; });
   const bool own_N = (gl == (N & 1));     // the DPP row holding row N (E[x_t]) in slot N/2
   // chain B, even T: its first smoother step repeats pair e-1, which chain A counts
-  const double wsp = (dir && !oddT) ? 0.0 : 1.0;
+  const bool skip2nd = dir && !oddT;
+  const bool own_e = oddT && !dir;        // who reports the meeting node
 
-  // loads of one step: replicated H[k] = [X | c][c][k] (row c of the record; lane N: e_N; lanes > N: 0)
-  // and, in slot layout / column form, Gc[j][c] = [X | c][2j+gl][c] (row N: e_N), Pi[j][c] = P^-1[2j+gl][c]
+  // node statistics: unconditional stores through per-lane walking pointers (idle lanes -> trash)
+  const bool dlane = col && (c & 1) == gl, xlane = col && own_N;
+  const long nstride = dir ? N : -N;      // towards smaller s
+  double* pdg = trash;
+  double* pex = trash + 1;
+  auto node_ptrs = [&](int s) {
+    const long o = ((long)b * T + (dir ? T - 1 - s : s)) * N + c;
+    pdg = dlane ? a.E_node_diagxx + o : trash;
+    pex = xlane ? a.E_node_x + o : trash + 1;
+  };
+  if (own_e) node_ptrs(e);
+
+  // operands of one step (prefetched one step ahead, every load unconditional)
+  //   full:  H[k] = [X | c][c][k] (row c of the record; lane N: e_N; lanes > N: 0), Gc[j][c] = [X | c][2j+gl][c]
+  //          (row N: e_N), Pi[j][c] = P^-1[2j+gl][c]
+  //   LEAN:  Pi[j] = [P^-1 | c][2j+gl][c] (lane N: c_i; rows >= N, lanes > N: the record's zero entry)
+  struct Ops { double H[LEAN ? 1 : N + 1]; double Gc[LEAN ? 1 : J1]; double Pi[J1]; };
   const double* hp_ = col ? rec0 + c * RW + N : (c == N ? zpage : zpage + N + 2);
-  const long tstride = col ? WS : 0;
-  const double* gptr[J1];
-  const double* pptr[J1];
-  long gstride[J1], pstride[J1];
+  const long hstride = col ? WS : 0;
+  const double* rp_[J1];                  // full: row i of the record at this lane's P^-1 column (page for idle lanes)
+  long rstride[J1];
+  int goff[J1];                           // full: from rp_ to this lane's entry of [X | c] (row N: e_N in the page)
+  unsigned poff[LEAN ? J1 : 1];
   static_for<0, J1>([&](auto j) {
     const int i = 2 * j + gl;
-    const bool gok = i < N && c <= N, pok = i < N && col;
-    gptr[j] = gok ? rec0 + i * RW + N + c : ((i == N && c < N + 2) ? zpage + c : zpage + N + 2);
-    pptr[j] = pok ? rec0 + i * RW + c : zpage + N + 2;
-    gstride[j] = gok ? WS : 0;
-    pstride[j] = pok ? WS : 0;
+    const bool rowok = i < N && c <= N;
+    rp_[j] = rowok ? rec0 + i * RW + cc : zpage + N + 2;
+    rstride[j] = rowok ? WS : 0;
+    goff[j] = rowok ? N + (c - cc) : ((i == N && c < N + 2) ? c - (N + 2) : 0);
+    if constexpr (LEAN) {
+      const int hi = i > c ? i : c, lo = i > c ? c : i;
+      poff[j] = 8u * (choff + ((i < N && col) ? hi * (hi + 1) / 2 + lo : ((i < N && c == N) ? TRI + i : LZERO)));   // bytes
+    }
   });
-  hp_ += (long)e * tstride;
-  static_for<0, J1>([&](auto j) { gptr[j] += (long)e * gstride[j]; pptr[j] += (long)e * pstride[j]; });
-  auto load_step = [&](double (&H)[N + 1], double (&Gc)[J1], double (&Pi)[J1]) {   // steps e, e-1, ..
-    load_row<N + 1>(hp_, H);
-    hp_ -= tstride;
-    static_for<0, J1>([&](auto j) {
-      Gc[j] = *gptr[j];
-      Pi[j] = *pptr[j];
-      gptr[j] -= gstride[j];
-      pptr[j] -= pstride[j];
-    });
+  const double cmask = col ? 1.0 : 0.0;
+  if constexpr (!LEAN) {
+    hp_ += (long)e * hstride;
+    static_for<0, J1>([&](auto j) { rp_[j] += (long)e * rstride[j]; });
+  }
+  const double* lrec = wsb + (long)e * WS;           // LEAN: uniform record pointer
+  auto load_ops = [&](Ops& o, bool more) {           // records e, e-1, .. (more: another record follows)
+    if constexpr (LEAN) {
+      static_for<0, J1>([&](auto j) { o.Pi[j] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(lrec) + poff[j]); });
+      lrec -= more ? WS : 0;
+    } else {
+      load_row<N + 1>(hp_, o.H);
+      static_for<0, J1>([&](auto j) {
+        o.Gc[j] = rp_[j][goff[j]];            // lane c: X[i][c], lane N: c_i; row N: e_N; else 0
+        o.Pi[j] = *rp_[j];                    // lane N of a real row reads P^-1[i][0]: masked where used
+      });
+      const long mv = more ? 1 : 0;
+      hp_ -= mv * hstride;
+      static_for<0, J1>([&](auto j) { rp_[j] -= mv * rstride[j]; });
+    }
   };
 
-  auto step = [&](int s, double (&H)[N + 1], double (&Gc)[J1], double (&Pi)[J1],
-                  double (&Hn)[N + 1], double (&Gcn)[J1], double (&Pin)[J1]) {
-    if (s > 0) load_step(Hn, Gcn, Pin);      // prefetch: hides the L2/HBM latency
-    dpp_fence(Gc);
-    const int t = dir ? T - 1 - s : s;
-    const bool own = s < e || (oddT && !dir);
+  // one smoother step.  KIND: 0 generic, 1 first (meeting record), 2 second (weight of the repeated pair)
+  auto step = [&](auto kind, int s, Ops& cur, Ops& nxt) {
+    constexpr int KIND = decltype(kind)::value;
+    load_ops(nxt, s > 1);                    // prefetch record s-1 (s = 0: re-reads record 0, unused)
+    if (INHOMOG && LEAN && KIND != 1) load_pair(s, false);   // G~ of step s uses pair s (the meeting record: G = 0)
+
+    double Gc[J1], H[N + 1];
+    if constexpr (LEAN) {
+      // G~ rows of this DPP row: X[i][c] = sum_k P^-1[i][k] J12'[k][c] (lanes < N), c_i (lane N); row N = e_N
+      static_for<0, J1>([&](auto j) { Gc[j] = (j == N / 2) ? __builtin_fma(EN, cur.Pi[j], CN) : EN * cur.Pi[j]; });
+      if (KIND != 1) {
+        dpp_fence(cur.Pi);
+        static_for<0, N>([&](auto k) {
+          static_for<0, J>([&](auto j) { mac_bc<k, true>(Gc[j], cur.Pi[j], NJ12c[k]); });
+        });
+      }
+      // transposed, replicated copy through LDS: H[k][lane c] = G~[c][k]
+      double* tb = tab + dir * 16 * RSL;
+      __builtin_amdgcn_wave_barrier();
+      static_for<0, J1>([&](auto j) { tb[(2 * j + gl) * RSL + c] = Gc[j]; });
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      static_for<0, (N + 2) / 2>([&](auto q) {
+        const double2 v = reinterpret_cast<const double2*>(tb + c * RSL)[q];
+        H[2 * q] = v.x;
+        if constexpr (2 * q + 1 <= N) H[2 * q + 1] = v.y;
+      });
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      static_for<0, J1>([&](auto j) { Gc[j] = cur.Gc[j]; });
+      static_for<0, N + 1>([&](auto k) { H[k] = cur.H[k]; });
+      dpp_fence(Gc);
+    }
 
     // W~[i] = S~[i] G~'  for my rows:  sum_k -/+ bcast_k(S[j]) H[k]
     double W[J1];
     static_for<0, J1>([&](auto j) { W[j] = 0.0; });
+    asm volatile("s_nop 1");
     static_for<0, N + 1>([&](auto k) {
       static_for<0, J1>([&](auto j) { mac_bc<k, (k < N)>(W[j], S[j], H[k]); });
     });
@@ -398,18 +507,20 @@ __global__ __launch_bounds__(64) void lds_estep_twoend_kernel(const LdsArgs a) {
     static_for<0, J1>([&](auto j) { pair_split(W[j], WR[2 * j], WR[(2 * j + 1 <= N) ? 2 * j + 1 : N + 1]); });
     // S~_t[i] = P^-1[i] + G~[i] W~ = Pi + sum_k -/+ bcast_k(Gc[j]) WR[k]
     double Sn[J1];
-    static_for<0, J1>([&](auto j) { Sn[j] = Pi[j]; });
+    static_for<0, J1>([&](auto j) { Sn[j] = LEAN ? __builtin_fma(-EN, cur.Pi[j], cur.Pi[j]) : cur.Pi[j] * cmask; });
     asm volatile("s_nop 1");
     static_for<0, N + 1>([&](auto k) {
       static_for<0, J1>([&](auto j) { mac_bc<k, (k < N)>(Sn[j], Gc[j], WR[k]); });
     });
 
+    const int t = dir ? T - 1 - s : s;
     if (INHOMOG) {
       // per-step pair blocks [E x_t x_t' | E x_t x_{t+1}' | E x_{t+1} x_{t+1}'] for pair index p:
       // the owner of node t writes S~_t into pair t (first block) and pair t-1 (third block); the
       // cross moment W~ = E[x~_{prev} x~_{this}'] is pair s (transposed) for A, pair T-2-s for B.
       double* EP = a.E_pair + (long)b * (T - 1) * 3 * N * N;
-      const bool crossw = s < e && !(dir && !oddT && s == e - 1);
+      const bool own = KIND != 1 || own_e;
+      const bool crossw = KIND != 1 && !(KIND == 2 && skip2nd);
       const int p = dir ? T - 2 - s : s;
       static_for<0, J>([&](auto j) {
         const int i = 2 * j + gl;
@@ -420,35 +531,42 @@ __global__ __launch_bounds__(64) void lds_estep_twoend_kernel(const LdsArgs a) {
         }
       });
     } else {
-      if (s == e) {
+      if constexpr (KIND == 1) {
         static_for<0, J>([&](auto j) { Stop[j] = Sn[j]; });
-      } else {
-        const double wgt = (s == e - 1) ? wsp : 1.0;
+      } else if constexpr (KIND == 2) {
         static_for<0, J>([&](auto j) {
-          sumS[j] = __builtin_fma(wgt, Sn[j], sumS[j]);
-          sumW[j] = __builtin_fma(wgt, W[j], sumW[j]);
+          sumS[j] = skip2nd ? 0.0 : Sn[j];
+          sumW[j] = skip2nd ? 0.0 : W[j];
+          Stop[j] = skip2nd ? Sn[j] : Stop[j];
         });
-        if (s == e - 1) static_for<0, J>([&](auto j) { Stop[j] = (wsp == 0.0) ? Sn[j] : Stop[j]; });
+      } else {
+        static_for<0, J>([&](auto j) { sumS[j] += Sn[j]; sumW[j] += W[j]; });
       }
     }
 
     // node statistics: diag E[x_t x_t'] (lane i of DPP row i & 1), E[x_t] = row N
     double dg = 0.0;
     static_for<0, J>([&](auto j) { dg = __builtin_fma(ED[j], Sn[j], dg); });
-    if (own && col && (c & 1) == gl) a.E_node_diagxx[((long)b * T + t) * N + c] = dg;
-    if (own && col && own_N) a.E_node_x[((long)b * T + t) * N + c] = Sn[N / 2];
+    *pdg = dg;
+    *pex = Sn[N / 2];
+    if constexpr (KIND == 1) node_ptrs(e - 1);
+    else { pdg += dlane ? nstride : 0; pex += xlane ? nstride : 0; }
     static_for<0, J1>([&](auto j) { S[j] = Sn[j]; });
   };
 
   {
-    double Ha[N + 1], Gca[J1], Pia[J1], Hb[N + 1], Gcb[J1], Pib[J1];
-    load_step(Ha, Gca, Pia);
-    int s = e;
-    for (; s >= 1; s -= 2) {          // two steps per trip: the prefetch buffers ping-pong
-      step(s, Ha, Gca, Pia, Hb, Gcb, Pib);
-      step(s - 1, Hb, Gcb, Pib, Ha, Gca, Pia);
+    Ops A, Bq;
+    constexpr std::integral_constant<int, 0> GEN{};
+    load_ops(A, true);
+    step(std::integral_constant<int, 1>{}, e, A, Bq);
+    step(std::integral_constant<int, 2>{}, e - 1, Bq, A);
+    int s = e - 2;
+    for (; s >= 2; s -= 2) {          // two steps per trip: the prefetch buffers ping-pong
+      step(GEN, s, A, Bq);
+      step(GEN, s - 1, Bq, A);
     }
-    if (s == 0) step(0, Ha, Gca, Pia, Hb, Gcb, Pib);
+    if (s == 1) { step(GEN, 1, A, Bq); step(GEN, 0, Bq, A); }
+    else if (s == 0) step(GEN, 0, A, Bq);
   }
 #ifdef SVAE_PHASE_TIMING
   TE_TICK(5)
@@ -458,7 +576,7 @@ __global__ __launch_bounds__(64) void lds_estep_twoend_kernel(const LdsArgs a) {
 
   // ---- global statistics ------------------------------------------------------------------------------
   // S = S~ at the chain's end node (x_0 for A, x_{T-1} for B).  Sums over the chain's pairs:
-  //   sumS = sum S~(s), s < e(weighted);  sumP = sum S~(s+1) = (sumS - S~(0)) + Stop;  sumW = sum W~(s)
+  //   sumS = sum S~(s) over its counted steps;  sumP = sum S~(s+1) = (sumS - S~(0)) + Stop;  sumW = sum W~(s)
   // A: first block += sumS, third += sumP, cross += sumW';  B: first += sumP, third += sumS, cross += sumW.
   if (!INHOMOG) {
     double sumP[J];
@@ -502,13 +620,17 @@ __global__ __launch_bounds__(64) void lds_estep_twoend_kernel(const LdsArgs a) {
 }
 
 template <int N>
-static int launch_estep_twoend(const LdsArgs& a, bool inhomog, hipStream_t stream) {
+static int launch_estep_twoend(const LdsArgs& a, bool inhomog, bool lean, hipStream_t stream) {
   if constexpr (N <= TE_MAX_N) {
     dim3 grid(a.B), block(64);
-    if (inhomog)
-      hipLaunchKernelGGL((lds_estep_twoend_kernel<N, true>), grid, block, 0, stream, a);
+    if (inhomog && lean)
+      hipLaunchKernelGGL((lds_estep_twoend_kernel<N, true, true>), grid, block, 0, stream, a);
+    else if (inhomog)
+      hipLaunchKernelGGL((lds_estep_twoend_kernel<N, true, false>), grid, block, 0, stream, a);
+    else if (lean)
+      hipLaunchKernelGGL((lds_estep_twoend_kernel<N, false, true>), grid, block, 0, stream, a);
     else
-      hipLaunchKernelGGL((lds_estep_twoend_kernel<N, false>), grid, block, 0, stream, a);
+      hipLaunchKernelGGL((lds_estep_twoend_kernel<N, false, false>), grid, block, 0, stream, a);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
   } else {
     return -3;

@@ -42,9 +42,9 @@ def test_workspace_size_formula():
     # plus one constant page (12 + 10 doubles) per sequence
     # and the cross-moment region ((n+1) rows of stride even(n+1)) per step
     # n <= 10: the main region is the larger of that and the two-ended kernel's layout (two chains per
-    # sequence: a constant page of 2(n+2) doubles + T/2 + 1 records of n rows [P^-1 | P^-1 J12 | c | pad])
+    # sequence: a constant page of 2(n+2)+2 doubles + T/2 + 1 records of n rows [P^-1 | P^-1 J12 | c | pad])
     one = lambda T, n: (n + 1 + (n + 1) % 2) + (n + n % 2) + T * n * ((n + 1 + (n + 1) % 2) + (n + n % 2))
-    two = lambda T, n: 2 * (2 * (n + 2) + (T // 2 + 1) * n * (2 * n + 2))
+    two = lambda T, n: 2 * (2 * (n + 2) + 2 + (T // 2 + 1) * n * (2 * n + 2))
     assert one(200, 10) == 22 + 200 * 10 * (12 + 10)
     assert lib.svae_lds_workspace_bytes(512, 200, 10) == 512 * (max(one(200, 10), two(200, 10)) + 200 * (10 * 10 + 10 + 11 * 12)) * 8
     assert lib.svae_lds_workspace_bytes(3, 7, 5) == 3 * (max(one(7, 5), two(7, 5)) + 7 * (5 * 5 + 5 + 6 * 6)) * 8

@@ -18,14 +18,14 @@ from oracle import lds_numpy, ref  # noqa: E402  (checker only)
 LDS_CASES = ["lds_T5_n3", "lds_T20_n10", "lds_T200_n10", "lds_T1_n4", "lds_T2_n15"]
 
 
-@pytest.fixture(params=["twoend", "split", "packed"], autouse=True)
+@pytest.fixture(params=["twoend", "twoend_full", "split", "packed"], autouse=True)
 def kernel_variant(request):
-    """Run every test through the three E-step kernels: the two-ended one (the default for n <= 10,
-    T >= 4 without sampler / VJP hand-off), and the one-directional small-batch (one sequence per
-    wavefront) and packed (four per wavefront) variants."""
+    """Run every test through all E-step kernels: the two-ended one (the default for n <= 10, T >= 4
+    without sampler / VJP hand-off) with its lean and its full hand-off record, and the one-directional
+    small-batch (one sequence per wavefront) and packed (four per wavefront) variants."""
     from svae_amd import _lib
     lib = _lib.load()
-    old_te = lib.svae_lds_set_twoend(1 if request.param == "twoend" else 0)
+    old_te = lib.svae_lds_set_twoend({"twoend": 1, "twoend_full": 2}.get(request.param, 0))
     old = lib.svae_lds_set_split_max_b(1 << 30 if request.param == "split" else 0)
     yield request.param
     lib.svae_lds_set_split_max_b(old)

@@ -22,6 +22,7 @@ def run(init, pair, node, twoend):
 
 names = ["lognorm", "ExxT0", "Ex0", "Ep0", "Ep1", "Ep2", "En_dxx", "En_x"]
 worst = 0.0
+MODE = int(os.environ.get("TE_MODE", "1"))
 for inhomog in (False, True):
     for n in (1, 2, 3, 5, 8, 9, 10):
         for T in (4, 5, 6, 7, 12, 33, 200):
@@ -32,7 +33,7 @@ for inhomog in (False, True):
                 ps = [rand_lds_natparam(n, rng)[1] for _ in range(T - 1)]
                 pair = tuple(np.stack([p[i] for p in ps]) for i in range(4))
             node = rand_node_potentials((B, T, n), rng, with_logZ=True)
-            a = run(init, pair, node, True)
+            a = run(init, pair, node, MODE)
             r = run(init, pair, node, False)
             errs = []
             for nm, x, y in zip(names, a, r):
