@@ -154,7 +154,7 @@ int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int k
   const bool split = B <= g_split_max_b;
   if (g_twoend && !keep && n <= svae::TE_MAX_N && T >= svae::TE_MIN_T) {
     switch (n) {
-#define SVAE_CASE_(NN) case NN: return svae_lds_launch_twoend_n##NN(&a, inhomog, g_twoend == 1, stream);
+#define SVAE_CASE_(NN) case NN: return svae_lds_launch_twoend_n##NN(&a, inhomog, g_twoend == 1 && !inhomog, stream);
 #define SVAE_CASE(NN) SVAE_CASE_(NN)
 #ifdef SVAE_ONLY_N
       SVAE_CASE(SVAE_ONLY_N)

@@ -30,6 +30,7 @@
 // factorisation, whose LDL' factors define the eps -> sample map), 4 <= T, n <= 10.
 #pragma once
 #include "lds_estep_kernel.hpp"
+#include "gj1r_gen.hpp"
 
 namespace svae {
 
@@ -43,23 +44,6 @@ __device__ __forceinline__ void pair_split(double x, double& even_row, double& o
   const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
   even_row = __hiloint2double(rh[0], rl[0]);
   odd_row = __hiloint2double(rh[1], rl[1]);
-}
-
-// Loads / stores the compiler's memory-counter bookkeeping does not see (see the forward loop: hipcc
-// merges the counter state of the loop entry with the back edge's and would wait for the previous
-// step's hand-off stores before touching a value prefetched a whole step earlier).
-__device__ __forceinline__ double asm_load(const double* p) {
-  double r;
-  asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
-  return r;
-}
-__device__ __forceinline__ void asm_store(double* p, double v) {
-  asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(p), "v"(v) : "memory");
-}
-// wait until at most CNT vector-memory operations issued after the loads of (x, y) are outstanding
-template <int CNT>
-__device__ __forceinline__ void asm_wait_loaded(double& x, double& y) {
-  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(x), "+v"(y) : "n"(CNT));
 }
 
 __device__ __forceinline__ double asm_sub(double a, double b) {        // a - b, kept in program order
@@ -123,6 +107,18 @@ __device__ __forceinline__ void gauss_jordan_1r(double (&M)[N], const double (&E
       M[k] = stored;
     }
   });
+}
+
+#ifndef SVAE_GJ_GENERATED
+#define SVAE_GJ_GENERATED 1   // 1: one hand-scheduled asm block per pivot (gj1r_gen.hpp, tools/gen_gj_asm.py);
+#endif                        // 0: the statement-by-statement version above (same arithmetic), for A/B
+template <int N>
+__device__ __forceinline__ void te_gauss_jordan(double (&M)[N], const double (&E)[N], double& qacc, double& vfull) {
+#if SVAE_GJ_GENERATED
+  gauss_jordan_1r_asm<N>(M, E, qacc, vfull);
+#else
+  gauss_jordan_1r<N>(M, E, qacc, vfull);
+#endif
 }
 
 #ifdef SVAE_PHASE_TIMING
@@ -246,10 +242,12 @@ __global__ __launch_bounds__(64) void lds_estep_twoend_kernel(const LdsArgs a) {
   int ldE = 0;
   double vworst = -1.0;     // max over steps of -1/p_c (>= 0 <=> some pivot was not positive)
 
-  // node potentials are prefetched one step ahead by hand (asm_load / asm_wait_loaded): exactly the N
-  // hand-off stores of a step are issued between a prefetch and its use
-  double Jo_n = asm_load(nJb + node_off(0));
-  double ho_n = asm_load(nhb + node_off(0));
+  // node potentials are prefetched one step ahead.  (hipcc merges the memory-counter state of the loop
+  // entry with the back edge's, so the wait at the loop head also covers the previous step's hand-off
+  // stores; loading by inline asm with a hand-placed s_waitcnt vmcnt(N) was tried and is NOT safe: the
+  // compiler may copy the destination register before the wait.)
+  double Jo_n = nJb[node_off(0)];
+  double ho_n = nhb[node_off(0)];
   double Mp[N];             // partner chain's An at the hand-over point
   static_for<0, N>([&](auto i) { Mp[i] = 0.0; });
   // ... and this chain's log-normaliser accumulators at that point: with even T the partner's last
@@ -270,18 +268,16 @@ __global__ __launch_bounds__(64) void lds_estep_twoend_kernel(const LdsArgs a) {
     }
   };
 
-  static_for<0, N>([&](auto i) { asm_store(trash, 0.0); });     // the first step's wait counts N stores too
 #ifdef SVAE_PHASE_TIMING
   long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tlast_ = __builtin_readcyclecounter();
 #endif
   for (int s = 0; s < e; ++s) {
     if (s == jx) take_partner();
-    if (INHOMOG) asm_wait_loaded<0>(Jo_n, ho_n); else asm_wait_loaded<N>(Jo_n, ho_n);
     const double JoX = col ? -2.0 * Jo_n : 1.0;
     double ho = ho_n;
-    Jo_n = asm_load(nJb + node_off(s + 1));     // s + 1 <= e: the meeting node's potentials included
-    ho_n = asm_load(nhb + node_off(s + 1));
+    Jo_n = nJb[node_off(s + 1)];           // s + 1 <= e: the meeting node's potentials included
+    ho_n = nhb[node_off(s + 1)];
     if (INHOMOG) load_pair(s, true);
 
     // condition on the node potential; right-hand sides ride in the upper lanes
@@ -295,7 +291,7 @@ __global__ __launch_bounds__(64) void lds_estep_twoend_kernel(const LdsArgs a) {
     TE_TICK(0)
 
     double vfull = col ? 0.0 : 1.0;
-    gauss_jordan_1r<N>(M, E, qacc, vfull);
+    te_gauss_jordan<N>(M, E, qacc, vfull);
     TE_TICK(1)
 
     // next pivot block, slot layout:  AnD[j] = Cc[j] + sum_k X[k][i] * Bt[k]   (row i = 2j + gl;
@@ -333,7 +329,6 @@ __global__ __launch_bounds__(64) void lds_estep_twoend_kernel(const LdsArgs a) {
   double qacc_m = 0.0, vfull_m = col ? 0.0 : 1.0;
   {
     const long o = pair_off(e - 1), o1 = pair_off(e);
-    asm_wait_loaded<0>(Jo_n, ho_n);
     const double JoX = col ? -2.0 * Jo_n : 1.0;
     double ho = ho_n;
     double M[N];
@@ -345,7 +340,7 @@ __global__ __launch_bounds__(64) void lds_estep_twoend_kernel(const LdsArgs a) {
     dpp_fence(ho);
     static_for<0, N>([&](auto i) { mac_bc<i>(M[i], ho, EH); });
     dpp_fence(M);
-    gauss_jordan_1r<N>(M, E, qacc_m, vfull_m);
+    te_gauss_jordan<N>(M, E, qacc_m, vfull_m);
     hand_off(e, M, vfull_m);
   }
 
@@ -402,6 +397,7 @@ __global__ __launch_bounds__(64) void lds_estep_twoend_kernel(const LdsArgs a) {
   const bool own_N = (gl == (N & 1));     // the DPP row holding row N (E[x_t]) in slot N/2
   // chain B, even T: its first smoother step repeats pair e-1, which chain A counts
   const bool skip2nd = dir && !oddT;
+  const double wsp = skip2nd ? 0.0 : 1.0;
   const bool own_e = oddT && !dir;        // who reports the meeting node
 
   // node statistics: unconditional stores through per-lane walking pointers (idle lanes -> trash)
@@ -534,10 +530,12 @@ __global__ __launch_bounds__(64) void lds_estep_twoend_kernel(const LdsArgs a) {
       if constexpr (KIND == 1) {
         static_for<0, J>([&](auto j) { Stop[j] = Sn[j]; });
       } else if constexpr (KIND == 2) {
+        // (multiplications by 0 / 1, exact: a select here makes hipcc merge the stores through a pointer
+        //  phi, which leaves three accumulators on the stack)
         static_for<0, J>([&](auto j) {
-          sumS[j] = skip2nd ? 0.0 : Sn[j];
-          sumW[j] = skip2nd ? 0.0 : W[j];
-          Stop[j] = skip2nd ? Sn[j] : Stop[j];
+          sumS[j] = wsp * Sn[j];
+          sumW[j] = wsp * W[j];
+          Stop[j] = __builtin_fma(wsp, Stop[j], __builtin_fma(-wsp, Sn[j], Sn[j]));
         });
       } else {
         static_for<0, J>([&](auto j) { sumS[j] += Sn[j]; sumW[j] += W[j]; });
@@ -565,8 +563,8 @@ __global__ __launch_bounds__(64) void lds_estep_twoend_kernel(const LdsArgs a) {
       step(GEN, s, A, Bq);
       step(GEN, s - 1, Bq, A);
     }
-    if (s == 1) { step(GEN, 1, A, Bq); step(GEN, 0, Bq, A); }
-    else if (s == 0) step(GEN, 0, A, Bq);
+    if (s == 1) { step(GEN, 1, A, Bq); A = Bq; }     // (copy: no swapped call sites, the buffers stay in registers)
+    step(GEN, 0, A, Bq);
   }
 #ifdef SVAE_PHASE_TIMING
   TE_TICK(5)
