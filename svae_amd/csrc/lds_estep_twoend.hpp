@@ -268,6 +268,11 @@ __global__ __launch_bounds__(64) void lds_estep_twoend_kernel(const LdsArgs a) {
     }
   };
 
+  // hipcc merges the memory-counter state of the loop entry with the back edge's and waits for the more
+  // pessimistic of the two: a dummy hand-off (N stores into the meeting record, rewritten later) behind the
+  // first loads makes both look alike, so the wait at the loop head is vmcnt(N) -- the prefetched node
+  // potentials -- instead of a wait for the previous step's hand-off stores.
+  hand_off(e, An, 1.0);
 #ifdef SVAE_PHASE_TIMING
   long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tlast_ = __builtin_readcyclecounter();
@@ -499,6 +504,7 @@ __global__ __launch_bounds__(64) void lds_estep_twoend_kernel(const LdsArgs a) {
       static_for<0, J1>([&](auto j) { mac_bc<k, (k < N)>(W[j], S[j], H[k]); });
     });
     dpp_fence(W);
+    if constexpr (!INHOMOG && KIND == 0) static_for<0, J>([&](auto j) { sumW[j] += W[j]; });   // (W dies in the split)
     double WR[N + 2];
     static_for<0, J1>([&](auto j) { pair_split(W[j], WR[2 * j], WR[(2 * j + 1 <= N) ? 2 * j + 1 : N + 1]); });
     // S~_t[i] = P^-1[i] + G~[i] W~ = Pi + sum_k -/+ bcast_k(Gc[j]) WR[k]
@@ -538,7 +544,7 @@ __global__ __launch_bounds__(64) void lds_estep_twoend_kernel(const LdsArgs a) {
           Stop[j] = __builtin_fma(wsp, Stop[j], __builtin_fma(-wsp, Sn[j], Sn[j]));
         });
       } else {
-        static_for<0, J>([&](auto j) { sumS[j] += Sn[j]; sumW[j] += W[j]; });
+        static_for<0, J>([&](auto j) { sumS[j] += Sn[j]; });
       }
     }
 
