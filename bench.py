@@ -12,8 +12,11 @@ Workload = BASELINE.json configs[1]: 512 sequences x T=200, n=10 per GPU (weak s
 configs[2], 4096 sequences sharded 8 x 512 with the stat all-reduce).
 
 Extra JSON objects: `roofline` (dominant kernel vs HBM peak, duration measured live with events
-on the launch stream) and, at N=1 on rank 0, `cpu_baseline` (the reference's own compiled E-step,
-oracle/_ref, timed on this box's host cores on a bounded sample of the same workload).
+on the launch stream), at N=1 on rank 0 `cpu_baseline` (the reference's own compiled E-step,
+oracle/_ref, timed on this box's host cores on a bounded sample of the same workload, plus the
+NumPy restatement of its Python path), and at N=1 `extra`: the same measurement for north_star's
+single-GPU target (4096 sequences on ONE GPU) and for BASELINE configs[4]'s shape (latent dim 64,
+T=1000), each with its own roofline -- reported beside `value`, never instead of it.
 """
 import argparse
 import json
@@ -28,12 +31,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-T_STEPS, N_LATENT, SEQS_PER_GPU = 200, 10, 512
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
 FP64_MFMA_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x (16x16x4x2 flop / 64 clk, tools/ubench/mfma_f64.hip) x 2.4 GHz
 # --workload: the headline (BASELINE configs[1]/[2]) or BASELINE configs[4] (latent dim 64, T=1000; the
 # batch is not specified there: 512 sequences per GPU = two workgroups per CU)
 WORKLOADS = {"lds10": (200, 10, 512), "lds64": (1000, 64, 512)}
+# committed rocprofv3 PMC passes (profiles/run_profile.sh), by (kernel family, sequences per GPU)
+PMC_PROFILES = {("twoend", 512): "r2_twoend", ("twoend", 4096): "r2_twoend_b4096",
+                ("split", 512): "r1_final", ("packed", 4096): "r1_final_b4096", ("tile", 512): "r1_tile_n64_b512"}
 
 
 def algorithmic_bytes_per_seq(T, n):
@@ -53,10 +58,108 @@ def cpu_baseline(B, T, n, budget_s=10.0):
     import subprocess
     r = subprocess.run([sys.executable, "-m", "oracle.cpu_baseline", "--B", str(B), "--T", str(T),
                         "--n", str(n), "--budget", str(budget_s)], cwd=ROOT, capture_output=True,
-                       text=True, timeout=20 * budget_s + 120)
+                       text=True, timeout=30 * budget_s + 120)
     if r.returncode != 0:
         raise RuntimeError(r.stderr[-400:])
     return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def kernel_name(lib, B, T, n):
+    """Which E-step kernel the library dispatches to (include/svae_hip.h: svae_lds_set_twoend,
+    svae_lds_set_split_max_b) -> (profile family, demangled name as rocprofv3 prints it)."""
+    from svae_amd import _lib
+    if n > _lib.LDS_MAX_N:
+        return "tile", "svae::lds_estep_tile_kernel<%d,false>" % ((n + 15) // 16)
+    split_max = lib.svae_lds_set_split_max_b(0)
+    lib.svae_lds_set_split_max_b(split_max)
+    twoend = lib.svae_lds_set_twoend(1)
+    lib.svae_lds_set_twoend(twoend)
+    if twoend and n <= 10 and T >= 4:
+        return "twoend", "svae::lds_estep_twoend_kernel<%d,false,%s>" % (n, "true" if twoend == 1 else "false")
+    if B <= split_max:
+        return "split", "svae::lds_estep_split_kernel<%d,false,false>" % n
+    return "packed", "svae::lds_estep_kernel<%d,false,false>" % n
+
+
+def measure(dev, rank, world, dist, lib, T, n, B, steps, warmup):
+    """W untimed + K timed steps of the hot path on B sequences per GPU -> (elapsed s [max over ranks],
+    mean kernel ms from events on the launch stream)."""
+    from svae_amd.lds.lds_inference import LDSEStepPlan
+    from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials
+    from svae_amd.parallel import allreduce_global_stats
+    init, pair = rand_lds_natparam(n, np.random.default_rng(0))       # replicated global params
+    node_J, node_h = rand_node_potentials((B, T, n), np.random.default_rng(1000 + rank))  # this rank's shard
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev).contiguous()
+    d_init = [t(init[0]), t(init[1]), t(init[2]).reshape(1)]
+    d_pair = [t(pair[0]), t(pair[1]), t(pair[2]), t(pair[3]).reshape(1)]
+    d_J, d_h = t(node_J), t(node_h)
+    del node_J, node_h
+    plan = LDSEStepPlan(B, T, n, dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+
+    def step(i=None):
+        if i is not None:
+            ev[i][0].record()
+        plan.launch(d_init[0], d_init[1], d_init[2], d_pair[0], d_pair[1], d_pair[2], d_pair[3],
+                    d_J, d_h, None)
+        if i is not None:
+            ev[i][1].record()
+        packed = plan.reduce()
+        if world > 1:
+            allreduce_global_stats(packed)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    plan.check_info()
+    if world > 1:
+        el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, steps)
+    return elapsed, kern_ms
+
+
+def roofline(lib, T, n, B, kern_ms):
+    from svae_amd import _lib
+    family, kernel = kernel_name(lib, B, T, n)
+    # HBM traffic of that kernel from the committed rocprofv3 PMC passes (separate runs of this same
+    # command, profiles/run_profile.sh); only quoted when kernel and workload match the profile.
+    traffic, traffic_src = None, None
+    tag = PMC_PROFILES.get((family, B))
+    prof = os.path.join(ROOT, "profiles", tag, "pmc_hbm.json") if tag else None
+    if prof and os.path.isfile(prof) and (T, n) in ((200, 10), (1000, 64)):
+        p = json.load(open(prof))
+        if kernel.replace(" ", "") in p.get("kernel", "").replace(" ", ""):
+            traffic, traffic_src = p["hbm_bytes_per_launch_corrected"], os.path.relpath(prof, ROOT)
+    bytes_launch = B * algorithmic_bytes_per_seq(T, n)
+    achieved = bytes_launch / (kern_ms * 1e-3) / 1e9
+    hbm = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+           "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+           "traffic_unit": "bytes per launch (rocprofv3 PMC, 2*FETCH_SIZE+WRITE_SIZE)",
+           "traffic_source": traffic_src,
+           "traffic_over_algorithmic": (traffic / bytes_launch) if traffic else None,
+           "kernel": kernel, "kernel_ms": kern_ms,
+           "algorithmic_bytes_per_launch": bytes_launch,
+           "kernel_sequences_per_s": B / (kern_ms * 1e-3)}
+    if n > _lib.LDS_MAX_N:      # dense contraction: priced against the fp64 MFMA peak (SURVEY.md 8d)
+        flops_launch = B * algorithmic_flops_per_seq(T, n)
+        tf = flops_launch / (kern_ms * 1e-3) / 1e12
+        return dict(hbm, bound="mfma", achieved=tf, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=tf / FP64_MFMA_PEAK_TFLOPS, algorithmic_flops_per_launch=flops_launch,
+                    hbm_algorithmic_GBps=achieved)
+    return hbm
 
 
 def main():
@@ -67,6 +170,7 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="lds10")
     ap.add_argument("--seqs-per-gpu", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra single-GPU configurations")
     ap.add_argument("--kernel", choices=["auto", "twoend", "twoend_full", "split", "packed"], default="auto",
                     help="A/B measurements: force one of the E-step kernels (n <= 15)")
     args = ap.parse_args()
@@ -83,10 +187,6 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
-    from svae_amd.lds.lds_inference import LDSEStepPlan
-    from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials
-    from svae_amd.parallel import allreduce_global_stats
-
     from svae_amd import _lib
     lib = _lib.load()
     if args.kernel != "auto":
@@ -94,94 +194,11 @@ def main():
         lib.svae_lds_set_split_max_b(1 << 30 if args.kernel == "split" else (0 if args.kernel == "packed" else 1023))
     T, n, B = WORKLOADS[args.workload]
     B = args.seqs_per_gpu or B
-    init, pair = rand_lds_natparam(n, np.random.default_rng(0))       # replicated global params
-    node_J, node_h = rand_node_potentials((B, T, n), np.random.default_rng(1000 + rank))  # this rank's shard
-    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev).contiguous()
-    d_init = [t(init[0]), t(init[1]), t(init[2]).reshape(1)]
-    d_pair = [t(pair[0]), t(pair[1]), t(pair[2]), t(pair[3]).reshape(1)]
-    d_J, d_h = t(node_J), t(node_h)
-    plan = LDSEStepPlan(B, T, n, dev)
 
-    def step():
-        plan.launch(d_init[0], d_init[1], d_init[2], d_pair[0], d_pair[1], d_pair[2], d_pair[3],
-                    d_J, d_h, None)
-        packed = plan.reduce()
-        if world > 1:
-            allreduce_global_stats(packed)
-        return packed
+    elapsed, kern_ms = measure(dev, rank, world, dist, lib, T, n, B, args.steps, args.warmup)
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(args.steps)]
-
-    def timed_step(i):
-        ev[i][0].record()
-        plan.launch(d_init[0], d_init[1], d_init[2], d_pair[0], d_pair[1], d_pair[2], d_pair[3],
-                    d_J, d_h, None)
-        ev[i][1].record()
-        packed = plan.reduce()
-        if world > 1:
-            allreduce_global_stats(packed)
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        timed_step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    plan.check_info()
-    if world > 1:
-        el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        elapsed = float(el.item())
-
-    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
-    # which E-step kernel the library dispatched to (include/svae_hip.h: svae_lds_set_split_max_b)
-    split_max = lib.svae_lds_set_split_max_b(0)
-    lib.svae_lds_set_split_max_b(split_max)
-    twoend = lib.svae_lds_set_twoend(1)
-    lib.svae_lds_set_twoend(twoend)
-    kernel = ("svae::lds_estep_split_kernel<%d,false,false>" if B <= split_max
-              else "svae::lds_estep_kernel<%d,false,false>") % n
-    if twoend and n <= 10 and T >= 4:
-        kernel = "svae::lds_estep_twoend_kernel<%d,false,%s>" % (n, "true" if twoend == 1 else "false")
-    if n > _lib.LDS_MAX_N:
-        kernel = "svae::lds_estep_tile_kernel<%d,false>" % ((n + 15) // 16)
-    # HBM traffic of that kernel from the committed rocprofv3 PMC passes (separate runs of this
-    # same command, see profiles/run_profile.sh); only quoted when the workload matches.
-    traffic, traffic_src = None, None
-    prof = os.path.join(ROOT, "profiles", ("r1_final" if B == 512 else "r1_final_b%d" % B) if n == 10
-                        else "r1_tile_n%d_b%d" % (n, B), "pmc_hbm.json")
-    if os.path.isfile(prof):
-        p = json.load(open(prof))
-        if kernel.split("<")[0] in p.get("kernel", ""):
-            traffic, traffic_src = p["hbm_bytes_per_launch_corrected"], os.path.relpath(prof, ROOT)
     if rank == 0:
         total_seqs = B * world * args.steps
-        bytes_launch = B * algorithmic_bytes_per_seq(T, n)
-        achieved = bytes_launch / (kern_ms * 1e-3) / 1e9
-        hbm = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-               "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-               "traffic_unit": "bytes per launch (rocprofv3 PMC, 2*FETCH_SIZE+WRITE_SIZE)",
-               "traffic_source": traffic_src,
-               "kernel": kernel, "kernel_ms": kern_ms,
-               "algorithmic_bytes_per_launch": bytes_launch,
-               "kernel_sequences_per_s": B / (kern_ms * 1e-3)}
-        if n > _lib.LDS_MAX_N:      # dense contraction: priced against the fp64 MFMA peak
-            flops_launch = B * algorithmic_flops_per_seq(T, n)
-            tf = flops_launch / (kern_ms * 1e-3) / 1e12
-            roof = dict(hbm, bound="mfma", achieved=tf, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=tf / FP64_MFMA_PEAK_TFLOPS, algorithmic_flops_per_launch=flops_launch,
-                        hbm_algorithmic_GBps=achieved)
-        else:
-            roof = hbm
         out = {
             "metric": "E-step sequences/sec (LDS fwd-bwd smoother, T=%d n=%d)" % (T, n),
             "value": total_seqs / elapsed, "unit": "sequences/s",
@@ -195,12 +212,32 @@ def main():
                        "sequences_per_gpu": B, "T": T, "n": n, "global_sequences": B * world,
                        "parallelism": "dp%d" % world,
                        "step": "estep kernel + batch stat reduce" + (" + RCCL all-reduce" if world > 1 else "")},
-            "roofline": roof,
+            "roofline": roofline(lib, T, n, B, kern_ms),
         }
+        if world == 1 and not args.no_extra and args.workload == "lds10" and args.seqs_per_gpu is None:
+            # the other single-GPU configurations BASELINE.json names, same measurement, fewer steps
+            extra = []
+            for (eT, en, eB, esteps, what) in ((200, 10, 4096, max(5, args.steps // 2),
+                                                "north_star single-GPU target: 4096 sequences x T=200, n=10 on ONE GPU"),
+                                               (1000, 64, 512, max(3, args.steps // 10),
+                                                "BASELINE configs[4] shape: latent dim 64, T=1000, 512 sequences per GPU")):
+                try:
+                    el, km = measure(dev, 0, 1, None, lib, eT, en, eB, esteps, 2)
+                    extra.append({"workload": what, "value": eB * esteps / el, "unit": "sequences/s",
+                                  "steps": esteps, "warmup": 2, "ms_per_step": 1e3 * el / esteps,
+                                  "roofline": roofline(lib, eT, en, eB, km)})
+                except Exception as e:  # the headline line must survive
+                    extra.append({"workload": what, "error": repr(e)})
+                torch.cuda.empty_cache()
+            out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(B, T, n)
                 out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+                if n == 10 and "extra" in out and "value" in out["extra"][0]:
+                    # north_star: >= 50x the reference CPU E-step on 4096 sequences at 1 GPU (quoted against
+                    # the FASTER CPU figure: the compiled reference on all host cores)
+                    out["extra"][0]["speedup_vs_cpu_baseline"] = out["extra"][0]["value"] / out["cpu_baseline"]["value"]
             except Exception as e:  # never lose the GPU line to a baseline hiccup
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))

@@ -87,6 +87,17 @@ def main():
             out.update(value=allc, cores=cores,
                        sample="%d sequences per process x %d processes (one per host core), drawn "
                               "from the %d bench sequences (T=%d, n=%d)" % (per, cores, a.B, a.T, a.n))
+    # the "NumPy/autograd path" north_star names (lds_inference.py:223-229): its NumPy restatement
+    # (oracle/lds_numpy.py), one core, a few seconds -- reported beside the compiled path above
+    from oracle import lds_numpy
+    z = np.zeros(a.T)
+    lds_numpy.natural_lds_estep_general(natparam, (node_J[0], node_h[0], z))
+    t0, k = time.perf_counter(), 0
+    while time.perf_counter() - t0 < min(5.0, a.budget) and k < a.B:
+        lds_numpy.natural_lds_estep_general(natparam, (node_J[k], node_h[k], z))
+        k += 1
+    out["numpy_path"] = {"value": k / (time.perf_counter() - t0), "unit": "sequences/s", "cores": 1,
+                         "kind": "numpy", "sample": "%d of the bench sequences, oracle/lds_numpy.py" % k}
     print(json.dumps(out))
 
 
