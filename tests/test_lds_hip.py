@@ -219,6 +219,32 @@ def test_sampler_against_reference_build():
     assert _rel(samples, want) < 1e-6
 
 
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+def test_sampler_full_size_against_reference_build():
+    """BASELINE configs[1] shape (512 x T=200, n=10): the whole batch sampled in one launch, 16 sequences
+    spot-checked against the reference's compiled sampler fed with the same noise."""
+    from svae_amd.lds.lds_inference import natural_lds_inference_general
+    from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials
+    rng = np.random.default_rng(21)
+    B, T, n, S = 512, 200, 10, 2
+    init, pair = rand_lds_natparam(n, rng)
+    node = rand_node_potentials((B, T, n), rng)
+    eps = rng.standard_normal((B, T, S, n))
+    idx = np.unique(np.linspace(0, B - 1, 16).astype(int))
+    want = {}
+    for b in idx:
+        want[int(b)], eps[b] = ref.sample_backward((init, pair), (node[0][b], node[1][b], np.zeros(T)), S,
+                                                   seed=500 + int(b))
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev)
+    samples, _, _ = natural_lds_inference_general(
+        (tuple(t(x) for x in init), tuple(t(x) for x in pair)), tuple(t(x) for x in node),
+        num_samples=S, eps=t(eps))
+    assert tuple(samples.shape) == (B, T, S, n)
+    for b in idx:
+        assert _rel(samples[b], want[int(b)]) < 1e-6
+
+
 def test_sampler_moments_match_smoother():
     """Size-independent property: over many samples, the sample mean / second moment of x_t
     converge to the smoother's E[x_t], E[x_t x_t'] (loose statistical tolerance)."""

@@ -144,3 +144,10 @@ def test_tile_estep_full_size_well_conditioned(n, T):
     want = lds_longdouble.estep(natparam, (node[0][1], node[1][1]))
     got = (lognorm[1], (tuple(x[1] for x in Ei), tuple(x[1] for x in Ep), tuple(x[1] for x in En)))
     _check(got, want, 1e-10)
+    # ... and directly against the reference's own compiled path at BASELINE configs[4]'s shape
+    # (north_star: 1e-5; on this well-conditioned model the two fp64 paths agree far better)
+    if ref.available():
+        for b in range(2):
+            r = ref.estep(natparam, (node[0][b], node[1][b], np.zeros(T)))
+            got = (lognorm[b], (tuple(x[b] for x in Ei), tuple(x[b] for x in Ep), tuple(x[b] for x in En)))
+            _check(got, r, 1e-8)

@@ -138,3 +138,57 @@ def test_vjp_inhomogeneous_with_statistics_cotangents(n, T, B, S, batched, with_
         assert _rel(nJ.grad[b], want[b][0]) < 1e-6, "g_node_J"
         assert _rel(nh.grad[b], want[b][1]) < 1e-6, "g_node_h"
         assert _rel(nz.grad[b], want[b][2]) < 1e-12, "g_node_logZ"
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("B", [512, 2304])
+def test_vjp_full_size_against_reference(B):
+    """BASELINE configs[1] shape (T=200, n=10): E-step + sampler + VJP of the whole batch, 16 sequences
+    spot-checked against the reference's compiled VJPs.  B = 512 runs the role-split sweeps (two
+    workgroups per four sequences, B <= 2048), B = 2304 the fused ones."""
+    from svae_amd.lds.lds_inference import lds_inference_differentiable
+    n, T, S = 10, 200, 1
+    init, pair, node, g = _setup(n, T, B, S, 4242)
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev)
+    idx = np.unique(np.linspace(0, B - 1, 16).astype(int))
+    want, eps = {}, np.random.default_rng(1).standard_normal((B, T, S, n))
+    for b in idx:
+        (gJ, gh, gz), e = ref.estep_vjp((init, pair), tuple(x[b] for x in node), g["ln"][b],
+                                        (g["dxx"][b], g["x"][b]), g["s"][b], seed=1000 + int(b))
+        want[int(b)] = (gJ, gh, gz)
+        eps[b] = e
+    nJ, nh, nz = (t(x).requires_grad_(True) for x in node)
+    lognorm, (dxx, ex), samples, _ = lds_inference_differentiable(
+        (tuple(t(x) for x in init), tuple(t(x) for x in pair)), (nJ, nh, nz), eps=t(eps))
+    loss = (t(g["ln"]) * lognorm).sum() + (t(g["dxx"]) * dxx).sum() + (t(g["x"]) * ex).sum() \
+        + (t(g["s"]) * samples).sum()
+    loss.backward()
+    worst = 0.0
+    for b in idx:
+        worst = max(worst, _rel(nJ.grad[b], want[int(b)][0]), _rel(nh.grad[b], want[int(b)][1]))
+        assert _rel(nz.grad[b], want[int(b)][2]) < 1e-12
+    assert worst < 1e-6, worst
+
+
+def test_forward_outputs_do_not_depend_on_the_hand_off_kept():
+    """keep = 0 (the E-step proper; the two-ended kernel for n <= 10) and keep = 3 (factor + cross
+    moments kept for the sampler / VJP: one-directional kernels) are different schedules of the same
+    arithmetic: their outputs agree to rounding at the headline shape."""
+    from svae_amd.lds.lds_inference import LDSEStepPlan
+    from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials
+    B, T, n = 512, 200, 10
+    rng = np.random.default_rng(77)
+    init, pair = rand_lds_natparam(n, rng)
+    node = rand_node_potentials((B, T, n), rng)
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev).contiguous()
+    args = [t(init[0]), t(init[1]), t(init[2]).reshape(1), t(pair[0]), t(pair[1]), t(pair[2]),
+            t(pair[3]).reshape(1), t(node[0]), t(node[1]), None]
+    plan = LDSEStepPlan(B, T, n, dev)
+    plan.launch(*args)
+    a = [x.clone() for x in (plan.lognorm, plan.E_init, plan.E_pair, plan.E_node_diagxx, plan.E_node_x)]
+    plan.launch(*args, False, True, True)
+    b = [plan.lognorm, plan.E_init, plan.E_pair, plan.E_node_diagxx, plan.E_node_x]
+    for x, y in zip(a, b):
+        assert float((x - y).abs().max()) <= 1e-12 * float(y.abs().max()) + 1e-300, float((x - y).abs().max())
