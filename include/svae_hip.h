@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SVAE_HIP_ABI_VERSION 2   /* 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
+#define SVAE_HIP_ABI_VERSION 3   /* 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
 #define SVAE_LDS_MAX_N 15   /* register/DPP path: one 16-lane row per sequence, n+1 <= 16 */
 #define SVAE_LDS_TILE_MAX_N 64   /* 16 <= n <= 64: LDS-tiled MFMA path (E-step only: keep must be 0) */
 
@@ -81,6 +81,20 @@ int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int k
                        double* lognorm, double* E_init, double* E_pair,
                        double* E_node_diagxx, double* E_node_x,
                        int32_t* info, void* workspace, size_t ws_bytes, void* stream);
+
+/* Filter only = natural_filter_forward_general (/root/reference/svae/lds/cython_lds_inference.pyx:28-90),
+ * the first of the six functions the reference imports at lds_inference.py:18-24, batched.  Same inputs as
+ * svae_lds_estep_f64 (n <= SVAE_LDS_MAX_N).
+ *  out: lognorm (B); the forward messages in the reference's scaling (natural parameters, :84-85), each
+ *       optional (NULL = not wanted):  J_pred, J_filt (B,T,n,n) = -1/2 precision,  h_pred, h_filt (B,T,n).
+ * The workspace afterwards holds what svae_lds_sample_f64 needs: filter + sampler without the smoother is
+ * cython_natural_lds_sample (lds_inference.py:260-264). */
+int svae_lds_filter_f64(int B, int T, int n, int inhomog, int pair_batched,
+                        const double* init_J, const double* init_h, const double* init_logZ,
+                        const double* J11, const double* J12, const double* J22, const double* logZ_pair,
+                        const double* node_J, const double* node_h, const double* node_logZ,
+                        double* lognorm, double* J_pred, double* h_pred, double* J_filt, double* h_filt,
+                        int32_t* info, void* workspace, size_t ws_bytes, void* stream);
 
 /* Kernel selection for svae_lds_estep_f64 (n <= SVAE_LDS_MAX_N).  With keep == 0, n <= 10 and T >= 4
  * the two-ended kernel runs (block elimination from both ends of the chain, meeting in the middle:

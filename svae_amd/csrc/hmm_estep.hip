@@ -15,7 +15,13 @@
 // their maximum and exponentiated ONCE per lane (the reference does K logsumexp's of K terms per
 // step), alpha is renormalised to sum 1, and log Z accumulates the scales as mantissa/exponent
 // pairs (one log per sequence).  Forward quantities needed by the backward pass (alpha_t, e_t/c_t)
-// go through a caller-owned workspace of 32 doubles per (sequence, step).
+// go through a caller-owned workspace of HMM_WS doubles per (sequence, step).
+// Dynamic range: a scaled step underflows when every path into the states the next observation allows
+// goes through transition potentials ~700 nats below the matrix' maximum (exp underflows to 0 where the
+// reference's log-space pass keeps e^-800).  Such a step (normaliser c_t below 1e-200: rare) is redone
+// in LOG SPACE for its sequence -- K log-sum-exps like the reference -- and flagged in the workspace; the
+// backward pass treats flagged steps in log space too.  Results then agree with the reference over its
+// whole range instead of turning into NaN.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -34,8 +40,10 @@ struct HmmArgs {
   double* __restrict__ E_init;            // (B,K)
   double* __restrict__ E_trans;           // (B,K,K)
   double* __restrict__ E_states;          // (B,T,K)
-  double* __restrict__ ws;                // (B,T,32)
+  double* __restrict__ ws;                // (B,T,HMM_WS)
 };
+constexpr int HMM_WS = 34;                // [alpha (16) | e/c or its log-space stand-in (16) | flag | pad]
+constexpr double HMM_TINY = 1e-200;
 
 template <int K>
 __global__ __launch_bounds__(64) void hmm_estep_kernel(const HmmArgs a) {
@@ -64,7 +72,8 @@ __global__ __launch_bounds__(64) void hmm_estep_kernel(const HmmArgs a) {
   static_for<0, K>([&](auto j) { P[j] = col ? exp(lp[j] - pmax) : 0.0; PT[j] = col ? exp(lpT[j] - pmax) : 0.0; });
 
   const double* node = a.node_params + ((long)b * T) * K + cc;
-  double* wsb = a.ws + ((long)b * T) * 32 + c;
+  double* wsb = a.ws + ((long)b * T) * HMM_WS + c;
+  double* wflag = a.ws + ((long)b * T) * HMM_WS + 32;
   double one = 1.0;
 
   // ---- forward ------------------------------------------------------------------------------------
@@ -94,20 +103,57 @@ __global__ __launch_bounds__(64) void hmm_estep_kernel(const HmmArgs a) {
     double cs = 0.0;
     dpp_fence(al);
     static_for<0, K>([&](auto k) { mac_bc<k, false, true>(cs, al, one); });            // c_t = sum_k
-    const double rc = 1.0 / cs;
+    double rc = 1.0 / cs;
+    double u_st = e * rc, shift = m + (t > 0 ? pmax : 0.0), flag = 0.0;
+    const bool tiny = !(cs > HMM_TINY);
+    if (__any(tiny)) {
+      // log-space redo of this step for the rows that underflowed (wave-uniform branch; rows that did
+      // not underflow keep their scaled result)
+      const double la = alpha > 0.0 ? ::log(alpha) : NEG_BIG;       // alpha_{t-1}
+      double lpred = 0.0;
+      if (t > 0) {
+        double sj[K], m2 = NEG_BIG;
+        static_for<0, K>([&](auto j) {
+          const double lpj = col ? pp[j * K + cc] : NEG_BIG;        // log P[j][c], reloaded (rare path)
+          sj[j] = bcast<j>(la) + lpj;
+          m2 = fmax(m2, sj[j]);
+        });
+        double sum = 0.0;
+        static_for<0, K>([&](auto j) { sum += exp(sj[j] - m2); });
+        lpred = m2 + ::log(sum);
+      }
+      const double lal = col ? lpred + nd : NEG_BIG;
+      double M = NEG_BIG;
+      static_for<0, K>([&](auto k) { M = fmax(M, bcast<k>(lal)); });
+      const double al2 = col ? exp(lal - M) : 0.0;
+      double cs2 = 0.0;
+      static_for<0, K>([&](auto k) { cs2 += bcast<k>(al2); });
+      if (tiny) {
+        cs = cs2;
+        rc = 1.0 / cs2;
+        al = al2;
+        shift = M;
+        flag = 1.0;
+        u_st = nd - M - ::log(cs2);          // log of (likelihood / normaliser): the backward pass adds log P
+      }
+    }
     alpha = al * rc;
-    if (valid) { wsb[(long)t * 32] = alpha; wsb[(long)t * 32 + 16] = e * rc; }
+    if (valid) { wsb[(long)t * HMM_WS] = alpha; wsb[(long)t * HMM_WS + 16] = u_st; }
+    if (valid && c == 0) wflag[(long)t * HMM_WS] = flag;
     lzM *= __builtin_amdgcn_frexp_mant(cs);
     lzE += __builtin_amdgcn_frexp_exp(cs);
-    lzS += m + (t > 0 ? pmax : 0.0);
+    lzS += shift;
     if ((t & 15) == 15) { lzE += __builtin_amdgcn_frexp_exp(lzM); lzM = __builtin_amdgcn_frexp_mant(lzM); }
   }
   if (valid && c == 0) a.logZ[b] = lzS + ::log(lzM) + (double)lzE * 0.6931471805599453094;
 
   // ---- backward + statistics ----------------------------------------------------------------------
   double beta = col ? 1.0 : 0.0;
-  double acc[K];
+  double acc[K];                       // xi sums without the transition factor (scaled steps)
   static_for<0, K>([&](auto j) { acc[j] = 0.0; });
+  double accS[K];                      // xi sums of the log-space steps (complete terms)
+  static_for<0, K>([&](auto j) { accS[j] = 0.0; });
+  bool any_slow = false;
   double* oS = a.E_states + ((long)b * T) * K + cc;
   {
     const double gam = alpha * beta;      // t = T-1
@@ -116,14 +162,50 @@ __global__ __launch_bounds__(64) void hmm_estep_kernel(const HmmArgs a) {
   }
   // (u, alpha) of a step are fetched one step ahead: the loop is serial in t and the forward pass
   // wrote them ~T steps ago
-  double u_n = T > 1 ? wsb[(long)(T - 1) * 32 + 16] : 0.0, al_n = T > 1 ? wsb[(long)(T - 2) * 32] : 0.0;
+  double u_n = T > 1 ? wsb[(long)(T - 1) * HMM_WS + 16] : 0.0, al_n = T > 1 ? wsb[(long)(T - 2) * HMM_WS] : 0.0;
+  double f_n = T > 1 ? wflag[(long)(T - 1) * HMM_WS] : 0.0;
   for (int t = T - 2; t >= 0; --t) {
-    const double u = u_n;                              // e_{t+1} / c_{t+1}
+    const double u = u_n;                              // e_{t+1} / c_{t+1}  (flagged step: its log-space stand-in)
     const double al = al_n;
+    const bool slow = f_n != 0.0;
     {
       const int tp = t > 0 ? t - 1 : 0;                // unconditional (clamped) prefetch of step t-1
-      u_n = wsb[(long)(tp + 1) * 32 + 16];
-      al_n = wsb[(long)tp * 32];
+      u_n = wsb[(long)(tp + 1) * HMM_WS + 16];
+      al_n = wsb[(long)tp * HMM_WS];
+      f_n = wflag[(long)(tp + 1) * HMM_WS];
+    }
+    if (__any(slow)) {
+      // step t+1 was redone in log space: beta_t[j] = sum_k exp(log P[j][k] + ul[k] + log beta[k]),
+      // xi_t[j][k] = alpha_t[j] * that term  (K exponentials per lane; rows not flagged take the scaled
+      // formulas below through the selects)
+      any_slow = true;
+      const double lw = (col && beta > 0.0) ? u + ::log(beta) : NEG_BIG;     // lane k
+      double bn2 = 0.0, term[K];
+      static_for<0, K>([&](auto k) {
+        const double lpk = col ? pp[cc * K + k] : NEG_BIG;                   // log P[c][k]
+        term[k] = exp(fmax(lpk + bcast<k>(lw), -745.0)) * ((lpk + bcast<k>(lw) > -745.0) ? 1.0 : 0.0);
+        bn2 += term[k];                                                      // lane j = c: sum over k
+      });
+      // xi: lane k of accS[j] += alpha_t[j] * term_{lane j}[k]: transpose through broadcasts
+      if (slow) {
+        static_for<0, K>([&](auto j) {
+          // value at (j, k) lives in lane j, register k; lane k needs it: K x K broadcasts (rare path)
+          double row = 0.0;
+          static_for<0, K>([&](auto k) { row = (c == k) ? bcast<j>(term[k]) : row; });
+          accS[j] += bcast<j>(al) * row;
+        });
+      }
+      double w0 = slow ? 0.0 : u * beta, al0 = slow ? 0.0 : al;
+      dpp_fence(w0);
+      dpp_fence(al0);
+      double bn = 0.0;
+      static_for<0, K>([&](auto k) { mac_bc<k, false, true>(bn, w0, PT[k]); });
+      static_for<0, K>([&](auto j) { mac_bc<j, false, true>(acc[j], al0, w0); });
+      beta = slow ? bn2 : bn;
+      const double gam = al * beta;
+      if (valid && col) oS[(long)t * K] = gam;
+      if (t == 0 && valid && col) a.E_init[(long)b * K + c] = gam;
+      continue;
     }
     double w = u * beta;
     double al_f = al;
@@ -138,7 +220,8 @@ __global__ __launch_bounds__(64) void hmm_estep_kernel(const HmmArgs a) {
     if (t == 0 && valid && col) a.E_init[(long)b * K + c] = gam;
   }
   if (valid && col) {
-    static_for<0, K>([&](auto j) { a.E_trans[(long)b * K * K + j * K + c] = acc[j] * P[j]; });
+    static_for<0, K>([&](auto j) { a.E_trans[(long)b * K * K + j * K + c] = __builtin_fma(acc[j], P[j], accS[j]); });
+    (void)any_slow;
   }
 }
 
@@ -152,7 +235,7 @@ static int launch_hmm(const HmmArgs& a, hipStream_t s) {
 
 extern "C" size_t svae_hmm_workspace_bytes(int B, int T, int K) {
   if (B <= 0 || T <= 0 || K <= 0 || K > 16) return 0;
-  return (size_t)B * T * 32 * sizeof(double);
+  return (size_t)B * T * svae::HMM_WS * sizeof(double);
 }
 
 extern "C" int svae_hmm_estep_f64(int B, int T, int K, int pair_batched,

@@ -51,6 +51,12 @@ struct LdsArgs {
   double* __restrict__ ws2;   // factor region for the sampler (nullptr: not kept)
   double* __restrict__ ws3;   // cross-moment region for the VJP: W~_t, (n+1) rows x ws_h_stride per step
   long pair_seq_stride;  // doubles between consecutive sequences' pair blocks (0 = shared)
+  // filter-only launches (svae_lds_filter_f64): the forward messages in the reference's scaling
+  // (natural parameters, cython_lds_inference.pyx:84-85), each (B,T,n,n) / (B,T,n) or nullptr
+  double* __restrict__ msg_Jp;
+  double* __restrict__ msg_hp;
+  double* __restrict__ msg_Jf;
+  double* __restrict__ msg_hf;
 };
 
 struct SampleArgs {

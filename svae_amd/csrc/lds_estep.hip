@@ -12,6 +12,7 @@ extern "C" {
 #define SVAE_DECL_(NN) int svae_lds_launch_n##NN(const svae::LdsArgs*, int, void*); \
   int svae_lds_launch_split_n##NN(const svae::LdsArgs*, int, void*);           \
   int svae_lds_launch_twoend_n##NN(const svae::LdsArgs*, int, int, void*);          \
+  int svae_lds_launch_filter_n##NN(const svae::LdsArgs*, int, void*);          \
   int svae_lds_sample_n##NN(const svae::SampleArgs*, void*);                   \
   int svae_lds_vjp_n##NN(const svae::VjpArgs*, void*);
 #define SVAE_DECL(NN) SVAE_DECL_(NN)
@@ -147,6 +148,7 @@ int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int k
   a.ws2 = (keep & 1) ? (double*)workspace + main_ws_doubles(B, T, n) : nullptr;
   a.ws3 = (keep & 2) ? (double*)workspace + main_ws_doubles(B, T, n) + factor_ws_doubles(B, T, n) : nullptr;
   a.pair_seq_stride = pair_batched ? (long)(T - 1) * n * n : 0;
+  a.msg_Jp = a.msg_hp = a.msg_Jf = a.msg_hf = nullptr;
   if (n > SVAE_LDS_MAX_N) {
     a.ws2 = a.ws3 = nullptr;
     return svae_lds_launch_tile(&a, n, inhomog, stream);
@@ -169,6 +171,54 @@ int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int k
   switch (n) {
 #define SVAE_CASE_(NN) case NN: return split ? svae_lds_launch_split_n##NN(&a, inhomog, stream) \
                                              : svae_lds_launch_n##NN(&a, inhomog, stream);
+#define SVAE_CASE(NN) SVAE_CASE_(NN)
+#ifdef SVAE_ONLY_N
+    SVAE_CASE(SVAE_ONLY_N)
+#else
+    SVAE_CASE(1) SVAE_CASE(2) SVAE_CASE(3) SVAE_CASE(4) SVAE_CASE(5) SVAE_CASE(6) SVAE_CASE(7)
+    SVAE_CASE(8) SVAE_CASE(9) SVAE_CASE(10) SVAE_CASE(11) SVAE_CASE(12) SVAE_CASE(13)
+    SVAE_CASE(14) SVAE_CASE(15)
+#endif
+#undef SVAE_CASE
+#undef SVAE_CASE_
+  }
+  return -3;
+}
+
+int svae_lds_filter_f64(int B, int T, int n, int inhomog, int pair_batched,
+                        const double* init_J, const double* init_h, const double* init_logZ,
+                        const double* J11, const double* J12, const double* J22, const double* logZ_pair,
+                        const double* node_J, const double* node_h, const double* node_logZ,
+                        double* lognorm, double* J_pred, double* h_pred, double* J_filt, double* h_filt,
+                        int32_t* info, void* workspace, size_t ws_bytes, void* stream) {
+  if (B < 0) return -1;
+  if (T < 1) return -2;
+  if (n < 1 || n > SVAE_LDS_MAX_N) return -3;
+  if (pair_batched && !inhomog) return -5;
+  if (!init_J) return -6;
+  if (!init_h) return -7;
+  if (!init_logZ) return -8;
+  if (T > 1 && (!J11 || !J12 || !J22 || !logZ_pair)) return -9;
+  if (!node_J) return -13;
+  if (!node_h) return -14;
+  if (!lognorm) return -16;
+  if (!info) return -21;
+  if (!workspace || ws_bytes < svae_lds_workspace_bytes(B, T, n)) return -22;
+  if (B == 0) return 0;
+  svae::LdsArgs a;
+  a.B = B; a.T = T;
+  a.init_J = init_J; a.init_h = init_h; a.init_logZ = init_logZ;
+  a.J11 = J11; a.J12 = J12; a.J22 = J22; a.logZ_pair = logZ_pair;
+  a.node_J = node_J; a.node_h = node_h; a.node_logZ = node_logZ;
+  a.lognorm = lognorm; a.E_init = nullptr; a.E_pair = nullptr;
+  a.E_node_diagxx = nullptr; a.E_node_x = nullptr;
+  a.info = info; a.ws = (double*)workspace;
+  a.ws2 = (double*)workspace + main_ws_doubles(B, T, n);      // factor region: the sampler may follow
+  a.ws3 = nullptr;
+  a.pair_seq_stride = pair_batched ? (long)(T - 1) * n * n : 0;
+  a.msg_Jp = J_pred; a.msg_hp = h_pred; a.msg_Jf = J_filt; a.msg_hf = h_filt;
+  switch (n) {
+#define SVAE_CASE_(NN) case NN: return svae_lds_launch_filter_n##NN(&a, inhomog, stream);
 #define SVAE_CASE(NN) SVAE_CASE_(NN)
 #ifdef SVAE_ONLY_N
     SVAE_CASE(SVAE_ONLY_N)

@@ -179,7 +179,10 @@ __device__ __forceinline__ void load_row(const double* __restrict__ p, double (&
   if constexpr (CNT % 2 == 1) r[CNT - 1] = p[CNT - 1];
 }
 
-template <int N, bool INHOMOG, bool CHOL>
+// FILT: filter only (natural_filter_forward_general, cython_lds_inference.pyx:28-90): stops after the
+// log-normaliser, keeps the hand-off and the factor region for the sampler (cython_natural_lds_sample,
+// lds_inference.py:260-264) and, on request, writes the forward messages in the reference's scaling.
+template <int N, bool INHOMOG, bool CHOL, bool FILT = false>
 __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
   static_assert(N >= 1 && N <= SVAE_LDS_MAX_N, "n+1 lanes must fit a 16-lane DPP row");
   constexpr int IL = SVAE_IL;
@@ -291,6 +294,20 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
     static_for<0, N>([&](auto i) { mac_bc<i>(X[i], ho, EN); });
     dpp_fence(P);
     TICK(0)
+    if constexpr (FILT) {
+      // messages of step t (natural scaling): J_filt = J_pred + diag(J_node) = -1/2 (P - J11_info);
+      // h_filt sits in lane N of X, h_pred in lane N of An
+      const long oj = INHOMOG ? (long)t * N * N : 0;
+      const long mo = ((long)b * T + t) * N * N, vo = ((long)b * T + t) * N;
+      static_for<0, N>([&](auto i) {
+        const double j11 = last ? 0.0 : pJ11[oj + i * N + cc];
+        const double jf = -0.5 * P[i] - j11;
+        if (st && a.msg_Jf) a.msg_Jf[mo + i * N + c] = jf;
+        if (st && a.msg_Jp) a.msg_Jp[mo + i * N + c] = __builtin_fma(0.5 * Jo, E[i], jf);
+        if (valid && c == N && a.msg_hf) a.msg_hf[vo + i] = X[i];
+        if (valid && c == N && a.msg_hp) a.msg_hp[vo + i] = An[i];
+      });
+    }
 
     // in-place Gauss-Jordan: P -> P^-1, X -> P^-1 X (gauss_jordan above)
     double pv = 0.0;                                   // CHOL: lane k <- pivot k
@@ -351,6 +368,7 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
   if (valid && c == 0) { for (int q = 0; q < 4; ++q) a.E_init[(long)b * (N * N + N) + q] = (double)tm[q]; }
   return;
 #endif
+  if constexpr (FILT) return;
   // ---- backward pass in moment form on homogeneous coordinates ---------------------------------
   // S[i] = row i of S~ (i = 0..N), lane c = column c (c = 0..N).  Start from S~_T := e_N e_N' so
   // that the generic step at t = T-1 (where G = 0, c = mu_{T-1}) yields [[Sigma+mu mu', mu],[mu',1]].
@@ -482,6 +500,16 @@ static int launch_estep(const LdsArgs& a, bool inhomog, hipStream_t stream) {
     hipLaunchKernelGGL((lds_estep_kernel<N, false, true>), grid, block, 0, stream, a);
   else
     hipLaunchKernelGGL((lds_estep_kernel<N, false, false>), grid, block, 0, stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+template <int N>
+static int launch_filter(const LdsArgs& a, bool inhomog, hipStream_t stream) {
+  dim3 grid((a.B + 3) / 4), block(64);
+  if (inhomog)
+    hipLaunchKernelGGL((lds_estep_kernel<N, true, true, true>), grid, block, 0, stream, a);
+  else
+    hipLaunchKernelGGL((lds_estep_kernel<N, false, true, true>), grid, block, 0, stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 

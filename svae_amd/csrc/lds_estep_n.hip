@@ -30,3 +30,7 @@ extern "C" int SVAE_CAT(svae_lds_launch_split_n, SVAE_N)(const svae::LdsArgs* a,
 extern "C" int SVAE_CAT(svae_lds_launch_twoend_n, SVAE_N)(const svae::LdsArgs* a, int inhomog, int lean, void* stream) {
   return svae::launch_estep_twoend<SVAE_N>(*a, inhomog != 0, lean != 0, (hipStream_t)stream);
 }
+
+extern "C" int SVAE_CAT(svae_lds_launch_filter_n, SVAE_N)(const svae::LdsArgs* a, int inhomog, void* stream) {
+  return svae::launch_filter<SVAE_N>(*a, inhomog != 0, (hipStream_t)stream);
+}

@@ -18,6 +18,7 @@ import torch
 from .. import _lib
 
 __all__ = ["LDSEStepPlan", "natural_lds_estep_general", "cython_natural_lds_estep_general",
+           "natural_filter_forward_general", "natural_lds_sample", "cython_natural_lds_sample",
            "natural_lds_inference_general", "cython_natural_lds_inference_general", "reduce_stats",
            "lds_inference_differentiable"]
 
@@ -40,7 +41,9 @@ def _canonical_init_params(init_params, device):
 
 class LDSEStepPlan(object):
     """Pre-allocated buffers for repeated E-steps of one shape (B, T, n): the launch itself does no
-    allocation, no host<->device copy and no synchronisation."""
+    allocation, no host<->device copy and no synchronisation.  The sampler and the VJP read the
+    workspace of the plan's LAST launch: a plan may be reused for a new forward pass only after the
+    backward pass of the previous one (checked through `epoch`)."""
 
     def __init__(self, B, T, n, device="cuda", inhomog=False, pair_batched=False):
         if not (1 <= n <= _lib.LDS_TILE_MAX_N):
@@ -66,6 +69,14 @@ class LDSEStepPlan(object):
         self.E_node_x = torch.empty(B, T, n, **f64)
         self.info = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.reduced = torch.empty(4 * n * n + n + 2, **f64)
+        # constants of the reference's statistic tuples (built once: no per-call allocation)
+        self.ones_B = torch.ones(B, **f64)
+        self.ones_BT = torch.ones(B, T, **f64)
+        self.ones_pair = torch.ones(B, max(T - 1, 0), **f64) if self.inhomog \
+            else torch.full((B,), float(T - 1), **f64)
+        # launch counter: the sampler / VJP read the workspace of the LAST launch, so an autograd node
+        # remembers the launch it belongs to and refuses to run after the plan has been reused
+        self.epoch = 0
 
     def launch(self, init_J, init_h, init_logZ, J11, J12, J22, logZ_pair, node_J, node_h,
                node_logZ=None, pair_batched=False, keep_factor=False, keep_cross=False):
@@ -80,8 +91,25 @@ class LDSEStepPlan(object):
             p(self.E_node_x), p(self.info), p(self.ws), self.ws_bytes,
             _lib.current_stream(self.device))
         _lib.check(rc, "svae_lds_estep_f64")
+        self.epoch += 1
         self.has_factor = bool(keep_factor)
         self.has_cross = bool(keep_cross)
+        self._J12 = J12
+        self._pair_batched = bool(pair_batched)
+
+    def filter(self, init_J, init_h, init_logZ, J11, J12, J22, logZ_pair, node_J, node_h,
+               node_logZ=None, pair_batched=False, J_pred=None, h_pred=None, J_filt=None, h_filt=None):
+        """Filter-only launch (svae_lds_filter_f64): lognorm, optional forward messages, and the hand-off
+        `sample()` needs."""
+        p = _lib.ptr
+        rc = self.lib.svae_lds_filter_f64(
+            self.B, self.T, self.n, int(self.inhomog), int(pair_batched),
+            p(init_J), p(init_h), p(init_logZ), p(J11), p(J12), p(J22), p(logZ_pair),
+            p(node_J), p(node_h), p(node_logZ), p(self.lognorm), p(J_pred), p(h_pred), p(J_filt), p(h_filt),
+            p(self.info), p(self.ws), self.ws_bytes, _lib.current_stream(self.device))
+        _lib.check(rc, "svae_lds_filter_f64")
+        self.epoch += 1
+        self.has_factor, self.has_cross = True, False
         self._J12 = J12
         self._pair_batched = bool(pair_batched)
 
@@ -138,6 +166,8 @@ class LDSEStepPlan(object):
 
     def reduce(self):
         """Deterministic batch sums [sum E_init | sum E_pair | sum lognorm | B] (homogeneous)."""
+        if self.inhomog:
+            raise ValueError("reduce(): per-step pair statistics (B,T-1,3,n,n) have no batch-summed form here")
         p = _lib.ptr
         rc = self.lib.svae_lds_reduce_stats_f64(
             self.B, self.n, p(self.E_init), p(self.E_pair), p(self.lognorm), p(self.reduced),
@@ -155,17 +185,9 @@ class LDSEStepPlan(object):
                                      "(potentials not positive definite)" % (v - 1))
 
 
-def natural_lds_estep_general(natparam, node_params, plan=None, check=True, keep_factor=False):
-    """E-step = filter + smoother (lds_inference.py:223-237).
-
-    natparam = (init_params, pair_params); init_params = (-1/2 J0, h0, logZ...) and
-    pair_params = (J11, J12, J22, logZ) homogeneous (n,n) or per-step (T-1,n,n)
-    [or (B,T-1,n,n) with batched nodes]; node_params = (J, h[, logZ]) with diagonal J of shape
-    (T,n) or (B,T,n).
-
-    Returns (lognorm, (E_init_stats, E_pair_stats, E_node_stats)) shaped like the reference's
-    (cython_lds_inference.pyx:197-210); with a batch axis first when the nodes are batched.
-    """
+def _prepare(natparam, node_params, plan):
+    """Shape checks / canonical device tensors shared by the E-step, filter and sampler wrappers
+    (`_canonical_node_params`, `_canonical_init_params`, lds_inference.py:59-82)."""
     init_params, pair_params = natparam
     if not isinstance(node_params, (tuple, list)) or len(node_params) not in (2, 3):
         raise ValueError("node_params must be (J, h) or (J, h, logZ)")
@@ -208,22 +230,41 @@ def natural_lds_estep_general(natparam, node_params, plan=None, check=True, keep
         plan = LDSEStepPlan(B, T, n, dev, inhomog, pair_batched)
     elif (plan.B, plan.T, plan.n, plan.inhomog) != (B, T, n, inhomog):
         raise ValueError("plan shape mismatch")
-    plan.launch(init_J, init_h, init_logZ, J11, J12, J22, logZ_pair, node_J, node_h, node_logZ,
-                pair_batched, keep_factor)
+    return dict(plan=plan, batched=batched, B=B, T=T, n=n, inhomog=inhomog, pair_batched=pair_batched,
+                args=(init_J, init_h, init_logZ, J11, J12, J22, logZ_pair, node_J, node_h, node_logZ))
+
+
+def natural_lds_estep_general(natparam, node_params, plan=None, check=False, keep_factor=False):
+    """E-step = filter + smoother (lds_inference.py:223-237).
+
+    natparam = (init_params, pair_params); init_params = (-1/2 J0, h0, logZ...) and
+    pair_params = (J11, J12, J22, logZ) homogeneous (n,n) or per-step (T-1,n,n)
+    [or (B,T-1,n,n) with batched nodes]; node_params = (J, h[, logZ]) with diagonal J of shape
+    (T,n) or (B,T,n).
+
+    Returns (lognorm, (E_init_stats, E_pair_stats, E_node_stats)) shaped like the reference's
+    (cython_lds_inference.pyx:197-210); with a batch axis first when the nodes are batched.
+
+    Asynchronous like the reference is silent: no host synchronisation unless `check=True`, which reads
+    the device-side status word and raises FloatingPointError for potentials that are not positive
+    definite (the reference ignores LAPACK `info`, cython_gaussian_grads.pxd:54-76); `plan.check_info()`
+    does the same later.  The returned tensors are views of the plan's buffers: valid until its next launch.
+    """
+    q = _prepare(natparam, node_params, plan)
+    plan, batched, B, T, n, inhomog = q["plan"], q["batched"], q["B"], q["T"], q["n"], q["inhomog"]
+    dev = plan.device
+    plan.launch(*q["args"], q["pair_batched"], keep_factor)
     if check:
         plan.check_info()
 
-    one = torch.ones((), dtype=torch.float64, device=dev)
     ExxT0 = plan.E_init[:, :n * n].reshape(B, n, n)
     Ex0 = plan.E_init[:, n * n:]
     if inhomog:
-        Ep = (plan.E_pair[:, :, 0], plan.E_pair[:, :, 1], plan.E_pair[:, :, 2],
-              torch.ones(B, T - 1, dtype=torch.float64, device=dev))
+        Ep = (plan.E_pair[:, :, 0], plan.E_pair[:, :, 1], plan.E_pair[:, :, 2], plan.ones_pair)
     else:
-        Ep = (plan.E_pair[:, 0], plan.E_pair[:, 1], plan.E_pair[:, 2],
-              torch.full((B,), float(T - 1), dtype=torch.float64, device=dev))
-    En = (plan.E_node_diagxx, plan.E_node_x, torch.ones(B, T, dtype=torch.float64, device=dev))
-    Ei = (ExxT0, Ex0, one.expand(B), one.expand(B))
+        Ep = (plan.E_pair[:, 0], plan.E_pair[:, 1], plan.E_pair[:, 2], plan.ones_pair)
+    En = (plan.E_node_diagxx, plan.E_node_x, plan.ones_BT)
+    Ei = (ExxT0, Ex0, plan.ones_B, plan.ones_B)
     lognorm = plan.lognorm
     if not batched:
         sq = lambda tup: tuple(x[0] for x in tup)
@@ -232,6 +273,49 @@ def natural_lds_estep_general(natparam, node_params, plan=None, check=True, keep
 
 
 cython_natural_lds_estep_general = natural_lds_estep_general
+
+
+def natural_filter_forward_general(init_params, pair_params, node_params, plan=None, check=False):
+    """The forward filter alone, with its messages: ((J_pred, h_pred), (J_filt, h_filt)), lognorm in the
+    reference's scaling (natural parameters: J = -1/2 precision), shapes (T,n,n) / (T,n) [(B,...) when
+    the nodes are batched] -- `natural_filter_forward_general` (cython_lds_inference.pyx:28-90, result
+    :84-87; Python twin lds_inference.py:86-106).  The plan's workspace afterwards serves `plan.sample`."""
+    q = _prepare((init_params, pair_params), node_params, plan)
+    plan, B, T, n = q["plan"], q["B"], q["T"], q["n"]
+    if n > _lib.LDS_MAX_N:
+        raise ValueError("filter messages: latent dimension <= %d" % _lib.LDS_MAX_N)
+    f64 = dict(dtype=torch.float64, device=plan.device)
+    Jp, Jf = torch.empty(B, T, n, n, **f64), torch.empty(B, T, n, n, **f64)
+    hp, hf = torch.empty(B, T, n, **f64), torch.empty(B, T, n, **f64)
+    plan.filter(*q["args"], q["pair_batched"], Jp, hp, Jf, hf)
+    if check:
+        plan.check_info()
+    lognorm = plan.lognorm
+    if not q["batched"]:
+        return ((Jp[0], hp[0]), (Jf[0], hf[0])), lognorm[0]
+    return ((Jp, hp), (Jf, hf)), lognorm
+
+
+def natural_lds_sample(natparam, node_params, num_samples=1, eps=None, plan=None, generator=None):
+    """Filter + backward sampling WITHOUT the smoother: `cython_natural_lds_sample`
+    (lds_inference.py:260-264) -> samples (T,S,n) [(B,T,S,n) batched].  `eps` as in
+    natural_lds_inference_general."""
+    q = _prepare(natparam, node_params, plan)
+    plan = q["plan"]
+    if q["n"] > _lib.LDS_MAX_N:
+        raise ValueError("sampler: latent dimension <= %d" % _lib.LDS_MAX_N)
+    plan.filter(*q["args"], q["pair_batched"])
+    S = int(num_samples)
+    if eps is None:
+        eps = torch.randn(plan.B, plan.T, S, plan.n, dtype=torch.float64, device=plan.device, generator=generator)
+    else:
+        eps = torch.as_tensor(eps, dtype=torch.float64)
+        eps = eps if q["batched"] else eps[None]
+    samples = plan.sample(eps)
+    return samples if q["batched"] else samples[0]
+
+
+cython_natural_lds_sample = natural_lds_sample
 
 
 def natural_lds_inference_general(natparam, node_params, num_samples=None, eps=None, plan=None,
@@ -294,8 +378,11 @@ class _LDSInference(torch.autograd.Function):
         init_J, init_h, init_logZ, J11, J12, J22, logZ_pair = params
         plan.launch(init_J, init_h, init_logZ, J11, J12, J22, logZ_pair, node_J, node_h, node_logZ,
                     pair_batched, True, True)
+        if eps is not None and eps.shape[2] > 16:
+            raise ValueError("at most 16 samples per sequence are differentiable (svae_lds_estep_vjp_f64)")
         samples = plan.sample(eps) if eps is not None else torch.zeros(0, dtype=torch.float64, device=plan.device)
         ctx.plan, ctx.has_logZ, ctx.has_samples = plan, node_logZ is not None, eps is not None
+        ctx.epoch = plan.epoch
         ctx.save_for_backward(eps if eps is not None else samples, samples)
         E_init, E_pair = plan.E_init.clone(), plan.E_pair.clone()
         if not plan.inhomog:
@@ -306,6 +393,10 @@ class _LDSInference(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_lognorm, g_dxx, g_x, g_samples, g_init, g_pair):
         plan = ctx.plan
+        if plan.epoch != ctx.epoch:
+            raise RuntimeError("LDSEStepPlan was launched again before backward(): the hand-off workspace of "
+                               "this forward pass is gone (use one plan per live autograd graph, or call "
+                               "backward before the next forward)")
         eps, samples = ctx.saved_tensors
         zero = lambda g, like: torch.zeros_like(like) if g is None else g
         g_lognorm = zero(g_lognorm, plan.lognorm)

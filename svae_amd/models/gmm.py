@@ -96,20 +96,45 @@ def local_meanfield(global_natparam, node_potentials, label_init=None, tol=1e-3,
     return local_stats, prior_stats, natparam, o["kl"][0]
 
 
-def prior_kl(global_natparam, prior_natparam):
-    """gmm.py:54-58: KL(q(theta) || p(theta)) of the Dirichlet x NIW^K global factors."""
+def prior_kl(global_natparam, prior_natparam, reference_compat=False):
+    """gmm.py:54-58: KL(q(theta) || p(theta)) of the Dirichlet x NIW^K global factors.
+
+    Default: the full contraction <eta_q - eta_p, E_q[t(theta)]> - (logZ(q) - logZ(p)) the code spells.
+    `reference_compat=True` returns what the reference AS SHIPPED computes: svae/util.py:169 rebinds
+    `flatten`, so `flat` (util.py:42) keeps only the FIRST scalar of each nested structure and the
+    contraction reduces to its first element (checked against the reference run in memory,
+    tests/golden/gmm_run_K5_N2_T60.npz `global_kl`)."""
     dev = torch.device("cuda", torch.cuda.current_device())
     g = [_dev64(x, dev) for x in global_natparam]
     p = [_dev64(x, dev) for x in prior_natparam]
     es = (expfam.dirichlet_expectedstats(g[0]), expfam.niw_expectedstats(g[1]))
-    diff = sum(((a - b) * e).sum() for a, b, e in zip(g, p, es))
+    if reference_compat:
+        diff = (g[0].reshape(-1)[0] - p[0].reshape(-1)[0]) * es[0].reshape(-1)[0]
+    else:
+        diff = sum(((a - b) * e).sum() for a, b, e in zip(g, p, es))
     logZ = lambda q: expfam.dirichlet_logZ(q[0]) + expfam.niw_logZ(q[1])
     return diff - (logZ(g) - logZ(p))
 
 
+def _allreduce_stats_and_kl(stats, local_kl, group):
+    """Sharded data points: ONE all-reduce of [dirichlet_stats | niw_stats | local_kl] (as the LDS model
+    does, svae_amd/parallel.py); the returned local_kl carries the global value and, if it is on the
+    autograd tape, this rank's gradient."""
+    from ..parallel import allreduce_global_stats
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return stats, local_kl
+    ds, ns = stats
+    packed = torch.cat([ds.reshape(-1), ns.reshape(-1), local_kl.detach().reshape(1)])
+    allreduce_global_stats(packed, group)
+    k = ds.numel()
+    return (packed[:k].reshape(ds.shape), packed[k:-1].reshape(ns.shape)), local_kl + (packed[-1] - local_kl.detach())
+
+
 def run_inference(prior_natparam, global_natparam, nn_potentials, num_samples, label_init=None,
-                  eps=None, generator=None):
-    """gmm.py:12-16 -> (samples (T,S,N), (dirichlet_stats, niw_stats), global_kl, local_kl)."""
+                  eps=None, generator=None, group=None, reference_compat=False):
+    """gmm.py:12-16 -> (samples (T,S,N), (dirichlet_stats, niw_stats), global_kl, local_kl).  Under
+    torch.distributed the points are this rank's shard; statistics and local_kl are summed over ranks."""
     _, stats, local_natparam, local_kl = local_meanfield(global_natparam, nn_potentials,
                                                          label_init=label_init, generator=generator)
     gn = local_natparam[1]
@@ -117,7 +142,8 @@ def run_inference(prior_natparam, global_natparam, nn_potentials, num_samples, l
     if eps is None:
         eps = torch.randn(T, num_samples, N, dtype=torch.float64, device=gn.device, generator=generator)
     samples = expfam.gaussian_natural_sample(gn, _dev64(eps, gn.device))
-    return samples, stats, prior_kl(global_natparam, prior_natparam), local_kl
+    stats, local_kl = _allreduce_stats_and_kl(stats, local_kl, group)
+    return samples, stats, prior_kl(global_natparam, prior_natparam, reference_compat), local_kl
 
 
 # --- differentiable call surface (what make_gradfun drives) ------------------------------------------
@@ -146,7 +172,8 @@ def _final_pass_torch(label_global, gaussian_globals, node_dense, label_stats):
 
 
 def run_inference_differentiable(prior_natparam, global_natparam, nn_potentials, num_samples,
-                                 label_init=None, eps=None, generator=None):
+                                 label_init=None, eps=None, generator=None, group=None,
+                                 reference_compat=False):
     """run_inference (gmm.py:12-16) with gradients w.r.t. nn_potentials flowing into `samples` and
     `local_kl`, exactly the two quantities the reference differentiates (svae.py:21-24); statistics
     are returned detached (`unbox(stats)`, gmm.py:16)."""
@@ -168,7 +195,8 @@ def run_inference_differentiable(prior_natparam, global_natparam, nn_potentials,
     samples = expfam.gaussian_natural_sample(gaussian_natparam, _dev64(eps, dev))
     dirichlet_stats = label_stats.detach().sum(0)
     niw_stats = torch.tensordot(label_stats.detach(), gaussian_stats.detach(), dims=([0], [0]))
-    return samples, (dirichlet_stats, niw_stats), prior_kl(global_natparam, prior_natparam), local_kl
+    stats, local_kl = _allreduce_stats_and_kl((dirichlet_stats, niw_stats), local_kl, group)
+    return samples, stats, prior_kl(global_natparam, prior_natparam, reference_compat), local_kl
 
 
 def init_pgm_param(K, N, alpha, niw_conc=10., random_scale=0., generator=None, dtype=torch.float64, device="cpu"):

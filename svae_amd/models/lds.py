@@ -20,7 +20,7 @@ import torch
 
 from ..distributions import expfam
 from ..lds.lds_inference import LDSEStepPlan, natural_lds_estep_general, reduce_stats
-from ..parallel import allreduce_global_stats
+from ..parallel import allreduce_lds_stats
 
 
 def _dev64(x, device):
@@ -88,18 +88,8 @@ def run_inference(prior_natparam, global_natparam, nn_potentials, num_samples, e
     local_kl = (nodeb[0] * En[0]).sum() + (nodeb[1] * En[1]).sum() - lognorm.sum()
     if len(nodeb) == 3:
         local_kl = local_kl + nodeb[2].sum()
-    # global statistics: deterministic device reduction, then the one collective
-    packed = plan.reduce().clone()
-    packed[-2] = local_kl                      # ship the local KL with the statistics
-    allreduce_global_stats(packed, group)
-    nn_ = n * n
-    cnt = packed[-1]
-    ExxT0, Ex0 = packed[:nn_].reshape(n, n), packed[nn_:nn_ + n]
-    o = nn_ + n
-    niw_stats = expfam.pack_dense(ExxT0, Ex0, cnt, cnt)
-    mniw_stats = (packed[o:o + nn_].reshape(n, n), packed[o + nn_:o + 2 * nn_].reshape(n, n),
-                  packed[o + 2 * nn_:o + 3 * nn_].reshape(n, n), cnt * (T - 1))
-    local_kl = packed[-2]
+    # global statistics: deterministic device reduction, then the one collective (statistics + local KL)
+    niw_stats, mniw_stats, local_kl = allreduce_lds_stats(plan.reduce(), local_kl, n, T, group)
     global_kl = lds_prior_kl(g, p, global_es)
     if not batched:
         samples = samples[0]
@@ -132,14 +122,9 @@ def run_inference_differentiable(prior_natparam, global_natparam, nn_potentials,
     local_kl = (nodeb[0] * dxx).sum() + (nodeb[1] * ex).sum() - lognorm.sum()
     if len(nodeb) == 3:
         local_kl = local_kl + nodeb[2].sum()
-    packed = plan.reduce().clone()
-    allreduce_global_stats(packed, group)
-    nn_ = n * n
-    cnt = packed[-1]
-    o = nn_ + n
-    niw_stats = expfam.pack_dense(packed[:nn_].reshape(n, n), packed[nn_:o], cnt, cnt)
-    mniw_stats = (packed[o:o + nn_].reshape(n, n), packed[o + nn_:o + 2 * nn_].reshape(n, n),
-                  packed[o + 2 * nn_:o + 3 * nn_].reshape(n, n), cnt * (T - 1))
+    # one collective for statistics AND the local KL (as run_inference): the returned local_kl has the
+    # global value and this rank's gradient
+    niw_stats, mniw_stats, local_kl = allreduce_lds_stats(plan.reduce(), local_kl, n, T, group)
     global_kl = lds_prior_kl(g, p, global_es)
     if not batched:
         samples = samples[0]

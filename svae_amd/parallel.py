@@ -27,3 +27,25 @@ def shard_bounds(num_items, rank=None, world=None):
     base, rem = divmod(num_items, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def allreduce_lds_stats(reduced, local_kl, n, T, group=None):
+    """The exchange step of the LDS model (svae/models/lds.py:35-52 with B sequences per rank).
+
+    `reduced` is this rank's buffer from svae_lds_reduce_stats_f64, [sum E_init (n^2+n) | sum E_pair (3n^2)
+    | sum lognorm | count]; `local_kl` this rank's sum of <nn_potentials, E_node> - lognorm.  ONE all-reduce
+    ships both (the sum-lognorm slot carries the local KL).  Returns (niw_stats dense-packed (n+2,n+2),
+    mniw_stats (4-tuple), local_kl) with the statistics and the VALUE of local_kl summed over all ranks;
+    if local_kl is on the autograd tape its gradient stays this rank's (each rank differentiates its own
+    shard, gradients are averaged by the caller's DDP)."""
+    from .distributions import expfam
+    packed = reduced.clone()
+    packed[-2] = local_kl.detach()
+    allreduce_global_stats(packed, group)
+    nn_ = n * n
+    o = nn_ + n
+    cnt = packed[-1]
+    niw_stats = expfam.pack_dense(packed[:nn_].reshape(n, n), packed[nn_:o], cnt, cnt)
+    mniw_stats = (packed[o:o + nn_].reshape(n, n), packed[o + nn_:o + 2 * nn_].reshape(n, n),
+                  packed[o + 2 * nn_:o + 3 * nn_].reshape(n, n), cnt * (T - 1))
+    return niw_stats, mniw_stats, local_kl + (packed[-2] - local_kl.detach())

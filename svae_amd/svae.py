@@ -49,16 +49,25 @@ def unflat_like(vec, struct):
     return build(struct)
 
 
-def split_into_batches(data, batch_size):
-    """util.py:120-123 without the permutation's global RNG: chunks of `batch_size` rows."""
+def split_into_batches(data, batch_size, permute=True, generator=None):
+    """util.py:120-126: chunks of `batch_size` consecutive rows, in a random order (the reference
+    permutes the chunks once with the global NumPy RNG; here `generator` seeds torch.randperm,
+    permute=False keeps the data order).  For (sequences, T, p) data a chunk is `batch_size` whole
+    sequences."""
     k = data.shape[0] // batch_size
-    return [data[i * batch_size:(i + 1) * batch_size] for i in range(k)], k
+    chunks = [data[i * batch_size:(i + 1) * batch_size] for i in range(k)]
+    if permute and k > 1:
+        order = torch.randperm(k, generator=generator).tolist()
+        chunks = [chunks[i] for i in order]
+    return chunks, k
 
 
 def make_gradfun(run_inference, recognize, loglike, pgm_prior, data, batch_size, num_samples,
-                 natgrad_scale=1., callback=callback):
-    num_datapoints = data.shape[0]
-    data_batches, num_batches = split_into_batches(data, batch_size)
+                 natgrad_scale=1., callback=callback, permute=True, generator=None):
+    # number of data points = rows (time steps / points), as get_num_datapoints(data) in the reference
+    # (svae.py:13): for (sequences, T, p) data every time step counts
+    num_datapoints = data.shape[0] * (data.shape[1] if data.dim() == 3 else 1)
+    data_batches, num_batches = split_into_batches(data, batch_size, permute, generator)
     get_batch = lambda i: data_batches[i % num_batches]
     saved = lambda: None
 

@@ -58,3 +58,42 @@ def test_hmm_batched_pair_params_and_unbatched_call():
         np.testing.assert_allclose(_np(Et[b]), ot, rtol=1e-8, atol=1e-11)
     lz1 = hmm_logZ((init, pairs[0], node[0]))
     assert lz1.dim() == 0 and float(lz1) == pytest.approx(float(logZ[0]), rel=1e-13)
+
+
+@pytest.mark.parametrize("gap", [40.0, 800.0])
+def test_hmm_near_deterministic_transitions(gap):
+    """Transition log-potentials `gap` below the diagonal (exp(-800) underflows in a scaled recursion;
+    the reference's log-space pass, cython_hmm_inference.pyx:93-121, keeps it).  The chain can only stay
+    where the initial potential puts it unless the likelihood gain of a switch exceeds the gap."""
+    from svae_amd.hmm.hmm_inference import hmm_estep
+    rng = np.random.default_rng(int(gap))
+    B, T, K = 4, 60, 6
+    init = np.log(rng.dirichlet(np.ones(K)))
+    pair = -gap * (1.0 - np.eye(K)) + 0.1 * rng.standard_normal((K, K))
+    node = 3.0 * rng.standard_normal((B, T, K))
+    logZ, (Ei, Et, Es) = hmm_estep((init, pair, node))
+    for b in range(B):
+        lz, (oi, ot, os_) = hmm_numpy.hmm_estep((init, pair, node[b]))
+        assert float(logZ[b]) == pytest.approx(lz, rel=1e-10, abs=1e-9)
+        np.testing.assert_allclose(_np(Es[b]), os_, rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(_np(Et[b]), ot, rtol=1e-8, atol=1e-11)
+        if ref.available():
+            rz, aux = ref.hmm_logZ((init, pair, node[b]))
+            assert float(logZ[b]) == pytest.approx(rz, rel=1e-10, abs=1e-9)
+    assert bool(torch.isfinite(logZ).all())
+
+
+def test_hmm_forced_transition_through_a_tiny_entry():
+    """The only path goes through a transition of log-potential -800 (state 0 becomes impossible after
+    t = 5 and its only exit is that entry): log Z ~ -800, finite, as in the reference."""
+    from svae_amd.hmm.hmm_inference import hmm_estep
+    K, T = 3, 12
+    init = np.array([0.0, -1e4, -1e4])
+    pair = np.array([[0.0, -800.0, -1e4], [-1e4, 0.0, -1.0], [-1e4, -1.0, 0.0]])
+    node = np.zeros((1, T, K))
+    node[0, 6:, 0] = -1e4
+    logZ, (Ei, Et, Es) = hmm_estep((init, pair, node))
+    lz, (oi, ot, os_) = hmm_numpy.hmm_estep((init, pair, node[0]))
+    assert np.isfinite(lz) and float(logZ[0]) == pytest.approx(lz, rel=1e-9)
+    np.testing.assert_allclose(_np(Es[0]), os_, rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(_np(Et[0]), ot, rtol=1e-7, atol=1e-9)

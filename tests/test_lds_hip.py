@@ -128,7 +128,7 @@ def test_non_positive_definite_is_reported():
     node = list(rand_node_potentials((6, 7, 4), rng))
     node[0][3, 2, :] = +1e6          # -1/2 J > 0  => indefinite filtered precision in sequence 3
     with pytest.raises(FloatingPointError, match="sequence 3"):
-        _run(init, pair, tuple(node))
+        _run(init, pair, tuple(node), check=True)
 
 
 @pytest.mark.parametrize("B", [512, 4096])
@@ -243,6 +243,53 @@ def test_sampler_full_size_against_reference_build():
     assert tuple(samples.shape) == (B, T, S, n)
     for b in idx:
         assert _rel(samples[b], want[int(b)]) < 1e-6
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("n,T,inhomog", [(10, 40, False), (3, 1, False), (4, 9, True), (15, 6, False)])
+def test_filter_messages_against_reference_build(n, T, inhomog):
+    """natural_filter_forward_general as its own entry point (lds_inference.py:18-24 imports it
+    separately): prediction / filtered messages in the reference's natural-parameter scaling."""
+    from svae_amd.lds.lds_inference import natural_filter_forward_general
+    from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials
+    rng = np.random.default_rng(3 * n + T)
+    B = 5
+    init, pair = rand_lds_natparam(n, rng)
+    if inhomog:
+        ps = [rand_lds_natparam(n, rng)[1] for _ in range(T - 1)]
+        pair = tuple(np.stack([p_[i] for p_ in ps]) for i in range(4))
+    node = rand_node_potentials((B, T, n), rng, with_logZ=True)
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev)
+    ((Jp, hp), (Jf, hf)), lognorm = natural_filter_forward_general(
+        tuple(t(x) for x in init), tuple(t(x) for x in pair), tuple(t(x) for x in node))
+    assert tuple(Jp.shape) == (B, T, n, n) and tuple(hf.shape) == (B, T, n)
+    for b in range(B):
+        ((rJp, rhp), (rJf, rhf)), rln, _ = ref.filter_forward(init, pair, tuple(x[b] for x in node))
+        assert _rel(lognorm[b], rln) < 1e-8
+        for got, want in ((Jp[b], rJp), (hp[b], rhp), (Jf[b], rJf), (hf[b], rhf)):
+            assert _rel(got, np.asarray(want)) < 1e-7
+    # unbatched call: the reference's shapes
+    ((Jp1, hp1), (Jf1, hf1)), ln1 = natural_filter_forward_general(
+        tuple(t(x) for x in init), tuple(t(x) for x in pair), tuple(t(x[0]) for x in node))
+    assert tuple(Jp1.shape) == (T, n, n) and ln1.dim() == 0 and torch.equal(Jf1, Jf[0])
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+def test_lds_sample_without_smoother_against_reference_build():
+    """cython_natural_lds_sample (lds_inference.py:260-264): filter + backward sampler only."""
+    from svae_amd.lds.lds_inference import cython_natural_lds_sample
+    from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials
+    rng = np.random.default_rng(12)
+    T, n, S = 30, 10, 3
+    init, pair = rand_lds_natparam(n, rng)
+    node = rand_node_potentials((T, n), rng, with_logZ=True)
+    want, eps = ref.sample_backward((init, pair), node, S, seed=77)
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev)
+    got = cython_natural_lds_sample((tuple(t(x) for x in init), tuple(t(x) for x in pair)),
+                                    tuple(t(x) for x in node), num_samples=S, eps=t(eps))
+    assert tuple(got.shape) == (T, S, n) and _rel(got, want) < 1e-7
 
 
 def test_sampler_moments_match_smoother():

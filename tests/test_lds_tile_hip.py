@@ -89,7 +89,7 @@ def test_tile_estep_flags_indefinite_potentials():
     t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev)
     nat = (tuple(t(x) for x in natparam[0]), tuple(t(x) for x in natparam[1]))
     with pytest.raises(Exception):
-        natural_lds_estep_general(nat, (t(J), t(h)))
+        natural_lds_estep_general(nat, (t(J), t(h)), check=True)
 
 
 def test_tile_estep_config4_properties():

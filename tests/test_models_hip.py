@@ -41,6 +41,10 @@ def test_gmm_run_inference_golden(golden_dir):
     logZ = lambda q: ef.dirichlet_logZ(q[0]) + ef.niw_logZ(q[1])
     shipped = (glob[0][0] - prior[0][0]) * es0 - (logZ(glob) - logZ(prior))
     assert shipped == pytest.approx(float(g["global_kl"]), rel=1e-12)
+    # ... and the compat switch reproduces the reference as shipped
+    _, _, kl_compat, _ = run_inference(prior, glob, (g["node_J"], g["node_h"]), g["eps"].shape[1],
+                                       label_init=g["label_init"], eps=g["eps"], reference_compat=True)
+    assert float(kl_compat) == pytest.approx(float(g["global_kl"]), rel=1e-10)
 
 
 def _lds_globals(n, rng, scale=1.0):

@@ -228,7 +228,7 @@ def test_make_gradfun_with_the_slds_model():
         samples, stats, gv, lv = slds_svae.run_inference_differentiable(prior_, glob_, pots, S_, generator=gen)
         return samples, slds_svae.global_stats_as_natparam(stats), -gv, -lv      # vlb -> kl sign of svae.py
 
-    gradfun = svae.make_gradfun(run, recognize, loglike, prior, data, B, S, callback=None)
+    gradfun = svae.make_gradfun(run, recognize, loglike, prior, data, B, S, callback=None, permute=False)
     natgrad, g_dec, g_rec = gradfun((glob, W_d, W_r), 0)
     assert svae.flat(natgrad).shape == svae.flat(glob).shape
     assert torch.isfinite(svae.flat(natgrad)).all()

@@ -72,7 +72,7 @@ def test_make_gradfun_lds_against_finite_differences_and_natgrad_formula():
     run = functools.partial(run_inference_differentiable, eps=eps)
     seen = []
     gradfun = make_gradfun(run, recognize, loglike, tuple(t64(x) if not isinstance(x, tuple) else tuple(t64(y) for y in x) for x in prior),
-                           data, Bn, 1, natgrad_scale=10., callback=lambda i, v, p_, g: seen.append(v))
+                           data, Bn, 1, natgrad_scale=10., callback=lambda i, v, p_, g: seen.append(v), permute=False)
     pgm_t = tuple(t64(x) if not isinstance(x, tuple) else tuple(t64(y) for y in x) for x in pgm)
     params = (pgm_t, loglike_p, recogn)
     pgm_natgrad, loglike_grad, recogn_grad = gradfun(params, 0)
@@ -97,7 +97,8 @@ def test_make_gradfun_lds_against_finite_differences_and_natgrad_formula():
     E_pair = [sum(np.asarray(w[1][1][i]) for w in want) for i in range(3)] + [Bn * (data.shape[1] - 1.)]
     flatnp = lambda s: np.concatenate([np.ravel(np.asarray(x, float)) for x in ([s[0]] + list(s[1]))])
     stats = flatnp((E_init, E_pair))
-    expect = -10. / data.shape[0] * (flatnp(prior) + 2 * stats - flatnp(pgm))
+    # (number of data points = time steps, get_num_datapoints of the reference, svae.py:13)
+    expect = -10. / (data.shape[0] * data.shape[1]) * (flatnp(prior) + 2 * stats - flatnp(pgm))
     got = _np(flat(pgm_natgrad))
     assert np.max(np.abs(got - expect)) < 1e-6 * np.max(np.abs(expect))
 

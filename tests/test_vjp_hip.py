@@ -192,3 +192,22 @@ def test_forward_outputs_do_not_depend_on_the_hand_off_kept():
     b = [plan.lognorm, plan.E_init, plan.E_pair, plan.E_node_diagxx, plan.E_node_x]
     for x, y in zip(a, b):
         assert float((x - y).abs().max()) <= 1e-12 * float(y.abs().max()) + 1e-300, float((x - y).abs().max())
+
+
+def test_plan_reuse_before_backward_is_refused():
+    """The VJP reads the workspace of the plan's last launch: a second forward on the same plan before
+    backward must raise instead of returning gradients of the wrong pass."""
+    from svae_amd.lds.lds_inference import LDSEStepPlan, lds_inference_differentiable
+    init, pair, node, g = _setup(4, 6, 2, 1, 3)
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev)
+    natparam = (tuple(t(x) for x in init), tuple(t(x) for x in pair))
+    plan = LDSEStepPlan(2, 6, 4, dev)
+    nJ, nh = t(node[0]).requires_grad_(True), t(node[1]).requires_grad_(True)
+    lognorm, _, _, _ = lds_inference_differentiable(natparam, (nJ, nh), plan=plan)
+    lds_inference_differentiable(natparam, (t(node[0]), t(node[1])), plan=plan)      # e.g. an evaluation pass
+    with pytest.raises(RuntimeError, match="launched again"):
+        lognorm.sum().backward()
+    lognorm2, _, _, _ = lds_inference_differentiable(natparam, (nJ, nh), plan=plan)
+    lognorm2.sum().backward()
+    assert torch.isfinite(nJ.grad).all()
