@@ -20,8 +20,10 @@
 // goes through transition potentials ~700 nats below the matrix' maximum (exp underflows to 0 where the
 // reference's log-space pass keeps e^-800).  Such a step (normaliser c_t below 1e-200: rare) is redone
 // in LOG SPACE for its sequence -- K log-sum-exps like the reference -- and flagged in the workspace; the
-// backward pass treats flagged steps in log space too.  Results then agree with the reference over its
-// whole range instead of turning into NaN.
+// backward pass treats flagged steps in log space too: no NaN, and the reference's value whenever the
+// paths that matter at a flagged step carried more than 1e-300 of the mass one step earlier.  (Components
+// of alpha below that are flushed to zero by the scaled steps in between -- only an all-log-space pass,
+// 4x the work, would keep them.)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

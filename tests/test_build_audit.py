@@ -17,13 +17,26 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 def test_audit_tool_detects_a_planted_hazard(tmp_path):
     s = tmp_path / "x.s"
-    s.write_text("f:\n\ts_nop 4\n\tv_fma_f64 v[2:3], v[4:5], v[6:7], v[8:9]\n"
-                 "\tv_fmac_f64_dpp v[10:11], v[2:3], v[6:7] row_newbcast:1 row_mask:0xf bank_mask:0xf\n")
+    s.write_text("f:\n\ts_nop 4\n\tv_fma_f64 v[2:3], v[4:5], v[6:7], v[8:9]\n\t;;#ASMSTART\n"
+                 "\tv_fmac_f64_dpp v[10:11], v[2:3], v[6:7] row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t;;#ASMEND\n")
     n, probs = audit_dpp_hazards.audit(str(s))
     assert n == 1 and len(probs) == 1 and "H1" in probs[0]
-    s.write_text("f:\n\ts_nop 4\n\tv_fma_f64 v[2:3], v[4:5], v[6:7], v[8:9]\n\ts_nop 1\n"
-                 "\tv_fmac_f64_dpp v[10:11], v[2:3], v[6:7] row_newbcast:1 row_mask:0xf bank_mask:0xf\n")
+    s.write_text("f:\n\ts_nop 4\n\tv_fma_f64 v[2:3], v[4:5], v[6:7], v[8:9]\n\ts_nop 1\n\t;;#ASMSTART\n"
+                 "\tv_fmac_f64_dpp v[10:11], v[2:3], v[6:7] row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t;;#ASMEND\n")
     assert audit_dpp_hazards.audit(str(s))[1] == []
+    # a DPP move the compiler emitted itself is padded by hipcc against producers it knows ...
+    s.write_text("f:\n\ts_nop 4\n\tv_fma_f64 v[2:3], v[4:5], v[6:7], v[8:9]\n"
+                 "\tv_mov_b64_dpp v[10:11], v[2:3] row_newbcast:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n")
+    assert audit_dpp_hazards.audit(str(s))[1] == []
+    # ... but not against one hidden in an inline-asm block
+    s.write_text("f:\n\ts_nop 4\n\t;;#ASMSTART\n\tv_fma_f64 v[2:3], v[4:5], v[6:7], v[8:9]\n\t;;#ASMEND\n"
+                 "\tv_mov_b64_dpp v[10:11], v[2:3] row_newbcast:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n")
+    assert len(audit_dpp_hazards.audit(str(s))[1]) == 1
+    # permlane swap (H3) and transcendental use (H4) inside asm
+    s.write_text("f:\n\ts_nop 4\n\t;;#ASMSTART\n\tv_mov_b32_e32 v2, v4\n\tv_permlane16_swap_b32_e32 v2, v3\n\t;;#ASMEND\n")
+    assert any("H3" in q for q in audit_dpp_hazards.audit(str(s))[1])
+    s.write_text("f:\n\ts_nop 4\n\tv_rcp_f64_e32 v[2:3], v[4:5]\n\tv_mul_f64 v[6:7], v[2:3], v[2:3]\n")
+    assert any("H4" in q for q in audit_dpp_hazards.audit(str(s))[1])
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")

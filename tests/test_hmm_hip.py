@@ -84,16 +84,21 @@ def test_hmm_near_deterministic_transitions(gap):
 
 
 def test_hmm_forced_transition_through_a_tiny_entry():
-    """The only path goes through a transition of log-potential -800 (state 0 becomes impossible after
-    t = 5 and its only exit is that entry): log Z ~ -800, finite, as in the reference."""
+    """The only path goes through a transition of log-potential -800 at a fixed time (state 0 is the only
+    possible state up to t = 5, impossible afterwards, and its only exit is that entry): a scaled step
+    underflows there; log Z ~ -800 must come out finite and equal to the reference's log-space value."""
     from svae_amd.hmm.hmm_inference import hmm_estep
     K, T = 3, 12
     init = np.array([0.0, -1e4, -1e4])
     pair = np.array([[0.0, -800.0, -1e4], [-1e4, 0.0, -1.0], [-1e4, -1.0, 0.0]])
-    node = np.zeros((1, T, K))
+    node = np.zeros((2, T, K))
+    node[0, :6, 1:] = -1e4
     node[0, 6:, 0] = -1e4
+    node[1] = 0.3 * np.random.default_rng(0).standard_normal((T, K))      # an ordinary sequence in the same wave
     logZ, (Ei, Et, Es) = hmm_estep((init, pair, node))
-    lz, (oi, ot, os_) = hmm_numpy.hmm_estep((init, pair, node[0]))
-    assert np.isfinite(lz) and float(logZ[0]) == pytest.approx(lz, rel=1e-9)
-    np.testing.assert_allclose(_np(Es[0]), os_, rtol=1e-7, atol=1e-10)
-    np.testing.assert_allclose(_np(Et[0]), ot, rtol=1e-7, atol=1e-9)
+    for b in range(2):
+        lz, (oi, ot, os_) = hmm_numpy.hmm_estep((init, pair, node[b]))
+        assert np.isfinite(lz) and float(logZ[b]) == pytest.approx(lz, rel=1e-9)
+        np.testing.assert_allclose(_np(Es[b]), os_, rtol=1e-7, atol=1e-10)
+        np.testing.assert_allclose(_np(Et[b]), ot, rtol=1e-7, atol=1e-9)
+    assert float(logZ[0]) < -790

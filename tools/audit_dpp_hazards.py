@@ -14,6 +14,10 @@ Wait states: every instruction issues in one wait state; `s_nop N` supplies N+1.
 linear per function; at a label (other predecessors possible) the history is reset to "unknown
 writer of everything" unless the block itself supplies the wait states.
 
+A DPP instruction the compiler emitted itself (outside ;;#ASMSTART .. ;;#ASMEND: the update_dpp
+intrinsic of dpp.hpp's bcast<>) is padded by hipcc against producers it knows; for those only a
+producer INSIDE an inline-asm block (invisible to the hazard recogniser) is reported.
+
 usage: audit_dpp_hazards.py file.s [...]     exit code 1 if any hazard is found.
 """
 import re
@@ -44,14 +48,19 @@ def audit(path):
     func = None
     hist = []          # list of (wait_states, written_vgprs or None(=unknown), writes_exec)
     n_dpp = 0
+    in_asm = False
     for ln, line in enumerate(open(path), 1):
+        if ";;#ASMSTART" in line:
+            in_asm = True
+        elif ";;#ASMEND" in line:
+            in_asm = False
         t = line.split(";")[0].strip()
         if not t:
             continue
         if t.endswith(":"):
             if not t.startswith(".L"):
                 func = t[:-1]
-            hist = [(0, None, True, None)]        # unknown predecessor state
+            hist = [(0, None, True, None, False)]        # unknown predecessor state
             continue
         if t.startswith("."):
             continue
@@ -72,10 +81,15 @@ def audit(path):
         if "_dpp" in op or is_swap:
             n_dpp += 1 if "_dpp" in op else 0
             src = regs(args[1]) if len(args) > 1 else set()
-            if op.startswith("v_mov") or is_swap:
-                src |= regs(args[0])                 # tied old operand / both operands of a swap
+            if (op.startswith("v_mov") and "bound_ctrl:1" not in t) or is_swap:
+                src |= regs(args[0])                 # tied old operand (unless every lane is written) / both operands of a swap
             ws = 0
-            for w, wr, wex, _tr in reversed(hist):
+            for w, wr, wex, _tr, w_asm in reversed(hist):
+                if not in_asm and not w_asm:       # compiler consumer, compiler (or unknown) producer: padded by hipcc
+                    ws += w
+                    if ws >= 5:
+                        break
+                    continue
                 if ws < 2 and (wr is None or (wr & src)):
                     problems.append("%s:%d [%s] %s read of v%s %d wait state(s) after its write: %s"
                                     % (path, ln, func, "H3: permlane-swap" if is_swap else "H1: DPP", sorted(src), ws, t))
@@ -88,16 +102,16 @@ def audit(path):
                 if ws >= 5:
                     break
         if op == "s_nop":
-            hist.append((int(args[0], 0) + 1, set(), False, None))
+            hist.append((int(args[0], 0) + 1, set(), False, None, in_asm))
         elif op.startswith("v_"):
             wex = op.startswith("v_cmpx")
             wr = set() if op.startswith("v_cmp") or op.startswith("v_readlane") or \
                 op.startswith("v_readfirstlane") else (regs(args[0]) if args else set())
             if is_swap and len(args) > 1:
                 wr |= regs(args[1])
-            hist.append((1, wr, wex, wr if is_trans(op) else None))
+            hist.append((1, wr, wex, wr if is_trans(op) else None, in_asm))
         else:
-            hist.append((1, set(), False, None))
+            hist.append((1, set(), False, None, in_asm))
         hist = hist[-8:]
     return n_dpp, problems
 
