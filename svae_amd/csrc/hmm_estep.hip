@@ -185,7 +185,10 @@ __global__ __launch_bounds__(64) void hmm_estep_kernel(const HmmArgs a) {
       double bn2 = 0.0, term[K];
       static_for<0, K>([&](auto k) {
         const double lpk = col ? pp[cc * K + k] : NEG_BIG;                   // log P[c][k]
-        term[k] = exp(fmax(lpk + bcast<k>(lw), -745.0)) * ((lpk + bcast<k>(lw) > -745.0) ? 1.0 : 0.0);
+        // (clamped: a state the forward pass excludes may have a future e^800 times likelier than the
+        //  states that carry the mass; its beta only ever multiplies an alpha or a likelihood of exactly 0)
+        const double x = lpk + bcast<k>(lw);
+        term[k] = x > -745.0 ? fmin(exp(fmin(x, 700.0)), 1e300) : 0.0;
         bn2 += term[k];                                                      // lane j = c: sum over k
       });
       // xi: lane k of accS[j] += alpha_t[j] * term_{lane j}[k]: transpose through broadcasts
@@ -193,7 +196,10 @@ __global__ __launch_bounds__(64) void hmm_estep_kernel(const HmmArgs a) {
         static_for<0, K>([&](auto j) {
           // value at (j, k) lives in lane j, register k; lane k needs it: K x K broadcasts (rare path)
           double row = 0.0;
-          static_for<0, K>([&](auto k) { row = (c == k) ? bcast<j>(term[k]) : row; });
+          static_for<0, K>([&](auto k) {
+            const double v = bcast<j>(term[k]);       // (unconditional: the source lane must be active)
+            row = (c == k) ? v : row;
+          });
           accS[j] += bcast<j>(al) * row;
         });
       }
@@ -203,7 +209,7 @@ __global__ __launch_bounds__(64) void hmm_estep_kernel(const HmmArgs a) {
       double bn = 0.0;
       static_for<0, K>([&](auto k) { mac_bc<k, false, true>(bn, w0, PT[k]); });
       static_for<0, K>([&](auto j) { mac_bc<j, false, true>(acc[j], al0, w0); });
-      beta = slow ? bn2 : bn;
+      beta = slow ? fmin(bn2, 1e300) : bn;
       const double gam = al * beta;
       if (valid && col) oS[(long)t * K] = gam;
       if (t == 0 && valid && col) a.E_init[(long)b * K + c] = gam;
