@@ -393,17 +393,17 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
   const long tstride = col ? WS : 0;
   const double* hp_ = hrow0 + (long)(T - 1) * tstride;     // walking pointers: steps T-1, T-2, ..
   const double* pp_ = prow0 + (long)(T - 1) * tstride;
-  auto load_step = [&](int, double (&h)[N + 1], double (&pi)[N]) {
+  auto load_step = [&](long more, double (&h)[N + 1], double (&pi)[N]) {   // more: another step follows
     load_row<N + 1>(hp_, h);
     load_row<N>(pp_, pi);
-    hp_ -= tstride;
-    pp_ -= tstride;
+    hp_ -= more * tstride;
+    pp_ -= more * tstride;
   };
 
   // one backward step: consumes (H, Pi) of step t, prefetches step t-1 into (Hn, Pin)
   auto step = [&](int tt, double (&H)[N + 1], double (&Pi)[N], double (&Hn)[N + 1], double (&Pin)[N]) {
     const int t = tt < 0 ? -1 - tt : tt;
-    if (tt > 0) load_step(t - 1, Hn, Pin);
+    if constexpr (!LOWREG) load_step(t > 1 ? 1 : 0, Hn, Pin);    // unconditional prefetch of step t-1 (t = 0: re-reads record 0, unused)
     dpp_fence(H);   // not a DPP source, but keeps the loads' consumers behind this point
 
     // W~ = S~_{t+1} G~'   (W[i][c] = E[x~_{t+1,i} x~_{t,c}])
@@ -457,12 +457,12 @@ __global__ __launch_bounds__(64) void lds_estep_kernel(const LdsArgs a) {
   if constexpr (LOWREG) {
     double Ha[N + 1], Pia[N];
     for (int t = T - 1; t >= 0; --t) {
-      load_step(t, Ha, Pia);
+      load_step(1, Ha, Pia);
       step(-1 - t, Ha, Pia, Ha, Pia);   // negative: "no prefetch" (see step)
     }
   } else {
     double Ha[N + 1], Pia[N], Hb[N + 1], Pib[N];
-    load_step(T - 1, Ha, Pia);
+    load_step(T > 1 ? 1 : 0, Ha, Pia);
     int t = T - 1;
     for (; t >= 1; t -= 2) {          // two steps per trip: the prefetch buffers ping-pong
       step(t, Ha, Pia, Hb, Pib);
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(64) void lds_sample_kernel(const SampleArgs a) {
       static_for<0, N + 1>([&](auto k) { H[k] = col ? Hn[k] : 0.0; });
       static_for<0, N>([&](auto k) { R[k] = col ? Rn[k] : 0.0; Y[k] = Yn[k]; });
       const double pv = col ? pvn : 1.0;
-      if (t > 0) fetch(t - 1);
+      fetch(t > 0 ? t - 1 : 0);                // (unconditional: see load_step)
       double dis = 1.0 / sqrt(pv);             // lane k: D_k^-1/2
       dpp_fence(H);
       dpp_fence(R);

@@ -213,14 +213,16 @@ __global__ __launch_bounds__(64) void lds_estep_split_kernel(const LdsArgs a) {
   // walking pointers (one 64-bit add per pointer and step instead of a 64-bit multiply)
   const double* hp_ = hrow0 + (long)(T - 1) * tstride;
   static_for<0, J1>([&](auto j) { gptr[j] += (long)(T - 1) * gstride[j]; pptr[j] += (long)(T - 1) * pstride[j]; });
-  auto load_step = [&](int, double (&H)[N + 1], double (&Gc)[J1], double (&Pi)[J1]) {   // steps T-1, T-2, ..
+  // (unconditional: a prefetch skipped by a branch makes hipcc wait for the loads just issued at the join;
+  //  `more` = another step follows, else the pointers stay and the last record is read once more, unused)
+  auto load_step = [&](long more, double (&H)[N + 1], double (&Gc)[J1], double (&Pi)[J1]) {   // steps T-1, T-2, ..
     load_row<N + 1>(hp_, H);
-    hp_ -= tstride;
+    hp_ -= more * tstride;
     static_for<0, J1>([&](auto j) {
       Gc[j] = *gptr[j];
       Pi[j] = *pptr[j];
-      gptr[j] -= gstride[j];
-      pptr[j] -= pstride[j];
+      gptr[j] -= more * gstride[j];
+      pptr[j] -= more * pstride[j];
     });
   };
 
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(64) void lds_estep_split_kernel(const LdsArgs a) {
   (void)warm; (void)sink;
   auto step = [&](int t, double (&H)[N + 1], double (&Gc)[J1], double (&Pi)[J1],
                   double (&Hn)[N + 1], double (&Gcn)[J1], double (&Pin)[J1]) {
-    if (t > 0) load_step(t - 1, Hn, Gcn, Pin);      // prefetch: hides the L2/HBM latency
+    load_step(t > 1 ? 1 : 0, Hn, Gcn, Pin);         // prefetch of step t-1: hides the L2/HBM latency
 #if SVAE_WARM_AHEAD > 0
     // L2 warming: one 128-byte line per lane of the hand-off record SVAE_WARM_AHEAD steps ahead (the
     // forward half wrote it ~T steps ago: HBM, further away than one step of arithmetic); the value
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(64) void lds_estep_split_kernel(const LdsArgs a) {
 
   {
     double Ha[N + 1], Gca[J1], Pia[J1], Hb[N + 1], Gcb[J1], Pib[J1];
-    load_step(T - 1, Ha, Gca, Pia);
+    load_step(T > 1 ? 1 : 0, Ha, Gca, Pia);
     int t = T - 1;
     for (; t >= 1; t -= 2) {          // two steps per trip: the prefetch buffers ping-pong
       step(t, Ha, Gca, Pia, Hb, Gcb, Pib);

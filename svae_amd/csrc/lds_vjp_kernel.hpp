@@ -116,27 +116,47 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep1_kernel(const VjpArgs a) {
   const int ss = sv ? c : 0;
 
   const double cm = col ? 1.0 : 0.0;
+  // Memory schedule: the operands a step STARTS with (role 0: W~' and the direct cotangents; role 1: the
+  // sample cotangents) are fetched into registers one step ahead; the others (H, P^-1, the LDL' factor) are
+  // requested raw at the top of the step and first touched a product later.  Every load unconditional.
+  const int cN = colN ? c : 0, ccl = col ? c : 0;
+  const bool has_gx = a.g_x != nullptr, has_gd = a.g_diagxx != nullptr;
+  double WTn[N + 1], gxn = 0.0, gdn = 0.0, gsn[SAMP ? N : 1];
+  auto fetch_next = [&](int t) {
+    if (do0) {
+      load_row<N + 1>(a.ws3 + ((long)b * T + t) * (N + 1) * HS + cN * HS, WTn);
+      const long o = ((long)b * T + t) * N + ccl;
+      gxn = has_gx ? a.g_x[o] : 0.0;
+      gdn = has_gd ? a.g_diagxx[o] : 0.0;
+    }
+    if constexpr (SAMP) {
+      if (do1) {
+        const double* gs = a.g_samples + (((long)b * T + t) * S + ss) * N;
+        static_for<0, N>([&](auto k) { gsn[k] = gs[k]; });
+      }
+    }
+  };
+  fetch_next(0);
   for (int t = 0; t < T; ++t) {
     const double* w = wsb + (long)t * WS;
-    const double* w3 = a.ws3 + ((long)b * T + t) * (N + 1) * HS;
     double* ad = a.adj + ((long)b * T + t) * AS;
-    double Hc[N];
-    static_for<0, N>([&](auto k) { const double v = w[k * HS + (colN ? c : 0)]; Hc[k] = colN ? v : 0.0; });
+    double Hcr[N];
+    static_for<0, N>([&](auto k) { Hcr[k] = w[k * HS + cN]; });
     double Gb[N];                              // G^ rows i < N (lanes 0..N); one share per role if SPLIT
     static_for<0, N>([&](auto i) { Gb[i] = 0.0; });
+    double WT[N + 1], Gc[N + 1], Pir[N], gx = 0.0, gd = 0.0, gsv[SAMP ? N : 1];
     if (do0) {
-    double WT[N + 1], Gc[N + 1];
-    {
-      double tmp[N + 1];
-      load_row<N + 1>(w3 + (colN ? c : 0) * HS, tmp);
-      static_for<0, N + 1>([&](auto k) { WT[k] = colN ? 2.0 * tmp[k] : 0.0; });      // 2 W~'
+      static_for<0, N + 1>([&](auto k) { WT[k] = colN ? 2.0 * WTn[k] : 0.0; });      // 2 W~'
+      gx = col ? 0.5 * gxn : 0.0;              // direct cotangents, symmetrised
+      gd = col ? gdn : 0.0;
+      static_for<0, N>([&](auto i) { Pir[i] = w[N * HS + i * PS + ccl]; });
     }
+    if constexpr (SAMP) static_for<0, N>([&](auto k) { gsv[k] = gsn[k]; });
+    fetch_next(t + 1 < T ? t + 1 : t);
+    double (&Hc)[N] = Hcr;      // raw: lanes > N are zeroed by sg / never broadcast
+    if (do0) {
     static_for<0, N>([&](auto k) { Gc[k] = Hc[k] * sg; });
     Gc[N] = EN;
-
-    // direct cotangents, symmetrised
-    double gx = (a.g_x && col) ? 0.5 * a.g_x[((long)b * T + t) * N + c] : 0.0;
-    const double gd = (a.g_diagxx && col) ? a.g_diagxx[((long)b * T + t) * N + c] : 0.0;
     Sh[N] += gx;
     dpp_fence(gx);
     static_for<0, N>([&](auto i) {
@@ -206,8 +226,7 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep1_kernel(const VjpArgs a) {
       //   -P^-1 Pinvbar P^-1,   Pinvbar = S^[:n,:n] (before the propagation below)
       double Pi[N], Pib[N], T1[N], Pbp[N];
       static_for<0, N>([&](auto i) {
-        const double v = w[N * HS + i * PS + (col ? c : 0)];
-        Pi[i] = col ? v : 0.0;
+        Pi[i] = Pir[i];
         Pib[i] = Sh[i] * cm;
         T1[i] = 0.0; Pbp[i] = 0.0;
       });
@@ -244,8 +263,12 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep1_kernel(const VjpArgs a) {
       if (do1) {
       // xhat_t = g_samples_t - X_{t-1}' xhat_{t-1}   (register k, lane = sample)
       double xn[N];
-      const double* gs = a.g_samples + (((long)b * T + t) * S + ss) * N;
-      static_for<0, N>([&](auto k) { const double v = gs[k]; xn[k] = sv ? v : 0.0; });
+      static_for<0, N>([&](auto k) { xn[k] = sv ? gsv[k] : 0.0; });
+      // the LDL' factor of the step (needed two product stages further down)
+      const double* w2 = a.ws2 + ((long)b * T + t) * (N * N + N);
+      double Rr[N];
+      static_for<0, N>([&](auto k) { Rr[k] = w2[k * N + ccl]; });
+      const double pvv = w2[N * N + ccl];
       dpp_fence(HcPrev);
       static_for<0, N>([&](auto j) {
         static_for<0, N>([&](auto k) { mac_bc<k, true>(xn[k], HcPrev[j], xh[j]); });
@@ -265,10 +288,8 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep1_kernel(const VjpArgs a) {
         }
       });
       // noise adjoint:  Pbar_t(direct) = -U (Lh U')  with  U = L^-T D^-1/2,  Lh from E' = sum_s eps_s z_s'
-      const double* w2 = a.ws2 + ((long)b * T + t) * (N * N + N);
       double R[N], U[N];
-      static_for<0, N>([&](auto k) { const double v = w2[k * N + (col ? c : 0)]; R[k] = col ? v : 0.0; });
-      const double pvv = w2[N * N + (col ? c : 0)];
+      static_for<0, N>([&](auto k) { R[k] = Rr[k]; });
       const double dis = col ? 1.0 / sqrt(pvv) : 0.0;
       static_for<0, N>([&](auto k) { U[k] = E[k] * dis; });
       dpp_fence(R);
@@ -331,30 +352,43 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep2_kernel(const VjpArgs a) {
   double Ab[N];                                               // [Abar | hbar] of step t+1
   static_for<0, N>([&](auto i) { Ab[i] = 0.0; });
 
+  // Memory schedule of a step (the sweep is serial in t, so nothing else hides a load):
+  //   * G^ of step t-1 (the operand the step STARTS with) is fetched into registers one step ahead;
+  //   * P^-1, H, H' of the step are requested at its top, raw, and first touched after the J12 product;
+  //   * the sweep-1 shares of Pbar are requested before the P^-1 product that precedes their use;
+  //   * (small batches) the records of a step VJP_AHEAD iterations ahead are touched so that all of these
+  //     find their lines in L2 (they were written ~T steps ago by other kernels: HBM otherwise).
+  const int cN = colN ? c : 0, cc = col ? c : 0;
+  double gbn[N], gb2n[(SAMP && SPLIT) ? N : 1];
+  auto fetch_g = [&](int t) {
+    const double* ad = a.adj + ((long)b * T + t) * AS;
+    static_for<0, N>([&](auto i) {
+      gbn[i] = ad[i * HS + cN];
+      if constexpr (SAMP && SPLIT) gb2n[i] = ad[N * HS + i * HS + cN];
+    });
+  };
+  fetch_g(T - 1);
   double warm = 0.0, sink = 0.0;
   for (int t = T - 1; t >= 0; --t) {
     const double* w = wsb + (long)t * WS;
     const double* ad = a.adj + ((long)b * T + t) * AS;
+    double Xc[N];
+    static_for<0, N>([&](auto i) {
+      double gb = gbn[i];
+      if constexpr (SAMP && SPLIT) gb += gb2n[i];
+      Xc[i] = colN ? gb * sg : 0.0;                            // [Xbar | cbar] = [-G^ | G^[:,n]]
+    });
+    // raw operands: lanes outside the tile read element 0 of the row (finite); they are never a DPP
+    // broadcast source and only reach lanes of the results that are masked or not stored
+    double Pi[N], Hc[N], HT[N + 1];
+    static_for<0, N>([&](auto i) { Pi[i] = w[N * HS + i * PS + cc]; Hc[i] = w[i * HS + cN]; });
+    load_row<N + 1>(w + cc * HS, HT);                          // H' (lane c: row c of H)
+    fetch_g(t > 0 ? t - 1 : 0);
     sink += warm;                                              // last iteration's touches have landed
     if (a.B <= 2048) {                                         // (large batches are bandwidth-bound: no extra traffic)
       const int tw = t >= VJP_AHEAD ? t - VJP_AHEAD : 0;
       warm = touch_lines<(WS + 15) / 16>(wsb + (long)tw * WS, c, WS)
            + touch_lines<(AS + 15) / 16>(a.adj + ((long)b * T + tw) * AS, c, AS);
-    }
-    double Pi[N], Hc[N], HT[N + 1], Xc[N];
-    static_for<0, N>([&](auto i) {
-      const double v = w[N * HS + i * PS + (col ? c : 0)];
-      Pi[i] = col ? v : 0.0;
-      const double h = w[i * HS + (colN ? c : 0)];
-      Hc[i] = colN ? h : 0.0;
-      double gb = ad[i * HS + (colN ? c : 0)];
-      if constexpr (SAMP && SPLIT) gb += ad[N * HS + i * HS + (colN ? c : 0)];
-      Xc[i] = colN ? gb * sg : 0.0;                            // [Xbar | cbar] = [-G^ | G^[:,n]]
-    });
-    {
-      double tmp[N + 1];
-      load_row<N + 1>(w + (col ? c : 0) * HS, tmp);
-      static_for<0, N + 1>([&](auto k) { HT[k] = col ? tmp[k] : 0.0; });    // H' (lane c: row c of H)
     }
     // [Xbar | cbar] -= J12_t [Abar | hbar]_{t+1}
     if (t < T - 1) {
@@ -366,11 +400,14 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep2_kernel(const VjpArgs a) {
       mm_ab<N, N, true>(Xc, J12c, Ab);
     }
     // Bbar = P^-1 [Xbar | cbar]
-    double Bb[N], Pb[N];
-    static_for<0, N>([&](auto i) { Bb[i] = 0.0; });
+    double Bb[N], Pb[N], Pxr[SAMP ? N : 1];
+    static_for<0, N>([&](auto i) {                             // sweep-1 shares of Pbar: land during the product
+      Pb[i] = ad[2 * N * HS + i * PS + cc];
+      if constexpr (SAMP) Pxr[i] = ad[2 * N * HS + N * PS + i * PS + cc];
+      Bb[i] = 0.0;
+    });
     mm_ab<N, N, false>(Bb, Pi, Xc);
     // Pbar = [-P^-1 Pinvbar P^-1: from sweep 1] - Bbar H' - 1/2 g (c c' + P^-1) [+ direct]
-    static_for<0, N>([&](auto i) { const double v = ad[2 * N * HS + i * PS + (col ? c : 0)]; Pb[i] = col ? v : 0.0; });
     mm_ab<N, N + 1, true>(Pb, Bb, HT);
     double cvs = -0.5 * g * HT[N];
     dpp_fence(cvs);
@@ -379,7 +416,7 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep2_kernel(const VjpArgs a) {
       Pb[i] = __builtin_fma(-0.5 * g, Pi[i], Pb[i]);
     });
     if constexpr (SAMP) {
-      static_for<0, N>([&](auto i) { const double v = ad[2 * N * HS + N * PS + i * PS + (col ? c : 0)]; Pb[i] += col ? v : 0.0; });
+      static_for<0, N>([&](auto i) { Pb[i] += Pxr[i]; });
     }
     // outputs and the adjoint handed to step t-1:  Ab = [Pbar | Bbar[:,n] + g c]
     double gJ = 0.0, gh = 0.0;
