@@ -120,6 +120,19 @@ __device__ __forceinline__ double rcp_nr(double p) {
   return r;
 }
 
+// 1/sqrt(p) to full fp64 accuracy without the library's sqrt + divide (~70 instructions): v_rsq_f64 seed
+// (~2^-24) + two coupled Newton steps (r <- r + r e (1/2 + 3/8 e), e = 1 - p r^2: cubic convergence).
+__device__ __forceinline__ double rsqrt_nr(double p) {
+  double r = __builtin_amdgcn_rsq(p);
+  static_for<0, 2>([&](auto) {
+    const double pr = p * r;
+    const double e = __builtin_fma(-pr, r, 1.0);
+    const double h = __builtin_fma(0.375, e, 0.5);
+    r = __builtin_fma(r * e, h, r);
+  });
+  return r;
+}
+
 // Ordered pieces of the reciprocal chain (v_rcp_f64 + two Newton steps) for hand-pipelined pivoting:
 // asm statements keep their place between the DPP row updates.
 __device__ __forceinline__ double asm_rcp(double p) {

@@ -562,7 +562,7 @@ __global__ __launch_bounds__(64) void lds_sample_kernel(const SampleArgs a) {
       static_for<0, N>([&](auto k) { R[k] = col ? Rn[k] : 0.0; Y[k] = Yn[k]; });
       const double pv = col ? pvn : 1.0;
       fetch(t > 0 ? t - 1 : 0);                // (unconditional: see load_step)
-      double dis = 1.0 / sqrt(pv);             // lane k: D_k^-1/2
+      double dis = rsqrt_nr(pv);               // lane k: D_k^-1/2
       dpp_fence(H);
       dpp_fence(R);
       dpp_fence(dis);

@@ -77,6 +77,18 @@ __device__ __forceinline__ double touch_lines(const double* rec, int c, long dou
   return s;
 }
 constexpr int VJP_AHEAD = 4;
+constexpr int SPRE = 2;      // samples whose x_{t+1} / eps rows are requested at the top of the sampler-adjoint role
+
+// f(integral_constant<s>) for s = S0, S0+1, .. while s < S (S <= 16 at run time): leaves at the first s >= S
+template <int S0, class F>
+__device__ __forceinline__ void for_samples(int S, F&& f) {
+  if constexpr (S0 < 16) {
+    if (S0 < S) {
+      f(std::integral_constant<int, S0>{});
+      for_samples<S0 + 1>(S, f);
+    }
+  }
+}
 
 // ---- sweep 1: smoother + sampler adjoints, forward in time ----------------------------------------
 // The two adjoint chains of this sweep are independent (the S^ recursion of the smoother; the xhat
@@ -269,6 +281,12 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep1_kernel(const VjpArgs a) {
       double Rr[N];
       static_for<0, N>([&](auto k) { Rr[k] = w2[k * N + ccl]; });
       const double pvv = w2[N * N + ccl];
+      double x1r[SPRE], epr[SPRE];
+      static_for<0, SPRE>([&](auto s) {
+        const int sq = s < S ? (int)s : 0;                      // (clamped: unconditional loads)
+        x1r[s] = a.samples[(((long)b * T + (t + 1 < T ? t + 1 : t)) * S + sq) * N + ccl];
+        epr[s] = a.eps[(((long)b * T + t) * S + sq) * N + ccl];
+      });
       dpp_fence(HcPrev);
       static_for<0, N>([&](auto j) {
         static_for<0, N>([&](auto k) { mac_bc<k, true>(xn[k], HcPrev[j], xh[j]); });
@@ -276,21 +294,21 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep1_kernel(const VjpArgs a) {
       static_for<0, N>([&](auto k) { xh[k] = xn[k]; HcPrev[k] = Hc[k]; });
       dpp_fence(xh);
       // cbar_t += sum_s xhat (lane N);  Xbar_t -= sum_s xhat x_{t+1}'  (i.e. G^[:, :n] += ...)
-      static_for<0, 16>([&](auto s) {
-        if (s < S) {
-          double v = EN;
-          if (t + 1 < T) {
-            const double x1 = a.samples[(((long)b * T + t + 1) * S + s) * N + (col ? c : 0)];
-            v += col ? x1 : 0.0;
-          }
-          asm volatile("s_nop 1");   // block entry after the branch: two wait states before the DPP reads (audit rule)
-          static_for<0, N>([&](auto i) { mac_bc<s>(Gb[i], xh[i], v); });
+      // (x_{t+1} and eps of the first samples were requested at the top of the role: x1r, epr)
+      for_samples<0>(S, [&](auto s) {
+        double v = EN;
+        if (t + 1 < T) {
+          const double x1 = (s < SPRE) ? x1r[s < SPRE ? (int)s : 0]
+                                       : a.samples[(((long)b * T + t + 1) * S + s) * N + ccl];
+          v += col ? x1 : 0.0;
         }
+        asm volatile("s_nop 1");   // block entry after the branch: two wait states before the DPP reads (audit rule)
+        static_for<0, N>([&](auto i) { mac_bc<s>(Gb[i], xh[i], v); });
       });
       // noise adjoint:  Pbar_t(direct) = -U (Lh U')  with  U = L^-T D^-1/2,  Lh from E' = sum_s eps_s z_s'
       double R[N], U[N];
       static_for<0, N>([&](auto k) { R[k] = Rr[k]; });
-      const double dis = col ? 1.0 / sqrt(pvv) : 0.0;
+      const double dis = col ? rsqrt_nr(pvv) : 0.0;
       static_for<0, N>([&](auto k) { U[k] = E[k] * dis; });
       dpp_fence(R);
       static_for<1, N>([&](auto jj) {
@@ -304,13 +322,12 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep1_kernel(const VjpArgs a) {
         static_for<0, N>([&](auto j) { mac_bc<j>(z[j], U[i], xh[i]); });        // z = U' xhat
       });
       dpp_fence(z);
-      static_for<0, 16>([&](auto s) {
-        if (s < S) {
-          const double e1 = a.eps[(((long)b * T + t) * S + s) * N + (col ? c : 0)];
-          const double ev = col ? e1 : 0.0;
-          asm volatile("s_nop 1");   // block entry (audit rule)
-          static_for<0, N>([&](auto j) { mac_bc<s>(ET[j], z[j], ev); });         // ET[j][c] = E[c][j]
-        }
+      for_samples<0>(S, [&](auto s) {
+        const double e1 = (s < SPRE) ? epr[s < SPRE ? (int)s : 0]
+                                     : a.eps[(((long)b * T + t) * S + s) * N + ccl];
+        const double ev = col ? e1 : 0.0;
+        asm volatile("s_nop 1");   // block entry (audit rule)
+        static_for<0, N>([&](auto j) { mac_bc<s>(ET[j], z[j], ev); });         // ET[j][c] = E[c][j]
       });
       double LhT[N], K[N], KT[N], Pex[N];
       static_for<0, N>([&](auto j) { LhT[j] = ET[j] * mU[j]; K[j] = 0.0; Pex[j] = 0.0; });
