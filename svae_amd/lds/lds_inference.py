@@ -82,9 +82,11 @@ class LDSEStepPlan(object):
                node_logZ=None, pair_batched=False, keep_factor=False, keep_cross=False):
         """Raw launch on the current stream.  All arguments: contiguous float64 device tensors."""
         p = _lib.ptr
+        keep = int(bool(keep_factor)) | (2 if keep_cross else 0)
+        if self.n > _lib.LDS_MAX_N:
+            keep = 0       # tile kernel: its hand-off always serves the (dense-algebra) sampler, lds_large.py
         rc = self.lib.svae_lds_estep_f64(
-            self.B, self.T, self.n, int(self.inhomog), int(pair_batched),
-            int(bool(keep_factor)) | (2 if keep_cross else 0),
+            self.B, self.T, self.n, int(self.inhomog), int(pair_batched), keep,
             p(init_J), p(init_h), p(init_logZ), p(J11), p(J12), p(J22), p(logZ_pair),
             p(node_J), p(node_h), p(node_logZ),
             p(self.lognorm), p(self.E_init), p(self.E_pair), p(self.E_node_diagxx),
@@ -92,8 +94,8 @@ class LDSEStepPlan(object):
             _lib.current_stream(self.device))
         _lib.check(rc, "svae_lds_estep_f64")
         self.epoch += 1
-        self.has_factor = bool(keep_factor)
-        self.has_cross = bool(keep_cross)
+        self.has_factor = bool(keep_factor) and self.n <= _lib.LDS_MAX_N
+        self.has_cross = bool(keep_cross) and self.n <= _lib.LDS_MAX_N
         self._J12 = J12
         self._pair_batched = bool(pair_batched)
 
@@ -117,6 +119,12 @@ class LDSEStepPlan(object):
         """Backward sampling from the messages of the last `launch(..., keep_factor=True)`.
         eps: (B,T,S,n) standard-normal draws -> samples (B,T,S,n)
         [natural_sample_backward, cython_lds_inference.pyx:310-355]."""
+        if self.n > _lib.LDS_MAX_N:
+            # 16 <= n <= 64: from the tile kernel's hand-off with batched dense linear algebra (lds_large.py)
+            from .lds_large import sample_from_handoff
+            if self.epoch == 0:
+                raise RuntimeError("sample() needs a preceding launch()")
+            return sample_from_handoff(self, eps.to(device=self.device, dtype=torch.float64))
         if not getattr(self, "has_factor", False):
             raise RuntimeError("sample() needs a preceding launch(..., keep_factor=True)")
         if eps.dim() != 4 or eps.shape[0] != self.B or eps.shape[1] != self.T or eps.shape[3] != self.n:
@@ -427,7 +435,9 @@ def lds_inference_differentiable(natparam, node_params, eps=None, plan=None):
         plan = LDSEStepPlan(B, T, n, dev, inhomog, pair_batched)
     params = (init_J, init_h, init_logZ, J11, J12, J22, logZ_pair)
     cont = lambda x: None if x is None else x.to(torch.float64).contiguous()
-    out = _LDSInference.apply(cont(node_J), cont(node_h), cont(node_logZ), cont(eps), plan, params,
-                              pair_batched)
+    fn = _LDSInference
+    if n > _lib.LDS_MAX_N:
+        from .lds_large import LDSInferenceLarge as fn     # tile-kernel forward, dense-algebra backward
+    out = fn.apply(cont(node_J), cont(node_h), cont(node_logZ), cont(eps), plan, params, pair_batched)
     lognorm, dxx, ex, samples, E_init, E_pair = out
     return lognorm, (dxx, ex), (samples if eps is not None else None), (E_init, E_pair)
