@@ -82,6 +82,7 @@ def torch_estep(params, node_J, node_h, eps=None, per_step_stats=False):
     hp = init_h.expand(B, n)
     lognorm = init_logZ.reshape(()).expand(B).clone()
     Gs, cs, Pis, Ls = [], [], [], []
+    eye = torch.eye(n, dtype=node_h.dtype, device=node_h.device)
     for t in range(T):
         last = t == T - 1
         P = Jp + torch.diag_embed(-2.0 * node_J[:, t])
@@ -89,14 +90,22 @@ def torch_estep(params, node_J, node_h, eps=None, per_step_stats=False):
         if not last:
             P = P + (-2.0) * _pair_at(J11, t)
         L = torch.linalg.cholesky(P)
-        c = torch.cholesky_solve(hf.unsqueeze(-1), L)[..., 0]
+        Lt = L.transpose(-1, -2)
+        # P^-1 [h | I | J12] by two triangular solves (torch.cholesky_solve is unreliable on this ROCm build:
+        # wrong results in 26 of 40 calls at n = 32, 37 of 40 at n = 48, right-hand side contiguous or not)
+        rhs = [hf.unsqueeze(-1), eye.expand(B, n, n)]
+        if not last:
+            R = -_pair_at(J12, t)                               # info-form off-diagonal block
+            rhs.append(R.expand(B, n, n))
+        sol = torch.linalg.solve_triangular(Lt, torch.linalg.solve_triangular(L, torch.cat(rhs, -1), upper=False),
+                                            upper=True)
+        c = sol[..., 0]
         lognorm = lognorm + 0.5 * (hf * c).sum(-1) - torch.log(torch.diagonal(L, dim1=-1, dim2=-2)).sum(-1)
-        Pis.append(torch.cholesky_inverse(L))
+        Pis.append(sol[..., 1:n + 1])
         cs.append(c)
         Ls.append(L)
         if not last:
-            R = -_pair_at(J12, t)                               # info-form off-diagonal block
-            X = torch.cholesky_solve(R.expand(B, n, n), L)      # P^-1 J12
+            X = sol[..., n + 1:]                                # P^-1 J12
             Gs.append(-X)
             Jp = -2.0 * _pair_at(J22, t) - torch.matmul(R.transpose(-1, -2), X)
             hp = -torch.matmul(R.transpose(-1, -2), c.unsqueeze(-1))[..., 0]

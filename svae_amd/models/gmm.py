@@ -157,8 +157,14 @@ def _final_pass_torch(label_global, gaussian_globals, node_dense, label_stats):
     neghalfJ, h = gaussian_natparam[..., :N, :N], gaussian_natparam[..., :N, N]
     J = -2 * neghalfJ
     L = torch.linalg.cholesky(J)
-    Ex = torch.cholesky_solve(h.unsqueeze(-1), L)[..., 0]
-    ExxT = torch.cholesky_inverse(L) + Ex.unsqueeze(-1) * Ex.unsqueeze(-2)
+    # J^-1 [h | I] by two triangular solves (torch.cholesky_solve / cholesky_inverse return wrong results
+    # intermittently on this ROCm build for some sizes, see svae_amd/lds/lds_large.py)
+    eye = torch.eye(N, dtype=J.dtype, device=J.device).expand(J.shape[0], N, N)
+    sol = torch.linalg.solve_triangular(
+        L.transpose(-1, -2), torch.linalg.solve_triangular(L, torch.cat([h.unsqueeze(-1), eye], -1), upper=False),
+        upper=True)
+    Ex = sol[..., 0]
+    ExxT = sol[..., 1:] + Ex.unsqueeze(-1) * Ex.unsqueeze(-2)
     ones = torch.ones(Ex.shape[0], dtype=Ex.dtype, device=Ex.device)
     gaussian_stats = expfam.pack_dense(ExxT, Ex, ones, ones)
     logZ = 0.5 * (h * Ex).sum() - torch.log(torch.diagonal(L, dim1=-1, dim2=-2)).sum() \
