@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SVAE_HIP_ABI_VERSION 3   /* 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
+#define SVAE_HIP_ABI_VERSION 4   /* 4: + svae_slds_lds_meanfield_f64; 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
 #define SVAE_LDS_MAX_N 15   /* register/DPP path: one 16-lane row per sequence, n+1 <= 16 */
 #define SVAE_LDS_TILE_MAX_N 64   /* 16 <= n <= 64: LDS-tiled MFMA path (E-step only: keep must be 0) */
 
@@ -106,6 +106,39 @@ int svae_lds_filter_f64(int B, int T, int n, int inhomog, int pair_batched,
  * value.  Host only (no environment variables are read). */
 int svae_lds_set_split_max_b(int max_b);
 int svae_lds_set_twoend(int mode);
+
+/* LDS mean-field step of the SLDS-SVAE coordinate ascent with the mixing of the K per-state parameter sets
+ * and the contraction of the pair statistics FUSED into the E-step:
+ *   lds_meanfield + get_var_lds_local_natparam  /root/reference/svae/models/slds_svae.py:80-103
+ *   the pair part of get_arhmm_local_nodeparams /root/reference/svae/models/slds_svae.py:131-147
+ * For sequence b the LDS has init potential sum_k w[b,0,k] (init_J_k, init_h_k) and, at step t, pair
+ * parameters sum_k w[b,t+1,k] (J11_k, J12_k, J22_k) -- never materialised: the K sets sit in LDS, w streams.
+ *  in : init_J (K,n,n), init_h (K,n), J11/J12/J22 (K,n,n) natural parameters per discrete state;
+ *       weights (rows,T,K) = E[z_t = k]; node potentials (rows,T,n) as in svae_lds_estep_f64;
+ *       seq_index (B) int32 or NULL: the launch processes B <= rows sequences, slot i working on row
+ *       seq_index[i] of every array and of the workspace (NULL: row i); rows not listed are left untouched
+ *       (converged sequences of the coordinate ascent are frozen, slds_svae.py:170-172: the caller lists the
+ *       ones still iterating)
+ *  out: lognorm (rows) WITHOUT the mixed constants sum_k w[b,0,k] init_logZ_k + sum_t sum_k w[b,t+1,k] logZ_k
+ *       (a (B,T,K) x (K) product the caller adds); E_init, E_node_diagxx, E_node_x as in svae_lds_estep_f64;
+ *       pair_contr (rows,T,2,K):  [b,t,0,k] = <E x_t x_t', J11_k> + <E x_t x_{t+1}', J12_k>   (t < T-1)
+ *                              [b,t,1,k] = <E x_t x_t', J22_k>                              (t > 0)
+ *         so that the HMM node potential of slds_svae.py:141-146 is
+ *         node[b,t+1,k] = pair_contr[b,t,0,k] + pair_contr[b,t+1,1,k] + logZ_k
+ *         (which of the two slots carries the cross term depends on the chain that owns node t; only the sum
+ *          above is defined).
+ * n <= 10, T >= 4, K <= 16 and svae_slds_lds_meanfield_lds_bytes(n, K) <= 160 KiB (else -4: use the
+ * per-step entry point).  workspace: svae_lds_workspace_bytes(rows, T, n). */
+size_t svae_slds_lds_meanfield_lds_bytes(int n, int K);
+int svae_slds_lds_meanfield_f64(int B, int rows, int T, int n, int K,
+                                const double* init_J, const double* init_h,
+                                const double* J11, const double* J12, const double* J22,
+                                const double* weights,
+                                const double* node_J, const double* node_h, const double* node_logZ,
+                                const int32_t* seq_index,
+                                double* lognorm, double* E_init, double* E_node_diagxx, double* E_node_x,
+                                double* pair_contr, int32_t* info,
+                                void* workspace, size_t ws_bytes, void* stream);
 
 /* Deterministic sum over the batch of the per-sequence global statistics (the quantity that is
  * all-reduced across GPUs for the natural-gradient step, svae.py:33-34):

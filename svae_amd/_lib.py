@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must precede CDLL: shares torch's HIP runtime)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVAE_AMD_LIB", os.path.join(_HERE, "libsvae_hip.so"))  # env: experiments only
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 LDS_MAX_N = 15        # register/DPP path (E-step, sampler, VJP)
 LDS_TILE_MAX_N = 64   # LDS-tiled MFMA path (E-step only)
 
@@ -30,6 +30,10 @@ SIGNATURES = {
                            + [_c_int_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "svae_lds_filter_f64": (ctypes.c_int, [ctypes.c_int] * 5 + [_c_double_p] * 15
                             + [_c_int_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "svae_slds_lds_meanfield_lds_bytes": (ctypes.c_size_t, [ctypes.c_int] * 2),
+    "svae_slds_lds_meanfield_f64": (ctypes.c_int, [ctypes.c_int] * 5 + [_c_double_p] * 9 + [_c_int_p]
+                                    + [_c_double_p] * 5 + [_c_int_p, ctypes.c_void_p, ctypes.c_size_t,
+                                                           ctypes.c_void_p]),
     "svae_lds_reduce_stats_f64": (ctypes.c_int, [ctypes.c_int] * 2 + [_c_double_p] * 4
                                   + [ctypes.c_void_p]),
     "svae_lds_vjp_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),

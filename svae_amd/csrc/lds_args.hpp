@@ -28,6 +28,18 @@ constexpr long te_chain_doubles(int n, int T) {
 constexpr long te_seq_doubles(int n, int T) { return 2 * te_chain_doubles(n, T); }
 constexpr int TE_MAX_N = 10;
 constexpr int TE_MIN_T = 4;
+// MIX launches of the two-ended kernel (K parameter sets mixed per step, svae_slds_lds_meanfield_f64): LDS
+// tables of 16-byte entries (two states each), see lds_estep_twoend.hpp
+constexpr int te_mix_nxl(int n) { return 15 - n; }                 // right-hand-side lanes n..14
+constexpr int te_mix_ent_ex(int n) { return 4 * te_mix_nxl(n) + 1; }
+constexpr int te_mix_ent_nj(int n) { return 2 * n + 1; }
+constexpr int te_mix_ent_c(int n) { return 4 * n + 1; }
+constexpr long te_mix_lds_bytes(int n, int K) {
+  const int kp2 = (K + 1) / 2, j = (n + 1) / 2, nc2 = (n + 1) / 2;
+  return 16L * (kp2 * (n * te_mix_ent_ex(n) + n * te_mix_ent_nj(n) + 2 * j * te_mix_ent_c(n)) + 4 * j * 2 * nc2 * 16);
+}
+constexpr int TE_MIX_MAX_K = 16;
+constexpr long TE_MIX_MAX_LDS = 160 * 1024;
 
 struct LdsArgs {
   int B, T;
@@ -57,6 +69,11 @@ struct LdsArgs {
   double* __restrict__ msg_hp;
   double* __restrict__ msg_Jf;
   double* __restrict__ msg_hf;
+  // MIX launches (svae_slds_lds_meanfield_f64): init_J/init_h/J11/J12/J22 carry a leading K axis
+  const double* __restrict__ mix_w;      // (B,T,K) weights E[z_t = k]
+  double* __restrict__ mix_out;          // (B,T,2,K) contractions with the K pair-parameter sets
+  const int32_t* __restrict__ seq_index; // (B) or nullptr: slot i of the launch works on row seq_index[i]
+  int mix_K;
 };
 
 struct SampleArgs {

@@ -12,6 +12,7 @@ extern "C" {
 #define SVAE_DECL_(NN) int svae_lds_launch_n##NN(const svae::LdsArgs*, int, void*); \
   int svae_lds_launch_split_n##NN(const svae::LdsArgs*, int, void*);           \
   int svae_lds_launch_twoend_n##NN(const svae::LdsArgs*, int, int, void*);          \
+  int svae_lds_launch_twoend_mix_n##NN(const svae::LdsArgs*, void*);          \
   int svae_lds_launch_filter_n##NN(const svae::LdsArgs*, int, void*);          \
   int svae_lds_sample_n##NN(const svae::SampleArgs*, void*);                   \
   int svae_lds_vjp_n##NN(const svae::VjpArgs*, void*);
@@ -149,6 +150,7 @@ int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int k
   a.ws3 = (keep & 2) ? (double*)workspace + main_ws_doubles(B, T, n) + factor_ws_doubles(B, T, n) : nullptr;
   a.pair_seq_stride = pair_batched ? (long)(T - 1) * n * n : 0;
   a.msg_Jp = a.msg_hp = a.msg_Jf = a.msg_hf = nullptr;
+  a.mix_w = nullptr; a.mix_out = nullptr; a.seq_index = nullptr; a.mix_K = 0;
   if (n > SVAE_LDS_MAX_N) {
     a.ws2 = a.ws3 = nullptr;
     return svae_lds_launch_tile(&a, n, inhomog, stream);
@@ -217,6 +219,7 @@ int svae_lds_filter_f64(int B, int T, int n, int inhomog, int pair_batched,
   a.ws3 = nullptr;
   a.pair_seq_stride = pair_batched ? (long)(T - 1) * n * n : 0;
   a.msg_Jp = J_pred; a.msg_hp = h_pred; a.msg_Jf = J_filt; a.msg_hf = h_filt;
+  a.mix_w = nullptr; a.mix_out = nullptr; a.seq_index = nullptr; a.mix_K = 0;
   switch (n) {
 #define SVAE_CASE_(NN) case NN: return svae_lds_launch_filter_n##NN(&a, inhomog, stream);
 #define SVAE_CASE(NN) SVAE_CASE_(NN)
@@ -226,6 +229,64 @@ int svae_lds_filter_f64(int B, int T, int n, int inhomog, int pair_batched,
     SVAE_CASE(1) SVAE_CASE(2) SVAE_CASE(3) SVAE_CASE(4) SVAE_CASE(5) SVAE_CASE(6) SVAE_CASE(7)
     SVAE_CASE(8) SVAE_CASE(9) SVAE_CASE(10) SVAE_CASE(11) SVAE_CASE(12) SVAE_CASE(13)
     SVAE_CASE(14) SVAE_CASE(15)
+#endif
+#undef SVAE_CASE
+#undef SVAE_CASE_
+  }
+  return -3;
+}
+
+size_t svae_slds_lds_meanfield_lds_bytes(int n, int K) {
+  if (n < 1 || n > svae::TE_MAX_N || K < 1 || K > svae::TE_MIX_MAX_K) return 0;
+  return (size_t)svae::te_mix_lds_bytes(n, K);
+}
+
+int svae_slds_lds_meanfield_f64(int B, int rows, int T, int n, int K,
+                                const double* init_J, const double* init_h,
+                                const double* J11, const double* J12, const double* J22,
+                                const double* weights,
+                                const double* node_J, const double* node_h, const double* node_logZ,
+                                const int32_t* seq_index,
+                                double* lognorm, double* E_init, double* E_node_diagxx, double* E_node_x,
+                                double* pair_contr, int32_t* info,
+                                void* workspace, size_t ws_bytes, void* stream) {
+  if (B < 0 || B > rows) return -1;
+  if (T < svae::TE_MIN_T) return -2;
+  if (n < 1 || n > svae::TE_MAX_N) return -3;
+  if (K < 1 || K > svae::TE_MIX_MAX_K || svae::te_mix_lds_bytes(n, K) > svae::TE_MIX_MAX_LDS) return -4;
+  if (!init_J) return -5;
+  if (!init_h) return -6;
+  if (!J11 || !J12 || !J22) return -7;
+  if (!weights) return -10;
+  if (!node_J) return -11;
+  if (!node_h) return -12;
+  if (!lognorm) return -15;
+  if (!E_init) return -16;
+  if (!E_node_diagxx) return -17;
+  if (!E_node_x) return -18;
+  if (!pair_contr) return -19;
+  if (!info) return -20;
+  if (!workspace || ws_bytes < svae_lds_workspace_bytes(rows, T, n)) return -21;
+  if (B == 0) return 0;
+  svae::LdsArgs a;
+  a.B = B; a.T = T;
+  a.init_J = init_J; a.init_h = init_h; a.init_logZ = nullptr;
+  a.J11 = J11; a.J12 = J12; a.J22 = J22; a.logZ_pair = nullptr;
+  a.node_J = node_J; a.node_h = node_h; a.node_logZ = node_logZ;
+  a.lognorm = lognorm; a.E_init = E_init; a.E_pair = nullptr;
+  a.E_node_diagxx = E_node_diagxx; a.E_node_x = E_node_x;
+  a.info = info; a.ws = (double*)workspace; a.ws2 = nullptr; a.ws3 = nullptr;
+  a.pair_seq_stride = 0;
+  a.msg_Jp = a.msg_hp = a.msg_Jf = a.msg_hf = nullptr;
+  a.mix_w = weights; a.mix_out = pair_contr; a.seq_index = seq_index; a.mix_K = K;
+  switch (n) {
+#define SVAE_CASE_(NN) case NN: return svae_lds_launch_twoend_mix_n##NN(&a, stream);
+#define SVAE_CASE(NN) SVAE_CASE_(NN)
+#ifdef SVAE_ONLY_N
+    SVAE_CASE(SVAE_ONLY_N)
+#else
+    SVAE_CASE(1) SVAE_CASE(2) SVAE_CASE(3) SVAE_CASE(4) SVAE_CASE(5) SVAE_CASE(6) SVAE_CASE(7)
+    SVAE_CASE(8) SVAE_CASE(9) SVAE_CASE(10)
 #endif
 #undef SVAE_CASE
 #undef SVAE_CASE_

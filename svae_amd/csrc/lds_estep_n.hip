@@ -31,6 +31,10 @@ extern "C" int SVAE_CAT(svae_lds_launch_twoend_n, SVAE_N)(const svae::LdsArgs* a
   return svae::launch_estep_twoend<SVAE_N>(*a, inhomog != 0, lean != 0, (hipStream_t)stream);
 }
 
+extern "C" int SVAE_CAT(svae_lds_launch_twoend_mix_n, SVAE_N)(const svae::LdsArgs* a, void* stream) {
+  return svae::launch_estep_twoend_mix<SVAE_N>(*a, (hipStream_t)stream);
+}
+
 extern "C" int SVAE_CAT(svae_lds_launch_filter_n, SVAE_N)(const svae::LdsArgs* a, int inhomog, void* stream) {
   return svae::launch_filter<SVAE_N>(*a, inhomog != 0, (hipStream_t)stream);
 }

@@ -130,10 +130,20 @@ __device__ __forceinline__ void te_gauss_jordan(double (&M)[N], const double (&E
 // LEAN hand-off (the default): per (chain, step) only the lower triangle of P^-1 and c = P^-1 h_filt
 // (te_lean_step_doubles: 68 doubles at n = 10 instead of 220); the smoother rebuilds G = -P^-1 J12 with one
 // split product per step and transposes it through 3 KB of LDS.  Algorithmic HBM bytes x ~4 instead of x 11.
-template <int N, bool INHOMOG, bool LEAN>
-__global__ __launch_bounds__(64) void lds_estep_twoend_kernel(const LdsArgs a) {
+//
+// MIX (svae_slds_lds_meanfield_f64, the SLDS mean field: /root/reference/svae/models/slds_svae.py:92-103,
+// 131-147): the pair parameters of step t are sum_k w[b,t+1,k] * P_k for K parameter sets resident in LDS
+// (mixed just in time, straight into the registers that consume them: M, Bt, the Schur accumulators), and
+// instead of per-step E_pair blocks the smoother contracts its tiles with the K sets on the spot,
+//   out[b,t,0,k] = <E x_t x_t', J11_k> (+ <E x_t x_{t+1}', J12_k> on chain A)      -> pair t
+//   out[b,t,1,k] = <E x_t x_t', J22_k> (+ <E x_{t-1} x_t', J12_k> on chain B)      -> pair t-1
+// (lane k of the DPP row accumulates state k: the lane reduction is the broadcast of the DPP operand).
+// W sequences (wavefronts) per workgroup share the tables; `seq_index` lists the rows a launch works on.
+template <int N, bool INHOMOG, bool LEAN, bool MIX = false>
+__global__ __launch_bounds__(MIX ? 512 : 64) void lds_estep_twoend_kernel(const LdsArgs a) {
   static_assert(N >= 1 && N <= TE_MAX_N && N + ((N - 1) >> 1) <= 14,
                 "the right-hand-side columns must fit lanes N..14 of two DPP rows");
+  static_assert(!MIX || (INHOMOG && !LEAN), "MIX: per-step parameters, full hand-off record");
   constexpr int RW = te_row_doubles(N), ZP = te_page_doubles(N);
   constexpr int WS = LEAN ? te_lean_step_doubles(N) : te_step_doubles(N);
   constexpr int TRI = N * (N + 1) / 2;    // LEAN record: [lower triangle | c (N) | 0.0 | trash | pad]
@@ -142,14 +152,20 @@ __global__ __launch_bounds__(64) void lds_estep_twoend_kernel(const LdsArgs a) {
   constexpr int J1 = (N + 2) / 2;         // slots holding rows 0..N
   constexpr int HL = 15;                  // lane of the h column
   constexpr int RSL = (N + 3) & ~1;       // LDS row stride of the transposition tile (even, >= N + 1)
-  __shared__ double tab[2 * 16 * 16];     // [chain][row 0..15][RSL]: G~ rows for the transposed read
+  __shared__ double tab_static[MIX ? 2 : 2 * 16 * 16];   // [chain][row 0..15][RSL]: G~ rows for the transposed read
+  extern __shared__ double2 te_dyn[];     // MIX: the parameter tables (te_mix_lds_bytes)
 
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
   const int c = lane & 15;
   const int g = lane >> 4;
   const int dir = g >> 1;                 // 0: chain A (forward in time), 1: chain B (reversed)
   const int gl = g & 1;                   // DPP row within the chain's pair
-  const int b = blockIdx.x;               // one sequence per wavefront
+  const int nwv = MIX ? (int)(blockDim.x >> 6) : 1;
+  const int bslot = MIX ? blockIdx.x * nwv + wv : blockIdx.x;   // one sequence per wavefront
+  // MIX: row of every array (and of the workspace) this launch slot works on (surplus slots: any valid row)
+  const int b = !MIX ? bslot : (a.seq_index ? a.seq_index[bslot < a.B ? bslot : 0] : bslot);
+  double* tab = tab_static;               // (MIX keeps the full hand-off record: no transposition tile)
   const bool col = c < N;
   const int cc = col ? c : 0;
   const int T = a.T;
@@ -162,6 +178,73 @@ __global__ __launch_bounds__(64) void lds_estep_twoend_kernel(const LdsArgs a) {
   const double EH = (c == HL) ? 1.0 : 0.0;
   const double EN = (c == N) ? 1.0 : 0.0;
 
+  // ---- MIX: the K parameter sets as LDS tables, one 16-byte entry = states (2kp, 2kp+1) -----------------
+  //   t_ex[kp][i][ENT_EX]  right-hand-side lanes: -J12'_k[i][x]           (entry (dir*2+gl)*NXL + c-N)
+  //   t_nj[kp][k'][ENT_NJ] lanes < N: nat J12'_k[k'][c]                   (entry dir*N + c)
+  //   t_22, t_11[kp][j][ENT_C]  lanes < N: -2 q22_k / -2 q11_k [2j+gl][c] (entry (dir*2+gl)*N + c)
+  //   the last entry of every row is zero (lanes with nothing to add);
+  //   ct[blk][j][gl][c/2][16]   entry = (P_k[2j+gl][c], P_k[2j+gl][c+1]) in lane k: blk 0 J11, 1 J22,
+  //                             2 J12 transposed (chain A's cross moment), 3 J12 (chain B's)
+  constexpr int NXL = te_mix_nxl(N);
+  constexpr int ENT_EX = te_mix_ent_ex(N), ENT_NJ = te_mix_ent_nj(N), ENT_C = te_mix_ent_c(N);
+  constexpr int NC2 = (N + 1) / 2;
+  const int K = MIX ? a.mix_K : 0, KP2 = (K + 1) >> 1;
+  double2* t_ex = te_dyn;
+  double2* t_nj = t_ex + KP2 * N * ENT_EX;
+  double2* t_22 = t_nj + KP2 * N * ENT_NJ;
+  double2* t_11 = t_22 + KP2 * J * ENT_C;
+  double2* ct = t_11 + KP2 * J * ENT_C;
+  if constexpr (MIX) {
+    auto P = [&](const double* base, int k, int idx) { return k < K ? base[(long)k * N * N + idx] : 0.0; };
+    const int nth = blockDim.x, tid = threadIdx.x;
+    for (int q = tid; q < KP2 * N * ENT_EX; q += nth) {
+      const int ent = q % ENT_EX, i = (q / ENT_EX) % N, kp = q / (ENT_EX * N);
+      double2 v = make_double2(0.0, 0.0);
+      if (ent < 4 * NXL) {
+        const int d = ent / (2 * NXL), r = (ent / NXL) & 1, x = 2 * (ent % NXL) + r;
+        if (x < N) {
+          const int idx = d ? x * N + i : i * N + x;
+          v = make_double2(-P(a.J12, 2 * kp, idx), -P(a.J12, 2 * kp + 1, idx));
+        }
+      }
+      t_ex[q] = v;
+    }
+    for (int q = tid; q < KP2 * N * ENT_NJ; q += nth) {
+      const int ent = q % ENT_NJ, i = (q / ENT_NJ) % N, kp = q / (ENT_NJ * N);
+      double2 v = make_double2(0.0, 0.0);
+      if (ent < 2 * N) {
+        const int d = ent / N, cq = ent % N;
+        const int idx = d ? cq * N + i : i * N + cq;
+        v = make_double2(P(a.J12, 2 * kp, idx), P(a.J12, 2 * kp + 1, idx));
+      }
+      t_nj[q] = v;
+    }
+    for (int q = tid; q < KP2 * J * ENT_C; q += nth) {
+      const int ent = q % ENT_C, j = (q / ENT_C) % J, kp = q / (ENT_C * J);
+      double2 v22 = make_double2(0.0, 0.0), v11 = v22;
+      if (ent < 4 * N) {
+        const int d = ent / (2 * N), r = (ent / N) & 1, cq = ent % N, i = 2 * j + r;
+        if (i < N) {
+          const double* Q22 = d ? a.J11 : a.J22;
+          const double* Q11 = d ? a.J22 : a.J11;
+          v22 = make_double2(-2.0 * P(Q22, 2 * kp, i * N + cq), -2.0 * P(Q22, 2 * kp + 1, i * N + cq));
+          v11 = make_double2(-2.0 * P(Q11, 2 * kp, i * N + cq), -2.0 * P(Q11, 2 * kp + 1, i * N + cq));
+        }
+      }
+      t_22[q] = v22;
+      t_11[q] = v11;
+    }
+    for (int q = tid; q < 4 * J * 2 * NC2 * 16; q += nth) {
+      const int k = q & 15, cp = (q >> 4) % NC2, r = (q / (16 * NC2)) & 1, j = (q / (32 * NC2)) % J, blk = q / (32 * NC2 * J);
+      const int i = 2 * j + r, c0 = 2 * cp, c1 = 2 * cp + 1;
+      const double* base = blk == 0 ? a.J11 : (blk == 1 ? a.J22 : a.J12);
+      auto at = [&](int cq) { return (i < N && cq < N) ? P(base, k, blk == 2 ? cq * N + i : i * N + cq) : 0.0; };
+      ct[q] = make_double2(at(c0), at(c1));
+    }
+    __syncthreads();
+    if (bslot >= a.B) return;
+  }
+
   // ---- pair parameters in the chain's own orientation ---------------------------------------------
   // chain A: (J11, J12, J22); chain B: (J22, J12', J11).  Local pair l joins local nodes l, l+1
   // (global pair index l for A, T-2-l for B).
@@ -173,6 +256,45 @@ __global__ __launch_bounds__(64) void lds_estep_twoend_kernel(const LdsArgs a) {
   const int xq = 2 * (c - N) + gl;                    // right-hand-side column of this lane (c >= N)
   const bool xok = c >= N && c < HL && xq < N;
   const int xx = xok ? xq : 0;
+  // MIX: this lane's table entries (registers and state pairs are immediate offsets from these)
+  const double2* ex_l = t_ex + (xok ? (dir * 2 + gl) * NXL + (c - N) : 4 * NXL);
+  const double2* nj_l = t_nj + (col ? dir * N + c : 2 * N);
+  const double2* c22_l = t_22 + (col ? (dir * 2 + gl) * N + c : 4 * N);
+  const double2* c11_l = t_11 + (col ? (dir * 2 + gl) * N + c : 4 * N);
+  const double2* cta_l = ct + gl * NC2 * 16 + c;
+  const double2* ctc_l = cta_l + J * 2 * NC2 * 16;
+  const double2* ctx_l = cta_l + (2 + dir) * J * 2 * NC2 * 16;
+  // acc[r] += sum_k w_k tbl[kp][r][entry]   (w_k = lane k of wreg: the DPP broadcast does the indexing)
+  // acc0[r] += sum_k w0_k t0[k][r],  acc1[r] += sum_k w1_k t1[k][r]   (r < R; tables [state pair][R][entries],
+  // acc0 / acc1 may be the same array).  A real loop over the state pairs: the weights sit in the lanes of
+  // w0 / w1 and are rotated two lanes per trip (row_ror:14: lane i <- lane i + 2), so that the DPP operand is
+  // always lanes 0 and 1.  The table reads are software-pipelined BY HAND, half a trip ahead: inline-asm
+  // statements are scheduling boundaries for hipcc, so a read written next to its FMAs is issued there and
+  // waited for at once (measured: ~90 cycles per read, 7 k cycles per step; tools/te_mix_phase_timing.py).
+  auto ror2 = [&](double x) { return __svae_update_dpp_f64(0.0, x, 0x12E, 0xf, 0xf, true); };
+  auto mix2 = [&](auto nreg, auto nent0, auto nent1, auto& acc0, auto& acc1, const double2* t0, const double2* t1,
+                  double w0, double w1) {
+    constexpr int R = decltype(nreg)::value, ENT0 = decltype(nent0)::value, ENT1 = decltype(nent1)::value;
+    double2 va[R], vb[R];
+    static_for<0, R>([&](auto r) { va[r] = t0[r * ENT0]; });
+    for (int kp = 0; kp < KP2; ++kp) {
+      static_for<0, R>([&](auto r) { vb[r] = t1[r * ENT1]; });
+      t1 += R * ENT1;
+      double wf[2] = {w0, w1};
+      dpp_fence(wf);
+      static_for<0, R>([&](auto r) { mac_bc<0>(acc0[r], wf[0], va[r].x); });
+      static_for<0, R>([&](auto r) { mac_bc<1>(acc0[r], wf[0], va[r].y); });
+      t0 += (kp + 1 < KP2) ? R * ENT0 : 0;          // last trip: re-reads its own group (unused)
+      static_for<0, R>([&](auto r) { va[r] = t0[r * ENT0]; });
+      static_for<0, R>([&](auto r) { mac_bc<0>(acc1[r], wf[1], vb[r].x); });
+      static_for<0, R>([&](auto r) { mac_bc<1>(acc1[r], wf[1], vb[r].y); });
+      w0 = ror2(wf[0]);
+      w1 = ror2(wf[1]);
+    }
+  };
+  const double wmask = (c < K) ? 1.0 : 0.0;
+  const double* wrow = a.mix_w + (MIX ? (long)b * T * K + (c < K ? c : 0) : 0);    // + r*K: weights of node r
+  auto wnode = [&](int l) { int r = dir ? T - 1 - l : l + 1; r = r < 0 ? 0 : (r > T - 1 ? T - 1 : r); return r; };   // node whose weights mix local pair l
   //   EX[i]: lanes < N identity row i; lane of column x: info-form J12'[i][x] = -nat J12'[i][x]
   //   NJ12c[k]: lanes < N: nat J12'[k][c] (= -J12'[k][c]); other lanes 0
   //   Cc[j] (row i = 2j+gl): lanes < N: info-form J22'(pair l) + J11'(pair l+1); other lanes 0
@@ -198,7 +320,22 @@ __global__ __launch_bounds__(64) void lds_estep_twoend_kernel(const LdsArgs a) {
   // node potential (incoming message + J11' of the pair ahead), lane 15 = incoming potential vector,
   // lanes N..14 zero.
   double An[N];
-  {
+  if constexpr (MIX) {
+    // init potential mixed by E[z_0], J11' of the chain's pair 0 by its own node's weights (once per sequence:
+    // straight from global memory)
+    const double* w0 = a.mix_w + (long)b * T * K;
+    const double* wq = w0 + (long)wnode(0) * K;
+    static_for<0, N>([&](auto i) { An[i] = 0.0; });
+    for (int k = 0; k < K; ++k) {
+      const double wi = dir ? 0.0 : w0[k], wp = wq[k];
+      const double* ij = a.init_J + (long)k * N * N, *ih = a.init_h + (long)k * N;
+      const double* j11 = (dir ? a.J22 : a.J11) + (long)k * N * N;
+      static_for<0, N>([&](auto i) {
+        const double v = -2.0 * (wi * ij[i * N + cc] + wp * j11[i * N + cc]);
+        An[i] += col ? v : ((c == HL) ? wi * ih[i] : 0.0);
+      });
+    }
+  } else {
     const long o0 = pair_off(0);
     static_for<0, N>([&](auto i) {
       const double ij = a.init_J[i * N + cc], ih = a.init_h[i], j11 = q11[o0 + i * N + cc];
@@ -277,21 +414,40 @@ __global__ __launch_bounds__(64) void lds_estep_twoend_kernel(const LdsArgs a) {
   long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tlast_ = __builtin_readcyclecounter();
 #endif
+  // MIX: weights of local pairs s and s + 1 (raw, fetched one step ahead like the node potentials)
+  double wr0 = MIX ? wrow[(long)wnode(0) * K] : 0.0, wr1 = MIX ? wrow[(long)wnode(1) * K] : 0.0;
   for (int s = 0; s < e; ++s) {
     if (s == jx) take_partner();
     const double JoX = col ? -2.0 * Jo_n : 1.0;
     double ho = ho_n;
     Jo_n = nJb[node_off(s + 1)];           // s + 1 <= e: the meeting node's potentials included
     ho_n = nhb[node_off(s + 1)];
-    if (INHOMOG) load_pair(s, true);
+    if (INHOMOG && !MIX) load_pair(s, true);
+    double wq[2] = {wr0 * wmask, wr1 * wmask};     // MIX: lane k = weight of state k (pair s, pair s + 1)
+    if constexpr (MIX) {
+      wr0 = wr1;
+      wr1 = wrow[(long)wnode(s + 2) * K];
+      dpp_fence(wq);
+    }
 
     // condition on the node potential; right-hand sides ride in the upper lanes
     double M[N], Bt[N];
-    static_for<0, N>([&](auto i) { M[i] = __builtin_fma(JoX, EX[i], An[i]); });
+    if constexpr (MIX) {
+      static_for<0, N>([&](auto i) { M[i] = __builtin_fma(JoX, E[i], An[i]); });
+    } else {
+      static_for<0, N>([&](auto i) { M[i] = __builtin_fma(JoX, EX[i], An[i]); });
+    }
     dpp_fence(ho);
     static_for<0, N>([&](auto i) { mac_bc<i>(M[i], ho, EH); });      // lane 15: h_filt = h_pred + h_node
     // B operand of the Schur stage: lanes < N: -J12'[k][c]; lane 15: -h_filt,k
-    static_for<0, N>([&](auto k) { Bt[k] = __builtin_fma(-EH, M[k], NJ12c[k]); });
+    if constexpr (MIX) {
+      // (the tables are zero in lane 15: the mixing leaves h_filt alone)
+      static_for<0, N>([&](auto k) { Bt[k] = -EH * M[k]; });
+      mix2(std::integral_constant<int, N>{}, std::integral_constant<int, ENT_EX>{}, std::integral_constant<int, ENT_NJ>{},
+           M, Bt, ex_l, nj_l, wq[0], wq[0]);
+    } else {
+      static_for<0, N>([&](auto k) { Bt[k] = __builtin_fma(-EH, M[k], NJ12c[k]); });
+    }
     dpp_fence(M);
     TE_TICK(0)
 
@@ -302,7 +458,13 @@ __global__ __launch_bounds__(64) void lds_estep_twoend_kernel(const LdsArgs a) {
     // next pivot block, slot layout:  AnD[j] = Cc[j] + sum_k X[k][i] * Bt[k]   (row i = 2j + gl;
     // X[k][i] = lane N + j of M[k] in this DPP row)
     double AnD[J];
-    static_for<0, J>([&](auto j) { AnD[j] = Cc[j]; });
+    if constexpr (MIX) {
+      static_for<0, J>([&](auto j) { AnD[j] = 0.0; });
+      mix2(std::integral_constant<int, J>{}, std::integral_constant<int, ENT_C>{}, std::integral_constant<int, ENT_C>{},
+           AnD, AnD, c22_l, c11_l, wq[0], wq[1]);
+    } else {
+      static_for<0, J>([&](auto j) { AnD[j] = Cc[j]; });
+    }
     asm volatile("s_nop 1");
     static_for<0, N>([&](auto k) {
       static_for<0, J>([&](auto j) { mac_bc<N + j>(AnD[j], M[k], Bt[k]); });
@@ -337,11 +499,27 @@ __global__ __launch_bounds__(64) void lds_estep_twoend_kernel(const LdsArgs a) {
     const double JoX = col ? -2.0 * Jo_n : 1.0;
     double ho = ho_n;
     double M[N];
-    static_for<0, N>([&](auto i) {
-      const double r22 = q22[o + i * N + cc], r11 = q11[o1 + i * N + cc];
-      const double dbl = col ? -2.0 * (r22 + r11) : 0.0;
-      M[i] = __builtin_fma(JoX, E[i], (An[i] + Mp[i]) - dbl);
-    });
+    if constexpr (MIX) {
+      double dbl[N];
+      static_for<0, N>([&](auto i) { dbl[i] = 0.0; });
+      const double* wa = a.mix_w + ((long)b * T + wnode(e - 1)) * K;
+      const double* wb = a.mix_w + ((long)b * T + wnode(e)) * K;
+      for (int k = 0; k < K; ++k) {
+        const double va = wa[k], vb = wb[k];
+        const double* p22 = (dir ? a.J11 : a.J22) + (long)k * N * N + cc;
+        const double* p11 = (dir ? a.J22 : a.J11) + (long)k * N * N + cc;
+        static_for<0, N>([&](auto i) { dbl[i] = __builtin_fma(va, p22[i * N], __builtin_fma(vb, p11[i * N], dbl[i])); });
+      }
+      static_for<0, N>([&](auto i) {
+        M[i] = __builtin_fma(JoX, E[i], (An[i] + Mp[i]) - (col ? -2.0 * dbl[i] : 0.0));
+      });
+    } else {
+      static_for<0, N>([&](auto i) {
+        const double r22 = q22[o + i * N + cc], r11 = q11[o1 + i * N + cc];
+        const double dbl = col ? -2.0 * (r22 + r11) : 0.0;
+        M[i] = __builtin_fma(JoX, E[i], (An[i] + Mp[i]) - dbl);
+      });
+    }
     dpp_fence(ho);
     static_for<0, N>([&](auto i) { mac_bc<i>(M[i], ho, EH); });
     dpp_fence(M);
@@ -368,11 +546,12 @@ __global__ __launch_bounds__(64) void lds_estep_twoend_kernel(const LdsArgs a) {
     if (a.node_logZ) {
       for (int t = c; t < T; t += 16) z += a.node_logZ[(long)b * T + t];
     }
-    if (INHOMOG) {
+    if (INHOMOG && !MIX) {
       const double* lz = a.logZ_pair + (a.pair_seq_stride ? (long)b * (T - 1) : 0);
       for (int t = c; t < T - 1; t += 16) z += lz[t];
     }
-    double total = row_sum16(z) + chain_total + meet_total + a.init_logZ[0];
+    // (MIX: the mixed log-normaliser constants sum_k w_k logZ_k are the caller's, a (B,T,K) x (K) product)
+    double total = row_sum16(z) + chain_total + meet_total + (MIX ? 0.0 : a.init_logZ[0]);
     if (!INHOMOG) total += (double)(T - 1) * a.logZ_pair[0];
     if (lane == 0) a.lognorm[b] = total;
     const bool lane_bad = col && (!(vworst < 0.0) || !(vfull_m < 0.0));
@@ -516,7 +695,58 @@ __global__ __launch_bounds__(64) void lds_estep_twoend_kernel(const LdsArgs a) {
     });
 
     const int t = dir ? T - 1 - s : s;
-    if (INHOMOG) {
+    if constexpr (MIX) {
+      // contraction of this node's tiles with the K parameter sets: lane k accumulates state k
+      //   acc0 = <S~_t, J11_k>, acc1 = <S~_t, J22_k>, acc2 = <W~, J12_k> (orientation by chain), my rows only
+      const bool own = KIND != 1 || own_e;
+      const double fX = (KIND != 1 && !(KIND == 2 && skip2nd)) ? 1.0 : 0.0;
+      double acc[3] = {0.0, 0.0, 0.0};
+      dpp_fence(Sn);
+      // groups of two column pairs x three tables, read one group ahead (see mix_rows)
+      constexpr int CG = 2, NCG = (NC2 + CG - 1) / CG, NQ = J * NCG;
+      double2 cb[2][3 * CG];
+      auto cload = [&](auto q, double2 (&b)[3 * CG]) {
+        constexpr int j = q / NCG, c0 = (q % NCG) * CG;
+        static_for<0, CG>([&](auto g) {
+          if constexpr (c0 + g < NC2) {
+            constexpr int off = (j * 2 * NC2 + c0 + g) * 16;
+            b[3 * g] = cta_l[off]; b[3 * g + 1] = ctc_l[off]; b[3 * g + 2] = ctx_l[off];
+          }
+        });
+      };
+      auto cfma = [&](auto q, const double2 (&b)[3 * CG]) {
+        constexpr int j = q / NCG, c0 = (q % NCG) * CG;
+        static_for<0, CG>([&](auto g) {
+          if constexpr (c0 + g < NC2) {
+            constexpr int cp = c0 + g;
+            mac_bc<2 * cp>(acc[0], Sn[j], b[3 * g].x);
+            mac_bc<2 * cp>(acc[1], Sn[j], b[3 * g + 1].x);
+            mac_bc<2 * cp>(acc[2], W[j], b[3 * g + 2].x);
+            if constexpr (2 * cp + 1 < N) {
+              mac_bc<2 * cp + 1>(acc[0], Sn[j], b[3 * g].y);
+              mac_bc<2 * cp + 1>(acc[1], Sn[j], b[3 * g + 1].y);
+              mac_bc<2 * cp + 1>(acc[2], W[j], b[3 * g + 2].y);
+            }
+          }
+        });
+      };
+      cload(std::integral_constant<int, 0>{}, cb[0]);
+      static_for<0, NQ>([&](auto q) {
+        if constexpr (q + 1 < NQ) cload(std::integral_constant<int, q + 1>{}, cb[(q + 1) & 1]);
+        cfma(q, cb[q & 1]);
+      });
+      // chain A's cross moment is pair t (slot 0), chain B's pair t-1 (slot 1); then the two DPP rows' shares
+      double o1 = __builtin_fma(dir ? 0.0 : fX, acc[2], acc[0]);
+      double o3 = __builtin_fma(dir ? fX : 0.0, acc[2], acc[1]);
+      double e1, d1, e3, d3;
+      pair_split(o1, e1, d1);
+      pair_split(o3, e3, d3);
+      const bool wr = own && gl == 0 && c < K;
+      double* q1 = wr ? a.mix_out + (((long)b * T + t) * 2) * K + c : trash;
+      double* q3 = wr ? q1 + K : trash + 1;
+      *q1 = e1 + d1;
+      *q3 = e3 + d3;
+    } else if (INHOMOG) {
       // per-step pair blocks [E x_t x_t' | E x_t x_{t+1}' | E x_{t+1} x_{t+1}'] for pair index p:
       // the owner of node t writes S~_t into pair t (first block) and pair t-1 (third block); the
       // cross moment W~ = E[x~_{prev} x~_{this}'] is pair s (transposed) for A, pair T-2-s for B.
@@ -635,6 +865,28 @@ static int launch_estep_twoend(const LdsArgs& a, bool inhomog, bool lean, hipStr
       hipLaunchKernelGGL((lds_estep_twoend_kernel<N, false, true>), grid, block, 0, stream, a);
     else
       hipLaunchKernelGGL((lds_estep_twoend_kernel<N, false, false>), grid, block, 0, stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+  } else {
+    return -3;
+  }
+}
+
+// MIX launch: 8 sequences (wavefronts) per workgroup share the LDS tables
+template <int N>
+static int launch_estep_twoend_mix(const LdsArgs& a, hipStream_t stream) {
+  if constexpr (N <= TE_MAX_N) {
+    const long bytes = te_mix_lds_bytes(N, a.mix_K);
+    if (a.mix_K < 1 || a.mix_K > TE_MIX_MAX_K || bytes > TE_MIX_MAX_LDS) return -30;
+    static long granted = 0;               // largest dynamic-LDS size requested so far for this instantiation
+    auto kern = lds_estep_twoend_kernel<N, true, false, true>;
+    if (bytes > granted) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)bytes) != hipSuccess) return -31;
+      granted = bytes;
+    }
+    constexpr int W = 8;
+    dim3 grid((a.B + W - 1) / W), block(64 * W);
+    hipLaunchKernelGGL(kern, grid, block, (size_t)bytes, stream, a);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
   } else {
     return -3;

@@ -151,7 +151,8 @@ class LDSEStepPlan(object):
         if not (getattr(self, "has_cross", False) and getattr(self, "has_factor", False)):
             raise RuntimeError("vjp() needs a preceding launch(..., keep_factor=True, keep_cross=True)")
         if g_E_pair is not None and not self.inhomog:
-            raise NotImplementedError("cotangents of the SUMMED pair statistics (homogeneous parameters)")
+            raise ValueError("a homogeneous plan keeps only the SUMMED pair statistics; their cotangents go through "
+                             "the per-step layout: lds_inference_differentiable(..., pair_stats_grad=True)")
         f64 = dict(dtype=torch.float64, device=self.device)
         c = lambda x: None if x is None else x.to(**f64).contiguous()
         g_lognorm, g_E_node_diagxx, g_E_node_x = c(g_lognorm), c(g_E_node_diagxx), c(g_E_node_x)
@@ -417,11 +418,19 @@ class _LDSInference(torch.autograd.Function):
         return gJ, gh, gz, None, None, None, None
 
 
-def lds_inference_differentiable(natparam, node_params, eps=None, plan=None):
+def lds_inference_differentiable(natparam, node_params, eps=None, plan=None, pair_stats_grad=False):
     """(lognorm (B), (E_node_diagxx, E_node_x) (B,T,n), samples (B,T,S,n) | None, (E_init, E_pair)):
     differentiable w.r.t. node_params = (J (B,T,n), h (B,T,n)[, logZ (B,T)]) through torch autograd.
     Pair parameters (n,n), (T-1,n,n) or (B,T-1,n,n); in the per-step cases E_init (B, n*n+n) and
-    E_pair (B,T-1,3,n,n) are differentiable too."""
+    E_pair (B,T-1,3,n,n) are differentiable too.
+
+    pair_stats_grad=True with HOMOGENEOUS pair parameters makes E_init and the summed E_pair (B,3,n,n)
+    differentiable as well -- the homogeneous branch of the reference's `_compute_stats_grad`
+    (cython_lds_inference.pyx:229-231: the cotangent of a sum is the same block at every step): the launch
+    uses the per-step layout with the (n,n) parameters repeated over time (T-1 copies, L2-resident), and the
+    sum over time is a torch reduction whose backward broadcasts the cotangent to the per-step blocks the
+    VJP kernel consumes.  Costs the per-step statistics' HBM traffic, so it is opt-in (no model of the
+    reference differentiates these: svae.py:21 keeps them in `saved.stats`)."""
     init_params, pair_params = natparam
     node_J, node_h = node_params[0], node_params[1]
     node_logZ = node_params[2] if len(node_params) == 3 else None
@@ -431,8 +440,15 @@ def lds_inference_differentiable(natparam, node_params, eps=None, plan=None):
     J11, J12, J22 = (_as_dev(x, dev) for x in pair_params[:3])
     logZ_pair = _as_dev(pair_params[3], dev).reshape(-1)
     inhomog, pair_batched = J11.dim() >= 3, J11.dim() == 4
+    sum_pairs = bool(pair_stats_grad) and not inhomog
+    if sum_pairs:
+        J11, J12, J22 = (x.expand(max(T - 1, 0), n, n).contiguous() for x in (J11, J12, J22))
+        logZ_pair = logZ_pair.reshape(1).expand(max(T - 1, 0)).contiguous()
+        inhomog = True
     if plan is None:
         plan = LDSEStepPlan(B, T, n, dev, inhomog, pair_batched)
+    elif plan.inhomog != inhomog:
+        raise ValueError("plan layout mismatch (pair_stats_grad=True needs a per-step plan: inhomog=True)")
     params = (init_J, init_h, init_logZ, J11, J12, J22, logZ_pair)
     cont = lambda x: None if x is None else x.to(torch.float64).contiguous()
     fn = _LDSInference
@@ -440,4 +456,6 @@ def lds_inference_differentiable(natparam, node_params, eps=None, plan=None):
         from .lds_large import LDSInferenceLarge as fn     # tile-kernel forward, dense-algebra backward
     out = fn.apply(cont(node_J), cont(node_h), cont(node_logZ), cont(eps), plan, params, pair_batched)
     lognorm, dxx, ex, samples, E_init, E_pair = out
+    if sum_pairs:
+        E_pair = E_pair.sum(1)                     # (B,3,n,n), differentiable
     return lognorm, (dxx, ex), (samples if eps is not None else None), (E_init, E_pair)

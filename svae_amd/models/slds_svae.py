@@ -17,6 +17,7 @@ Batched: node potentials (B,T,n); every sequence runs its own coordinate ascent 
 """
 import torch
 
+from .. import _lib
 from ..distributions import expfam
 from ..hmm.hmm_inference import hmm_estep, hmm_logZ_differentiable
 from ..lds.lds_inference import (LDSEStepPlan, lds_inference_differentiable, natural_lds_estep_general,
@@ -45,6 +46,20 @@ def get_all_lds_local_natparams(lds_global_natparams):
     return stack(inits), stack(pairs)          # each: 4 tensors with leading K
 
 
+def global_to_local_maps(global_natparam, device):
+    """The once-per-step global -> local maps of the SLDS (hmm_prior_expectedstats :124-130 and
+    get_all_lds_local_natparams :86-89): O(K n^3) arithmetic on K small matrices, evaluated in float64 ON THE
+    HOST (a few hundred tiny device launches cost 7 ms; SURVEY section 8a row a9: "keep on host") and moved to
+    `device` as 10 small tensors.  -> (hmm_init (K), hmm_pair (K,K), dense_init 4-tuple, dense_pair 4-tuple)."""
+    hmm_global, lds_global = global_natparam
+    cpu = torch.device("cpu")
+    hmm_init, hmm_pair = hmm_prior_expectedstats(tuple(_dev64(x, cpu) for x in hmm_global))
+    lds_cpu = [(_dev64(a, cpu), tuple(_dev64(y, cpu) for y in m)) for a, m in lds_global]
+    dense_init, dense_pair = get_all_lds_local_natparams(lds_cpu)
+    to = lambda x: x.to(device).contiguous()
+    return to(hmm_init), to(hmm_pair), tuple(to(x) for x in dense_init), tuple(to(x) for x in dense_pair)
+
+
 def get_var_lds_local_natparam(dense_init, dense_pair, expected_states):
     """(:92-103) expected_states (B,T,K) -> init params (B,..) and per-step pair params (B,T-1,..)."""
     w0, w1 = expected_states[:, 0], expected_states[:, 1:]
@@ -53,19 +68,154 @@ def get_var_lds_local_natparam(dense_init, dense_pair, expected_states):
     return init, pair
 
 
+def _packed_pair_stats(pair_stats):
+    """Per-step pair statistics as ONE (B,T-1,3 n^2) matrix per sequence: `pair_stats` is the kernels' packed
+    (B,T-1,3,n,n) tensor, or the reference's 3-tuple of (B,T-1,n,n) blocks (stacked: one copy)."""
+    if isinstance(pair_stats, torch.Tensor):
+        B, Tm1 = pair_stats.shape[:2]
+        return pair_stats.reshape(B, Tm1, -1)
+    Exx = pair_stats[0]
+    B, Tm1, n = Exx.shape[:3]
+    base = getattr(Exx, "_base", None)
+    if base is not None and tuple(base.shape) == (B, Tm1, 3, n, n) and base.is_contiguous() and all(
+            getattr(x, "_base", None) is base and x.data_ptr() == base.data_ptr() + 8 * i * n * n
+            and x.stride() == (3 * Tm1 * n * n, 3 * n * n, n, 1) for i, x in enumerate(pair_stats[:3])):
+        return (base.detach() if not Exx.requires_grad else base).reshape(B, Tm1, -1)   # the kernels' own packed buffer
+    return torch.stack(tuple(pair_stats[:3]), 2).reshape(B, Tm1, -1)
+
+
 def get_arhmm_local_nodeparams(dense_init, dense_pair, init_stats, pair_stats):
-    """(:131-147) node[b,0,k] = <init_stats_b, init_params_k>, node[b,t+1,k] = <pair_stats_bt, pair_params_k>."""
+    """(:131-147) node[b,0,k] = <init_stats_b, init_params_k>, node[b,t+1,k] = <pair_stats_bt, pair_params_k>.
+    pair_stats: 3-tuple of (B,T-1,n,n) or the packed (B,T-1,3,n,n) tensor (one GEMM against the K stacked
+    parameter sets instead of three strided contractions)."""
     ExxT0, Ex0 = init_stats
-    n0 = torch.einsum("bij,kij->bk", ExxT0, dense_init[0]) + torch.einsum("bi,ki->bk", Ex0, dense_init[1]) \
+    K = dense_init[0].shape[0]
+    n0 = ExxT0.reshape(ExxT0.shape[0], -1) @ dense_init[0].reshape(K, -1).T + Ex0 @ dense_init[1].T \
         + dense_init[2] + dense_init[3]
-    Exx, Exxn, Exnxn = pair_stats
-    nt = torch.einsum("btij,kij->btk", Exx, dense_pair[0]) + torch.einsum("btij,kij->btk", Exxn, dense_pair[1]) \
-        + torch.einsum("btij,kij->btk", Exnxn, dense_pair[2]) + dense_pair[3]
+    P = torch.cat([dense_pair[i].reshape(K, -1) for i in range(3)], 1)          # (K, 3 n^2)
+    nt = _packed_pair_stats(pair_stats) @ P.T + dense_pair[3]
     return torch.cat([n0[:, None], nt], 1)
 
 
 def initialize_local_meanfield(node_potentials, eps):
     """(:203-226) statistics of ONE posterior sample path of a random-walk LDS; eps (B,T,1,n)."""
+    x = _initial_sample_path(node_potentials, eps)
+    out = lambda a, b: a.unsqueeze(-1) * b.unsqueeze(-2)
+    init_stats = (out(x[:, 0], x[:, 0]), x[:, 0])
+    pair_stats = (out(x[:, :-1], x[:, :-1]), out(x[:, :-1], x[:, 1:]), out(x[:, 1:], x[:, 1:]))
+    return init_stats, pair_stats
+
+
+class SLDSMeanfieldPlan(object):
+    """Buffers of the FUSED LDS mean-field step (svae_slds_lds_meanfield_f64): the K per-state parameter sets
+    stay in LDS, the HMM marginals stream in as weights, and the pair statistics leave the kernel already
+    contracted with the K sets (B,T,2,K) -- neither the per-step pair parameters nor the per-step pair
+    statistics ((B,T-1,n,n) x 3 each, slds_svae.py:92-103 / :141-146) are ever materialised.  The buffers
+    are the persistent state of the coordinate ascent: a launch with a `seq_index` list rewrites only the
+    rows of the sequences still iterating (and costs only their share of the work)."""
+
+    def __init__(self, B, T, n, K, device):
+        self.lib = _lib.load()
+        self.B, self.T, self.n, self.K = B, T, n, K
+        self.device = torch.device(device)
+        f64 = dict(dtype=torch.float64, device=self.device)
+        self.ws_bytes = int(self.lib.svae_lds_workspace_bytes(max(B, 1), T, n))
+        self.ws = torch.empty(self.ws_bytes // 8, **f64)
+        self.lognorm = torch.zeros(B, **f64)
+        self.E_init = torch.zeros(B, n * n + n, **f64)
+        self.E_node_diagxx = torch.zeros(B, T, n, **f64)
+        self.E_node_x = torch.zeros(B, T, n, **f64)
+        self.pair_contr = torch.zeros(B, T, 2, K, **f64)
+        self.info = torch.zeros(1, dtype=torch.int32, device=self.device)
+
+    @staticmethod
+    def supported(n, T, K):
+        """The fused kernel covers n <= 10, T >= 4 and K parameter sets that fit the 160 KiB of LDS."""
+        if n > 10 or T < 4 or K > 16:
+            return False
+        nbytes = int(_lib.load().svae_slds_lds_meanfield_lds_bytes(n, K))
+        return 0 < nbytes <= 160 * 1024
+
+    def launch(self, dense_init, dense_pair, weights, node, seq_index=None):
+        """dense_init = (J (K,n,n), h (K,n), a (K), b (K)), dense_pair = (J11, J12, J22 (K,n,n), logZ (K)),
+        weights (B,T,K), node = (J, h[, logZ]); seq_index: int32 tensor of the rows to process, or None = all."""
+        p = _lib.ptr
+        nrun = self.B if seq_index is None else int(seq_index.numel())
+        rc = self.lib.svae_slds_lds_meanfield_f64(
+            nrun, self.B, self.T, self.n, self.K, p(dense_init[0]), p(dense_init[1]),
+            p(dense_pair[0]), p(dense_pair[1]), p(dense_pair[2]), p(weights),
+            p(node[0]), p(node[1]), p(node[2]) if len(node) > 2 else None, p(seq_index),
+            p(self.lognorm), p(self.E_init), p(self.E_node_diagxx), p(self.E_node_x), p(self.pair_contr),
+            p(self.info), p(self.ws), self.ws_bytes, _lib.current_stream(self.device))
+        _lib.check(rc, "svae_slds_lds_meanfield_f64")
+
+    def hmm_nodeparams(self, dense_init, dense_pair, rows=None):
+        """get_arhmm_local_nodeparams (:131-147) from the kernel's contracted pair statistics
+        (rows: int64 index tensor = only those sequences)."""
+        n = self.n
+        E_init = self.E_init if rows is None else self.E_init.index_select(0, rows)
+        pc = self.pair_contr if rows is None else self.pair_contr.index_select(0, rows)
+        ExxT0, Ex0 = E_init[:, :n * n], E_init[:, n * n:]
+        n0 = ExxT0 @ dense_init[0].reshape(self.K, n * n).T + Ex0 @ dense_init[1].T + dense_init[2] + dense_init[3]
+        nt = pc[:, :-1, 0] + pc[:, 1:, 1] + dense_pair[3]
+        return torch.cat([n0[:, None], nt], 1)
+
+    def lds_vlb(self, dense_init, dense_pair, weights):
+        """log-normaliser of the mixed LDS = kernel part + the mixed constants."""
+        return self.lognorm + weights[:, 0] @ (dense_init[2] + dense_init[3]) + (weights[:, 1:] @ dense_pair[3]).sum(1)
+
+
+def _arhmm_nodeparams_from_path(dense_init, dense_pair, x):
+    """get_arhmm_local_nodeparams (:131-147) for the statistics of ONE sample path x (B,T,n)
+    (initialize_local_meanfield, :203-226) as quadratic forms -- without building the outer products."""
+    x0, xa, xb = x[:, 0], x[:, :-1], x[:, 1:]
+    n0 = torch.einsum("bi,kij,bj->bk", x0, dense_init[0], x0) + x0 @ dense_init[1].T + dense_init[2] + dense_init[3]
+    q = lambda u, M, v: (torch.einsum("bti,kij->btkj", u, M) * v.unsqueeze(2)).sum(-1)
+    nt = q(xa, dense_pair[0], xa) + q(xa, dense_pair[1], xb) + q(xb, dense_pair[2], xb) + dense_pair[3]
+    return torch.cat([n0[:, None], nt], 1)
+
+
+def _optimize_local_meanfield_fused(hmm_init, hmm_pair, dense_init, dense_pair, node, init_eps, tol, max_iter):
+    """The coordinate ascent of optimize_local_meanfield on the fused kernel.  Same iteration as the
+    materialised path (and the reference): hmm_meanfield -> lds_meanfield -> |delta vlb| < tol per sequence."""
+    B, T, n = node[1].shape
+    K = dense_init[0].shape[0]
+    dev = node[1].device
+    plan = SLDSMeanfieldPlan(B, T, n, K, dev)
+    dense_init = tuple(x.contiguous() for x in dense_init)
+    dense_pair = tuple(x.contiguous() for x in dense_pair)
+    x = _initial_sample_path(node, init_eps)
+    node_hmm = _arhmm_nodeparams_from_path(dense_init, dense_pair, x)
+    vlb = torch.full((B,), -float("inf"), dtype=torch.float64, device=dev)
+    active = torch.ones(B, dtype=torch.bool, device=dev)
+    iters = torch.zeros(B, dtype=torch.int64, device=dev)
+    st, rows, rows32 = None, None, None      # rows: the sequences still iterating (None = all)
+    for _ in range(max_iter):
+        # both kernels run on the sequences still iterating only; the others keep the state of their last
+        # iteration (the reference's per-sequence `break`)
+        hmm_vlb, (Ei, Et, Es) = hmm_estep((hmm_init, hmm_pair, node_hmm))
+        if st is None:
+            st = dict(Ei=Ei, Et=Et, Es=Es, hmm_vlb=hmm_vlb, node_hmm=node_hmm)
+        else:
+            for name, val in (("Ei", Ei), ("Et", Et), ("Es", Es), ("hmm_vlb", hmm_vlb), ("node_hmm", node_hmm)):
+                st[name].index_copy_(0, rows, val)
+        plan.launch(dense_init, dense_pair, st["Es"], node, rows32)
+        lds_vlb = plan.lds_vlb(dense_init, dense_pair, st["Es"])
+        new_vlb = st["hmm_vlb"] + lds_vlb
+        iters += active.to(torch.int64)
+        done = (new_vlb - vlb).abs() < tol
+        vlb = new_vlb
+        active = active & ~done
+        rows = active.nonzero().squeeze(1)          # (host sync: the launch sizes of the next sweep)
+        if rows.numel() == 0:
+            break
+        rows32 = rows.to(torch.int32)
+        node_hmm = plan.hmm_nodeparams(dense_init, dense_pair, rows)
+    return plan, st, lds_vlb, iters
+
+
+def _initial_sample_path(node_potentials, eps):
+    """(:203-226) ONE posterior sample path x (B,T,n) of a random-walk LDS given the node potentials."""
     nJ = node_potentials[0]
     B, T, n = nJ.shape
     dev = nJ.device
@@ -74,22 +224,39 @@ def initialize_local_meanfield(node_potentials, eps):
     natparam = ((-0.5 * eye, torch.zeros(n, dtype=torch.float64, device=dev), torch.zeros((), dtype=torch.float64, device=dev)),
                 (-0.5 * A.T @ A, A.T.contiguous(), -0.5 * eye, torch.zeros((), dtype=torch.float64, device=dev)))
     x, _, _ = natural_lds_inference_general(natparam, node_potentials, num_samples=1, eps=eps)
-    x = x[:, :, 0]                                                   # (B,T,n)
-    out = lambda a, b: a.unsqueeze(-1) * b.unsqueeze(-2)
-    init_stats = (out(x[:, 0], x[:, 0]), x[:, 0])
-    pair_stats = (out(x[:, :-1], x[:, :-1]), out(x[:, :-1], x[:, 1:]), out(x[:, 1:], x[:, 1:]))
-    return init_stats, pair_stats
+    return x[:, :, 0]                                                # (B,T,n)
 
 
-def optimize_local_meanfield(global_natparam, node_potentials, init_eps, tol=1e-2, max_iter=100):
-    """(:159-175).  Returns ((hmm_stats, lds_stats), (hmm_natparam, lds_natparam), (hmm_vlb, lds_vlb), iters)."""
+def optimize_local_meanfield(global_natparam, node_potentials, init_eps, tol=1e-2, max_iter=100, fused=None,
+                             pair_stats=True):
+    """(:159-175).  Returns ((hmm_stats, lds_stats), (hmm_natparam, lds_natparam), (hmm_vlb, lds_vlb), iters).
+
+    fused=None picks the fused LDS mean-field kernel (SLDSMeanfieldPlan) when it covers the shape, else the
+    path that materialises per-step pair parameters and statistics; True / False force one.  On the fused
+    path the per-step pair statistics of the reference's `lds_stats` tuple exist only if `pair_stats` (one
+    extra E-step on the converged mean field): callers that run their own final pass (run_inference) skip it
+    and get `None` in that slot."""
     hmm_global, lds_global = global_natparam
     dev = node_potentials[0].device
     node = tuple(_dev64(x, dev) for x in node_potentials)
     B, T, n = node[1].shape
-    hmm_init, hmm_pair = hmm_prior_expectedstats(tuple(_dev64(x, dev) for x in hmm_global))
-    lds_global = [(_dev64(a, dev), tuple(_dev64(y, dev) for y in m)) for a, m in lds_global]
-    dense_init, dense_pair = get_all_lds_local_natparams(lds_global)
+    hmm_init, hmm_pair, dense_init, dense_pair = global_to_local_maps(global_natparam, dev)
+    K = dense_init[0].shape[0]
+    if fused is None:
+        fused = SLDSMeanfieldPlan.supported(n, T, K)
+    if fused:
+        fplan, st, lds_vlb, iters = _optimize_local_meanfield_fused(
+            hmm_init, hmm_pair, dense_init, dense_pair, node, _dev64(init_eps, dev), tol, max_iter)
+        lds_init, lds_pair = get_var_lds_local_natparam(dense_init, dense_pair, st["Es"])
+        init_stats = (fplan.E_init[:, :n * n].reshape(B, n, n), fplan.E_init[:, n * n:])
+        pstats = None
+        if pair_stats:
+            plan = LDSEStepPlan(B, T, n, dev, inhomog=True, pair_batched=True)
+            _, (_, Ep, _) = _lds_estep_batched_init(plan, lds_init, lds_pair, node)
+            pstats = tuple(Ep[:3])
+        lds_stats = (init_stats, pstats, (fplan.E_node_diagxx, fplan.E_node_x))
+        return ((st["Ei"], st["Et"], st["Es"]), lds_stats), \
+            ((hmm_init, hmm_pair, st["node_hmm"]), (lds_init, lds_pair)), (st["hmm_vlb"], lds_vlb), iters
     plan = LDSEStepPlan(B, T, n, dev, inhomog=True, pair_batched=True)
 
     init_stats, pair_stats = initialize_local_meanfield(node, _dev64(init_eps, dev))
@@ -150,8 +317,7 @@ def optimize_local_meanfield_withlabels(global_natparam, node_potentials, labels
     E_trans = torch.einsum("bti,btj->bij", ind[:, :-1], ind[:, 1:])
     soft = ind + 1e-2
     hmm_stats = (ind[:, 0], E_trans, soft / soft.sum(-1, keepdim=True))
-    lds_global = [(_dev64(a, dev), tuple(_dev64(y, dev) for y in m)) for a, m in lds_global]
-    dense_init, dense_pair = get_all_lds_local_natparams(lds_global)
+    _, _, dense_init, dense_pair = global_to_local_maps(global_natparam, dev)
     lds_init, lds_pair = get_var_lds_local_natparam(dense_init, dense_pair, hmm_stats[2])
     plan = LDSEStepPlan(B, T, n, dev, inhomog=True, pair_batched=True)
     lds_vlb, (Ei, Ep, En) = _lds_estep_batched_init(plan, lds_init, lds_pair, node)
@@ -189,8 +355,13 @@ def get_global_stats(hmm_stats, init_stats, pair_stats):
     w0, w1 = Es[:, 0], Es[:, 1:]
     ExxT0, Ex0 = init_stats
     ones = torch.ones_like(w0)
-    g_init = (torch.einsum("bk,bij->kij", w0, ExxT0), torch.einsum("bk,bi->ki", w0, Ex0), w0.sum(0), w0.sum(0))
-    g_pair = tuple(torch.einsum("btk,btij->kij", w1, p) for p in pair_stats) + (w1.sum((0, 1)),)
+    B, n = Ex0.shape
+    K = w0.shape[1]
+    g_init = ((w0.T @ ExxT0.reshape(B, n * n)).reshape(K, n, n), w0.T @ Ex0, w0.sum(0), w0.sum(0))
+    # sum_{b,t} w1[b,t,k] * stats[b,t]: per sequence (K x T-1)(T-1 x 3n^2), then the batch sum (one long
+    # reduction axis as a single GEMM is pathological in rocBLAS: 110 ms at B T = 1e6)
+    gp = torch.bmm(w1.transpose(1, 2), _packed_pair_stats(pair_stats)).sum(0).reshape(K, 3, n, n)
+    g_pair = (gp[:, 0], gp[:, 1], gp[:, 2], w1.sum((0, 1)))
     return (Ei.sum(0), Et.sum(0)), (g_init, g_pair)
 
 
@@ -215,19 +386,17 @@ def run_inference(prior_natparam, global_natparam, nn_potentials, num_samples, i
     B, T, n = node[1].shape
     if init_eps is None:
         init_eps = torch.randn(B, T, 1, n, dtype=torch.float64, device=dev, generator=generator)
-    (hmm_stats, _), (hmm_nat, (lds_init, lds_pair)), _, _ = optimize_local_meanfield(global_natparam, node, init_eps, tol)
+    (hmm_stats, _), (hmm_nat, (lds_init, lds_pair)), _, _ = optimize_local_meanfield(global_natparam, node, init_eps, tol, pair_stats=False)
     plan = LDSEStepPlan(B, T, n, dev, inhomog=True, pair_batched=True)
     lognorm, (Ei, Ep, En) = _lds_estep_batched_init(plan, lds_init, lds_pair, node, keep_factor=True)
     S = int(num_samples)
     if eps is None:
         eps = torch.randn(B, T, S, n, dtype=torch.float64, device=dev, generator=generator)
     samples = plan.sample(_dev64(eps, dev))
-    hmm_global, lds_global = global_natparam
-    lds_global_d = [(_dev64(a, dev), tuple(_dev64(y, dev) for y in m)) for a, m in lds_global]
-    dense_init, dense_pair = get_all_lds_local_natparams(lds_global_d)
-    node_hmm = get_arhmm_local_nodeparams(dense_init, dense_pair, (Ei[0], Ei[1]), (Ep[0], Ep[1], Ep[2]))
+    _, _, dense_init, dense_pair = global_to_local_maps(global_natparam, dev)
+    node_hmm = get_arhmm_local_nodeparams(dense_init, dense_pair, (Ei[0], Ei[1]), plan.E_pair)
     hmm_vlb, _ = hmm_estep((hmm_nat[0], hmm_nat[1], node_hmm))
-    expected_stats = get_global_stats(hmm_stats, (Ei[0], Ei[1]), (Ep[0], Ep[1], Ep[2]))
+    expected_stats = get_global_stats(hmm_stats, (Ei[0], Ei[1]), plan.E_pair)
     lds_vlb = lognorm - ((node[0] * En[0]).sum((1, 2)) + (node[1] * En[1]).sum((1, 2)))
     local_vlb = (hmm_vlb + lds_vlb).sum()
     global_vlb = slds_prior_vlb(global_natparam, prior_natparam, dev)
@@ -236,6 +405,8 @@ def run_inference(prior_natparam, global_natparam, nn_potentials, num_samples, i
 
 def slds_prior_vlb(global_natparam, prior_natparam, dev):
     """(:248-286) <prior - global, E_global[stats]> - (logZ(prior) - logZ(global))."""
+    out_dev, dev = dev, torch.device("cpu")     # K small matrices: evaluated on the host, one scalar moved back
+
     def parts(natparam):
         (d, md), lds = natparam
         return (_dev64(d, dev), _dev64(md, dev)), [(_dev64(a, dev), tuple(_dev64(y, dev) for y in m)) for a, m in lds]
@@ -247,7 +418,7 @@ def slds_prior_vlb(global_natparam, prior_natparam, dev):
     for (ga, gm), (pa, pm) in zip(glds, plds):
         val = val + ((pa - ga) * expfam.niw_expectedstats(ga)).sum()
         val = val + sum(((x - y) * e).sum() for x, y, e in zip(pm, gm, expfam.mniw_expectedstats(gm)))
-    return val - (logZ(pd, pmd, plds) - logZ(gd, gmd, glds))
+    return (val - (logZ(pd, pmd, plds) - logZ(gd, gmd, glds))).to(out_dev)
 
 
 def final_pass_differentiable(global_natparam, hmm_natparam, lds_natparam, nn_potentials, eps):
@@ -270,12 +441,10 @@ def final_pass_differentiable(global_natparam, hmm_natparam, lds_natparam, nn_po
                 (J11.contiguous(), J12.contiguous(), J22.contiguous(), lz.contiguous()))
     lognorm, (dxx, ex), samples, (E_init, E_pair) = lds_inference_differentiable(natparam, (nJ, nh_eff), eps=eps)
     lognorm = lognorm + a0 + b0
-    hmm_global, lds_global = global_natparam
-    lds_global_d = [(_dev64(a, dev), tuple(_dev64(y, dev) for y in m)) for a, m in lds_global]
-    dense_init, dense_pair = get_all_lds_local_natparams(lds_global_d)
+    _, _, dense_init, dense_pair = global_to_local_maps(global_natparam, dev)
     init_stats = (E_init[:, :n * n].reshape(B, n, n), E_init[:, n * n:])
     pair_stats = (E_pair[:, :, 0], E_pair[:, :, 1], E_pair[:, :, 2])
-    node_hmm = get_arhmm_local_nodeparams(dense_init, dense_pair, init_stats, pair_stats)
+    node_hmm = get_arhmm_local_nodeparams(dense_init, dense_pair, init_stats, E_pair)
     hmm_vlb = hmm_logZ_differentiable((hmm_natparam[0], hmm_natparam[1], node_hmm))
     lds_vlb = lognorm - ((nJ * dxx).sum((1, 2)) + (nh * ex).sum((1, 2)))
     return samples, (init_stats, pair_stats), (hmm_vlb + lds_vlb).sum()
@@ -292,7 +461,7 @@ def run_inference_differentiable(prior_natparam, global_natparam, nn_potentials,
     B, T, n = node_d[1].shape
     if init_eps is None:
         init_eps = torch.randn(B, T, 1, n, dtype=torch.float64, device=dev, generator=generator)
-    (hmm_stats, _), (hmm_nat, lds_nat), _, _ = optimize_local_meanfield(global_natparam, node_d, init_eps, tol)
+    (hmm_stats, _), (hmm_nat, lds_nat), _, _ = optimize_local_meanfield(global_natparam, node_d, init_eps, tol, pair_stats=False)
     if eps is None:
         eps = torch.randn(B, T, int(num_samples), n, dtype=torch.float64, device=dev, generator=generator)
     samples, (init_stats, pair_stats), local_vlb = final_pass_differentiable(

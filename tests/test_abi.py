@@ -20,7 +20,8 @@ def test_header_declares_the_expected_entry_points():
     for s in ("svae_lds_estep_f64", "svae_lds_workspace_bytes", "svae_lds_workspace_bytes_ex", "svae_lds_set_split_max_b", "svae_lds_set_twoend", "svae_lds_filter_f64",
               "svae_lds_reduce_stats_f64",
               "svae_lds_sample_f64", "svae_lds_estep_vjp_f64", "svae_lds_vjp_workspace_bytes",
-              "svae_hmm_estep_f64", "svae_hmm_workspace_bytes",
+              "svae_hmm_estep_f64", "svae_hmm_workspace_bytes", "svae_slds_lds_meanfield_f64",
+              "svae_slds_lds_meanfield_lds_bytes",
               "svae_gmm_meanfield_f64", "svae_hip_abi_version"):
         assert s in syms
 

@@ -43,8 +43,9 @@ def _nodes(B, T, n, rng):
     return J, h
 
 
-@pytest.mark.parametrize("K,n,T,B", [(3, 2, 12, 3), (4, 5, 30, 6), (2, 10, 16, 2)])
-def test_optimize_local_meanfield_matches_oracle(K, n, T, B):
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("K,n,T,B", [(3, 2, 12, 3), (4, 5, 30, 6), (2, 10, 16, 2), (5, 9, 7, 9), (1, 3, 5, 2)])
+def test_optimize_local_meanfield_matches_oracle(K, n, T, B, fused):
     from svae_amd.models import slds_svae
     rng = np.random.default_rng(100 * K + n)
     glob = _globals(K, n, rng)
@@ -52,7 +53,8 @@ def test_optimize_local_meanfield_matches_oracle(K, n, T, B):
     eps = rng.standard_normal((B, T, 1, n))
     dev = torch.device("cuda:0")
     node = (torch.as_tensor(J, device=dev), torch.as_tensor(h, device=dev))
-    (hmm_stats, lds_stats), _, (hmm_vlb, lds_vlb), iters = slds_svae.optimize_local_meanfield(glob, node, eps)
+    (hmm_stats, lds_stats), _, (hmm_vlb, lds_vlb), iters = slds_svae.optimize_local_meanfield(glob, node, eps,
+                                                                                             fused=fused)
     for b in range(B):
         ref = slds_numpy.optimize_local_meanfield(glob, (J[b], h[b]), eps[b])
         assert int(iters[b]) == ref["iters"]
@@ -117,7 +119,59 @@ def test_withlabels_matches_oracle():
             _close(got[b], want)
 
 
-def test_config3_shape_properties():
+@pytest.mark.parametrize("K,n,T,B", [(3, 4, 9, 5), (8, 10, 40, 11), (7, 10, 5, 3), (16, 6, 12, 4), (2, 2, 4, 2)])
+def test_fused_lds_meanfield_step_matches_materialised(K, n, T, B):
+    """One LDS mean-field step through svae_slds_lds_meanfield_f64 (K parameter sets in LDS, mixed per step
+    by the HMM marginals, pair statistics contracted in the kernel) against the path that materialises the
+    per-step pair parameters and statistics (get_var_lds_local_natparam / get_arhmm_local_nodeparams,
+    slds_svae.py:92-103, 131-147, themselves pinned against the NumPy restatement above); sequences not
+    listed in `seq_index` (frozen ones) keep their buffers."""
+    from svae_amd.lds.lds_inference import LDSEStepPlan
+    from svae_amd.models import slds_svae
+    rng = np.random.default_rng(1000 * K + 10 * n + T)
+    (_, _), lds = _globals(K, n, rng)
+    J, h = _nodes(B, T, n, rng)
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev)
+    node = (t(J), t(h), t(rng.standard_normal((B, T))))
+    lds_d = [(t(a), tuple(t(y) for y in m)) for a, m in lds]
+    dense_init, dense_pair = slds_svae.get_all_lds_local_natparams(lds_d)
+    dense_init = tuple(x.to(dev) for x in dense_init)
+    dense_pair = tuple(x.to(dev) for x in dense_pair)
+    w = rng.random((B, T, K)) ** 3 + 1e-3
+    w = t(w / w.sum(-1, keepdims=True))
+    assert slds_svae.SLDSMeanfieldPlan.supported(n, T, K)
+    plan = slds_svae.SLDSMeanfieldPlan(B, T, n, K, dev)
+    sentinel = -7.25
+    for buf in (plan.lognorm, plan.E_init, plan.E_node_diagxx, plan.E_node_x, plan.pair_contr):
+        buf.fill_(sentinel)
+    rows = [b for b in range(B) if b != B // 2]
+    rows = torch.tensor(rows[1::2] + rows[0::2], dtype=torch.int32, device=dev)      # any order
+    plan.launch(dense_init, dense_pair, w, node, rows)
+    torch.cuda.synchronize()
+    assert int(plan.info.item()) == 0
+    # materialised path
+    lds_init, lds_pair = slds_svae.get_var_lds_local_natparam(dense_init, dense_pair, w)
+    mplan = LDSEStepPlan(B, T, n, dev, inhomog=True, pair_batched=True)
+    lognorm, (Ei, Ep, En) = slds_svae._lds_estep_batched_init(mplan, lds_init, lds_pair, node)
+    node_hmm = slds_svae.get_arhmm_local_nodeparams(dense_init, dense_pair, (Ei[0], Ei[1]), (Ep[0], Ep[1], Ep[2]))
+    got_vlb = plan.lds_vlb(dense_init, dense_pair, w)
+    got_hmm = plan.hmm_nodeparams(dense_init, dense_pair)
+    for b in range(B):
+        if b == B // 2:
+            for buf in (plan.lognorm, plan.E_init, plan.E_node_diagxx, plan.E_node_x, plan.pair_contr):
+                assert bool((buf[b] == sentinel).all()), "frozen sequence was rewritten"
+            continue
+        assert float(got_vlb[b]) == pytest.approx(float(lognorm[b]), rel=1e-10, abs=1e-9)
+        _close(plan.E_init[b, :n * n].reshape(n, n), _np(Ei[0][b]), 1e-8)
+        _close(plan.E_init[b, n * n:], _np(Ei[1][b]), 1e-8)
+        _close(plan.E_node_diagxx[b], _np(En[0][b]), 1e-8)
+        _close(plan.E_node_x[b], _np(En[1][b]), 1e-8)
+        _close(got_hmm[b], _np(node_hmm[b]), 1e-8)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_config3_shape_properties(fused):
     """BASELINE configs[3] shape (K=8 states, latent dim 10, T=500), a slice of the batch:
     size-independent properties of the converged local mean field plus parity of one sequence."""
     from svae_amd.models import slds_svae
@@ -128,7 +182,8 @@ def test_config3_shape_properties():
     eps = rng.standard_normal((B, T, 1, n))
     dev = torch.device("cuda:0")
     node = (torch.as_tensor(J, device=dev), torch.as_tensor(h, device=dev))
-    (hmm_stats, lds_stats), _, (hmm_vlb, lds_vlb), iters = slds_svae.optimize_local_meanfield(glob, node, eps)
+    (hmm_stats, lds_stats), _, (hmm_vlb, lds_vlb), iters = slds_svae.optimize_local_meanfield(glob, node, eps,
+                                                                                             fused=fused)
     Ei, Et, Es = hmm_stats
     assert int(iters.max()) < 100
     assert torch.allclose(Es.sum(-1), torch.ones_like(Es.sum(-1)), atol=1e-12)

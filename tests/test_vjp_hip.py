@@ -141,6 +141,54 @@ def test_vjp_inhomogeneous_with_statistics_cotangents(n, T, B, S, batched, with_
 
 
 @pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("n,T,B,S", [(3, 6, 2, 2), (10, 30, 3, 1), (6, 2, 2, 1)])
+@pytest.mark.parametrize("with_samples", [False, True])
+def test_vjp_homogeneous_summed_pair_statistics_cotangents(n, T, B, S, with_samples):
+    """Homogeneous pair parameters, cotangents of E_init and of the SUMMED E_pair (B,3,n,n): the homogeneous
+    branch of the reference's _compute_stats_grad (cython_lds_inference.pyx:229-231), through
+    lds_inference_differentiable(..., pair_stats_grad=True)."""
+    from svae_amd.lds.lds_inference import lds_inference_differentiable
+    from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials
+    rng = np.random.default_rng(31 * n + T)
+    init, pair = rand_lds_natparam(n, rng)
+    node = rand_node_potentials((B, T, n), rng, with_logZ=True)
+    g = dict(ln=rng.standard_normal(B), dxx=rng.standard_normal((B, T, n)), x=rng.standard_normal((B, T, n)),
+             s=rng.standard_normal((B, T, S, n)), i=rng.standard_normal((B, n * n + n)),
+             p=rng.standard_normal((B, 3, n, n)))
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev)
+    want, eps, fwd = [], np.zeros((B, T, S, n)), []
+    for b in range(B):
+        (gJ, gh, gz), e = ref.estep_vjp(
+            (init, pair), tuple(x[b] for x in node), g["ln"][b], (g["dxx"][b], g["x"][b]),
+            g["s"][b] if with_samples else None, seed=300 + b,
+            g_E_init=(g["i"][b, :n * n].reshape(n, n), g["i"][b, n * n:]),
+            g_E_pair=(g["p"][b, 0], g["p"][b, 1], g["p"][b, 2]))
+        want.append((gJ, gh, gz))
+        fwd.append(ref.estep((init, pair), tuple(x[b] for x in node)))
+        if with_samples:
+            eps[b] = e
+    nJ, nh, nz = (t(x).requires_grad_(True) for x in node)
+    lognorm, (dxx, ex), samples, (E_init, E_pair) = lds_inference_differentiable(
+        (tuple(t(x) for x in init), tuple(t(x) for x in pair)), (nJ, nh, nz),
+        eps=t(eps) if with_samples else None, pair_stats_grad=True)
+    assert tuple(E_pair.shape) == (B, 3, n, n)
+    for b in range(B):          # the summed statistics themselves
+        _, (Ei, Ep, En) = fwd[b]
+        for i in range(3):
+            assert _rel(E_pair[b, i], np.asarray(Ep[i])) < 1e-8
+    loss = (t(g["ln"]) * lognorm).sum() + (t(g["dxx"]) * dxx).sum() + (t(g["x"]) * ex).sum() \
+        + (t(g["i"]) * E_init).sum() + (t(g["p"]) * E_pair).sum()
+    if with_samples:
+        loss = loss + (t(g["s"]) * samples).sum()
+    loss.backward()
+    for b in range(B):
+        assert _rel(nJ.grad[b], want[b][0]) < 1e-6, "g_node_J"
+        assert _rel(nh.grad[b], want[b][1]) < 1e-6, "g_node_h"
+        assert _rel(nz.grad[b], want[b][2]) < 1e-12, "g_node_logZ"
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
 @pytest.mark.parametrize("B", [512, 2304])
 def test_vjp_full_size_against_reference(B):
     """BASELINE configs[1] shape (T=200, n=10): E-step + sampler + VJP of the whole batch, 16 sequences
