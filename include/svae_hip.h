@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SVAE_HIP_ABI_VERSION 4   /* 4: + svae_slds_lds_meanfield_f64; 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
+#define SVAE_HIP_ABI_VERSION 4   /* 4: + svae_slds_lds_meanfield_f64, svae_gmm_mw_*; 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
 #define SVAE_LDS_MAX_N 15   /* register/DPP path: one 16-lane row per sequence, n+1 <= 16 */
 #define SVAE_LDS_TILE_MAX_N 64   /* 16 <= n <= 64: LDS-tiled MFMA path (E-step only: keep must be 0) */
 
@@ -245,6 +245,32 @@ int svae_gmm_meanfield_f64(int T, int N, int K,
                            double* dirichlet_stats, double* niw_stats,
                            double* kl, int32_t* iters, int32_t* assign,
                            int32_t* info, void* stream);
+
+/* The same fixed point spread over MANY workgroups -- and, through the caller's all-reduce, over many GPUs --
+ * with the reference's stopping rule on the batch-total KL (/root/reference/svae/models/gmm.py:104-105)
+ * kept exact: one launch per sweep, each ending in a fixed-order reduction of its workgroups' KL partials
+ * into kl_hist[sweep] (first max_iter+1 doubles of the workspace; svae_gmm_mw_kl_hist); every launch first
+ * scans kl_hist for an earlier sweep that met |kl_j - kl_{j-1}| < tol and is a no-op if there is one, so the
+ * host enqueues max_iter sweeps blindly, with no synchronisation.  Multi-GPU (points sharded over ranks):
+ * all-reduce kl_hist[sweep] in place after each sweep launch -- every rank then takes the same decision.
+ *   svae_gmm_mw_begin     zeroes the state (once per fixed point)
+ *   svae_gmm_mw_step_f64  phase 0: sweep number `sweep`; phase 1: the final pass of gmm.py:74-86 (writes
+ *                         every per-point output, kl = this rank's total, iters); phase 2: the global
+ *                         statistics (dirichlet_stats, niw_stats of this rank's points).
+ * Arguments as svae_gmm_meanfield_f64.  Results agree with the single-workgroup kernel up to the summation
+ * order of the KL total (same per-point arithmetic: identical labels unless a sweep sits on the tolerance). */
+size_t svae_gmm_mw_workspace_bytes(int T, int N, int K, int max_iter);
+int svae_gmm_mw_begin(int T, int N, int K, int max_iter, void* workspace, size_t ws_bytes, void* stream);
+int svae_gmm_mw_step_f64(int phase, int sweep, int T, int N, int K,
+                         const double* label_global, const double* gaussian_globals,
+                         const double* node_J, const double* node_h,
+                         const double* label_init, double tol, int max_iter,
+                         double* label_stats, double* label_fixed, double* gaussian_stats,
+                         double* label_natparam, double* gaussian_natparam,
+                         double* dirichlet_stats, double* niw_stats,
+                         double* kl, int32_t* iters, int32_t* assign, int32_t* info,
+                         void* workspace, size_t ws_bytes, void* stream);
+double* svae_gmm_mw_kl_hist(void* workspace);
 
 #ifdef __cplusplus
 }

@@ -31,9 +31,73 @@ def initialize_meanfield(T, K, device, generator=None):
     return r / r.sum(-1, keepdim=True)
 
 
+GMM_SINGLE_WG_MAX_T = 4096     # above: the multi-workgroup sweeps (one workgroup: 16 k points = 330 us per sweep)
+
+
+def run_sweeps(backend, max_iter, group=None):
+    """The sweep protocol of the multi-workgroup / multi-GPU fixed point (include/svae_hip.h, svae_gmm_mw_*):
+    `backend` enqueues begin / sweep(i) / final / stats and exposes `kl_hist` (tensor, one total per sweep).
+    Under torch.distributed (points sharded over the ranks of `group`) kl_hist[i] is all-reduced in place
+    after sweep i, so that every rank applies the reference's stopping rule to the SAME batch-total KL
+    (gmm.py:104-105).  No host synchronisation: sweeps after convergence are device-side no-ops."""
+    import torch.distributed as dist
+    sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    backend.begin()
+    for i in range(max_iter):
+        backend.sweep(i)
+        if sharded:
+            dist.all_reduce(backend.kl_hist[i:i + 1], group=group)
+    backend.final()
+    backend.stats()
+
+
+class _HipSweeps(object):
+    """run_sweeps backend on libsvae_hip.so (svae_gmm_mw_begin / svae_gmm_mw_step_f64)."""
+
+    def __init__(self, lib, dims, tensors, out, tol, max_iter, dev):
+        self.lib, self.dims, self.t, self.out = lib, dims, tensors, out
+        self.tol, self.max_iter, self.dev = float(tol), int(max_iter), dev
+        T, N, K = dims
+        self.ws_bytes = int(lib.svae_gmm_mw_workspace_bytes(T, N, K, self.max_iter))
+        self.ws = torch.empty((self.ws_bytes + 7) // 8, dtype=torch.float64, device=dev)
+        self.kl_hist = self.ws[:self.max_iter + 1]
+
+    def begin(self):
+        T, N, K = self.dims
+        _lib.check(self.lib.svae_gmm_mw_begin(T, N, K, self.max_iter, _lib.ptr(self.ws), self.ws_bytes,
+                                              _lib.current_stream(self.dev)), "svae_gmm_mw_begin")
+
+    def _step(self, phase, sweep):
+        T, N, K = self.dims
+        p, o = _lib.ptr, self.out
+        lg, gg, nJ, nh, li = self.t
+        rc = self.lib.svae_gmm_mw_step_f64(
+            phase, sweep, T, N, K, p(lg), p(gg), p(nJ), p(nh), p(li), self.tol, self.max_iter,
+            p(o["label_stats"]), p(o["label_fixed"]), p(o["gaussian_stats"]), p(o["label_natparam"]),
+            p(o["gaussian_natparam"]), p(o["dirichlet_stats"]), p(o["niw_stats"]),
+            p(o["kl"]), p(o["iters"]), p(o["assign"]), p(o["info"]), p(self.ws), self.ws_bytes,
+            _lib.current_stream(self.dev))
+        _lib.check(rc, "svae_gmm_mw_step_f64")
+
+    def sweep(self, i):
+        self._step(0, i)
+
+    def final(self):
+        self._step(1, 0)
+
+    def stats(self):
+        self._step(2, 0)
+
+
 def meanfield_from_globals(label_global, gaussian_globals, node_potentials, label_init,
-                           tol=1e-3, max_iter=100, check=True):
-    """The kernel call: everything after gmm.py:68.  Returns a dict of device tensors."""
+                           tol=1e-3, max_iter=100, check=True, multi_wg=None, group=None):
+    """The kernel call: everything after gmm.py:68.  Returns a dict of device tensors.
+
+    multi_wg=None picks the single-workgroup, single-launch kernel for small minibatches and the
+    multi-workgroup sweeps (svae_gmm_mw_*) above GMM_SINGLE_WG_MAX_T points or when the points are sharded
+    over the ranks of `group` (then T is this rank's share, the stopping rule runs on the all-reduced KL and
+    `kl` / the statistics returned are this rank's: run_inference sums them)."""
+    import torch.distributed as dist
     lib = _lib.load()
     dev = gaussian_globals.device if isinstance(gaussian_globals, torch.Tensor) and \
         gaussian_globals.is_cuda else torch.device("cuda", torch.cuda.current_device())
@@ -60,12 +124,20 @@ def meanfield_from_globals(label_global, gaussian_globals, node_potentials, labe
                assign=torch.empty(T, dtype=torch.int32, device=dev),
                info=torch.zeros(1, dtype=torch.int32, device=dev))
     p = _lib.ptr
-    rc = lib.svae_gmm_meanfield_f64(
-        T, N, K, p(lg), p(gg), p(nJ), p(nh), p(li), float(tol), int(max_iter),
-        p(out["label_stats"]), p(out["label_fixed"]), p(out["gaussian_stats"]), p(out["label_natparam"]),
-        p(out["gaussian_natparam"]), p(out["dirichlet_stats"]), p(out["niw_stats"]),
-        p(out["kl"]), p(out["iters"]), p(out["assign"]), p(out["info"]), _lib.current_stream(dev))
-    _lib.check(rc, "svae_gmm_meanfield_f64")
+    sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if multi_wg is None:
+        multi_wg = sharded or T > GMM_SINGLE_WG_MAX_T
+    if sharded and not multi_wg:
+        raise ValueError("sharded points need the multi-workgroup sweeps (batch-total stopping rule)")
+    if multi_wg:
+        run_sweeps(_HipSweeps(lib, (T, N, K), (lg, gg, nJ, nh, li), out, tol, max_iter, dev), int(max_iter), group)
+    else:
+        rc = lib.svae_gmm_meanfield_f64(
+            T, N, K, p(lg), p(gg), p(nJ), p(nh), p(li), float(tol), int(max_iter),
+            p(out["label_stats"]), p(out["label_fixed"]), p(out["gaussian_stats"]), p(out["label_natparam"]),
+            p(out["gaussian_natparam"]), p(out["dirichlet_stats"]), p(out["niw_stats"]),
+            p(out["kl"]), p(out["iters"]), p(out["assign"]), p(out["info"]), _lib.current_stream(dev))
+        _lib.check(rc, "svae_gmm_meanfield_f64")
     if check:
         v = int(out["info"].item())
         if v != 0:
@@ -75,8 +147,10 @@ def meanfield_from_globals(label_global, gaussian_globals, node_potentials, labe
 
 
 def local_meanfield(global_natparam, node_potentials, label_init=None, tol=1e-3, max_iter=100,
-                    generator=None):
-    """gmm.py:62-88 -> (local_stats, prior_stats, natparam, kl)."""
+                    generator=None, group=None, multi_wg=None):
+    """gmm.py:62-88 -> (local_stats, prior_stats, natparam, kl).  With the points sharded over the ranks of
+    `group`: the fixed point stops on the all-reduced batch-total KL like the reference's single process;
+    prior_stats and kl are this rank's share."""
     dirichlet_natparam, niw_natparams = global_natparam
     dev = torch.device("cuda", torch.cuda.current_device())
     for x in (niw_natparams, node_potentials[0]):
@@ -89,7 +163,7 @@ def local_meanfield(global_natparam, node_potentials, label_init=None, tol=1e-3,
     if label_init is None:
         label_init = initialize_meanfield(T, dn.shape[0], dev, generator)
     o = meanfield_from_globals(label_global, gaussian_globals, node_potentials, label_init,
-                               tol, max_iter)
+                               tol, max_iter, multi_wg=multi_wg, group=group)
     local_stats = o["label_stats"], o["gaussian_stats"]
     prior_stats = o["dirichlet_stats"], o["niw_stats"]
     natparam = o["label_natparam"], o["gaussian_natparam"]
@@ -136,7 +210,7 @@ def run_inference(prior_natparam, global_natparam, nn_potentials, num_samples, l
     """gmm.py:12-16 -> (samples (T,S,N), (dirichlet_stats, niw_stats), global_kl, local_kl).  Under
     torch.distributed the points are this rank's shard; statistics and local_kl are summed over ranks."""
     _, stats, local_natparam, local_kl = local_meanfield(global_natparam, nn_potentials,
-                                                         label_init=label_init, generator=generator)
+                                                         label_init=label_init, generator=generator, group=group)
     gn = local_natparam[1]
     T, N = gn.shape[0], gn.shape[-1] - 2
     if eps is None:
@@ -191,7 +265,7 @@ def run_inference_differentiable(prior_natparam, global_natparam, nn_potentials,
     T, N = nh.shape
     if label_init is None:
         label_init = initialize_meanfield(T, g[0].shape[0], dev, generator)
-    o = meanfield_from_globals(label_global, gaussian_globals, (nJ.detach(), nh.detach()), label_init)
+    o = meanfield_from_globals(label_global, gaussian_globals, (nJ.detach(), nh.detach()), label_init, group=group)
     label_fixed = o["label_fixed"]          # the fixed point the final pass starts from (gmm.py:71)
     node_dense = expfam.pack_dense(nJ, nh)
     (label_stats, gaussian_stats), (label_natparam, gaussian_natparam), local_kl = \

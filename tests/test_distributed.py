@@ -119,3 +119,123 @@ def test_two_rank_stat_allreduce_matches_single_process():
         np.testing.assert_allclose(g[10], 6.0)                 #      2 + 4
         assert g[11] == pytest.approx(2.0)                     #      0.5 + 1.5
     assert got[0][3][-1] == B
+
+
+# ---- GMM fixed point with the points sharded over ranks: the sweep protocol (models.gmm.run_sweeps) -------
+
+class _NumpySweeps(object):
+    """run_sweeps backend with the HIP kernels' semantics (include/svae_hip.h, svae_gmm_mw_*) restated on the
+    oracle's per-point functions: sweep i is a no-op once an earlier sweep met the stopping rule on kl_hist."""
+
+    def __init__(self, lg, gg, node_dense, init, tol, max_iter):
+        from oracle import gmm_numpy
+        self.g, self.lg, self.gg, self.node, self.tol, self.max_iter = gmm_numpy, lg, gg, node_dense, tol, max_iter
+        self.kl_hist = torch.zeros(max_iter + 1, dtype=torch.float64)
+        self.r = init
+
+    def _converged_at(self, upto):
+        prev = np.inf
+        for j in range(upto):
+            if abs(float(self.kl_hist[j]) - prev) < self.tol:
+                return j
+            prev = float(self.kl_hist[j])
+        return -1
+
+    def begin(self):
+        self.kl_hist.zero_()
+
+    def sweep(self, i):
+        if self._converged_at(i) >= 0:
+            return
+        g = self.g
+        natparam, stats, gkl = g.gaussian_meanfield(self.gg, self.node, self.r)
+        _, r_new, lkl = g.label_meanfield(self.lg, self.gg, stats)
+        lin = natparam - np.tensordot(r_new, self.gg, [1, 0]) - self.node
+        self.kl_hist[i] = float(lkl + gkl + np.tensordot(lin, stats, 3))       # this rank's points only
+        self.r = r_new
+
+    def final(self):
+        g = self.g
+        conv = self._converged_at(self.max_iter)
+        self.iters = conv + 1 if conv >= 0 else self.max_iter
+        _, self.gstats, gkl = g.gaussian_meanfield(self.gg, self.node, self.r)
+        _, self.r, lkl = g.label_meanfield(self.lg, self.gg, self.gstats)
+        self.kl = float(lkl + gkl)
+
+    def stats(self):
+        self.dirichlet_stats = self.r.sum(0)
+        self.niw_stats = np.tensordot(self.r, self.gstats, [0, 0])
+
+
+def _gmm_problem(T, N, K, seed):
+    from oracle import expfam_numpy as ef
+    rng = np.random.default_rng(seed)
+    niw = np.stack([ef.niw_standard_to_natural((N + 10.) * np.eye(N), 2 * rng.standard_normal(N), np.array(10.),
+                                               np.array(N + 10.)) for _ in range(K)])
+    lg, gg = ef.dirichlet_expectedstats(rng.random(K) + 0.5), ef.niw_expectedstats(niw)
+    node = rand_node_potentials((T, N), rng)
+    init = rng.random((T, K))
+    init /= init.sum(-1, keepdims=True)
+    return lg, gg, ef.pack_dense(*node), node, init
+
+
+def _gmm_worker(rank, world, port, T, N, K, tol, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from svae_amd.models.gmm import run_sweeps, _allreduce_stats_and_kl
+        lg, gg, dense, _, init = _gmm_problem(T, N, K, 3)
+        lo, hi = shard_bounds(T)
+        be = _NumpySweeps(lg, gg, dense[lo:hi], init[lo:hi], tol, 100)
+        run_sweeps(be, 100)
+        (ds, ns), kl = _allreduce_stats_and_kl((torch.from_numpy(be.dirichlet_stats), torch.from_numpy(be.niw_stats)),
+                                               torch.tensor(be.kl, dtype=torch.float64), None)
+        q.put((rank, lo, hi, be.iters, be.r, ds.numpy(), ns.numpy(), float(kl)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_gmm_fixed_point_stops_on_the_batch_total_kl():
+    """Points sharded over 2 ranks, kl_hist[i] all-reduced after every sweep: same iteration count, same
+    responsibilities and the same summed statistics as ONE process on all the points (the reference's rule is on
+    the minibatch total, gmm.py:104-105); each shard ALONE would stop at a different sweep."""
+    from oracle import gmm_numpy
+    T, N, K, tol, world = 301, 2, 5, 1e-3, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gmm_worker, args=(r, world, port, T, N, K, tol, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=150) for _ in range(world)], key=lambda g: g[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    lg, gg, dense, node, init = _gmm_problem(T, N, K, 3)
+    (ls, gs), (ds, ns), _, kl, iters = gmm_numpy.local_meanfield(lg, gg, node, init, tol)
+    alone = [gmm_numpy.meanfield_fixed_point(lg, gg, dense[g[1]:g[2]], init[g[1]:g[2]], tol, return_iters=True)[1]
+             for g in got]
+    assert any(a != iters for a in alone), "pick a problem whose shards stop at different sweeps on their own"
+    for g in got:
+        assert g[3] == iters
+        np.testing.assert_allclose(g[4], ls[g[1]:g[2]], rtol=1e-10, atol=1e-13)
+        assert np.array_equal(g[4].argmax(1), ls[g[1]:g[2]].argmax(1))
+        np.testing.assert_allclose(g[5], ds, rtol=1e-11)
+        np.testing.assert_allclose(g[6], ns, rtol=1e-10, atol=1e-10)
+        assert g[7] == pytest.approx(kl, rel=1e-10)
+
+
+def test_sweep_protocol_single_process_matches_the_fixed_point():
+    """run_sweeps without a process group = the plain fixed point (iteration count and responsibilities)."""
+    from oracle import gmm_numpy
+    from svae_amd.models.gmm import run_sweeps
+    for T, N, K, mi in ((150, 2, 4, 100), (40, 3, 3, 2), (10, 1, 2, 0)):
+        lg, gg, dense, node, init = _gmm_problem(T, N, K, T)
+        be = _NumpySweeps(lg, gg, dense, init, 1e-3, mi)
+        run_sweeps(be, mi)
+        (ls, _), (ds, ns), _, kl, iters = gmm_numpy.local_meanfield(lg, gg, node, init, 1e-3, mi)
+        assert be.iters == iters
+        np.testing.assert_allclose(be.r, ls, rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(be.niw_stats, ns, rtol=1e-12, atol=1e-12)
+        assert be.kl == pytest.approx(kl, rel=1e-12)

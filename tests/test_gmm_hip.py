@@ -44,9 +44,10 @@ def test_global_maps_match_golden(golden_dir):
         np.testing.assert_allclose(_np(x), g["mniw_es%d" % i], rtol=1e-10, atol=1e-12)
 
 
+@pytest.mark.parametrize("multi_wg", [False, True])
 @pytest.mark.parametrize("T,N,K", [(1000, 2, 5), (500, 2, 15), (3000, 2, 8), (257, 4, 6),
                                    (64, 8, 3), (1, 2, 5), (7, 1, 1)])
-def test_against_oracle(T, N, K):
+def test_against_oracle(T, N, K, multi_wg):
     """BASELINE configs[0] (K=5, 2-D, 1k points), the shipped script's shape (K=15, 500 points), more
     points than lanes (3000 > 1024), and the corners N=1..8, T=1, K=1."""
     from svae_amd.models.gmm import meanfield_from_globals
@@ -61,7 +62,7 @@ def test_against_oracle(T, N, K):
     node = rand_node_potentials((T, N), rng)
     init = rng.random((T, K))
     init /= init.sum(-1, keepdims=True)
-    o = meanfield_from_globals(lg, gg, node, init)
+    o = meanfield_from_globals(lg, gg, node, init, multi_wg=multi_wg)
     (ls, gs), (ds, ns), (ln, gn), kl, iters = gmm_numpy.local_meanfield(lg, gg, node, init)
     assert int(o["iters"].item()) == iters
     assert np.array_equal(_np(o["assign"]), ls.argmax(1))
@@ -72,6 +73,31 @@ def test_against_oracle(T, N, K):
     np.testing.assert_allclose(_np(o["dirichlet_stats"]), ds, rtol=1e-10)
     np.testing.assert_allclose(_np(o["gaussian_natparam"]), gn, rtol=1e-10, atol=1e-12)
     assert float(o["kl"].item()) == pytest.approx(kl, rel=1e-9)
+
+
+@pytest.mark.parametrize("T,N,K", [(20000, 2, 15), (300000, 2, 5), (5000, 3, 7)])
+def test_multi_workgroup_sweeps_match_the_single_workgroup_kernel(T, N, K):
+    """Large minibatches: the multi-workgroup sweeps (one launch per sweep, fixed-order KL reduction, device-side
+    stop) against the single-workgroup kernel on the same inputs -- same iteration count, identical labels,
+    reals to rounding -- and the oracle's responsibilities on a slice."""
+    from svae_amd.models.gmm import meanfield_from_globals
+    from svae_amd.lds.synthetic_data import rand_node_potentials
+    rng = np.random.default_rng(T % 1000 + N + K)
+    niw = np.stack([ef.niw_standard_to_natural((N + 10.) * np.eye(N), 2 * rng.standard_normal(N), np.array(10.),
+                                               np.array(N + 10.)) for _ in range(K)])
+    lg, gg = ef.dirichlet_expectedstats(rng.random(K) + 0.5), ef.niw_expectedstats(niw)
+    node = rand_node_potentials((T, N), rng)
+    init = rng.random((T, K)); init /= init.sum(-1, keepdims=True)
+    a = meanfield_from_globals(lg, gg, node, init, multi_wg=False)
+    b = meanfield_from_globals(lg, gg, node, init, multi_wg=True)
+    c = meanfield_from_globals(lg, gg, node, init)                   # default dispatch: multi-workgroup here
+    assert int(a["iters"].item()) == int(b["iters"].item()) == int(c["iters"].item())
+    assert torch.equal(a["assign"], b["assign"])
+    for k in ("label_stats", "label_fixed", "gaussian_stats", "label_natparam", "gaussian_natparam"):
+        assert torch.equal(a[k], b[k]), k                            # per-point arithmetic is the same code
+    for k in ("dirichlet_stats", "niw_stats", "kl"):
+        np.testing.assert_allclose(_np(b[k]), _np(a[k]), rtol=1e-11, atol=1e-9, err_msg=k)
+        assert torch.equal(b[k], c[k])                               # run to run bit-reproducible
 
 
 def test_max_iter_and_determinism():
@@ -87,6 +113,11 @@ def test_max_iter_and_determinism():
     a = meanfield_from_globals(lg, gg, node, init, max_iter=3)
     b = meanfield_from_globals(lg, gg, node, init, max_iter=3)
     assert int(a["iters"].item()) == 3
+    for mi in (0, 1, 3):
+        x = meanfield_from_globals(lg, gg, node, init, max_iter=mi, multi_wg=False)
+        y = meanfield_from_globals(lg, gg, node, init, max_iter=mi, multi_wg=True)
+        assert int(x["iters"].item()) == int(y["iters"].item())
+        assert torch.equal(x["label_stats"], y["label_stats"]) and torch.equal(x["label_fixed"], y["label_fixed"])
     for k in ("label_stats", "niw_stats", "kl"):
         assert torch.equal(a[k], b[k])                      # bit-reproducible run to run
     ls, it = gmm_numpy.meanfield_fixed_point(lg, gg, ef.pack_dense(*node), init, max_iter=3,
