@@ -76,7 +76,7 @@ __device__ __forceinline__ void rows_lane_bcast(double (&out)[MO], const double 
 // pivot is broadcast, and v_rcp_f64 + the two Newton steps are issued as asm statements BETWEEN the
 // remaining row updates.
 #ifndef SVAE_GJ_ONE_PLUS
-#define SVAE_GJ_ONE_PLUS 1   // 0: exact two-instruction form (lane clear + FMA), for A/B comparisons
+#define SVAE_GJ_ONE_PLUS 0   // 0: exact two-instruction form (lane clear + FMA); 1: the one-FMA shortcut (A/B only)
 #endif
 template <int N, bool CHOL, class StoreR>
 __device__ __forceinline__ void gauss_jordan(double (&P)[N], double (&X)[N], const double (&E)[N],
