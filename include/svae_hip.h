@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SVAE_HIP_ABI_VERSION 4   /* 4: + svae_slds_lds_meanfield_f64, svae_gmm_mw_*; 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
+#define SVAE_HIP_ABI_VERSION 4   /* 4: + svae_slds_lds_meanfield_f64, svae_gmm_mw_*, svae_lds_global_step_f64, svae_lds_natgrad_f64; 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
 #define SVAE_LDS_MAX_N 15   /* register/DPP path: one 16-lane row per sequence, n+1 <= 16 */
 #define SVAE_LDS_TILE_MAX_N 64   /* 16 <= n <= 64: LDS-tiled MFMA path (E-step only: keep must be 0) */
 
@@ -139,6 +139,33 @@ int svae_slds_lds_meanfield_f64(int B, int rows, int T, int n, int K,
                                 double* lognorm, double* E_init, double* E_node_diagxx, double* E_node_x,
                                 double* pair_contr, int32_t* info,
                                 void* workspace, size_t ws_bytes, void* stream);
+
+/* The once-per-step GLOBAL side of the LDS-SVAE in one launch ("global->local maps
+ * on device"): niw.expectedstats (/root/reference/svae/distributions/niw.py:15-25) and mniw.expectedstats
+ * (/root/reference/svae/distributions/mniw.py:19-20, 33-55) of the global factors -> the LDS init and pair
+ * potentials (svae/models/lds.py:23-25), and the prior KL of svae/models/lds.py:16-20 (with niw.logZ niw.py:27-31
+ * and mniw.logZ mniw.py:13-17) against `prior_*` (all five NULL: no KL).
+ *  in : niw (n+2,n+2) dense-packed NIW natural parameter; mniw_A, mniw_B, mniw_C (n,n), mniw_d (1)
+ *  out: init_J (n,n) = -1/2 E[J], init_h (n) = E[h], init_logZ (1) = -1/2 E[h'J^-1 h] + 1/2 E[log|J|];
+ *       J11, J12, J22 (n,n), logZ_pair (1) = the MNIW expected statistics;
+ *       niw_expectedstats (n+2,n+2) dense-packed or NULL; global_kl (1) or NULL;
+ *       info: 1 if an inversion met a non-positive pivot (natural parameters outside the domain).   n <= 64. */
+int svae_lds_global_step_f64(int n, const double* niw, const double* mniw_A, const double* mniw_B,
+                             const double* mniw_C, const double* mniw_d,
+                             const double* prior_niw, const double* prior_A, const double* prior_B,
+                             const double* prior_C, const double* prior_d,
+                             double* init_J, double* init_h, double* init_logZ,
+                             double* J11, double* J12, double* J22, double* logZ_pair,
+                             double* niw_expectedstats, double* global_kl, int32_t* info, void* stream);
+
+/* Natural-gradient expression of /root/reference/svae/svae.py:33-34 for the LDS global parameter, straight from
+ * the (all-reduced) buffer of svae_lds_reduce_stats_f64:
+ *   natgrad = -scale * (prior + num_batches * stats - params)
+ * over the flat parameter [NIW dense (n+2)^2 | A (n^2) | B (n^2) | C (n^2) | d (1)], where stats =
+ * (pack_dense(sum E[x0 x0'], sum E[x0], count, count), (E_pair sums, count (T-1))).  One launch. */
+int svae_lds_natgrad_f64(int n, int T, const double* packed_stats, const double* prior_flat,
+                         const double* params_flat, double num_batches, double scale,
+                         double* natgrad_flat, void* stream);
 
 /* Deterministic sum over the batch of the per-sequence global statistics (the quantity that is
  * all-reduced across GPUs for the natural-gradient step, svae.py:33-34):

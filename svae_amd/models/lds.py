@@ -18,6 +18,7 @@ torch.distributed, all-reduced across ranks by `svae_amd.parallel.allreduce_glob
 """
 import torch
 
+from .. import _lib
 from ..distributions import expfam
 from ..lds.lds_inference import LDSEStepPlan, natural_lds_estep_general, reduce_stats
 from ..parallel import allreduce_lds_stats
@@ -62,14 +63,91 @@ def local_natparam_from_global(global_natparam):
     return (init_params, es[1]), es
 
 
+GLOBAL_STEP_MAX_N = 64
+
+
+def global_step(global_natparam, prior_natparam=None):
+    """The once-per-step global side in ONE kernel launch (svae_lds_global_step_f64): the LDS potentials from
+    the global factors (lds.py:23-25 = niw.expectedstats niw.py:15-25 + mniw.expectedstats mniw.py:33-55) and,
+    if `prior_natparam` is given, the prior KL of lds.py:16-20.  Inputs are device tensors
+    (NIW dense (n+2,n+2), (A, B, C, d)).  Returns ((init_params, pair_params), global_kl | None, niw_expectedstats)
+    with init_params = (-1/2 E[J], E[h], logZ) and pair_params = (J11, J12, J22, logZ) as the E-step takes them.
+    Same values as local_natparam_from_global / lds_prior_kl (the torch path, ~150 small launches)."""
+    niw, (A, B, C, d) = global_natparam
+    dev = niw.device
+    n = niw.shape[-1] - 2
+    if not (1 <= n <= GLOBAL_STEP_MAX_N):
+        raise ValueError("global_step: latent dimension %d outside 1..%d" % (n, GLOBAL_STEP_MAX_N))
+    f64 = dict(dtype=torch.float64, device=dev)
+    c = lambda x: torch.as_tensor(x, **f64).contiguous()
+    niw, A, B, C, d = c(niw), c(A), c(B), c(C), c(d).reshape(1)
+    pr = [None] * 5
+    if prior_natparam is not None:
+        pn, (pA, pB, pC, pd) = prior_natparam
+        pr = [c(pn), c(pA), c(pB), c(pC), c(pd).reshape(1)]
+    out = torch.empty(4 * n * n + n + 3 + (n + 2) * (n + 2), **f64)      # one allocation for every output
+    o = [0]
+
+    def take(k, shape):
+        v = out[o[0]:o[0] + k].view(shape)
+        o[0] += k
+        return v
+    init_J, init_h, init_logZ = take(n * n, (n, n)), take(n, (n,)), take(1, (1,))
+    J11, J12, J22, lz = take(n * n, (n, n)), take(n * n, (n, n)), take(n * n, (n, n)), take(1, (1,))
+    kl, es = take(1, (1,)), take((n + 2) * (n + 2), (n + 2, n + 2))
+    info = torch.zeros(1, dtype=torch.int32, device=dev)
+    p = _lib.ptr
+    rc = _lib.load().svae_lds_global_step_f64(
+        n, p(niw), p(A), p(B), p(C), p(d), p(pr[0]), p(pr[1]), p(pr[2]), p(pr[3]), p(pr[4]),
+        p(init_J), p(init_h), p(init_logZ), p(J11), p(J12), p(J22), p(lz), p(es),
+        p(kl) if prior_natparam is not None else None, p(info), _lib.current_stream(dev))
+    _lib.check(rc, "svae_lds_global_step_f64")
+    return ((init_J, init_h, init_logZ), (J11, J12, J22, lz)), (kl[0] if prior_natparam is not None else None), es
+
+
+class PackedLDSStats(tuple):
+    """(niw_stats, mniw_stats) as the reference returns them, carrying the packed all-reduced buffer of
+    svae_lds_reduce_stats_f64 they were unpacked from (`.packed`, `.T`): the natural-gradient kernel reads it."""
+    packed = None
+    T = None
+
+
+def natural_gradient(prior_natparam, global_natparam, stats, num_batches, scale):
+    """svae.py:33-34 for the LDS global parameter in one launch (svae_lds_natgrad_f64):
+    -scale * (prior + num_batches * stats - params), nested like the parameters.  `stats` must be the
+    PackedLDSStats run_inference returns."""
+    dev = stats.packed.device
+    flatten = lambda q: torch.cat([torch.as_tensor(x, dtype=torch.float64, device=dev).reshape(-1)
+                                   for x in (q[0],) + tuple(q[1])])
+    prior, params = flatten(prior_natparam), flatten(global_natparam)
+    n = stats[0].shape[-1] - 2
+    out = torch.empty_like(params)
+    p = _lib.ptr
+    rc = _lib.load().svae_lds_natgrad_f64(n, int(stats.T), p(stats.packed), p(prior), p(params), float(num_batches),
+                                          float(scale), p(out), _lib.current_stream(dev))
+    _lib.check(rc, "svae_lds_natgrad_f64")
+    D2, nn = (n + 2) * (n + 2), n * n
+    return out[:D2].view(n + 2, n + 2), (out[D2:D2 + nn].view(n, n), out[D2 + nn:D2 + 2 * nn].view(n, n),
+                                          out[D2 + 2 * nn:D2 + 3 * nn].view(n, n), out[D2 + 3 * nn])
+
+
+def _globals_on_device(prior_natparam, global_natparam, dev):
+    """(local_natparam, global_kl) through the global-step kernel (n <= 64), else the torch maps."""
+    g = (_dev64(global_natparam[0], dev), tuple(_dev64(x, dev) for x in global_natparam[1]))
+    p = (_dev64(prior_natparam[0], dev), tuple(_dev64(x, dev) for x in prior_natparam[1]))
+    if g[0].shape[-1] - 2 <= GLOBAL_STEP_MAX_N:
+        local_natparam, global_kl, _ = global_step(g, p)
+        return local_natparam, global_kl
+    local_natparam, global_es = local_natparam_from_global(g)
+    return local_natparam, lds_prior_kl(g, p, global_es)
+
+
 def run_inference(prior_natparam, global_natparam, nn_potentials, num_samples, eps=None,
                   plan=None, generator=None, group=None):
     """lds.py:35-52.  Returns (samples, global_expected_stats, global_kl, local_kl); with B sequences,
     samples is (B,T,S,n) and the statistics / local_kl are sums over the (global) batch."""
     dev = torch.device("cuda", torch.cuda.current_device())
-    g = (_dev64(global_natparam[0], dev), tuple(_dev64(x, dev) for x in global_natparam[1]))
-    p = (_dev64(prior_natparam[0], dev), tuple(_dev64(x, dev) for x in prior_natparam[1]))
-    local_natparam, global_es = local_natparam_from_global(g)
+    local_natparam, global_kl = _globals_on_device(prior_natparam, global_natparam, dev)
     node = tuple(_dev64(x, dev) for x in nn_potentials)
     batched = node[1].dim() == 3
     nodeb = node if batched else tuple(x[None] for x in node)
@@ -89,11 +167,19 @@ def run_inference(prior_natparam, global_natparam, nn_potentials, num_samples, e
     if len(nodeb) == 3:
         local_kl = local_kl + nodeb[2].sum()
     # global statistics: deterministic device reduction, then the one collective (statistics + local KL)
-    niw_stats, mniw_stats, local_kl = allreduce_lds_stats(plan.reduce(), local_kl, n, T, group)
-    global_kl = lds_prior_kl(g, p, global_es)
+    stats, local_kl = _exchange(plan, local_kl, n, T, group)
     if not batched:
         samples = samples[0]
-    return samples, (niw_stats, mniw_stats), global_kl, local_kl
+    return samples, stats, global_kl, local_kl
+
+
+def _exchange(plan, local_kl, n, T, group):
+    """Batch reduction on the device, the ONE collective, and the statistics as the reference nests them
+    (carrying the packed buffer for natural_gradient)."""
+    niw_stats, mniw_stats, local_kl, packed = allreduce_lds_stats(plan.reduce(), local_kl, n, T, group, return_packed=True)
+    stats = PackedLDSStats((niw_stats, mniw_stats))
+    stats.packed, stats.T = packed, T
+    return stats, local_kl
 
 
 def run_inference_differentiable(prior_natparam, global_natparam, nn_potentials, num_samples,
@@ -103,9 +189,7 @@ def run_inference_differentiable(prior_natparam, global_natparam, nn_potentials,
     these two, svae.py:21-24; the statistics go to `saved.stats` undifferentiated)."""
     from ..lds.lds_inference import lds_inference_differentiable
     dev = nn_potentials[1].device
-    g = (_dev64(global_natparam[0], dev), tuple(_dev64(x, dev) for x in global_natparam[1]))
-    p = (_dev64(prior_natparam[0], dev), tuple(_dev64(x, dev) for x in prior_natparam[1]))
-    local_natparam, global_es = local_natparam_from_global(g)
+    local_natparam, global_kl = _globals_on_device(prior_natparam, global_natparam, dev)
     node = tuple(x.to(torch.float64) for x in nn_potentials)
     batched = node[1].dim() == 3
     nodeb = node if batched else tuple(x[None] for x in node)
@@ -124,11 +208,10 @@ def run_inference_differentiable(prior_natparam, global_natparam, nn_potentials,
         local_kl = local_kl + nodeb[2].sum()
     # one collective for statistics AND the local KL (as run_inference): the returned local_kl has the
     # global value and this rank's gradient
-    niw_stats, mniw_stats, local_kl = allreduce_lds_stats(plan.reduce(), local_kl, n, T, group)
-    global_kl = lds_prior_kl(g, p, global_es)
+    stats, local_kl = _exchange(plan, local_kl, n, T, group)
     if not batched:
         samples = samples[0]
-    return samples, (niw_stats, mniw_stats), global_kl, local_kl
+    return samples, stats, global_kl, local_kl
 
 
 def make_prior_natparam(n, random=False, scaling=1., dtype=torch.float64, device="cpu"):

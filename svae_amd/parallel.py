@@ -29,7 +29,7 @@ def shard_bounds(num_items, rank=None, world=None):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def allreduce_lds_stats(reduced, local_kl, n, T, group=None):
+def allreduce_lds_stats(reduced, local_kl, n, T, group=None, return_packed=False):
     """The exchange step of the LDS model (svae/models/lds.py:35-52 with B sequences per rank).
 
     `reduced` is this rank's buffer from svae_lds_reduce_stats_f64, [sum E_init (n^2+n) | sum E_pair (3n^2)
@@ -48,4 +48,5 @@ def allreduce_lds_stats(reduced, local_kl, n, T, group=None):
     niw_stats = expfam.pack_dense(packed[:nn_].reshape(n, n), packed[nn_:o], cnt, cnt)
     mniw_stats = (packed[o:o + nn_].reshape(n, n), packed[o + nn_:o + 2 * nn_].reshape(n, n),
                   packed[o + 2 * nn_:o + 3 * nn_].reshape(n, n), cnt * (T - 1))
-    return niw_stats, mniw_stats, local_kl + (packed[-2] - local_kl.detach())
+    kl = local_kl + (packed[-2] - local_kl.detach())
+    return (niw_stats, mniw_stats, kl, packed) if return_packed else (niw_stats, mniw_stats, kl)

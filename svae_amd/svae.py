@@ -91,10 +91,16 @@ def make_gradfun(run_inference, recognize, loglike, pgm_prior, data, batch_size,
         loglike_grad = unflat_like(torch.cat([g.reshape(-1) for g in grads[:nl]]) if nl else torch.zeros(0), loglike_params)
         recogn_grad = unflat_like(torch.cat([g.reshape(-1) for g in grads[nl:]]), recogn_params)
         # this expression drops the same term the reference's does (svae.py:31-32)
-        dev = flat(saved.stats).device
-        pgm_natgrad = -natgrad_scale / num_datapoints * \
-            (flat(pgm_prior).to(dev) + num_batches * flat(saved.stats) - flat(pgm_params).to(dev))
-        grad = unflat_like(pgm_natgrad, pgm_prior), loglike_grad, recogn_grad
+        if getattr(saved.stats, "packed", None) is not None:
+            # LDS model: one launch on the packed, all-reduced statistics buffer (svae_lds_natgrad_f64)
+            from .models.lds import natural_gradient
+            pgm_grad = natural_gradient(pgm_prior, pgm_params, saved.stats, num_batches, natgrad_scale / num_datapoints)
+        else:
+            dev = flat(saved.stats).device
+            pgm_natgrad = -natgrad_scale / num_datapoints * \
+                (flat(pgm_prior).to(dev) + num_batches * flat(saved.stats) - flat(pgm_params).to(dev))
+            pgm_grad = unflat_like(pgm_natgrad, pgm_prior)
+        grad = pgm_grad, loglike_grad, recogn_grad
         if callback:
             callback(i, float(val.detach()), params, grad)
         return grad

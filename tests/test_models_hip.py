@@ -88,3 +88,62 @@ def test_lds_run_inference_unbatched_shapes():
     samples, (niw_stats, mniw_stats), global_kl, local_kl = run_inference(prior, glob, node, 3)
     assert tuple(samples.shape) == (T, 3, n) and tuple(niw_stats.shape) == (n + 2, n + 2)
     assert float(niw_stats[n, n]) == 1.0 and float(mniw_stats[3]) == T - 1
+
+
+def _rand_lds_global(n, rng, dev):
+    """A valid (NIW dense, MNIW 4-tuple) natural parameter, not the symmetric textbook one."""
+    from svae_amd.distributions import expfam
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev)
+    R = rng.standard_normal((n, n)) / np.sqrt(n)
+    S = (n + 2.) * np.eye(n) + R @ R.T
+    niw = expfam.niw_standard_to_natural(t(S), t(0.3 * rng.standard_normal(n)), t(0.7 + rng.random()), t(n + 1.5 + rng.random()))
+    R2 = rng.standard_normal((n, n)) / np.sqrt(n)
+    S2 = (n + 1.) * np.eye(n) + R2 @ R2.T
+    R3 = rng.standard_normal((n, n)) / np.sqrt(n)
+    K = 0.5 * np.eye(n) + 0.1 * R3 @ R3.T
+    M = 0.9 * np.eye(n) + 0.1 * rng.standard_normal((n, n))
+    mniw = expfam.mniw_standard_to_natural(t(n + 2.5 + rng.random()), t(S2), t(M), t(K))
+    return niw, mniw
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 10, 16, 33, 64])
+def test_global_step_kernel_matches_the_exponential_family_maps(n):
+    """svae_lds_global_step_f64 (one launch) against the torch restatements of niw / mniw expectedstats and logZ
+    (svae_amd/distributions/expfam.py, themselves pinned to the reference's Python through tests/golden/expfam.npz)."""
+    from svae_amd.models import lds as lds_model
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(n)
+    g, p = _rand_lds_global(n, rng, dev), _rand_lds_global(n, rng, dev)
+    (init, pair), kl, es = lds_model.global_step(g, p)
+    (want_init, want_pair), want_es = lds_model.local_natparam_from_global(g)
+    want_kl = lds_model.lds_prior_kl(g, p, want_es)
+    tol = dict(rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(_np(init[0]), _np(want_init[0]), **tol)
+    np.testing.assert_allclose(_np(init[1]), _np(want_init[1]), **tol)
+    np.testing.assert_allclose(float(init[2]), float(want_init[2] + want_init[3]), rtol=1e-10)
+    for got, want in zip(pair[:3], want_pair[:3]):
+        np.testing.assert_allclose(_np(got), _np(want), **tol)
+    np.testing.assert_allclose(float(pair[3]), float(want_pair[3]), rtol=1e-10)
+    np.testing.assert_allclose(_np(es), _np(want_es[0]), **tol)
+    assert float(kl) == pytest.approx(float(want_kl), rel=1e-8, abs=1e-8)
+    # without a prior: potentials only
+    (init2, pair2), kl2, _ = lds_model.global_step(g)
+    assert kl2 is None and torch.equal(init2[0], init[0]) and torch.equal(pair2[1], pair[1])
+
+
+def test_natural_gradient_kernel_matches_the_flat_expression():
+    """svae_lds_natgrad_f64 against make_gradfun's generic expression (svae.py:33-34) on the same statistics."""
+    from svae_amd import svae as svae_mod
+    from svae_amd.models import lds as lds_model
+    from svae_amd.lds.synthetic_data import rand_node_potentials
+    dev = torch.device("cuda:0")
+    n, T, B = 6, 9, 5
+    rng = np.random.default_rng(0)
+    prior, glob = _rand_lds_global(n, rng, dev), _rand_lds_global(n, rng, dev)
+    node = tuple(torch.as_tensor(x, device=dev) for x in rand_node_potentials((B, T, n), rng))
+    _, stats, _, _ = lds_model.run_inference(prior, glob, node, 1)
+    assert stats.packed is not None and stats.T == T
+    nb, scale = 7.0, 0.125
+    got = lds_model.natural_gradient(prior, glob, stats, nb, scale)
+    want = -scale * (svae_mod.flat(prior) + nb * svae_mod.flat(tuple(stats)) - svae_mod.flat(glob))
+    np.testing.assert_allclose(_np(svae_mod.flat(got)), _np(want), rtol=1e-13, atol=1e-13)

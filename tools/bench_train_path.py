@@ -32,6 +32,30 @@ def main():
     print("B=%d T=%d n=%d S=%d: E-step %.3f ms | E-step keeping factor+cross %.3f | sampler %.3f | VJP %.3f  "
           "=> training path %.3f ms (%.0f seq/s)   [VJP without sample cotangents: %.3f ms]"
           % (B, T, n, S, ms[0], ms[1], ms[2], ms[3], sum(ms[1:4]), B / sum(ms[1:4]) * 1e3, ms[4]))
+    # the same path through the model layer (models.lds.run_inference_differentiable + backward): host wall
+    # clock per iteration vs the kernels' sum above = launch / allocation / glue overhead
+    import time
+    from svae_amd.models import lds as lds_model
+    prior = lds_model.make_prior_natparam(n, device=dev)
+    glob = lds_model.make_prior_natparam(n, device=dev)
+    nodeJ, nodeh = args[7].clone().requires_grad_(True), args[8].clone().requires_grad_(True)
+    mplan = LDSEStepPlan(B, T, n, dev)
+
+    def it():
+        samples, stats, gkl, lkl = lds_model.run_inference_differentiable(prior, glob, (nodeJ, nodeh), S, eps=eps, plan=mplan)
+        loss = (samples * g[3]).sum() + lkl
+        gJ, gh = torch.autograd.grad(loss, [nodeJ, nodeh])
+        return gJ
+    for _ in range(3):
+        it()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 10
+    for _ in range(reps):
+        it()
+    torch.cuda.synchronize()
+    print("  model layer (run_inference_differentiable + autograd backward): %.3f ms per iteration (host wall clock)"
+          % ((time.perf_counter() - t0) / reps * 1e3))
 
 
 if __name__ == "__main__":
