@@ -180,12 +180,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    dev = torch.device("cuda", local_rank)
+    # (modulo: a rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks, see SVAE_BENCH_BACKEND)
+    dev = torch.device("cuda", local_rank % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL ("nccl") is the product path.  SVAE_BENCH_BACKEND=gloo only exists to rehearse the multi-rank
+        # control flow (barriers, max-over-ranks timing, the packed all-reduce) on ONE GPU shared by the ranks,
+        # where RCCL refuses duplicate devices; such a run is not a scaling measurement.
+        backend = os.environ.get("SVAE_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from svae_amd import _lib
     lib = _lib.load()
@@ -210,8 +218,8 @@ def main():
                                    "(%s)" % (n, T, B, "BASELINE configs[1]; x8 GPUs = configs[2]" if n == 10
                                                   else "BASELINE configs[4] shape; batch chosen here"),
                        "sequences_per_gpu": B, "T": T, "n": n, "global_sequences": B * world,
-                       "parallelism": "dp%d" % world,
-                       "step": "estep kernel + batch stat reduce" + (" + RCCL all-reduce" if world > 1 else "")},
+                       "parallelism": "dp%d" % world, "collective_backend": (dist.get_backend() if world > 1 else None),
+                       "step": "estep kernel + batch stat reduce" + (" + %s all-reduce" % ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend()) if world > 1 else "")},
             "roofline": roofline(lib, T, n, B, kern_ms),
         }
         if world == 1 and not args.no_extra and args.workload == "lds10" and args.seqs_per_gpu is None:
