@@ -11,9 +11,11 @@ launch-bound, a few hundred ms at T = 1000), so that BASELINE configs[4] can tak
     noise map is chol(P_t)^-T eps_t; chol(P)^-T is the unique upper-triangular M with P^-1 = M M', i.e.
     the Cholesky factor of the index-reversed P^-1, index-reversed -- computed for all (sequence, step)
     at once; only the recursion x_t = c_t + G_t x_{t+1} + noise_t is serial.
-  * VJP: backward() re-runs the forward recursion (information-form filter by Cholesky, moment-form
-    smoother, sampler: the same algebra as the kernels) in torch with autograd enabled and differentiates
-    it; the VALUES the model uses always come from the HIP kernel.
+  * VJP: `vjp_from_handoff` -- the adjoint of the kernels' recursion written out by hand on the tile kernel's
+    hand-off (three passes over time of batched matrix products; the Cholesky adjoint of the noise factor
+    batched over all (sequence, step) pairs), checked against autograd through `torch_estep` (the torch
+    restatement of the recursion, which remains the fallback for per-step pair-statistic cotangents and was
+    50x slower: 4.6 s at B = 64, T = 1000, n = 64).
 
 Everything here is float64 on the GPU; there is no CPU path.
 """
@@ -71,7 +73,7 @@ def _pair_at(M, t):
     return M[:, t]
 
 
-def torch_estep(params, node_J, node_h, eps=None, per_step_stats=False):
+def torch_estep(params, node_J, node_h, eps=None, per_step_stats=False, return_handoff=False):
     """Differentiable restatement of the E-step (+ sampler) on batched torch tensors: the algebra of the
     kernels (filter: P = J_pred + J11 + diag(J_node), Schur complement; smoother in moment form;
     sampler x_t = c_t + G_t x_{t+1} + chol(P_t)^-T eps_t).  Returns (lognorm (B), E_node_diagxx, E_node_x
@@ -153,7 +155,121 @@ def torch_estep(params, node_J, node_h, eps=None, per_step_stats=False):
                 x = x + torch.matmul(out[t + 1], Gs[t].transpose(-1, -2))
             out[t] = x
         samples = torch.stack(out, 1)
+    if return_handoff:      # (G (B,T,n,n) with G_{T-1} = 0, Pinv (B,T,n,n), c (B,T,n)) as the tile kernel hands them off
+        Gall = torch.stack(Gs + [torch.zeros_like(Pis[0])], 1)
+        return (lognorm, dxx, Exs, samples, E_init, E_pair), (Gall, torch.stack(Pis, 1), torch.stack(cs, 1))
     return lognorm, dxx, Exs, samples, E_init, E_pair
+
+
+def _upper_factor(Pinv):
+    """Upper-triangular M with Pinv = M M' (= chol(P)^-T: the reference's noise map), batched: the Cholesky
+    factor of the index-reversed matrix, index-reversed."""
+    return torch.linalg.cholesky(Pinv.flip(-1, -2)).flip(-1, -2)
+
+
+def _upper_factor_adjoint(M, Mbar):
+    """Cotangent of Pinv under Pinv -> M (upper, Pinv = M M'), given Mbar (upper): the Cholesky adjoint
+    A_bar = sym(L^-T Phi(L' L_bar) L^-1) (Phi: lower triangle, diagonal halved) on the index-reversed problem."""
+    L, Lbar = M.flip(-1, -2), Mbar.flip(-1, -2)
+    K = torch.matmul(L.transpose(-1, -2), Lbar)
+    Phi = torch.tril(K)
+    Phi = Phi - 0.5 * torch.diag_embed(torch.diagonal(Phi, dim1=-1, dim2=-2))
+    Q = torch.linalg.solve_triangular(L.transpose(-1, -2), Phi, upper=True)              # L^-T Phi
+    Q = torch.linalg.solve_triangular(L.transpose(-1, -2), Q.transpose(-1, -2), upper=True).transpose(-1, -2)   # (...) L^-1
+    return (0.5 * (Q + Q.transpose(-1, -2))).flip(-1, -2)
+
+
+def vjp_from_handoff(G, Pinv, c, m, J12, g_lognorm, g_dxx, g_x, samples=None, eps=None, g_samples=None,
+                     g_E_init=None, chunk_bytes=4 << 30):
+    """Reverse-mode derivative of the E-step (+ sampler) w.r.t. the node potentials from the forward pass's own
+    quantities -- the adjoint of the recursion the kernels run, written out by hand as batched matrix products
+    (what natural_filter_grad / natural_smoother_general_grad / natural_sample_backward_grad compute,
+    cython_lds_inference.pyx:92-145, 236-306, 357-409):
+      G (B,T,n,n) = -P_t^-1 J12 (info form), Pinv (B,T,n,n) = P_t^-1, c (B,T,n) = P_t^-1 h_filt  -- the hand-off;
+      m (B,T,n) = E[x_t]; J12: natural pair parameter (n,n) | (T-1,n,n) | (B,T-1,n,n);
+      cotangents g_lognorm (B), g_dxx / g_x (B,T,n) of diag E[x x'] / E[x], g_samples (B,T,S,n) of the samples
+      drawn with eps (B,T,S,n), g_E_init (B, n*n+n) of (E[x_0 x_0'], E[x_0]).
+    Three passes over time: (0) smoothed covariances Sigma_t (backward in time, stored); (1) adjoint of the
+    smoother / sampler recursions (forward in time): Sigma_bar, m_bar, x_bar -> per-step cotangents of G_t,
+    c_t, P_t^-1; the cotangent through the noise factor chol(P_t)^-T is a Cholesky adjoint batched over ALL
+    (sequence, step) pairs at once; (2) adjoint of the filter (backward in time).  -> (g_node_J, g_node_h)."""
+    B, T, n = c.shape
+    f64 = dict(dtype=c.dtype, device=c.device)
+    zeros = lambda *shape: torch.zeros(*shape, **f64)
+    R_at = lambda t: -_pair_at(J12, t)                      # info-form off-diagonal block of pair t
+    tr = lambda A: A.transpose(-1, -2)
+    mv = lambda A, v: torch.matmul(A, v.unsqueeze(-1))[..., 0]
+    has_s = g_samples is not None
+    g_dxx = zeros(B, T, n) if g_dxx is None else g_dxx
+    g_x = zeros(B, T, n) if g_x is None else g_x
+    # ---- pass 0: Sigma_t = Pinv_t + G_t Sigma_{t+1} G_t'
+    Sig = torch.empty(B, T, n, n, **f64)
+    Sig[:, T - 1] = Pinv[:, T - 1]
+    for t in range(T - 2, -1, -1):
+        S = Pinv[:, t] + torch.matmul(torch.matmul(G[:, t], Sig[:, t + 1]), tr(G[:, t]))
+        Sig[:, t] = 0.5 * (S + tr(S))
+    # ---- pass 1: adjoint of the smoother / sampler recursions
+    Sb, mb = zeros(B, n, n), zeros(B, n)
+    xb = zeros(B, samples.shape[2], n) if has_s else None
+    Pinv_bar = torch.empty(B, T, n, n, **f64)
+    c_bar = torch.empty(B, T, n, **f64)
+    G_bar = torch.empty(B, max(T - 1, 0), n, n, **f64)
+    xb_all = torch.empty(B, T, samples.shape[2], n, **f64) if has_s else None
+    for t in range(T):
+        Sb = Sb + torch.diag_embed(g_dxx[:, t])
+        mb = mb + g_x[:, t] + 2.0 * g_dxx[:, t] * m[:, t]
+        if t == 0 and g_E_init is not None:
+            gS = g_E_init[:, :n * n].reshape(B, n, n)
+            Sb = Sb + 0.5 * (gS + tr(gS))
+            mb = mb + g_E_init[:, n * n:] + mv(gS + tr(gS), m[:, 0])
+        Pinv_bar[:, t] = Sb
+        cb = mb
+        if has_s:
+            xb = xb + g_samples[:, t]
+            xb_all[:, t] = xb
+            cb = cb + xb.sum(1)
+        c_bar[:, t] = cb
+        if t < T - 1:
+            Gt = G[:, t]
+            SG = torch.matmul(Sb, Gt)
+            Gb = 2.0 * torch.matmul(SG, Sig[:, t + 1]) + mb.unsqueeze(-1) * m[:, t + 1].unsqueeze(-2)
+            if has_s:
+                Gb = Gb + torch.matmul(tr(xb), samples[:, t + 1])
+                xb = torch.matmul(xb, Gt)
+            G_bar[:, t] = Gb
+            Sb = torch.matmul(tr(Gt), SG)
+            Sb = 0.5 * (Sb + tr(Sb))
+            mb = mv(tr(Gt), mb)
+    del Sig
+    if has_s:
+        # noise_t = M_t eps_t, M_t = upper factor of Pinv_t: M_bar = triu(sum_s x_bar_s eps_s'), all (b,t) at once
+        per_seq = T * n * n * 8 * 6
+        step = max(1, int(chunk_bytes // per_seq))
+        for b0 in range(0, B, step):
+            sl = slice(b0, b0 + step)
+            M = _upper_factor(Pinv[sl])
+            Mbar = torch.triu(torch.matmul(tr(xb_all[sl]), eps[sl]))
+            Pinv_bar[sl] += _upper_factor_adjoint(M, Mbar)
+    # ---- pass 2: adjoint of the filter
+    gJ, gh = torch.empty(B, T, n, **f64), torch.empty(B, T, n, **f64)
+    Jb, hb = zeros(B, n, n), zeros(B, n)
+    gl = g_lognorm.reshape(B, 1, 1)
+    for t in range(T - 1, -1, -1):
+        Pi, ct, cb = Pinv[:, t], c[:, t], c_bar[:, t]
+        Pb = -torch.matmul(torch.matmul(Pi, Pinv_bar[:, t]), Pi)
+        if t < T - 1:
+            R = R_at(t)
+            Xb = -torch.matmul(R.expand(B, n, n), Jb) - G_bar[:, t]
+            cb = cb - mv(R.expand(B, n, n), hb)
+            Pb = Pb + torch.matmul(torch.matmul(Pi, Xb), tr(G[:, t]))
+        Pc = mv(Pi, cb)
+        Pb = Pb - Pc.unsqueeze(-1) * ct.unsqueeze(-2) - 0.5 * gl * (ct.unsqueeze(-1) * ct.unsqueeze(-2)) - 0.5 * gl * Pi
+        Pb = 0.5 * (Pb + tr(Pb))
+        hfb = Pc + g_lognorm.reshape(B, 1) * ct
+        gJ[:, t] = -2.0 * torch.diagonal(Pb, dim1=-1, dim2=-2)
+        gh[:, t] = hfb
+        Jb, hb = Pb, hfb
+    return gJ, gh
 
 
 class LDSInferenceLarge(torch.autograd.Function):
@@ -169,6 +285,9 @@ class LDSInferenceLarge(torch.autograd.Function):
         samples = sample_from_handoff(plan, eps) if eps is not None else \
             torch.zeros(0, dtype=torch.float64, device=plan.device)
         ctx.params, ctx.inhomog, ctx.has_logZ, ctx.has_eps = params, plan.inhomog, node_logZ is not None, eps is not None
+        ctx.plan, ctx.epoch = plan, plan.epoch
+        ctx.ex = plan.E_node_x.clone()
+        ctx.samples = samples if eps is not None else None
         ctx.save_for_backward(node_J, node_h, eps if eps is not None else samples)
         E_init, E_pair = plan.E_init.clone(), plan.E_pair.clone()
         if not plan.inhomog:
@@ -178,6 +297,23 @@ class LDSInferenceLarge(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_lognorm, g_dxx, g_x, g_samples, g_init, g_pair):
         node_J, node_h, eps = ctx.saved_tensors
+        B, T = node_h.shape[:2]
+        if g_pair is None or not ctx.inhomog:
+            # the adjoint of the kernels' recursion, from the hand-off of THIS forward pass (vjp_from_handoff)
+            plan = ctx.plan
+            if plan.epoch != ctx.epoch:
+                raise RuntimeError("LDSEStepPlan was launched again before backward(): the hand-off workspace of "
+                                   "this forward pass is gone (use one plan per live autograd graph)")
+            G, Pinv, c = handoff_views(plan)
+            zero = lambda g, like: torch.zeros_like(like) if g is None else g
+            gs = g_samples if (ctx.has_eps and g_samples is not None) else None
+            gJ, gh = vjp_from_handoff(G, Pinv, c, ctx.ex, ctx.params[4], zero(g_lognorm, plan.lognorm), g_dxx, g_x,
+                                      ctx.samples if gs is not None else None, eps if gs is not None else None, gs,
+                                      g_init if ctx.inhomog else None)
+            gz = g_lognorm[:, None].expand(B, T).clone() if (ctx.has_logZ and g_lognorm is not None) else None
+            return gJ, gh, gz, None, None, None, None
+        # per-step pair-statistic cotangents (per-step pair parameters at n > 15): autograd through the torch
+        # restatement of the recursion
         with torch.enable_grad():
             nJ = node_J.detach().requires_grad_(True)
             nh = node_h.detach().requires_grad_(True)
