@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SVAE_HIP_ABI_VERSION 4   /* 4: + svae_slds_lds_meanfield_f64, svae_gmm_mw_*, svae_lds_global_step_f64, svae_lds_natgrad_f64; 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
+#define SVAE_HIP_ABI_VERSION 4   /* 4: + svae_slds_lds_meanfield_f64, svae_gmm_mw_*, svae_lds_global_step_f64, svae_lds_natgrad_f64, svae_lds_tile_vjp_f64; 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
 #define SVAE_LDS_MAX_N 15   /* register/DPP path: one 16-lane row per sequence, n+1 <= 16 */
 #define SVAE_LDS_TILE_MAX_N 64   /* 16 <= n <= 64: LDS-tiled MFMA path (E-step only: keep must be 0) */
 
@@ -139,6 +139,26 @@ int svae_slds_lds_meanfield_f64(int B, int rows, int T, int n, int K,
                                 double* lognorm, double* E_init, double* E_node_diagxx, double* E_node_x,
                                 double* pair_contr, int32_t* info,
                                 void* workspace, size_t ws_bytes, void* stream);
+
+/* Reverse-mode derivative of the E-step (+ sampler) w.r.t. the node potentials for latent dimension 16 <= n <= 64,
+ * on the hand-off the LDS-tiled E-step kernel leaves in `handoff_workspace` (the workspace of the LAST
+ * svae_lds_estep_f64 call with this (B,T,n)): natural_filter_grad / natural_smoother_general_grad /
+ * natural_sample_backward_grad, /root/reference/svae/lds/cython_lds_inference.pyx:92-145, 236-306, 357-409,
+ * composed as /root/reference/svae/lds/lds_inference.py:26-39.  Three phases, one call each, in order:
+ *   0: smoothed covariances (backward in time); 1: adjoint of the smoother / sampler recursions (forward in
+ *   time); 2: adjoint of the filter (backward in time) -> g_node_J, g_node_h (B,T,n).
+ * Between phases 1 and 2 the caller adds the Cholesky adjoint of the sampler's noise factor -- batched over all
+ * (sequence, step) pairs, from `xbar` and eps -- into the `pinv_bar` section of `workspace`
+ * (layout [sig (B,T,n,n) | pinv_bar (B,T,n,n) | g_bar (B,T-1,n,n) | c_bar (B,T,n) | xbar (B,T,S,n)],
+ * svae_lds_tile_vjp_workspace_doubles); without sample cotangents (g_samples NULL) there is nothing to add.
+ * Cotangents: g_lognorm (B); g_E_node_diagxx, g_E_node_x (B,T,n) or NULL; g_E_init (B, n*n+n) or NULL;
+ * g_samples (B,T,S,n) or NULL with the samples drawn (S <= 16).  J12 as in svae_lds_estep_vjp_ex_f64. */
+size_t svae_lds_tile_vjp_workspace_doubles(int B, int T, int n, int S);
+int svae_lds_tile_vjp_f64(int phase, int B, int T, int n, int S, int inhomog, int pair_batched,
+                          const double* J12, const double* g_lognorm, const double* g_E_node_diagxx,
+                          const double* g_E_node_x, const double* g_E_init, const double* g_samples,
+                          const double* samples, const double* E_node_x, double* g_node_J, double* g_node_h,
+                          const void* handoff_workspace, void* workspace, size_t ws_doubles, void* stream);
 
 /* The once-per-step GLOBAL side of the LDS-SVAE in one launch ("global->local maps
  * on device"): niw.expectedstats (/root/reference/svae/distributions/niw.py:15-25) and mniw.expectedstats

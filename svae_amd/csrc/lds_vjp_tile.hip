@@ -1,0 +1,419 @@
+// lds_vjp_tile.hip -- reverse-mode derivative of the LDS E-step (+ sampler) w.r.t. the node potentials for
+// latent dimension 16 <= n <= 64 (any n <= 64 works), on the hand-off of the LDS-tiled E-step kernel
+// (lds_estep_tile.hip): what natural_filter_grad / natural_smoother_general_grad / natural_sample_backward_grad
+// compute in the reference (svae/lds/cython_lds_inference.pyx:92-145, 236-306, 357-409), as the adjoint of THIS
+// library's recursion (derivation and torch restatement: svae_amd/lds/lds_large.py, vjp_from_handoff).
+//
+// Three passes over time, each one workgroup (256 threads) per sequence with the n x n state in LDS:
+//   phase 0 (t = T-1 .. 0)  Sigma_t = Pinv_t + G_t Sigma_{t+1} G_t'                      -> sig (B,T,n,n)
+//   phase 1 (t = 0 .. T-1)  adjoint of the smoother / sampler recursions: Sigma_bar, m_bar, x_bar
+//                           -> pinv_bar (B,T,n,n), g_bar (B,T-1,n,n), c_bar (B,T,n), xbar (B,T,S,n)
+//   [the caller adds the Cholesky adjoint of the noise factor, batched over all (b,t), into pinv_bar]
+//   phase 2 (t = T-1 .. 0)  adjoint of the filter -> g_node_J, g_node_h (B,T,n)
+// Every O(n^3) product is C = A B on LDS-resident operands (row stride 66 doubles), each thread owning a 4 x 4
+// block of C (16 x 16 threads), operands read as 16-byte pairs; transposed operands are produced when a
+// matrix is copied into LDS, never inside the product.  fp64 VALU: v_mfma_f64 has the same rate on MI355X.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/svae_hip.h"
+
+namespace svae {
+
+constexpr int TV_LD = 66;                 // LDS row stride in doubles (16-byte aligned rows, 2-way conflicts at most)
+constexpr int TV_MAT = 64 * TV_LD;        // one matrix buffer
+constexpr int TV_MAX_S = 16;
+
+struct TileVjpArgs {
+  int B, T, n, S, NP;                     // NP: padded dimension of the hand-off (n rounded up to 16)
+  const double* ws;                       // tile-kernel hand-off: per (b,t) [G (NP x NP) | Pinv (NP x NP) | c (NP)]
+  const double* J12; long pair_t_stride, pair_seq_stride;     // natural pair parameter
+  const double* E_node_x;                 // (B,T,n) smoothed means
+  const double* samples; const double* g_samples;             // (B,T,S,n) or nullptr
+  const double* g_lognorm;                // (B)
+  const double* g_dxx; const double* g_x; // (B,T,n) or nullptr
+  const double* g_E_init;                 // (B, n*n+n) or nullptr
+  double* sig; double* pinv_bar; double* g_bar; double* c_bar; double* xbar;   // VJP workspace
+  double* g_node_J; double* g_node_h;
+};
+
+struct Acc { double v[4][4]; };
+
+__device__ __forceinline__ void acc_zero(Acc& a) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a.v[i][j] = 0.0;
+}
+
+// acc += A B for this thread's 4 x 4 block (rows 4 ty.., columns 4 tx..); A, B in LDS; k < n4 (multiple of 4)
+__device__ __forceinline__ void gemm_nn(const double* A, const double* Bm, int n4, int ty, int tx, Acc& acc) {
+  if (4 * ty >= n4 || 4 * tx >= n4) return;
+  const double* ap = A + (4 * ty) * TV_LD;
+  const double* bp = Bm + 4 * tx;
+  for (int k = 0; k < n4; k += 2) {
+    double2 a[4], b0[2], b1[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const double2*>(ap + i * TV_LD + k);
+    b0[0] = *reinterpret_cast<const double2*>(bp + k * TV_LD);
+    b0[1] = *reinterpret_cast<const double2*>(bp + k * TV_LD + 2);
+    b1[0] = *reinterpret_cast<const double2*>(bp + (k + 1) * TV_LD);
+    b1[1] = *reinterpret_cast<const double2*>(bp + (k + 1) * TV_LD + 2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc.v[i][0] = __builtin_fma(a[i].x, b0[0].x, acc.v[i][0]);
+      acc.v[i][1] = __builtin_fma(a[i].x, b0[0].y, acc.v[i][1]);
+      acc.v[i][2] = __builtin_fma(a[i].x, b0[1].x, acc.v[i][2]);
+      acc.v[i][3] = __builtin_fma(a[i].x, b0[1].y, acc.v[i][3]);
+      acc.v[i][0] = __builtin_fma(a[i].y, b1[0].x, acc.v[i][0]);
+      acc.v[i][1] = __builtin_fma(a[i].y, b1[0].y, acc.v[i][1]);
+      acc.v[i][2] = __builtin_fma(a[i].y, b1[1].x, acc.v[i][2]);
+      acc.v[i][3] = __builtin_fma(a[i].y, b1[1].y, acc.v[i][3]);
+    }
+  }
+}
+
+// global (row stride gld) -> LDS buffer, zero-padded to n4 x n4; TRANS: dst[c][r] = src[r][c]; scaled by `scale`
+template <bool TRANS>
+__device__ __forceinline__ void load_mat(double* dst, const double* src, int gld, int n, int n4, double scale) {
+  for (int e = threadIdx.x; e < n4 * n4; e += 256) {
+    const int r = e / n4, c = e % n4;
+    const double v = (r < n && c < n) ? scale * src[(long)r * gld + c] : 0.0;
+    if (TRANS) dst[c * TV_LD + r] = v; else dst[r * TV_LD + c] = v;
+  }
+}
+
+__device__ __forceinline__ void store_block(double* dst, const Acc& a, int ty, int tx, int n4, bool trans) {
+  if (4 * ty >= n4 || 4 * tx >= n4) return;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (trans) dst[(4 * tx + j) * TV_LD + 4 * ty + i] = a.v[i][j];
+      else dst[(4 * ty + i) * TV_LD + 4 * tx + j] = a.v[i][j];
+    }
+}
+
+// in place: M <- (M + M') / 2 on the n4 x n4 LDS matrix (barriers inside)
+__device__ __forceinline__ void symmetrize_lds(double* M, int n4) {
+  __syncthreads();
+  double keep[16];
+  int cnt = 0;
+  for (int e = threadIdx.x; e < n4 * n4; e += 256) {
+    const int r = e / n4, c = e % n4;
+    keep[cnt++] = 0.5 * (M[r * TV_LD + c] + M[c * TV_LD + r]);
+  }
+  __syncthreads();
+  cnt = 0;
+  for (int e = threadIdx.x; e < n4 * n4; e += 256) {
+    const int r = e / n4, c = e % n4;
+    M[r * TV_LD + c] = keep[cnt++];
+  }
+  __syncthreads();
+}
+
+// y[i] = sum_j A[i][j] x[j]  (TRANS: A[j][i]) for i < n; A in LDS; x, y LDS vectors (y != x); barrier after
+template <bool TRANS>
+__device__ __forceinline__ void matvec(const double* A, const double* x, double* y, int n) {
+  for (int i = threadIdx.x; i < n; i += 256) {
+    double s = 0.0;
+    for (int j = 0; j < n; ++j) s = __builtin_fma(TRANS ? A[j * TV_LD + i] : A[i * TV_LD + j], x[j], s);
+    y[i] = s;
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ const double* handoff(const TileVjpArgs& a, int b, int t) {
+  return a.ws + ((long)b * a.T + t) * (2L * a.NP * a.NP + a.NP);
+}
+
+// ---- phase 0 ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tile_vjp_phase0(const TileVjpArgs a) {
+  extern __shared__ double sm[];
+  double *L0 = sm, *L1 = sm + TV_MAT, *L3 = sm + 2 * TV_MAT;
+  const int b = blockIdx.x, n = a.n, n4 = (n + 3) & ~3, NP = a.NP, T = a.T;
+  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+  load_mat<false>(L3, handoff(a, b, T - 1) + (long)NP * NP, NP, n, n4, 1.0);
+  __syncthreads();
+  for (int t = T - 1; t >= 0; --t) {
+    if (t < T - 1) {
+      const double* h = handoff(a, b, t);
+      load_mat<false>(L0, h, NP, n, n4, 1.0);                     // G_t
+      __syncthreads();
+      Acc acc;
+      acc_zero(acc);
+      gemm_nn(L0, L3, n4, ty, tx, acc);                           // G Sigma
+      store_block(L1, acc, ty, tx, n4, true);                     // (G Sigma)'
+      __syncthreads();
+      acc_zero(acc);
+      gemm_nn(L0, L1, n4, ty, tx, acc);                           // G (G Sigma)' = G Sigma G'
+      const double* P = h + (long)NP * NP;
+      if (4 * ty < n4 && 4 * tx < n4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int r = 4 * ty + i, c = 4 * tx + j;
+            acc.v[i][j] += (r < n && c < n) ? P[(long)r * NP + c] : 0.0;
+          }
+      }
+      __syncthreads();                                            // everyone done reading L3
+      store_block(L3, acc, ty, tx, n4, false);
+      symmetrize_lds(L3, n4);
+    }
+    double* out = a.sig + ((long)b * T + t) * n * n;
+    for (int e = threadIdx.x; e < n * n; e += 256) out[e] = L3[(e / n) * TV_LD + (e % n)];
+  }
+}
+
+// ---- phase 1 ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tile_vjp_phase1(const TileVjpArgs a) {
+  extern __shared__ double sm[];
+  double *L0 = sm, *L1 = sm + TV_MAT, *L2 = sm + 2 * TV_MAT, *L3 = sm + 3 * TV_MAT;
+  double* vec = sm + 4 * TV_MAT;          // mb (64) | tmp (64) | mnext (64) | xb (S x 64) | xtmp (S x 64) | xnext (S x 64)
+  double *mb = vec, *tmpv = vec + 64, *mnext = vec + 128, *xb = vec + 192, *xtmp = xb + TV_MAX_S * 64, *xnext = xtmp + TV_MAX_S * 64;
+  const int b = blockIdx.x, n = a.n, n4 = (n + 3) & ~3, NP = a.NP, T = a.T, S = a.g_samples ? a.S : 0;
+  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+  for (int e = threadIdx.x; e < 64 * TV_LD; e += 256) L3[e] = 0.0;             // Sigma_bar
+  for (int e = threadIdx.x; e < 192 + 3 * TV_MAX_S * 64; e += 256) vec[e] = 0.0;
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    const long bt = (long)b * T + t;
+    const double* mt = a.E_node_x + bt * n;
+    // direct cotangents of step t
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const double gd = a.g_dxx ? a.g_dxx[bt * n + i] : 0.0;
+      L3[i * TV_LD + i] += gd;
+      mb[i] += (a.g_x ? a.g_x[bt * n + i] : 0.0) + 2.0 * gd * mt[i];
+    }
+    if (t == 0 && a.g_E_init) {
+      __syncthreads();
+      const double* gi = a.g_E_init + (long)b * (n * n + n);
+      for (int e = threadIdx.x; e < n * n; e += 256) {
+        const int r = e / n, c = e % n;
+        L3[r * TV_LD + c] += 0.5 * (gi[r * n + c] + gi[c * n + r]);
+      }
+      for (int i = threadIdx.x; i < n; i += 256) {
+        double s = gi[n * n + i];
+        for (int j = 0; j < n; ++j) s = __builtin_fma(gi[i * n + j] + gi[j * n + i], mt[j], s);
+        mb[i] += s;
+      }
+    }
+    for (int e = threadIdx.x; e < S * n; e += 256) {
+      const int s_ = e / n, i = e % n;
+      xb[s_ * 64 + i] += a.g_samples[(bt * a.S + s_) * n + i];
+    }
+    __syncthreads();
+    // records for phase 2
+    double* pb = a.pinv_bar + bt * n * n;
+    for (int e = threadIdx.x; e < n * n; e += 256) pb[e] = L3[(e / n) * TV_LD + (e % n)];
+    for (int i = threadIdx.x; i < n; i += 256) {
+      double s = mb[i];
+      for (int s_ = 0; s_ < S; ++s_) s += xb[s_ * 64 + i];
+      a.c_bar[bt * n + i] = s;
+    }
+    for (int e = threadIdx.x; e < S * n; e += 256) a.xbar[(bt * a.S + e / n) * n + e % n] = xb[(e / n) * 64 + e % n];
+    if (t == T - 1) break;
+    // propagate to t + 1
+    const double* h = handoff(a, b, t);
+    load_mat<false>(L0, h, NP, n, n4, 1.0);                                      // G_t
+    load_mat<false>(L2, a.sig + (bt + 1) * n * n, n, n, n4, 1.0);               // Sigma_{t+1}
+    __syncthreads();
+    Acc acc;
+    acc_zero(acc);
+    gemm_nn(L3, L0, n4, ty, tx, acc);                                           // SG = Sigma_bar G
+    store_block(L1, acc, ty, tx, n4, false);
+    __syncthreads();
+    acc_zero(acc);
+    gemm_nn(L1, L2, n4, ty, tx, acc);                                           // SG Sigma_{t+1}
+    {
+      // G_bar = 2 SG Sigma_{t+1} + m_bar m_{t+1}' + sum_s x_bar_s x_{t+1,s}'
+      const double* mn = a.E_node_x + (bt + 1) * n;
+      double* gb = a.g_bar + ((long)b * (T - 1) + t) * n * n;
+      if (4 * ty < n4 && 4 * tx < n4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int r = 4 * ty + i, c = 4 * tx + j;
+            if (r < n && c < n) {
+              double v = 2.0 * acc.v[i][j] + mb[r] * mn[c];
+              for (int s_ = 0; s_ < S; ++s_) v = __builtin_fma(xb[s_ * 64 + r], a.samples[((bt + 1) * a.S + s_) * n + c], v);
+              gb[r * n + c] = v;
+            }
+          }
+      }
+    }
+    // m_bar <- G' m_bar ; x_bar <- x_bar G
+    matvec<true>(L0, mb, mnext, n);
+    for (int e = threadIdx.x; e < S * n; e += 256) {
+      const int s_ = e / n, j = e % n;
+      double v = 0.0;
+      for (int i = 0; i < n; ++i) v = __builtin_fma(xb[s_ * 64 + i], L0[i * TV_LD + j], v);
+      xnext[s_ * 64 + j] = v;
+    }
+    __syncthreads();                                                             // L2 (Sigma_{t+1}) and mb / xb no longer read
+    for (int i = threadIdx.x; i < n; i += 256) mb[i] = mnext[i];
+    for (int e = threadIdx.x; e < S * n; e += 256) xb[(e / n) * 64 + e % n] = xnext[(e / n) * 64 + e % n];
+    load_mat<true>(L2, h, NP, n, n4, 1.0);                                       // G_t'
+    __syncthreads();
+    acc_zero(acc);
+    gemm_nn(L2, L1, n4, ty, tx, acc);                                           // G' SG
+    __syncthreads();
+    store_block(L3, acc, ty, tx, n4, false);
+    symmetrize_lds(L3, n4);
+  }
+  (void)tmpv; (void)xtmp;
+}
+
+// ---- phase 2 ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tile_vjp_phase2(const TileVjpArgs a) {
+  extern __shared__ double sm[];
+  double *L0 = sm, *L1 = sm + TV_MAT, *L2 = sm + 2 * TV_MAT, *L3 = sm + 3 * TV_MAT;
+  double* vec = sm + 4 * TV_MAT;          // hb | cb | Pc | tmp
+  double *hb = vec, *cb = vec + 64, *Pc = vec + 128, *tmpv = vec + 192;
+  const int b = blockIdx.x, n = a.n, n4 = (n + 3) & ~3, NP = a.NP, T = a.T;
+  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+  const double gl = a.g_lognorm[b];
+  for (int e = threadIdx.x; e < 64 * TV_LD; e += 256) L3[e] = 0.0;             // J_bar of step t + 1
+  for (int e = threadIdx.x; e < 256; e += 256) vec[e] = 0.0;
+  __syncthreads();
+  for (int t = T - 1; t >= 0; --t) {
+    const long bt = (long)b * T + t;
+    const double* h = handoff(a, b, t);
+    const double* ct = h + 2L * NP * NP;
+    load_mat<false>(L0, h + (long)NP * NP, NP, n, n4, 1.0);                      // Pinv_t
+    for (int i = threadIdx.x; i < n; i += 256) cb[i] = a.c_bar[bt * n + i];
+    Acc pbar;
+    acc_zero(pbar);
+    if (t < T - 1) {
+      // R = -J12 (info form):  X_bar = -R J_bar - G_bar = J12 J_bar - G_bar ;  c_bar -= R h_bar = += J12 h_bar
+      const double* J12 = a.J12 + (long)b * a.pair_seq_stride + (long)t * a.pair_t_stride;
+      load_mat<false>(L1, J12, n, n, n4, 1.0);
+      __syncthreads();
+      matvec<false>(L1, hb, tmpv, n);
+      for (int i = threadIdx.x; i < n; i += 256) cb[i] += tmpv[i];
+      Acc acc;
+      acc_zero(acc);
+      gemm_nn(L1, L3, n4, ty, tx, acc);                                         // J12 J_bar
+      const double* gb = a.g_bar + ((long)b * (T - 1) + t) * n * n;
+      if (4 * ty < n4 && 4 * tx < n4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int r = 4 * ty + i, c = 4 * tx + j;
+            acc.v[i][j] -= (r < n && c < n) ? gb[r * n + c] : 0.0;
+          }
+      }
+      store_block(L2, acc, ty, tx, n4, false);                                  // X_bar
+      __syncthreads();
+      acc_zero(acc);
+      gemm_nn(L0, L2, n4, ty, tx, acc);                                         // PX = Pinv X_bar
+      __syncthreads();
+      store_block(L1, acc, ty, tx, n4, false);
+      load_mat<true>(L2, h, NP, n, n4, 1.0);                                     // G_t'
+      __syncthreads();
+      gemm_nn(L1, L2, n4, ty, tx, pbar);                                        // P_bar = PX G'
+      __syncthreads();
+    } else {
+      __syncthreads();
+    }
+    load_mat<false>(L1, a.pinv_bar + bt * n * n, n, n, n4, 1.0);                // Pinv_bar (direct + Cholesky part)
+    __syncthreads();
+    {
+      Acc acc;
+      acc_zero(acc);
+      gemm_nn(L0, L1, n4, ty, tx, acc);                                         // Pinv Pinv_bar
+      store_block(L2, acc, ty, tx, n4, false);
+      __syncthreads();
+      acc_zero(acc);
+      gemm_nn(L2, L0, n4, ty, tx, acc);                                         // (Pinv Pinv_bar) Pinv
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pbar.v[i][j] -= acc.v[i][j];
+    }
+    matvec<false>(L0, cb, Pc, n);                                               // Pc = Pinv c_bar  (barrier inside)
+    // P_bar -= Pc c' + gl/2 c c' + gl/2 Pinv
+    if (4 * ty < n4 && 4 * tx < n4) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 4 * ty + i, c = 4 * tx + j;
+          if (r < n && c < n) pbar.v[i][j] -= Pc[r] * ct[c] + 0.5 * gl * (ct[r] * ct[c] + L0[r * TV_LD + c]);
+          else pbar.v[i][j] = 0.0;
+        }
+    }
+    __syncthreads();
+    store_block(L3, pbar, ty, tx, n4, false);
+    symmetrize_lds(L3, n4);
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const double hf = Pc[i] + gl * ct[i];
+      a.g_node_J[bt * n + i] = -2.0 * L3[i * TV_LD + i];
+      a.g_node_h[bt * n + i] = hf;
+      hb[i] = hf;
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace svae
+
+extern "C" size_t svae_lds_tile_vjp_workspace_doubles(int B, int T, int n, int S) {
+  if (B <= 0 || T <= 0 || n <= 0 || n > 64 || S < 0) return 0;
+  return (size_t)B * T * n * n * 2 + (size_t)B * (T > 1 ? T - 1 : 0) * n * n + (size_t)B * T * n + (size_t)B * T * (S > 0 ? S : 0) * n;
+}
+
+// phase 0, 1, 2 as described at the top; `workspace` holds [sig | pinv_bar | g_bar | c_bar | xbar] in that
+// order (svae_lds_tile_vjp_workspace_doubles); between phase 1 and phase 2 the caller adds the Cholesky adjoint
+// of the noise factor into pinv_bar (it is batched over all (sequence, step) pairs and needs xbar).
+extern "C" int svae_lds_tile_vjp_f64(int phase, int B, int T, int n, int S, int inhomog, int pair_batched,
+                                     const double* J12, const double* g_lognorm, const double* g_E_node_diagxx,
+                                     const double* g_E_node_x, const double* g_E_init, const double* g_samples,
+                                     const double* samples, const double* E_node_x, double* g_node_J, double* g_node_h,
+                                     const void* handoff_workspace, void* workspace, size_t ws_doubles, void* stream) {
+  if (phase < 0 || phase > 2) return -1;
+  if (B < 0) return -2;
+  if (T < 1) return -3;
+  if (n < 1 || n > 64) return -4;
+  if (g_samples && (S < 1 || S > svae::TV_MAX_S)) return -5;
+  if (pair_batched && !inhomog) return -6;
+  if (T > 1 && !J12) return -8;
+  if (!g_lognorm) return -9;
+  if (g_samples && !samples) return -14;
+  if (!E_node_x) return -15;
+  if (!g_node_J || !g_node_h) return -16;
+  if (!handoff_workspace) return -18;
+  if (!workspace || ws_doubles < svae_lds_tile_vjp_workspace_doubles(B, T, n, g_samples ? S : 0)) return -19;
+  if (B == 0) return 0;
+  svae::TileVjpArgs a;
+  a.B = B; a.T = T; a.n = n; a.S = g_samples ? S : 0; a.NP = 16 * ((n + 15) / 16);
+  a.ws = (const double*)handoff_workspace;
+  a.J12 = J12; a.pair_t_stride = inhomog ? (long)n * n : 0; a.pair_seq_stride = pair_batched ? (long)(T - 1) * n * n : 0;
+  a.E_node_x = E_node_x; a.samples = samples; a.g_samples = g_samples; a.g_lognorm = g_lognorm;
+  a.g_dxx = g_E_node_diagxx; a.g_x = g_E_node_x; a.g_E_init = g_E_init;
+  double* w = (double*)workspace;
+  a.sig = w; w += (size_t)B * T * n * n;
+  a.pinv_bar = w; w += (size_t)B * T * n * n;
+  a.g_bar = w; w += (size_t)B * (T > 1 ? T - 1 : 0) * n * n;
+  a.c_bar = w; w += (size_t)B * T * n;
+  a.xbar = w;
+  a.g_node_J = g_node_J; a.g_node_h = g_node_h;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds0 = (size_t)3 * svae::TV_MAT * sizeof(double);
+  const size_t lds12 = (size_t)(4 * svae::TV_MAT + 192 + 3 * svae::TV_MAX_S * 64) * sizeof(double);
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(svae::tile_vjp_phase0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(svae::tile_vjp_phase1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds12) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(svae::tile_vjp_phase2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds12) != hipSuccess)
+      return -1001;
+    attr = true;
+  }
+  if (phase == 0) hipLaunchKernelGGL(svae::tile_vjp_phase0, dim3(B), dim3(256), lds0, s, a);
+  else if (phase == 1) hipLaunchKernelGGL(svae::tile_vjp_phase1, dim3(B), dim3(256), lds12, s, a);
+  else hipLaunchKernelGGL(svae::tile_vjp_phase2, dim3(B), dim3(256), lds12, s, a);
+  return hipGetLastError() == hipSuccess ? 0 : -1000;
+}

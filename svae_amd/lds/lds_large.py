@@ -272,6 +272,52 @@ def vjp_from_handoff(G, Pinv, c, m, J12, g_lognorm, g_dxx, g_x, samples=None, ep
     return gJ, gh
 
 
+def vjp_from_handoff_hip(plan, J12, pair_batched, ex, g_lognorm, g_dxx, g_x, samples=None, eps=None, g_samples=None,
+                         g_E_init=None):
+    """vjp_from_handoff on the device kernels (svae_lds_tile_vjp_f64: three phases, one workgroup per sequence,
+    n x n state in LDS); the Cholesky adjoint of the sampler's noise factor -- parallel over all (sequence, step)
+    pairs -- stays a batched library call between phases 1 and 2.  Reads the hand-off of the plan's last launch."""
+    lib = _lib.load()
+    B, T, n = plan.B, plan.T, plan.n
+    dev = plan.device
+    f64 = dict(dtype=torch.float64, device=dev)
+    cont = lambda x: None if x is None else x.to(**f64).contiguous()
+    g_lognorm, g_dxx, g_x, g_E_init = cont(g_lognorm), cont(g_dxx), cont(g_x), cont(g_E_init)
+    has_s = g_samples is not None
+    samples, eps, g_samples = (cont(samples), cont(eps), cont(g_samples)) if has_s else (None, None, None)
+    S = samples.shape[2] if has_s else 0
+    if S > 16:
+        raise ValueError("at most 16 samples per sequence are differentiable")
+    nws = int(lib.svae_lds_tile_vjp_workspace_doubles(max(B, 1), T, n, S))
+    ws = torch.empty(nws, **f64)
+    gJ, gh = torch.empty(B, T, n, **f64), torch.empty(B, T, n, **f64)
+    J12 = cont(J12)
+    inhomog = J12.dim() >= 3
+    p = _lib.ptr
+
+    def phase(k):
+        rc = lib.svae_lds_tile_vjp_f64(k, B, T, n, S, int(inhomog), int(bool(pair_batched)), p(J12), p(g_lognorm),
+                                       p(g_dxx), p(g_x), p(g_E_init), p(g_samples), p(samples), p(ex), p(gJ), p(gh),
+                                       p(plan.ws), p(ws), nws, _lib.current_stream(dev))
+        _lib.check(rc, "svae_lds_tile_vjp_f64")
+    phase(0)
+    phase(1)
+    if has_s:
+        _, Pinv, _ = handoff_views(plan)
+        o = 2 * B * T * n * n + B * max(T - 1, 0) * n * n + B * T * n
+        pinv_bar = ws[B * T * n * n:2 * B * T * n * n].view(B, T, n, n)
+        xbar = ws[o:o + B * T * S * n].view(B, T, S, n)
+        per_seq = T * n * n * 8 * 6
+        step = max(1, int((4 << 30) // per_seq))
+        for b0 in range(0, B, step):
+            sl = slice(b0, b0 + step)
+            M = _upper_factor(Pinv[sl])
+            Mbar = torch.triu(torch.matmul(xbar[sl].transpose(-1, -2), eps[sl]))
+            pinv_bar[sl] += _upper_factor_adjoint(M, Mbar)
+    phase(2)
+    return gJ, gh
+
+
 class LDSInferenceLarge(torch.autograd.Function):
     """Differentiable (w.r.t. the node potentials) E-step + sampler for 16 <= n <= 64: forward = the
     tile kernel (+ sample_from_handoff), backward = autograd through torch_estep re-run on the same
@@ -285,7 +331,7 @@ class LDSInferenceLarge(torch.autograd.Function):
         samples = sample_from_handoff(plan, eps) if eps is not None else \
             torch.zeros(0, dtype=torch.float64, device=plan.device)
         ctx.params, ctx.inhomog, ctx.has_logZ, ctx.has_eps = params, plan.inhomog, node_logZ is not None, eps is not None
-        ctx.plan, ctx.epoch = plan, plan.epoch
+        ctx.plan, ctx.epoch, ctx.pair_batched = plan, plan.epoch, pair_batched
         ctx.ex = plan.E_node_x.clone()
         ctx.samples = samples if eps is not None else None
         ctx.save_for_backward(node_J, node_h, eps if eps is not None else samples)
@@ -304,12 +350,11 @@ class LDSInferenceLarge(torch.autograd.Function):
             if plan.epoch != ctx.epoch:
                 raise RuntimeError("LDSEStepPlan was launched again before backward(): the hand-off workspace of "
                                    "this forward pass is gone (use one plan per live autograd graph)")
-            G, Pinv, c = handoff_views(plan)
             zero = lambda g, like: torch.zeros_like(like) if g is None else g
             gs = g_samples if (ctx.has_eps and g_samples is not None) else None
-            gJ, gh = vjp_from_handoff(G, Pinv, c, ctx.ex, ctx.params[4], zero(g_lognorm, plan.lognorm), g_dxx, g_x,
-                                      ctx.samples if gs is not None else None, eps if gs is not None else None, gs,
-                                      g_init if ctx.inhomog else None)
+            gJ, gh = vjp_from_handoff_hip(plan, ctx.params[4], ctx.pair_batched, ctx.ex, zero(g_lognorm, plan.lognorm),
+                                          g_dxx, g_x, ctx.samples if gs is not None else None,
+                                          eps if gs is not None else None, gs, g_init if ctx.inhomog else None)
             gz = g_lognorm[:, None].expand(B, T).clone() if (ctx.has_logZ and g_lognorm is not None) else None
             return gJ, gh, gz, None, None, None, None
         # per-step pair-statistic cotangents (per-step pair parameters at n > 15): autograd through the torch

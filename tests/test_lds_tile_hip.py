@@ -226,3 +226,47 @@ def test_tile_training_step_at_latent_dim_32():
     spec.loader.exec_module(mod)
     vals = mod.main(["--iters", "6", "--seqs", "16", "--T", "20", "--n", "32", "--p", "40", "--batch", "8", "--quiet"])
     assert len(vals) == 6 and np.all(np.isfinite(vals))
+
+
+@pytest.mark.parametrize("n,T,B,S,mode", [(16, 7, 3, 2, "homog"), (20, 5, 2, 0, "homog"), (33, 6, 2, 3, "inhomog"),
+                                          (64, 5, 2, 1, "batched"), (48, 1, 2, 1, "homog"), (64, 40, 3, 2, "homog")])
+def test_tile_vjp_kernels_match_the_torch_adjoint(n, T, B, S, mode):
+    """svae_lds_tile_vjp_f64 (three phases, one workgroup per sequence) against the same adjoint written as
+    batched torch products (lds_large.vjp_from_handoff, itself checked against autograd on the CPU), both on the
+    hand-off of ONE tile-kernel launch; cotangents of lognorm, E_node, E_init and the samples."""
+    from svae_amd.lds import lds_large
+    from svae_amd.lds.lds_inference import LDSEStepPlan
+    rng = np.random.default_rng(5 * n + T)
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev).contiguous()
+    init = _wellcond_natparam(n, rng)[0]
+    if mode == "homog":
+        pair = tuple(t(x) for x in _wellcond_natparam(n, rng)[1])
+    else:
+        sets = B if mode == "batched" else 1
+        pairs = [[_wellcond_natparam(n, rng)[1] for _ in range(T - 1)] for _ in range(sets)]
+        st = lambda i: t(np.stack([np.stack([p[i] for p in row]) for row in pairs]))
+        pair = tuple(st(i) for i in range(4))
+        if mode != "batched":
+            pair = tuple(x[0] for x in pair)
+    nJ, nh = (t(x) for x in rand_node_potentials((B, T, n), rng))
+    plan = LDSEStepPlan(B, T, n, dev, inhomog=mode != "homog", pair_batched=mode == "batched")
+    plan.launch(t(init[0]), t(init[1]), t(init[2]).reshape(1), pair[0], pair[1], pair[2], pair[3].reshape(-1).contiguous(),
+                nJ, nh, None, mode == "batched", False, False)
+    eps = t(rng.standard_normal((B, T, S, n))) if S else None
+    samples = lds_large.sample_from_handoff(plan, eps) if S else None
+    g = dict(ln=t(rng.standard_normal(B)), dxx=t(rng.standard_normal((B, T, n))), x=t(rng.standard_normal((B, T, n))),
+             s=t(rng.standard_normal((B, T, max(S, 1), n))), i=t(rng.standard_normal((B, n * n + n))))
+    G, Pinv, c = lds_large.handoff_views(plan)
+    ex = plan.E_node_x.clone()
+    want = lds_large.vjp_from_handoff(G, Pinv, c, ex, pair[1], g["ln"], g["dxx"], g["x"], samples, eps,
+                                      g["s"] if S else None, g["i"])
+    got = lds_large.vjp_from_handoff_hip(plan, pair[1], mode == "batched", ex, g["ln"], g["dxx"], g["x"], samples, eps,
+                                         g["s"] if S else None, g["i"])
+    for a, b in zip(got, want):
+        assert _rel(a, b.cpu().numpy()) < 1e-9
+    # without the optional cotangents
+    want = lds_large.vjp_from_handoff(G, Pinv, c, ex, pair[1], g["ln"], None, g["x"])
+    got = lds_large.vjp_from_handoff_hip(plan, pair[1], mode == "batched", ex, g["ln"], None, g["x"])
+    for a, b in zip(got, want):
+        assert _rel(a, b.cpu().numpy()) < 1e-9
