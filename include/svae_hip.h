@@ -160,6 +160,13 @@ int svae_lds_tile_vjp_f64(int phase, int B, int T, int n, int S, int inhomog, in
                           const double* samples, const double* E_node_x, double* g_node_J, double* g_node_h,
                           const void* handoff_workspace, void* workspace, size_t ws_doubles, void* stream);
 
+/* Backward sampling (natural_sample_backward, /root/reference/svae/lds/cython_lds_inference.pyx:310-355) for latent
+ * dimension 16 <= n <= 64 from the hand-off of the tiled svae_lds_estep_f64: the serial recursion
+ * x_t = c_t + noise_t + G_t x_{t+1}; `noise` (B,T,S,n) = chol(P_t)^-T eps_t is the caller's batched factorisation
+ * of the hand-off's P_t^-1 (it does not depend on the recursion).  S <= 16. */
+int svae_lds_tile_sample_f64(int B, int T, int n, int S, const double* noise, double* samples,
+                             const void* handoff_workspace, void* stream);
+
 /* The once-per-step GLOBAL side of the LDS-SVAE in one launch ("global->local maps
  * on device"): niw.expectedstats (/root/reference/svae/distributions/niw.py:15-25) and mniw.expectedstats
  * (/root/reference/svae/distributions/mniw.py:19-20, 33-55) of the global factors -> the LDS init and pair

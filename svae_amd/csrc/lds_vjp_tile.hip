@@ -359,6 +359,43 @@ __global__ __launch_bounds__(256) void tile_vjp_phase2(const TileVjpArgs a) {
   }
 }
 
+// ---- backward sampler recursion ----------------------------------------------------------------------------------
+// x_t = c_t + noise_t + G_t x_{t+1}  (t = T-1 .. 0; natural_sample_backward, cython_lds_inference.pyx:310-355, with the
+// noise chol(P_t)^-T eps_t precomputed for all (sequence, step) pairs: it does not depend on the recursion).
+// One workgroup per sequence, G_t staged in LDS, S <= 16 samples.
+__global__ __launch_bounds__(256) void tile_sample_kernel(int T, int n, int S, int NP, const double* ws,
+                                                          const double* noise, double* samples) {
+  extern __shared__ double sm[];
+  double* Gs = sm;                       // n x (n + 1)
+  double* xn = sm + 64 * 65;             // S x 64: x_{t+1}
+  const int b = blockIdx.x, ld = n + 1;
+  for (int t = T - 1; t >= 0; --t) {
+    const double* h = ws + ((long)b * T + t) * (2L * NP * NP + NP);
+    const double* ct = h + 2L * NP * NP;
+    if (t < T - 1) {
+      for (int e = threadIdx.x; e < n * n; e += 256) Gs[(e / n) * ld + (e % n)] = h[(long)(e / n) * NP + (e % n)];
+    }
+    __syncthreads();
+    double out[4];
+    int cnt = 0;
+    for (int e = threadIdx.x; e < S * n; e += 256) {
+      const int s_ = e / n, i = e % n;
+      double v = ct[i] + noise[(((long)b * T + t) * S + s_) * n + i];
+      if (t < T - 1)
+        for (int j = 0; j < n; ++j) v = __builtin_fma(Gs[i * ld + j], xn[s_ * 64 + j], v);
+      out[cnt++] = v;
+    }
+    __syncthreads();
+    cnt = 0;
+    for (int e = threadIdx.x; e < S * n; e += 256) {
+      const int s_ = e / n, i = e % n;
+      xn[s_ * 64 + i] = out[cnt];
+      samples[(((long)b * T + t) * S + s_) * n + i] = out[cnt++];
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace svae
 
 extern "C" size_t svae_lds_tile_vjp_workspace_doubles(int B, int T, int n, int S) {
@@ -415,5 +452,23 @@ extern "C" int svae_lds_tile_vjp_f64(int phase, int B, int T, int n, int S, int 
   if (phase == 0) hipLaunchKernelGGL(svae::tile_vjp_phase0, dim3(B), dim3(256), lds0, s, a);
   else if (phase == 1) hipLaunchKernelGGL(svae::tile_vjp_phase1, dim3(B), dim3(256), lds12, s, a);
   else hipLaunchKernelGGL(svae::tile_vjp_phase2, dim3(B), dim3(256), lds12, s, a);
+  return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+// Backward sampling for latent dimension 16 <= n <= 64 from the hand-off of the tiled E-step: `noise` (B,T,S,n) =
+// chol(P_t)^-T eps_t (the caller's batched factorisation of P_t^-1), samples (B,T,S,n) out.
+extern "C" int svae_lds_tile_sample_f64(int B, int T, int n, int S, const double* noise, double* samples,
+                                        const void* handoff_workspace, void* stream) {
+  if (B < 0) return -1;
+  if (T < 1) return -2;
+  if (n < 1 || n > 64) return -3;
+  if (S < 1 || S > svae::TV_MAX_S) return -4;
+  if (!noise) return -5;
+  if (!samples) return -6;
+  if (!handoff_workspace) return -7;
+  if (B == 0) return 0;
+  const size_t lds = (size_t)(64 * 65 + svae::TV_MAX_S * 64) * sizeof(double);
+  hipLaunchKernelGGL(svae::tile_sample_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, T, n, S,
+                     16 * ((n + 15) / 16), (const double*)handoff_workspace, noise, samples);
   return hipGetLastError() == hipSuccess ? 0 : -1000;
 }

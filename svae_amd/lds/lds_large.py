@@ -56,6 +56,11 @@ def sample_from_handoff(plan, eps, chunk_bytes=2 << 30):
         M = Lf.flip(-1, -2)                                    # upper triangular, P^-1 = M M'
         noise[b0:b0 + step] = torch.matmul(eps[b0:b0 + step], M.transpose(-1, -2))
     out = torch.empty_like(noise)
+    if S <= 16:      # the serial recursion in one launch (svae_lds_tile_sample_f64)
+        rc = _lib.load().svae_lds_tile_sample_f64(B, T, n, S, _lib.ptr(noise), _lib.ptr(out), _lib.ptr(plan.ws),
+                                                  _lib.current_stream(plan.device))
+        _lib.check(rc, "svae_lds_tile_sample_f64")
+        return out
     x = c[:, T - 1, None, :] + noise[:, T - 1]
     out[:, T - 1] = x
     for t in range(T - 2, -1, -1):
