@@ -51,6 +51,7 @@ __device__ __forceinline__ void gemm_nn(const double* A, const double* Bm, int n
   if (4 * ty >= n4 || 4 * tx >= n4) return;
   const double* ap = A + (4 * ty) * TV_LD;
   const double* bp = Bm + 4 * tx;
+#pragma unroll 4
   for (int k = 0; k < n4; k += 2) {
     double2 a[4], b0[2], b1[2];
 #pragma unroll
@@ -73,13 +74,41 @@ __device__ __forceinline__ void gemm_nn(const double* A, const double* Bm, int n
   }
 }
 
-// global (row stride gld) -> LDS buffer, zero-padded to n4 x n4; TRANS: dst[c][r] = src[r][c]; scaled by `scale`
+// global (row stride gld) -> LDS buffer, zero-padded to n4 x n4; TRANS: dst[c][r] = src[r][c]; scaled by `scale`.
+// Thread (ty, tx) copies columns 4 tx .. 4 tx + 3 of rows ty, ty + 16, ty + 32, ty + 48: 16 independent loads in
+// flight per thread, 512 contiguous bytes per row across the 16 tx (no index divisions).
 template <bool TRANS>
 __device__ __forceinline__ void load_mat(double* dst, const double* src, int gld, int n, int n4, double scale) {
-  for (int e = threadIdx.x; e < n4 * n4; e += 256) {
-    const int r = e / n4, c = e % n4;
-    const double v = (r < n && c < n) ? scale * src[(long)r * gld + c] : 0.0;
-    if (TRANS) dst[c * TV_LD + r] = v; else dst[r * TV_LD + c] = v;
+  const int ty = threadIdx.x >> 4, c0 = 4 * (threadIdx.x & 15);
+  if (c0 >= n4) return;
+  double v[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = ty + 16 * i;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[i][j] = (r < n && c0 + j < n) ? src[(long)r * gld + c0 + j] : 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = ty + 16 * i;
+    if (r < n4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (TRANS) dst[(c0 + j) * TV_LD + r] = scale * v[i][j]; else dst[r * TV_LD + c0 + j] = scale * v[i][j];
+      }
+    }
+  }
+}
+
+// LDS matrix -> global n x n (dense, row stride n), same thread mapping as load_mat
+__device__ __forceinline__ void store_mat(double* dst, const double* src, int n) {
+  const int ty = threadIdx.x >> 4, c0 = 4 * (threadIdx.x & 15);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = ty + 16 * i;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (r < n && c0 + j < n) dst[(long)r * n + c0 + j] = src[r * TV_LD + c0 + j];
   }
 }
 
@@ -94,20 +123,24 @@ __device__ __forceinline__ void store_block(double* dst, const Acc& a, int ty, i
     }
 }
 
-// in place: M <- (M + M') / 2 on the n4 x n4 LDS matrix (barriers inside)
+// in place: M <- (M + M') / 2 on the n4 x n4 LDS matrix (barriers inside); each thread handles its 4 x 4 block
 __device__ __forceinline__ void symmetrize_lds(double* M, int n4) {
+  const int r0 = 4 * (threadIdx.x >> 4), c0 = 4 * (threadIdx.x & 15);
+  const bool on = r0 < n4 && c0 < n4;
   __syncthreads();
-  double keep[16];
-  int cnt = 0;
-  for (int e = threadIdx.x; e < n4 * n4; e += 256) {
-    const int r = e / n4, c = e % n4;
-    keep[cnt++] = 0.5 * (M[r * TV_LD + c] + M[c * TV_LD + r]);
+  double keep[4][4];
+  if (on) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) keep[i][j] = 0.5 * (M[(r0 + i) * TV_LD + c0 + j] + M[(c0 + j) * TV_LD + r0 + i]);
   }
   __syncthreads();
-  cnt = 0;
-  for (int e = threadIdx.x; e < n4 * n4; e += 256) {
-    const int r = e / n4, c = e % n4;
-    M[r * TV_LD + c] = keep[cnt++];
+  if (on) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) M[(r0 + i) * TV_LD + c0 + j] = keep[i][j];
   }
   __syncthreads();
 }
@@ -161,8 +194,7 @@ __global__ __launch_bounds__(256) void tile_vjp_phase0(const TileVjpArgs a) {
       store_block(L3, acc, ty, tx, n4, false);
       symmetrize_lds(L3, n4);
     }
-    double* out = a.sig + ((long)b * T + t) * n * n;
-    for (int e = threadIdx.x; e < n * n; e += 256) out[e] = L3[(e / n) * TV_LD + (e % n)];
+    store_mat(a.sig + ((long)b * T + t) * n * n, L3, n);
   }
 }
 
@@ -205,8 +237,7 @@ __global__ __launch_bounds__(256) void tile_vjp_phase1(const TileVjpArgs a) {
     }
     __syncthreads();
     // records for phase 2
-    double* pb = a.pinv_bar + bt * n * n;
-    for (int e = threadIdx.x; e < n * n; e += 256) pb[e] = L3[(e / n) * TV_LD + (e % n)];
+    store_mat(a.pinv_bar + bt * n * n, L3, n);
     for (int i = threadIdx.x; i < n; i += 256) {
       double s = mb[i];
       for (int s_ = 0; s_ < S; ++s_) s += xb[s_ * 64 + i];

@@ -1,0 +1,8 @@
+#!/bin/bash
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+O=$REPO/gpurun_out/prof_r2_tile_train; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python $REPO/tools/bench_tile_train.py 64 1000 64 1 > $O/bench.log 2>&1
+grep -v "^[EW]2026" $O/bench.log | tail -2
+find $O -name "*kernel_trace.csv" -size +2M -delete
+head -14 $O/trace/bench_kernel_stats.csv | cut -c1-140
