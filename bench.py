@@ -16,7 +16,9 @@ on the launch stream), at N=1 on rank 0 `cpu_baseline` (the reference's own comp
 oracle/_ref, timed on this box's host cores on a bounded sample of the same workload, plus the
 NumPy restatement of its Python path), and at N=1 `extra`: the same measurement for north_star's
 single-GPU target (4096 sequences on ONE GPU) and for BASELINE configs[4]'s shape (latent dim 64,
-T=1000), each with its own roofline -- reported beside `value`, never instead of it.
+T=1000), each with its own roofline, plus the training path at the headline shape (E-step keeping the
+hand-off + sampler + VJP), BASELINE configs[3] (SLDS local mean field) and configs[0] (GMM fixed point)
+-- reported beside `value`, never instead of it.
 """
 import argparse
 import json
@@ -162,6 +164,82 @@ def roofline(lib, T, n, B, kern_ms):
     return hbm
 
 
+def measure_training_path(dev, T, n, B, S=1, reps=5):
+    """E-step keeping the sampler / VJP hand-off + sampler + VJP at the headline shape (what one SVAE training
+    step adds around the recognition / decoder networks): ms per pass, events on the launch stream."""
+    from svae_amd.lds.lds_inference import LDSEStepPlan
+    from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials
+    rng = np.random.default_rng(0)
+    (J0, h0, z0), (J11, J12, J22, zp) = rand_lds_natparam(n, rng)
+    nJ, nh = rand_node_potentials((B, T, n), rng)
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev).contiguous()
+    args = [t(x) for x in (J0, h0, z0, J11, J12, J22, zp, nJ, nh)]
+    eps = torch.randn(B, T, S, n, dtype=torch.float64, device=dev)
+    g = [torch.randn(B, dtype=torch.float64, device=dev), torch.randn(B, T, n, dtype=torch.float64, device=dev),
+         torch.randn(B, T, n, dtype=torch.float64, device=dev), torch.randn(B, T, S, n, dtype=torch.float64, device=dev)]
+    plan = LDSEStepPlan(B, T, n, dev)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    acc = [0.0, 0.0, 0.0]
+    for rep in range(reps + 1):
+        ev[0].record(); plan.launch(*args, None, False, True, True)
+        ev[1].record(); smp = plan.sample(eps)
+        ev[2].record(); plan.vjp(g[0], g[1], g[2], g[3], eps, smp)
+        ev[3].record(); torch.cuda.synchronize()
+        if rep:
+            for i in range(3):
+                acc[i] += ev[i].elapsed_time(ev[i + 1]) / reps
+    return {"workload": "training path at the headline shape: E-step keeping the hand-off + backward sampler + VJP, "
+                        "%d sequences x T=%d, n=%d, %d sample" % (B, T, n, S),
+            "estep_with_handoff_ms": acc[0], "sampler_ms": acc[1], "vjp_ms": acc[2], "ms_per_pass": sum(acc),
+            "value": B / sum(acc) * 1e3, "unit": "sequences/s"}
+
+
+def measure_slds(dev, B=2048, T=500, n=10, K=8):
+    """BASELINE configs[3]: SLDS-SVAE local mean field (coordinate ascent between the HMM kernel and the fused LDS
+    mean-field kernel), wall clock of the whole ascent."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from bench_slds import globals_
+    from svae_amd.models import slds_svae
+    rng = np.random.default_rng(0)
+    glob = globals_(K, n, rng)
+    node = (torch.as_tensor(-0.5 * (0.5 + rng.random((B, T, n))), device=dev),
+            torch.as_tensor(2. * rng.standard_normal((B, T, n)), device=dev))
+    eps = torch.randn(B, T, 1, n, dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(0))
+    best = None
+    for rep in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        _, _, _, iters = slds_svae.optimize_local_meanfield(glob, node, eps, pair_stats=False)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return {"workload": "BASELINE configs[3]: SLDS-SVAE local mean field, K=%d, n=%d, %d sequences x T=%d" % (K, n, B, T),
+            "ms_per_ascent": 1e3 * best, "sweeps_max": int(iters.max()), "sweeps_mean": float(iters.double().mean()),
+            "value": B / best, "unit": "sequences/s", "kernel": "svae::lds_estep_twoend_kernel<10,true,false,true> + svae::hmm_estep_kernel<8>"}
+
+
+def measure_gmm(dev, K=5, N=2, T=1000):
+    """BASELINE configs[0]: GMM mean-field fixed point, K = 5, 2-D, 1000 points: us per fixed point."""
+    from svae_amd.distributions import expfam
+    from svae_amd.models import gmm
+    gen = torch.Generator().manual_seed(K)
+    d, niws = gmm.init_pgm_param(K, N, alpha=0.05 / K, niw_conc=0.5, random_scale=3., generator=gen)
+    lg, gg = expfam.dirichlet_expectedstats(d).to(dev), expfam.niw_expectedstats(niws).to(dev)
+    rng = np.random.default_rng(0)
+    node = (torch.as_tensor(-0.5 * np.log1p(np.exp(rng.standard_normal((T, N)))), device=dev),
+            torch.as_tensor(3. * rng.standard_normal((T, N)), device=dev))
+    init = gmm.initialize_meanfield(T, K, dev, torch.Generator(device=dev).manual_seed(1))
+    o = gmm.meanfield_from_globals(lg, gg, node, init)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 20
+    e0.record()
+    for _ in range(reps):
+        o = gmm.meanfield_from_globals(lg, gg, node, init, check=False)
+    e1.record(); torch.cuda.synchronize()
+    us = 1e3 * e0.elapsed_time(e1) / reps
+    return {"workload": "BASELINE configs[0]: GMM mean-field fixed point, K=%d, %d-D, %d points" % (K, N, T),
+            "us_per_fixed_point": us, "sweeps": int(o["iters"]), "value": T / us * 1e6, "unit": "points/s"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -236,6 +314,13 @@ def main():
                                   "roofline": roofline(lib, eT, en, eB, km)})
                 except Exception as e:  # the headline line must survive
                     extra.append({"workload": what, "error": repr(e)})
+                torch.cuda.empty_cache()
+            # the other BASELINE configurations and the training path: measured beside `value`, never instead of it
+            for fn in (lambda: measure_training_path(dev, T, n, B), lambda: measure_slds(dev), lambda: measure_gmm(dev)):
+                try:
+                    extra.append(fn())
+                except Exception as e:
+                    extra.append({"error": repr(e)})
                 torch.cuda.empty_cache()
             out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
