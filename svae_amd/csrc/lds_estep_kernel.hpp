@@ -590,9 +590,82 @@ __global__ __launch_bounds__(64) void lds_sample_kernel(const SampleArgs a) {
   }
 }
 
+// Few samples per sequence (S <= 4, the training step's S = 1): lanes are VECTOR COMPONENTS instead (lane c holds
+// x[c]), one register per sample.  Per step and sample: z = D^-1/2 eps locally; the back substitution with L'
+// column by column (y_i final -> every lane j < i subtracts L[i][j] y_i: one fenced DPP FMA per column, the
+// factor read transposed by the addressing: lane c loads row c of the stored factor block = column c of L);
+// the mean term with x_{t+1}[j] as the broadcast operand.  ~25 instructions per step and sample instead of
+// ~165 for a 16-sample pass whose lanes would be mostly idle.
+template <int N>
+__global__ __launch_bounds__(64) void lds_sample_vec_kernel(const SampleArgs a) {
+  constexpr int HS = ws_h_stride(N), WS = ws_step_doubles(N);
+  constexpr int SMAX = 4;
+  const int lane = threadIdx.x;
+  const int c = lane & 15;
+  const int brow = blockIdx.x * 4 + (lane >> 4);
+  const bool valid = brow < a.B;
+  const int b = valid ? brow : a.B - 1;
+  const bool col = c < N;
+  const int cc = col ? c : 0;
+  const int T = a.T, S = a.S;
+  const double* wsb = a.ws + (long)b * ws_seq_doubles(N, T) + ws_zpage_doubles(N);
+  const double* ws2b = a.ws2 + ((long)b * T) * (N * N + N);
+  const bool st = valid && col;
+
+  double X[SMAX];                              // x_{t+1}[c] per sample
+  static_for<0, SMAX>([&](auto s) { X[s] = 0.0; });
+  // Operands are fetched NST steps ahead into a ring of register stages: the records were written by the
+  // E-step ~T steps earlier and come from HBM / the memory-side cache, further away than one step of arithmetic
+  // (one stage ahead: 0.76 us per step, the load latency; the arithmetic is ~0.25 us).
+  constexpr int NST = N <= 10 ? 3 : 2;
+  struct Stage { double H[N + 1], L[N], pv, E[SMAX]; };
+  Stage ring[NST];
+  auto fetch = [&](Stage& g, int t) {
+    const double* w2 = ws2b + (long)t * (N * N + N);
+    load_row<N + 1>(wsb + (long)t * WS + cc * HS, g.H);                  // H[j] = [P^-1 J12 | c][c][j]
+    static_for<0, N>([&](auto i) { g.L[i] = w2[cc * N + i]; });          // factor block row c: lane i of register c = L[i][c]
+    g.pv = w2[N * N + cc];
+    static_for<0, SMAX>([&](auto s) { g.E[s] = a.eps[(((long)b * T + t) * S + (s < S ? s : S - 1)) * N + cc]; });
+  };
+  static_for<0, NST>([&](auto q) { fetch(ring[q], T - 1 - q > 0 ? T - 1 - q : 0); });
+  for (int t0 = T - 1; t0 >= 0; t0 -= NST) {
+    static_for<0, NST>([&](auto q) {
+      const int t = t0 - q;
+      if (t >= 0) {
+        double H[N + 1], Lc[N], Y[SMAX];
+        static_for<0, N + 1>([&](auto k) { H[k] = col ? ring[q].H[k] : 0.0; });
+        static_for<0, N>([&](auto i) { Lc[i] = (c < i && col) ? ring[q].L[i] : 0.0; });   // L[i][c] below the diagonal only
+        const double dis = rsqrt_nr(col ? ring[q].pv : 1.0);
+        static_for<0, SMAX>([&](auto s) { Y[s] = col ? dis * ring[q].E[s] : 0.0; });
+        fetch(ring[q], t - NST > 0 ? t - NST : 0);
+        dpp_fence(X);
+        dpp_fence(Y);
+        static_for<0, SMAX>([&](auto s) {
+          if (s < S) {
+            // y = L^-T z: columns N-1 .. 1
+            static_for<1, N>([&](auto jj) {
+              constexpr int i = N - jj;
+              mac_bc<i, true, true>(Y[s], Y[s], Lc[i]);
+            });
+            // x_t = y + c_t - (P^-1 J12) x_{t+1}
+            double acc0 = Y[s] + H[N], acc1 = 0.0;
+            static_for<0, N>([&](auto j) {
+              if constexpr (j % 2 == 0) mac_bc<j, true>(acc0, X[s], H[j]); else mac_bc<j, true>(acc1, X[s], H[j]);
+            });
+            const double xt = acc0 + acc1;
+            if (st) a.samples[(((long)b * T + t) * S + s) * N + c] = xt;
+            X[s] = xt;
+          }
+        });
+      }
+    });
+  }
+}
+
 template <int N>
 static int launch_sample(const SampleArgs& a, hipStream_t stream) {
-  hipLaunchKernelGGL((lds_sample_kernel<N>), dim3((a.B + 3) / 4), dim3(64), 0, stream, a);
+  if (a.S <= 4) hipLaunchKernelGGL((lds_sample_vec_kernel<N>), dim3((a.B + 3) / 4), dim3(64), 0, stream, a);
+  else hipLaunchKernelGGL((lds_sample_kernel<N>), dim3((a.B + 3) / 4), dim3(64), 0, stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
