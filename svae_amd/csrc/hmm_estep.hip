@@ -105,7 +105,7 @@ __global__ __launch_bounds__(64) void hmm_estep_kernel(const HmmArgs a) {
     double cs = 0.0;
     dpp_fence(al);
     static_for<0, K>([&](auto k) { mac_bc<k, false, true>(cs, al, one); });            // c_t = sum_k
-    double rc = 1.0 / cs;
+    double rc = rcp_nr(cs);                 // (v_rcp_f64 + two Newton steps: no fp64 divide on the serial chain)
     double u_st = e * rc, shift = m + (t > 0 ? pmax : 0.0), flag = 0.0;
     const bool tiny = !(cs > HMM_TINY);
     if (__any(tiny)) {
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(64) void hmm_estep_kernel(const HmmArgs a) {
       static_for<0, K>([&](auto k) { cs2 += bcast<k>(al2); });
       if (tiny) {
         cs = cs2;
-        rc = 1.0 / cs2;
+        rc = rcp_nr(cs2);
         al = al2;
         shift = M;
         flag = 1.0;

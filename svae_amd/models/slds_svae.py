@@ -19,6 +19,7 @@ import torch
 
 from .. import _lib
 from ..distributions import expfam
+from ..parallel import allreduce_nested
 from ..hmm.hmm_inference import hmm_estep, hmm_logZ_differentiable
 from ..lds.lds_inference import (LDSEStepPlan, lds_inference_differentiable, natural_lds_estep_general,
                                      natural_lds_inference_general)
@@ -378,9 +379,11 @@ def global_stats_as_natparam(stats):
 
 
 def run_inference(prior_natparam, global_natparam, nn_potentials, num_samples, init_eps=None, eps=None,
-                  generator=None, tol=1e-2):
+                  generator=None, tol=1e-2, group=None):
     """(:289-310) -> (samples (B,T,S,n), expected_stats, global_vlb, local_vlb); forward values only
-    (see run_inference_differentiable)."""
+    (see run_inference_differentiable).  Under torch.distributed the sequences are this rank's shard (every
+    sequence runs its own coordinate ascent: no collective inside it); the statistics and local_vlb are summed
+    over the ranks of `group` with ONE all-reduce."""
     dev = nn_potentials[1].device
     node = tuple(_dev64(x, dev) for x in nn_potentials)
     B, T, n = node[1].shape
@@ -399,6 +402,7 @@ def run_inference(prior_natparam, global_natparam, nn_potentials, num_samples, i
     expected_stats = get_global_stats(hmm_stats, (Ei[0], Ei[1]), plan.E_pair)
     lds_vlb = lognorm - ((node[0] * En[0]).sum((1, 2)) + (node[1] * En[1]).sum((1, 2)))
     local_vlb = (hmm_vlb + lds_vlb).sum()
+    expected_stats, local_vlb = allreduce_nested(expected_stats, local_vlb, group)
     global_vlb = slds_prior_vlb(global_natparam, prior_natparam, dev)
     return samples, expected_stats, global_vlb, local_vlb
 
@@ -451,7 +455,7 @@ def final_pass_differentiable(global_natparam, hmm_natparam, lds_natparam, nn_po
 
 
 def run_inference_differentiable(prior_natparam, global_natparam, nn_potentials, num_samples, init_eps=None,
-                                 eps=None, generator=None, tol=1e-2):
+                                 eps=None, generator=None, tol=1e-2, group=None):
     """run_inference (slds_svae.py:289-310) with torch autograd attached to nn_potentials = (J, h),
     each (B,T,n): the local mean field is optimised on detached values (the reference's `unbox`),
     then the final pass is differentiated through the E-step / sampler VJP kernels and the HMM
@@ -468,6 +472,7 @@ def run_inference_differentiable(prior_natparam, global_natparam, nn_potentials,
         global_natparam, hmm_nat, lds_nat, (nn_potentials[0], nn_potentials[1]), _dev64(eps, dev))
     expected_stats = get_global_stats(hmm_stats, tuple(x.detach() for x in init_stats),
                                       tuple(x.detach() for x in pair_stats))
+    expected_stats, local_vlb = allreduce_nested(expected_stats, local_vlb, group)
     global_vlb = slds_prior_vlb(global_natparam, prior_natparam, dev)
     return samples, expected_stats, global_vlb, local_vlb
 

@@ -29,6 +29,43 @@ def shard_bounds(num_items, rank=None, world=None):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def allreduce_nested(struct, scalar=None, group=None):
+    """ONE all-reduce (sum) of every tensor leaf of a nested tuple/list `struct` plus an optional scalar tensor:
+    the leaves are packed into one buffer, reduced, and unpacked into the same nesting (the exchange step of the
+    SLDS model: svae/models/slds_svae.py:229-243 statistics are sums over sequences).  Returns (struct, scalar);
+    the scalar carries the global VALUE and, if it is on the autograd tape, this rank's gradient.  No-op without
+    a process group."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return struct, scalar
+    leaves = []
+
+    def walk(s):
+        if isinstance(s, (tuple, list)):
+            for x in s:
+                walk(x)
+        else:
+            leaves.append(s)
+    walk(struct)
+    parts = [x.detach().reshape(-1).to(torch.float64) for x in leaves]
+    if scalar is not None:
+        parts.append(scalar.detach().reshape(1).to(torch.float64))
+    packed = torch.cat(parts)
+    allreduce_global_stats(packed, group)
+    pos = [0]
+
+    def build(s):
+        if isinstance(s, (tuple, list)):
+            return tuple(build(x) for x in s)
+        k = s.numel()
+        out = packed[pos[0]:pos[0] + k].reshape(s.shape)
+        pos[0] += k
+        return out
+    out = build(struct)
+    if scalar is not None:
+        scalar = scalar + (packed[-1] - scalar.detach())
+    return out, scalar
+
+
 def allreduce_lds_stats(reduced, local_kl, n, T, group=None, return_packed=False):
     """The exchange step of the LDS model (svae/models/lds.py:35-52 with B sequences per rank).
 

@@ -239,3 +239,45 @@ def test_sweep_protocol_single_process_matches_the_fixed_point():
         np.testing.assert_allclose(be.r, ls, rtol=1e-12, atol=1e-14)
         np.testing.assert_allclose(be.niw_stats, ns, rtol=1e-12, atol=1e-12)
         assert be.kl == pytest.approx(kl, rel=1e-12)
+
+
+def _nested_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from svae_amd.parallel import allreduce_nested
+        K, n = 3, 2
+        f = lambda *shape: torch.full(shape, 1.0 + rank, dtype=torch.float64)
+        stats = ((f(K), f(K, K)), ((f(K, n, n), f(K, n), f(K), f(K)), (f(K, n, n), f(K, n, n), f(K, n, n), f(K))))   # get_global_stats nesting
+        w = torch.ones((), dtype=torch.float64, requires_grad=True)
+        out, vlb = allreduce_nested(stats, w * (10.0 + rank))
+        vlb.backward()
+        leaves = []
+        def walk(s):
+            for x in s:
+                walk(x) if isinstance(x, tuple) else leaves.append(x)
+        walk(out)
+        q.put((rank, [float(x.min()) for x in leaves], [tuple(x.shape) for x in leaves], float(vlb.detach()), float(w.grad)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_nested_allreduce_of_the_slds_statistics():
+    """The SLDS exchange step (models.slds_svae.run_inference(group=...)): every leaf of the nested statistics
+    and the local bound summed over ranks in ONE collective, nesting and shapes preserved, gradient local."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nested_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=100) for _ in range(world)]
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    for rank, mins, shapes, vlb, grad in got:
+        assert all(m == 3.0 for m in mins)                       # 1 + 2 in every entry
+        assert shapes == [(3,), (3, 3), (3, 2, 2), (3, 2), (3,), (3,), (3, 2, 2), (3, 2, 2), (3, 2, 2), (3,)]
+        assert vlb == 21.0 and grad == 10.0 + rank               # global value, this rank's gradient
