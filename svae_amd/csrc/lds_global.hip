@@ -34,14 +34,14 @@ __device__ inline double digamma_pos(double x) {
 // sum_{i<n} psi((nu - i)/2)  and  multigammaln(nu/2, n)  (scipy.special.multigammaln): every thread returns both
 __device__ inline void wishart_terms(double nu, int n, double* red, double& psi_sum, double& mgl) {
   double a = 0.0, b = 0.0;
-  for (int i = threadIdx.x; i < n; i += GL_BLOCK) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
     a += digamma_pos(0.5 * (nu - i));
     b += lgamma(0.5 * (nu - i));
   }
   red[threadIdx.x] = a;
   red[GL_BLOCK + threadIdx.x] = b;
   __syncthreads();
-  for (int s = GL_BLOCK / 2; s > 0; s >>= 1) {
+  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
     if (threadIdx.x < s) { red[threadIdx.x] += red[threadIdx.x + s]; red[GL_BLOCK + threadIdx.x] += red[GL_BLOCK + threadIdx.x + s]; }
     __syncthreads();
   }
@@ -61,12 +61,12 @@ __device__ inline double spd_inverse(double* M, int n, int ld, double* rowk, dou
     if (!(p > 0.0) && threadIdx.x == 0) *bad = 1;
     logdet += log(p);
     const double pinv = 1.0 / p;
-    for (int j = threadIdx.x; j < n; j += GL_BLOCK) {
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
       rowk[j] = (j == k) ? pinv : M[k * ld + j] * pinv;
       colk[j] = (j == k) ? 0.0 : M[j * ld + k];
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < n * n; e += GL_BLOCK) {
+    for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
       const int i = e / n, j = e % n;
       double v;
       if (i == k) v = rowk[j];
@@ -80,7 +80,7 @@ __device__ inline double spd_inverse(double* M, int n, int ld, double* rowk, dou
 }
 
 __device__ inline void symmetrize(double* M, int n, int ld) {
-  for (int e = threadIdx.x; e < n * n; e += GL_BLOCK) {
+  for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
     const int i = e / n, j = e % n;
     if (i < j) { const double v = 0.5 * (M[i * ld + j] + M[j * ld + i]); M[i * ld + j] = v; M[j * ld + i] = v; }
   }
@@ -133,9 +133,9 @@ __global__ __launch_bounds__(GL_BLOCK) void lds_global_kernel(const GlobalArgs a
     const double nu2 = q ? a.p_md[0] : a.md[0];
     // ---- NIW: S = A - b m', m = b / kappa -----------------------------------------------------------
     const double kappa = niw[n * D + n], nu = niw[(n + 1) * D + n + 1];
-    for (int j = tid; j < n; j += GL_BLOCK) v0[j] = niw[j * D + n] / kappa;          // m
+    for (int j = tid; j < n; j += blockDim.x) v0[j] = niw[j * D + n] / kappa;          // m
     __syncthreads();
-    for (int e = tid; e < n * n; e += GL_BLOCK) {
+    for (int e = tid; e < n * n; e += blockDim.x) {
       const int i = e / n, j = e % n;
       W0[e] = niw[i * D + j] - niw[i * D + n] * v0[j];
     }
@@ -147,9 +147,9 @@ __global__ __launch_bounds__(GL_BLOCK) void lds_global_kernel(const GlobalArgs a
     const double niw_logZ = 0.5 * n * nu * 0.69314718055994530942 + mgl - 0.5 * nu * logdetS - 0.5 * n * log(kappa);
     if (q == 0) {
       // E_J = nu S^-1 + fudge I;  E_h = E_J m;  E_hTJinvh = n / kappa + m' E_h;  E_logdetJ = psi + n log 2 - logdet S
-      for (int e = tid; e < n * n; e += GL_BLOCK) W0[e] = nu * W0[e] + ((e / n == e % n) ? GL_FUDGE : 0.0);
+      for (int e = tid; e < n * n; e += blockDim.x) W0[e] = nu * W0[e] + ((e / n == e % n) ? GL_FUDGE : 0.0);
       __syncthreads();
-      for (int i = tid; i < n; i += GL_BLOCK) {
+      for (int i = tid; i < n; i += blockDim.x) {
         double s = 0.0;
         for (int j = 0; j < n; ++j) s = __builtin_fma(W0[i * n + j], v0[j], s);
         v1[i] = s;                                                                   // E_h
@@ -159,13 +159,13 @@ __global__ __launch_bounds__(GL_BLOCK) void lds_global_kernel(const GlobalArgs a
       for (int j = 0; j < n; ++j) mEh = __builtin_fma(v0[j], v1[j], mEh);
       const double es_c = -0.5 * ((double)n / kappa + mEh);                           // -1/2 E[h' J^-1 h]
       const double es_d = 0.5 * (psi + n * 0.69314718055994530942 - logdetS);         // 1/2 E[log |J|]
-      for (int e = tid; e < n * n; e += GL_BLOCK) {
+      for (int e = tid; e < n * n; e += blockDim.x) {
         const double val = -0.5 * W0[e];
         a.init_J[e] = val;
         if (a.niw_es) a.niw_es[(e / n) * D + (e % n)] = val;
         if (a.p_niw) es_dot = __builtin_fma(a.p_niw[(e / n) * D + (e % n)] - a.niw[(e / n) * D + (e % n)], val, es_dot);
       }
-      for (int j = tid; j < n; j += GL_BLOCK) {
+      for (int j = tid; j < n; j += blockDim.x) {
         a.init_h[j] = v1[j];
         if (a.niw_es) a.niw_es[j * D + n] = v1[j];
         if (a.p_niw) es_dot = __builtin_fma(a.p_niw[j * D + n] - a.niw[j * D + n], v1[j], es_dot);
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(GL_BLOCK) void lds_global_kernel(const GlobalArgs a
         if (a.p_niw) es_dot += (a.p_niw[n * D + n] - kappa) * es_c + (a.p_niw[(n + 1) * D + n + 1] - nu) * es_d;
       }
       if (a.niw_es) {   // the structurally zero entries of the dense packing
-        for (int e = tid; e < D * D; e += GL_BLOCK) {
+        for (int e = tid; e < D * D; e += blockDim.x) {
           const int i = e / D, j = e % D;
           const bool used = (i < n && j <= n) || (i == j);
           if (!used) a.niw_es[e] = 0.0;
@@ -185,18 +185,18 @@ __global__ __launch_bounds__(GL_BLOCK) void lds_global_kernel(const GlobalArgs a
       __syncthreads();
     }
     // ---- MNIW (A, B, C, d): K = sym(A^-1), M = (K B)', S = C - M B --------------------------------------
-    for (int e = tid; e < n * n; e += GL_BLOCK) W1[e] = mA[e];
+    for (int e = tid; e < n * n; e += blockDim.x) W1[e] = mA[e];
     __syncthreads();
     const double logdetA = spd_inverse(W1, n, n, rowk, colk, &bad);                   // W1 = K
     symmetrize(W1, n, n);
-    for (int e = tid; e < n * n; e += GL_BLOCK) {                                     // W2 = M' = K B   (M[i][j] = W2[j][i])
+    for (int e = tid; e < n * n; e += blockDim.x) {                                     // W2 = M' = K B   (M[i][j] = W2[j][i])
       const int i = e / n, j = e % n;
       double s = 0.0;
       for (int k = 0; k < n; ++k) s = __builtin_fma(W1[i * n + k], mB[k * n + j], s);
       W2[e] = s;
     }
     __syncthreads();
-    for (int e = tid; e < n * n; e += GL_BLOCK) {                                     // W3 = S = C - M B
+    for (int e = tid; e < n * n; e += blockDim.x) {                                     // W3 = S = C - M B
       const int i = e / n, j = e % n;
       double s = mC[e];
       for (int k = 0; k < n; ++k) s = __builtin_fma(-W2[k * n + i], mB[k * n + j], s);
@@ -211,14 +211,14 @@ __global__ __launch_bounds__(GL_BLOCK) void lds_global_kernel(const GlobalArgs a
     if (q == 0) {
       logZ_g = niw_logZ + mniw_logZ;
       // SinvM = S^-1 M  -> W0 ;  E_Sigmainv_A = nu SinvM ;  E_AT_Sigmainv_A = n K + nu sym(M' SinvM) + fudge I
-      for (int e = tid; e < n * n; e += GL_BLOCK) {
+      for (int e = tid; e < n * n; e += blockDim.x) {
         const int i = e / n, j = e % n;
         double s = 0.0;
         for (int k = 0; k < n; ++k) s = __builtin_fma(W3[i * n + k], W2[j * n + k], s);   // M[k][j] = W2[j][k]
         W0[e] = s;
       }
       __syncthreads();
-      for (int e = tid; e < n * n; e += GL_BLOCK) {
+      for (int e = tid; e < n * n; e += blockDim.x) {
         const int i = e / n, j = e % n;
         double sij = 0.0, sji = 0.0;                                                   // (M' SinvM)[i][j] and [j][i]
         for (int k = 0; k < n; ++k) {
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(GL_BLOCK) void lds_global_kernel(const GlobalArgs a
   if (a.global_kl && a.p_niw) {
     red[tid] = es_dot;
     __syncthreads();
-    for (int s = GL_BLOCK / 2; s > 0; s >>= 1) {
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
       if (tid < s) red[tid] += red[tid + s];
       __syncthreads();
     }
@@ -314,6 +314,8 @@ extern "C" int svae_lds_global_step_f64(int n, const double* niw, const double* 
                                   sizeof(double))) != hipSuccess) return -1001;
     attr = true;
   }
+  // (80 us at n = 10: ~60 serial pivot steps of log / divide / two barriers; one wavefront instead of four was
+  //  measured slower, 93 us.  It does not depend on the minibatch and overlaps the recognition network.)
   hipLaunchKernelGGL(svae::lds_global_kernel, dim3(1), dim3(svae::GL_BLOCK), lds, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
