@@ -20,8 +20,11 @@
 
 namespace svae {
 
-constexpr int TV_LD = 66;                 // LDS row stride in doubles (16-byte aligned rows, 2-way conflicts at most)
-constexpr int TV_MAT = 64 * TV_LD;        // one matrix buffer
+// LDS matrices: row stride ld = n4 + 2 doubles (16-byte aligned rows, 2-way bank conflicts at most), one buffer
+// = n4 * ld doubles (n4 = n rounded up to 4): 33.8 KB at n = 64, 8.7 KB at n = 32 -- sized at launch, so that
+// smaller latent dimensions fit several workgroups per CU
+__host__ __device__ constexpr int tv_ld(int n4) { return n4 + 2; }
+__host__ __device__ constexpr int tv_mat(int n4) { return n4 * (n4 + 2); }
 constexpr int TV_MAX_S = 16;
 
 struct TileVjpArgs {
@@ -48,6 +51,7 @@ __device__ __forceinline__ void acc_zero(Acc& a) {
 
 // acc += A B for this thread's 4 x 4 block (rows 4 ty.., columns 4 tx..); A, B in LDS; k < n4 (multiple of 4)
 __device__ __forceinline__ void gemm_nn(const double* A, const double* Bm, int n4, int ty, int tx, Acc& acc) {
+  const int TV_LD = tv_ld(n4);
   if (4 * ty >= n4 || 4 * tx >= n4) return;
   const double* ap = A + (4 * ty) * TV_LD;
   const double* bp = Bm + 4 * tx;
@@ -79,6 +83,7 @@ __device__ __forceinline__ void gemm_nn(const double* A, const double* Bm, int n
 // flight per thread, 512 contiguous bytes per row across the 16 tx (no index divisions).
 template <bool TRANS>
 __device__ __forceinline__ void load_mat(double* dst, const double* src, int gld, int n, int n4, double scale) {
+  const int TV_LD = tv_ld(n4);
   const int ty = threadIdx.x >> 4, c0 = 4 * (threadIdx.x & 15);
   if (c0 >= n4) return;
   double v[4][4];
@@ -102,6 +107,7 @@ __device__ __forceinline__ void load_mat(double* dst, const double* src, int gld
 
 // LDS matrix -> global n x n (dense, row stride n), same thread mapping as load_mat
 __device__ __forceinline__ void store_mat(double* dst, const double* src, int n) {
+  const int TV_LD = tv_ld((n + 3) & ~3);
   const int ty = threadIdx.x >> 4, c0 = 4 * (threadIdx.x & 15);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -113,6 +119,7 @@ __device__ __forceinline__ void store_mat(double* dst, const double* src, int n)
 }
 
 __device__ __forceinline__ void store_block(double* dst, const Acc& a, int ty, int tx, int n4, bool trans) {
+  const int TV_LD = tv_ld(n4);
   if (4 * ty >= n4 || 4 * tx >= n4) return;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -125,6 +132,7 @@ __device__ __forceinline__ void store_block(double* dst, const Acc& a, int ty, i
 
 // in place: M <- (M + M') / 2 on the n4 x n4 LDS matrix (barriers inside); each thread handles its 4 x 4 block
 __device__ __forceinline__ void symmetrize_lds(double* M, int n4) {
+  const int TV_LD = tv_ld(n4);
   const int r0 = 4 * (threadIdx.x >> 4), c0 = 4 * (threadIdx.x & 15);
   const bool on = r0 < n4 && c0 < n4;
   __syncthreads();
@@ -148,6 +156,7 @@ __device__ __forceinline__ void symmetrize_lds(double* M, int n4) {
 // y[i] = sum_j A[i][j] x[j]  (TRANS: A[j][i]) for i < n; A in LDS; x, y LDS vectors (y != x); barrier after
 template <bool TRANS>
 __device__ __forceinline__ void matvec(const double* A, const double* x, double* y, int n) {
+  const int TV_LD = tv_ld((n + 3) & ~3);
   for (int i = threadIdx.x; i < n; i += 256) {
     double s = 0.0;
     for (int j = 0; j < n; ++j) s = __builtin_fma(TRANS ? A[j * TV_LD + i] : A[i * TV_LD + j], x[j], s);
@@ -163,8 +172,9 @@ __device__ __forceinline__ const double* handoff(const TileVjpArgs& a, int b, in
 // ---- phase 0 ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void tile_vjp_phase0(const TileVjpArgs a) {
   extern __shared__ double sm[];
-  double *L0 = sm, *L1 = sm + TV_MAT, *L3 = sm + 2 * TV_MAT;
   const int b = blockIdx.x, n = a.n, n4 = (n + 3) & ~3, NP = a.NP, T = a.T;
+  const int TV_MAT = tv_mat(n4);
+  double *L0 = sm, *L1 = sm + TV_MAT, *L3 = sm + 2 * TV_MAT;
   const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
   load_mat<false>(L3, handoff(a, b, T - 1) + (long)NP * NP, NP, n, n4, 1.0);
   __syncthreads();
@@ -201,12 +211,13 @@ __global__ __launch_bounds__(256) void tile_vjp_phase0(const TileVjpArgs a) {
 // ---- phase 1 ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void tile_vjp_phase1(const TileVjpArgs a) {
   extern __shared__ double sm[];
+  const int b = blockIdx.x, n = a.n, n4 = (n + 3) & ~3, NP = a.NP, T = a.T, S = a.g_samples ? a.S : 0;
+  const int TV_LD = tv_ld(n4), TV_MAT = tv_mat(n4);
   double *L0 = sm, *L1 = sm + TV_MAT, *L2 = sm + 2 * TV_MAT, *L3 = sm + 3 * TV_MAT;
   double* vec = sm + 4 * TV_MAT;          // mb (64) | tmp (64) | mnext (64) | xb (S x 64) | xtmp (S x 64) | xnext (S x 64)
   double *mb = vec, *tmpv = vec + 64, *mnext = vec + 128, *xb = vec + 192, *xtmp = xb + TV_MAX_S * 64, *xnext = xtmp + TV_MAX_S * 64;
-  const int b = blockIdx.x, n = a.n, n4 = (n + 3) & ~3, NP = a.NP, T = a.T, S = a.g_samples ? a.S : 0;
   const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
-  for (int e = threadIdx.x; e < 64 * TV_LD; e += 256) L3[e] = 0.0;             // Sigma_bar
+  for (int e = threadIdx.x; e < TV_MAT; e += 256) L3[e] = 0.0;                 // Sigma_bar
   for (int e = threadIdx.x; e < 192 + 3 * TV_MAX_S * 64; e += 256) vec[e] = 0.0;
   __syncthreads();
   for (int t = 0; t < T; ++t) {
@@ -300,13 +311,14 @@ __global__ __launch_bounds__(256) void tile_vjp_phase1(const TileVjpArgs a) {
 // ---- phase 2 ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void tile_vjp_phase2(const TileVjpArgs a) {
   extern __shared__ double sm[];
+  const int b = blockIdx.x, n = a.n, n4 = (n + 3) & ~3, NP = a.NP, T = a.T;
+  const int TV_LD = tv_ld(n4), TV_MAT = tv_mat(n4);
   double *L0 = sm, *L1 = sm + TV_MAT, *L2 = sm + 2 * TV_MAT, *L3 = sm + 3 * TV_MAT;
   double* vec = sm + 4 * TV_MAT;          // hb | cb | Pc | tmp
   double *hb = vec, *cb = vec + 64, *Pc = vec + 128, *tmpv = vec + 192;
-  const int b = blockIdx.x, n = a.n, n4 = (n + 3) & ~3, NP = a.NP, T = a.T;
   const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
   const double gl = a.g_lognorm[b];
-  for (int e = threadIdx.x; e < 64 * TV_LD; e += 256) L3[e] = 0.0;             // J_bar of step t + 1
+  for (int e = threadIdx.x; e < TV_MAT; e += 256) L3[e] = 0.0;                 // J_bar of step t + 1
   for (int e = threadIdx.x; e < 256; e += 256) vec[e] = 0.0;
   __syncthreads();
   for (int t = T - 1; t >= 0; --t) {
@@ -470,13 +482,16 @@ extern "C" int svae_lds_tile_vjp_f64(int phase, int B, int T, int n, int S, int 
   a.xbar = w;
   a.g_node_J = g_node_J; a.g_node_h = g_node_h;
   hipStream_t s = (hipStream_t)stream;
-  const size_t lds0 = (size_t)3 * svae::TV_MAT * sizeof(double);
-  const size_t lds12 = (size_t)(4 * svae::TV_MAT + 192 + 3 * svae::TV_MAX_S * 64) * sizeof(double);
+  const int n4 = (n + 3) & ~3;
+  const size_t lds0 = (size_t)3 * svae::tv_mat(n4) * sizeof(double);
+  const size_t lds12 = (size_t)(4 * svae::tv_mat(n4) + 192 + 3 * svae::TV_MAX_S * 64) * sizeof(double);
+  const size_t lds0_max = (size_t)3 * svae::tv_mat(64) * sizeof(double);
+  const size_t lds12_max = (size_t)(4 * svae::tv_mat(64) + 192 + 3 * svae::TV_MAX_S * 64) * sizeof(double);
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(svae::tile_vjp_phase0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(svae::tile_vjp_phase1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds12) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(svae::tile_vjp_phase2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds12) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(svae::tile_vjp_phase0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0_max) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(svae::tile_vjp_phase1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds12_max) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(svae::tile_vjp_phase2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds12_max) != hipSuccess)
       return -1001;
     attr = true;
   }
