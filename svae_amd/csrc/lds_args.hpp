@@ -31,12 +31,11 @@ constexpr int TE_MIN_T = 4;
 // MIX launches of the two-ended kernel (K parameter sets mixed per step, svae_slds_lds_meanfield_f64): LDS
 // tables of 16-byte entries (two states each), see lds_estep_twoend.hpp
 constexpr int te_mix_nxl(int n) { return 15 - n; }                 // right-hand-side lanes n..14
-constexpr int te_mix_ent_ex(int n) { return 4 * te_mix_nxl(n) + 1; }
-constexpr int te_mix_ent_nj(int n) { return 2 * n + 1; }
+constexpr int te_mix_ent_j(int n) { return 4 * te_mix_nxl(n) + 2 * n + 1; }   // J12 table: rhs lanes | Schur-operand lanes | zero
 constexpr int te_mix_ent_c(int n) { return 4 * n + 1; }
 constexpr long te_mix_lds_bytes(int n, int K) {
   const int kp2 = (K + 1) / 2, j = (n + 1) / 2, nc2 = (n + 1) / 2;
-  return 16L * (kp2 * (n * te_mix_ent_ex(n) + n * te_mix_ent_nj(n) + 2 * j * te_mix_ent_c(n)) + 4 * j * 2 * nc2 * 16);
+  return 16L * (kp2 * (n * te_mix_ent_j(n) + 2 * j * te_mix_ent_c(n)) + 4 * j * 2 * nc2 * 16);
 }
 constexpr int TE_MIX_MAX_K = 16;
 constexpr long TE_MIX_MAX_LDS = 160 * 1024;

@@ -179,26 +179,26 @@ __global__ __launch_bounds__(MIX ? 512 : 64) void lds_estep_twoend_kernel(const 
   const double EN = (c == N) ? 1.0 : 0.0;
 
   // ---- MIX: the K parameter sets as LDS tables, one 16-byte entry = states (2kp, 2kp+1) -----------------
-  //   t_ex[kp][i][ENT_EX]  right-hand-side lanes: -J12'_k[i][x]           (entry (dir*2+gl)*NXL + c-N)
-  //   t_nj[kp][k'][ENT_NJ] lanes < N: nat J12'_k[k'][c]                   (entry dir*N + c)
+  //   t_j[kp][i][ENT_J]    ONE table for the two places J12' enters a step, whose lanes are disjoint:
+  //                        right-hand-side lanes: -J12'_k[i][x]          (entry (dir*2+gl)*NXL + c-N)
+  //                        lanes < N (Schur operand): nat J12'_k[i][c]   (entry 4 NXL + dir*N + c)
   //   t_22, t_11[kp][j][ENT_C]  lanes < N: -2 q22_k / -2 q11_k [2j+gl][c] (entry (dir*2+gl)*N + c)
   //   the last entry of every row is zero (lanes with nothing to add);
   //   ct[blk][j][gl][c/2][16]   entry = (P_k[2j+gl][c], P_k[2j+gl][c+1]) in lane k: blk 0 J11, 1 J22,
   //                             2 J12 transposed (chain A's cross moment), 3 J12 (chain B's)
   constexpr int NXL = te_mix_nxl(N);
-  constexpr int ENT_EX = te_mix_ent_ex(N), ENT_NJ = te_mix_ent_nj(N), ENT_C = te_mix_ent_c(N);
+  constexpr int ENT_J = te_mix_ent_j(N), ENT_C = te_mix_ent_c(N);
   constexpr int NC2 = (N + 1) / 2;
   const int K = MIX ? a.mix_K : 0, KP2 = (K + 1) >> 1;
-  double2* t_ex = te_dyn;
-  double2* t_nj = t_ex + KP2 * N * ENT_EX;
-  double2* t_22 = t_nj + KP2 * N * ENT_NJ;
+  double2* t_j = te_dyn;
+  double2* t_22 = t_j + KP2 * N * ENT_J;
   double2* t_11 = t_22 + KP2 * J * ENT_C;
   double2* ct = t_11 + KP2 * J * ENT_C;
   if constexpr (MIX) {
     auto P = [&](const double* base, int k, int idx) { return k < K ? base[(long)k * N * N + idx] : 0.0; };
     const int nth = blockDim.x, tid = threadIdx.x;
-    for (int q = tid; q < KP2 * N * ENT_EX; q += nth) {
-      const int ent = q % ENT_EX, i = (q / ENT_EX) % N, kp = q / (ENT_EX * N);
+    for (int q = tid; q < KP2 * N * ENT_J; q += nth) {
+      const int ent = q % ENT_J, i = (q / ENT_J) % N, kp = q / (ENT_J * N);
       double2 v = make_double2(0.0, 0.0);
       if (ent < 4 * NXL) {
         const int d = ent / (2 * NXL), r = (ent / NXL) & 1, x = 2 * (ent % NXL) + r;
@@ -206,18 +206,12 @@ __global__ __launch_bounds__(MIX ? 512 : 64) void lds_estep_twoend_kernel(const 
           const int idx = d ? x * N + i : i * N + x;
           v = make_double2(-P(a.J12, 2 * kp, idx), -P(a.J12, 2 * kp + 1, idx));
         }
-      }
-      t_ex[q] = v;
-    }
-    for (int q = tid; q < KP2 * N * ENT_NJ; q += nth) {
-      const int ent = q % ENT_NJ, i = (q / ENT_NJ) % N, kp = q / (ENT_NJ * N);
-      double2 v = make_double2(0.0, 0.0);
-      if (ent < 2 * N) {
-        const int d = ent / N, cq = ent % N;
+      } else if (ent < 4 * NXL + 2 * N) {
+        const int e2 = ent - 4 * NXL, d = e2 / N, cq = e2 % N;
         const int idx = d ? cq * N + i : i * N + cq;
         v = make_double2(P(a.J12, 2 * kp, idx), P(a.J12, 2 * kp + 1, idx));
       }
-      t_nj[q] = v;
+      t_j[q] = v;
     }
     for (int q = tid; q < KP2 * J * ENT_C; q += nth) {
       const int ent = q % ENT_C, j = (q / ENT_C) % J, kp = q / (ENT_C * J);
@@ -257,8 +251,8 @@ __global__ __launch_bounds__(MIX ? 512 : 64) void lds_estep_twoend_kernel(const 
   const bool xok = c >= N && c < HL && xq < N;
   const int xx = xok ? xq : 0;
   // MIX: this lane's table entries (registers and state pairs are immediate offsets from these)
-  const double2* ex_l = t_ex + (xok ? (dir * 2 + gl) * NXL + (c - N) : 4 * NXL);
-  const double2* nj_l = t_nj + (col ? dir * N + c : 2 * N);
+  const double2* tj_l = t_j + (xok ? (dir * 2 + gl) * NXL + (c - N) : (col ? 4 * NXL + dir * N + c : 4 * NXL + 2 * N));
+  const double rmask = xok ? 1.0 : 0.0, jcmask = col ? 1.0 : 0.0;
   const double2* c22_l = t_22 + (col ? (dir * 2 + gl) * N + c : 4 * N);
   const double2* c11_l = t_11 + (col ? (dir * 2 + gl) * N + c : 4 * N);
   const double2* cta_l = ct + gl * NC2 * 16 + c;
@@ -272,22 +266,24 @@ __global__ __launch_bounds__(MIX ? 512 : 64) void lds_estep_twoend_kernel(const 
   // statements are scheduling boundaries for hipcc, so a read written next to its FMAs is issued there and
   // waited for at once (measured: ~90 cycles per read, 7 k cycles per step; tools/te_mix_phase_timing.py).
   auto ror2 = [&](double x) { return __svae_update_dpp_f64(0.0, x, 0x12E, 0xf, 0xf, true); };
-  auto mix2 = [&](auto nreg, auto nent0, auto nent1, auto& acc0, auto& acc1, const double2* t0, const double2* t1,
-                  double w0, double w1) {
-    constexpr int R = decltype(nreg)::value, ENT0 = decltype(nent0)::value, ENT1 = decltype(nent1)::value;
-    double2 va[R], vb[R];
-    static_for<0, R>([&](auto r) { va[r] = t0[r * ENT0]; });
+  // (chunk sizes R0 / R1 registers, ENT entries per register row, STRIDE entries per state pair in both tables)
+  auto mix2 = [&](auto nreg0, auto nreg1, auto nent, auto stride, auto& acc0, auto& acc1, const double2* t0,
+                  const double2* t1, double w0, double w1) {
+    constexpr int R0 = decltype(nreg0)::value, R1 = decltype(nreg1)::value, ENT = decltype(nent)::value,
+                  STRIDE = decltype(stride)::value;
+    double2 va[R0], vb[R1 > 0 ? R1 : 1];
+    static_for<0, R0>([&](auto r) { va[r] = t0[r * ENT]; });
     for (int kp = 0; kp < KP2; ++kp) {
-      static_for<0, R>([&](auto r) { vb[r] = t1[r * ENT1]; });
-      t1 += R * ENT1;
+      static_for<0, R1>([&](auto r) { vb[r] = t1[r * ENT]; });
+      t1 += STRIDE;
       double wf[2] = {w0, w1};
       dpp_fence(wf);
-      static_for<0, R>([&](auto r) { mac_bc<0>(acc0[r], wf[0], va[r].x); });
-      static_for<0, R>([&](auto r) { mac_bc<1>(acc0[r], wf[0], va[r].y); });
-      t0 += (kp + 1 < KP2) ? R * ENT0 : 0;          // last trip: re-reads its own group (unused)
-      static_for<0, R>([&](auto r) { va[r] = t0[r * ENT0]; });
-      static_for<0, R>([&](auto r) { mac_bc<0>(acc1[r], wf[1], vb[r].x); });
-      static_for<0, R>([&](auto r) { mac_bc<1>(acc1[r], wf[1], vb[r].y); });
+      static_for<0, R0>([&](auto r) { mac_bc<0>(acc0[r], wf[0], va[r].x); });
+      static_for<0, R0>([&](auto r) { mac_bc<1>(acc0[r], wf[0], va[r].y); });
+      t0 += (kp + 1 < KP2) ? STRIDE : 0;            // last trip: re-reads its own group (unused)
+      static_for<0, R0>([&](auto r) { va[r] = t0[r * ENT]; });
+      static_for<0, R1>([&](auto r) { mac_bc<0>(acc1[r], wf[1], vb[r].x); });
+      static_for<0, R1>([&](auto r) { mac_bc<1>(acc1[r], wf[1], vb[r].y); });
       w0 = ror2(wf[0]);
       w1 = ror2(wf[1]);
     }
@@ -441,10 +437,19 @@ __global__ __launch_bounds__(MIX ? 512 : 64) void lds_estep_twoend_kernel(const 
     static_for<0, N>([&](auto i) { mac_bc<i>(M[i], ho, EH); });      // lane 15: h_filt = h_pred + h_node
     // B operand of the Schur stage: lanes < N: -J12'[k][c]; lane 15: -h_filt,k
     if constexpr (MIX) {
-      // (the tables are zero in lane 15: the mixing leaves h_filt alone)
-      static_for<0, N>([&](auto k) { Bt[k] = -EH * M[k]; });
-      mix2(std::integral_constant<int, N>{}, std::integral_constant<int, ENT_EX>{}, std::integral_constant<int, ENT_NJ>{},
-           M, Bt, ex_l, nj_l, wq[0], wq[0]);
+      // mixed J12' of this pair, once, for both of its uses (disjoint lanes; zero in lane 15: h_filt is left alone)
+      constexpr int R0 = (N + 1) / 2, R1 = N - R0;
+      double mjA[R0], mjB[R1 > 0 ? R1 : 1];
+      static_for<0, R0>([&](auto r) { mjA[r] = 0.0; });
+      static_for<0, R1>([&](auto r) { mjB[r] = 0.0; });
+      mix2(std::integral_constant<int, R0>{}, std::integral_constant<int, R1>{}, std::integral_constant<int, ENT_J>{},
+           std::integral_constant<int, N * ENT_J>{}, mjA, mjB, tj_l, tj_l + R0 * ENT_J, wq[0], wq[0]);
+      static_for<0, N>([&](auto k) {
+        double mj;
+        if constexpr (k < R0) mj = mjA[k]; else mj = mjB[k - R0];
+        Bt[k] = __builtin_fma(jcmask, mj, -EH * M[k]);
+        M[k] = __builtin_fma(rmask, mj, M[k]);
+      });
     } else {
       static_for<0, N>([&](auto k) { Bt[k] = __builtin_fma(-EH, M[k], NJ12c[k]); });
     }
@@ -460,8 +465,8 @@ __global__ __launch_bounds__(MIX ? 512 : 64) void lds_estep_twoend_kernel(const 
     double AnD[J];
     if constexpr (MIX) {
       static_for<0, J>([&](auto j) { AnD[j] = 0.0; });
-      mix2(std::integral_constant<int, J>{}, std::integral_constant<int, ENT_C>{}, std::integral_constant<int, ENT_C>{},
-           AnD, AnD, c22_l, c11_l, wq[0], wq[1]);
+      mix2(std::integral_constant<int, J>{}, std::integral_constant<int, J>{}, std::integral_constant<int, ENT_C>{},
+           std::integral_constant<int, J * ENT_C>{}, AnD, AnD, c22_l, c11_l, wq[0], wq[1]);
     } else {
       static_for<0, J>([&](auto j) { AnD[j] = Cc[j]; });
     }
