@@ -199,6 +199,41 @@ def test_config3_shape_properties(fused):
         _close(got[b], want, 1e-5)
 
 
+def test_config3_full_size_fused_ascent_against_oracle():
+    """BASELINE configs[3] at FULL size (K = 8, latent dim 10, 2048 sequences x T = 500) through the fused LDS
+    mean-field kernel: size-independent properties over the whole batch, and parity of the converged mean field
+    (iteration counts, HMM marginals, bounds, node statistics) for sequences spread over the batch against the
+    NumPy restatement (1e-5; observed 1e-9 .. 1e-7)."""
+    from svae_amd.models import slds_svae
+    K, n, T, B = 8, 10, 500, 2048
+    rng = np.random.default_rng(3)
+    glob = _globals(K, n, rng)
+    J, h = _nodes(B, T, n, rng)
+    eps = rng.standard_normal((B, T, 1, n))
+    dev = torch.device("cuda:0")
+    node = (torch.as_tensor(J, device=dev), torch.as_tensor(h, device=dev))
+    assert slds_svae.SLDSMeanfieldPlan.supported(n, T, K)
+    (hmm_stats, lds_stats), _, (hmm_vlb, lds_vlb), iters = slds_svae.optimize_local_meanfield(
+        glob, node, torch.as_tensor(eps, device=dev), fused=True, pair_stats=False)
+    Ei, Et, Es = hmm_stats
+    assert int(iters.max()) < 100 and int(iters.min()) >= 1
+    assert torch.allclose(Es.sum(-1), torch.ones_like(Es.sum(-1)), atol=1e-12)
+    assert torch.allclose(Et.sum((-1, -2)), torch.full((B,), T - 1., dtype=torch.float64, device=dev), atol=1e-9)
+    assert torch.allclose(Ei, Es[:, 0], atol=1e-12)
+    var = lds_stats[2][0] - lds_stats[2][1] ** 2
+    assert float(var.min()) > 0 and torch.isfinite(hmm_vlb + lds_vlb).all()
+    for b in (0, 777, 1531, 2047):
+        ref = slds_numpy.optimize_local_meanfield(glob, (J[b], h[b]), eps[b])
+        assert int(iters[b]) == ref["iters"]
+        assert float(hmm_vlb[b]) == pytest.approx(ref["hmm_vlb"], rel=1e-6, abs=1e-6)
+        assert float(lds_vlb[b]) == pytest.approx(ref["lds_vlb"], rel=1e-6, abs=1e-6)
+        _close(Es[b], ref["hmm_stats"][2], 1e-5)
+        for got, want in zip(lds_stats[0], ref["init_stats"]):
+            _close(got[b], want, 1e-5)
+        _close(lds_stats[2][0][b], ref["node_stats"][0], 1e-5)
+        _close(lds_stats[2][1][b], ref["node_stats"][1], 1e-5)
+
+
 def test_final_pass_gradient_against_finite_differences():
     """d(local_vlb + <g, samples>)/d(nn_potentials) through the VJP kernels (per-step pair parameters,
     cotangents of E_init / E_pair from the HMM bound) against central differences of the forward."""
