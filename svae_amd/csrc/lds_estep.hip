@@ -14,6 +14,7 @@ extern "C" {
   int svae_lds_launch_twoend_n##NN(const svae::LdsArgs*, int, int, void*);          \
   int svae_lds_launch_twoend_mix_n##NN(const svae::LdsArgs*, void*);          \
   int svae_lds_launch_filter_n##NN(const svae::LdsArgs*, int, void*);          \
+  int svae_lds_launch_filter_split_n##NN(const svae::LdsArgs*, int, void*);    \
   int svae_lds_sample_n##NN(const svae::SampleArgs*, void*);                   \
   int svae_lds_vjp_n##NN(const svae::VjpArgs*, void*);
 #define SVAE_DECL(NN) SVAE_DECL_(NN)
@@ -88,11 +89,12 @@ int svae_lds_set_twoend(int mode) {
 
 int svae_hip_abi_version(void) { return SVAE_HIP_ABI_VERSION; }
 
-// main region: the larger of the one-directional layout (lds_args.hpp) and the two-ended one
+// main region: the one-directional layout (lds_args.hpp), then -- n <= 10 -- the two-ended one (a launch that
+// keeps the sampler / VJP hand-off runs BOTH kernels, see svae_lds_estep_f64), then B doubles of scratch
+static size_t one_ws_doubles(int B, int T, int n) { return (size_t)B * (size_t)svae::ws_seq_doubles(n, T); }
 static size_t main_ws_doubles(int B, int T, int n) {
-  const long one = svae::ws_seq_doubles(n, T);
   const long two = n <= svae::TE_MAX_N ? svae::te_seq_doubles(n, T) : 0;
-  return (size_t)B * (size_t)(one > two ? one : two);
+  return one_ws_doubles(B, T, n) + (size_t)B * (size_t)two + (size_t)B;
 }
 static size_t factor_ws_doubles(int B, int T, int n) { return (size_t)B * T * (n * n + n); }
 static size_t cross_ws_doubles(int B, int T, int n) { return (size_t)B * T * (n + 1) * svae::ws_h_stride(n); }
@@ -156,6 +158,46 @@ int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int k
     return svae_lds_launch_tile(&a, n, inhomog, stream);
   }
   const bool split = B <= g_split_max_b;
+  if (g_twoend && keep && split && n <= svae::TE_MAX_N && T >= svae::TE_MIN_T) {
+    // Small batch, hand-off kept: the statistics (and the cross moments the VJP reads: posterior moments, the same
+    // whichever way the chain is eliminated) come from the two-ended kernel, while the one-directional FILTER --
+    // whose factorisation defines the sampler's eps -> sample map and the records the sweeps differentiate --
+    // runs CONCURRENTLY on a second stream, on the SIMDs the small batch leaves idle (512 + 512 wavefronts on
+    // 1024 SIMDs at B = 512): 0.48 -> 0.25 ms.  Fork / join by events: the caller's stream sees one operation.
+    static hipStream_t aux = nullptr;
+    static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    if (!aux) {
+      if (hipStreamCreateWithFlags(&aux, hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) return -1002;
+    }
+    hipStream_t us = (hipStream_t)stream;
+    svae::LdsArgs f = a;                       // the filter: one-directional layout at the start of the workspace
+    f.ws2 = (double*)workspace + main_ws_doubles(B, T, n);
+    f.ws3 = nullptr;
+    f.lognorm = (double*)workspace + main_ws_doubles(B, T, n) - B;      // scratch (the E-step's lognorm is the other kernel's)
+    f.E_init = nullptr; f.E_pair = nullptr; f.E_node_diagxx = nullptr; f.E_node_x = nullptr;
+    svae::LdsArgs e = a;                       // the E-step: two-ended records behind the one-directional ones
+    e.ws = (double*)workspace + one_ws_doubles(B, T, n);
+    e.ws2 = nullptr;
+    if (hipEventRecord(ev_fork, us) != hipSuccess || hipStreamWaitEvent(aux, ev_fork, 0) != hipSuccess) return -1002;
+    int rc = -3, rc2 = -3;
+    switch (n) {
+#define SVAE_CASE_(NN) case NN: rc = svae_lds_launch_filter_split_n##NN(&f, inhomog, aux); \
+                                rc2 = svae_lds_launch_twoend_n##NN(&e, inhomog, !inhomog, us); break;
+#define SVAE_CASE(NN) SVAE_CASE_(NN)
+#ifdef SVAE_ONLY_N
+      SVAE_CASE(SVAE_ONLY_N)
+#else
+      SVAE_CASE(1) SVAE_CASE(2) SVAE_CASE(3) SVAE_CASE(4) SVAE_CASE(5) SVAE_CASE(6) SVAE_CASE(7)
+      SVAE_CASE(8) SVAE_CASE(9) SVAE_CASE(10)
+#endif
+#undef SVAE_CASE
+#undef SVAE_CASE_
+    }
+    if (hipEventRecord(ev_join, aux) != hipSuccess || hipStreamWaitEvent(us, ev_join, 0) != hipSuccess) return -1002;
+    return rc ? rc : rc2;
+  }
   if (g_twoend && !keep && n <= svae::TE_MAX_N && T >= svae::TE_MIN_T) {
     switch (n) {
 #define SVAE_CASE_(NN) case NN: return svae_lds_launch_twoend_n##NN(&a, inhomog, g_twoend == 1 && !inhomog, stream);
@@ -220,8 +262,11 @@ int svae_lds_filter_f64(int B, int T, int n, int inhomog, int pair_batched,
   a.pair_seq_stride = pair_batched ? (long)(T - 1) * n * n : 0;
   a.msg_Jp = J_pred; a.msg_hp = h_pred; a.msg_Jf = J_filt; a.msg_hf = h_filt;
   a.mix_w = nullptr; a.mix_out = nullptr; a.seq_index = nullptr; a.mix_K = 0;
+  // small batches without message outputs: one sequence per wavefront (0.62 -> 0.24 ms at B = 512, T = 200, n = 10)
+  const bool fsplit = B <= g_split_max_b && !J_pred && !h_pred && !J_filt && !h_filt;
   switch (n) {
-#define SVAE_CASE_(NN) case NN: return svae_lds_launch_filter_n##NN(&a, inhomog, stream);
+#define SVAE_CASE_(NN) case NN: return fsplit ? svae_lds_launch_filter_split_n##NN(&a, inhomog, stream) \
+                                              : svae_lds_launch_filter_n##NN(&a, inhomog, stream);
 #define SVAE_CASE(NN) SVAE_CASE_(NN)
 #ifdef SVAE_ONLY_N
     SVAE_CASE(SVAE_ONLY_N)

@@ -38,3 +38,7 @@ extern "C" int SVAE_CAT(svae_lds_launch_twoend_mix_n, SVAE_N)(const svae::LdsArg
 extern "C" int SVAE_CAT(svae_lds_launch_filter_n, SVAE_N)(const svae::LdsArgs* a, int inhomog, void* stream) {
   return svae::launch_filter<SVAE_N>(*a, inhomog != 0, (hipStream_t)stream);
 }
+
+extern "C" int SVAE_CAT(svae_lds_launch_filter_split_n, SVAE_N)(const svae::LdsArgs* a, int inhomog, void* stream) {
+  return svae::launch_filter_split<SVAE_N>(*a, inhomog != 0, (hipStream_t)stream);
+}

@@ -35,7 +35,10 @@ __device__ __forceinline__ void all_gather_rows(double* tab, int g, int c, const
   __builtin_amdgcn_wave_barrier();
 }
 
-template <int N, bool INHOMOG, bool CHOL>
+// FILT: forward filter only (stops after the log-normaliser; the hand-off and the factor region are what the
+// sampler and the VJP sweeps read) -- the small-batch twin of lds_estep_kernel<.., FILT = true>, without the
+// message outputs.
+template <int N, bool INHOMOG, bool CHOL, bool FILT = false>
 __global__ __launch_bounds__(64) void lds_estep_split_kernel(const LdsArgs a) {
   static_assert(N >= 1 && N <= SVAE_LDS_MAX_N, "n+1 lanes must fit a 16-lane DPP row");
   constexpr int HS = ws_h_stride(N), PS = ws_p_stride(N), WS = ws_step_doubles(N);
@@ -43,6 +46,10 @@ __global__ __launch_bounds__(64) void lds_estep_split_kernel(const LdsArgs a) {
   constexpr int J1 = (N + 4) / 4;         // slots holding rows 0..N
   constexpr int RS = 4 * J1;              // LDS row stride (even, >= N+1)
   __shared__ double tab[16 * RS];
+  // FILT runs concurrently with the two-ended E-step kernel (svae_lds_estep_f64, keep != 0): touching a high AGPR
+  // pushes the wavefront's register allocation past half of the SIMD's file, so that no two wavefronts -- of either
+  // kernel -- can share a SIMD (measured without it: the filter slows from 0.34 to 0.46 ms when they do)
+  if constexpr (FILT) asm volatile("v_accvgpr_write_b32 a63, 0" ::: "a63");
 
   const int lane = threadIdx.x;
   const int c = lane & 15;
@@ -185,6 +192,7 @@ __global__ __launch_bounds__(64) void lds_estep_split_kernel(const LdsArgs a) {
     }
   }
 
+  if constexpr (FILT) return;
   // ---- backward pass: S~ in slot layout (row i = 4j+g in DPP row g), W~ gathered per step ---------
   double S[J1];
   static_for<0, J1>([&](auto j) { S[j] = (4 * j + g == N) ? EN : 0.0; });
@@ -318,6 +326,17 @@ __global__ __launch_bounds__(64) void lds_estep_split_kernel(const LdsArgs a) {
 #if SVAE_WARM_AHEAD > 0
   if (sink == 1.2345e300) a.lognorm[b] = sink;        // keeps the touches alive; never true
 #endif
+}
+
+// filter only, one sequence per wavefront (keeps the factor region: a.ws2 must be set)
+template <int N>
+static int launch_filter_split(const LdsArgs& a, bool inhomog, hipStream_t stream) {
+  dim3 grid(a.B), block(64);
+  if (inhomog)
+    hipLaunchKernelGGL((lds_estep_split_kernel<N, true, true, true>), grid, block, 0, stream, a);
+  else
+    hipLaunchKernelGGL((lds_estep_split_kernel<N, false, true, true>), grid, block, 0, stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
 template <int N>

@@ -139,11 +139,20 @@ __device__ __forceinline__ void te_gauss_jordan(double (&M)[N], const double (&E
 //   out[b,t,1,k] = <E x_t x_t', J22_k> (+ <E x_{t-1} x_t', J12_k> on chain B)      -> pair t-1
 // (lane k of the DPP row accumulates state k: the lane reduction is the broadcast of the DPP operand).
 // W sequences (wavefronts) per workgroup share the tables; `seq_index` lists the rows a launch works on.
-template <int N, bool INHOMOG, bool LEAN, bool MIX = false>
+//
+// CROSS: also write the cross moments W~_t = E[x~_{t+1} x~_t'] ((n+1) x (n+1), t = 0 .. T-1, the record of
+// t = T-1 being e_n [mu_{T-1}; 1]') in the layout the reverse-mode sweeps read (a.ws3; lds_vjp_kernel.hpp).
+// They are posterior moments -- the same whichever way the chain was eliminated -- so the training step may take
+// statistics and cross moments from this kernel while the one-directional FILTER (whose factorisation defines the
+// sampler's eps -> sample map and the hand-off the sweeps differentiate) runs concurrently on the SIMDs a small
+// batch leaves idle (lds_estep.hip: svae_lds_estep_f64 with keep != 0).
+template <int N, bool INHOMOG, bool LEAN, bool MIX = false, bool CROSS = false>
 __global__ __launch_bounds__(MIX ? 512 : 64) void lds_estep_twoend_kernel(const LdsArgs a) {
   static_assert(N >= 1 && N <= TE_MAX_N && N + ((N - 1) >> 1) <= 14,
                 "the right-hand-side columns must fit lanes N..14 of two DPP rows");
   static_assert(!MIX || (INHOMOG && !LEAN), "MIX: per-step parameters, full hand-off record");
+  // (CROSS runs next to the one-directional filter: one wavefront per SIMD, see lds_estep_split.hpp)
+  if constexpr (CROSS) asm volatile("v_accvgpr_write_b32 a63, 0" ::: "a63");
   constexpr int RW = te_row_doubles(N), ZP = te_page_doubles(N);
   constexpr int WS = LEAN ? te_lean_step_doubles(N) : te_step_doubles(N);
   constexpr int TRI = N * (N + 1) / 2;    // LEAN record: [lower triangle | c (N) | 0.0 | trash | pad]
@@ -688,6 +697,21 @@ __global__ __launch_bounds__(MIX ? 512 : 64) void lds_estep_twoend_kernel(const 
       static_for<0, J1>([&](auto j) { mac_bc<k, (k < N)>(W[j], S[j], H[k]); });
     });
     dpp_fence(W);
+    if constexpr (CROSS && KIND != 1) {
+      // chain A: W[i][c] = W~_s[i][c] (record s);  chain B: W[i][c] = E[x~_{t-1,i} x~_{t,c}] = W~_{t-1}[c][i]
+      // (record T-2-s, transposed).  One unconditional store per slot; lanes / rows outside the tile, and chain B's
+      // repeat of pair e-1 with even T, go to the trash slot.
+      constexpr int HSX = ws_h_stride(N);
+      const int tr = dir ? T - 2 - s : s;
+      double* w3 = a.ws3 + ((long)b * T + tr) * (N + 1) * HSX;
+      const bool skipx = KIND == 2 && skip2nd;
+      static_for<0, J1>([&](auto j) {
+        const int i = 2 * j + gl;
+        const bool ok = i <= N && c <= N && !skipx;
+        double* q = ok ? w3 + (dir ? c * HSX + i : i * HSX + c) : trash;
+        *q = W[j];
+      });
+    }
     if constexpr (!INHOMOG && KIND == 0) static_for<0, J>([&](auto j) { sumW[j] += W[j]; });   // (W dies in the split)
     double WR[N + 2];
     static_for<0, J1>([&](auto j) { pair_split(W[j], WR[2 * j], WR[(2 * j + 1 <= N) ? 2 * j + 1 : N + 1]); });
@@ -849,6 +873,17 @@ __global__ __launch_bounds__(MIX ? 512 : 64) void lds_estep_twoend_kernel(const 
       });
     }
   }
+  if constexpr (CROSS) {
+    // record T-1: W~_{T-1} = e_n [mu_{T-1}; 1]'  (what the one-directional smoother's first step leaves there)
+    if (dir) {
+      constexpr int HSX = ws_h_stride(N);
+      double* w3 = a.ws3 + ((long)b * T + (T - 1)) * (N + 1) * HSX;
+      static_for<0, J1>([&](auto j) {
+        const int i = 2 * j + gl;
+        if (i <= N && c <= N) w3[i * HSX + c] = (i == N) ? S[j] : 0.0;
+      });
+    }
+  }
   if (!dir) {
     static_for<0, J>([&](auto j) {
       const int i = 2 * j + gl;
@@ -862,6 +897,13 @@ template <int N>
 static int launch_estep_twoend(const LdsArgs& a, bool inhomog, bool lean, hipStream_t stream) {
   if constexpr (N <= TE_MAX_N) {
     dim3 grid(a.B), block(64);
+    if (a.ws3) {     // with the cross moments for the reverse-mode sweeps (CROSS): homogeneous lean / per-step full record
+      if (inhomog)
+        hipLaunchKernelGGL((lds_estep_twoend_kernel<N, true, false, false, true>), grid, block, 0, stream, a);
+      else
+        hipLaunchKernelGGL((lds_estep_twoend_kernel<N, false, true, false, true>), grid, block, 0, stream, a);
+      return hipGetLastError() == hipSuccess ? 0 : -1000;
+    }
     if (inhomog && lean)
       hipLaunchKernelGGL((lds_estep_twoend_kernel<N, true, true>), grid, block, 0, stream, a);
     else if (inhomog)
