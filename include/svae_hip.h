@@ -96,7 +96,11 @@ int svae_lds_filter_f64(int B, int T, int n, int inhomog, int pair_batched,
                         double* lognorm, double* J_pred, double* h_pred, double* J_filt, double* h_filt,
                         int32_t* info, void* workspace, size_t ws_bytes, void* stream);
 
-/* Kernel selection for svae_lds_estep_f64 (n <= SVAE_LDS_MAX_N).  With keep == 0, n <= 10 and T >= 4
+/* Kernel selection for svae_lds_estep_f64 (n <= SVAE_LDS_MAX_N).  With keep != 0, n <= 10, T >= 4 and B <= max_b
+ * (svae_lds_set_split_max_b) the call runs TWO kernels side by side, joined by events before it returns to the
+ * caller's stream: the two-ended E-step (statistics, log-normaliser, and the cross moments the VJP reads) and the
+ * one-directional filter (hand-off records and LDL' factors for svae_lds_sample_f64 / svae_lds_estep_vjp_f64).
+ * With keep == 0, n <= 10 and T >= 4
  * the two-ended kernel runs (block elimination from both ends of the chain, meeting in the middle:
  * half the serial depth; svae_lds_set_twoend: 1 = with the lean hand-off record (default), 2 = with the
  * full record, 0 = off).  Otherwise batches with B <= max_b run

@@ -15,6 +15,7 @@ extern "C" {
   int svae_lds_launch_twoend_mix_n##NN(const svae::LdsArgs*, void*);          \
   int svae_lds_launch_filter_n##NN(const svae::LdsArgs*, int, void*);          \
   int svae_lds_launch_filter_split_n##NN(const svae::LdsArgs*, int, void*);    \
+  int svae_lds_launch_filter_1r_n##NN(const svae::LdsArgs*, int, void*);       \
   int svae_lds_sample_n##NN(const svae::SampleArgs*, void*);                   \
   int svae_lds_vjp_n##NN(const svae::VjpArgs*, void*);
 #define SVAE_DECL(NN) SVAE_DECL_(NN)
@@ -183,7 +184,7 @@ int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int k
     if (hipEventRecord(ev_fork, us) != hipSuccess || hipStreamWaitEvent(aux, ev_fork, 0) != hipSuccess) return -1002;
     int rc = -3, rc2 = -3;
     switch (n) {
-#define SVAE_CASE_(NN) case NN: rc = svae_lds_launch_filter_split_n##NN(&f, inhomog, aux); \
+#define SVAE_CASE_(NN) case NN: rc = svae_lds_launch_filter_1r_n##NN(&f, inhomog, aux); \
                                 rc2 = svae_lds_launch_twoend_n##NN(&e, inhomog, !inhomog, us); break;
 #define SVAE_CASE(NN) SVAE_CASE_(NN)
 #ifdef SVAE_ONLY_N
@@ -265,8 +266,9 @@ int svae_lds_filter_f64(int B, int T, int n, int inhomog, int pair_batched,
   // small batches without message outputs: one sequence per wavefront (0.62 -> 0.24 ms at B = 512, T = 200, n = 10)
   const bool fsplit = B <= g_split_max_b && !J_pred && !h_pred && !J_filt && !h_filt;
   switch (n) {
-#define SVAE_CASE_(NN) case NN: return fsplit ? svae_lds_launch_filter_split_n##NN(&a, inhomog, stream) \
-                                              : svae_lds_launch_filter_n##NN(&a, inhomog, stream);
+#define SVAE_CASE_(NN) case NN: return !fsplit ? svae_lds_launch_filter_n##NN(&a, inhomog, stream)          \
+                                       : (NN <= svae::TE_MAX_N && g_twoend) ? svae_lds_launch_filter_1r_n##NN(&a, inhomog, stream) \
+                                       : svae_lds_launch_filter_split_n##NN(&a, inhomog, stream);
 #define SVAE_CASE(NN) SVAE_CASE_(NN)
 #ifdef SVAE_ONLY_N
     SVAE_CASE(SVAE_ONLY_N)

@@ -8,6 +8,7 @@
 #include "lds_estep_kernel.hpp"
 #include "lds_estep_split.hpp"
 #include "lds_estep_twoend.hpp"
+#include "lds_filter_1r.hpp"
 
 #ifndef SVAE_N
 #error "compile with -DSVAE_N=<latent dim>"
@@ -37,6 +38,10 @@ extern "C" int SVAE_CAT(svae_lds_launch_twoend_mix_n, SVAE_N)(const svae::LdsArg
 
 extern "C" int SVAE_CAT(svae_lds_launch_filter_n, SVAE_N)(const svae::LdsArgs* a, int inhomog, void* stream) {
   return svae::launch_filter<SVAE_N>(*a, inhomog != 0, (hipStream_t)stream);
+}
+
+extern "C" int SVAE_CAT(svae_lds_launch_filter_1r_n, SVAE_N)(const svae::LdsArgs* a, int inhomog, void* stream) {
+  return svae::launch_filter_1r<SVAE_N>(*a, inhomog != 0, (hipStream_t)stream);
 }
 
 extern "C" int SVAE_CAT(svae_lds_launch_filter_split_n, SVAE_N)(const svae::LdsArgs* a, int inhomog, void* stream) {

@@ -44,14 +44,16 @@ def test_workspace_size_formula():
     # factor region: n*n + n
     # plus one constant page (12 + 10 doubles) per sequence
     # and the cross-moment region ((n+1) rows of stride even(n+1)) per step
-    # n <= 10: the main region is the larger of that and the two-ended kernel's layout (two chains per
-    # sequence: a constant page of 2(n+2)+2 doubles + T/2 + 1 records of n rows [P^-1 | P^-1 J12 | c | pad])
+    # n <= 10: the main region holds BOTH that and the two-ended kernel's layout (two chains per sequence: a
+    # constant page of 2(n+2)+2 doubles + T/2 + 1 records of n rows [P^-1 | P^-1 J12 | c | pad]): a launch that
+    # keeps the sampler / VJP hand-off runs the one-directional filter and the two-ended E-step side by side;
+    # one scratch double per sequence follows in every case
     one = lambda T, n: (n + 1 + (n + 1) % 2) + (n + n % 2) + T * n * ((n + 1 + (n + 1) % 2) + (n + n % 2))
     two = lambda T, n: 2 * (2 * (n + 2) + 2 + (T // 2 + 1) * n * (2 * n + 2))
     assert one(200, 10) == 22 + 200 * 10 * (12 + 10)
-    assert lib.svae_lds_workspace_bytes(512, 200, 10) == 512 * (max(one(200, 10), two(200, 10)) + 200 * (10 * 10 + 10 + 11 * 12)) * 8
-    assert lib.svae_lds_workspace_bytes(3, 7, 5) == 3 * (max(one(7, 5), two(7, 5)) + 7 * (5 * 5 + 5 + 6 * 6)) * 8
-    assert lib.svae_lds_workspace_bytes(3, 7, 12) == 3 * (one(7, 12) + 7 * (12 * 12 + 12 + 13 * 14)) * 8
+    assert lib.svae_lds_workspace_bytes(512, 200, 10) == 512 * (one(200, 10) + two(200, 10) + 1 + 200 * (10 * 10 + 10 + 11 * 12)) * 8
+    assert lib.svae_lds_workspace_bytes(3, 7, 5) == 3 * (one(7, 5) + two(7, 5) + 1 + 7 * (5 * 5 + 5 + 6 * 6)) * 8
+    assert lib.svae_lds_workspace_bytes(3, 7, 12) == 3 * (one(7, 12) + 1 + 7 * (12 * 12 + 12 + 13 * 14)) * 8
     assert lib.svae_lds_vjp_workspace_bytes(3, 7, 5) == 3 * 7 * 5 * (2 * 6 + 2 * 6) * 8
     # n > 15: tiled path, per step X and P^-1 (NP x NP, NP = n rounded up to 16) and c (NP)
     # + the pair parameters re-packed in fragment order: 2 slots (homogeneous) or T-1 per set, 3 NP^2 each

@@ -51,7 +51,10 @@ def test_estep_kernel_isa_has_no_dpp_hazards(n, tmp_path):
     assert probs == [], "\n".join(probs[:10])
     if n <= 10:                                   # the headline sizes must not spill at all
         txt = out.read_text()
-        assert "scratch_" not in txt and "v_accvgpr" not in txt
+        # (the one AGPR instruction allowed is the occupancy marker `v_accvgpr_write_b32 a63, 0` of the kernels that
+        #  run two at a time, one wavefront per SIMD: lds_estep_split.hpp FILT, lds_estep_twoend.hpp CROSS, lds_filter_1r.hpp)
+        acc = [l for l in txt.splitlines() if "v_accvgpr" in l and "v_accvgpr_write_b32 a63, 0" not in l]
+        assert "scratch_" not in txt and acc == [], acc[:5]
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
