@@ -171,6 +171,17 @@ int svae_lds_tile_vjp_f64(int phase, int B, int T, int n, int S, int inhomog, in
 int svae_lds_tile_sample_f64(int B, int T, int n, int S, const double* noise, double* samples,
                              const void* handoff_workspace, void* stream);
 
+/* The sampler's noise factor for latent dimension 16 <= n <= 64 and its adjoint, from the P_t^-1 of the tiled
+ * E-step's hand-off, one workgroup per (sequence, step): the reference's noise map is chol(P_t)^-T eps_t
+ * (/root/reference/svae/lds/cython_gaussian_grads.pxd:431-454), and chol(P_t)^-T is the upper-triangular M with
+ * P_t^-1 = M M'.
+ *   mode 0: noise (B,T,S,n) = M_t eps_t   (input of svae_lds_tile_sample_f64)
+ *   mode 1: adds the Cholesky-path cotangent sym(M^-T Phi(M' Mbar) M^-1), Mbar = triu(sum_s xbar_s eps_s'), into the
+ *           pinv_bar section of `vjp_workspace` -- between phases 1 and 2 of svae_lds_tile_vjp_f64
+ *           (the adjoint of cython_gaussian_grads.pxd:456-487 `_natural_sample_grad`).           S <= 16. */
+int svae_lds_tile_noise_f64(int mode, int B, int T, int n, int S, const double* eps, double* noise,
+                            const void* handoff_workspace, void* vjp_workspace, int32_t* info, void* stream);
+
 /* The once-per-step GLOBAL side of the LDS-SVAE in one launch ("global->local maps
  * on device"): niw.expectedstats (/root/reference/svae/distributions/niw.py:15-25) and mniw.expectedstats
  * (/root/reference/svae/distributions/mniw.py:19-20, 33-55) of the global factors -> the LDS init and pair

@@ -54,6 +54,8 @@ SIGNATURES = {
     "svae_lds_tile_vjp_workspace_doubles": (ctypes.c_size_t, [ctypes.c_int] * 4),
     "svae_lds_tile_vjp_f64": (ctypes.c_int, [ctypes.c_int] * 7 + [_c_double_p] * 10
                               + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "svae_lds_tile_noise_f64": (ctypes.c_int, [ctypes.c_int] * 5 + [_c_double_p] * 2
+                                + [ctypes.c_void_p, ctypes.c_void_p, _c_int_p, ctypes.c_void_p]),
     "svae_lds_tile_sample_f64": (ctypes.c_int, [ctypes.c_int] * 4 + [_c_double_p] * 2 + [ctypes.c_void_p, ctypes.c_void_p]),
     "svae_lds_global_step_f64": (ctypes.c_int, [ctypes.c_int] + [_c_double_p] * 19 + [_c_int_p, ctypes.c_void_p]),
     "svae_lds_natgrad_f64": (ctypes.c_int, [ctypes.c_int] * 2 + [_c_double_p] * 3 + [ctypes.c_double] * 2

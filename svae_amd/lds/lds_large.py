@@ -8,9 +8,9 @@ batched dense linear algebra (rocBLAS / rocSOLVER through torch, one launch per 
 launch-bound, a few hundred ms at T = 1000), so that BASELINE configs[4] can take a training step:
 
   * sampler: from the tile kernel's hand-off (G_t = -P_t^-1 J12, c_t, P_t^-1 per step).  The reference's
-    noise map is chol(P_t)^-T eps_t; chol(P)^-T is the unique upper-triangular M with P^-1 = M M', i.e.
-    the Cholesky factor of the index-reversed P^-1, index-reversed -- computed for all (sequence, step)
-    at once; only the recursion x_t = c_t + G_t x_{t+1} + noise_t is serial.
+    noise map is chol(P_t)^-T eps_t; chol(P)^-T is the unique upper-triangular M with P^-1 = M M' ("UL"
+    Cholesky), computed per (sequence, step) by svae_lds_tile_noise_f64 (one workgroup each: it does not depend
+    on the recursion); the serial recursion x_t = c_t + G_t x_{t+1} + noise_t is svae_lds_tile_sample_f64.
   * VJP: `vjp_from_handoff` -- the adjoint of the kernels' recursion written out by hand on the tile kernel's
     hand-off (three passes over time of batched matrix products; the Cholesky adjoint of the noise factor
     batched over all (sequence, step) pairs), checked against autograd through `torch_estep` (the torch
@@ -48,6 +48,16 @@ def sample_from_handoff(plan, eps, chunk_bytes=2 << 30):
     G, Pinv, c = handoff_views(plan)
     S = eps.shape[2]
     noise = torch.empty(B, T, S, n, dtype=torch.float64, device=plan.device)
+    if S <= 16:      # noise factor per (sequence, step) and the serial recursion: two launches
+        lib, p = _lib.load(), _lib.ptr
+        eps = eps.contiguous()
+        out = torch.empty_like(noise)
+        rc = lib.svae_lds_tile_noise_f64(0, B, T, n, S, p(eps), p(noise), p(plan.ws), None, p(plan.info),
+                                         _lib.current_stream(plan.device))
+        _lib.check(rc, "svae_lds_tile_noise_f64")
+        rc = lib.svae_lds_tile_sample_f64(B, T, n, S, p(noise), p(out), p(plan.ws), _lib.current_stream(plan.device))
+        _lib.check(rc, "svae_lds_tile_sample_f64")
+        return out
     per_seq = T * n * n * 8 * 3
     step = max(1, int(chunk_bytes // per_seq))
     for b0 in range(0, B, step):
@@ -55,12 +65,8 @@ def sample_from_handoff(plan, eps, chunk_bytes=2 << 30):
         Lf = torch.linalg.cholesky(P.flip(-1, -2))
         M = Lf.flip(-1, -2)                                    # upper triangular, P^-1 = M M'
         noise[b0:b0 + step] = torch.matmul(eps[b0:b0 + step], M.transpose(-1, -2))
+    # (more than 16 samples per sequence: batched library calls for the factor, a torch loop for the recursion)
     out = torch.empty_like(noise)
-    if S <= 16:      # the serial recursion in one launch (svae_lds_tile_sample_f64)
-        rc = _lib.load().svae_lds_tile_sample_f64(B, T, n, S, _lib.ptr(noise), _lib.ptr(out), _lib.ptr(plan.ws),
-                                                  _lib.current_stream(plan.device))
-        _lib.check(rc, "svae_lds_tile_sample_f64")
-        return out
     x = c[:, T - 1, None, :] + noise[:, T - 1]
     out[:, T - 1] = x
     for t in range(T - 2, -1, -1):
@@ -307,18 +313,10 @@ def vjp_from_handoff_hip(plan, J12, pair_batched, ex, g_lognorm, g_dxx, g_x, sam
         _lib.check(rc, "svae_lds_tile_vjp_f64")
     phase(0)
     phase(1)
-    if has_s:
-        _, Pinv, _ = handoff_views(plan)
-        o = 2 * B * T * n * n + B * max(T - 1, 0) * n * n + B * T * n
-        pinv_bar = ws[B * T * n * n:2 * B * T * n * n].view(B, T, n, n)
-        xbar = ws[o:o + B * T * S * n].view(B, T, S, n)
-        per_seq = T * n * n * 8 * 6
-        step = max(1, int((4 << 30) // per_seq))
-        for b0 in range(0, B, step):
-            sl = slice(b0, b0 + step)
-            M = _upper_factor(Pinv[sl])
-            Mbar = torch.triu(torch.matmul(xbar[sl].transpose(-1, -2), eps[sl]))
-            pinv_bar[sl] += _upper_factor_adjoint(M, Mbar)
+    if has_s:    # Cholesky adjoint of the noise factor, one workgroup per (sequence, step), into pinv_bar
+        rc = lib.svae_lds_tile_noise_f64(1, B, T, n, S, p(eps), None, p(plan.ws), p(ws), p(plan.info),
+                                         _lib.current_stream(dev))
+        _lib.check(rc, "svae_lds_tile_noise_f64")
     phase(2)
     return gJ, gh
 
