@@ -194,6 +194,36 @@ def measure_training_path(dev, T, n, B, S=1, reps=5):
             "value": B / sum(acc) * 1e3, "unit": "sequences/s"}
 
 
+def measure_tile_training(dev, B=64, T=1000, n=64, S=1):
+    """BASELINE configs[4] shape through a whole training-path pass (tile-kernel E-step, sampler, VJP kernels)."""
+    from svae_amd.lds.lds_inference import LDSEStepPlan, lds_inference_differentiable
+    from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials
+    rng = np.random.default_rng(0)
+    init, pair = rand_lds_natparam(n, rng)
+    nJ, nh = rand_node_potentials((B, T, n), rng)
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev).contiguous()
+    natparam = (tuple(t(x) for x in init), tuple(t(x) for x in pair))
+    nJ, nh = t(nJ).requires_grad_(True), t(nh).requires_grad_(True)
+    eps = torch.randn(B, T, S, n, dtype=torch.float64, device=dev)
+    gs = torch.randn(B, T, S, n, dtype=torch.float64, device=dev)
+    plan = LDSEStepPlan(B, T, n, dev)
+
+    def it():
+        lognorm, (dxx, ex), samples, _ = lds_inference_differentiable(natparam, (nJ, nh), eps=eps, plan=plan)
+        loss = lognorm.sum() + (dxx * 0.3).sum() + ex.sum() + (samples * gs).sum()
+        return torch.autograd.grad(loss, [nJ, nh])
+    it(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 2
+    for _ in range(reps):
+        it()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    return {"workload": "training path at BASELINE configs[4] shape: tile-kernel E-step + sampler + VJP kernels, "
+                        "%d sequences x T=%d, n=%d, %d sample" % (B, T, n, S),
+            "ms_per_pass": ms, "value": B / ms * 1e3, "unit": "sequences/s"}
+
+
 def measure_slds(dev, B=2048, T=500, n=10, K=8):
     """BASELINE configs[3]: SLDS-SVAE local mean field (coordinate ascent between the HMM kernel and the fused LDS
     mean-field kernel), wall clock of the whole ascent."""
@@ -316,7 +346,8 @@ def main():
                     extra.append({"workload": what, "error": repr(e)})
                 torch.cuda.empty_cache()
             # the other BASELINE configurations and the training path: measured beside `value`, never instead of it
-            for fn in (lambda: measure_training_path(dev, T, n, B), lambda: measure_slds(dev), lambda: measure_gmm(dev)):
+            for fn in (lambda: measure_training_path(dev, T, n, B), lambda: measure_tile_training(dev),
+                       lambda: measure_slds(dev), lambda: measure_gmm(dev)):
                 try:
                     extra.append(fn())
                 except Exception as e:

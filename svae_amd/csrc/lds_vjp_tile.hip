@@ -413,11 +413,35 @@ __global__ __launch_bounds__(256) void tile_sample_kernel(int T, int n, int S, i
   double* Gs = sm;                       // n x (n + 1)
   double* xn = sm + 64 * 65;             // S x 64: x_{t+1}
   const int b = blockIdx.x, ld = n + 1;
-  for (int t = T - 1; t >= 0; --t) {
+  // G_t of the NEXT step travels through registers (16 entries per thread: rows ty + 16 i, columns 4 tx ..) while the
+  // current step computes from LDS: the 32 KB tile comes from HBM, further away than one matrix-vector product
+  const int ty = threadIdx.x >> 4, c0 = 4 * (threadIdx.x & 15);
+  double pre[4][4];
+  auto fetch = [&](int t) {
     const double* h = ws + ((long)b * T + t) * (2L * NP * NP + NP);
-    const double* ct = h + 2L * NP * NP;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = ty + 16 * i, cq = c0 + j;
+        pre[i][j] = (r < n && cq < n) ? h[(long)r * NP + cq] : 0.0;
+      }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = ty + 16 * i, cq = c0 + j;
+        if (r < n && cq < n) Gs[r * ld + cq] = pre[i][j];
+      }
+  };
+  if (T > 1) fetch(T - 2);
+  for (int t = T - 1; t >= 0; --t) {
+    const double* ct = ws + ((long)b * T + t) * (2L * NP * NP + NP) + 2L * NP * NP;
     if (t < T - 1) {
-      for (int e = threadIdx.x; e < n * n; e += 256) Gs[(e / n) * ld + (e % n)] = h[(long)(e / n) * NP + (e % n)];
+      stage();                           // G_t, requested one step ago
+      if (t > 0) fetch(t - 1);
     }
     __syncthreads();
     double out[4];
