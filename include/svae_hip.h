@@ -132,8 +132,10 @@ int svae_lds_set_twoend(int mode);
  *         (which of the two slots carries the cross term depends on the chain that owns node t; only the sum
  *          above is defined).
  * n <= 10, T >= 4, K <= 16 and svae_slds_lds_meanfield_lds_bytes(n, K) <= 160 KiB (else -4: use the
- * per-step entry point).  workspace: svae_lds_workspace_bytes(rows, T, n). */
+ * per-step entry point).  workspace: svae_slds_lds_meanfield_workspace_bytes(rows, T, n) (the two-ended kernel's
+ * records only: a third of svae_lds_workspace_bytes). */
 size_t svae_slds_lds_meanfield_lds_bytes(int n, int K);
+size_t svae_slds_lds_meanfield_workspace_bytes(int rows, int T, int n);
 int svae_slds_lds_meanfield_f64(int B, int rows, int T, int n, int K,
                                 const double* init_J, const double* init_h,
                                 const double* J11, const double* J12, const double* J22,

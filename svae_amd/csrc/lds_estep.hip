@@ -283,6 +283,11 @@ int svae_lds_filter_f64(int B, int T, int n, int inhomog, int pair_batched,
   return -3;
 }
 
+size_t svae_slds_lds_meanfield_workspace_bytes(int rows, int T, int n) {
+  if (rows <= 0 || T < svae::TE_MIN_T || n < 1 || n > svae::TE_MAX_N) return 0;
+  return (size_t)rows * (size_t)svae::te_seq_doubles(n, T) * sizeof(double);     // the two-ended records only
+}
+
 size_t svae_slds_lds_meanfield_lds_bytes(int n, int K) {
   if (n < 1 || n > svae::TE_MAX_N || K < 1 || K > svae::TE_MIX_MAX_K) return 0;
   return (size_t)svae::te_mix_lds_bytes(n, K);
@@ -313,7 +318,7 @@ int svae_slds_lds_meanfield_f64(int B, int rows, int T, int n, int K,
   if (!E_node_x) return -18;
   if (!pair_contr) return -19;
   if (!info) return -20;
-  if (!workspace || ws_bytes < svae_lds_workspace_bytes(rows, T, n)) return -21;
+  if (!workspace || ws_bytes < svae_slds_lds_meanfield_workspace_bytes(rows, T, n)) return -21;
   if (B == 0) return 0;
   svae::LdsArgs a;
   a.B = B; a.T = T;

@@ -120,7 +120,7 @@ class SLDSMeanfieldPlan(object):
         self.B, self.T, self.n, self.K = B, T, n, K
         self.device = torch.device(device)
         f64 = dict(dtype=torch.float64, device=self.device)
-        self.ws_bytes = int(self.lib.svae_lds_workspace_bytes(max(B, 1), T, n))
+        self.ws_bytes = int(self.lib.svae_slds_lds_meanfield_workspace_bytes(max(B, 1), T, n))
         self.ws = torch.empty(self.ws_bytes // 8, **f64)
         self.lognorm = torch.zeros(B, **f64)
         self.E_init = torch.zeros(B, n * n + n, **f64)
