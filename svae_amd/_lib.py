@@ -67,6 +67,9 @@ SIGNATURES = {
                              + [ctypes.c_double, ctypes.c_int] + [_c_double_p] * 8
                              + [_c_int_p] * 3 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "svae_gmm_mw_kl_hist": (ctypes.c_void_p, [ctypes.c_void_p]),
+    "svae_gmm_mw_fixed_point_f64": (ctypes.c_int, [ctypes.c_int] * 3 + [_c_double_p] * 5
+                                    + [ctypes.c_double, ctypes.c_int] + [_c_double_p] * 8
+                                    + [_c_int_p] * 3 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
 }
 
 _lib = None

@@ -19,6 +19,7 @@
 // [N,N], d at [N+1,N+1]; every other entry is zero.  G_k is required to have that sparsity (it is
 // the output of niw.expectedstats, niw.py:25), node potentials have A diagonal.
 #include <hip/hip_runtime.h>
+#include <hip/hip_cooperative_groups.h>
 #include <stdint.h>
 #include <type_traits>
 
@@ -395,6 +396,57 @@ __global__ __launch_bounds__(GMM_MW_BLOCK) void gmm_mw_sweep_kernel(const GmmMwA
   }
 }
 
+// The same sweeps in ONE cooperative launch (single GPU): a grid barrier per sweep instead of a launch per sweep
+// (16 .. 21 us each, the whole cost of a sweep below ~100 k points).  Every workgroup sums the per-workgroup KL
+// partials in index order itself (all reach the same total and the same stopping decision); the partials are
+// double-buffered by sweep parity so that one barrier per sweep suffices.
+template <int N>
+__global__ __launch_bounds__(GMM_MW_BLOCK) void gmm_mw_persistent_kernel(const GmmMwArgs m) {
+  namespace cg = cooperative_groups;
+  cg::grid_group grid = cg::this_grid();
+  const GmmArgs& a = m.g;
+  __shared__ double red[GMM_MW_BLOCK];
+  const int tid = threadIdx.x, K = a.K, T = a.T, G = gridDim.x;
+  double prev = 1.0 / 0.0;
+  int iters = 0;
+  for (int i = 0; i < a.max_iter; ++i) {
+    iters = i + 1;
+    double klpart = 0.0;
+    for (int t = blockIdx.x * GMM_MW_BLOCK + tid; t < T; t += G * GMM_MW_BLOCK)
+      klpart += gmm_point<N>(a, t, (i == 0 ? a.label_init : a.label_stats) + (long)t * K, false);
+    const double wgsum = block_sum<GMM_MW_BLOCK>(klpart, red);
+    double* part = m.partials + (i & 1) * G;
+    if (tid == 0) part[blockIdx.x] = wgsum;
+    __threadfence();
+    grid.sync();
+    const double total = gmm_fixed_order_sum(part, G, red);
+    if (blockIdx.x == 0 && tid == 0) m.kl_hist[i] = total;
+    const bool stop = fabs(total - prev) < a.tol;
+    prev = total;
+    if (stop) break;
+  }
+  // final pass (gmm.py:74-86)
+  const bool from_init = a.max_iter == 0;
+  double klpart = 0.0;
+  for (int t = blockIdx.x * GMM_MW_BLOCK + tid; t < T; t += G * GMM_MW_BLOCK) {
+    const double* rin = (from_init ? a.label_init : a.label_stats) + (long)t * K;
+    if (a.label_fixed)
+      for (int k = 0; k < K; ++k) a.label_fixed[(long)t * K + k] = rin[k];
+    if (from_init)
+      for (int k = 0; k < K; ++k) a.label_stats[(long)t * K + k] = rin[k];
+    klpart += gmm_point<N>(a, t, rin, true);
+  }
+  const double wgsum = block_sum<GMM_MW_BLOCK>(klpart, red);
+  double* part = m.partials + 2 * G;
+  if (tid == 0) part[blockIdx.x] = wgsum;
+  __threadfence();
+  grid.sync();
+  if (blockIdx.x == 0) {
+    const double total = gmm_fixed_order_sum(part, G, red);
+    if (tid == 0) { a.kl[0] = total; a.iters[0] = iters; }
+  }
+}
+
 // global statistics  dirichlet_stats = sum_t r_t,  niw_stats_k = sum_t r_tk stats_t  over many workgroups:
 // thread j of a workgroup accumulates output j over the workgroup's slice of points; the last workgroup to
 // arrive sums the per-workgroup partials in index order.
@@ -495,14 +547,14 @@ static int gmm_mw_stats_grid(int T) {
 struct GmmMwLayout { double* kl_hist; double* partials; double* spart; int32_t* counters; };
 static size_t gmm_mw_doubles(int T, int N, int K, int max_iter) {
   const int D = N + 2;
-  return (size_t)(max_iter + 1) + gmm_mw_grid(T) + (size_t)gmm_mw_stats_grid(T) * K * (1 + D * D);
+  return (size_t)(max_iter + 1) + 3 * gmm_mw_grid(T) + (size_t)gmm_mw_stats_grid(T) * K * (1 + D * D);
 }
 static GmmMwLayout gmm_mw_layout(void* ws, int T, int N, int K, int max_iter) {
   const int D = N + 2;
   GmmMwLayout l;
   l.kl_hist = (double*)ws;
   l.partials = l.kl_hist + (max_iter + 1);
-  l.spart = l.partials + gmm_mw_grid(T);
+  l.spart = l.partials + 3 * gmm_mw_grid(T);
   l.counters = (int32_t*)(l.spart + (size_t)gmm_mw_stats_grid(T) * K * (1 + D * D));
   return l;
 }
@@ -589,3 +641,68 @@ extern "C" int svae_gmm_mw_step_f64(int phase, int sweep, int T, int N, int K,
 
 /* device address of kl_hist[0] inside the workspace (the scalar a multi-GPU caller all-reduces per sweep) */
 extern "C" double* svae_gmm_mw_kl_hist(void* workspace) { return (double*)workspace; }
+
+// The whole fixed point + final pass in ONE cooperative launch (grid barrier per sweep), then the statistics
+// launch: the single-GPU form of the svae_gmm_mw_* sweeps (same per-point code, same fixed-order KL reduction, same
+// results).  Returns -50 if the device cannot co-schedule the grid (fall back to svae_gmm_mw_step_f64).
+extern "C" int svae_gmm_mw_fixed_point_f64(int T, int N, int K,
+                                           const double* label_global, const double* gaussian_globals,
+                                           const double* node_J, const double* node_h,
+                                           const double* label_init, double tol, int max_iter,
+                                           double* label_stats, double* label_fixed, double* gaussian_stats,
+                                           double* label_natparam, double* gaussian_natparam,
+                                           double* dirichlet_stats, double* niw_stats,
+                                           double* kl, int32_t* iters, int32_t* assign, int32_t* info,
+                                           void* workspace, size_t ws_bytes, void* stream) {
+  if (T < 0) return -3;
+  if (N < 1 || N > 8) return -4;
+  if (K < 1 || K > 64) return -5;
+  if (!label_global) return -6;
+  if (!gaussian_globals) return -7;
+  if (T > 0 && (!node_J || !node_h || !label_init)) return -8;
+  if (!(tol >= 0.0)) return -11;
+  if (max_iter < 0) return -12;
+  if (T > 0 && (!label_stats || !gaussian_stats || !label_natparam || !gaussian_natparam)) return -13;
+  if (!dirichlet_stats || !niw_stats || !kl || !iters) return -18;
+  if (T > 0 && !assign) return -22;
+  if (!info) return -23;
+  if (!workspace || ws_bytes < svae_gmm_mw_workspace_bytes(T, N, K, max_iter)) return -24;
+  svae::GmmMwArgs m;
+  svae::GmmArgs& a = m.g;
+  a.T = T; a.K = K; a.max_iter = max_iter; a.tol = tol;
+  a.label_global = label_global; a.gaussian_globals = gaussian_globals;
+  a.node_J = node_J; a.node_h = node_h; a.label_init = label_init;
+  a.label_stats = label_stats; a.label_fixed = label_fixed; a.gaussian_stats = gaussian_stats;
+  a.label_natparam = label_natparam; a.gaussian_natparam = gaussian_natparam;
+  a.dirichlet_stats = dirichlet_stats; a.niw_stats = niw_stats;
+  a.kl = kl; a.iters = iters; a.assign = assign; a.info = info;
+  const svae::GmmMwLayout l = svae::gmm_mw_layout(workspace, T, N, K, max_iter);
+  m.kl_hist = l.kl_hist; m.partials = l.partials; m.counters = l.counters; m.sweep = 0; m.mode = 0;
+  hipStream_t s = (hipStream_t)stream;
+  const void* kern = nullptr;
+  switch (N) {
+    case 1: kern = (const void*)svae::gmm_mw_persistent_kernel<1>; break;
+    case 2: kern = (const void*)svae::gmm_mw_persistent_kernel<2>; break;
+    case 3: kern = (const void*)svae::gmm_mw_persistent_kernel<3>; break;
+    case 4: kern = (const void*)svae::gmm_mw_persistent_kernel<4>; break;
+    case 5: kern = (const void*)svae::gmm_mw_persistent_kernel<5>; break;
+    case 6: kern = (const void*)svae::gmm_mw_persistent_kernel<6>; break;
+    case 7: kern = (const void*)svae::gmm_mw_persistent_kernel<7>; break;
+    case 8: kern = (const void*)svae::gmm_mw_persistent_kernel<8>; break;
+  }
+  int per_cu = 0, dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, svae::GMM_MW_BLOCK, 0) != hipSuccess) return -50;
+  int G = svae::gmm_mw_grid(T);
+  const int cap = per_cu * cus;
+  if (cap < 1) return -50;
+  if (G > cap) G = cap;
+  // the counters section doubles as the statistics kernel's ticket: zero it (kl_hist needs no reset here)
+  if (hipMemsetAsync(l.counters, 0, (size_t)(max_iter + 3) * sizeof(int32_t), s) != hipSuccess) return -1000;
+  void* params[] = {(void*)&m};
+  if (hipLaunchCooperativeKernel(kern, dim3(G), dim3(svae::GMM_MW_BLOCK), params, 0, s) != hipSuccess) return -50;
+  hipLaunchKernelGGL(svae::gmm_mw_stats_kernel, dim3(svae::gmm_mw_stats_grid(T)), dim3(svae::GMM_MW_BLOCK), 0, s,
+                     a, N + 2, l.spart, l.counters + max_iter + 2);
+  return hipGetLastError() == hipSuccess ? 0 : -1000;
+}

@@ -31,7 +31,12 @@ def initialize_meanfield(T, K, device, generator=None):
     return r / r.sum(-1, keepdim=True)
 
 
-GMM_SINGLE_WG_MAX_T = 4096     # above: the multi-workgroup sweeps (one workgroup: 16 k points = 330 us per sweep)
+# Dispatch by minibatch size (measured, tools/bench_gmm.py): one workgroup / one launch up to 512 points (20 us per
+# sweep at 1000 points); several workgroups in ONE cooperative launch with a grid barrier per sweep up to 8192
+# (12 us per sweep at 1000 points; the barrier costs ~20 us on larger grids); beyond, one launch per sweep
+# (16 us at 16 k points, 146 us at 1 M) -- which is also the form that shards over GPUs.
+GMM_SINGLE_WG_MAX_T = 512
+GMM_PERSISTENT_MAX_T = 8192
 
 
 def run_sweeps(backend, max_iter, group=None):
@@ -90,7 +95,7 @@ class _HipSweeps(object):
 
 
 def meanfield_from_globals(label_global, gaussian_globals, node_potentials, label_init,
-                           tol=1e-3, max_iter=100, check=True, multi_wg=None, group=None):
+                           tol=1e-3, max_iter=100, check=True, multi_wg=None, group=None, persistent=True):
     """The kernel call: everything after gmm.py:68.  Returns a dict of device tensors.
 
     multi_wg=None picks the single-workgroup, single-launch kernel for small minibatches and the
@@ -130,7 +135,20 @@ def meanfield_from_globals(label_global, gaussian_globals, node_potentials, labe
     if sharded and not multi_wg:
         raise ValueError("sharded points need the multi-workgroup sweeps (batch-total stopping rule)")
     if multi_wg:
-        run_sweeps(_HipSweeps(lib, (T, N, K), (lg, gg, nJ, nh, li), out, tol, max_iter, dev), int(max_iter), group)
+        be = _HipSweeps(lib, (T, N, K), (lg, gg, nJ, nh, li), out, tol, max_iter, dev)
+        rc = -50
+        if not sharded and persistent and T <= GMM_PERSISTENT_MAX_T:
+            # single GPU: one cooperative launch, a grid barrier per sweep (svae_gmm_mw_fixed_point_f64)
+            rc = lib.svae_gmm_mw_fixed_point_f64(
+                T, N, K, p(lg), p(gg), p(nJ), p(nh), p(li), float(tol), int(max_iter),
+                p(out["label_stats"]), p(out["label_fixed"]), p(out["gaussian_stats"]), p(out["label_natparam"]),
+                p(out["gaussian_natparam"]), p(out["dirichlet_stats"]), p(out["niw_stats"]),
+                p(out["kl"]), p(out["iters"]), p(out["assign"]), p(out["info"]), p(be.ws), be.ws_bytes,
+                _lib.current_stream(dev))
+            if rc != -50:
+                _lib.check(rc, "svae_gmm_mw_fixed_point_f64")
+        if rc == -50:       # sharded points, or the device cannot co-schedule the grid: one launch per sweep
+            run_sweeps(be, int(max_iter), group)
     else:
         rc = lib.svae_gmm_meanfield_f64(
             T, N, K, p(lg), p(gg), p(nJ), p(nh), p(li), float(tol), int(max_iter),

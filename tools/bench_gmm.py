@@ -12,7 +12,7 @@ from svae_amd.models import gmm
 def main():
     dev = torch.device("cuda:0")
     for K, N, T, mw in [(5, 2, 1000, False), (15, 2, 500, False), (5, 2, 16384, False), (5, 2, 16384, True),
-                        (5, 2, 1000, True), (15, 2, 262144, True), (5, 2, 1048576, True)]:
+                        (5, 2, 16384, "sweeps"), (5, 2, 1000, True), (15, 2, 262144, True), (5, 2, 1048576, True)]:
         gen = torch.Generator().manual_seed(K)
         d, niws = gmm.init_pgm_param(K, N, alpha=0.05 / K, niw_conc=0.5, random_scale=3., generator=gen)
         label_global = expfam.dirichlet_expectedstats(d).to(dev)
@@ -21,18 +21,19 @@ def main():
         node = (torch.as_tensor(-0.5 * np.log1p(np.exp(rng.standard_normal((T, N)))), device=dev),
                 torch.as_tensor(3. * rng.standard_normal((T, N)), device=dev))
         init = gmm.initialize_meanfield(T, K, dev)
-        o = gmm.meanfield_from_globals(label_global, gaussian_globals, node, init, multi_wg=mw)
+        kw = dict(multi_wg=bool(mw), persistent=(mw is True))
+        o = gmm.meanfield_from_globals(label_global, gaussian_globals, node, init, **kw)
         torch.cuda.synchronize()
         reps = 20 if T < 100000 else 5
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         ev[0].record()
         for _ in range(reps):
-            o = gmm.meanfield_from_globals(label_global, gaussian_globals, node, init, check=False, multi_wg=mw)
+            o = gmm.meanfield_from_globals(label_global, gaussian_globals, node, init, check=False, **kw)
         ev[1].record(); torch.cuda.synchronize()
         ms = ev[0].elapsed_time(ev[1]) / reps
         it = int(o["iters"])
         print("GMM mean field [%s] K=%d N=%d T=%d: %.1f us per call (host wrapper included), %d sweeps, %.1f us per sweep, "
-              "%.1f M point-sweeps/s, kl %.4f" % ("one launch per sweep, many workgroups" if mw else "one workgroup, one launch",
+              "%.1f M point-sweeps/s, kl %.4f" % (("many workgroups, one cooperative launch" if (mw is True and T <= gmm.GMM_PERSISTENT_MAX_T) else "many workgroups, one launch per sweep") if mw else "one workgroup, one launch",
                                                   K, N, T, 1e3 * ms, it, 1e3 * ms / max(it, 1), T * it / ms / 1e3, float(o["kl"])))
 
 
