@@ -227,11 +227,10 @@ def measure_tile_training(dev, B=64, T=1000, n=64, S=1):
 def measure_slds(dev, B=2048, T=500, n=10, K=8):
     """BASELINE configs[3]: SLDS-SVAE local mean field (coordinate ascent between the HMM kernel and the fused LDS
     mean-field kernel), wall clock of the whole ascent."""
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    from bench_slds import globals_
+    from svae_amd.lds.synthetic_data import rand_slds_global_natparam
     from svae_amd.models import slds_svae
     rng = np.random.default_rng(0)
-    glob = globals_(K, n, rng)
+    glob = rand_slds_global_natparam(K, n, rng)
     node = (torch.as_tensor(-0.5 * (0.5 + rng.random((B, T, n))), device=dev),
             torch.as_tensor(2. * rng.standard_normal((B, T, n)), device=dev))
     eps = torch.randn(B, T, 1, n, dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(0))

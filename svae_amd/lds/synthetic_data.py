@@ -39,3 +39,22 @@ def rand_node_potentials(shape, rng, with_logZ=False):
     if with_logZ:
         return J, h, 0.1 * rng.standard_normal(shape[:-1])
     return J, h
+
+
+def rand_slds_global_natparam(K, n, rng):
+    """SLDS global natural parameters for benchmarks (BASELINE configs[3]): K rotation-like dynamics with different
+    angles, as ((dirichlet (K), dirichlet rows (K,K)), [(NIW dense, MNIW 4-tuple)] * K) of float64 CPU tensors --
+    the nesting of svae/models/slds_svae.py:27-31 (standard -> natural parameters through svae_amd.distributions)."""
+    import torch
+    from ..distributions import expfam
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64)
+    lds = []
+    for k in range(K):
+        nu, S = n + 1. + rng.random(), 2. * (n + 1) * np.eye(n)
+        th = 0.3 * (k + 1)
+        M = 0.95 * np.eye(n)
+        if n >= 2:
+            M[:2, :2] = 0.95 * np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        lds.append((expfam.niw_standard_to_natural(t(S), t(0.3 * rng.standard_normal(n)), t(0.5), t(nu)),
+                    expfam.mniw_standard_to_natural(t(nu), t(S), t(M), t(0.2 * np.eye(n)))))
+    return (t(rng.random(K) * 2.), t(rng.random((K, K)) * 2. + 3. * np.eye(K))), lds

@@ -11,17 +11,8 @@ from svae_amd.lds.lds_inference import LDSEStepPlan
 
 
 def globals_(K, n, rng):
-    """K rotation-like dynamics with different angles (standard -> natural parameters in torch)."""
-    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64)
-    lds = []
-    for k in range(K):
-        nu, S = n + 1. + rng.random(), 2. * (n + 1) * np.eye(n)
-        th = 0.3 * (k + 1)
-        M = 0.95 * np.eye(n)
-        M[:2, :2] = 0.95 * np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
-        lds.append((expfam.niw_standard_to_natural(t(S), t(0.3 * rng.standard_normal(n)), t(0.5), t(nu)),
-                    expfam.mniw_standard_to_natural(t(nu), t(S), t(M), t(0.2 * np.eye(n)))))
-    return (t(rng.random(K) * 2.), t(rng.random((K, K)) * 2. + 3. * np.eye(K))), lds
+    from svae_amd.lds.synthetic_data import rand_slds_global_natparam
+    return rand_slds_global_natparam(K, n, rng)
 
 
 def main():
