@@ -342,18 +342,98 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep1_kernel(const VjpArgs a) {
   }
 }
 
+// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding GLOBAL load and
+// store (s_waitcnt vmcnt(0)), i.e. for the producer's whole prefetch ring and the consumer's output stores, each step
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+typedef double vd2 __attribute__((ext_vector_type(2)));   // (a native vector: stays in registers)
+// one pipeline stage of a producer wavefront: a (sequence, step) record pair as 16-byte pieces, one per lane and k
+template <int KW, int KA> struct Stage { vd2 w[KW], ad[KA]; };
+template <int WP, int AP, int KW, int KA>
+__device__ __forceinline__ void prod_issue(Stage<KW, KA>& sg, const vd2* wrec, const vd2* arec, int t, int lane) {
+  static_for<0, KW>([&](auto k) {
+    const int q = k * 64 + lane;
+    sg.w[k] = wrec[(long)t * WP + (q < WP ? q : WP - 1)];
+  });
+  static_for<0, KA>([&](auto k) {
+    const int q = k * 64 + lane;
+    sg.ad[k] = arec[(long)t * AP + (q < AP ? q : AP - 1)];
+  });
+}
+template <int WP, int AP, int KW, int KA>
+__device__ __forceinline__ void prod_publish(const Stage<KW, KA>& sg, vd2* slot, int lane) {
+  static_for<0, KW>([&](auto k) {
+    const int q = k * 64 + lane;
+    slot[q < WP ? q : WP - 1] = sg.w[k];                  // (clamped lanes rewrite the last pair)
+  });
+  static_for<0, KA>([&](auto k) {
+    const int q = k * 64 + lane;
+    slot[WP + (q < AP ? q : AP - 1)] = sg.ad[k];
+  });
+}
+
 // ---- sweep 2: filter adjoint, backward in time -----------------------------------------------------
-template <int N, bool SAMP, bool SPLIT>
-__global__ __launch_bounds__(64) void lds_vjp_sweep2_kernel(const VjpArgs a) {
+// PROD (small batches): four more wavefronts of the workgroup are PRODUCERS, one per sequence.  The sweep is serial in t and every
+// step's operands -- the E-step record and the sweep-1 record of step t, 5 KB per sequence, written long ago -- come
+// from HBM, ~2 us away, against ~0.9 us of arithmetic; the consumer's registers cannot hold enough steps in flight.
+// The producer can: it keeps PD steps of records in its own registers (it does nothing else), publishes the oldest into
+// an LDS ring of three slots each step, and the consumer reads its operands from LDS.  One s_barrier per step.
+template <int N, bool SAMP, bool SPLIT, bool PROD>
+__device__ __forceinline__ void lds_vjp_sweep2_body(const VjpArgs& a) {
   constexpr int HS = ws_h_stride(N), PS = ws_p_stride(N), WS = ws_step_doubles(N);
   constexpr int AS = vjp_step_doubles(N);
-  const int lane = threadIdx.x;
+  constexpr int REC = WS + AS;                 // doubles per (sequence, step) in a ring slot
+  constexpr int SLOT = 4 * REC;
+  constexpr int PD = 4;                        // steps each producer keeps in flight (24 VGPRs per step: no spills -- scratch reloads would be in-order VMEM too)
+  constexpr int KW = (WS / 2 + 63) / 64, KA = (AS / 2 + 63) / 64;   // 16-byte loads per lane, sequence and record
+  static_assert(WS % 2 == 0 && AS % 2 == 0, "records are copied as 16-byte pairs");
+  __shared__ double ring[PROD ? 3 * SLOT : 2];
+  const int lane = threadIdx.x & 63;
+  const int T = a.T;
+  if constexpr (PROD) {
+    const int wv = threadIdx.x >> 6;
+    if (wv >= 1) {
+      // ---- producer wavefronts: wavefront 1 + r streams the records of the workgroup's sequence r ---------------
+      const int r = wv - 1;
+      const int br = blockIdx.x * 4 + r;
+      const int bb = br < a.B ? br : a.B - 1;
+      const vd2* wrec = reinterpret_cast<const vd2*>(a.ws + (long)bb * ws_seq_doubles(N, T) + ws_zpage_doubles(N));
+      const vd2* arec = reinterpret_cast<const vd2*>(a.adj + ((long)bb * T) * AS);
+      Stage<KW, KA> s0, s1, s2, s3;                      // stage of step t: (T - 1 - t) % 4
+      static_assert(PD == 4, "four named stages");
+      vd2* slot0 = reinterpret_cast<vd2*>(ring) + r * (REC / 2);
+      auto rec = [&](int t) { return t > 0 ? t : 0; };
+      prod_issue<WS / 2, AS / 2>(s0, wrec, arec, rec(T - 1), lane);
+      prod_issue<WS / 2, AS / 2>(s1, wrec, arec, rec(T - 2), lane);
+      prod_issue<WS / 2, AS / 2>(s2, wrec, arec, rec(T - 3), lane);
+      prod_issue<WS / 2, AS / 2>(s3, wrec, arec, rec(T - 4), lane);
+      prod_publish<WS / 2, AS / 2>(s0, slot0 + ((T - 1) % 3) * (SLOT / 2), lane);
+      prod_issue<WS / 2, AS / 2>(s0, wrec, arec, rec(T - 5), lane);
+      lds_barrier();                                     // slot of step T-1 is ready
+      // consumer iteration t: publish step t-1, refill its stage with step t-1-PD, barrier
+#define SVAE_PROD_STEP(sg, t)                                                                         \
+      if ((t) >= 0) {                                                                                   \
+        if ((t) >= 1) prod_publish<WS / 2, AS / 2>(sg, slot0 + (((t) - 1) % 3) * (SLOT / 2), lane);     \
+        prod_issue<WS / 2, AS / 2>(sg, wrec, arec, rec((t) - 1 - PD), lane);                            \
+        lds_barrier();                                                                                  \
+      }
+      for (int t0 = T - 1; t0 >= 0; t0 -= PD) {
+        SVAE_PROD_STEP(s1, t0)
+        SVAE_PROD_STEP(s2, t0 - 1)
+        SVAE_PROD_STEP(s3, t0 - 2)
+        SVAE_PROD_STEP(s0, t0 - 3)
+      }
+#undef SVAE_PROD_STEP
+      return;
+    }
+  }
   const int c = lane & 15;
   const int brow = blockIdx.x * 4 + (lane >> 4);
   const bool valid = brow < a.B;
   const int b = valid ? brow : a.B - 1;
   const bool col = c < N, colN = c <= N;
-  const int T = a.T;
   double E[N];
   static_for<0, N>([&](auto i) { E[i] = (c == i) ? 1.0 : 0.0; });
   const double EN = (c == N) ? 1.0 : 0.0;
@@ -366,6 +446,7 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep2_kernel(const VjpArgs a) {
   const double g = a.g_lognorm[b];
 
   const double* wsb = a.ws + (long)b * ws_seq_doubles(N, T) + ws_zpage_doubles(N);
+  const double* ringrow = ring + (PROD ? (lane >> 4) * REC : 0);   // PROD: this DPP row's record inside a ring slot
   double Ab[N];                                               // [Abar | hbar] of step t+1
   static_for<0, N>([&](auto i) { Ab[i] = 0.0; });
 
@@ -378,17 +459,22 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep2_kernel(const VjpArgs a) {
   const int cN = colN ? c : 0, cc = col ? c : 0;
   double gbn[N], gb2n[(SAMP && SPLIT) ? N : 1];
   auto fetch_g = [&](int t) {
-    const double* ad = a.adj + ((long)b * T + t) * AS;
+    const double* ad = PROD ? ringrow + (t % 3) * SLOT + WS : a.adj + ((long)b * T + t) * AS;
     static_for<0, N>([&](auto i) {
       gbn[i] = ad[i * HS + cN];
       if constexpr (SAMP && SPLIT) gb2n[i] = ad[N * HS + i * HS + cN];
     });
   };
-  fetch_g(T - 1);
+  if constexpr (PROD) lds_barrier();                        // the producers have published step T-1
+  if constexpr (!PROD) fetch_g(T - 1);
   double warm = 0.0, sink = 0.0;
   for (int t = T - 1; t >= 0; --t) {
-    const double* w = wsb + (long)t * WS;
-    const double* ad = a.adj + ((long)b * T + t) * AS;
+    if constexpr (PROD) {
+      lds_barrier();                                          // steps t and t-1 are in the ring
+      fetch_g(t);                                             // (from LDS: no step-ahead register copy needed)
+    }
+    const double* w = PROD ? ringrow + (t % 3) * SLOT : wsb + (long)t * WS;
+    const double* ad = PROD ? w + WS : a.adj + ((long)b * T + t) * AS;
     double Xc[N];
     static_for<0, N>([&](auto i) {
       double gb = gbn[i];
@@ -400,9 +486,9 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep2_kernel(const VjpArgs a) {
     double Pi[N], Hc[N], HT[N + 1];
     static_for<0, N>([&](auto i) { Pi[i] = w[N * HS + i * PS + cc]; Hc[i] = w[i * HS + cN]; });
     load_row<N + 1>(w + cc * HS, HT);                          // H' (lane c: row c of H)
-    fetch_g(t > 0 ? t - 1 : 0);
+    if constexpr (!PROD) fetch_g(t > 0 ? t - 1 : 0);
     sink += warm;                                              // last iteration's touches have landed
-    if (a.B <= 2048) {                                         // (large batches are bandwidth-bound: no extra traffic)
+    if (!PROD && a.B <= 2048) {                                // (large batches are bandwidth-bound: no extra traffic)
       const int tw = t >= VJP_AHEAD ? t - VJP_AHEAD : 0;
       warm = touch_lines<(WS + 15) / 16>(wsb + (long)tw * WS, c, WS)
            + touch_lines<(AS + 15) / 16>(a.adj + ((long)b * T + tw) * AS, c, AS);
@@ -452,6 +538,16 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep2_kernel(const VjpArgs a) {
   }
 }
 
+template <int N, bool SAMP, bool SPLIT>
+__global__ __launch_bounds__(64) void lds_vjp_sweep2_kernel(const VjpArgs a) {
+  lds_vjp_sweep2_body<N, SAMP, SPLIT, false>(a);
+}
+// consumer wavefront + four producer wavefronts
+template <int N, bool SAMP, bool SPLIT>
+__global__ __launch_bounds__(320) void lds_vjp_sweep2_prod_kernel(const VjpArgs a) {
+  lds_vjp_sweep2_body<N, SAMP, SPLIT, true>(a);
+}
+
 template <int N>
 static int launch_vjp(const VjpArgs& a, hipStream_t stream) {
   dim3 grid((a.B + 3) / 4), grid2(2 * ((a.B + 3) / 4)), block(64);
@@ -462,7 +558,8 @@ static int launch_vjp(const VjpArgs& a, hipStream_t stream) {
     else if (statc) hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, true, true, false>), grid, block, 0, stream, a);
     else if (split) hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, true, false, true>), grid2, block, 0, stream, a);
     else hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, true, false, false>), grid, block, 0, stream, a);
-    if (split) hipLaunchKernelGGL((lds_vjp_sweep2_kernel<N, true, true>), grid, block, 0, stream, a);
+    if (split && a.B <= 1024) hipLaunchKernelGGL((lds_vjp_sweep2_prod_kernel<N, true, true>), grid, dim3(320), 0, stream, a);
+    else if (split) hipLaunchKernelGGL((lds_vjp_sweep2_kernel<N, true, true>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((lds_vjp_sweep2_kernel<N, true, false>), grid, block, 0, stream, a);
   } else {
     if (statc) hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, false, true, false>), grid, block, 0, stream, a);
