@@ -90,23 +90,149 @@ __device__ __forceinline__ void for_samples(int S, F&& f) {
   }
 }
 
+// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding GLOBAL load and
+// store (s_waitcnt vmcnt(0)), i.e. for the producer's whole prefetch ring and the consumer's output stores, each step
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+typedef double vd2 __attribute__((ext_vector_type(2)));   // (a native vector: stays in registers)
+// one pipeline stage of a producer wavefront: a (sequence, step) record pair as 16-byte pieces, one per lane and k
+template <int KW, int KA> struct Stage { vd2 w[KW], ad[KA]; };
+template <int WP, int AP, int KW, int KA>
+__device__ __forceinline__ void prod_issue(Stage<KW, KA>& sg, const vd2* wrec, const vd2* arec, int t, int lane) {
+  static_for<0, KW>([&](auto k) {
+    const int q = k * 64 + lane;
+    sg.w[k] = wrec[(long)t * WP + (q < WP ? q : WP - 1)];
+  });
+  static_for<0, KA>([&](auto k) {
+    const int q = k * 64 + lane;
+    sg.ad[k] = arec[(long)t * AP + (q < AP ? q : AP - 1)];
+  });
+}
+template <int WP, int AP, int KW, int KA>
+__device__ __forceinline__ void prod_publish(const Stage<KW, KA>& sg, vd2* slot, int lane) {
+  static_for<0, KW>([&](auto k) {
+    const int q = k * 64 + lane;
+    slot[q < WP ? q : WP - 1] = sg.w[k];                  // (clamped lanes rewrite the last pair)
+  });
+  static_for<0, KA>([&](auto k) {
+    const int q = k * 64 + lane;
+    slot[WP + (q < AP ? q : AP - 1)] = sg.ad[k];
+  });
+}
+
+// producer stage of sweep 1: the step's record is GATHERED from several arrays (8-byte pieces, piece k of lane l is
+// element k*64 + l of the concatenated record); base / stride / step offset of every piece are set up once
+template <int KT> struct GStage { double v[KT]; };
+template <int KT>
+__device__ __forceinline__ void gather_issue(GStage<KT>& sg, const double* const (&base)[KT], const int (&stp)[KT],
+                                             const int (&off)[KT], int t, int T, int kt) {
+  static_for<0, KT>([&](auto k) {
+    if (k < kt) {
+      int tt = t + off[k];
+      tt = tt < T ? tt : T - 1;
+      sg.v[k] = base[k][(long)tt * stp[k]];
+    }
+  });
+}
+template <int KT>
+__device__ __forceinline__ void gather_publish(const GStage<KT>& sg, double* slot, int lane, int kt) {
+  static_for<0, KT>([&](auto k) { if (k < kt) slot[k * 64 + lane] = sg.v[k]; });
+}
+
 // ---- sweep 1: smoother + sampler adjoints, forward in time ----------------------------------------
 // The two adjoint chains of this sweep are independent (the S^ recursion of the smoother; the xhat
 // recursion + noise adjoint of the sampler): with samples they run as two ROLES in separate
 // workgroups (blockIdx.x & 1), each writing its own share of G^ -- the sweep is latency-bound on one
 // wavefront's instruction stream, and small batches leave most SIMDs idle.
-template <int N, bool SAMP, bool STATC, bool SPLIT>
-__global__ __launch_bounds__(64) void lds_vjp_sweep1_kernel(const VjpArgs a) {
+// PROD (small batches, S <= 4): as in sweep 2 below, four more wavefronts of the workgroup are producers, one per
+// sequence; each gathers the step's operands of the workgroup's role (role 0: E-step record, W~, direct cotangents;
+// role 1: H, the LDL' factor, sample cotangents, x_{t+1}, eps) PD steps ahead and publishes them into a two-slot LDS
+// ring; the consumer wavefront reads LDS only.  One s_barrier per step.
+constexpr int VJP_PROD_MAX_S = 4;
+template <int N> constexpr int vjp_s1_pieces() {
+  constexpr int HS = ws_h_stride(N), WS = ws_step_doubles(N);
+  constexpr int r0 = WS + (N + 1) * HS + 2 * N, r1 = N * HS + N * N + N + 3 * VJP_PROD_MAX_S * N;
+  return ((r0 > r1 ? r0 : r1) + 63) / 64;
+}
+// ROLE: 0 = smoother adjoint, 1 = sampler adjoint (SPLIT: the workgroup's role, chosen by the caller -- each role is
+// its own instantiation so that the register allocation is the larger of the two, not their union), 2 = both
+template <int N, bool SAMP, bool STATC, bool SPLIT, bool PROD, int ROLE>
+__device__ __forceinline__ void lds_vjp_sweep1_body(const VjpArgs& a, double* tabs, double* ring) {
   constexpr int HS = ws_h_stride(N), PS = ws_p_stride(N), WS = ws_step_doubles(N);
   constexpr int AS = vjp_step_doubles(N);
-  __shared__ double tabs[4 * 256];
-  const int lane = threadIdx.x;
+  constexpr int W3 = (N + 1) * HS, R1 = N * HS + N * N + N;
+  constexpr int KT = vjp_s1_pieces<N>(), REC = KT * 64, SLOT = 4 * REC, PD = 4;
+  static_assert(!PROD || (!STATC && (SPLIT || !SAMP)), "producers: one role per workgroup, no statistics cotangents");
+  static_assert(ROLE == 2 ? !(SAMP && SPLIT) : (ROLE == 0 || (SAMP && SPLIT)), "role / split mismatch");
+  const int lane = threadIdx.x & 63;
+  if constexpr (PROD) {
+    const int wv = threadIdx.x >> 6;
+    if (wv >= 1) {
+      // ---- producer wavefronts: wavefront 1 + r gathers the records of the workgroup's sequence r ----------------
+      const int r = wv - 1, T = a.T, SN = a.S * N;
+      constexpr bool role1 = ROLE == 1;
+      const int br = (SAMP ? (blockIdx.x >> 1) : blockIdx.x) * 4 + r;
+      const long bb = br < a.B ? br : a.B - 1;
+      const double* wsq = a.ws + bb * ws_seq_doubles(N, T) + ws_zpage_doubles(N);
+      const double* base[KT];
+      int stp[KT], off[KT];
+      static_for<0, KT>([&](auto k) { base[k] = wsq; stp[k] = 0; off[k] = 0; });
+      int start = 0;
+      auto seg = [&](const double* p, int len, int stride, int o) {   // next `len` elements of the record <- p[t * stride ..]
+        static_for<0, KT>([&](auto k) {
+          const int f = k * 64 + lane - start;
+          if (f >= 0 && f < len) { base[k] = p + f; stp[k] = stride; off[k] = o; }
+        });
+        start += len;
+      };
+      if (!role1) {
+        seg(wsq, WS, WS, 0);
+        seg(a.ws3 + bb * T * W3, W3, W3, 0);
+        seg(a.g_x ? a.g_x + bb * T * N : wsq, N, a.g_x ? N : 0, 0);
+        seg(a.g_diagxx ? a.g_diagxx + bb * T * N : wsq, N, a.g_diagxx ? N : 0, 0);
+      } else {
+        seg(wsq, N * HS, WS, 0);
+        seg(a.ws2 + bb * T * (N * N + N), N * N + N, N * N + N, 0);
+        seg(a.g_samples + bb * T * SN, SN, SN, 0);
+        seg(a.samples + bb * T * SN, SN, SN, 1);                    // x_{t+1}
+        seg(a.eps + bb * T * SN, SN, SN, 0);
+      }
+      const int kt = (start + 63) / 64;
+      GStage<KT> s0, s1, s2, s3;                          // stage of step t: t % 4
+      static_assert(PD == 4, "four named stages");
+      double* slot0 = ring + r * REC;
+      gather_issue<KT>(s0, base, stp, off, 0, T, kt);
+      gather_issue<KT>(s1, base, stp, off, 1, T, kt);
+      gather_issue<KT>(s2, base, stp, off, 2, T, kt);
+      gather_issue<KT>(s3, base, stp, off, 3, T, kt);
+      gather_publish<KT>(s0, slot0, lane, kt);
+      gather_issue<KT>(s0, base, stp, off, 4, T, kt);
+      lds_barrier();                                     // barrier 0: step 0 is in slot 0
+      // consumer iteration t (between barriers t and t+1) reads slot t%2: publish step t+1 into the other slot
+#define SVAE_PROD_STEP(sg, t)                                                   \
+      if ((t) + 1 < T) {                                                          \
+        gather_publish<KT>(sg, slot0 + (((t) + 1) & 1) * SLOT, lane, kt);         \
+        gather_issue<KT>(sg, base, stp, off, (t) + 1 + PD, T, kt);                \
+        lds_barrier();                                                            \
+      }
+      for (int t0 = 0; t0 < T; t0 += PD) {
+        SVAE_PROD_STEP(s1, t0)
+        SVAE_PROD_STEP(s2, t0 + 1)
+        SVAE_PROD_STEP(s3, t0 + 2)
+        SVAE_PROD_STEP(s0, t0 + 3)
+      }
+#undef SVAE_PROD_STEP
+      return;
+    }
+  }
   const int c = lane & 15;
   double* tab = tabs + (lane >> 4) * 256;
   // SPLIT (small batches): role 0 = smoother adjoint, role 1 = sampler adjoint, in separate workgroups;
   // otherwise one workgroup runs both bodies back to back
-  const bool do0 = !(SAMP && SPLIT) || (blockIdx.x & 1) == 0;
-  const bool do1 = SAMP && (!SPLIT || (blockIdx.x & 1) == 1);
+  constexpr bool do0 = ROLE != 1;
+  constexpr bool do1 = SAMP && ROLE != 0;
   const int brow = ((SAMP && SPLIT) ? (blockIdx.x >> 1) : blockIdx.x) * 4 + (lane >> 4);
   const bool valid = brow < a.B;
   const int b = valid ? brow : a.B - 1;
@@ -128,6 +254,8 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep1_kernel(const VjpArgs a) {
   const int ss = sv ? c : 0;
 
   const double cm = col ? 1.0 : 0.0;
+  const double* ringrow = ring + (PROD ? (lane >> 4) * REC : 0);    // PROD: this DPP row's record inside a ring slot
+  const int SN = S * N;
   // Memory schedule: the operands a step STARTS with (role 0: W~' and the direct cotangents; role 1: the
   // sample cotangents) are fetched into registers one step ahead; the others (H, P^-1, the LDL' factor) are
   // requested raw at the top of the step and first touched a product later.  Every load unconditional.
@@ -135,22 +263,33 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep1_kernel(const VjpArgs a) {
   const bool has_gx = a.g_x != nullptr, has_gd = a.g_diagxx != nullptr;
   double WTn[N + 1], gxn = 0.0, gdn = 0.0, gsn[SAMP ? N : 1];
   auto fetch_next = [&](int t) {
+    const double* rec = ringrow + (t & 1) * SLOT;               // (PROD)
     if (do0) {
-      load_row<N + 1>(a.ws3 + ((long)b * T + t) * (N + 1) * HS + cN * HS, WTn);
-      const long o = ((long)b * T + t) * N + ccl;
-      gxn = has_gx ? a.g_x[o] : 0.0;
-      gdn = has_gd ? a.g_diagxx[o] : 0.0;
+      load_row<N + 1>(PROD ? rec + WS + cN * HS : a.ws3 + ((long)b * T + t) * (N + 1) * HS + cN * HS, WTn);
+      if constexpr (PROD) {
+        const double x = rec[WS + W3 + ccl], d = rec[WS + W3 + N + ccl];
+        gxn = has_gx ? x : 0.0;
+        gdn = has_gd ? d : 0.0;
+      } else {
+        const long o = ((long)b * T + t) * N + ccl;
+        gxn = has_gx ? a.g_x[o] : 0.0;
+        gdn = has_gd ? a.g_diagxx[o] : 0.0;
+      }
     }
     if constexpr (SAMP) {
       if (do1) {
-        const double* gs = a.g_samples + (((long)b * T + t) * S + ss) * N;
+        const double* gs = PROD ? rec + R1 + ss * N : a.g_samples + (((long)b * T + t) * S + ss) * N;
         static_for<0, N>([&](auto k) { gsn[k] = gs[k]; });
       }
     }
   };
-  fetch_next(0);
+  if constexpr (!PROD) fetch_next(0);
   for (int t = 0; t < T; ++t) {
-    const double* w = wsb + (long)t * WS;
+    if constexpr (PROD) {
+      lds_barrier();                                            // barrier t: step t is in slot t%2
+      fetch_next(t);
+    }
+    const double* w = PROD ? ringrow + (t & 1) * SLOT : wsb + (long)t * WS;
     double* ad = a.adj + ((long)b * T + t) * AS;
     double Hcr[N];
     static_for<0, N>([&](auto k) { Hcr[k] = w[k * HS + cN]; });
@@ -164,7 +303,7 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep1_kernel(const VjpArgs a) {
       static_for<0, N>([&](auto i) { Pir[i] = w[N * HS + i * PS + ccl]; });
     }
     if constexpr (SAMP) static_for<0, N>([&](auto k) { gsv[k] = gsn[k]; });
-    fetch_next(t + 1 < T ? t + 1 : t);
+    if constexpr (!PROD) fetch_next(t + 1 < T ? t + 1 : t);
     double (&Hc)[N] = Hcr;      // raw: lanes > N are zeroed by sg / never broadcast
     if (do0) {
     static_for<0, N>([&](auto k) { Gc[k] = Hc[k] * sg; });
@@ -277,15 +416,17 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep1_kernel(const VjpArgs a) {
       double xn[N];
       static_for<0, N>([&](auto k) { xn[k] = sv ? gsv[k] : 0.0; });
       // the LDL' factor of the step (needed two product stages further down)
-      const double* w2 = a.ws2 + ((long)b * T + t) * (N * N + N);
+      const double* w2 = PROD ? w + N * HS : a.ws2 + ((long)b * T + t) * (N * N + N);
+      const double* x1rec = PROD ? w + R1 + SN : a.samples + ((long)b * T + (t + 1 < T ? t + 1 : t)) * SN;   // x_{t+1}, per sample
+      const double* eprec = PROD ? w + R1 + 2 * SN : a.eps + ((long)b * T + t) * SN;
       double Rr[N];
       static_for<0, N>([&](auto k) { Rr[k] = w2[k * N + ccl]; });
       const double pvv = w2[N * N + ccl];
       double x1r[SPRE], epr[SPRE];
       static_for<0, SPRE>([&](auto s) {
         const int sq = s < S ? (int)s : 0;                      // (clamped: unconditional loads)
-        x1r[s] = a.samples[(((long)b * T + (t + 1 < T ? t + 1 : t)) * S + sq) * N + ccl];
-        epr[s] = a.eps[(((long)b * T + t) * S + sq) * N + ccl];
+        x1r[s] = x1rec[sq * N + ccl];
+        epr[s] = eprec[sq * N + ccl];
       });
       dpp_fence(HcPrev);
       static_for<0, N>([&](auto j) {
@@ -298,8 +439,7 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep1_kernel(const VjpArgs a) {
       for_samples<0>(S, [&](auto s) {
         double v = EN;
         if (t + 1 < T) {
-          const double x1 = (s < SPRE) ? x1r[s < SPRE ? (int)s : 0]
-                                       : a.samples[(((long)b * T + t + 1) * S + s) * N + ccl];
+          const double x1 = (s < SPRE) ? x1r[s < SPRE ? (int)s : 0] : x1rec[s * N + ccl];
           v += col ? x1 : 0.0;
         }
         asm volatile("s_nop 1");   // block entry after the branch: two wait states before the DPP reads (audit rule)
@@ -323,8 +463,7 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep1_kernel(const VjpArgs a) {
       });
       dpp_fence(z);
       for_samples<0>(S, [&](auto s) {
-        const double e1 = (s < SPRE) ? epr[s < SPRE ? (int)s : 0]
-                                     : a.eps[(((long)b * T + t) * S + s) * N + ccl];
+        const double e1 = (s < SPRE) ? epr[s < SPRE ? (int)s : 0] : eprec[s * N + ccl];
         const double ev = col ? e1 : 0.0;
         asm volatile("s_nop 1");   // block entry (audit rule)
         static_for<0, N>([&](auto j) { mac_bc<s>(ET[j], z[j], ev); });         // ET[j][c] = E[c][j]
@@ -342,36 +481,28 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep1_kernel(const VjpArgs a) {
   }
 }
 
-// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding GLOBAL load and
-// store (s_waitcnt vmcnt(0)), i.e. for the producer's whole prefetch ring and the consumer's output stores, each step
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+template <int N> constexpr int vjp_s1_ring_doubles() { return 2 * 4 * vjp_s1_pieces<N>() * 64; }
+template <int N, bool SAMP, bool STATC, bool SPLIT>
+__global__ __launch_bounds__(64) void lds_vjp_sweep1_kernel(const VjpArgs a) {
+  __shared__ double tabs[4 * 256];
+  if constexpr (SAMP && SPLIT) {
+    if ((blockIdx.x & 1) == 0) lds_vjp_sweep1_body<N, SAMP, STATC, SPLIT, false, 0>(a, tabs, nullptr);
+    else lds_vjp_sweep1_body<N, SAMP, STATC, SPLIT, false, 1>(a, tabs, nullptr);
+  } else {
+    lds_vjp_sweep1_body<N, SAMP, STATC, SPLIT, false, 2>(a, tabs, nullptr);
+  }
 }
-
-typedef double vd2 __attribute__((ext_vector_type(2)));   // (a native vector: stays in registers)
-// one pipeline stage of a producer wavefront: a (sequence, step) record pair as 16-byte pieces, one per lane and k
-template <int KW, int KA> struct Stage { vd2 w[KW], ad[KA]; };
-template <int WP, int AP, int KW, int KA>
-__device__ __forceinline__ void prod_issue(Stage<KW, KA>& sg, const vd2* wrec, const vd2* arec, int t, int lane) {
-  static_for<0, KW>([&](auto k) {
-    const int q = k * 64 + lane;
-    sg.w[k] = wrec[(long)t * WP + (q < WP ? q : WP - 1)];
-  });
-  static_for<0, KA>([&](auto k) {
-    const int q = k * 64 + lane;
-    sg.ad[k] = arec[(long)t * AP + (q < AP ? q : AP - 1)];
-  });
-}
-template <int WP, int AP, int KW, int KA>
-__device__ __forceinline__ void prod_publish(const Stage<KW, KA>& sg, vd2* slot, int lane) {
-  static_for<0, KW>([&](auto k) {
-    const int q = k * 64 + lane;
-    slot[q < WP ? q : WP - 1] = sg.w[k];                  // (clamped lanes rewrite the last pair)
-  });
-  static_for<0, KA>([&](auto k) {
-    const int q = k * 64 + lane;
-    slot[WP + (q < AP ? q : AP - 1)] = sg.ad[k];
-  });
+// consumer wavefront + four producer wavefronts
+template <int N, bool SAMP>
+__global__ __launch_bounds__(320) void lds_vjp_sweep1_prod_kernel(const VjpArgs a) {
+  __shared__ double tabs[4 * 256];
+  __shared__ double ring[vjp_s1_ring_doubles<N>()];
+  if constexpr (SAMP) {
+    if ((blockIdx.x & 1) == 0) lds_vjp_sweep1_body<N, true, false, true, true, 0>(a, tabs, ring);
+    else lds_vjp_sweep1_body<N, true, false, true, true, 1>(a, tabs, ring);
+  } else {
+    lds_vjp_sweep1_body<N, false, false, false, true, 2>(a, tabs, ring);
+  }
 }
 
 // ---- sweep 2: filter adjoint, backward in time -----------------------------------------------------
@@ -379,7 +510,7 @@ __device__ __forceinline__ void prod_publish(const Stage<KW, KA>& sg, vd2* slot,
 // step's operands -- the E-step record and the sweep-1 record of step t, 5 KB per sequence, written long ago -- come
 // from HBM, ~2 us away, against ~0.9 us of arithmetic; the consumer's registers cannot hold enough steps in flight.
 // The producer can: it keeps PD steps of records in its own registers (it does nothing else), publishes the oldest into
-// an LDS ring of three slots each step, and the consumer reads its operands from LDS.  One s_barrier per step.
+// an LDS ring of two slots each step, and the consumer reads its operands from LDS.  One s_barrier per step.
 template <int N, bool SAMP, bool SPLIT, bool PROD>
 __device__ __forceinline__ void lds_vjp_sweep2_body(const VjpArgs& a) {
   constexpr int HS = ws_h_stride(N), PS = ws_p_stride(N), WS = ws_step_doubles(N);
@@ -389,7 +520,7 @@ __device__ __forceinline__ void lds_vjp_sweep2_body(const VjpArgs& a) {
   constexpr int PD = 4;                        // steps each producer keeps in flight (24 VGPRs per step: no spills -- scratch reloads would be in-order VMEM too)
   constexpr int KW = (WS / 2 + 63) / 64, KA = (AS / 2 + 63) / 64;   // 16-byte loads per lane, sequence and record
   static_assert(WS % 2 == 0 && AS % 2 == 0, "records are copied as 16-byte pairs");
-  __shared__ double ring[PROD ? 3 * SLOT : 2];
+  __shared__ double ring[PROD ? 2 * SLOT : 2];
   const int lane = threadIdx.x & 63;
   const int T = a.T;
   if constexpr (PROD) {
@@ -409,13 +540,14 @@ __device__ __forceinline__ void lds_vjp_sweep2_body(const VjpArgs& a) {
       prod_issue<WS / 2, AS / 2>(s1, wrec, arec, rec(T - 2), lane);
       prod_issue<WS / 2, AS / 2>(s2, wrec, arec, rec(T - 3), lane);
       prod_issue<WS / 2, AS / 2>(s3, wrec, arec, rec(T - 4), lane);
-      prod_publish<WS / 2, AS / 2>(s0, slot0 + ((T - 1) % 3) * (SLOT / 2), lane);
+      prod_publish<WS / 2, AS / 2>(s0, slot0 + ((T - 1) & 1) * (SLOT / 2), lane);
       prod_issue<WS / 2, AS / 2>(s0, wrec, arec, rec(T - 5), lane);
-      lds_barrier();                                     // slot of step T-1 is ready
-      // consumer iteration t: publish step t-1, refill its stage with step t-1-PD, barrier
+      lds_barrier();                                     // barrier 0: step T-1 is in its slot
+      // consumer iteration t (between two barriers) reads slot t%2: publish step t-1 into the other slot, refill the
+      // stage with step t-1-PD
 #define SVAE_PROD_STEP(sg, t)                                                                         \
-      if ((t) >= 0) {                                                                                   \
-        if ((t) >= 1) prod_publish<WS / 2, AS / 2>(sg, slot0 + (((t) - 1) % 3) * (SLOT / 2), lane);     \
+      if ((t) >= 1) {                                                                                   \
+        prod_publish<WS / 2, AS / 2>(sg, slot0 + (((t) - 1) & 1) * (SLOT / 2), lane);                   \
         prod_issue<WS / 2, AS / 2>(sg, wrec, arec, rec((t) - 1 - PD), lane);                            \
         lds_barrier();                                                                                  \
       }
@@ -459,21 +591,20 @@ __device__ __forceinline__ void lds_vjp_sweep2_body(const VjpArgs& a) {
   const int cN = colN ? c : 0, cc = col ? c : 0;
   double gbn[N], gb2n[(SAMP && SPLIT) ? N : 1];
   auto fetch_g = [&](int t) {
-    const double* ad = PROD ? ringrow + (t % 3) * SLOT + WS : a.adj + ((long)b * T + t) * AS;
+    const double* ad = PROD ? ringrow + (t & 1) * SLOT + WS : a.adj + ((long)b * T + t) * AS;
     static_for<0, N>([&](auto i) {
       gbn[i] = ad[i * HS + cN];
       if constexpr (SAMP && SPLIT) gb2n[i] = ad[N * HS + i * HS + cN];
     });
   };
-  if constexpr (PROD) lds_barrier();                        // the producers have published step T-1
   if constexpr (!PROD) fetch_g(T - 1);
   double warm = 0.0, sink = 0.0;
   for (int t = T - 1; t >= 0; --t) {
     if constexpr (PROD) {
-      lds_barrier();                                          // steps t and t-1 are in the ring
+      lds_barrier();                                          // step t is in slot t%2
       fetch_g(t);                                             // (from LDS: no step-ahead register copy needed)
     }
-    const double* w = PROD ? ringrow + (t % 3) * SLOT : wsb + (long)t * WS;
+    const double* w = PROD ? ringrow + (t & 1) * SLOT : wsb + (long)t * WS;
     const double* ad = PROD ? w + WS : a.adj + ((long)b * T + t) * AS;
     double Xc[N];
     static_for<0, N>([&](auto i) {
@@ -548,6 +679,7 @@ __global__ __launch_bounds__(320) void lds_vjp_sweep2_prod_kernel(const VjpArgs 
   lds_vjp_sweep2_body<N, SAMP, SPLIT, true>(a);
 }
 
+constexpr int VJP_PROD2_MAX_N = 12;     // sweep 2 with producers: beyond, the ring exceeds 64 KB and the consumer spills
 template <int N>
 static int launch_vjp(const VjpArgs& a, hipStream_t stream) {
   dim3 grid((a.B + 3) / 4), grid2(2 * ((a.B + 3) / 4)), block(64);
@@ -556,15 +688,33 @@ static int launch_vjp(const VjpArgs& a, hipStream_t stream) {
   if (a.g_samples) {
     if (statc && split) hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, true, true, true>), grid2, block, 0, stream, a);
     else if (statc) hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, true, true, false>), grid, block, 0, stream, a);
+    else if (split && a.B <= 1024 && a.S <= VJP_PROD_MAX_S)
+      hipLaunchKernelGGL((lds_vjp_sweep1_prod_kernel<N, true>), grid2, dim3(320), 0, stream, a);
     else if (split) hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, true, false, true>), grid2, block, 0, stream, a);
     else hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, true, false, false>), grid, block, 0, stream, a);
-    if (split && a.B <= 1024) hipLaunchKernelGGL((lds_vjp_sweep2_prod_kernel<N, true, true>), grid, dim3(320), 0, stream, a);
+    bool done2 = false;
+    if constexpr (N <= VJP_PROD2_MAX_N) {
+      if (split && a.B <= 1024) {
+        hipLaunchKernelGGL((lds_vjp_sweep2_prod_kernel<N, true, true>), grid, dim3(320), 0, stream, a);
+        done2 = true;
+      }
+    }
+    if (done2) {}
     else if (split) hipLaunchKernelGGL((lds_vjp_sweep2_kernel<N, true, true>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((lds_vjp_sweep2_kernel<N, true, false>), grid, block, 0, stream, a);
   } else {
+    const bool prod = a.B <= 1024;       // small batches: producer wavefronts hide the HBM latency of the serial sweeps
     if (statc) hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, false, true, false>), grid, block, 0, stream, a);
+    else if (prod) hipLaunchKernelGGL((lds_vjp_sweep1_prod_kernel<N, false>), grid, dim3(320), 0, stream, a);
     else hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, false, false, false>), grid, block, 0, stream, a);
-    hipLaunchKernelGGL((lds_vjp_sweep2_kernel<N, false, false>), grid, block, 0, stream, a);
+    bool done2 = false;
+    if constexpr (N <= VJP_PROD2_MAX_N) {
+      if (prod) {
+        hipLaunchKernelGGL((lds_vjp_sweep2_prod_kernel<N, false, false>), grid, dim3(320), 0, stream, a);
+        done2 = true;
+      }
+    }
+    if (!done2) hipLaunchKernelGGL((lds_vjp_sweep2_kernel<N, false, false>), grid, block, 0, stream, a);
   }
   return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
