@@ -125,20 +125,21 @@ __device__ __forceinline__ void prod_publish(const Stage<KW, KA>& sg, vd2* slot,
 // producer stage of sweep 1: the step's record is GATHERED from several arrays (8-byte pieces, piece k of lane l is
 // element k*64 + l of the concatenated record); base / stride / step offset of every piece are set up once
 template <int KT> struct GStage { double v[KT]; };
+// (every piece is loaded and published every step, also those beyond the record's end -- they re-read one valid
+// address: a load count that is not a compile-time constant makes hipcc wait for vmcnt(0), i.e. for the whole prefetch
+// ring, before each publish)
 template <int KT>
 __device__ __forceinline__ void gather_issue(GStage<KT>& sg, const double* const (&base)[KT], const int (&stp)[KT],
-                                             const int (&off)[KT], int t, int T, int kt) {
+                                             const int (&off)[KT], int t, int T) {
   static_for<0, KT>([&](auto k) {
-    if (k < kt) {
-      int tt = t + off[k];
-      tt = tt < T ? tt : T - 1;
-      sg.v[k] = base[k][(long)tt * stp[k]];
-    }
+    int tt = t + off[k];
+    tt = tt < T ? tt : T - 1;
+    sg.v[k] = base[k][(long)tt * stp[k]];
   });
 }
 template <int KT>
-__device__ __forceinline__ void gather_publish(const GStage<KT>& sg, double* slot, int lane, int kt) {
-  static_for<0, KT>([&](auto k) { if (k < kt) slot[k * 64 + lane] = sg.v[k]; });
+__device__ __forceinline__ void gather_publish(const GStage<KT>& sg, double* slot, int lane) {
+  static_for<0, KT>([&](auto k) { slot[k * 64 + lane] = sg.v[k]; });
 }
 
 // ---- sweep 1: smoother + sampler adjoints, forward in time ----------------------------------------
@@ -148,9 +149,17 @@ __device__ __forceinline__ void gather_publish(const GStage<KT>& sg, double* slo
 // wavefront's instruction stream, and small batches leave most SIMDs idle.
 // PROD (small batches, S <= 4): as in sweep 2 below, four more wavefronts of the workgroup are producers, one per
 // sequence; each gathers the step's operands of the workgroup's role (role 0: E-step record, W~, direct cotangents;
-// role 1: H, the LDL' factor, sample cotangents, x_{t+1}, eps) PD steps ahead and publishes them into a two-slot LDS
+// role 1: H, the LDL' factor, sample cotangents, x_{t+1}, eps) PD steps ahead and publishes them into a three-slot LDS
 // ring; the consumer wavefront reads LDS only.  One s_barrier per step.
+// The consumer keeps ONLY the recursions (role 0: S^ and G^; role 1: xhat and its share of G^).  What a step computes
+// without feeding the next one -- role 0: -P^-1 Pinvbar P^-1; role 1: the whole noise adjoint -- goes to HELPER
+// wavefronts of the workgroup (role 0: one; role 1: two, taking alternate steps, each job spread over two barrier
+// intervals): the consumer leaves Pinvbar_t / xhat_t in an LDS mailbox, the helper picks it up one barrier later
+// together with the step's record, which is still in the ring.
+// Barriers are numbered 0 .. T and every wavefront of the workgroup executes each exactly once:
+//   barrier t (t < T): step t's record is in ring slot t%3;  barrier t+1: the consumer's mailbox of step t is written.
 constexpr int VJP_PROD_MAX_S = 4;
+constexpr int VJP_S1_WAVES = 7;              // consumer, 4 producers, up to 2 helpers
 template <int N> constexpr int vjp_s1_pieces() {
   constexpr int HS = ws_h_stride(N), WS = ws_step_doubles(N);
   constexpr int r0 = WS + (N + 1) * HS + 2 * N, r1 = N * HS + N * N + N + 3 * VJP_PROD_MAX_S * N;
@@ -159,16 +168,98 @@ template <int N> constexpr int vjp_s1_pieces() {
 // ROLE: 0 = smoother adjoint, 1 = sampler adjoint (SPLIT: the workgroup's role, chosen by the caller -- each role is
 // its own instantiation so that the register allocation is the larger of the two, not their union), 2 = both
 template <int N, bool SAMP, bool STATC, bool SPLIT, bool PROD, int ROLE>
-__device__ __forceinline__ void lds_vjp_sweep1_body(const VjpArgs& a, double* tabs, double* ring) {
+__device__ __forceinline__ void lds_vjp_sweep1_body(const VjpArgs& a, double* tabs, double* ring, double* mail) {
   constexpr int HS = ws_h_stride(N), PS = ws_p_stride(N), WS = ws_step_doubles(N);
   constexpr int AS = vjp_step_doubles(N);
   constexpr int W3 = (N + 1) * HS, R1 = N * HS + N * N + N;
   constexpr int KT = vjp_s1_pieces<N>(), REC = KT * 64, SLOT = 4 * REC, PD = 4;
   static_assert(!PROD || (!STATC && (SPLIT || !SAMP)), "producers: one role per workgroup, no statistics cotangents");
   static_assert(ROLE == 2 ? !(SAMP && SPLIT) : (ROLE == 0 || (SAMP && SPLIT)), "role / split mismatch");
+  constexpr int MSLOT = 4 * N * 16;            // mailbox slot: per DPP row, N registers of 16 lanes
   const int lane = threadIdx.x & 63;
   if constexpr (PROD) {
     const int wv = threadIdx.x >> 6;
+    if (wv >= 5) {
+      // ---- helper wavefronts ---------------------------------------------------------------------------------------
+      constexpr int NH = ROLE == 1 ? 2 : 1;
+      const int h = wv - 5, T = a.T;
+      if (h >= NH) return;
+      const int c = lane & 15, row = lane >> 4;
+      const int brow = (SAMP ? (blockIdx.x >> 1) : blockIdx.x) * 4 + row;
+      const bool valid = brow < a.B;
+      const long b = valid ? brow : a.B - 1;
+      const bool col = c < N;
+      const int ccl = col ? c : 0;
+      const double* ringrow = ring + row * REC;
+      const double* mailrow = mail + row * N * 16;
+      if constexpr (ROLE != 1) {
+        // the part of Pbar_t that does not depend on sweep 2:  -P^-1 Pinvbar P^-1
+        lds_barrier();                                                 // barrier 0
+        for (int t = 0; t < T; ++t) {
+          lds_barrier();                                               // barrier t+1: Pinvbar_t is in the mailbox
+          const double* rec = ringrow + (t % 3) * SLOT;
+          const double* mb = mailrow + (t & 1) * MSLOT;
+          double Pi[N], Pib[N], T1[N], Pbp[N];
+          static_for<0, N>([&](auto i) {
+            Pi[i] = rec[N * HS + i * PS + ccl];
+            Pib[i] = mb[i * 16 + c];
+            T1[i] = 0.0; Pbp[i] = 0.0;
+          });
+          mm_ab<N, N, false>(T1, Pib, Pi);
+          mm_ab<N, N, true>(Pbp, Pi, T1);
+          double* ad = a.adj + (b * T + t) * AS;
+          if (valid && col) static_for<0, N>([&](auto i) { ad[2 * N * HS + i * PS + c] = Pbp[i]; });
+        }
+      } else {
+        // noise adjoint:  Pbar_t(direct) = -U (Lh U')  with  U = L^-T D^-1/2,  Lh from E' = sum_s eps_s z_s'
+        const int S = a.S, SN = S * N;
+        double* tab = tabs + (h * 4 + row) * 256;
+        double E[N], mU[N];
+        static_for<0, N>([&](auto i) { E[i] = (c == i) ? 1.0 : 0.0; });
+        static_for<0, N>([&](auto j) { mU[j] = (c > j) ? 1.0 : ((c == j) ? 0.5 : 0.0); });
+        for (int k = 0; k <= h; ++k) lds_barrier();                    // barriers 0 .. h
+        for (int t = h; t < T; t += 2) {
+          lds_barrier();                                               // barrier t+1: xhat_t is in the mailbox
+          const double* rec = ringrow + (t % 3) * SLOT;
+          const double* mb = mailrow + (t & 1) * MSLOT;
+          double xh[N], R[N], epr[VJP_PROD_MAX_S];
+          static_for<0, N>([&](auto k) { xh[k] = mb[k * 16 + c]; R[k] = rec[N * HS + k * N + ccl]; });
+          const double pvv = rec[N * HS + N * N + ccl];
+          static_for<0, VJP_PROD_MAX_S>([&](auto s) {
+            const int sq = s < S ? (int)s : 0;
+            epr[s] = rec[R1 + 2 * SN + sq * N + ccl];
+          });
+          double U[N];
+          const double dis = col ? rsqrt_nr(pvv) : 0.0;
+          static_for<0, N>([&](auto k) { U[k] = E[k] * dis; });
+          dpp_fence(R);
+          static_for<1, N>([&](auto jj) {
+            constexpr int j = N - jj;
+            static_for<0, j>([&](auto k) { mac_bc<j, true>(U[k], R[k], U[j]); });
+          });
+          double z[N], ET[N];
+          static_for<0, N>([&](auto j) { z[j] = 0.0; ET[j] = 0.0; });
+          dpp_fence(U);
+          static_for<0, N>([&](auto i) {
+            static_for<0, N>([&](auto j) { mac_bc<j>(z[j], U[i], xh[i]); });        // z = U' xhat
+          });
+          dpp_fence(z);
+          static_for<0, VJP_PROD_MAX_S>([&](auto s) {
+            const double ev = (col && s < S) ? epr[s] : 0.0;                         // (S <= 4: no branches)
+            static_for<0, N>([&](auto j) { mac_bc<s>(ET[j], z[j], ev); });         // ET[j][c] = E[c][j]
+          });
+          if (t + 2 <= T) lds_barrier();                               // barrier t+2 (the job spans two intervals)
+          double LhT[N], K[N], KT_[N], Pex[N];
+          static_for<0, N>([&](auto j) { LhT[j] = ET[j] * mU[j]; K[j] = 0.0; Pex[j] = 0.0; });
+          mm_ab<N, N, false>(K, U, LhT);              // K = U Lh'
+          transpose_tile<N>(tab, c, K, KT_);          // KT = Lh U'
+          mm_ab<N, N, true>(Pex, U, KT_);             // Pex = -U Lh U'
+          double* ad = a.adj + (b * T + t) * AS;
+          if (valid && col) static_for<0, N>([&](auto i) { ad[2 * N * HS + N * PS + i * PS + c] = Pex[i]; });
+        }
+      }
+      return;
+    }
     if (wv >= 1) {
       // ---- producer wavefronts: wavefront 1 + r gathers the records of the workgroup's sequence r ----------------
       const int r = wv - 1, T = a.T, SN = a.S * N;
@@ -199,36 +290,44 @@ __device__ __forceinline__ void lds_vjp_sweep1_body(const VjpArgs& a, double* ta
         seg(a.samples + bb * T * SN, SN, SN, 1);                    // x_{t+1}
         seg(a.eps + bb * T * SN, SN, SN, 0);
       }
-      const int kt = (start + 63) / 64;
       GStage<KT> s0, s1, s2, s3;                          // stage of step t: t % 4
       static_assert(PD == 4, "four named stages");
       double* slot0 = ring + r * REC;
-      gather_issue<KT>(s0, base, stp, off, 0, T, kt);
-      gather_issue<KT>(s1, base, stp, off, 1, T, kt);
-      gather_issue<KT>(s2, base, stp, off, 2, T, kt);
-      gather_issue<KT>(s3, base, stp, off, 3, T, kt);
-      gather_publish<KT>(s0, slot0, lane, kt);
-      gather_issue<KT>(s0, base, stp, off, 4, T, kt);
+      gather_issue<KT>(s0, base, stp, off, 0, T);
+      gather_issue<KT>(s1, base, stp, off, 1, T);
+      gather_issue<KT>(s2, base, stp, off, 2, T);
+      gather_issue<KT>(s3, base, stp, off, 3, T);
+      gather_publish<KT>(s0, slot0, lane);
+      gather_issue<KT>(s0, base, stp, off, 4, T);
       lds_barrier();                                     // barrier 0: step 0 is in slot 0
-      // consumer iteration t (between barriers t and t+1) reads slot t%2: publish step t+1 into the other slot
-#define SVAE_PROD_STEP(sg, t)                                                   \
-      if ((t) + 1 < T) {                                                          \
-        gather_publish<KT>(sg, slot0 + (((t) + 1) & 1) * SLOT, lane, kt);         \
-        gather_issue<KT>(sg, base, stp, off, (t) + 1 + PD, T, kt);                \
-        lds_barrier();                                                            \
+      // consumer iteration t (between barriers t and t+1) reads slot t%3, the helpers slot (t-1)%3: publish step t+1
+      // into the third
+      // (the steady-state loop has no branch inside: across one, hipcc's wait-count bookkeeping degrades to
+      // vmcnt(0) before every publish, i.e. a prefetch distance of one step)
+#define SVAE_PROD_STEP(sg, t)                                                 \
+      {                                                                         \
+        gather_publish<KT>(sg, slot0 + (((t) + 1) % 3) * SLOT, lane);           \
+        gather_issue<KT>(sg, base, stp, off, (t) + 1 + PD, T);                  \
+        lds_barrier();                                                          \
       }
-      for (int t0 = 0; t0 < T; t0 += PD) {
+      int t0 = 0;
+      for (; t0 + 4 < T; t0 += PD) {
         SVAE_PROD_STEP(s1, t0)
         SVAE_PROD_STEP(s2, t0 + 1)
         SVAE_PROD_STEP(s3, t0 + 2)
         SVAE_PROD_STEP(s0, t0 + 3)
       }
+      if (t0 + 1 < T) SVAE_PROD_STEP(s1, t0)
+      if (t0 + 2 < T) SVAE_PROD_STEP(s2, t0 + 1)
+      if (t0 + 3 < T) SVAE_PROD_STEP(s3, t0 + 2)
 #undef SVAE_PROD_STEP
+      lds_barrier();                                     // barrier T
       return;
     }
   }
   const int c = lane & 15;
   double* tab = tabs + (lane >> 4) * 256;
+  double* mailrow = mail + (PROD ? (lane >> 4) * N * 16 : 0);
   // SPLIT (small batches): role 0 = smoother adjoint, role 1 = sampler adjoint, in separate workgroups;
   // otherwise one workgroup runs both bodies back to back
   constexpr bool do0 = ROLE != 1;
@@ -263,7 +362,7 @@ __device__ __forceinline__ void lds_vjp_sweep1_body(const VjpArgs& a, double* ta
   const bool has_gx = a.g_x != nullptr, has_gd = a.g_diagxx != nullptr;
   double WTn[N + 1], gxn = 0.0, gdn = 0.0, gsn[SAMP ? N : 1];
   auto fetch_next = [&](int t) {
-    const double* rec = ringrow + (t & 1) * SLOT;               // (PROD)
+    const double* rec = ringrow + (t % 3) * SLOT;               // (PROD)
     if (do0) {
       load_row<N + 1>(PROD ? rec + WS + cN * HS : a.ws3 + ((long)b * T + t) * (N + 1) * HS + cN * HS, WTn);
       if constexpr (PROD) {
@@ -286,10 +385,10 @@ __device__ __forceinline__ void lds_vjp_sweep1_body(const VjpArgs& a, double* ta
   if constexpr (!PROD) fetch_next(0);
   for (int t = 0; t < T; ++t) {
     if constexpr (PROD) {
-      lds_barrier();                                            // barrier t: step t is in slot t%2
+      lds_barrier();                                            // barrier t: step t is in slot t%3
       fetch_next(t);
     }
-    const double* w = PROD ? ringrow + (t & 1) * SLOT : wsb + (long)t * WS;
+    const double* w = PROD ? ringrow + (t % 3) * SLOT : wsb + (long)t * WS;
     double* ad = a.adj + ((long)b * T + t) * AS;
     double Hcr[N];
     static_for<0, N>([&](auto k) { Hcr[k] = w[k * HS + cN]; });
@@ -300,7 +399,7 @@ __device__ __forceinline__ void lds_vjp_sweep1_body(const VjpArgs& a, double* ta
       static_for<0, N + 1>([&](auto k) { WT[k] = colN ? 2.0 * WTn[k] : 0.0; });      // 2 W~'
       gx = col ? 0.5 * gxn : 0.0;              // direct cotangents, symmetrised
       gd = col ? gdn : 0.0;
-      static_for<0, N>([&](auto i) { Pir[i] = w[N * HS + i * PS + ccl]; });
+      if constexpr (!PROD) static_for<0, N>([&](auto i) { Pir[i] = w[N * HS + i * PS + ccl]; });
     }
     if constexpr (SAMP) static_for<0, N>([&](auto k) { gsv[k] = gsn[k]; });
     if constexpr (!PROD) fetch_next(t + 1 < T ? t + 1 : t);
@@ -372,7 +471,11 @@ __device__ __forceinline__ void lds_vjp_sweep1_body(const VjpArgs& a, double* ta
         mm_ab<N, N, false>(Gb, Cb, Snx);
       }
     }
-    {
+    if constexpr (PROD) {
+      // Pinvbar = S^[:n,:n] (before the propagation below) for the helper wavefront
+      double* mb = mailrow + (t & 1) * MSLOT;
+      static_for<0, N>([&](auto i) { mb[i * 16 + c] = Sh[i] * cm; });
+    } else {
       // the part of Pbar_t that does not depend on the filter-adjoint recursion of sweep 2:
       //   -P^-1 Pinvbar P^-1,   Pinvbar = S^[:n,:n] (before the propagation below)
       double Pi[N], Pib[N], T1[N], Pbp[N];
@@ -419,20 +522,26 @@ __device__ __forceinline__ void lds_vjp_sweep1_body(const VjpArgs& a, double* ta
       const double* w2 = PROD ? w + N * HS : a.ws2 + ((long)b * T + t) * (N * N + N);
       const double* x1rec = PROD ? w + R1 + SN : a.samples + ((long)b * T + (t + 1 < T ? t + 1 : t)) * SN;   // x_{t+1}, per sample
       const double* eprec = PROD ? w + R1 + 2 * SN : a.eps + ((long)b * T + t) * SN;
-      double Rr[N];
-      static_for<0, N>([&](auto k) { Rr[k] = w2[k * N + ccl]; });
-      const double pvv = w2[N * N + ccl];
+      double Rr[N], pvv = 1.0;
+      if constexpr (!PROD) {
+        static_for<0, N>([&](auto k) { Rr[k] = w2[k * N + ccl]; });
+        pvv = w2[N * N + ccl];
+      }
       double x1r[SPRE], epr[SPRE];
       static_for<0, SPRE>([&](auto s) {
         const int sq = s < S ? (int)s : 0;                      // (clamped: unconditional loads)
         x1r[s] = x1rec[sq * N + ccl];
-        epr[s] = eprec[sq * N + ccl];
+        if constexpr (!PROD) epr[s] = eprec[sq * N + ccl];
       });
       dpp_fence(HcPrev);
       static_for<0, N>([&](auto j) {
         static_for<0, N>([&](auto k) { mac_bc<k, true>(xn[k], HcPrev[j], xh[j]); });
       });
       static_for<0, N>([&](auto k) { xh[k] = xn[k]; HcPrev[k] = Hc[k]; });
+      if constexpr (PROD) {                        // xhat_t for the helper wavefronts (noise adjoint)
+        double* mb = mailrow + (t & 1) * MSLOT;
+        static_for<0, N>([&](auto k) { mb[k * 16 + c] = xh[k]; });
+      }
       dpp_fence(xh);
       // cbar_t += sum_s xhat (lane N);  Xbar_t -= sum_s xhat x_{t+1}'  (i.e. G^[:, :n] += ...)
       // (x_{t+1} and eps of the first samples were requested at the top of the role: x1r, epr)
@@ -445,6 +554,7 @@ __device__ __forceinline__ void lds_vjp_sweep1_body(const VjpArgs& a, double* ta
         asm volatile("s_nop 1");   // block entry after the branch: two wait states before the DPP reads (audit rule)
         static_for<0, N>([&](auto i) { mac_bc<s>(Gb[i], xh[i], v); });
       });
+      if constexpr (!PROD) {
       // noise adjoint:  Pbar_t(direct) = -U (Lh U')  with  U = L^-T D^-1/2,  Lh from E' = sum_s eps_s z_s'
       double R[N], U[N];
       static_for<0, N>([&](auto k) { R[k] = Rr[k]; });
@@ -474,34 +584,37 @@ __device__ __forceinline__ void lds_vjp_sweep1_body(const VjpArgs& a, double* ta
       transpose_tile<N>(tab, c, K, KT);           // KT = Lh U'
       mm_ab<N, N, true>(Pex, U, KT);              // Pex = -U Lh U'
       if (valid && col) static_for<0, N>([&](auto i) { ad[2 * N * HS + N * PS + i * PS + c] = Pex[i]; });
+      }
       // sampler share of G^ (SPLIT), or the total when this workgroup ran both bodies
       if (valid && colN) static_for<0, N>([&](auto i) { ad[(SPLIT ? N * HS : 0) + i * HS + c] = Gb[i]; });
       }   // sampler adjoint
     }
   }
+  if constexpr (PROD) lds_barrier();               // barrier T
 }
 
-template <int N> constexpr int vjp_s1_ring_doubles() { return 2 * 4 * vjp_s1_pieces<N>() * 64; }
+template <int N> constexpr int vjp_s1_ring_doubles() { return 3 * 4 * vjp_s1_pieces<N>() * 64; }
 template <int N, bool SAMP, bool STATC, bool SPLIT>
 __global__ __launch_bounds__(64) void lds_vjp_sweep1_kernel(const VjpArgs a) {
   __shared__ double tabs[4 * 256];
   if constexpr (SAMP && SPLIT) {
-    if ((blockIdx.x & 1) == 0) lds_vjp_sweep1_body<N, SAMP, STATC, SPLIT, false, 0>(a, tabs, nullptr);
-    else lds_vjp_sweep1_body<N, SAMP, STATC, SPLIT, false, 1>(a, tabs, nullptr);
+    if ((blockIdx.x & 1) == 0) lds_vjp_sweep1_body<N, SAMP, STATC, SPLIT, false, 0>(a, tabs, nullptr, nullptr);
+    else lds_vjp_sweep1_body<N, SAMP, STATC, SPLIT, false, 1>(a, tabs, nullptr, nullptr);
   } else {
-    lds_vjp_sweep1_body<N, SAMP, STATC, SPLIT, false, 2>(a, tabs, nullptr);
+    lds_vjp_sweep1_body<N, SAMP, STATC, SPLIT, false, 2>(a, tabs, nullptr, nullptr);
   }
 }
-// consumer wavefront + four producer wavefronts
+// consumer wavefront + four producer wavefronts + helper wavefronts
 template <int N, bool SAMP>
-__global__ __launch_bounds__(320) void lds_vjp_sweep1_prod_kernel(const VjpArgs a) {
-  __shared__ double tabs[4 * 256];
+__global__ __launch_bounds__(64 * VJP_S1_WAVES) void lds_vjp_sweep1_prod_kernel(const VjpArgs a) {
+  __shared__ double tabs[2 * 4 * 256];
   __shared__ double ring[vjp_s1_ring_doubles<N>()];
+  __shared__ double mail[2 * 4 * N * 16];
   if constexpr (SAMP) {
-    if ((blockIdx.x & 1) == 0) lds_vjp_sweep1_body<N, true, false, true, true, 0>(a, tabs, ring);
-    else lds_vjp_sweep1_body<N, true, false, true, true, 1>(a, tabs, ring);
+    if ((blockIdx.x & 1) == 0) lds_vjp_sweep1_body<N, true, false, true, true, 0>(a, tabs, ring, mail);
+    else lds_vjp_sweep1_body<N, true, false, true, true, 1>(a, tabs, ring, mail);
   } else {
-    lds_vjp_sweep1_body<N, false, false, false, true, 2>(a, tabs, ring);
+    lds_vjp_sweep1_body<N, false, false, false, true, 2>(a, tabs, ring, mail);
   }
 }
 
@@ -545,18 +658,23 @@ __device__ __forceinline__ void lds_vjp_sweep2_body(const VjpArgs& a) {
       lds_barrier();                                     // barrier 0: step T-1 is in its slot
       // consumer iteration t (between two barriers) reads slot t%2: publish step t-1 into the other slot, refill the
       // stage with step t-1-PD
+      // (no branch inside the steady-state loop: see sweep 1)
 #define SVAE_PROD_STEP(sg, t)                                                                         \
-      if ((t) >= 1) {                                                                                   \
+      {                                                                                                 \
         prod_publish<WS / 2, AS / 2>(sg, slot0 + (((t) - 1) & 1) * (SLOT / 2), lane);                   \
         prod_issue<WS / 2, AS / 2>(sg, wrec, arec, rec((t) - 1 - PD), lane);                            \
         lds_barrier();                                                                                  \
       }
-      for (int t0 = T - 1; t0 >= 0; t0 -= PD) {
+      int t0 = T - 1;
+      for (; t0 >= 4; t0 -= PD) {
         SVAE_PROD_STEP(s1, t0)
         SVAE_PROD_STEP(s2, t0 - 1)
         SVAE_PROD_STEP(s3, t0 - 2)
         SVAE_PROD_STEP(s0, t0 - 3)
       }
+      if (t0 >= 1) SVAE_PROD_STEP(s1, t0)
+      if (t0 >= 2) SVAE_PROD_STEP(s2, t0 - 1)
+      if (t0 >= 3) SVAE_PROD_STEP(s3, t0 - 2)
 #undef SVAE_PROD_STEP
       return;
     }
@@ -689,7 +807,7 @@ static int launch_vjp(const VjpArgs& a, hipStream_t stream) {
     if (statc && split) hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, true, true, true>), grid2, block, 0, stream, a);
     else if (statc) hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, true, true, false>), grid, block, 0, stream, a);
     else if (split && a.B <= 1024 && a.S <= VJP_PROD_MAX_S)
-      hipLaunchKernelGGL((lds_vjp_sweep1_prod_kernel<N, true>), grid2, dim3(320), 0, stream, a);
+      hipLaunchKernelGGL((lds_vjp_sweep1_prod_kernel<N, true>), grid2, dim3(64 * VJP_S1_WAVES), 0, stream, a);
     else if (split) hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, true, false, true>), grid2, block, 0, stream, a);
     else hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, true, false, false>), grid, block, 0, stream, a);
     bool done2 = false;
@@ -705,7 +823,7 @@ static int launch_vjp(const VjpArgs& a, hipStream_t stream) {
   } else {
     const bool prod = a.B <= 1024;       // small batches: producer wavefronts hide the HBM latency of the serial sweeps
     if (statc) hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, false, true, false>), grid, block, 0, stream, a);
-    else if (prod) hipLaunchKernelGGL((lds_vjp_sweep1_prod_kernel<N, false>), grid, dim3(320), 0, stream, a);
+    else if (prod) hipLaunchKernelGGL((lds_vjp_sweep1_prod_kernel<N, false>), grid, dim3(64 * VJP_S1_WAVES), 0, stream, a);
     else hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, false, false, false>), grid, block, 0, stream, a);
     bool done2 = false;
     if constexpr (N <= VJP_PROD2_MAX_N) {
