@@ -29,7 +29,11 @@ def _setup(n, T, B, S, seed):
 
 
 @pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
-@pytest.mark.parametrize("n,T,B,S", [(3, 6, 2, 2), (10, 25, 5, 1), (10, 40, 3, 4), (15, 5, 1, 3), (1, 4, 2, 1)])
+# (small batches run the sweeps with producer / helper wavefronts for S <= 4, sweep 2 for n <= 12: the cases cover
+#  T = 1, 2, 3 -- every wavefront of a workgroup must execute the same T+1 barriers --, S > 4 and n > 12)
+@pytest.mark.parametrize("n,T,B,S", [(3, 6, 2, 2), (10, 25, 5, 1), (10, 40, 3, 4), (15, 5, 1, 3), (1, 4, 2, 1),
+                                     (5, 1, 3, 1), (7, 2, 5, 2), (10, 3, 2, 4), (6, 9, 3, 6), (13, 7, 2, 2),
+                                     (12, 8, 6, 3)])
 @pytest.mark.parametrize("with_samples", [False, True])
 def test_vjp_against_reference_compiled_vjps(n, T, B, S, with_samples):
     from svae_amd.lds.lds_inference import lds_inference_differentiable
