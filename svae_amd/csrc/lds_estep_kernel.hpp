@@ -513,6 +513,58 @@ static int launch_filter(const LdsArgs& a, bool inhomog, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
+// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding GLOBAL load and
+// store (s_waitcnt vmcnt(0)), i.e. for the producer's whole prefetch ring and the consumer's output stores, each step
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+typedef double vd2 __attribute__((ext_vector_type(2)));   // (a native vector: stays in registers)
+// one pipeline stage of a producer wavefront: a (sequence, step) record pair as 16-byte pieces, one per lane and k
+template <int KW, int KA> struct Stage { vd2 w[KW], ad[KA]; };
+template <int WP, int AP, int KW, int KA>
+__device__ __forceinline__ void prod_issue(Stage<KW, KA>& sg, const vd2* wrec, const vd2* arec, int t, int lane) {
+  static_for<0, KW>([&](auto k) {
+    const int q = k * 64 + lane;
+    sg.w[k] = wrec[(long)t * WP + (q < WP ? q : WP - 1)];
+  });
+  static_for<0, KA>([&](auto k) {
+    const int q = k * 64 + lane;
+    sg.ad[k] = arec[(long)t * AP + (q < AP ? q : AP - 1)];
+  });
+}
+template <int WP, int AP, int KW, int KA>
+__device__ __forceinline__ void prod_publish(const Stage<KW, KA>& sg, vd2* slot, int lane) {
+  static_for<0, KW>([&](auto k) {
+    const int q = k * 64 + lane;
+    slot[q < WP ? q : WP - 1] = sg.w[k];                  // (clamped lanes rewrite the last pair)
+  });
+  static_for<0, KA>([&](auto k) {
+    const int q = k * 64 + lane;
+    slot[WP + (q < AP ? q : AP - 1)] = sg.ad[k];
+  });
+}
+
+// producer stage of sweep 1: the step's record is GATHERED from several arrays (8-byte pieces, piece k of lane l is
+// element k*64 + l of the concatenated record); base / stride / step offset of every piece are set up once
+template <int KT> struct GStage { double v[KT]; };
+// (every piece is loaded and published every step, also those beyond the record's end -- they re-read one valid
+// address: a load count that is not a compile-time constant makes hipcc wait for vmcnt(0), i.e. for the whole prefetch
+// ring, before each publish)
+template <int KT>
+__device__ __forceinline__ void gather_issue(GStage<KT>& sg, const double* const (&base)[KT], const int (&stp)[KT],
+                                             const int (&off)[KT], int t, int T) {
+  static_for<0, KT>([&](auto k) {
+    int tt = t + off[k];
+    tt = tt < T ? tt : T - 1;
+    sg.v[k] = base[k][(long)tt * stp[k]];
+  });
+}
+template <int KT>
+__device__ __forceinline__ void gather_publish(const GStage<KT>& sg, double* slot, int lane) {
+  static_for<0, KT>([&](auto k) { slot[k * 64 + lane] = sg.v[k]; });
+}
+
 // ---- backward sampler ---------------------------------------------------------------------------
 // natural_sample_backward (svae/lds/cython_lds_inference.pyx:310-355; _natural_sample
 // cython_gaussian_grads.pxd:431-454, _natural_condition_on :489-508):
@@ -662,9 +714,131 @@ __global__ __launch_bounds__(64) void lds_sample_vec_kernel(const SampleArgs a) 
   }
 }
 
+// The same sampler with PRODUCER wavefronts (small batches): at ~0.2 us of arithmetic per step a three-stage register
+// ring cannot cover ~2 us of HBM latency (0.67 us per step measured).  Four more wavefronts of the workgroup, one per
+// sequence, keep SAMPLE_PD steps of the sequence's records in flight in their own registers (H rows, LDL' factor,
+// eps: gathered as 8-byte pieces) and publish the oldest into a two-slot LDS ring each step; the consumer reads LDS
+// only.  One s_waitcnt lgkmcnt(0) + s_barrier per step; every wavefront executes T barriers.
+constexpr int SAMPLE_PD = 8;
+template <int N>
+__global__ __launch_bounds__(320) void lds_sample_vec_prod_kernel(const SampleArgs a) {
+  constexpr int HS = ws_h_stride(N), WS = ws_step_doubles(N);
+  constexpr int SMAX = 4, PD = SAMPLE_PD;
+  constexpr int R1 = N * HS + N * N + N;
+  constexpr int KT = (R1 + SMAX * N + 63) / 64, REC = KT * 64, SLOT = 4 * REC;
+  __shared__ double ring[2 * SLOT];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int T = a.T, S = a.S, SN = S * N;
+  if (wv >= 1) {
+    // ---- producer wavefronts ---------------------------------------------------------------------------------------
+    const int r = wv - 1;
+    const int br = blockIdx.x * 4 + r;
+    const long bb = br < a.B ? br : a.B - 1;
+    const double* wsq = a.ws + bb * ws_seq_doubles(N, T) + ws_zpage_doubles(N);
+    const double* base[KT];
+    int stp[KT], off[KT];
+    static_for<0, KT>([&](auto k) { base[k] = wsq; stp[k] = 0; off[k] = 0; });
+    int start = 0;
+    auto seg = [&](const double* p, int len, int stride) {
+      static_for<0, KT>([&](auto k) {
+        const int f = k * 64 + lane - start;
+        if (f >= 0 && f < len) { base[k] = p + f; stp[k] = stride; }
+      });
+      start += len;
+    };
+    seg(wsq, N * HS, WS);
+    seg(a.ws2 + bb * T * (N * N + N), N * N + N, N * N + N);
+    seg(a.eps + bb * T * SN, SN, SN);
+    GStage<KT> s0, s1, s2, s3, s4, s5, s6, s7;           // stage of step t: (T - 1 - t) % 8
+    static_assert(PD == 8, "eight named stages");
+    double* slot0 = ring + r * REC;
+    auto rec = [&](int t) { return t > 0 ? t : 0; };
+    gather_issue<KT>(s0, base, stp, off, rec(T - 1), T);
+    gather_issue<KT>(s1, base, stp, off, rec(T - 2), T);
+    gather_issue<KT>(s2, base, stp, off, rec(T - 3), T);
+    gather_issue<KT>(s3, base, stp, off, rec(T - 4), T);
+    gather_issue<KT>(s4, base, stp, off, rec(T - 5), T);
+    gather_issue<KT>(s5, base, stp, off, rec(T - 6), T);
+    gather_issue<KT>(s6, base, stp, off, rec(T - 7), T);
+    gather_issue<KT>(s7, base, stp, off, rec(T - 8), T);
+    gather_publish<KT>(s0, slot0 + ((T - 1) & 1) * SLOT, lane);
+    gather_issue<KT>(s0, base, stp, off, rec(T - 9), T);
+    lds_barrier();                                       // barrier 0: step T-1 is in its slot
+    // consumer iteration t reads slot t%2: publish step t-1 into the other, refill the stage with step t-1-PD
+    // (no branch inside the steady-state loop: across one, hipcc's wait counts degrade to vmcnt(0))
+#define SVAE_PROD_STEP(sg, t)                                                 \
+    {                                                                           \
+      gather_publish<KT>(sg, slot0 + (((t) - 1) & 1) * SLOT, lane);             \
+      gather_issue<KT>(sg, base, stp, off, rec((t) - 1 - PD), T);               \
+      lds_barrier();                                                            \
+    }
+    int t0 = T - 1;
+    for (; t0 >= 8; t0 -= PD) {
+      SVAE_PROD_STEP(s1, t0)
+      SVAE_PROD_STEP(s2, t0 - 1)
+      SVAE_PROD_STEP(s3, t0 - 2)
+      SVAE_PROD_STEP(s4, t0 - 3)
+      SVAE_PROD_STEP(s5, t0 - 4)
+      SVAE_PROD_STEP(s6, t0 - 5)
+      SVAE_PROD_STEP(s7, t0 - 6)
+      SVAE_PROD_STEP(s0, t0 - 7)
+    }
+    if (t0 >= 1) SVAE_PROD_STEP(s1, t0)
+    if (t0 >= 2) SVAE_PROD_STEP(s2, t0 - 1)
+    if (t0 >= 3) SVAE_PROD_STEP(s3, t0 - 2)
+    if (t0 >= 4) SVAE_PROD_STEP(s4, t0 - 3)
+    if (t0 >= 5) SVAE_PROD_STEP(s5, t0 - 4)
+    if (t0 >= 6) SVAE_PROD_STEP(s6, t0 - 5)
+    if (t0 >= 7) SVAE_PROD_STEP(s7, t0 - 6)
+#undef SVAE_PROD_STEP
+    return;
+  }
+  const int c = lane & 15;
+  const int brow = blockIdx.x * 4 + (lane >> 4);
+  const bool valid = brow < a.B;
+  const int b = valid ? brow : a.B - 1;
+  const bool col = c < N;
+  const int cc = col ? c : 0;
+  const bool st = valid && col;
+  const double* ringrow = ring + (lane >> 4) * REC;
+  double X[SMAX];                              // x_{t+1}[c] per sample
+  static_for<0, SMAX>([&](auto s) { X[s] = 0.0; });
+  for (int t = T - 1; t >= 0; --t) {
+    lds_barrier();                             // step t is in slot t%2
+    const double* rec = ringrow + (t & 1) * SLOT;
+    double H[N + 1], Lc[N], Y[SMAX], E[SMAX];
+    load_row<N + 1>(rec + cc * HS, H);                                       // H[j] = [P^-1 J12 | c][c][j]
+    static_for<0, N>([&](auto i) { Lc[i] = rec[N * HS + cc * N + i]; });     // lane c of register i = L[i][c]
+    const double pv = rec[N * HS + N * N + cc];
+    static_for<0, SMAX>([&](auto s) { E[s] = rec[R1 + (s < S ? s : S - 1) * N + cc]; });
+    static_for<0, N + 1>([&](auto k) { H[k] = col ? H[k] : 0.0; });
+    static_for<0, N>([&](auto i) { Lc[i] = (c < i && col) ? Lc[i] : 0.0; }); // L[i][c] below the diagonal only
+    const double dis = rsqrt_nr(col ? pv : 1.0);
+    static_for<0, SMAX>([&](auto s) { Y[s] = col ? dis * E[s] : 0.0; });
+    dpp_fence(X);
+    dpp_fence(Y);
+    static_for<0, SMAX>([&](auto s) {
+      if (s < S) {
+        static_for<1, N>([&](auto jj) {                                      // y = L^-T z: columns N-1 .. 1
+          constexpr int i = N - jj;
+          mac_bc<i, true, true>(Y[s], Y[s], Lc[i]);
+        });
+        double acc0 = Y[s] + H[N], acc1 = 0.0;                               // x_t = y + c_t - (P^-1 J12) x_{t+1}
+        static_for<0, N>([&](auto j) {
+          if constexpr (j % 2 == 0) mac_bc<j, true>(acc0, X[s], H[j]); else mac_bc<j, true>(acc1, X[s], H[j]);
+        });
+        const double xt = acc0 + acc1;
+        if (st) a.samples[(((long)b * T + t) * S + s) * N + c] = xt;
+        X[s] = xt;
+      }
+    });
+  }
+}
+
 template <int N>
 static int launch_sample(const SampleArgs& a, hipStream_t stream) {
-  if (a.S <= 4) hipLaunchKernelGGL((lds_sample_vec_kernel<N>), dim3((a.B + 3) / 4), dim3(64), 0, stream, a);
+  if (a.S <= 4 && a.B <= 1024) hipLaunchKernelGGL((lds_sample_vec_prod_kernel<N>), dim3((a.B + 3) / 4), dim3(320), 0, stream, a);
+  else if (a.S <= 4) hipLaunchKernelGGL((lds_sample_vec_kernel<N>), dim3((a.B + 3) / 4), dim3(64), 0, stream, a);
   else hipLaunchKernelGGL((lds_sample_kernel<N>), dim3((a.B + 3) / 4), dim3(64), 0, stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -1000;
 }

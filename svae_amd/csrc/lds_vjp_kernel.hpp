@@ -90,58 +90,6 @@ __device__ __forceinline__ void for_samples(int S, F&& f) {
   }
 }
 
-// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding GLOBAL load and
-// store (s_waitcnt vmcnt(0)), i.e. for the producer's whole prefetch ring and the consumer's output stores, each step
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-typedef double vd2 __attribute__((ext_vector_type(2)));   // (a native vector: stays in registers)
-// one pipeline stage of a producer wavefront: a (sequence, step) record pair as 16-byte pieces, one per lane and k
-template <int KW, int KA> struct Stage { vd2 w[KW], ad[KA]; };
-template <int WP, int AP, int KW, int KA>
-__device__ __forceinline__ void prod_issue(Stage<KW, KA>& sg, const vd2* wrec, const vd2* arec, int t, int lane) {
-  static_for<0, KW>([&](auto k) {
-    const int q = k * 64 + lane;
-    sg.w[k] = wrec[(long)t * WP + (q < WP ? q : WP - 1)];
-  });
-  static_for<0, KA>([&](auto k) {
-    const int q = k * 64 + lane;
-    sg.ad[k] = arec[(long)t * AP + (q < AP ? q : AP - 1)];
-  });
-}
-template <int WP, int AP, int KW, int KA>
-__device__ __forceinline__ void prod_publish(const Stage<KW, KA>& sg, vd2* slot, int lane) {
-  static_for<0, KW>([&](auto k) {
-    const int q = k * 64 + lane;
-    slot[q < WP ? q : WP - 1] = sg.w[k];                  // (clamped lanes rewrite the last pair)
-  });
-  static_for<0, KA>([&](auto k) {
-    const int q = k * 64 + lane;
-    slot[WP + (q < AP ? q : AP - 1)] = sg.ad[k];
-  });
-}
-
-// producer stage of sweep 1: the step's record is GATHERED from several arrays (8-byte pieces, piece k of lane l is
-// element k*64 + l of the concatenated record); base / stride / step offset of every piece are set up once
-template <int KT> struct GStage { double v[KT]; };
-// (every piece is loaded and published every step, also those beyond the record's end -- they re-read one valid
-// address: a load count that is not a compile-time constant makes hipcc wait for vmcnt(0), i.e. for the whole prefetch
-// ring, before each publish)
-template <int KT>
-__device__ __forceinline__ void gather_issue(GStage<KT>& sg, const double* const (&base)[KT], const int (&stp)[KT],
-                                             const int (&off)[KT], int t, int T) {
-  static_for<0, KT>([&](auto k) {
-    int tt = t + off[k];
-    tt = tt < T ? tt : T - 1;
-    sg.v[k] = base[k][(long)tt * stp[k]];
-  });
-}
-template <int KT>
-__device__ __forceinline__ void gather_publish(const GStage<KT>& sg, double* slot, int lane) {
-  static_for<0, KT>([&](auto k) { slot[k * 64 + lane] = sg.v[k]; });
-}
-
 // ---- sweep 1: smoother + sampler adjoints, forward in time ----------------------------------------
 // The two adjoint chains of this sweep are independent (the S^ recursion of the smoother; the xhat
 // recursion + noise adjoint of the sampler): with samples they run as two ROLES in separate
