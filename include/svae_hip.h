@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SVAE_HIP_ABI_VERSION 4   /* 4: + svae_slds_lds_meanfield_f64, svae_gmm_mw_*, svae_lds_global_step_f64, svae_lds_natgrad_f64, svae_lds_tile_vjp_f64; 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
+#define SVAE_HIP_ABI_VERSION 5   /* 5: + svae_lds_set_prod_max_b; 4: + svae_slds_lds_meanfield_f64, svae_gmm_mw_*, svae_lds_global_step_f64, svae_lds_natgrad_f64, svae_lds_tile_vjp_f64; 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
 #define SVAE_LDS_MAX_N 15   /* register/DPP path: one 16-lane row per sequence, n+1 <= 16 */
 #define SVAE_LDS_TILE_MAX_N 64   /* 16 <= n <= 64: LDS-tiled MFMA path (E-step only: keep must be 0) */
 
@@ -110,6 +110,13 @@ int svae_lds_filter_f64(int B, int T, int n, int inhomog, int pair_batched,
  * value.  Host only (no environment variables are read). */
 int svae_lds_set_split_max_b(int max_b);
 int svae_lds_set_twoend(int mode);
+
+/* svae_lds_sample_f64 (S <= 4) and the sweeps of svae_lds_estep_vjp_f64 run, for batches B <= max_b (default 1024),
+ * with PRODUCER wavefronts: the serial loop of a workgroup's four sequences reads its per-step records from an LDS
+ * ring that four more wavefronts of the workgroup fill several steps ahead (and, in the first sweep, HELPER
+ * wavefronts take the work that does not feed the recursion).  Same results; larger batches hide the latency by
+ * occupancy instead.  0 = never.  Returns the previous value. */
+int svae_lds_set_prod_max_b(int max_b);
 
 /* LDS mean-field step of the SLDS-SVAE coordinate ascent with the mixing of the K per-state parameter sets
  * and the contraction of the pair statistics FUSED into the E-step:

@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must precede CDLL: shares torch's HIP runtime)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVAE_AMD_LIB", os.path.join(_HERE, "libsvae_hip.so"))  # env: experiments only
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 LDS_MAX_N = 15        # register/DPP path (E-step, sampler, VJP)
 LDS_TILE_MAX_N = 64   # LDS-tiled MFMA path (E-step only)
 
@@ -26,6 +26,7 @@ SIGNATURES = {
     "svae_lds_workspace_bytes_ex": (ctypes.c_size_t, [ctypes.c_int] * 5),
     "svae_lds_set_split_max_b": (ctypes.c_int, [ctypes.c_int]),
     "svae_lds_set_twoend": (ctypes.c_int, [ctypes.c_int]),
+    "svae_lds_set_prod_max_b": (ctypes.c_int, [ctypes.c_int]),
     "svae_lds_estep_f64": (ctypes.c_int, [ctypes.c_int] * 6 + [_c_double_p] * 15
                            + [_c_int_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "svae_lds_filter_f64": (ctypes.c_int, [ctypes.c_int] * 5 + [_c_double_p] * 15

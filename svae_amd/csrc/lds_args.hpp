@@ -77,6 +77,7 @@ struct LdsArgs {
 
 struct SampleArgs {
   int B, T, S;
+  int prod_max_b;                     // largest batch that runs with producer wavefronts (svae_lds_set_prod_max_b)
   const double* __restrict__ eps;     // (B, T, S, n)
   double* __restrict__ samples;       // (B, T, S, n)
   const double* __restrict__ ws;      // main region (G~' rows, c, P^-1)
@@ -86,6 +87,7 @@ struct SampleArgs {
 // reverse-mode sweeps (lds_vjp_kernel.hpp)
 struct VjpArgs {
   int B, T, S;
+  int prod_max_b;                        // largest batch that runs with producer / helper wavefronts
   const double* __restrict__ J12;        // natural pair parameter: (n,n), (T-1,n,n) or (B,T-1,n,n)
   long pair_t_stride;                    // doubles between consecutive steps' J12 (0 = homogeneous)
   long pair_seq_stride;                  // doubles between consecutive sequences' J12 blocks (0 = shared)

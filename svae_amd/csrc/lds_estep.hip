@@ -75,6 +75,13 @@ extern "C" {
 // exist for A/B measurements and for the tests that run every kernel.
 static int g_split_max_b = 1023;
 static int g_twoend = 1;
+static int g_prod_max_b = 1024;
+
+int svae_lds_set_prod_max_b(int max_b) {
+  const int old = g_prod_max_b;
+  g_prod_max_b = max_b < 0 ? 0 : max_b;
+  return old;
+}
 
 int svae_lds_set_split_max_b(int max_b) {
   const int old = g_split_max_b;
@@ -374,6 +381,7 @@ extern "C" int svae_lds_sample_f64(int B, int T, int n, int S, const double* eps
   if (B == 0) return 0;
   svae::SampleArgs a;
   a.B = B; a.T = T; a.S = S; a.eps = eps; a.samples = samples;
+  a.prod_max_b = g_prod_max_b;
   a.ws = (const double*)workspace;
   a.ws2 = (const double*)workspace + main_ws_doubles(B, T, n);
   switch (n) {
@@ -422,6 +430,7 @@ extern "C" int svae_lds_estep_vjp_ex_f64(int B, int T, int n, int S, int inhomog
   if (B == 0) return 0;
   svae::VjpArgs a;
   a.B = B; a.T = T; a.S = g_samples ? S : 0;
+  a.prod_max_b = g_prod_max_b;
   a.J12 = J12; a.g_lognorm = g_lognorm; a.g_diagxx = g_E_node_diagxx; a.g_x = g_E_node_x;
   a.pair_t_stride = inhomog ? (long)n * n : 0;
   a.pair_seq_stride = pair_batched ? (long)(T - 1) * n * n : 0;

@@ -837,7 +837,7 @@ __global__ __launch_bounds__(320) void lds_sample_vec_prod_kernel(const SampleAr
 
 template <int N>
 static int launch_sample(const SampleArgs& a, hipStream_t stream) {
-  if (a.S <= 4 && a.B <= 1024) hipLaunchKernelGGL((lds_sample_vec_prod_kernel<N>), dim3((a.B + 3) / 4), dim3(320), 0, stream, a);
+  if (a.S <= 4 && a.B <= a.prod_max_b) hipLaunchKernelGGL((lds_sample_vec_prod_kernel<N>), dim3((a.B + 3) / 4), dim3(320), 0, stream, a);
   else if (a.S <= 4) hipLaunchKernelGGL((lds_sample_vec_kernel<N>), dim3((a.B + 3) / 4), dim3(64), 0, stream, a);
   else hipLaunchKernelGGL((lds_sample_kernel<N>), dim3((a.B + 3) / 4), dim3(64), 0, stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -1000;

@@ -754,13 +754,13 @@ static int launch_vjp(const VjpArgs& a, hipStream_t stream) {
   if (a.g_samples) {
     if (statc && split) hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, true, true, true>), grid2, block, 0, stream, a);
     else if (statc) hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, true, true, false>), grid, block, 0, stream, a);
-    else if (split && a.B <= 1024 && a.S <= VJP_PROD_MAX_S)
+    else if (split && a.B <= a.prod_max_b && a.S <= VJP_PROD_MAX_S)
       hipLaunchKernelGGL((lds_vjp_sweep1_prod_kernel<N, true>), grid2, dim3(64 * VJP_S1_WAVES), 0, stream, a);
     else if (split) hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, true, false, true>), grid2, block, 0, stream, a);
     else hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, true, false, false>), grid, block, 0, stream, a);
     bool done2 = false;
     if constexpr (N <= VJP_PROD2_MAX_N) {
-      if (split && a.B <= 1024) {
+      if (split && a.B <= a.prod_max_b) {
         hipLaunchKernelGGL((lds_vjp_sweep2_prod_kernel<N, true, true>), grid, dim3(320), 0, stream, a);
         done2 = true;
       }
@@ -769,7 +769,7 @@ static int launch_vjp(const VjpArgs& a, hipStream_t stream) {
     else if (split) hipLaunchKernelGGL((lds_vjp_sweep2_kernel<N, true, true>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((lds_vjp_sweep2_kernel<N, true, false>), grid, block, 0, stream, a);
   } else {
-    const bool prod = a.B <= 1024;       // small batches: producer wavefronts hide the HBM latency of the serial sweeps
+    const bool prod = a.B <= a.prod_max_b;       // small batches: producer wavefronts hide the HBM latency of the serial sweeps
     if (statc) hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, false, true, false>), grid, block, 0, stream, a);
     else if (prod) hipLaunchKernelGGL((lds_vjp_sweep1_prod_kernel<N, false>), grid, dim3(64 * VJP_S1_WAVES), 0, stream, a);
     else hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, false, false, false>), grid, block, 0, stream, a);

@@ -17,7 +17,7 @@ def _header_symbols():
 
 def test_header_declares_the_expected_entry_points():
     syms = _header_symbols()
-    for s in ("svae_lds_estep_f64", "svae_lds_workspace_bytes", "svae_lds_workspace_bytes_ex", "svae_lds_set_split_max_b", "svae_lds_set_twoend", "svae_lds_filter_f64",
+    for s in ("svae_lds_estep_f64", "svae_lds_workspace_bytes", "svae_lds_workspace_bytes_ex", "svae_lds_set_split_max_b", "svae_lds_set_twoend", "svae_lds_set_prod_max_b", "svae_lds_filter_f64",
               "svae_lds_reduce_stats_f64",
               "svae_lds_sample_f64", "svae_lds_estep_vjp_f64", "svae_lds_vjp_workspace_bytes",
               "svae_hmm_estep_f64", "svae_hmm_workspace_bytes", "svae_slds_lds_meanfield_f64",

@@ -177,7 +177,9 @@ def test_full_size_against_reference_and_properties(B):
     assert torch.equal(r2, plan.reduce())                         # bit-reproducible
 
 
-@pytest.mark.parametrize("n,T,S", [(10, 30, 3), (4, 12, 16), (3, 7, 21), (15, 5, 2), (1, 6, 4)])
+# (S <= 4 at small batches runs with producer wavefronts, eight steps in flight: T around that depth and T = 1)
+@pytest.mark.parametrize("n,T,S", [(10, 30, 3), (4, 12, 16), (3, 7, 21), (15, 5, 2), (1, 6, 4),
+                                   (6, 9, 2), (5, 10, 1), (7, 17, 4), (8, 8, 3), (4, 1, 1)])
 def test_sampler_against_oracle(n, T, S):
     """natural_sample_backward with the noise passed in: same eps => same samples (1e-9)."""
     from svae_amd.lds.lds_inference import natural_lds_inference_general
