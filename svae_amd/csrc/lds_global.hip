@@ -53,8 +53,36 @@ __device__ inline void wishart_terms(double nu, int n, double* red, double& psi_
 // In place: M (n x n, row stride ld, SPD) -> M^-1; returns log det M (every thread); *bad set on a non-positive pivot.
 // Gauss-Jordan: per pivot k the scaled pivot row and the multiplier column are staged, then every thread updates
 // its elements.
-__device__ inline double spd_inverse(double* M, int n, int ld, double* rowk, double* colk, int* bad) {
+__device__ inline double spd_inverse(double* M, int n, int ld, double* rowk, double* colk, int* bad, double* alt) {
   double logdet = 0.0;
+  if (n * n <= GL_BLOCK && ld == n) {
+    // small matrices (n <= 16): thread e owns element (i, j) in a register for the whole elimination; per pivot it
+    // publishes the element into one of two LDS copies (ping-pong: ONE barrier per pivot) and reads M[i][k], M[k][j]
+    // and the pivot back.  No index arithmetic inside the loop.
+    const int e = threadIdx.x, i = e / n, j = e - i * n;
+    const bool own = e < n * n;
+    double v = own ? M[e] : 0.0;
+    __syncthreads();                       // (M is one of the two copies: everyone has read its element)
+    for (int k = 0; k < n; ++k) {
+      double* cur = (k & 1) ? alt : M;
+      if (own) cur[e] = v;
+      __syncthreads();
+      const double p = cur[k * n + k];
+      if (!(p > 0.0) && threadIdx.x == 0) *bad = 1;
+      logdet += log(p);
+      if (own) {
+        const double pinv = 1.0 / p;
+        const double mik = cur[i * n + k], mkj = cur[k * n + j];
+        if (i == k) v = (j == k) ? pinv : mkj * pinv;
+        else if (j == k) v = -mik * pinv;
+        else v = __builtin_fma(-mik, mkj * pinv, v);
+      }
+    }
+    __syncthreads();                       // the last copy has been read
+    if (own) M[e] = v;
+    __syncthreads();
+    return logdet;
+  }
   for (int k = 0; k < n; ++k) {
     const double p = M[k * ld + k];
     __syncthreads();
@@ -116,16 +144,19 @@ __global__ __launch_bounds__(GL_BLOCK) void lds_global_kernel(const GlobalArgs a
   double* rowk = v1 + n;
   double* colk = rowk + n;
   double* red = colk + n;           // 2 * GL_BLOCK
+  double* alt = red + 2 * GL_BLOCK; // GL_BLOCK: second copy of a small matrix during its inversion
   __shared__ int bad;
   if (tid == 0) bad = 0;
   __syncthreads();
 
   double kl = 0.0;                  // accumulated by thread 0 only where noted
-  // two passes: q = 0 the global factors (outputs written), q = 1 the prior (log-normalisers only)
+  // two passes, one WORKGROUP each (they are independent): q = 0 the global factors (outputs written), q = 1 the
+  // prior (log-normalisers only).  Each adds its share of the KL to *global_kl (zeroed by the launcher): two terms,
+  // so the sum does not depend on the order of the two atomic additions.
   double es_dot = 0.0;              // <prior - global, E_global[t]>  partial of this thread
   double logZ_g = 0.0, logZ_p = 0.0;
-  const int passes = a.p_niw ? 2 : 1;
-  for (int q = 0; q < passes; ++q) {
+  {
+    const int q = blockIdx.x;
     const double* niw = q ? a.p_niw : a.niw;
     const double* mA = q ? a.p_mA : a.mA;
     const double* mB = q ? a.p_mB : a.mB;
@@ -140,7 +171,7 @@ __global__ __launch_bounds__(GL_BLOCK) void lds_global_kernel(const GlobalArgs a
       W0[e] = niw[i * D + j] - niw[i * D + n] * v0[j];
     }
     __syncthreads();
-    const double logdetS = spd_inverse(W0, n, n, rowk, colk, &bad);
+    const double logdetS = spd_inverse(W0, n, n, rowk, colk, &bad, alt);
     symmetrize(W0, n, n);
     double psi, mgl;
     wishart_terms(nu, n, red, psi, mgl);
@@ -187,7 +218,7 @@ __global__ __launch_bounds__(GL_BLOCK) void lds_global_kernel(const GlobalArgs a
     // ---- MNIW (A, B, C, d): K = sym(A^-1), M = (K B)', S = C - M B --------------------------------------
     for (int e = tid; e < n * n; e += blockDim.x) W1[e] = mA[e];
     __syncthreads();
-    const double logdetA = spd_inverse(W1, n, n, rowk, colk, &bad);                   // W1 = K
+    const double logdetA = spd_inverse(W1, n, n, rowk, colk, &bad, alt);                   // W1 = K
     symmetrize(W1, n, n);
     for (int e = tid; e < n * n; e += blockDim.x) {                                     // W2 = M' = K B   (M[i][j] = W2[j][i])
       const int i = e / n, j = e % n;
@@ -203,7 +234,7 @@ __global__ __launch_bounds__(GL_BLOCK) void lds_global_kernel(const GlobalArgs a
       W3[e] = s;
     }
     __syncthreads();
-    const double logdetS2 = spd_inverse(W3, n, n, rowk, colk, &bad);                  // W3 = S^-1
+    const double logdetS2 = spd_inverse(W3, n, n, rowk, colk, &bad, alt);                  // W3 = S^-1
     symmetrize(W3, n, n);
     double psi2, mgl2;
     wishart_terms(nu2, n, red, psi2, mgl2);
@@ -252,7 +283,7 @@ __global__ __launch_bounds__(GL_BLOCK) void lds_global_kernel(const GlobalArgs a
       if (tid < s) red[tid] += red[tid + s];
       __syncthreads();
     }
-    if (tid == 0) a.global_kl[0] = -red[0] + (logZ_p - logZ_g) + kl;                   // lds.py:16-20
+    if (tid == 0) atomicAdd(a.global_kl, blockIdx.x == 0 ? -red[0] - logZ_g + kl : logZ_p);   // lds.py:16-20
   }
   if (tid == 0 && bad) atomicMax(a.info, 1);
 }
@@ -305,18 +336,20 @@ extern "C" int svae_lds_global_step_f64(int n, const double* niw, const double* 
   a.init_J = init_J; a.init_h = init_h; a.init_logZ = init_logZ;
   a.J11 = J11; a.J12 = J12; a.J22 = J22; a.logZ_pair = logZ_pair;
   a.niw_es = niw_expectedstats; a.global_kl = global_kl; a.info = info;
-  const size_t lds = (size_t)(4 * n * n + 4 * n + 2 * svae::GL_BLOCK) * sizeof(double);
+  const size_t lds = (size_t)(4 * n * n + 4 * n + 3 * svae::GL_BLOCK) * sizeof(double);
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(svae::lds_global_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)((4 * svae::GL_MAX_N * svae::GL_MAX_N + 4 * svae::GL_MAX_N + 2 * svae::GL_BLOCK) *
+                            (int)((4 * svae::GL_MAX_N * svae::GL_MAX_N + 4 * svae::GL_MAX_N + 3 * svae::GL_BLOCK) *
                                   sizeof(double))) != hipSuccess) return -1001;
     attr = true;
   }
-  // (80 us at n = 10: ~60 serial pivot steps of log / divide / two barriers; one wavefront instead of four was
-  //  measured slower, 93 us.  It does not depend on the minibatch and overlaps the recognition network.)
-  hipLaunchKernelGGL(svae::lds_global_kernel, dim3(1), dim3(svae::GL_BLOCK), lds, (hipStream_t)stream, a);
+  // (n = 10: 80 us with staged pivot rows and both passes in one workgroup; 62 us with register-resident elements
+  //  and one barrier per pivot; one workgroup per pass: see DESIGN.md 4c.  It does not depend on the minibatch.)
+  const bool with_kl = global_kl && prior_niw;
+  if (with_kl && hipMemsetAsync(global_kl, 0, sizeof(double), (hipStream_t)stream) != hipSuccess) return -1000;
+  hipLaunchKernelGGL(svae::lds_global_kernel, dim3(prior_niw ? 2 : 1), dim3(svae::GL_BLOCK), lds, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
