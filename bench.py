@@ -77,6 +77,8 @@ def kernel_name(lib, B, T, n):
     twoend = lib.svae_lds_set_twoend(1)
     lib.svae_lds_set_twoend(twoend)
     if twoend and n <= 10 and T >= 4:
+        if twoend == 1 and B <= 512:     # TE_S4_MAX_B (csrc/lds_args.hpp): one chain per wavefront in the smoother phase
+            return "twoend", "svae::lds_estep_twoend_kernel<%d,false,true,false,false,true>" % n
         return "twoend", "svae::lds_estep_twoend_kernel<%d,false,%s>" % (n, "true" if twoend == 1 else "false")
     if B <= split_max:
         return "split", "svae::lds_estep_split_kernel<%d,false,false>" % n

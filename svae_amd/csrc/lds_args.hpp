@@ -28,6 +28,7 @@ constexpr long te_chain_doubles(int n, int T) {
 constexpr long te_seq_doubles(int n, int T) { return 2 * te_chain_doubles(n, T); }
 constexpr int TE_MAX_N = 10;
 constexpr int TE_MIN_T = 4;
+constexpr int TE_S4_MAX_B = 512;     // two-ended kernel: second wavefront per sequence in the smoother phase up to this batch
 // MIX launches of the two-ended kernel (K parameter sets mixed per step, svae_slds_lds_meanfield_f64): LDS
 // tables of 16-byte entries (two states each), see lds_estep_twoend.hpp
 constexpr int te_mix_nxl(int n) { return 15 - n; }                 // right-hand-side lanes n..14

@@ -31,6 +31,7 @@
 #pragma once
 #include "lds_estep_kernel.hpp"
 #include "gj1r_gen.hpp"
+#include "lds_estep_twoend_s4.hpp"
 
 namespace svae {
 
@@ -146,13 +147,19 @@ __device__ __forceinline__ void te_gauss_jordan(double (&M)[N], const double (&E
 // statistics and cross moments from this kernel while the one-directional FILTER (whose factorisation defines the
 // sampler's eps -> sample map and the hand-off the sweeps differentiate) runs concurrently on the SIMDs a small
 // batch leaves idle (lds_estep.hip: svae_lds_estep_f64 with keep != 0).
-template <int N, bool INHOMOG, bool LEAN, bool MIX = false, bool CROSS = false>
-__global__ __launch_bounds__(MIX ? 512 : 64) void lds_estep_twoend_kernel(const LdsArgs a) {
+//
+// S4 (small batches, homogeneous lean variant): the workgroup has a SECOND wavefront that waits at a barrier through
+// the elimination phase and then runs chain B's smoother while this one runs chain A's, each with four DPP rows per
+// chain (lds_estep_twoend_s4.hpp).
+template <int N, bool INHOMOG, bool LEAN, bool MIX = false, bool CROSS = false, bool S4 = false>
+__global__ __launch_bounds__(MIX ? 512 : (S4 ? 128 : 64)) void lds_estep_twoend_kernel(const LdsArgs a) {
+  static_assert(!S4 || (LEAN && !INHOMOG && !MIX && !CROSS), "S4: the homogeneous lean variant only");
   static_assert(N >= 1 && N <= TE_MAX_N && N + ((N - 1) >> 1) <= 14,
                 "the right-hand-side columns must fit lanes N..14 of two DPP rows");
   static_assert(!MIX || (INHOMOG && !LEAN), "MIX: per-step parameters, full hand-off record");
   // (CROSS runs next to the one-directional filter: one wavefront per SIMD, see lds_estep_split.hpp)
-  if constexpr (CROSS) asm volatile("v_accvgpr_write_b32 a63, 0" ::: "a63");
+  // (S4: 2 B wavefronts on 1024 SIMDs -- without the marker two of them may share a SIMD: 180 us instead of 152)
+  if constexpr (CROSS || S4) asm volatile("v_accvgpr_write_b32 a63, 0" ::: "a63");
   constexpr int RW = te_row_doubles(N), ZP = te_page_doubles(N);
   constexpr int WS = LEAN ? te_lean_step_doubles(N) : te_step_doubles(N);
   constexpr int TRI = N * (N + 1) / 2;    // LEAN record: [lower triangle | c (N) | 0.0 | trash | pad]
@@ -162,6 +169,7 @@ __global__ __launch_bounds__(MIX ? 512 : 64) void lds_estep_twoend_kernel(const 
   constexpr int HL = 15;                  // lane of the h column
   constexpr int RSL = (N + 3) & ~1;       // LDS row stride of the transposition tile (even, >= N + 1)
   __shared__ double tab_static[MIX ? 2 : 2 * 16 * 16];   // [chain][row 0..15][RSL]: G~ rows for the transposed read
+  __shared__ double xch_static[S4 ? 2 * ((N + 3) / 4) * 64 + 256 : 2];   // S4: chain B's sums on their way to chain A
   extern __shared__ double2 te_dyn[];     // MIX: the parameter tables (te_mix_lds_bytes)
 
   const int lane = threadIdx.x & 63;
@@ -175,6 +183,14 @@ __global__ __launch_bounds__(MIX ? 512 : 64) void lds_estep_twoend_kernel(const 
   // MIX: row of every array (and of the workspace) this launch slot works on (surplus slots: any valid row)
   const int b = !MIX ? bslot : (a.seq_index ? a.seq_index[bslot < a.B ? bslot : 0] : bslot);
   double* tab = tab_static;               // (MIX keeps the full hand-off record: no transposition tile)
+  if constexpr (S4) {
+    if (wv == 1) {                        // chain B's smoother wavefront: sleeps until the records are complete
+      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      te_smooth4<N>(a, b, 1, lane, tab_static + 256, xch_static);
+      return;
+    }
+  }
   const bool col = c < N;
   const int cc = col ? c : 0;
   const int T = a.T;
@@ -580,6 +596,12 @@ __global__ __launch_bounds__(MIX ? 512 : 64) void lds_estep_twoend_kernel(const 
     }
   }
   TE_TICK(4)
+  if constexpr (S4) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    te_smooth4<N>(a, b, 0, lane, tab_static, xch_static);
+    return;
+  }
 
   // ---- smoother phase: moment form on homogeneous coordinates, local steps e, e-1, .., 0 ---------------
   // S~ in slot layout (row i = 2j+gl of the (N+1) x (N+1) tile, lane = column); starts from e_N e_N' so that
@@ -908,6 +930,8 @@ static int launch_estep_twoend(const LdsArgs& a, bool inhomog, bool lean, hipStr
       hipLaunchKernelGGL((lds_estep_twoend_kernel<N, true, true>), grid, block, 0, stream, a);
     else if (inhomog)
       hipLaunchKernelGGL((lds_estep_twoend_kernel<N, true, false>), grid, block, 0, stream, a);
+    else if (lean && a.B <= TE_S4_MAX_B)     // one chain per wavefront in the smoother phase while SIMDs are idle
+      hipLaunchKernelGGL((lds_estep_twoend_kernel<N, false, true, false, false, true>), grid, dim3(128), 0, stream, a);
     else if (lean)
       hipLaunchKernelGGL((lds_estep_twoend_kernel<N, false, true>), grid, block, 0, stream, a);
     else
