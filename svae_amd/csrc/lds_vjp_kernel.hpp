@@ -30,6 +30,7 @@
 // stand-alone broadcasts fence theirs; `make audit` checks the ISA of every latent dimension.
 #pragma once
 #include "lds_estep_kernel.hpp"
+#include "lds_estep_twoend_s4.hpp"   // quad_gather
 
 namespace svae {
 
@@ -735,6 +736,156 @@ __device__ __forceinline__ void lds_vjp_sweep2_body(const VjpArgs& a) {
   }
 }
 
+// ---- sweep 2, ONE SEQUENCE PER WAVEFRONT (B <= VJP_S4_MAX_B: the packed sweep leaves 7/8 of the SIMDs idle) ------------
+// The same recursion as lds_vjp_sweep2_body with the four DPP rows of the consumer wavefront SPLITTING every product
+// stage by output row (row i of a tile in DPP row i & 3, slot i >> 2, as in lds_estep_twoend_s4.hpp): 96 instead of
+// 320 DPP multiply-adds per step; the two operands a product needs replicated ([Xbar | cbar] for Bbar = P^-1 [..], and
+// [Abar | hbar] for the J12 product of the next step) are all-gathered with v_permlane16_swap + v_permlane32_swap.
+// Second wavefront of the workgroup: the producer of the sequence's records (VJP_S4_PD steps in flight, two-slot LDS
+// ring, one barrier per step; T barriers per wavefront).
+constexpr int VJP_S4_MAX_B = 512;
+constexpr int VJP_S4_PD = 6;
+template <int N, bool SAMP>
+__global__ __launch_bounds__(128) void lds_vjp_sweep2_s4_kernel(const VjpArgs a) {
+  constexpr int HS = ws_h_stride(N), PS = ws_p_stride(N), WS = ws_step_doubles(N);
+  constexpr int AS = vjp_step_doubles(N);
+  constexpr int REC = WS + AS, PD = VJP_S4_PD;
+  constexpr int KW = (WS / 2 + 63) / 64, KA = (AS / 2 + 63) / 64;
+  constexpr int J = (N + 3) / 4;                 // slots holding rows 0..N-1 (row i = 4j + r)
+  static_assert(WS % 2 == 0 && AS % 2 == 0, "records are copied as 16-byte pairs");
+  __shared__ double ring[2 * REC];
+  const int lane = threadIdx.x & 63;
+  const int T = a.T;
+  const long b = blockIdx.x;
+  if ((threadIdx.x >> 6) == 1) {
+    // ---- producer wavefront ---------------------------------------------------------------------------------------
+    const vd2* wrec = reinterpret_cast<const vd2*>(a.ws + b * ws_seq_doubles(N, T) + ws_zpage_doubles(N));
+    const vd2* arec = reinterpret_cast<const vd2*>(a.adj + (b * T) * AS);
+    Stage<KW, KA> s0, s1, s2, s3, s4, s5;          // stage of step t: (T - 1 - t) % 6
+    static_assert(PD == 6, "six named stages");
+    vd2* slot0 = reinterpret_cast<vd2*>(ring);
+    auto rec = [&](int t) { return t > 0 ? t : 0; };
+    prod_issue<WS / 2, AS / 2>(s0, wrec, arec, rec(T - 1), lane);
+    prod_issue<WS / 2, AS / 2>(s1, wrec, arec, rec(T - 2), lane);
+    prod_issue<WS / 2, AS / 2>(s2, wrec, arec, rec(T - 3), lane);
+    prod_issue<WS / 2, AS / 2>(s3, wrec, arec, rec(T - 4), lane);
+    prod_issue<WS / 2, AS / 2>(s4, wrec, arec, rec(T - 5), lane);
+    prod_issue<WS / 2, AS / 2>(s5, wrec, arec, rec(T - 6), lane);
+    prod_publish<WS / 2, AS / 2>(s0, slot0 + ((T - 1) & 1) * (REC / 2), lane);
+    prod_issue<WS / 2, AS / 2>(s0, wrec, arec, rec(T - 7), lane);
+    lds_barrier();                                     // barrier 0: step T-1 is in its slot
+#define SVAE_PROD_STEP(sg, t)                                                                         \
+    {                                                                                                   \
+      prod_publish<WS / 2, AS / 2>(sg, slot0 + (((t) - 1) & 1) * (REC / 2), lane);                      \
+      prod_issue<WS / 2, AS / 2>(sg, wrec, arec, rec((t) - 1 - PD), lane);                              \
+      lds_barrier();                                                                                    \
+    }
+    int t0 = T - 1;
+    for (; t0 >= 6; t0 -= PD) {                        // (no branch inside the steady-state loop: see sweep 1)
+      SVAE_PROD_STEP(s1, t0)
+      SVAE_PROD_STEP(s2, t0 - 1)
+      SVAE_PROD_STEP(s3, t0 - 2)
+      SVAE_PROD_STEP(s4, t0 - 3)
+      SVAE_PROD_STEP(s5, t0 - 4)
+      SVAE_PROD_STEP(s0, t0 - 5)
+    }
+    if (t0 >= 1) SVAE_PROD_STEP(s1, t0)
+    if (t0 >= 2) SVAE_PROD_STEP(s2, t0 - 1)
+    if (t0 >= 3) SVAE_PROD_STEP(s3, t0 - 2)
+    if (t0 >= 4) SVAE_PROD_STEP(s4, t0 - 3)
+    if (t0 >= 5) SVAE_PROD_STEP(s5, t0 - 4)
+#undef SVAE_PROD_STEP
+    return;
+  }
+  // ---- consumer wavefront -------------------------------------------------------------------------------------------
+  const int c = lane & 15, r = lane >> 4;
+  const bool col = c < N, colN = c <= N;
+  const int cN = colN ? c : 0, cc = col ? c : 0;
+  const double EN = (c == N) ? 1.0 : 0.0;
+  const double sg = col ? -1.0 : (c == N ? 1.0 : 0.0);
+  double ED[J];                                     // ED[j][c] = (c == 4j + r): the diagonal in slot layout
+  static_for<0, J>([&](auto j) { ED[j] = (c == 4 * j + r && c < N) ? 1.0 : 0.0; });
+  int ri[J];                                        // this DPP row's tile rows (clamped) and their validity
+  double rm[J];
+  static_for<0, J>([&](auto j) { const int i = 4 * j + r; ri[j] = i < N ? i : 0; rm[j] = i < N ? 1.0 : 0.0; });
+  double J12c[J];                                   // info form: J12 = -natJ12, my rows
+  const double* pJ12 = a.J12 + b * a.pair_seq_stride;
+  static_for<0, J>([&](auto j) { J12c[j] = 0.0; });
+  if (T > 1 && a.pair_t_stride == 0)
+    static_for<0, J>([&](auto j) { const double v = pJ12[ri[j] * N + cc]; J12c[j] = col ? -v * rm[j] : 0.0; });
+  const double g = a.g_lognorm[b];
+  double AbR[N];                                    // [Abar | hbar] of step t+1, replicated over the DPP rows
+  static_for<0, N>([&](auto i) { AbR[i] = 0.0; });
+  const bool olane = col && (c & 3) == r;           // lane i of DPP row i & 3 reports node i
+
+  for (int t = T - 1; t >= 0; --t) {
+    lds_barrier();                                  // step t is in slot t % 2
+    const double* w = ring + (t & 1) * REC;
+    const double* ad = w + WS;
+    double gb[J], Pi[J], Hc[J], Pb[J], HT[N + 1];
+    static_for<0, J>([&](auto j) {
+      gb[j] = ad[ri[j] * HS + cN];
+      if constexpr (SAMP) gb[j] += ad[N * HS + ri[j] * HS + cN];
+      Pi[j] = w[N * HS + ri[j] * PS + cc];
+      Hc[j] = w[ri[j] * HS + cN];
+      Pb[j] = ad[2 * N * HS + ri[j] * PS + cc];
+      if constexpr (SAMP) Pb[j] += ad[2 * N * HS + N * PS + ri[j] * PS + cc];
+    });
+    load_row<N + 1>(w + cc * HS, HT);               // H' (lane c: row c of H), the same in every DPP row
+    // [Xbar | cbar] = [-G^ | G^[:,n]] - J12_t [Abar | hbar]_{t+1}      (my rows)
+    double Xc[J];
+    static_for<0, J>([&](auto j) { Xc[j] = colN ? gb[j] * sg * rm[j] : 0.0; });
+    if (t < T - 1) {
+      if (a.pair_t_stride != 0) {
+        const double* pj = pJ12 + (long)t * a.pair_t_stride;
+        static_for<0, J>([&](auto j) { const double v = pj[ri[j] * N + cc]; J12c[j] = col ? -v * rm[j] : 0.0; });
+      }
+      dpp_fence(J12c);
+      static_for<0, N>([&](auto k) {
+        static_for<0, J>([&](auto j) { mac_bc<k, true>(Xc[j], J12c[j], AbR[k]); });
+      });
+    }
+    dpp_fence(Xc);
+    double XcR[4 * J];
+    static_for<0, J>([&](auto j) { quad_gather(Xc[j], XcR[4 * j], XcR[4 * j + 1], XcR[4 * j + 2], XcR[4 * j + 3]); });
+    // Bbar = P^-1 [Xbar | cbar]
+    double Bb[J];
+    static_for<0, J>([&](auto j) { Bb[j] = 0.0; Pi[j] *= rm[j]; });
+    dpp_fence(Pi);
+    static_for<0, N>([&](auto k) {
+      static_for<0, J>([&](auto j) { mac_bc<k>(Bb[j], Pi[j], XcR[k]); });
+    });
+    // Pbar = [sweep-1 shares] - Bbar H' - 1/2 g (c c' + P^-1)
+    dpp_fence(Bb);
+    static_for<0, N + 1>([&](auto k) {
+      static_for<0, J>([&](auto j) { mac_bc<k, true>(Pb[j], Bb[j], HT[k]); });
+    });
+    double cvs[J];
+    static_for<0, J>([&](auto j) { cvs[j] = -0.5 * g * Hc[j] * rm[j]; });       // lane N: -1/2 g c_i
+    dpp_fence(cvs);
+    static_for<0, J>([&](auto j) {
+      mac_bc<N>(Pb[j], cvs[j], HT[N]);
+      Pb[j] = __builtin_fma(-0.5 * g, Pi[j], Pb[j]);
+    });
+    // outputs and the adjoint handed to step t-1:  Ab = [Pbar | Bbar[:,n] + g c]
+    double AbD[J], gJ = 0.0, gh = 0.0;
+    static_for<0, J>([&](auto j) {
+      const double hfb = __builtin_fma(g, Hc[j], Bb[j]);                          // lane N: hfbar_i
+      AbD[j] = __builtin_fma(EN, hfb - Pb[j], Pb[j]) * rm[j];
+      gJ = __builtin_fma(ED[j], Pb[j], gJ);
+    });
+    dpp_fence(AbD);
+    static_for<0, J>([&](auto j) { mac_bc<N>(gh, AbD[j], ED[j]); });
+    double AbG[4 * J];
+    static_for<0, J>([&](auto j) { quad_gather(AbD[j], AbG[4 * j], AbG[4 * j + 1], AbG[4 * j + 2], AbG[4 * j + 3]); });
+    static_for<0, N>([&](auto i) { AbR[i] = AbG[i]; });
+    if (olane) {
+      a.g_node_J[(b * T + t) * N + c] = -2.0 * gJ;
+      a.g_node_h[(b * T + t) * N + c] = gh;
+    }
+  }
+}
+
 template <int N, bool SAMP, bool SPLIT>
 __global__ __launch_bounds__(64) void lds_vjp_sweep2_kernel(const VjpArgs a) {
   lds_vjp_sweep2_body<N, SAMP, SPLIT, false>(a);
@@ -759,8 +910,12 @@ static int launch_vjp(const VjpArgs& a, hipStream_t stream) {
     else if (split) hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, true, false, true>), grid2, block, 0, stream, a);
     else hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, true, false, false>), grid, block, 0, stream, a);
     bool done2 = false;
+    if (split && a.B <= a.prod_max_b && a.B <= VJP_S4_MAX_B) {
+      hipLaunchKernelGGL((lds_vjp_sweep2_s4_kernel<N, true>), dim3(a.B), dim3(128), 0, stream, a);
+      done2 = true;
+    }
     if constexpr (N <= VJP_PROD2_MAX_N) {
-      if (split && a.B <= a.prod_max_b) {
+      if (!done2 && split && a.B <= a.prod_max_b) {
         hipLaunchKernelGGL((lds_vjp_sweep2_prod_kernel<N, true, true>), grid, dim3(320), 0, stream, a);
         done2 = true;
       }
@@ -774,8 +929,12 @@ static int launch_vjp(const VjpArgs& a, hipStream_t stream) {
     else if (prod) hipLaunchKernelGGL((lds_vjp_sweep1_prod_kernel<N, false>), grid, dim3(64 * VJP_S1_WAVES), 0, stream, a);
     else hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, false, false, false>), grid, block, 0, stream, a);
     bool done2 = false;
+    if (prod && a.B <= VJP_S4_MAX_B) {
+      hipLaunchKernelGGL((lds_vjp_sweep2_s4_kernel<N, false>), dim3(a.B), dim3(128), 0, stream, a);
+      done2 = true;
+    }
     if constexpr (N <= VJP_PROD2_MAX_N) {
-      if (prod) {
+      if (!done2 && prod) {
         hipLaunchKernelGGL((lds_vjp_sweep2_prod_kernel<N, false, false>), grid, dim3(320), 0, stream, a);
         done2 = true;
       }
