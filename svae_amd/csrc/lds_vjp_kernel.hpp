@@ -116,12 +116,191 @@ template <int N> constexpr int vjp_s1_pieces() {
 }
 // ROLE: 0 = smoother adjoint, 1 = sampler adjoint (SPLIT: the workgroup's role, chosen by the caller -- each role is
 // its own instantiation so that the register allocation is the larger of the two, not their union), 2 = both
+// The smoother adjoint of sweep 1 with ONE SEQUENCE PER WORKGROUP (no sample cotangents, B <= VJP_S4_MAX_B): wavefront 0 = consumer,
+// 1 = producer, 2 = helper; ring (3 slots of one record), mailbox (2 slots) and barrier protocol are those of
+// lds_vjp_sweep1_body.  The consumer's and the helper's four DPP rows split every product stage by output row (row i
+// of a tile in DPP row i & 3, slot i >> 2; cf. lds_vjp_sweep2_s4_kernel): 99 instead of 352 DPP multiply-adds per
+// consumer step, 60 instead of 200 per helper step, one all-gather each.  The transposed product S^ <- G~' M needs
+// column i of G~ per output row: row i of G~' is read from the record with the lane as the row index instead.
+template <int N>
+__device__ __forceinline__ void s1_role0_wg(const VjpArgs& a, double* ring, double* mail, const int seq) {
+  constexpr int HS = ws_h_stride(N), PS = ws_p_stride(N), WS = ws_step_doubles(N), AS = vjp_step_doubles(N);
+  constexpr int W3 = (N + 1) * HS;
+  constexpr int KT = vjp_s1_pieces<N>(), SLOT = KT * 64, MSLOT = N * 16, PD = 6;
+  constexpr int J = (N + 3) / 4;             // slots holding rows 0..N-1 (row i = 4j + r)
+  constexpr int J1 = (N + 4) / 4;            // slots holding rows 0..N
+  constexpr int NS = N >> 2, NR = N & 3;     // row N: slot NS of DPP row NR
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c = lane & 15, r = lane >> 4;
+  const long b = seq;
+  const int T = a.T;
+  const bool col = c < N, colN = c <= N;
+  const int cN = colN ? c : 0, ccl = col ? c : 0;
+  if (wv >= 3) return;
+  if (wv == 1) {
+    // ---- producer: gathers the step's record [E-step record | W~ | g_x | g_diagxx] PD steps ahead -----------------
+    const double* wsq = a.ws + b * ws_seq_doubles(N, T) + ws_zpage_doubles(N);
+    const double* base[KT];
+    int stp[KT], off[KT];
+    static_for<0, KT>([&](auto k) { base[k] = wsq; stp[k] = 0; off[k] = 0; });
+    int start = 0;
+    auto seg = [&](const double* p, int len, int stride) {
+      static_for<0, KT>([&](auto k) {
+        const int f = k * 64 + lane - start;
+        if (f >= 0 && f < len) { base[k] = p + f; stp[k] = stride; }
+      });
+      start += len;
+    };
+    seg(wsq, WS, WS);
+    seg(a.ws3 + b * T * W3, W3, W3);
+    seg(a.g_x ? a.g_x + b * T * N : wsq, N, a.g_x ? N : 0);
+    seg(a.g_diagxx ? a.g_diagxx + b * T * N : wsq, N, a.g_diagxx ? N : 0);
+    GStage<KT> s0, s1, s2, s3, s4, s5;                  // stage of step t: t % 6
+    static_assert(PD == 6, "six named stages");
+    gather_issue<KT>(s0, base, stp, off, 0, T);
+    gather_issue<KT>(s1, base, stp, off, 1, T);
+    gather_issue<KT>(s2, base, stp, off, 2, T);
+    gather_issue<KT>(s3, base, stp, off, 3, T);
+    gather_issue<KT>(s4, base, stp, off, 4, T);
+    gather_issue<KT>(s5, base, stp, off, 5, T);
+    gather_publish<KT>(s0, ring, lane);
+    gather_issue<KT>(s0, base, stp, off, 6, T);
+    lds_barrier();                                     // barrier 0: step 0 is in slot 0
+#define SVAE_PROD_STEP(sg, t)                                                 \
+    {                                                                           \
+      gather_publish<KT>(sg, ring + (((t) + 1) % 3) * SLOT, lane);              \
+      gather_issue<KT>(sg, base, stp, off, (t) + 1 + PD, T);                    \
+      lds_barrier();                                                            \
+    }
+    int t0 = 0;
+    for (; t0 + 6 < T; t0 += PD) {                     // (no branch inside the steady-state loop)
+      SVAE_PROD_STEP(s1, t0)
+      SVAE_PROD_STEP(s2, t0 + 1)
+      SVAE_PROD_STEP(s3, t0 + 2)
+      SVAE_PROD_STEP(s4, t0 + 3)
+      SVAE_PROD_STEP(s5, t0 + 4)
+      SVAE_PROD_STEP(s0, t0 + 5)
+    }
+    if (t0 + 1 < T) SVAE_PROD_STEP(s1, t0)
+    if (t0 + 2 < T) SVAE_PROD_STEP(s2, t0 + 1)
+    if (t0 + 3 < T) SVAE_PROD_STEP(s3, t0 + 2)
+    if (t0 + 4 < T) SVAE_PROD_STEP(s4, t0 + 3)
+    if (t0 + 5 < T) SVAE_PROD_STEP(s5, t0 + 4)
+#undef SVAE_PROD_STEP
+    lds_barrier();                                     // barrier T
+    return;
+  }
+  double rm[J];
+  int ri[J1];
+  static_for<0, J>([&](auto j) { rm[j] = (4 * j + r < N) ? 1.0 : 0.0; });
+  static_for<0, J1>([&](auto j) { const int i = 4 * j + r; ri[j] = i <= N ? i : 0; });
+  if (wv == 2) {
+    // ---- helper: the part of Pbar_t that does not depend on sweep 2,  -P^-1 Pinvbar P^-1 -----------------------------
+    lds_barrier();                                     // barrier 0
+    for (int t = 0; t < T; ++t) {
+      lds_barrier();                                   // barrier t+1: Pinvbar_t is in the mailbox
+      const double* rec = ring + (t % 3) * SLOT;
+      const double* mb = mail + (t & 1) * MSLOT;
+      double PiR[N], PiD[J], PibD[J], T1[J], Pbp[J];
+      static_for<0, N>([&](auto k) { PiR[k] = rec[N * HS + k * PS + ccl]; });                 // rows of P^-1, replicated
+      static_for<0, J>([&](auto j) {
+        const int i = 4 * j + r < N ? 4 * j + r : 0;
+        PiD[j] = rec[N * HS + i * PS + ccl] * rm[j];                                          // my rows
+        PibD[j] = mb[i * 16 + c] * rm[j];
+        T1[j] = 0.0; Pbp[j] = 0.0;
+      });
+      dpp_fence(PibD);
+      static_for<0, N>([&](auto k) {
+        static_for<0, J>([&](auto j) { mac_bc<k>(T1[j], PibD[j], PiR[k]); });
+      });
+      dpp_fence(T1);
+      double T1R[4 * J];
+      static_for<0, J>([&](auto j) { quad_gather(T1[j], T1R[4 * j], T1R[4 * j + 1], T1R[4 * j + 2], T1R[4 * j + 3]); });
+      dpp_fence(PiD);
+      static_for<0, N>([&](auto k) {
+        static_for<0, J>([&](auto j) { mac_bc<k, true>(Pbp[j], PiD[j], T1R[k]); });
+      });
+      double* ad = a.adj + (b * T + t) * AS;
+      if (col) static_for<0, J>([&](auto j) { if (4 * j + r < N) ad[2 * N * HS + (4 * j + r) * PS + c] = Pbp[j]; });
+    }
+    return;
+  }
+  // ---- consumer ------------------------------------------------------------------------------------------------------
+  const double EN = (c == N) ? 1.0 : 0.0;
+  const double sg = col ? -1.0 : (c == N ? 1.0 : 0.0);
+  const double cm = col ? 1.0 : 0.0;
+  const bool own_N = (r == NR);
+  const bool has_gx = a.g_x != nullptr, has_gd = a.g_diagxx != nullptr;
+  double ED[J], sgi[J1], dN[J1];
+  static_for<0, J>([&](auto j) { ED[j] = (c == 4 * j + r && c < N) ? 1.0 : 0.0; });
+  static_for<0, J1>([&](auto j) {
+    const int i = 4 * j + r;
+    sgi[j] = i < N ? -1.0 : (i == N ? 1.0 : 0.0);       // sign of column i of G~ (0: no such row)
+    dN[j] = (i == N) ? EN : 0.0;                        // row N of G~ is e_N: G~[N][i] = (i == N), in lane N
+  });
+  double Sh[J1];
+  static_for<0, J1>([&](auto j) { Sh[j] = 0.0; });
+  for (int t = 0; t < T; ++t) {
+    lds_barrier();                                            // barrier t: step t is in slot t % 3
+    const double* rec = ring + (t % 3) * SLOT;
+    double WT[N + 1], Gc[N + 1], GcT[J1], gxs[J];
+    load_row<N + 1>(rec + WS + cN * HS, WT);                    // row c of W~: WT[k][c] = W~[c][k]
+    static_for<0, N>([&](auto k) { Gc[k] = rec[k * HS + cN]; });
+    static_for<0, J1>([&](auto j) { GcT[j] = rec[ccl * HS + ri[j]]; });        // lane k: H[k][i]
+    static_for<0, J>([&](auto j) { gxs[j] = rec[WS + W3 + (4 * j + r < N ? 4 * j + r : 0)]; });
+    const double gxl = rec[WS + W3 + ccl], gdl = rec[WS + W3 + N + ccl];
+    static_for<0, N + 1>([&](auto k) { WT[k] = colN ? 2.0 * WT[k] : 0.0; });  // 2 W~'
+    static_for<0, N>([&](auto k) { Gc[k] *= sg; });                            // G~ row k (replicated)
+    Gc[N] = EN;
+    static_for<0, J1>([&](auto j) { GcT[j] = __builtin_fma(cm * sgi[j], GcT[j], dN[j]); });   // row i of G~'
+    // S^ += direct cotangents, symmetrised: S^[i][N] += g_x[i] / 2, S^[N][c] += g_x[c] / 2, S^[i][i] += g_diagxx[i]
+    const double gx = (has_gx && col) ? 0.5 * gxl : 0.0, gd = (has_gd && col) ? gdl : 0.0;
+    static_for<0, J>([&](auto j) {
+      Sh[j] = __builtin_fma(EN * rm[j], has_gx ? 0.5 * gxs[j] : 0.0, Sh[j]);
+      Sh[j] = __builtin_fma(gd, ED[j], Sh[j]);
+    });
+    Sh[NS] += own_N ? gx : 0.0;
+    dpp_fence(Sh);
+    // G^ rows i < N:  2 S^ W~'
+    double Gb[J];
+    static_for<0, J>([&](auto j) { Gb[j] = 0.0; });
+    static_for<0, N + 1>([&](auto k) {
+      static_for<0, J>([&](auto j) { mac_bc<k>(Gb[j], Sh[j], WT[k]); });
+    });
+    // Pinvbar = S^[:n,:n] (before the propagation) for the helper wavefront
+    {
+      double* mb = mail + (t & 1) * MSLOT;
+      static_for<0, J>([&](auto j) { if (4 * j + r < N) mb[(4 * j + r) * 16 + c] = Sh[j] * cm; });
+    }
+    // S^ <- G~' (S^ G~)
+    double M[J1];
+    static_for<0, J1>([&](auto j) { M[j] = 0.0; });
+    static_for<0, N + 1>([&](auto k) {
+      static_for<0, J1>([&](auto j) { mac_bc<k>(M[j], Sh[j], Gc[k]); });
+    });
+    dpp_fence(M);
+    double MR[4 * J1];
+    static_for<0, J1>([&](auto j) { quad_gather(M[j], MR[4 * j], MR[4 * j + 1], MR[4 * j + 2], MR[4 * j + 3]); });
+    double Sn[J1];
+    static_for<0, J1>([&](auto j) { Sn[j] = 0.0; });
+    dpp_fence(GcT);
+    static_for<0, N + 1>([&](auto k) {
+      static_for<0, J1>([&](auto j) { mac_bc<k>(Sn[j], GcT[j], MR[k]); });
+    });
+    static_for<0, J1>([&](auto j) { Sh[j] = Sn[j]; });
+    double* ad = a.adj + (b * T + t) * AS;
+    if (colN) static_for<0, J>([&](auto j) { if (4 * j + r < N) ad[(4 * j + r) * HS + c] = Gb[j]; });
+  }
+  lds_barrier();                                              // barrier T
+}
+
+// grp: index of the workgroup's group of four sequences
 template <int N, bool SAMP, bool STATC, bool SPLIT, bool PROD, int ROLE>
-__device__ __forceinline__ void lds_vjp_sweep1_body(const VjpArgs& a, double* tabs, double* ring, double* mail) {
+__device__ __forceinline__ void lds_vjp_sweep1_body(const VjpArgs& a, double* tabs, double* ring, double* mail,
+                                                    const int grp) {
   constexpr int HS = ws_h_stride(N), PS = ws_p_stride(N), WS = ws_step_doubles(N);
   constexpr int AS = vjp_step_doubles(N);
   constexpr int W3 = (N + 1) * HS, R1 = N * HS + N * N + N;
-  constexpr int KT = vjp_s1_pieces<N>(), REC = KT * 64, SLOT = 4 * REC, PD = 4;
+  constexpr int KT = vjp_s1_pieces<N>(), REC = KT * 64, SLOT = 4 * REC, PD = 6;
   static_assert(!PROD || (!STATC && (SPLIT || !SAMP)), "producers: one role per workgroup, no statistics cotangents");
   static_assert(ROLE == 2 ? !(SAMP && SPLIT) : (ROLE == 0 || (SAMP && SPLIT)), "role / split mismatch");
   constexpr int MSLOT = 4 * N * 16;            // mailbox slot: per DPP row, N registers of 16 lanes
@@ -134,7 +313,7 @@ __device__ __forceinline__ void lds_vjp_sweep1_body(const VjpArgs& a, double* ta
       const int h = wv - 5, T = a.T;
       if (h >= NH) return;
       const int c = lane & 15, row = lane >> 4;
-      const int brow = (SAMP ? (blockIdx.x >> 1) : blockIdx.x) * 4 + row;
+      const int brow = grp * 4 + row;
       const bool valid = brow < a.B;
       const long b = valid ? brow : a.B - 1;
       const bool col = c < N;
@@ -213,7 +392,7 @@ __device__ __forceinline__ void lds_vjp_sweep1_body(const VjpArgs& a, double* ta
       // ---- producer wavefronts: wavefront 1 + r gathers the records of the workgroup's sequence r ----------------
       const int r = wv - 1, T = a.T, SN = a.S * N;
       constexpr bool role1 = ROLE == 1;
-      const int br = (SAMP ? (blockIdx.x >> 1) : blockIdx.x) * 4 + r;
+      const int br = grp * 4 + r;
       const long bb = br < a.B ? br : a.B - 1;
       const double* wsq = a.ws + bb * ws_seq_doubles(N, T) + ws_zpage_doubles(N);
       const double* base[KT];
@@ -239,15 +418,17 @@ __device__ __forceinline__ void lds_vjp_sweep1_body(const VjpArgs& a, double* ta
         seg(a.samples + bb * T * SN, SN, SN, 1);                    // x_{t+1}
         seg(a.eps + bb * T * SN, SN, SN, 0);
       }
-      GStage<KT> s0, s1, s2, s3;                          // stage of step t: t % 4
-      static_assert(PD == 4, "four named stages");
+      GStage<KT> s0, s1, s2, s3, s4, s5;                  // stage of step t: t % 6
+      static_assert(PD == 6, "six named stages");
       double* slot0 = ring + r * REC;
       gather_issue<KT>(s0, base, stp, off, 0, T);
       gather_issue<KT>(s1, base, stp, off, 1, T);
       gather_issue<KT>(s2, base, stp, off, 2, T);
       gather_issue<KT>(s3, base, stp, off, 3, T);
+      gather_issue<KT>(s4, base, stp, off, 4, T);
+      gather_issue<KT>(s5, base, stp, off, 5, T);
       gather_publish<KT>(s0, slot0, lane);
-      gather_issue<KT>(s0, base, stp, off, 4, T);
+      gather_issue<KT>(s0, base, stp, off, 6, T);
       lds_barrier();                                     // barrier 0: step 0 is in slot 0
       // consumer iteration t (between barriers t and t+1) reads slot t%3, the helpers slot (t-1)%3: publish step t+1
       // into the third
@@ -260,15 +441,19 @@ __device__ __forceinline__ void lds_vjp_sweep1_body(const VjpArgs& a, double* ta
         lds_barrier();                                                          \
       }
       int t0 = 0;
-      for (; t0 + 4 < T; t0 += PD) {
+      for (; t0 + 6 < T; t0 += PD) {
         SVAE_PROD_STEP(s1, t0)
         SVAE_PROD_STEP(s2, t0 + 1)
         SVAE_PROD_STEP(s3, t0 + 2)
-        SVAE_PROD_STEP(s0, t0 + 3)
+        SVAE_PROD_STEP(s4, t0 + 3)
+        SVAE_PROD_STEP(s5, t0 + 4)
+        SVAE_PROD_STEP(s0, t0 + 5)
       }
       if (t0 + 1 < T) SVAE_PROD_STEP(s1, t0)
       if (t0 + 2 < T) SVAE_PROD_STEP(s2, t0 + 1)
       if (t0 + 3 < T) SVAE_PROD_STEP(s3, t0 + 2)
+      if (t0 + 4 < T) SVAE_PROD_STEP(s4, t0 + 3)
+      if (t0 + 5 < T) SVAE_PROD_STEP(s5, t0 + 4)
 #undef SVAE_PROD_STEP
       lds_barrier();                                     // barrier T
       return;
@@ -281,7 +466,7 @@ __device__ __forceinline__ void lds_vjp_sweep1_body(const VjpArgs& a, double* ta
   // otherwise one workgroup runs both bodies back to back
   constexpr bool do0 = ROLE != 1;
   constexpr bool do1 = SAMP && ROLE != 0;
-  const int brow = ((SAMP && SPLIT) ? (blockIdx.x >> 1) : blockIdx.x) * 4 + (lane >> 4);
+  const int brow = grp * 4 + (lane >> 4);
   const bool valid = brow < a.B;
   const int b = valid ? brow : a.B - 1;
   const bool col = c < N, colN = c <= N;
@@ -547,10 +732,10 @@ template <int N, bool SAMP, bool STATC, bool SPLIT>
 __global__ __launch_bounds__(64) void lds_vjp_sweep1_kernel(const VjpArgs a) {
   __shared__ double tabs[4 * 256];
   if constexpr (SAMP && SPLIT) {
-    if ((blockIdx.x & 1) == 0) lds_vjp_sweep1_body<N, SAMP, STATC, SPLIT, false, 0>(a, tabs, nullptr, nullptr);
-    else lds_vjp_sweep1_body<N, SAMP, STATC, SPLIT, false, 1>(a, tabs, nullptr, nullptr);
+    if ((blockIdx.x & 1) == 0) lds_vjp_sweep1_body<N, SAMP, STATC, SPLIT, false, 0>(a, tabs, nullptr, nullptr, blockIdx.x >> 1);
+    else lds_vjp_sweep1_body<N, SAMP, STATC, SPLIT, false, 1>(a, tabs, nullptr, nullptr, blockIdx.x >> 1);
   } else {
-    lds_vjp_sweep1_body<N, SAMP, STATC, SPLIT, false, 2>(a, tabs, nullptr, nullptr);
+    lds_vjp_sweep1_body<N, SAMP, STATC, SPLIT, false, 2>(a, tabs, nullptr, nullptr, blockIdx.x);
   }
 }
 // consumer wavefront + four producer wavefronts + helper wavefronts
@@ -560,10 +745,10 @@ __global__ __launch_bounds__(64 * VJP_S1_WAVES) void lds_vjp_sweep1_prod_kernel(
   __shared__ double ring[vjp_s1_ring_doubles<N>()];
   __shared__ double mail[2 * 4 * N * 16];
   if constexpr (SAMP) {
-    if ((blockIdx.x & 1) == 0) lds_vjp_sweep1_body<N, true, false, true, true, 0>(a, tabs, ring, mail);
-    else lds_vjp_sweep1_body<N, true, false, true, true, 1>(a, tabs, ring, mail);
+    if ((blockIdx.x & 1) == 0) lds_vjp_sweep1_body<N, true, false, true, true, 0>(a, tabs, ring, mail, blockIdx.x >> 1);
+    else lds_vjp_sweep1_body<N, true, false, true, true, 1>(a, tabs, ring, mail, blockIdx.x >> 1);
   } else {
-    lds_vjp_sweep1_body<N, false, false, false, true, 2>(a, tabs, ring, mail);
+    lds_vjp_sweep1_body<N, false, false, false, true, 2>(a, tabs, ring, mail, blockIdx.x);
   }
 }
 
@@ -734,6 +919,19 @@ __device__ __forceinline__ void lds_vjp_sweep2_body(const VjpArgs& a) {
       a.g_node_h[((long)b * T + t) * N + c] = gh;
     }
   }
+}
+
+// Sweep 1 WITHOUT sample cotangents for B <= VJP_S4_MAX_B: the smoother adjoint with ONE SEQUENCE PER WORKGROUP --
+// consumer, producer and helper wavefront, all in the four-row split layout (s1_role0_wg) -- so that its heavy
+// wavefronts spread over the chip's SIMDs instead of sharing the four of one CU (0.23 -> 0.15 ms at 512 x 200 x 10).
+// With samples the packed two-role kernel stays: next to role 1's workgroups the split layout's extra wavefronts
+// (1024 + 384 heavy ones on 1024 SIMDs) cost more than the shorter instruction stream gains (measured: 0.46 vs 0.43 ms
+// for the whole VJP).
+template <int N>
+__global__ __launch_bounds__(192) void lds_vjp_sweep1_s4_kernel(const VjpArgs a) {
+  __shared__ double ring[3 * vjp_s1_pieces<N>() * 64];
+  __shared__ double mail[2 * N * 16];
+  s1_role0_wg<N>(a, ring, mail, blockIdx.x);
 }
 
 // ---- sweep 2, ONE SEQUENCE PER WAVEFRONT (B <= VJP_S4_MAX_B: the packed sweep leaves 7/8 of the SIMDs idle) ------------
@@ -926,6 +1124,8 @@ static int launch_vjp(const VjpArgs& a, hipStream_t stream) {
   } else {
     const bool prod = a.B <= a.prod_max_b;       // small batches: producer wavefronts hide the HBM latency of the serial sweeps
     if (statc) hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, false, true, false>), grid, block, 0, stream, a);
+    else if (prod && a.B <= VJP_S4_MAX_B)
+      hipLaunchKernelGGL((lds_vjp_sweep1_s4_kernel<N>), dim3(a.B), dim3(192), 0, stream, a);
     else if (prod) hipLaunchKernelGGL((lds_vjp_sweep1_prod_kernel<N, false>), grid, dim3(64 * VJP_S1_WAVES), 0, stream, a);
     else hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, false, false, false>), grid, block, 0, stream, a);
     bool done2 = false;
