@@ -263,3 +263,40 @@ def test_plan_reuse_before_backward_is_refused():
     lognorm2, _, _, _ = lds_inference_differentiable(natparam, (nJ, nh), plan=plan)
     lognorm2.sum().backward()
     assert torch.isfinite(nJ.grad).all()
+
+
+@pytest.mark.parametrize("n,T,B,S", [(10, 37, 7, 1), (6, 12, 3, 3), (13, 9, 5, 2)])
+def test_producer_wavefront_kernels_agree_with_the_packed_ones(n, T, B, S):
+    """svae_lds_set_prod_max_b(0) sends the sampler and the sweeps through the packed kernels (one wavefront per
+    four sequences, register prefetch); the default runs them with producer / helper wavefronts and, up to 512
+    sequences, with one sequence per wavefront.  Different schedules of the same arithmetic: gradients and samples
+    agree to rounding."""
+    from svae_amd import _lib
+    from svae_amd.lds.lds_inference import lds_inference_differentiable
+    lib = _lib.load()
+    init, pair, node, g = _setup(n, T, B, S, 11 * n + T)
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev)
+    natparam = (tuple(t(x) for x in init), tuple(t(x) for x in pair))
+    eps = t(np.random.default_rng(3).standard_normal((B, T, S, n)))
+
+    def run(with_samples):
+        nJ, nh = t(node[0]).requires_grad_(True), t(node[1]).requires_grad_(True)
+        lognorm, (dxx, ex), samples, _ = lds_inference_differentiable(natparam, (nJ, nh),
+                                                                    eps=eps if with_samples else None)
+        loss = (t(g["ln"]) * lognorm).sum() + (t(g["dxx"]) * dxx).sum() + (t(g["x"]) * ex).sum()
+        if with_samples:
+            loss = loss + (t(g["s"]) * samples).sum()
+        loss.backward()
+        return [nJ.grad.clone(), nh.grad.clone()] + ([samples.detach().clone()] if with_samples else [])
+
+    for with_samples in (False, True):
+        old = lib.svae_lds_set_prod_max_b(0)
+        try:
+            packed = run(with_samples)
+        finally:
+            lib.svae_lds_set_prod_max_b(old)
+        assert lib.svae_lds_set_prod_max_b(old) == old
+        default = run(with_samples)
+        for x, y in zip(default, packed):
+            assert float((x - y).abs().max()) <= 1e-11 * float(y.abs().max()) + 1e-300, float((x - y).abs().max())
