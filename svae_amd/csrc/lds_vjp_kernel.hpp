@@ -309,7 +309,7 @@ __device__ __forceinline__ void lds_vjp_sweep1_body(const VjpArgs& a, double* ta
     const int wv = threadIdx.x >> 6;
     if (wv >= 5) {
       // ---- helper wavefronts ---------------------------------------------------------------------------------------
-      constexpr int NH = ROLE == 1 ? 2 : 1;
+      constexpr int NH = 2;              // role 0: Pbar share | G^ rows;  role 1: the noise adjoint of alternate steps
       const int h = wv - 5, T = a.T;
       if (h >= NH) return;
       const int c = lane & 15, row = lane >> 4;
@@ -321,22 +321,35 @@ __device__ __forceinline__ void lds_vjp_sweep1_body(const VjpArgs& a, double* ta
       const double* ringrow = ring + row * REC;
       const double* mailrow = mail + row * N * 16;
       if constexpr (ROLE != 1) {
-        // the part of Pbar_t that does not depend on sweep 2:  -P^-1 Pinvbar P^-1
+        const double cm = col ? 1.0 : 0.0;
+        const bool colN = c <= N;
+        const int cN = colN ? c : 0;
         lds_barrier();                                                 // barrier 0
         for (int t = 0; t < T; ++t) {
-          lds_barrier();                                               // barrier t+1: Pinvbar_t is in the mailbox
+          lds_barrier();                                               // barrier t+1: rows 0..N-1 of S^_t are in the mailbox
           const double* rec = ringrow + (t % 3) * SLOT;
           const double* mb = mailrow + (t & 1) * MSLOT;
-          double Pi[N], Pib[N], T1[N], Pbp[N];
-          static_for<0, N>([&](auto i) {
-            Pi[i] = rec[N * HS + i * PS + ccl];
-            Pib[i] = mb[i * 16 + c];
-            T1[i] = 0.0; Pbp[i] = 0.0;
-          });
-          mm_ab<N, N, false>(T1, Pib, Pi);
-          mm_ab<N, N, true>(Pbp, Pi, T1);
           double* ad = a.adj + (b * T + t) * AS;
-          if (valid && col) static_for<0, N>([&](auto i) { ad[2 * N * HS + i * PS + c] = Pbp[i]; });
+          if (h == 0) {
+            // the part of Pbar_t that does not depend on sweep 2:  -P^-1 Pinvbar P^-1,  Pinvbar = S^[:n,:n]
+            double Pi[N], Pib[N], T1[N], Pbp[N];
+            static_for<0, N>([&](auto i) {
+              Pi[i] = rec[N * HS + i * PS + ccl];
+              Pib[i] = mb[i * 16 + c] * cm;
+              T1[i] = 0.0; Pbp[i] = 0.0;
+            });
+            mm_ab<N, N, false>(T1, Pib, Pi);
+            mm_ab<N, N, true>(Pbp, Pi, T1);
+            if (valid && col) static_for<0, N>([&](auto i) { ad[2 * N * HS + i * PS + c] = Pbp[i]; });
+          } else {
+            // G^ rows i < N:  2 S^ W~'   (lanes 0..N; with samples: this role's share)
+            double Sm[N], WT[N + 1], Gb[N];
+            load_row<N + 1>(rec + WS + cN * HS, WT);
+            static_for<0, N>([&](auto i) { Sm[i] = mb[i * 16 + c]; Gb[i] = 0.0; });
+            static_for<0, N + 1>([&](auto k) { WT[k] = colN ? 2.0 * WT[k] : 0.0; });
+            mm_ab<N, N + 1, false>(Gb, Sm, WT);
+            if (valid && colN) static_for<0, N>([&](auto i) { ad[i * HS + c] = Gb[i]; });
+          }
         }
       } else {
         // noise adjoint:  Pbar_t(direct) = -U (Lh U')  with  U = L^-T D^-1/2,  Lh from E' = sum_s eps_s z_s'
@@ -498,7 +511,7 @@ __device__ __forceinline__ void lds_vjp_sweep1_body(const VjpArgs& a, double* ta
   auto fetch_next = [&](int t) {
     const double* rec = ringrow + (t % 3) * SLOT;               // (PROD)
     if (do0) {
-      load_row<N + 1>(PROD ? rec + WS + cN * HS : a.ws3 + ((long)b * T + t) * (N + 1) * HS + cN * HS, WTn);
+      if constexpr (!PROD) load_row<N + 1>(a.ws3 + ((long)b * T + t) * (N + 1) * HS + cN * HS, WTn);
       if constexpr (PROD) {
         const double x = rec[WS + W3 + ccl], d = rec[WS + W3 + N + ccl];
         gxn = has_gx ? x : 0.0;
@@ -530,7 +543,7 @@ __device__ __forceinline__ void lds_vjp_sweep1_body(const VjpArgs& a, double* ta
     static_for<0, N>([&](auto i) { Gb[i] = 0.0; });
     double WT[N + 1], Gc[N + 1], Pir[N], gx = 0.0, gd = 0.0, gsv[SAMP ? N : 1];
     if (do0) {
-      static_for<0, N + 1>([&](auto k) { WT[k] = colN ? 2.0 * WTn[k] : 0.0; });      // 2 W~'
+      if constexpr (!PROD) static_for<0, N + 1>([&](auto k) { WT[k] = colN ? 2.0 * WTn[k] : 0.0; });      // 2 W~'
       gx = col ? 0.5 * gxn : 0.0;              // direct cotangents, symmetrised
       gd = col ? gdn : 0.0;
       if constexpr (!PROD) static_for<0, N>([&](auto i) { Pir[i] = w[N * HS + i * PS + ccl]; });
@@ -588,8 +601,8 @@ __device__ __forceinline__ void lds_vjp_sweep1_body(const VjpArgs& a, double* ta
       }
     }
 
-    // G^ rows i < N:  2 S^ W~'   (lanes 0..N)
-    mm_ab<N, N + 1, false>(Gb, Sh, WT);
+    // G^ rows i < N:  2 S^ W~'   (lanes 0..N)      (PROD: the second helper wavefront's job)
+    if constexpr (!PROD) mm_ab<N, N + 1, false>(Gb, Sh, WT);
     if constexpr (STATC) {
       if (cross) {
         // G^[i] += sum_k Cb[i][k] S~_{t+1}[k]:  S~_{t+1} rows from the forward outputs
@@ -606,9 +619,9 @@ __device__ __forceinline__ void lds_vjp_sweep1_body(const VjpArgs& a, double* ta
       }
     }
     if constexpr (PROD) {
-      // Pinvbar = S^[:n,:n] (before the propagation below) for the helper wavefront
+      // rows 0..N-1 of S^ (before the propagation below) for the helper wavefronts: Pinvbar = S^[:n,:n], G^ = 2 S^ W~'
       double* mb = mailrow + (t & 1) * MSLOT;
-      static_for<0, N>([&](auto i) { mb[i * 16 + c] = Sh[i] * cm; });
+      static_for<0, N>([&](auto i) { mb[i * 16 + c] = Sh[i]; });
     } else {
       // the part of Pbar_t that does not depend on the filter-adjoint recursion of sweep 2:
       //   -P^-1 Pinvbar P^-1,   Pinvbar = S^[:n,:n] (before the propagation below)
@@ -644,7 +657,7 @@ __device__ __forceinline__ void lds_vjp_sweep1_body(const VjpArgs& a, double* ta
       }
     }
 
-    if (!do1) { if (valid && colN) static_for<0, N>([&](auto i) { ad[i * HS + c] = Gb[i]; }); }
+    if (!do1 && !PROD) { if (valid && colN) static_for<0, N>([&](auto i) { ad[i * HS + c] = Gb[i]; }); }
     }   // smoother adjoint
 
     if constexpr (SAMP) {
