@@ -179,7 +179,15 @@ __global__ __launch_bounds__(64) void lds_filter_1r_kernel(const LdsArgs a) {
     double* fbase = foff >= 0 ? w2 + foff : w + TRASH;
     const long fstride = foff >= 0 ? N : 0;
     double vfull = col ? 0.0 : 1.0;
-    gauss_jordan_1r_hook<N>(M, E, qacc, vfull, [&](auto k, double ru) { fbase[k * fstride] = ru; });
+    // the generated, hand-scheduled elimination (gj1r_gen.hpp) returning every scaled pivot row: lanes j > k of
+    // row k are L[j][k], the unit LDL' factor the backward sampler reads
+    double RU[N];
+#if SVAE_GJ_GENERATED
+    gauss_jordan_1r_asm_rows<N>(M, E, qacc, vfull, RU);
+#else
+    gauss_jordan_1r_hook<N>(M, E, qacc, vfull, [&](auto k, double ru) { RU[k] = ru; });
+#endif
+    static_for<0, N>([&](auto k) { fbase[k * fstride] = RU[k]; });
     // pivots d_c = -1 / vfull_c
     {
       const double pvv = -rcp_nr(col ? vfull : -1.0);
