@@ -419,7 +419,12 @@ __global__ __launch_bounds__(MIX ? 512 : (S4 ? 128 : 64)) void lds_estep_twoend_
   auto hand_off = [&](int s, const double (&M)[N], double vfull) {
     if constexpr (LEAN) {
       char* w = reinterpret_cast<char*>(wsb + (long)s * WS);     // uniform base + 32-bit lane offset
-      static_for<0, N>([&](auto i) { *reinterpret_cast<double*>(w + loff[i]) = M[i] * vfull; });
+      // (the offset passes through an empty asm: hipcc otherwise hoists its zero-extension out of the loop and pays
+      //  a 64-bit add per store instead of the SGPR-base + 32-bit-offset addressing mode)
+      static_for<0, N>([&](auto i) {
+        asm volatile("" : "+v"(loff[i]));
+        *reinterpret_cast<double*>(w + loff[i]) = M[i] * vfull;
+      });
     } else {
       double* w = rec0 + (long)s * WS + stoff;
       static_for<0, N>([&](auto i) { w[i * RW] = M[i] * vfull; });

@@ -108,7 +108,11 @@ __device__ __forceinline__ void te_smooth4(const LdsArgs& a, const int b, const 
   const double* lrec = wsb + (long)e * WS;
   int nextrec = e;                                   // index of the record the next load_ops fetches (.., 1, 0, 0, ..)
   auto load_ops = [&](Ops& o) {
-    static_for<0, J1>([&](auto j) { o.Pi[j] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(lrec) + poff[j]); });
+    // (offsets through an empty asm: keeps the SGPR-base + 32-bit-offset addressing mode, see hand_off in lds_estep_twoend.hpp)
+    static_for<0, J1>([&](auto j) {
+      asm volatile("" : "+v"(poff[j]));
+      o.Pi[j] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(lrec) + poff[j]);
+    });
     lrec -= nextrec > 0 ? WS : 0;
     nextrec -= nextrec > 0 ? 1 : 0;
   };
