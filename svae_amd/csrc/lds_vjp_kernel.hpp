@@ -28,6 +28,13 @@
 // Layout: as the packed E-step kernel (one DPP row per sequence, lane = column, fused DPP FMAs).
 // Hazards: every product stage fences its DPP-read operand array once (mm_ab / mm_atb), the few
 // stand-alone broadcasts fence theirs; `make audit` checks the ISA of every latent dimension.
+// Variants (launch_vjp picks by batch size; all run the same recursion, tests/test_vjp_hip.py compares them):
+//   packed          lds_vjp_sweep{1,2}_kernel: four sequences per wavefront, register prefetch; any batch, any S,
+//                   statistics cotangents (STATC)
+//   + producers     lds_vjp_sweep{1,2}_prod_kernel (B <= prod_max_b): producer wavefronts stream the records through an
+//                   LDS ring; sweep 1 also has helper wavefronts for the work that does not feed the recursion
+//   one sequence    lds_vjp_sweep2_s4_kernel, lds_vjp_sweep1_s4_kernel (B <= VJP_S4_MAX_B): one sequence per consumer
+//   per wavefront   wavefront, product stages split over its four DPP rows
 #pragma once
 #include "lds_estep_kernel.hpp"
 #include "lds_estep_twoend_s4.hpp"   // quad_gather
