@@ -41,7 +41,11 @@ def _install_shims():
         return
 
     def _no_grad(*a, **k):
-        raise NotImplementedError("autograd is not available; forward values only")
+        # grad(f) / value_and_grad(f) may be formed at import time (hmm_inference.py:65); only
+        # CALLING the derivative is impossible here.
+        def _raise(*a2, **k2):
+            raise NotImplementedError("autograd is not available; forward values only")
+        return _raise
 
     class _Prim(object):
         def __init__(self, f, aux=False):
@@ -205,3 +209,65 @@ def load_reference(with_cython=True):
         sys.modules.setdefault("svae.hmm.cython_hmm_inference", _ref._load("cython_hmm_inference"))
     import svae
     return svae
+
+
+def load_reference_slds():
+    """The reference's svae/models/slds_svae.py (and svae/models/lds.py), executed as shipped.
+
+    Both modules fail to import in the reference tree itself because of four DEAD import lines, not
+    because of anything they compute with:
+      * `from svae.lds import niw, mniw` (slds_svae.py:16, models/lds.py:12): the exp-family modules
+        live in svae/distributions/ in this tree -> aliased to svae.distributions.{niw,mniw}.
+      * `from svae.hmm import dirichlet` (slds_svae.py:18) -> svae.distributions.dirichlet.
+      * `from lds_svae import lds_prior_expectedstats` (slds_svae.py:19): no such module.  The name
+        is rebuilt from the reference's own functions with the reference's own definition
+        (svae/lds/lds_prior.py:7-9, models/lds.py:24-26: `niw.expectedstats, mniw.expectedstats`),
+        composed with the reference's gaussian.unpack_dense (distributions/gaussian.py:47-57)
+        because the LDS code consumes init params as the tuple (J, h, a, b)
+        (cython_lds_inference.pyx:30-32) while distributions/niw.py:25 returns them dense-packed.
+      * `pyhsmm.internals.hmm_messages_interface` (hmm_inference.py:8-10; un-vendored, un-pinned):
+        stand-in names that raise; `hmm_estep` is then re-bound inside slds_svae to the
+        reference's own `hmm_estep_slow = vgrad(hmm_logZ)` (hmm_inference.py:65) evaluated with
+        the COMPILED hmm_logZ / hmm_logZ_grad(1.0, .) of cython_hmm_inference.pyx:93-166.
+    Everything else -- get_var_lds_local_natparam (:92-103), hmm_prior_expectedstats (:120-128),
+    get_arhmm_local_nodeparams (:131-147), optimize_local_meanfield (:159-175),
+    initialize_local_meanfield (:203-226), get_global_stats (:229-243), run_inference
+    (:289-310, forward values) -- is the reference's code on the reference's compiled kernels.
+    Returns the module svae.models.slds_svae."""
+    import numpy as np
+    svae = load_reference(with_cython=True)
+    from . import ref as _ref
+    import svae.distributions.niw as niw
+    import svae.distributions.mniw as mniw
+    import svae.distributions.dirichlet as dirichlet
+    import svae.distributions.gaussian as dgauss
+    import svae.lds
+    import svae.hmm
+    sys.modules["svae.lds.niw"] = svae.lds.niw = niw
+    sys.modules["svae.lds.mniw"] = svae.lds.mniw = mniw
+    sys.modules["svae.hmm.dirichlet"] = svae.hmm.dirichlet = dirichlet
+    chmm = _ref._load("cython_hmm_inference")
+    sys.modules.setdefault("cython_hmm_inference", chmm)       # hmm_inference.py:12 (py2 implicit relative)
+
+    def _absent(*a, **k):
+        raise NotImplementedError("pyhsmm is not vendored by the reference")
+    _mod("pyhsmm")
+    _mod("pyhsmm.internals")
+    _mod("pyhsmm.internals.hmm_messages_interface", messages_backwards_log=_absent,
+         messages_forwards_log=_absent, expected_statistics_log=_absent, viterbi=_absent)
+
+    def lds_prior_expectedstats(natparam):
+        niw_natparam, mniw_natparam = natparam
+        J, h, a, b = dgauss.unpack_dense(niw.expectedstats(niw_natparam))
+        return (J, h, a, b), tuple(mniw.expectedstats(mniw_natparam))
+    _mod("lds_svae", lds_prior_expectedstats=lds_prior_expectedstats)
+
+    import svae.models.slds_svae as slds
+
+    def hmm_estep(natparam):
+        natparam = tuple(np.require(x, np.double, "C") for x in natparam)
+        logZ, aux = chmm.hmm_logZ(natparam)
+        E_init, E_trans, E_states = chmm.hmm_logZ_grad(1.0, aux)
+        return logZ, (np.asarray(E_init), np.asarray(E_trans), np.asarray(E_states))
+    slds.hmm_estep = hmm_estep
+    return slds

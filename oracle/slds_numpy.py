@@ -1,11 +1,18 @@
 """NumPy restatement of the reference's SLDS-SVAE local inference.  TEST INFRASTRUCTURE.
 
-Follows svae/models/slds_svae.py:80-310 for ONE sequence (the reference has no batch axis).  The
-reference module does not import as shipped (svae.lds.niw / svae.lds.mniw / svae.hmm.dirichlet /
-lds_svae are not in the tree; hmm_estep needs pyhsmm), so parity here is pinned through its pieces:
-oracle.lds_numpy and oracle.hmm_numpy are each checked against the compiled reference
-(tests/test_oracle.py), and the glue below is restated line by line.  "parity unpinned" for the
-glue as a whole.
+Follows svae/models/slds_svae.py:80-310 for ONE sequence (the reference has no batch axis).
+
+PARITY PINNED (round 3): the reference module itself runs through oracle/ref_py2.py:
+load_reference_slds (its four dead import lines aliased to the modules that exist in the tree,
+hmm_estep evaluated with the reference's compiled hmm_logZ / hmm_logZ_grad); its outputs for the
+glue functions, a whole optimize_local_meanfield run and run_inference are committed as
+tests/golden/slds_*.npz (tests/golden/make_golden.py: slds_case) and this restatement is held to
+them in tests/test_oracle.py.
+
+`cython_init_logZ`: the reference's compiled filter reads init_params[2] only
+(cython_lds_inference.pyx:32), so with the SLDS's 4-tuple init potential (J, h, a, b) the term
+b = 1/2 E log|J| never enters lds_vlb AS SHIPPED; the reference's Python twin sums the tail
+(lds_inference.py:62-63).  True reproduces the shipped value, False (default) the Python twin's.
 """
 import numpy as np
 
@@ -43,10 +50,11 @@ def get_arhmm_local_nodeparams(inits, pairs, init_stats, pair_stats):
     return node
 
 
-def lds_meanfield(inits, pairs, node_potentials, expected_states):
+def lds_meanfield(inits, pairs, node_potentials, expected_states, cython_init_logZ=False):
     """slds_svae.py:80-84 -> (vlb, init_stats, pair_stats, node_stats, natparam)."""
     natparam = get_var_lds_local_natparam(inits, pairs, expected_states)
-    lognorm, (E_init, E_pair, E_node) = lds_numpy.natural_lds_estep_general(natparam, node_potentials)
+    est = (natparam[0][:3], natparam[1]) if cython_init_logZ else natparam
+    lognorm, (E_init, E_pair, E_node) = lds_numpy.natural_lds_estep_general(est, node_potentials)
     return lognorm, (E_init[0], E_init[1]), E_pair[:3], E_node[:2], natparam
 
 
@@ -63,7 +71,8 @@ def initialize_local_meanfield(node_potentials, eps):
     return (outer(x[0], x[0]), x[0]), (outer(x[:-1], x[:-1]), outer(x[:-1], x[1:]), outer(x[1:], x[1:]))
 
 
-def optimize_local_meanfield(global_natparam, node_potentials, init_eps, tol=1e-2, max_iter=100):
+def optimize_local_meanfield(global_natparam, node_potentials, init_eps, tol=1e-2, max_iter=100,
+                             cython_init_logZ=False):
     """slds_svae.py:159-175."""
     (dir_nat, mdir_nat), lds_global = global_natparam
     hmm_init, hmm_pair = ef.dirichlet_expectedstats(dir_nat), ef.dirichlet_expectedstats(mdir_nat)
@@ -73,7 +82,8 @@ def optimize_local_meanfield(global_natparam, node_potentials, init_eps, tol=1e-
     for it in range(1, max_iter + 1):
         node_hmm = get_arhmm_local_nodeparams(inits, pairs, init_stats, pair_stats)
         hmm_vlb, hmm_stats = hmm_numpy.hmm_estep((hmm_init, hmm_pair, node_hmm))
-        lds_vlb, init_stats, pair_stats, node_stats, lds_nat = lds_meanfield(inits, pairs, node_potentials, hmm_stats[2])
+        lds_vlb, init_stats, pair_stats, node_stats, lds_nat = lds_meanfield(inits, pairs, node_potentials, hmm_stats[2],
+                                                                             cython_init_logZ)
         new_vlb = hmm_vlb + lds_vlb
         if abs(new_vlb - vlb) < tol:
             break

@@ -32,6 +32,21 @@ def rand_lds_natparam(n, rng):
     return (J0, h0, logZ0), (J11, J12, J22, logZ)
 
 
+def rotation_lds_natparam(n, rng):
+    """A well-conditioned LDS in natural form: rotation-like dynamics A = 0.97 Q (Q orthogonal, spectral radius
+    0.97) with nearly isotropic state noise (cond ~ 10), unit initial covariance.  `rand_lds_natparam`'s state
+    noise B B' has cond ~ n^2, on which the reference's own fp64 path drifts by ~1e-5 from extended precision at
+    n = 64, T = 1000 (tests/test_lds_tile_hip.py); this is the model the latent-dim-64 workload of bench.py runs and
+    the tests pin against the reference's compiled path at 1e-8."""
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    A = 0.97 * Q
+    Bm = rng.standard_normal((n, n))
+    S = 0.3 * np.eye(n) + 0.02 * (Bm @ Bm.T) / n
+    Si = np.linalg.inv(S)
+    J0, h0 = -0.5 * np.eye(n), rng.standard_normal(n)
+    return (J0, h0, 0.), (-0.5 * A.T @ Si @ A, A.T @ Si, -0.5 * Si, -0.5 * np.linalg.slogdet(S)[1])
+
+
 def rand_node_potentials(shape, rng, with_logZ=False):
     """shape = (T, n) or (B, T, n) -> (J diag, h[, logZ]) like nnet.gaussian_info (nnet.py:43-47)."""
     J = -0.5 * np.log1p(np.exp(rng.standard_normal(shape)))

@@ -10,8 +10,16 @@
 
 The reference module is stale as shipped (imports svae.lds.niw/mniw, svae.hmm.dirichlet, lds_svae,
 none of which exist; hmm_estep needs the un-vendored pyhsmm).  Formulas are taken from it with
-svae/distributions/{niw,mniw,dirichlet}.py.  The two message-passing hot loops run in the HIP
-kernels; the contractions between them (O(B T K n^2) einsums) are torch ops on the device.
+svae/distributions/{niw,mniw,dirichlet}.py; tests/golden/slds_*.npz hold the outputs of the reference
+module itself (dead imports aliased, oracle/ref_py2.py) and the GPU tests check against them.  The two
+message-passing hot loops run in the HIP kernels; the contractions between them (O(B T K n^2) einsums)
+are torch ops on the device.
+
+`reference_compat`: the reference's COMPILED filter reads init_params[2] only
+(cython_lds_inference.pyx:32), so the 4th entry of the SLDS's init potential (b = 1/2 E log|J|, mixed
+over E[z_0]) is missing from lds_vlb / local_vlb as shipped, while its Python twin sums the tail
+(lds_inference.py:62-63).  Default False = the Python twin (the bound that is actually a bound);
+True reproduces the shipped compiled path bit for bit in that term (it also moves the stopping test).
 Batched: node potentials (B,T,n); every sequence runs its own coordinate ascent and stops on its own
 |delta vlb| < tol like the reference (converged sequences are frozen).
 """
@@ -161,9 +169,10 @@ class SLDSMeanfieldPlan(object):
         nt = pc[:, :-1, 0] + pc[:, 1:, 1] + dense_pair[3]
         return torch.cat([n0[:, None], nt], 1)
 
-    def lds_vlb(self, dense_init, dense_pair, weights):
+    def lds_vlb(self, dense_init, dense_pair, weights, reference_compat=False):
         """log-normaliser of the mixed LDS = kernel part + the mixed constants."""
-        return self.lognorm + weights[:, 0] @ (dense_init[2] + dense_init[3]) + (weights[:, 1:] @ dense_pair[3]).sum(1)
+        const0 = dense_init[2] if reference_compat else dense_init[2] + dense_init[3]
+        return self.lognorm + weights[:, 0] @ const0 + (weights[:, 1:] @ dense_pair[3]).sum(1)
 
 
 def _arhmm_nodeparams_from_path(dense_init, dense_pair, x):
@@ -176,7 +185,8 @@ def _arhmm_nodeparams_from_path(dense_init, dense_pair, x):
     return torch.cat([n0[:, None], nt], 1)
 
 
-def _optimize_local_meanfield_fused(hmm_init, hmm_pair, dense_init, dense_pair, node, init_eps, tol, max_iter):
+def _optimize_local_meanfield_fused(hmm_init, hmm_pair, dense_init, dense_pair, node, init_eps, tol, max_iter,
+                                    reference_compat=False):
     """The coordinate ascent of optimize_local_meanfield on the fused kernel.  Same iteration as the
     materialised path (and the reference): hmm_meanfield -> lds_meanfield -> |delta vlb| < tol per sequence."""
     B, T, n = node[1].shape
@@ -201,7 +211,7 @@ def _optimize_local_meanfield_fused(hmm_init, hmm_pair, dense_init, dense_pair, 
             for name, val in (("Ei", Ei), ("Et", Et), ("Es", Es), ("hmm_vlb", hmm_vlb), ("node_hmm", node_hmm)):
                 st[name].index_copy_(0, rows, val)
         plan.launch(dense_init, dense_pair, st["Es"], node, rows32)
-        lds_vlb = plan.lds_vlb(dense_init, dense_pair, st["Es"])
+        lds_vlb = plan.lds_vlb(dense_init, dense_pair, st["Es"], reference_compat)
         new_vlb = st["hmm_vlb"] + lds_vlb
         iters += active.to(torch.int64)
         done = (new_vlb - vlb).abs() < tol
@@ -229,7 +239,7 @@ def _initial_sample_path(node_potentials, eps):
 
 
 def optimize_local_meanfield(global_natparam, node_potentials, init_eps, tol=1e-2, max_iter=100, fused=None,
-                             pair_stats=True):
+                             pair_stats=True, reference_compat=False):
     """(:159-175).  Returns ((hmm_stats, lds_stats), (hmm_natparam, lds_natparam), (hmm_vlb, lds_vlb), iters).
 
     fused=None picks the fused LDS mean-field kernel (SLDSMeanfieldPlan) when it covers the shape, else the
@@ -247,7 +257,7 @@ def optimize_local_meanfield(global_natparam, node_potentials, init_eps, tol=1e-
         fused = SLDSMeanfieldPlan.supported(n, T, K)
     if fused:
         fplan, st, lds_vlb, iters = _optimize_local_meanfield_fused(
-            hmm_init, hmm_pair, dense_init, dense_pair, node, _dev64(init_eps, dev), tol, max_iter)
+            hmm_init, hmm_pair, dense_init, dense_pair, node, _dev64(init_eps, dev), tol, max_iter, reference_compat)
         lds_init, lds_pair = get_var_lds_local_natparam(dense_init, dense_pair, st["Es"])
         init_stats = (fplan.E_init[:, :n * n].reshape(B, n, n), fplan.E_init[:, n * n:])
         pstats = None
@@ -284,7 +294,8 @@ def optimize_local_meanfield(global_natparam, node_potentials, init_eps, tol=1e-
         lds_init, lds_pair = get_var_lds_local_natparam(dense_init, dense_pair, Es)
         # the E-step API takes one shared init potential per launch: fold each sequence's init
         # potential into its first node potential instead (identical model: both multiply x_0's factor)
-        lds_vlb, (Ei_l, Ep_l, En_l) = _lds_estep_batched_init(plan, lds_init, lds_pair, node)
+        lds_vlb, (Ei_l, Ep_l, En_l) = _lds_estep_batched_init(plan, lds_init, lds_pair, node,
+                                                              reference_compat=reference_compat)
         all_active = bool(active.all())
         for name, val in (("Ei", Ei), ("Et", Et), ("Es", Es), ("node_hmm", node_hmm), ("E_init", plan.E_init),
                           ("E_pair", plan.E_pair), ("dxx", En_l[0]), ("ex", En_l[1]), ("hmm_vlb", hmm_vlb),
@@ -326,7 +337,7 @@ def optimize_local_meanfield_withlabels(global_natparam, node_potentials, labels
     return (hmm_stats, lds_stats), (None, (lds_init, lds_pair)), (torch.zeros_like(lds_vlb), lds_vlb.clone())
 
 
-def _lds_estep_batched_init(plan, lds_init, lds_pair, node, keep_factor=False):
+def _lds_estep_batched_init(plan, lds_init, lds_pair, node, keep_factor=False, reference_compat=False):
     """LDS E-step with a PER-SEQUENCE init potential (the SLDS mixes K init potentials by E[z_0]):
     run the kernel with a zero shared init potential and add each sequence's (J0, h0) to its first
     node potential's dense block... the kernel's node potentials are diagonal, so instead the init
@@ -346,7 +357,7 @@ def _lds_estep_batched_init(plan, lds_init, lds_pair, node, keep_factor=False):
                     (J11.contiguous(), J12.contiguous(), J22.contiguous(), lz.contiguous()))
         lognorm, stats = natural_lds_estep_general(natparam, (nJ, nh) + tuple(node[2:]), plan=plan,
                                                    keep_factor=keep_factor)
-        return lognorm + a0 + b0, stats
+        return (lognorm + a0 if reference_compat else lognorm + a0 + b0), stats
     raise NotImplementedError("SLDS needs T > 1")
 
 
@@ -379,7 +390,7 @@ def global_stats_as_natparam(stats):
 
 
 def run_inference(prior_natparam, global_natparam, nn_potentials, num_samples, init_eps=None, eps=None,
-                  generator=None, tol=1e-2, group=None):
+                  generator=None, tol=1e-2, group=None, reference_compat=False):
     """(:289-310) -> (samples (B,T,S,n), expected_stats, global_vlb, local_vlb); forward values only
     (see run_inference_differentiable).  Under torch.distributed the sequences are this rank's shard (every
     sequence runs its own coordinate ascent: no collective inside it); the statistics and local_vlb are summed
@@ -389,9 +400,11 @@ def run_inference(prior_natparam, global_natparam, nn_potentials, num_samples, i
     B, T, n = node[1].shape
     if init_eps is None:
         init_eps = torch.randn(B, T, 1, n, dtype=torch.float64, device=dev, generator=generator)
-    (hmm_stats, _), (hmm_nat, (lds_init, lds_pair)), _, _ = optimize_local_meanfield(global_natparam, node, init_eps, tol, pair_stats=False)
+    (hmm_stats, _), (hmm_nat, (lds_init, lds_pair)), _, _ = optimize_local_meanfield(
+        global_natparam, node, init_eps, tol, pair_stats=False, reference_compat=reference_compat)
     plan = LDSEStepPlan(B, T, n, dev, inhomog=True, pair_batched=True)
-    lognorm, (Ei, Ep, En) = _lds_estep_batched_init(plan, lds_init, lds_pair, node, keep_factor=True)
+    lognorm, (Ei, Ep, En) = _lds_estep_batched_init(plan, lds_init, lds_pair, node, keep_factor=True,
+                                                    reference_compat=reference_compat)
     S = int(num_samples)
     if eps is None:
         eps = torch.randn(B, T, S, n, dtype=torch.float64, device=dev, generator=generator)
@@ -425,7 +438,8 @@ def slds_prior_vlb(global_natparam, prior_natparam, dev):
     return (val - (logZ(pd, pmd, plds) - logZ(gd, gmd, glds))).to(out_dev)
 
 
-def final_pass_differentiable(global_natparam, hmm_natparam, lds_natparam, nn_potentials, eps):
+def final_pass_differentiable(global_natparam, hmm_natparam, lds_natparam, nn_potentials, eps,
+                              reference_compat=False):
     """The part of run_inference that depends on nn_potentials with gradients attached
     (slds_svae.py:295-307, "recompute terms that depend on nn_potentials at optimum"): the LDS
     E-step + sampler on the FIXED mean-field natural parameters, the HMM bound evaluated on its
@@ -444,7 +458,7 @@ def final_pass_differentiable(global_natparam, hmm_natparam, lds_natparam, nn_po
     natparam = ((torch.zeros(n, n, dtype=torch.float64, device=dev), torch.zeros(n, dtype=torch.float64, device=dev), zero),
                 (J11.contiguous(), J12.contiguous(), J22.contiguous(), lz.contiguous()))
     lognorm, (dxx, ex), samples, (E_init, E_pair) = lds_inference_differentiable(natparam, (nJ, nh_eff), eps=eps)
-    lognorm = lognorm + a0 + b0
+    lognorm = lognorm + a0 if reference_compat else lognorm + a0 + b0
     _, _, dense_init, dense_pair = global_to_local_maps(global_natparam, dev)
     init_stats = (E_init[:, :n * n].reshape(B, n, n), E_init[:, n * n:])
     pair_stats = (E_pair[:, :, 0], E_pair[:, :, 1], E_pair[:, :, 2])
@@ -455,7 +469,7 @@ def final_pass_differentiable(global_natparam, hmm_natparam, lds_natparam, nn_po
 
 
 def run_inference_differentiable(prior_natparam, global_natparam, nn_potentials, num_samples, init_eps=None,
-                                 eps=None, generator=None, tol=1e-2, group=None):
+                                 eps=None, generator=None, tol=1e-2, group=None, reference_compat=False):
     """run_inference (slds_svae.py:289-310) with torch autograd attached to nn_potentials = (J, h),
     each (B,T,n): the local mean field is optimised on detached values (the reference's `unbox`),
     then the final pass is differentiated through the E-step / sampler VJP kernels and the HMM
@@ -465,11 +479,12 @@ def run_inference_differentiable(prior_natparam, global_natparam, nn_potentials,
     B, T, n = node_d[1].shape
     if init_eps is None:
         init_eps = torch.randn(B, T, 1, n, dtype=torch.float64, device=dev, generator=generator)
-    (hmm_stats, _), (hmm_nat, lds_nat), _, _ = optimize_local_meanfield(global_natparam, node_d, init_eps, tol, pair_stats=False)
+    (hmm_stats, _), (hmm_nat, lds_nat), _, _ = optimize_local_meanfield(
+        global_natparam, node_d, init_eps, tol, pair_stats=False, reference_compat=reference_compat)
     if eps is None:
         eps = torch.randn(B, T, int(num_samples), n, dtype=torch.float64, device=dev, generator=generator)
     samples, (init_stats, pair_stats), local_vlb = final_pass_differentiable(
-        global_natparam, hmm_nat, lds_nat, (nn_potentials[0], nn_potentials[1]), _dev64(eps, dev))
+        global_natparam, hmm_nat, lds_nat, (nn_potentials[0], nn_potentials[1]), _dev64(eps, dev), reference_compat)
     expected_stats = get_global_stats(hmm_stats, tuple(x.detach() for x in init_stats),
                                       tuple(x.detach() for x in pair_stats))
     expected_stats, local_vlb = allreduce_nested(expected_stats, local_vlb, group)

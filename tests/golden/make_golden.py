@@ -9,6 +9,12 @@ exists):  python tests/golden/make_golden.py
                global NumPy RNG seeded so that `initialize_meanfield` (gmm.py:126-128) is
                reproducible; the drawn initial responsibilities are stored too.
   expfam.npz : niw / mniw / dirichlet expectedstats and logZ from svae/distributions/*.py.
+  slds_*.npz : the SLDS glue of svae/models/slds_svae.py executed as shipped (oracle/ref_py2.py:
+               load_reference_slds -- four dead import lines aliased, nothing else touched) on the
+               reference's compiled LDS / HMM kernels: get_var_lds_local_natparam (:92-103),
+               hmm_prior_expectedstats (:120-128), get_arhmm_local_nodeparams (:131-147),
+               get_global_stats (:229-243), optimize_local_meanfield (:159-175, with the number of
+               sweeps it took) and run_inference (:289-310, forward values), RNG draws replayed.
 
 Fixtures are small (< 1 MB total) and are what the GPU box checks against (it has no
 /root/reference).
@@ -129,6 +135,132 @@ def expfam_case():
     print("expfam ok")
 
 
+def _slds_globals(K, n, rng):
+    """Global natural parameters of an SLDS with K rotating/decaying dynamics (NIW / MNIW natural
+    parameters through the reference's own standard_to_natural, distributions/niw.py:39-42,
+    mniw.py:25-31)."""
+    from svae.distributions import niw, mniw
+    dir_nat = rng.random(K) * 2.
+    mdir_nat = rng.random((K, K)) * 2. + 3. * np.eye(K)
+    lds = []
+    for k in range(K):
+        nu, S = n + 1. + rng.random(), 2. * (n + 1) * np.eye(n)
+        mu, kappa = 0.3 * rng.standard_normal(n), 0.5
+        th = 0.4 * (k + 1)
+        M = 0.95 * np.eye(n)
+        M[:2, :2] = 0.95 * np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        lds.append((niw.standard_to_natural(S, mu, np.array(kappa), np.array(nu)),
+                    tuple(np.asarray(x, float) for x in mniw.standard_to_natural(nu, S, M, 0.2 * np.eye(n)))))
+    return (dir_nat, mdir_nat), lds
+
+
+def slds_case(name, K, n, T, B, S, seed):
+    slds = ref_py2.load_reference_slds()
+    rng = np.random.default_rng(seed)
+    glob = _slds_globals(K, n, rng)
+    prior = _slds_globals(K, n, rng)
+    (dir_nat, mdir_nat), lds = glob
+    out = dict(dir_nat=dir_nat, mdir_nat=mdir_nat, niw_nat=np.stack([a for a, _ in lds]),
+               prior_dir_nat=prior[0][0], prior_mdir_nat=prior[0][1],
+               prior_niw_nat=np.stack([a for a, _ in prior[1]]))
+    for i in range(4):
+        out["mniw_nat%d" % i] = np.stack([np.asarray(m[i], float) for _, m in lds])
+        out["prior_mniw_nat%d" % i] = np.stack([np.asarray(m[i], float) for _, m in prior[1]])
+    node_J = -0.5 * (0.5 + rng.random((B, T, n)))
+    node_h = rng.standard_normal((B, T, n)) * 2.
+    out["node_J"], out["node_h"] = node_J, node_h
+
+    # --- the pure glue functions on fixed random inputs ----------------------------------------
+    hmm_init, hmm_pair = slds.hmm_prior_expectedstats(glob[0])
+    out["hmm_init"], out["hmm_pair"] = hmm_init, hmm_pair
+    all_init, all_pair = slds.get_all_lds_local_natparams(lds)
+    for i in range(4):
+        out["dense_init%d" % i] = np.stack([np.asarray(p[i], float) for p in all_init])
+        out["dense_pair%d" % i] = np.stack([np.asarray(p[i], float) for p in all_pair])
+    w = rng.random((T, K)); w /= w.sum(1, keepdims=True)
+    out["glue_states"] = w
+    gi, gp = slds.get_var_lds_local_natparam(lds, (None, None, w))
+    for i in range(4):
+        out["glue_init%d" % i], out["glue_pair%d" % i] = np.asarray(gi[i], float), np.asarray(gp[i], float)
+    x = rng.standard_normal((T, n))
+    o = lambda a, b: a[..., :, None] * b[..., None, :]
+    A = rng.standard_normal((T - 1, n, n)) * 0.1
+    init_stats = (o(x[0], x[0]) + 0.3 * np.eye(n), x[0], 1., 1.)
+    pair_stats = [o(x[:-1], x[:-1]) + A @ A.transpose(0, 2, 1), o(x[:-1], x[1:]) + A,
+                  o(x[1:], x[1:]) + A.transpose(0, 2, 1) @ A, np.ones(T - 1)]
+    out["glue_ExxT0"], out["glue_Ex0"] = init_stats[0], init_stats[1]
+    for i in range(3):
+        out["glue_pairstat%d" % i] = pair_stats[i]
+    out["glue_node_hmm"] = slds.get_arhmm_local_nodeparams(lds, (init_stats, pair_stats))
+    Etrans = rng.random((K, K))
+    (ghi, ght), glds = slds.get_global_stats((w[0], Etrans, w), (init_stats, pair_stats))
+    glds = list(glds)
+    out["glue_gstat_hmm_init"], out["glue_gstat_hmm_trans"] = ghi, ght
+    out["glue_gstat_init_xx"] = np.stack([g[0][0] for g in glds])
+    out["glue_gstat_init_x"] = np.stack([g[0][1] for g in glds])
+    out["glue_gstat_init_1"] = np.array([[g[0][2], g[0][3]] for g in glds])
+    for i in range(4):
+        out["glue_gstat_pair%d" % i] = np.stack([np.asarray(list(g[1])[i], float) for g in glds])
+
+    # --- the coordinate ascent, as shipped ---------------------------------------------------
+    # The compiled filter reads init_params[2] only (cython_lds_inference.pyx:32): with the
+    # 4-tuple init potential (J, h, a, b) the SLDS builds, the `b` = 1/2 E log|J| term is NOT in
+    # lds_vlb (the Python twin sums the tail, lds_inference.py:62-63).  Goldens hold the shipped
+    # value; `*_init_b` is the dropped term sum_k E[z_0 = k] b_k for the other convention.
+    calls = [0]
+    estep0 = slds.hmm_estep
+
+    def counting(natparam):
+        calls[0] += 1
+        return estep0(natparam)
+    slds.hmm_estep = counting
+    keys = ("iters", "hmm_vlb", "lds_vlb", "init_b", "E_hmm_init", "E_hmm_trans", "E_states", "ExxT0", "Ex0",
+            "Epair0", "Epair1", "Epair2", "Enode_diagxx", "Enode_x", "init_eps", "node_hmm")
+    acc = {k: [] for k in keys}
+    bvec = out["dense_init3"]
+    for b in range(B):
+        node = (node_J[b], node_h[b], np.zeros(T))
+        np.random.seed(seed * 1000 + b)
+        acc["init_eps"].append(np.random.randn(T, 1, n)[::-1].copy())    # as oracle/ref.py:sample_backward
+        np.random.seed(seed * 1000 + b)
+        calls[0] = 0
+        (hmm_stats, lds_stats), (hmm_nat, lds_nat), (hv, lv) = slds.optimize_local_meanfield(glob, node)
+        acc["iters"].append(calls[0])
+        acc["hmm_vlb"].append(hv); acc["lds_vlb"].append(lv)
+        acc["init_b"].append(float(hmm_stats[2][0] @ bvec))
+        acc["E_hmm_init"].append(hmm_stats[0]); acc["E_hmm_trans"].append(hmm_stats[1])
+        acc["E_states"].append(hmm_stats[2])
+        E_init, E_pair, E_node = lds_stats
+        E_pair = list(E_pair)
+        acc["ExxT0"].append(E_init[0]); acc["Ex0"].append(E_init[1])
+        for i in range(3):
+            acc["Epair%d" % i].append(np.asarray(E_pair[i]))
+        acc["Enode_diagxx"].append(E_node[0]); acc["Enode_x"].append(E_node[1])
+        acc["node_hmm"].append(hmm_nat[2])
+    slds.hmm_estep = estep0
+    for k in keys:
+        out["opt_" + k] = np.stack([np.asarray(v, float) for v in acc[k]])
+
+    # --- run_inference (:289-310), forward values, one sequence --------------------------------
+    node = (node_J[0], node_h[0], np.zeros(T))
+    np.random.seed(seed + 77)
+    out["run_init_eps"] = np.random.randn(T, 1, n)[::-1].copy()
+    out["run_eps"] = np.random.randn(T, S, n)[::-1].copy()
+    np.random.seed(seed + 77)
+    samples, stats, gvlb, lvlb = slds.run_inference(prior, glob, node, S)
+    (shi, sht), slds_g = stats
+    slds_g = list(slds_g)
+    out["run_samples"] = np.asarray(samples)
+    out["run_global_vlb"], out["run_local_vlb"] = np.asarray(gvlb), np.asarray(lvlb)
+    out["run_stat_hmm_init"], out["run_stat_hmm_trans"] = shi, sht
+    out["run_stat_init_xx"] = np.stack([g[0][0] for g in slds_g])
+    out["run_stat_init_x"] = np.stack([g[0][1] for g in slds_g])
+    for i in range(4):
+        out["run_stat_pair%d" % i] = np.stack([np.asarray(list(g[1])[i], float) for g in slds_g])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "iters", out["opt_iters"], "vlb", out["opt_hmm_vlb"] + out["opt_lds_vlb"], "local_vlb", lvlb)
+
+
 if __name__ == "__main__":
     assert build_ref.build(), "reference build failed"
     lds_case("lds_T5_n3", B=2, T=5, n=3, seed=0)
@@ -142,3 +274,5 @@ if __name__ == "__main__":
     gmm_case("gmm_K4_N3_T33", K=4, N=3, T=33, seed=2)
     gmm_run_case("gmm_run_K5_N2_T60", K=5, N=2, T=60, S=3, seed=4)
     expfam_case()
+    slds_case("slds_K3_n4_T12", K=3, n=4, T=12, B=3, S=2, seed=11)
+    slds_case("slds_K8_n10_T40", K=8, n=10, T=40, B=2, S=1, seed=12)

@@ -177,6 +177,30 @@ def test_full_size_against_reference_and_properties(B):
     assert torch.equal(r2, plan.reduce())                         # bit-reproducible
 
 
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("n", [11, 12, 13, 14, 15])
+def test_full_size_latent_dims_11_to_15_against_reference(n):
+    """T = 200, B = 512 at the latent dimensions above the two-ended kernel's limit (n <= 10; these run the
+    split kernel, and the packed kernel above B = 1023: also launched here at B = 1040) against the reference's
+    own compiled path on a spread of sequences."""
+    from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials
+    T = 200
+    rng = np.random.default_rng(n)
+    init, pair = rand_lds_natparam(n, rng)
+    for B, picks in ((512, 10), (1040, 5)):
+        node = rand_node_potentials((B, T, n), rng)
+        lognorm, (Ei, Ep, En) = _run(init, pair, node)
+        worst = 0.0
+        for b in np.unique(np.linspace(0, B - 1, picks).astype(int)):
+            ln, (oi, op, on) = ref.estep((init, pair), (node[0][b], node[1][b], np.zeros(T)))
+            errs = [_rel(lognorm[b], ln), _rel(Ei[0][b], oi[0]), _rel(Ei[1][b], oi[1]),
+                    _rel(En[0][b], on[0]), _rel(En[1][b], on[1])]
+            errs += [_rel(Ep[i][b], np.asarray(op[i])) for i in range(3)]
+            worst = max(worst, max(errs))
+        print("n=%d T=%d B=%d vs compiled reference: worst rel err %.2e" % (n, T, B, worst))
+        assert worst < 1e-6, (B, worst)
+
+
 # (S <= 4 at small batches runs with producer wavefronts, eight steps in flight: T around that depth and T = 1)
 @pytest.mark.parametrize("n,T,S", [(10, 30, 3), (4, 12, 16), (3, 7, 21), (15, 5, 2), (1, 6, 4),
                                    (6, 9, 2), (5, 10, 1), (7, 17, 4), (8, 8, 3), (4, 1, 1)])

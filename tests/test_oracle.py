@@ -188,3 +188,53 @@ def test_slds_coordinate_ascent_oracle_is_monotone():
     inits, pairs = slds_numpy.get_all_lds_local_natparams(lds)
     node_hmm = slds_numpy.get_arhmm_local_nodeparams(inits, pairs, r_tight["init_stats"], r_tight["pair_stats"])
     np.testing.assert_allclose(node_hmm, r_tight["node_hmm"], atol=1e-3)
+
+
+@pytest.mark.parametrize("case", ["slds_K3_n4_T12", "slds_K8_n10_T40"])
+def test_slds_glue_oracle_matches_reference_golden(case, golden_dir):
+    """oracle/slds_numpy.py against the outputs of the reference's own slds_svae.py (run through
+    oracle/ref_py2.load_reference_slds): get_var_lds_local_natparam (:92-103),
+    hmm_prior_expectedstats (:120-128), get_arhmm_local_nodeparams (:131-147), get_global_stats
+    (:229-243) on fixed inputs, then whole optimize_local_meanfield runs (:159-175): same number of
+    sweeps, same statistics, same bounds."""
+    from oracle import slds_numpy
+    import _slds_golden as G
+    g = G.load(golden_dir, case)
+    glob = G.global_natparam(g)
+    (dir_nat, mdir_nat), lds = glob
+    K = len(lds)
+    np.testing.assert_allclose(ef.dirichlet_expectedstats(dir_nat), g["hmm_init"], rtol=1e-12)
+    np.testing.assert_allclose(ef.dirichlet_expectedstats(mdir_nat), g["hmm_pair"], rtol=1e-12)
+    inits, pairs = slds_numpy.get_all_lds_local_natparams(lds)
+    for i in range(4):
+        assert G.rel(np.stack([np.asarray(p[i], float) for p in inits]), g["dense_init%d" % i]) < 1e-12
+        assert G.rel(np.stack([np.asarray(p[i], float) for p in pairs]), g["dense_pair%d" % i]) < 1e-12
+    gi, gp = slds_numpy.get_var_lds_local_natparam(inits, pairs, g["glue_states"])
+    for i in range(4):
+        assert G.rel(gi[i], g["glue_init%d" % i]) < 1e-13 and G.rel(gp[i], g["glue_pair%d" % i]) < 1e-13
+    pstats = tuple(g["glue_pairstat%d" % i] for i in range(3))
+    node_hmm = slds_numpy.get_arhmm_local_nodeparams(inits, pairs, (g["glue_ExxT0"], g["glue_Ex0"]), pstats)
+    assert G.rel(node_hmm, g["glue_node_hmm"]) < 1e-13
+    w = g["glue_states"]
+    (_, _), (g_init, g_pair) = slds_numpy.get_global_stats((w[0], None, w), (g["glue_ExxT0"], g["glue_Ex0"]), pstats)
+    assert G.rel(g_init[0], g["glue_gstat_init_xx"]) < 1e-13 and G.rel(g_init[1], g["glue_gstat_init_x"]) < 1e-13
+    assert G.rel(np.stack([g_init[2], g_init[3]], 1), g["glue_gstat_init_1"]) < 1e-13
+    for i in range(4):
+        assert G.rel(g_pair[i], g["glue_gstat_pair%d" % i]) < 1e-13
+    B = g["node_J"].shape[0]
+    for b in range(B):
+        r = slds_numpy.optimize_local_meanfield(glob, (g["node_J"][b], g["node_h"][b]), g["opt_init_eps"][b],
+                                                cython_init_logZ=True)
+        assert r["iters"] == int(g["opt_iters"][b])
+        assert abs(r["hmm_vlb"] - g["opt_hmm_vlb"][b]) < 1e-8 * abs(g["opt_hmm_vlb"][b])
+        assert abs(r["lds_vlb"] - g["opt_lds_vlb"][b]) < 1e-8 * abs(g["opt_lds_vlb"][b])
+        for got, key in ((r["hmm_stats"][0], "E_hmm_init"), (r["hmm_stats"][1], "E_hmm_trans"),
+                         (r["hmm_stats"][2], "E_states"), (r["init_stats"][0], "ExxT0"), (r["init_stats"][1], "Ex0"),
+                         (r["pair_stats"][0], "Epair0"), (r["pair_stats"][1], "Epair1"), (r["pair_stats"][2], "Epair2"),
+                         (r["node_stats"][0], "Enode_diagxx"), (r["node_stats"][1], "Enode_x"),
+                         (r["node_hmm"], "node_hmm")):
+            assert G.rel(got, g["opt_" + key][b]) < 1e-8, key
+        # the Python twin's convention (lds_inference.py:62-63) adds the init potential's 4th entry
+        r2 = slds_numpy.optimize_local_meanfield(glob, (g["node_J"][b], g["node_h"][b]), g["opt_init_eps"][b])
+        if r2["iters"] == r["iters"]:
+            assert abs(r2["lds_vlb"] - (g["opt_lds_vlb"][b] + g["opt_init_b"][b])) < 1e-8 * abs(g["opt_lds_vlb"][b])
