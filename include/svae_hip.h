@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SVAE_HIP_ABI_VERSION 5   /* 5: + svae_lds_set_prod_max_b; 4: + svae_slds_lds_meanfield_f64, svae_gmm_mw_*, svae_lds_global_step_f64, svae_lds_natgrad_f64, svae_lds_tile_vjp_f64; 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
+#define SVAE_HIP_ABI_VERSION 6   /* 6: per-call `options` word replaces the process-global svae_lds_set_* selectors (re-entrant library); 5: + svae_lds_set_prod_max_b; 4: + svae_slds_lds_meanfield_f64, svae_gmm_mw_*, svae_lds_global_step_f64, svae_lds_natgrad_f64, svae_lds_tile_vjp_f64; 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
 #define SVAE_LDS_MAX_N 15   /* register/DPP path: one 16-lane row per sequence, n+1 <= 16 */
 #define SVAE_LDS_TILE_MAX_N 64   /* 16 <= n <= 64: LDS-tiled MFMA path (E-step only: keep must be 0) */
 
@@ -73,7 +73,7 @@ size_t svae_lds_workspace_bytes_ex(int B, int T, int n, int inhomog, int pair_ba
  *       E_node_diagxx (B,T,n) = diag E[x_t x_t'],   E_node_x (B,T,n) = E[x_t]
  *       info (1) int32, must be zeroed by the caller (or by a previous successful call)
  */
-int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int keep,
+int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int keep, unsigned options,
                        const double* init_J, const double* init_h, const double* init_logZ,
                        const double* J11, const double* J12, const double* J22,
                        const double* logZ_pair,
@@ -89,34 +89,39 @@ int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int k
  *       optional (NULL = not wanted):  J_pred, J_filt (B,T,n,n) = -1/2 precision,  h_pred, h_filt (B,T,n).
  * The workspace afterwards holds what svae_lds_sample_f64 needs: filter + sampler without the smoother is
  * cython_natural_lds_sample (lds_inference.py:260-264). */
-int svae_lds_filter_f64(int B, int T, int n, int inhomog, int pair_batched,
+int svae_lds_filter_f64(int B, int T, int n, int inhomog, int pair_batched, unsigned options,
                         const double* init_J, const double* init_h, const double* init_logZ,
                         const double* J11, const double* J12, const double* J22, const double* logZ_pair,
                         const double* node_J, const double* node_h, const double* node_logZ,
                         double* lognorm, double* J_pred, double* h_pred, double* J_filt, double* h_filt,
                         int32_t* info, void* workspace, size_t ws_bytes, void* stream);
 
-/* Kernel selection for svae_lds_estep_f64 (n <= SVAE_LDS_MAX_N).  With keep != 0, n <= 10, T >= 4 and B <= max_b
- * (svae_lds_set_split_max_b) the call runs TWO kernels side by side, joined by events before it returns to the
+/* `options` word of svae_lds_estep_f64 / svae_lds_filter_f64 / svae_lds_sample_f64 / svae_lds_estep_vjp_ex_f64
+ * (n <= SVAE_LDS_MAX_N; ignored above).  0 = the library's own choice; the bits force one of the kernel variants --
+ * all give the same results up to rounding -- for A/B measurements and for the tests that run every kernel.  The
+ * library keeps NO process-global selection state and reads no environment variables: two host threads / streams /
+ * devices may use different options at the same time.
+ *
+ * Default dispatch of svae_lds_estep_f64: with keep == 0, n <= 10 and T >= 4 the two-ended kernel (block elimination
+ * from both ends of the chain, meeting in the middle: half the serial depth; lean hand-off record).  With keep != 0,
+ * n <= 10, T >= 4 and B <= 1023 the call runs TWO kernels side by side, joined by events before it returns to the
  * caller's stream: the two-ended E-step (statistics, log-normaliser, and the cross moments the VJP reads) and the
- * one-directional filter (hand-off records and LDL' factors for svae_lds_sample_f64 / svae_lds_estep_vjp_f64).
- * With keep == 0, n <= 10 and T >= 4
- * the two-ended kernel runs (block elimination from both ends of the chain, meeting in the middle:
- * half the serial depth; svae_lds_set_twoend: 1 = with the lean hand-off record (default), 2 = with the
- * full record, 0 = off).  Otherwise batches with B <= max_b run
- * the one-directional small-batch variant (one sequence per wavefront, product stages split across
- * the four DPP rows), larger ones the packed kernel (four sequences per wavefront); default 1023,
- * 0 = never.  All three give the same results up to rounding.  Each setter returns the previous
- * value.  Host only (no environment variables are read). */
-int svae_lds_set_split_max_b(int max_b);
-int svae_lds_set_twoend(int mode);
-
-/* svae_lds_sample_f64 (S <= 4) and the sweeps of svae_lds_estep_vjp_f64 run, for batches B <= max_b (default 1024),
- * with PRODUCER wavefronts: the serial loop of a workgroup's four sequences reads its per-step records from an LDS
- * ring that four more wavefronts of the workgroup fill several steps ahead (and, in the first sweep, HELPER
- * wavefronts take the work that does not feed the recursion).  Same results; larger batches hide the latency by
- * occupancy instead.  0 = never.  Returns the previous value. */
-int svae_lds_set_prod_max_b(int max_b);
+ * one-directional filter (hand-off records and LDL' factors for svae_lds_sample_f64 / svae_lds_estep_vjp_f64); the
+ * helper stream and the two events are created once per (device, caller stream).  Otherwise batches with B <= 1023
+ * run the one-directional small-batch variant (one sequence per wavefront, product stages split across the four DPP
+ * rows), larger ones the packed kernel (four sequences per wavefront).
+ * svae_lds_sample_f64 (S <= 4) and the sweeps of svae_lds_estep_vjp_f64 run, for batches B <= 1024, with PRODUCER
+ * wavefronts: the serial loop of a workgroup's sequences reads its per-step records from an LDS ring that more
+ * wavefronts of the workgroup fill several steps ahead (and, in the first sweep, HELPER wavefronts take the work that
+ * does not feed the recursion); larger batches hide the latency by occupancy instead. */
+#define SVAE_OPT_DEFAULT        0x00u
+#define SVAE_OPT_TWOEND_OFF     0x01u   /* never the two-ended kernel (one-directional kernels only) */
+#define SVAE_OPT_TWOEND_FULL    0x02u   /* two-ended kernel with the full hand-off record (no lean record) */
+#define SVAE_OPT_LAYOUT_SPLIT   0x04u   /* one sequence per wavefront whatever B */
+#define SVAE_OPT_LAYOUT_PACKED  0x08u   /* four sequences per wavefront whatever B */
+#define SVAE_OPT_PRODUCERS_ON   0x10u   /* producer / helper wavefronts whatever B */
+#define SVAE_OPT_PRODUCERS_OFF  0x20u   /* never */
+#define SVAE_OPT_ALL            0x3fu   /* (contradictory pairs or unknown bits: the call returns -24) */
 
 /* LDS mean-field step of the SLDS-SVAE coordinate ascent with the mixing of the K per-state parameter sets
  * and the contraction of the pair statistics FUSED into the E-step:
@@ -165,11 +170,13 @@ int svae_slds_lds_meanfield_f64(int B, int rows, int T, int n, int K,
  * (layout [sig (B,T,n,n) | pinv_bar (B,T,n,n) | g_bar (B,T-1,n,n) | c_bar (B,T,n) | xbar (B,T,S,n)],
  * svae_lds_tile_vjp_workspace_doubles); without sample cotangents (g_samples NULL) there is nothing to add.
  * Cotangents: g_lognorm (B); g_E_node_diagxx, g_E_node_x (B,T,n) or NULL; g_E_init (B, n*n+n) or NULL;
- * g_samples (B,T,S,n) or NULL with the samples drawn (S <= 16).  J12 as in svae_lds_estep_vjp_ex_f64. */
+ * g_E_pair (B,T-1,3,n,n) or NULL: of the per-step pair statistics (inhomog only; _compute_stats_grad,
+ * cython_lds_inference.pyx:212-234); g_samples (B,T,S,n) or NULL with the samples drawn (S <= 16).  J12 as in svae_lds_estep_vjp_ex_f64. */
 size_t svae_lds_tile_vjp_workspace_doubles(int B, int T, int n, int S);
 int svae_lds_tile_vjp_f64(int phase, int B, int T, int n, int S, int inhomog, int pair_batched,
                           const double* J12, const double* g_lognorm, const double* g_E_node_diagxx,
-                          const double* g_E_node_x, const double* g_E_init, const double* g_samples,
+                          const double* g_E_node_x, const double* g_E_init, const double* g_E_pair,
+                          const double* g_samples,
                           const double* samples, const double* E_node_x, double* g_node_J, double* g_node_h,
                           const void* handoff_workspace, void* workspace, size_t ws_doubles, void* stream);
 
@@ -232,7 +239,7 @@ int svae_lds_reduce_stats_f64(int B, int n, const double* E_init, const double* 
  *           in makes the op deterministic and parity-testable)
  *   samples (B,T,S,n)
  */
-int svae_lds_sample_f64(int B, int T, int n, int S, const double* eps, double* samples,
+int svae_lds_sample_f64(int B, int T, int n, int S, unsigned options, const double* eps, double* samples,
                         const void* workspace, size_t ws_bytes, void* stream);
 
 /* Bytes of scratch svae_lds_estep_vjp_f64 needs in addition to the E-step workspace. */
@@ -268,7 +275,7 @@ int svae_lds_estep_vjp_f64(int B, int T, int n, int S, const double* J12,
  *   g_E_pair (B,T-1,3,n,n) or NULL (inhomog only): cotangent of the per-step pair statistics; needs
  *     the forward outputs E_pair (B,T-1,3,n,n) and E_node_x (B,T,n) of the E-step call
  * All other arguments as svae_lds_estep_vjp_f64 (which is this with inhomog = 0 and NULLs). */
-int svae_lds_estep_vjp_ex_f64(int B, int T, int n, int S, int inhomog, int pair_batched,
+int svae_lds_estep_vjp_ex_f64(int B, int T, int n, int S, int inhomog, int pair_batched, unsigned options,
                               const double* J12, const double* g_lognorm,
                               const double* g_E_node_diagxx, const double* g_E_node_x,
                               const double* g_E_init, const double* g_E_pair,

@@ -6,8 +6,14 @@ initialised the HIP runtime):  python -m oracle.cpu_baseline --B 512 --T 200 --n
 Times `cython_natural_lds_estep_general` (svae/lds/lds_inference.py:232-237) = the reference's own
 compiled filter + smoother built by oracle/build_ref.py ("reference"), or, when oracle/_ref is
 absent, the NumPy restatement ("port"), per sequence, on a BOUNDED sample of the bench workload
-(same generator and seeds as bench.py rank 0): first on 1 core, then on all host cores with a
-process pool (BLAS pinned to 1 thread per process).  Prints one JSON object.
+(same generator and seeds as bench.py rank 0): first on 1 core, then on all USABLE host cores
+(len(os.sched_getaffinity(0)): what this process may actually run on, not os.cpu_count()) with a
+process pool (BLAS pinned to 1 thread per process) in which every process works until a COMMON
+deadline, so that no straggler sets the wall time and the leg takes `budget` seconds whatever the
+scaling.  Reports, next to the aggregate rate, the mean
+per-process rate and the scaling efficiency = aggregate / (processes x one-core rate): SMT siblings,
+shared caches and memory bandwidth make it far less than 1 on a 256-thread box, and the GPU/CPU
+ratio must be read with it.  Prints one JSON object.
 """
 import argparse
 import json
@@ -36,7 +42,7 @@ def _estep_fn():
 
 
 def _worker(count):
-    """E-step `count` sequences (cycling through the sample); returns elapsed seconds."""
+    """E-step `count` sequences (cycling through the sample); returns (elapsed seconds, count)."""
     natparam, node_J, node_h = _G["data"]
     _, est = _estep_fn()
     T = node_h.shape[1]
@@ -46,7 +52,28 @@ def _worker(count):
     for i in range(count):
         b = i % B
         est(natparam, (node_J[b], node_h[b], z))
-    return time.perf_counter() - t0
+    return time.perf_counter() - t0, count
+
+
+def _worker_until(deadline):
+    """E-step sequences (cycling through the sample) until the system-wide monotonic clock passes `deadline`;
+    returns (busy seconds, count)."""
+    natparam, node_J, node_h = _G["data"]
+    _, est = _estep_fn()
+    z = np.zeros(node_h.shape[1])
+    B = node_h.shape[0]
+    t0, i = time.perf_counter(), 0
+    while time.perf_counter() < deadline:
+        est(natparam, (node_J[i % B], node_h[i % B], z))
+        i += 1
+    return time.perf_counter() - t0, i
+
+
+def usable_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
 
 
 def main():
@@ -56,37 +83,42 @@ def main():
     ap.add_argument("--n", type=int, default=10)
     ap.add_argument("--budget", type=float, default=10.0, help="seconds of wall time per leg")
     a = ap.parse_args()
-    from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials
-    natparam = rand_lds_natparam(a.n, np.random.default_rng(0))
+    from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials, rotation_lds_natparam
+    natparam = (rotation_lds_natparam if a.n > 15 else rand_lds_natparam)(a.n, np.random.default_rng(0))   # = bench.bench_natparam
     node_J, node_h = rand_node_potentials((a.B, a.T, a.n), np.random.default_rng(1000))
     _G["data"] = (natparam, node_J, node_h)
     kind, _ = _estep_fn()
 
     lo = 32 if a.n * a.n * a.T < 100000 else 4        # smallest sample (big sequences cost ~0.1 s each)
     _worker(max(1, lo // 4))                          # warm-up / page-in
-    probe = _worker(lo) / float(lo)                   # seconds per sequence
+    probe = _worker(lo)[0] / float(lo)                # seconds per sequence
     n1 = int(max(lo, min(a.B, a.budget / probe)))
-    dt1 = _worker(n1)
+    dt1 = _worker(n1)[0]
     one_core = n1 / dt1
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     out = {"value": one_core, "unit": "sequences/s", "cores": 1, "kind": kind,
-           "one_core_value": one_core, "host_cores": cores,
+           "one_core_value": one_core, "host_cores": cores, "os_cpu_count": os.cpu_count(),
            "sample": "%d of the %d bench sequences (T=%d, n=%d), 1 core" % (n1, a.B, a.T, a.n)}
     if cores > 1:
         import multiprocessing as mp
-        # (big sequences scale poorly over cores -- measured 6x on 256 -- so their all-core sample stays small)
-        per = lo if lo < 32 else int(max(lo, min(a.B, a.budget * one_core)))
         with mp.get_context("fork").Pool(cores) as pool:      # no GPU runtime in this process
-            pool.map(_worker, [max(1, lo // 8)] * cores)
+            pool.map(_worker, [max(1, lo // 8)] * cores)      # warm every process
             t0 = time.perf_counter()
-            pool.map(_worker, [per] * cores)
+            res = pool.map(_worker_until, [t0 + a.budget] * cores, chunksize=1)   # one task per process
             wall = time.perf_counter() - t0
-        allc = per * cores / wall
+        done = sum(c for _, c in res)
+        busy = sum(dt for dt, _ in res)
+        allc = done / wall
         out["all_cores_value"] = allc
+        out["all_cores"] = {"processes": cores, "sequences": done, "wall_s": wall,
+                            "per_process_value": done / busy,                  # mean rate of a process while it runs
+                            "scaling_efficiency": allc / (cores * one_core)}   # 1.0 = linear in the process count
         if allc > one_core:
             out.update(value=allc, cores=cores,
-                       sample="%d sequences per process x %d processes (one per host core), drawn "
-                              "from the %d bench sequences (T=%d, n=%d)" % (per, cores, a.B, a.T, a.n))
+                       sample="%d sequences in %.1f s over %d processes (one per usable host core, "
+                              "sched_getaffinity; common deadline), drawn from the %d bench sequences (T=%d, n=%d); "
+                              "scaling efficiency %.2f vs one core" % (done, wall, cores, a.B, a.T, a.n,
+                                                                       allc / (cores * one_core)))
     # the "NumPy/autograd path" north_star names (lds_inference.py:223-229): its NumPy restatement
     # (oracle/lds_numpy.py), one core, a few seconds -- reported beside the compiled path above
     from oracle import lds_numpy

@@ -12,9 +12,16 @@ import torch  # noqa: F401  (must precede CDLL: shares torch's HIP runtime)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVAE_AMD_LIB", os.path.join(_HERE, "libsvae_hip.so"))  # env: experiments only
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 LDS_MAX_N = 15        # register/DPP path (E-step, sampler, VJP)
 LDS_TILE_MAX_N = 64   # LDS-tiled MFMA path (E-step only)
+
+# per-call `options` word of the LDS entry points (include/svae_hip.h, SVAE_OPT_*): 0 = the library's choice
+OPT_DEFAULT, OPT_TWOEND_OFF, OPT_TWOEND_FULL = 0x00, 0x01, 0x02
+OPT_LAYOUT_SPLIT, OPT_LAYOUT_PACKED, OPT_PRODUCERS_ON, OPT_PRODUCERS_OFF = 0x04, 0x08, 0x10, 0x20
+# names used by tests / tools / bench.py --kernel for the E-step kernel families
+KERNEL_OPTIONS = {"auto": OPT_DEFAULT, "twoend": OPT_DEFAULT, "twoend_full": OPT_TWOEND_FULL,
+                  "split": OPT_TWOEND_OFF | OPT_LAYOUT_SPLIT, "packed": OPT_TWOEND_OFF | OPT_LAYOUT_PACKED}
 
 _c_double_p = ctypes.c_void_p   # raw device pointers travel as integers
 _c_int_p = ctypes.c_void_p
@@ -24,12 +31,9 @@ SIGNATURES = {
     "svae_hip_abi_version": (ctypes.c_int, []),
     "svae_lds_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
     "svae_lds_workspace_bytes_ex": (ctypes.c_size_t, [ctypes.c_int] * 5),
-    "svae_lds_set_split_max_b": (ctypes.c_int, [ctypes.c_int]),
-    "svae_lds_set_twoend": (ctypes.c_int, [ctypes.c_int]),
-    "svae_lds_set_prod_max_b": (ctypes.c_int, [ctypes.c_int]),
-    "svae_lds_estep_f64": (ctypes.c_int, [ctypes.c_int] * 6 + [_c_double_p] * 15
+    "svae_lds_estep_f64": (ctypes.c_int, [ctypes.c_int] * 6 + [ctypes.c_uint] + [_c_double_p] * 15
                            + [_c_int_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
-    "svae_lds_filter_f64": (ctypes.c_int, [ctypes.c_int] * 5 + [_c_double_p] * 15
+    "svae_lds_filter_f64": (ctypes.c_int, [ctypes.c_int] * 5 + [ctypes.c_uint] + [_c_double_p] * 15
                             + [_c_int_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "svae_slds_lds_meanfield_lds_bytes": (ctypes.c_size_t, [ctypes.c_int] * 2),
     "svae_slds_lds_meanfield_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
@@ -42,10 +46,10 @@ SIGNATURES = {
     "svae_lds_estep_vjp_f64": (ctypes.c_int, [ctypes.c_int] * 4 + [_c_double_p] * 9
                                + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
                                   ctypes.c_void_p]),
-    "svae_lds_estep_vjp_ex_f64": (ctypes.c_int, [ctypes.c_int] * 6 + [_c_double_p] * 13
+    "svae_lds_estep_vjp_ex_f64": (ctypes.c_int, [ctypes.c_int] * 6 + [ctypes.c_uint] + [_c_double_p] * 13
                                   + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
                                      ctypes.c_void_p]),
-    "svae_lds_sample_f64": (ctypes.c_int, [ctypes.c_int] * 4 + [_c_double_p] * 2
+    "svae_lds_sample_f64": (ctypes.c_int, [ctypes.c_int] * 4 + [ctypes.c_uint] + [_c_double_p] * 2
                             + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "svae_hmm_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
     "svae_hmm_estep_f64": (ctypes.c_int, [ctypes.c_int] * 4 + [_c_double_p] * 7
@@ -54,7 +58,7 @@ SIGNATURES = {
                                + [ctypes.c_double, ctypes.c_int] + [_c_double_p] * 8
                                + [_c_int_p] * 3 + [ctypes.c_void_p]),
     "svae_lds_tile_vjp_workspace_doubles": (ctypes.c_size_t, [ctypes.c_int] * 4),
-    "svae_lds_tile_vjp_f64": (ctypes.c_int, [ctypes.c_int] * 7 + [_c_double_p] * 10
+    "svae_lds_tile_vjp_f64": (ctypes.c_int, [ctypes.c_int] * 7 + [_c_double_p] * 11
                               + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "svae_lds_tile_noise_f64": (ctypes.c_int, [ctypes.c_int] * 5 + [_c_double_p] * 2
                                 + [ctypes.c_void_p, ctypes.c_void_p, _c_int_p, ctypes.c_void_p]),

@@ -693,7 +693,10 @@ extern "C" int svae_gmm_mw_fixed_point_f64(int T, int N, int K,
   int per_cu = 0, dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess ||
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, svae::GMM_MW_BLOCK, 0) != hipSuccess) return -50;
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, svae::GMM_MW_BLOCK, 0) != hipSuccess) {
+    (void)hipGetLastError();      // -50 = "use the per-sweep launches instead": leave no sticky error behind for them
+    return -50;
+  }
   int G = svae::gmm_mw_grid(T);
   const int cap = per_cu * cus;
   if (cap < 1) return -50;
@@ -701,7 +704,10 @@ extern "C" int svae_gmm_mw_fixed_point_f64(int T, int N, int K,
   // the counters section doubles as the statistics kernel's ticket: zero it (kl_hist needs no reset here)
   if (hipMemsetAsync(l.counters, 0, (size_t)(max_iter + 3) * sizeof(int32_t), s) != hipSuccess) return -1000;
   void* params[] = {(void*)&m};
-  if (hipLaunchCooperativeKernel(kern, dim3(G), dim3(svae::GMM_MW_BLOCK), params, 0, s) != hipSuccess) return -50;
+  if (hipLaunchCooperativeKernel(kern, dim3(G), dim3(svae::GMM_MW_BLOCK), params, 0, s) != hipSuccess) {
+    (void)hipGetLastError();
+    return -50;
+  }
   hipLaunchKernelGGL(svae::gmm_mw_stats_kernel, dim3(svae::gmm_mw_stats_grid(T)), dim3(svae::GMM_MW_BLOCK), 0, s,
                      a, N + 2, l.spart, l.counters + max_iter + 2);
   return hipGetLastError() == hipSuccess ? 0 : -1000;

@@ -7,6 +7,7 @@
 
 #include "../../include/svae_hip.h"
 #include "lds_args.hpp"
+#include "per_device.hpp"
 
 extern "C" {
 #define SVAE_DECL_(NN) int svae_lds_launch_n##NN(const svae::LdsArgs*, int, void*); \
@@ -66,33 +67,22 @@ __global__ __launch_bounds__(256) void lds_reduce_stats_kernel(int B, int n, con
 
 extern "C" {
 
-// Kernel selection for keep == 0 (no sampler / VJP hand-off), n <= 10, T >= 4: the two-ended kernel
-// (lds_estep_twoend.hpp: one sequence per wavefront, both elimination chains in one instruction
-// stream).  Otherwise batches up to g_split_max_b run the one-directional latency variant (one sequence
-// per wavefront, product stages split across the DPP rows: lds_estep_split.hpp), larger ones the
-// packed kernel (four sequences per wavefront).  Measured crossover split/packed on MI355X
-// (T=200, n=10): B ~ 1024 (one wavefront per SIMD).  svae_lds_set_split_max_b / svae_lds_set_twoend
-// exist for A/B measurements and for the tests that run every kernel.
-static int g_split_max_b = 1023;
-static int g_twoend = 1;
-static int g_prod_max_b = 1024;
-
-int svae_lds_set_prod_max_b(int max_b) {
-  const int old = g_prod_max_b;
-  g_prod_max_b = max_b < 0 ? 0 : max_b;
-  return old;
-}
-
-int svae_lds_set_split_max_b(int max_b) {
-  const int old = g_split_max_b;
-  g_split_max_b = max_b < 0 ? 0 : max_b;
-  return old;
-}
-
-int svae_lds_set_twoend(int mode) {
-  const int old = g_twoend;
-  g_twoend = (mode == 1 || mode == 2) ? mode : 0;
-  return old;
+// Kernel selection (include/svae_hip.h, SVAE_OPT_*): keep == 0, n <= 10, T >= 4 -> the two-ended kernel
+// (lds_estep_twoend.hpp: one sequence per wavefront, both elimination chains in one instruction stream).
+// Otherwise batches up to 1023 run the one-directional latency variant (one sequence per wavefront, product
+// stages split across the DPP rows: lds_estep_split.hpp), larger ones the packed kernel (four sequences per
+// wavefront).  Measured crossover split/packed on MI355X (T=200, n=10): B ~ 1024 (one wavefront per SIMD).
+// The selection is a function of the call's arguments only: the library holds no process-global state.
+struct Selection { int twoend; bool split; int prod_max_b; };
+static bool decode_options(unsigned options, int B, Selection* s) {
+  if (options & ~SVAE_OPT_ALL) return false;
+  if ((options & SVAE_OPT_TWOEND_OFF) && (options & SVAE_OPT_TWOEND_FULL)) return false;
+  if ((options & SVAE_OPT_LAYOUT_SPLIT) && (options & SVAE_OPT_LAYOUT_PACKED)) return false;
+  if ((options & SVAE_OPT_PRODUCERS_ON) && (options & SVAE_OPT_PRODUCERS_OFF)) return false;
+  s->twoend = (options & SVAE_OPT_TWOEND_OFF) ? 0 : (options & SVAE_OPT_TWOEND_FULL) ? 2 : 1;
+  s->split = (options & SVAE_OPT_LAYOUT_SPLIT) ? true : (options & SVAE_OPT_LAYOUT_PACKED) ? false : B <= 1023;
+  s->prod_max_b = (options & SVAE_OPT_PRODUCERS_ON) ? 0x7fffffff : (options & SVAE_OPT_PRODUCERS_OFF) ? 0 : 1024;
+  return true;
 }
 
 int svae_hip_abi_version(void) { return SVAE_HIP_ABI_VERSION; }
@@ -120,7 +110,7 @@ size_t svae_lds_workspace_bytes(int B, int T, int n) {
   return (main_ws_doubles(B, T, n) + factor_ws_doubles(B, T, n) + cross_ws_doubles(B, T, n)) * sizeof(double);
 }
 
-int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int keep,
+int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int keep, unsigned options,
                        const double* init_J, const double* init_h, const double* init_logZ,
                        const double* J11, const double* J12, const double* J22,
                        const double* logZ_pair,
@@ -146,7 +136,10 @@ int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int k
   if (!E_node_x) return -20;
   if (!info) return -21;
   if (!workspace || ws_bytes < svae_lds_workspace_bytes_ex(B, T, n, inhomog, pair_batched)) return -22;
+  Selection sel;
+  if (!decode_options(options, B, &sel)) return -24;
   if (B == 0) return 0;
+  const int twoend = sel.twoend;
 
   svae::LdsArgs a;
   a.B = B; a.T = T;
@@ -165,21 +158,18 @@ int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int k
     a.ws2 = a.ws3 = nullptr;
     return svae_lds_launch_tile(&a, n, inhomog, stream);
   }
-  const bool split = B <= g_split_max_b;
-  if (g_twoend && keep && split && n <= svae::TE_MAX_N && T >= svae::TE_MIN_T) {
+  const bool split = sel.split;
+  if (twoend && keep && split && n <= svae::TE_MAX_N && T >= svae::TE_MIN_T) {
     // Small batch, hand-off kept: the statistics (and the cross moments the VJP reads: posterior moments, the same
     // whichever way the chain is eliminated) come from the two-ended kernel, while the one-directional FILTER --
     // whose factorisation defines the sampler's eps -> sample map and the records the sweeps differentiate --
     // runs CONCURRENTLY on a second stream, on the SIMDs the small batch leaves idle (512 + 512 wavefronts on
     // 1024 SIMDs at B = 512): 0.48 -> 0.25 ms.  Fork / join by events: the caller's stream sees one operation.
-    static hipStream_t aux = nullptr;
-    static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    if (!aux) {
-      if (hipStreamCreateWithFlags(&aux, hipStreamNonBlocking) != hipSuccess ||
-          hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
-          hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) return -1002;
-    }
     hipStream_t us = (hipStream_t)stream;
+    svae::ForkJoin fj;
+    if (!svae::fork_join_for(us, &fj)) return -1002;
+    hipStream_t aux = fj.aux;
+    hipEvent_t ev_fork = fj.fork, ev_join = fj.join;
     svae::LdsArgs f = a;                       // the filter: one-directional layout at the start of the workspace
     f.ws2 = (double*)workspace + main_ws_doubles(B, T, n);
     f.ws3 = nullptr;
@@ -206,9 +196,9 @@ int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int k
     if (hipEventRecord(ev_join, aux) != hipSuccess || hipStreamWaitEvent(us, ev_join, 0) != hipSuccess) return -1002;
     return rc ? rc : rc2;
   }
-  if (g_twoend && !keep && n <= svae::TE_MAX_N && T >= svae::TE_MIN_T) {
+  if (twoend && !keep && n <= svae::TE_MAX_N && T >= svae::TE_MIN_T) {
     switch (n) {
-#define SVAE_CASE_(NN) case NN: return svae_lds_launch_twoend_n##NN(&a, inhomog, g_twoend == 1 && !inhomog, stream);
+#define SVAE_CASE_(NN) case NN: return svae_lds_launch_twoend_n##NN(&a, inhomog, twoend == 1 && !inhomog, stream);
 #define SVAE_CASE(NN) SVAE_CASE_(NN)
 #ifdef SVAE_ONLY_N
       SVAE_CASE(SVAE_ONLY_N)
@@ -237,7 +227,7 @@ int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int k
   return -3;
 }
 
-int svae_lds_filter_f64(int B, int T, int n, int inhomog, int pair_batched,
+int svae_lds_filter_f64(int B, int T, int n, int inhomog, int pair_batched, unsigned options,
                         const double* init_J, const double* init_h, const double* init_logZ,
                         const double* J11, const double* J12, const double* J22, const double* logZ_pair,
                         const double* node_J, const double* node_h, const double* node_logZ,
@@ -256,7 +246,10 @@ int svae_lds_filter_f64(int B, int T, int n, int inhomog, int pair_batched,
   if (!lognorm) return -16;
   if (!info) return -21;
   if (!workspace || ws_bytes < svae_lds_workspace_bytes(B, T, n)) return -22;
+  Selection sel;
+  if (!decode_options(options, B, &sel)) return -24;
   if (B == 0) return 0;
+  const int twoend = sel.twoend;
   svae::LdsArgs a;
   a.B = B; a.T = T;
   a.init_J = init_J; a.init_h = init_h; a.init_logZ = init_logZ;
@@ -271,10 +264,10 @@ int svae_lds_filter_f64(int B, int T, int n, int inhomog, int pair_batched,
   a.msg_Jp = J_pred; a.msg_hp = h_pred; a.msg_Jf = J_filt; a.msg_hf = h_filt;
   a.mix_w = nullptr; a.mix_out = nullptr; a.seq_index = nullptr; a.mix_K = 0;
   // small batches without message outputs: one sequence per wavefront (0.62 -> 0.24 ms at B = 512, T = 200, n = 10)
-  const bool fsplit = B <= g_split_max_b && !J_pred && !h_pred && !J_filt && !h_filt;
+  const bool fsplit = sel.split && !J_pred && !h_pred && !J_filt && !h_filt;
   switch (n) {
 #define SVAE_CASE_(NN) case NN: return !fsplit ? svae_lds_launch_filter_n##NN(&a, inhomog, stream)          \
-                                       : (NN <= svae::TE_MAX_N && g_twoend) ? svae_lds_launch_filter_1r_n##NN(&a, inhomog, stream) \
+                                       : (NN <= svae::TE_MAX_N && twoend) ? svae_lds_launch_filter_1r_n##NN(&a, inhomog, stream) \
                                        : svae_lds_launch_filter_split_n##NN(&a, inhomog, stream);
 #define SVAE_CASE(NN) SVAE_CASE_(NN)
 #ifdef SVAE_ONLY_N
@@ -369,7 +362,7 @@ int svae_lds_reduce_stats_f64(int B, int n, const double* E_init, const double* 
 
 }  // extern "C"
 
-extern "C" int svae_lds_sample_f64(int B, int T, int n, int S, const double* eps, double* samples,
+extern "C" int svae_lds_sample_f64(int B, int T, int n, int S, unsigned options, const double* eps, double* samples,
                                    const void* workspace, size_t ws_bytes, void* stream) {
   if (B < 0) return -1;
   if (T < 1) return -2;
@@ -378,10 +371,12 @@ extern "C" int svae_lds_sample_f64(int B, int T, int n, int S, const double* eps
   if (!eps) return -5;
   if (!samples) return -6;
   if (!workspace || ws_bytes < svae_lds_workspace_bytes(B, T, n)) return -7;
+  Selection sel;
+  if (!decode_options(options, B, &sel)) return -24;
   if (B == 0) return 0;
   svae::SampleArgs a;
   a.B = B; a.T = T; a.S = S; a.eps = eps; a.samples = samples;
-  a.prod_max_b = g_prod_max_b;
+  a.prod_max_b = sel.prod_max_b;
   a.ws = (const double*)workspace;
   a.ws2 = (const double*)workspace + main_ws_doubles(B, T, n);
   switch (n) {
@@ -405,7 +400,7 @@ extern "C" size_t svae_lds_vjp_workspace_bytes(int B, int T, int n) {
   return (size_t)B * T * svae::vjp_step_doubles(n) * sizeof(double);
 }
 
-extern "C" int svae_lds_estep_vjp_ex_f64(int B, int T, int n, int S, int inhomog, int pair_batched,
+extern "C" int svae_lds_estep_vjp_ex_f64(int B, int T, int n, int S, int inhomog, int pair_batched, unsigned options,
                                          const double* J12, const double* g_lognorm,
                                          const double* g_E_node_diagxx, const double* g_E_node_x,
                                          const double* g_E_init, const double* g_E_pair,
@@ -427,10 +422,12 @@ extern "C" int svae_lds_estep_vjp_ex_f64(int B, int T, int n, int S, int inhomog
   if (!g_node_h) return -13;
   if (!workspace || ws_bytes < svae_lds_workspace_bytes(B, T, n)) return -14;
   if (!vjp_workspace || vjp_ws_bytes < svae_lds_vjp_workspace_bytes(B, T, n)) return -16;
+  Selection sel;
+  if (!decode_options(options, B, &sel)) return -24;
   if (B == 0) return 0;
   svae::VjpArgs a;
   a.B = B; a.T = T; a.S = g_samples ? S : 0;
-  a.prod_max_b = g_prod_max_b;
+  a.prod_max_b = sel.prod_max_b;
   a.J12 = J12; a.g_lognorm = g_lognorm; a.g_diagxx = g_E_node_diagxx; a.g_x = g_E_node_x;
   a.pair_t_stride = inhomog ? (long)n * n : 0;
   a.pair_seq_stride = pair_batched ? (long)(T - 1) * n * n : 0;
@@ -464,7 +461,7 @@ extern "C" int svae_lds_estep_vjp_f64(int B, int T, int n, int S, const double* 
                                       double* g_node_J, double* g_node_h,
                                       const void* workspace, size_t ws_bytes,
                                       void* vjp_workspace, size_t vjp_ws_bytes, void* stream) {
-  const int rc = svae_lds_estep_vjp_ex_f64(B, T, n, S, 0, 0, J12, g_lognorm, g_E_node_diagxx, g_E_node_x,
+  const int rc = svae_lds_estep_vjp_ex_f64(B, T, n, S, 0, 0, SVAE_OPT_DEFAULT, J12, g_lognorm, g_E_node_diagxx, g_E_node_x,
                                            nullptr, nullptr, g_samples, eps, samples, nullptr, nullptr,
                                            g_node_J, g_node_h, workspace, ws_bytes, vjp_workspace,
                                            vjp_ws_bytes, stream);

@@ -32,6 +32,7 @@
 #include "../../include/svae_hip.h"
 #include "dpp.hpp"
 #include "lds_args.hpp"
+#include "per_device.hpp"
 
 #ifndef SVAE_TILE_SGB
 #define SVAE_TILE_SGB 5
@@ -750,12 +751,8 @@ static int launch_tile(const LdsArgs& a, int n, int inhomog, hipStream_t s) {
     if (hipGetLastError() != hipSuccess) return -1000;
   }
   auto go = [&](auto kern) {
-    static bool attr_set = false;     // per instantiation
-    if (!attr_set) {
-      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return -1001;
-      attr_set = true;
-    }
+    static LdsGrant grant;            // per instantiation, per device inside
+    if (!grant.ensure((const void*)kern, (long)lds)) return -1001;
     hipLaunchKernelGGL(kern, dim3(a.B), dim3(256), lds, s, a, n, (const double*)pk, batched);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
   };

@@ -30,6 +30,7 @@
 // factorisation, whose LDL' factors define the eps -> sample map), 4 <= T, n <= 10.
 #pragma once
 #include "lds_estep_kernel.hpp"
+#include "per_device.hpp"
 #include "gj1r_gen.hpp"
 #include "lds_estep_twoend_s4.hpp"
 
@@ -953,13 +954,9 @@ static int launch_estep_twoend_mix(const LdsArgs& a, hipStream_t stream) {
   if constexpr (N <= TE_MAX_N) {
     const long bytes = te_mix_lds_bytes(N, a.mix_K);
     if (a.mix_K < 1 || a.mix_K > TE_MIX_MAX_K || bytes > TE_MIX_MAX_LDS) return -30;
-    static long granted = 0;               // largest dynamic-LDS size requested so far for this instantiation
+    static LdsGrant grant;                 // largest dynamic-LDS size granted so far (this instantiation, per device)
     auto kern = lds_estep_twoend_kernel<N, true, false, true>;
-    if (bytes > granted) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)bytes) != hipSuccess) return -31;
-      granted = bytes;
-    }
+    if (!grant.ensure(reinterpret_cast<const void*>(kern), bytes)) return -31;
     constexpr int W = 8;
     dim3 grid((a.B + W - 1) / W), block(64 * W);
     hipLaunchKernelGGL(kern, grid, block, (size_t)bytes, stream, a);

@@ -14,6 +14,7 @@
 #include <stdint.h>
 
 #include "../../include/svae_hip.h"
+#include "per_device.hpp"
 
 namespace svae {
 
@@ -337,14 +338,10 @@ extern "C" int svae_lds_global_step_f64(int n, const double* niw, const double* 
   a.J11 = J11; a.J12 = J12; a.J22 = J22; a.logZ_pair = logZ_pair;
   a.niw_es = niw_expectedstats; a.global_kl = global_kl; a.info = info;
   const size_t lds = (size_t)(4 * n * n + 4 * n + 3 * svae::GL_BLOCK) * sizeof(double);
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(svae::lds_global_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)((4 * svae::GL_MAX_N * svae::GL_MAX_N + 4 * svae::GL_MAX_N + 3 * svae::GL_BLOCK) *
-                                  sizeof(double))) != hipSuccess) return -1001;
-    attr = true;
-  }
+  static svae::LdsGrant grant;
+  if (!grant.ensure(reinterpret_cast<const void*>(svae::lds_global_kernel),
+                    (long)((4 * svae::GL_MAX_N * svae::GL_MAX_N + 4 * svae::GL_MAX_N + 3 * svae::GL_BLOCK) * sizeof(double))))
+    return -1001;
   // (n = 10: 80 us with staged pivot rows and both passes in one workgroup; 62 us with register-resident elements
   //  and one barrier per pivot; one workgroup per pass: see DESIGN.md 4c.  It does not depend on the minibatch.)
   const bool with_kl = global_kl && prior_niw;

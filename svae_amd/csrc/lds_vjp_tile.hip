@@ -18,6 +18,7 @@
 #include <type_traits>
 
 #include "../../include/svae_hip.h"
+#include "per_device.hpp"
 
 namespace svae {
 
@@ -37,6 +38,7 @@ struct TileVjpArgs {
   const double* g_lognorm;                // (B)
   const double* g_dxx; const double* g_x; // (B,T,n) or nullptr
   const double* g_E_init;                 // (B, n*n+n) or nullptr
+  const double* g_E_pair;                 // (B,T-1,3,n,n) or nullptr: cotangents of the per-step pair statistics
   double* sig; double* pinv_bar; double* g_bar; double* c_bar; double* xbar;   // VJP workspace
   double* g_node_J; double* g_node_h;
 };
@@ -243,6 +245,32 @@ __global__ __launch_bounds__(256) void tile_vjp_phase1(const TileVjpArgs a) {
         mb[i] += s;
       }
     }
+    if (a.g_E_pair) {
+      // per-step pair statistics (_compute_stats_grad, cython_lds_inference.pyx:212-234): E_pair[t] = (E x_t x_t',
+      // E x_t x_{t+1}', E x_{t+1} x_{t+1}').  Node t is the FIRST node of pair t (cotangents A0, A1) and the SECOND of
+      // pair t-1 (A2', A1'):  Sigma_bar_t += sym(A0) + sym(A2'),  m_bar_t += (A0 + A0' + A2' + A2'') m_t + A1 m_{t+1}
+      // + A1'' m_{t-1}.  (The covariance part of the cross statistic, G_t Sigma_{t+1}, is handled below.)
+      __syncthreads();
+      const double* A = t < T - 1 ? a.g_E_pair + ((long)b * (T - 1) + t) * 3 * n * n : nullptr;
+      const double* Ap = t > 0 ? a.g_E_pair + ((long)b * (T - 1) + t - 1) * 3 * n * n : nullptr;
+      for (int e = threadIdx.x; e < n * n; e += 256) {
+        const int r = e / n, c = e % n;
+        double v = 0.0;
+        if (A) v += 0.5 * (A[r * n + c] + A[c * n + r]);
+        if (Ap) v += 0.5 * (Ap[2 * n * n + r * n + c] + Ap[2 * n * n + c * n + r]);
+        L3[r * TV_LD + c] += v;
+      }
+      const double* mnx = a.E_node_x + (bt + 1) * n;
+      const double* mpv = a.E_node_x + (bt - 1) * n;
+      for (int i = threadIdx.x; i < n; i += 256) {
+        double s = 0.0;
+        for (int j = 0; j < n; ++j) {
+          if (A) s += (A[i * n + j] + A[j * n + i]) * mt[j] + A[n * n + i * n + j] * mnx[j];
+          if (Ap) s += (Ap[2 * n * n + i * n + j] + Ap[2 * n * n + j * n + i]) * mt[j] + Ap[n * n + j * n + i] * mpv[j];
+        }
+        mb[i] += s;
+      }
+    }
     for (int e = threadIdx.x; e < S * n; e += 256) {
       const int s_ = e / n, i = e % n;
       xb[s_ * 64 + i] += a.g_samples[(bt * a.S + s_) * n + i];
@@ -269,8 +297,17 @@ __global__ __launch_bounds__(256) void tile_vjp_phase1(const TileVjpArgs a) {
     __syncthreads();
     acc_zero(acc);
     gemm_nn(L1, L2, n4, ty, tx, acc);                                           // SG Sigma_{t+1}
+    Acc accp;                                                                    // A1 Sigma_{t+1} (pair-statistic cotangent)
+    acc_zero(accp);
+    if (a.g_E_pair) {
+      // E x_t x_{t+1}' = G_t Sigma_{t+1} + m_t m_{t+1}':  G_bar += A1 Sigma_{t+1};  Sigma_bar_{t+1} += sym(G_t' A1).
+      // Sigma_bar (L3) has been consumed (SG in L1, pinv_bar stored): A1 takes its buffer until the new one is formed.
+      load_mat<false>(L3, a.g_E_pair + (((long)b * (T - 1) + t) * 3 + 1) * n * n, n, n, n4, 1.0);
+      __syncthreads();
+      gemm_nn(L3, L2, n4, ty, tx, accp);
+    }
     {
-      // G_bar = 2 SG Sigma_{t+1} + m_bar m_{t+1}' + sum_s x_bar_s x_{t+1,s}'
+      // G_bar = 2 SG Sigma_{t+1} + A1 Sigma_{t+1} + m_bar m_{t+1}' + sum_s x_bar_s x_{t+1,s}'
       const double* mn = a.E_node_x + (bt + 1) * n;
       double* gb = a.g_bar + ((long)b * (T - 1) + t) * n * n;
       if (4 * ty < n4 && 4 * tx < n4) {
@@ -280,7 +317,7 @@ __global__ __launch_bounds__(256) void tile_vjp_phase1(const TileVjpArgs a) {
           for (int j = 0; j < 4; ++j) {
             const int r = 4 * ty + i, c = 4 * tx + j;
             if (r < n && c < n) {
-              double v = 2.0 * acc.v[i][j] + mb[r] * mn[c];
+              double v = 2.0 * acc.v[i][j] + accp.v[i][j] + mb[r] * mn[c];
               for (int s_ = 0; s_ < S; ++s_) v = __builtin_fma(xb[s_ * 64 + r], a.samples[((bt + 1) * a.S + s_) * n + c], v);
               gb[r * n + c] = v;
             }
@@ -302,6 +339,7 @@ __global__ __launch_bounds__(256) void tile_vjp_phase1(const TileVjpArgs a) {
     __syncthreads();
     acc_zero(acc);
     gemm_nn(L2, L1, n4, ty, tx, acc);                                           // G' SG
+    if (a.g_E_pair) gemm_nn(L2, L3, n4, ty, tx, acc);                           // + G' A1 (symmetrised below)
     __syncthreads();
     store_block(L3, acc, ty, tx, n4, false);
     symmetrize_lds(L3, n4);
@@ -617,7 +655,8 @@ extern "C" size_t svae_lds_tile_vjp_workspace_doubles(int B, int T, int n, int S
 // of the noise factor into pinv_bar (it is batched over all (sequence, step) pairs and needs xbar).
 extern "C" int svae_lds_tile_vjp_f64(int phase, int B, int T, int n, int S, int inhomog, int pair_batched,
                                      const double* J12, const double* g_lognorm, const double* g_E_node_diagxx,
-                                     const double* g_E_node_x, const double* g_E_init, const double* g_samples,
+                                     const double* g_E_node_x, const double* g_E_init, const double* g_E_pair,
+                                     const double* g_samples,
                                      const double* samples, const double* E_node_x, double* g_node_J, double* g_node_h,
                                      const void* handoff_workspace, void* workspace, size_t ws_doubles, void* stream) {
   if (phase < 0 || phase > 2) return -1;
@@ -628,6 +667,7 @@ extern "C" int svae_lds_tile_vjp_f64(int phase, int B, int T, int n, int S, int 
   if (pair_batched && !inhomog) return -6;
   if (T > 1 && !J12) return -8;
   if (!g_lognorm) return -9;
+  if (g_E_pair && !inhomog) return -13;          /* per-step pair statistics only (as svae_lds_estep_vjp_ex_f64) */
   if (g_samples && !samples) return -14;
   if (!E_node_x) return -15;
   if (!g_node_J || !g_node_h) return -16;
@@ -639,7 +679,7 @@ extern "C" int svae_lds_tile_vjp_f64(int phase, int B, int T, int n, int S, int 
   a.ws = (const double*)handoff_workspace;
   a.J12 = J12; a.pair_t_stride = inhomog ? (long)n * n : 0; a.pair_seq_stride = pair_batched ? (long)(T - 1) * n * n : 0;
   a.E_node_x = E_node_x; a.samples = samples; a.g_samples = g_samples; a.g_lognorm = g_lognorm;
-  a.g_dxx = g_E_node_diagxx; a.g_x = g_E_node_x; a.g_E_init = g_E_init;
+  a.g_dxx = g_E_node_diagxx; a.g_x = g_E_node_x; a.g_E_init = g_E_init; a.g_E_pair = T > 1 ? g_E_pair : nullptr;
   double* w = (double*)workspace;
   a.sig = w; w += (size_t)B * T * n * n;
   a.pinv_bar = w; w += (size_t)B * T * n * n;
@@ -653,14 +693,11 @@ extern "C" int svae_lds_tile_vjp_f64(int phase, int B, int T, int n, int S, int 
   const size_t lds12 = (size_t)(4 * svae::tv_mat(n4) + 192 + 3 * svae::TV_MAX_S * 64) * sizeof(double);
   const size_t lds0_max = (size_t)3 * svae::tv_mat(64) * sizeof(double);
   const size_t lds12_max = (size_t)(4 * svae::tv_mat(64) + 192 + 3 * svae::TV_MAX_S * 64) * sizeof(double);
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(svae::tile_vjp_phase0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0_max) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(svae::tile_vjp_phase1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds12_max) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(svae::tile_vjp_phase2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds12_max) != hipSuccess)
-      return -1001;
-    attr = true;
-  }
+  static svae::LdsGrant grant0, grant1, grant2;
+  if (!grant0.ensure(reinterpret_cast<const void*>(svae::tile_vjp_phase0), (long)lds0_max) ||
+      !grant1.ensure(reinterpret_cast<const void*>(svae::tile_vjp_phase1), (long)lds12_max) ||
+      !grant2.ensure(reinterpret_cast<const void*>(svae::tile_vjp_phase2), (long)lds12_max))
+    return -1001;
   if (phase == 0) hipLaunchKernelGGL(svae::tile_vjp_phase0, dim3(B), dim3(256), lds0, s, a);
   else if (phase == 1) hipLaunchKernelGGL(svae::tile_vjp_phase1, dim3(B), dim3(256), lds12, s, a);
   else hipLaunchKernelGGL(svae::tile_vjp_phase2, dim3(B), dim3(256), lds12, s, a);
@@ -711,11 +748,8 @@ extern "C" int svae_lds_tile_noise_f64(int mode, int B, int T, int n, int S, con
     constexpr int NC = decltype(nc)::value, MD = decltype(md)::value;
     const size_t lds = (size_t)svae::CholCfg<NC>::LDS_DOUBLES * sizeof(double);
     auto kern = svae::tile_chol_kernel<NC, MD>;
-    static bool attr = false;               // (one flag per instantiation of this lambda)
-    if (!attr && lds > 64 * 1024) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1001;
-      attr = true;
-    }
+    static svae::LdsGrant grant;            // (one per instantiation of this lambda, per device inside)
+    if (lds > 64 * 1024 && !grant.ensure(reinterpret_cast<const void*>(kern), (long)lds)) return -1001;
     hipLaunchKernelGGL(kern, dim3((unsigned)BT), dim3(64), lds, st, n, S, NP, (const double*)handoff_workspace, eps, xbar,
                        noise, pinv_bar, info);
     return hipGetLastError() == hipSuccess ? 0 : -1000;

@@ -39,13 +39,26 @@ def _canonical_init_params(init_params, device):
     return J, h, logZ.reshape(1).contiguous()
 
 
+_default_options = _lib.OPT_DEFAULT
+
+
+def set_default_options(options):
+    """Kernel-selection word (svae_amd._lib.OPT_*) that plans created WITHOUT an explicit `options` take; returns
+    the previous one.  Host-side convenience for the tests and A/B tools that run a whole suite through one
+    kernel family -- the library itself holds no selection state: each plan passes its word with every call."""
+    global _default_options
+    old, _default_options = _default_options, int(options)
+    return old
+
+
 class LDSEStepPlan(object):
     """Pre-allocated buffers for repeated E-steps of one shape (B, T, n): the launch itself does no
     allocation, no host<->device copy and no synchronisation.  The sampler and the VJP read the
     workspace of the plan's LAST launch: a plan may be reused for a new forward pass only after the
-    backward pass of the previous one (checked through `epoch`)."""
+    backward pass of the previous one (checked through `epoch`).  `options`: kernel-selection word passed with
+    every call of this plan (svae_amd._lib.OPT_*, include/svae_hip.h SVAE_OPT_*; None = set_default_options)."""
 
-    def __init__(self, B, T, n, device="cuda", inhomog=False, pair_batched=False):
+    def __init__(self, B, T, n, device="cuda", inhomog=False, pair_batched=False, options=None):
         if not (1 <= n <= _lib.LDS_TILE_MAX_N):
             raise ValueError("latent dimension n=%d outside the supported range (1..%d)"
                              % (n, _lib.LDS_TILE_MAX_N))
@@ -53,6 +66,7 @@ class LDSEStepPlan(object):
             raise ValueError("need T >= 1 and B >= 0")
         self.lib = _lib.load()
         self.B, self.T, self.n, self.inhomog = B, T, n, bool(inhomog)
+        self.options = _default_options if options is None else int(options)
         self.device = torch.device(device)
         f64 = dict(dtype=torch.float64, device=self.device)
         # (n > 15: the workspace also holds the re-packed pair parameters, one set per sequence if batched)
@@ -84,9 +98,9 @@ class LDSEStepPlan(object):
         p = _lib.ptr
         keep = int(bool(keep_factor)) | (2 if keep_cross else 0)
         if self.n > _lib.LDS_MAX_N:
-            keep = 0       # tile kernel: its hand-off always serves the (dense-algebra) sampler, lds_large.py
+            keep = 0       # tile kernel: its hand-off always serves the sampler / VJP kernels (lds_large.py)
         rc = self.lib.svae_lds_estep_f64(
-            self.B, self.T, self.n, int(self.inhomog), int(pair_batched), keep,
+            self.B, self.T, self.n, int(self.inhomog), int(pair_batched), keep, self.options,
             p(init_J), p(init_h), p(init_logZ), p(J11), p(J12), p(J22), p(logZ_pair),
             p(node_J), p(node_h), p(node_logZ),
             p(self.lognorm), p(self.E_init), p(self.E_pair), p(self.E_node_diagxx),
@@ -105,7 +119,7 @@ class LDSEStepPlan(object):
         `sample()` needs."""
         p = _lib.ptr
         rc = self.lib.svae_lds_filter_f64(
-            self.B, self.T, self.n, int(self.inhomog), int(pair_batched),
+            self.B, self.T, self.n, int(self.inhomog), int(pair_batched), self.options,
             p(init_J), p(init_h), p(init_logZ), p(J11), p(J12), p(J22), p(logZ_pair),
             p(node_J), p(node_h), p(node_logZ), p(self.lognorm), p(J_pred), p(h_pred), p(J_filt), p(h_filt),
             p(self.info), p(self.ws), self.ws_bytes, _lib.current_stream(self.device))
@@ -119,22 +133,23 @@ class LDSEStepPlan(object):
         """Backward sampling from the messages of the last `launch(..., keep_factor=True)`.
         eps: (B,T,S,n) standard-normal draws -> samples (B,T,S,n)
         [natural_sample_backward, cython_lds_inference.pyx:310-355]."""
+        if eps.dim() != 4 or eps.shape[0] != self.B or eps.shape[1] != self.T or eps.shape[3] != self.n \
+                or eps.shape[2] < 1:
+            raise ValueError("eps must be (B,T,S,n) with S >= 1")
         if self.n > _lib.LDS_MAX_N:
-            # 16 <= n <= 64: from the tile kernel's hand-off with batched dense linear algebra (lds_large.py)
+            # 16 <= n <= 64: noise-factor kernel + recursion kernel on the tile kernel's hand-off (lds_large.py)
             from .lds_large import sample_from_handoff
             if self.epoch == 0:
                 raise RuntimeError("sample() needs a preceding launch()")
             return sample_from_handoff(self, eps.to(device=self.device, dtype=torch.float64))
         if not getattr(self, "has_factor", False):
             raise RuntimeError("sample() needs a preceding launch(..., keep_factor=True)")
-        if eps.dim() != 4 or eps.shape[0] != self.B or eps.shape[1] != self.T or eps.shape[3] != self.n:
-            raise ValueError("eps must be (B,T,S,n)")
         eps = eps.to(device=self.device, dtype=torch.float64).contiguous()
         S = eps.shape[2]
         if out is None:
             out = torch.empty_like(eps)
         p = _lib.ptr
-        rc = self.lib.svae_lds_sample_f64(self.B, self.T, self.n, S, p(eps), p(out), p(self.ws),
+        rc = self.lib.svae_lds_sample_f64(self.B, self.T, self.n, S, self.options, p(eps), p(out), p(self.ws),
                                           self.ws_bytes, _lib.current_stream(self.device))
         _lib.check(rc, "svae_lds_sample_f64")
         return out
@@ -159,6 +174,18 @@ class LDSEStepPlan(object):
         g_samples, eps, samples = c(g_samples), c(eps), c(samples)
         g_E_init, g_E_pair = c(g_E_init), c(g_E_pair)
         S = 0 if g_samples is None else g_samples.shape[2]
+        if S > 16:
+            # the kernels take 16 sample cotangents per launch; the VJP is linear in the cotangents: the first chunk
+            # travels with all the others, the remaining chunks alone
+            gJ, gh = self.vjp(g_lognorm, g_E_node_diagxx, g_E_node_x, g_samples[:, :, :16], eps[:, :, :16],
+                              samples[:, :, :16], g_E_init, g_E_pair)
+            zero = torch.zeros_like(g_lognorm)
+            for s0 in range(16, S, 16):
+                aJ, ah = self.vjp(zero, None, None, g_samples[:, :, s0:s0 + 16], eps[:, :, s0:s0 + 16],
+                                  samples[:, :, s0:s0 + 16])
+                gJ += aJ
+                gh += ah
+            return gJ, gh
         if not hasattr(self, "vjp_ws"):
             self.vjp_ws_bytes = int(self.lib.svae_lds_vjp_workspace_bytes(max(self.B, 1), self.T, self.n))
             self.vjp_ws = torch.empty(self.vjp_ws_bytes // 8, **f64)
@@ -166,7 +193,7 @@ class LDSEStepPlan(object):
         gh = torch.empty(self.B, self.T, self.n, **f64)
         p = _lib.ptr
         rc = self.lib.svae_lds_estep_vjp_ex_f64(
-            self.B, self.T, self.n, S, int(self.inhomog), int(self._pair_batched),
+            self.B, self.T, self.n, S, int(self.inhomog), int(self._pair_batched), self.options,
             p(self._J12), p(g_lognorm), p(g_E_node_diagxx), p(g_E_node_x), p(g_E_init), p(g_E_pair),
             p(g_samples), p(eps), p(samples), p(self.E_pair), p(self.E_node_x), p(gJ), p(gh),
             p(self.ws), self.ws_bytes, p(self.vjp_ws), self.vjp_ws_bytes, _lib.current_stream(self.device))
@@ -191,7 +218,8 @@ class LDSEStepPlan(object):
         if v != 0:
             self.info.zero_()
             raise FloatingPointError("LDS E-step: sequence %d hit a non-positive pivot "
-                                     "(potentials not positive definite)" % (v - 1))
+                                     "(potentials not positive definite; through models.lds.run_inference also: the "
+                                     "global natural parameters are not valid)" % (v - 1))
 
 
 def _prepare(natparam, node_params, plan):
@@ -387,11 +415,10 @@ class _LDSInference(torch.autograd.Function):
         init_J, init_h, init_logZ, J11, J12, J22, logZ_pair = params
         plan.launch(init_J, init_h, init_logZ, J11, J12, J22, logZ_pair, node_J, node_h, node_logZ,
                     pair_batched, True, True)
-        if eps is not None and eps.shape[2] > 16:
-            raise ValueError("at most 16 samples per sequence are differentiable (svae_lds_estep_vjp_f64)")
         samples = plan.sample(eps) if eps is not None else torch.zeros(0, dtype=torch.float64, device=plan.device)
         ctx.plan, ctx.has_logZ, ctx.has_samples = plan, node_logZ is not None, eps is not None
         ctx.epoch = plan.epoch
+        ctx.set_materialize_grads(False)       # an output nobody differentiated arrives as None, not as zeros
         ctx.save_for_backward(eps if eps is not None else samples, samples)
         E_init, E_pair = plan.E_init.clone(), plan.E_pair.clone()
         if not plan.inhomog:
@@ -453,7 +480,7 @@ def lds_inference_differentiable(natparam, node_params, eps=None, plan=None, pai
     cont = lambda x: None if x is None else x.to(torch.float64).contiguous()
     fn = _LDSInference
     if n > _lib.LDS_MAX_N:
-        from .lds_large import LDSInferenceLarge as fn     # tile-kernel forward, dense-algebra backward
+        from .lds_large import LDSInferenceLarge as fn     # tile-kernel forward, tile VJP kernels backward
     out = fn.apply(cont(node_J), cont(node_h), cont(node_logZ), cont(eps), plan, params, pair_batched)
     lognorm, dxx, ex, samples, E_init, E_pair = out
     if sum_pairs:

@@ -66,13 +66,17 @@ def local_natparam_from_global(global_natparam):
 GLOBAL_STEP_MAX_N = 64
 
 
-def global_step(global_natparam, prior_natparam=None):
+def global_step(global_natparam, prior_natparam=None, info=None):
     """The once-per-step global side in ONE kernel launch (svae_lds_global_step_f64): the LDS potentials from
     the global factors (lds.py:23-25 = niw.expectedstats niw.py:15-25 + mniw.expectedstats mniw.py:33-55) and,
     if `prior_natparam` is given, the prior KL of lds.py:16-20.  Inputs are device tensors
     (NIW dense (n+2,n+2), (A, B, C, d)).  Returns ((init_params, pair_params), global_kl | None, niw_expectedstats)
     with init_params = (-1/2 E[J], E[h], logZ) and pair_params = (J11, J12, J22, logZ) as the E-step takes them.
-    Same values as local_natparam_from_global / lds_prior_kl (the torch path, ~150 small launches)."""
+    Same values as local_natparam_from_global / lds_prior_kl (the torch path, ~150 small launches).
+    `info`: (1,) int32 device status word; the kernel raises it to 1 on a non-positive Gauss-Jordan pivot, i.e. global
+    natural parameters that are not valid (the reference asserts is_posdef in mniw.expectedstats, mniw.py:49-50).
+    Without one a fresh word is allocated and kept as `global_step.last_info` -- never read here: checking costs a
+    host synchronisation; run_inference passes the plan's word, so that plan.check_info() reports it."""
     niw, (A, B, C, d) = global_natparam
     dev = niw.device
     n = niw.shape[-1] - 2
@@ -95,7 +99,9 @@ def global_step(global_natparam, prior_natparam=None):
     init_J, init_h, init_logZ = take(n * n, (n, n)), take(n, (n,)), take(1, (1,))
     J11, J12, J22, lz = take(n * n, (n, n)), take(n * n, (n, n)), take(n * n, (n, n)), take(1, (1,))
     kl, es = take(1, (1,)), take((n + 2) * (n + 2), (n + 2, n + 2))
-    info = torch.zeros(1, dtype=torch.int32, device=dev)
+    if info is None:
+        info = torch.zeros(1, dtype=torch.int32, device=dev)
+    global_step.last_info = info
     p = _lib.ptr
     rc = _lib.load().svae_lds_global_step_f64(
         n, p(niw), p(A), p(B), p(C), p(d), p(pr[0]), p(pr[1]), p(pr[2]), p(pr[3]), p(pr[4]),
@@ -131,12 +137,12 @@ def natural_gradient(prior_natparam, global_natparam, stats, num_batches, scale)
                                           out[D2 + 2 * nn:D2 + 3 * nn].view(n, n), out[D2 + 3 * nn])
 
 
-def _globals_on_device(prior_natparam, global_natparam, dev):
+def _globals_on_device(prior_natparam, global_natparam, dev, info=None):
     """(local_natparam, global_kl) through the global-step kernel (n <= 64), else the torch maps."""
     g = (_dev64(global_natparam[0], dev), tuple(_dev64(x, dev) for x in global_natparam[1]))
     p = (_dev64(prior_natparam[0], dev), tuple(_dev64(x, dev) for x in prior_natparam[1]))
     if g[0].shape[-1] - 2 <= GLOBAL_STEP_MAX_N:
-        local_natparam, global_kl, _ = global_step(g, p)
+        local_natparam, global_kl, _ = global_step(g, p, info)
         return local_natparam, global_kl
     local_natparam, global_es = local_natparam_from_global(g)
     return local_natparam, lds_prior_kl(g, p, global_es)
@@ -147,13 +153,14 @@ def run_inference(prior_natparam, global_natparam, nn_potentials, num_samples, e
     """lds.py:35-52.  Returns (samples, global_expected_stats, global_kl, local_kl); with B sequences,
     samples is (B,T,S,n) and the statistics / local_kl are sums over the (global) batch."""
     dev = torch.device("cuda", torch.cuda.current_device())
-    local_natparam, global_kl = _globals_on_device(prior_natparam, global_natparam, dev)
     node = tuple(_dev64(x, dev) for x in nn_potentials)
     batched = node[1].dim() == 3
     nodeb = node if batched else tuple(x[None] for x in node)
     B, T, n = nodeb[1].shape
     if plan is None:
         plan = LDSEStepPlan(B, T, n, dev)
+    # (invalid global parameters raise the PLAN's status word: plan.check_info() / check=True report them)
+    local_natparam, global_kl = _globals_on_device(prior_natparam, global_natparam, dev, plan.info)
     lognorm, (Ei, Ep, En) = natural_lds_estep_general(local_natparam, nodeb, plan=plan, keep_factor=True)
     S = 1 if num_samples is None else int(num_samples)
     if eps is None:
@@ -189,7 +196,6 @@ def run_inference_differentiable(prior_natparam, global_natparam, nn_potentials,
     these two, svae.py:21-24; the statistics go to `saved.stats` undifferentiated)."""
     from ..lds.lds_inference import lds_inference_differentiable
     dev = nn_potentials[1].device
-    local_natparam, global_kl = _globals_on_device(prior_natparam, global_natparam, dev)
     node = tuple(x.to(torch.float64) for x in nn_potentials)
     batched = node[1].dim() == 3
     nodeb = node if batched else tuple(x[None] for x in node)
@@ -202,6 +208,7 @@ def run_inference_differentiable(prior_natparam, global_natparam, nn_potentials,
         eps = eps if batched else eps[None]
     if plan is None:
         plan = LDSEStepPlan(B, T, n, dev)
+    local_natparam, global_kl = _globals_on_device(prior_natparam, global_natparam, dev, plan.info)
     lognorm, (dxx, ex), samples, _ = lds_inference_differentiable(local_natparam, nodeb, eps=eps, plan=plan)
     local_kl = (nodeb[0] * dxx).sum() + (nodeb[1] * ex).sum() - lognorm.sum()
     if len(nodeb) == 3:

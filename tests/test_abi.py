@@ -17,7 +17,7 @@ def _header_symbols():
 
 def test_header_declares_the_expected_entry_points():
     syms = _header_symbols()
-    for s in ("svae_lds_estep_f64", "svae_lds_workspace_bytes", "svae_lds_workspace_bytes_ex", "svae_lds_set_split_max_b", "svae_lds_set_twoend", "svae_lds_set_prod_max_b", "svae_lds_filter_f64",
+    for s in ("svae_lds_estep_f64", "svae_lds_workspace_bytes", "svae_lds_workspace_bytes_ex", "svae_lds_filter_f64",
               "svae_lds_reduce_stats_f64",
               "svae_lds_sample_f64", "svae_lds_estep_vjp_f64", "svae_lds_vjp_workspace_bytes",
               "svae_hmm_estep_f64", "svae_hmm_workspace_bytes", "svae_slds_lds_meanfield_f64",
@@ -74,16 +74,35 @@ def test_bad_arguments_are_rejected_on_the_host():
     lib = _lib.load()
     null = None
     args = [null] * 15 + [null, null, 0, null]
-    assert lib.svae_lds_estep_f64(4, 0, 3, 0, 0, 0, *args) == -2       # T < 1
-    assert lib.svae_lds_estep_f64(4, 5, 65, 0, 0, 0, *args) == -3      # n too large
-    assert lib.svae_lds_estep_f64(4, 5, 16, 0, 0, 1, *args) == -23     # tiled path keeps no sampler factors
-    assert lib.svae_lds_estep_f64(4, 5, 3, 0, 1, 0, *args) == -5       # batched pair w/o inhomog
-    assert lib.svae_lds_estep_f64(4, 5, 3, 0, 0, 0, *args) == -6       # NULL init_J
-    assert lib.svae_lds_sample_f64(4, 5, 3, 0, null, null, null, 0, null) == -4    # S < 1
+    assert lib.svae_lds_estep_f64(4, 0, 3, 0, 0, 0, 0, *args) == -2       # T < 1
+    assert lib.svae_lds_estep_f64(4, 5, 65, 0, 0, 0, 0, *args) == -3      # n too large
+    assert lib.svae_lds_estep_f64(4, 5, 16, 0, 0, 1, 0, *args) == -23     # tiled path keeps no sampler factors
+    assert lib.svae_lds_estep_f64(4, 5, 3, 0, 1, 0, 0, *args) == -5       # batched pair w/o inhomog
+    assert lib.svae_lds_estep_f64(4, 5, 3, 0, 0, 0, 0, *args) == -6       # NULL init_J
+    assert lib.svae_lds_sample_f64(4, 5, 3, 0, 0, null, null, null, 0, null) == -4    # S < 1
     assert lib.svae_gmm_meanfield_f64(10, 9, 3, *([null] * 5), 1e-3, 100,
                                       *([null] * 8), null, null, null, null) == -2
     assert lib.svae_gmm_meanfield_f64(10, 2, 65, *([null] * 5), 1e-3, 100,
                                       *([null] * 8), null, null, null, null) == -3
+
+
+def test_contradictory_or_unknown_options_are_rejected():
+    """The per-call selection word (SVAE_OPT_*): contradictory pairs and unknown bits return -24 after the pointer
+    checks and before any HIP call; the library exports no process-global selectors any more."""
+    import ctypes as C
+    from svae_amd import _lib
+    lib = _lib.load()
+    buf = (C.c_double * 4096)()
+    ptr = C.cast(buf, C.c_void_p)
+    ws = lib.svae_lds_workspace_bytes(1, 4, 2)
+    assert 0 < ws <= 8 * 4096
+    args = [ptr] * 15 + [ptr, ptr, ws, None]
+    for bad in (_lib.OPT_TWOEND_OFF | _lib.OPT_TWOEND_FULL, _lib.OPT_LAYOUT_SPLIT | _lib.OPT_LAYOUT_PACKED,
+                _lib.OPT_PRODUCERS_ON | _lib.OPT_PRODUCERS_OFF, 0x40, 0x80000000):
+        assert lib.svae_lds_estep_f64(1, 4, 2, 0, 0, 0, bad, *args) == -24
+        assert lib.svae_lds_sample_f64(1, 4, 2, 1, bad, ptr, ptr, ptr, ws, None) == -24
+    for name in ("svae_lds_set_twoend", "svae_lds_set_split_max_b", "svae_lds_set_prod_max_b"):
+        assert not hasattr(lib, name)
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

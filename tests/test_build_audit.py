@@ -39,6 +39,14 @@ def test_audit_tool_detects_a_planted_hazard(tmp_path):
     assert any("H4" in q for q in audit_dpp_hazards.audit(str(s))[1])
 
 
+def test_generated_gauss_jordan_header_is_what_the_generator_emits():
+    """svae_amd/csrc/gj1r_gen.hpp (the hand-scheduled pivot blocks of the headline kernel, 2 365 generated lines) is
+    committed; it must be byte for byte what tools/gen_gj_asm.py emits today."""
+    import gen_gj_asm
+    committed = open(os.path.join(ROOT, "svae_amd", "csrc", "gj1r_gen.hpp")).read()
+    assert gen_gj_asm.generate() == committed, "regenerate: python tools/gen_gj_asm.py"
+
+
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 @pytest.mark.parametrize("n", [2, 10, 12, 15])
 def test_estep_kernel_isa_has_no_dpp_hazards(n, tmp_path):

@@ -24,12 +24,10 @@ def kernel_variant(request):
     without sampler / VJP hand-off) with its lean and its full hand-off record, and the one-directional
     small-batch (one sequence per wavefront) and packed (four per wavefront) variants."""
     from svae_amd import _lib
-    lib = _lib.load()
-    old_te = lib.svae_lds_set_twoend({"twoend": 1, "twoend_full": 2}.get(request.param, 0))
-    old = lib.svae_lds_set_split_max_b(1 << 30 if request.param == "split" else 0)
+    from svae_amd.lds.lds_inference import set_default_options
+    old = set_default_options(_lib.KERNEL_OPTIONS[request.param])      # (a per-plan word; the library has no state)
     yield request.param
-    lib.svae_lds_set_split_max_b(old)
-    lib.svae_lds_set_twoend(old_te)
+    set_default_options(old)
 
 
 def _rel(a, b):

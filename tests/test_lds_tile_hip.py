@@ -280,6 +280,79 @@ def test_tile_vjp_full_size_against_reference_compiled_vjps(n, T, S):
     assert max(e[0] for e in errs) < 1e-6 and max(e[1] for e in errs) < 1e-6 and max(e[2] for e in errs) < 1e-12
 
 
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("n,T,S", [(16, 9, 2), (32, 12, 0), (64, 5, 1)])
+def test_tile_vjp_pair_statistic_cotangents_against_reference(n, T, S):
+    """Per-step pair parameters at 16 <= n <= 64 (the SLDS final pass above the register path): cotangents of E_init
+    and of the PER-STEP pair statistics through svae_lds_tile_vjp_f64 against the reference's compiled
+    _compute_stats_grad + natural_smoother_general_grad (cython_lds_inference.pyx:212-306)."""
+    from svae_amd.lds.lds_inference import lds_inference_differentiable
+    rng = np.random.default_rng(13 * n + T)
+    init = _wellcond_natparam(n, rng)[0]
+    pairs = [_wellcond_natparam(n, rng)[1] for _ in range(T - 1)]
+    pair = tuple(np.stack([p[i] for p in pairs]) for i in range(4))
+    B = 2
+    node = rand_node_potentials((B, T, n), rng, with_logZ=True)
+    g = dict(ln=rng.standard_normal(B), dxx=rng.standard_normal((B, T, n)), x=rng.standard_normal((B, T, n)),
+             s=rng.standard_normal((B, T, max(S, 1), n)), i0=rng.standard_normal((B, n, n)), i1=rng.standard_normal((B, n)),
+             p=rng.standard_normal((B, T - 1, 3, n, n)))
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev)
+    want, eps = [], np.zeros((B, T, max(S, 1), n))
+    for b in range(B):
+        (gJ, gh, gz), e = ref.estep_vjp((init, pair), tuple(x[b] for x in node), g["ln"][b], (g["dxx"][b], g["x"][b]),
+                                        g["s"][b] if S else None, seed=500 + b, g_E_init=(g["i0"][b], g["i1"][b]),
+                                        g_E_pair=tuple(g["p"][b][:, k] for k in range(3)))
+        want.append((gJ, gh, gz))
+        if S:
+            eps[b] = e
+    nJ, nh, nz = (t(x).requires_grad_(True) for x in node)
+    nat = (tuple(t(x) for x in init), tuple(t(x) for x in pair))
+    lognorm, (dxx, ex), samples, (E_init, E_pair) = lds_inference_differentiable(nat, (nJ, nh, nz),
+                                                                                 eps=t(eps) if S else None)
+    gi = torch.cat([t(g["i0"]).reshape(B, n * n), t(g["i1"])], 1)
+    loss = (t(g["ln"]) * lognorm).sum() + (t(g["dxx"]) * dxx).sum() + (t(g["x"]) * ex).sum() \
+        + (gi * E_init).sum() + (t(g["p"]) * E_pair).sum()
+    if S:
+        loss = loss + (t(g["s"]) * samples).sum()
+    loss.backward()
+    for b in range(B):
+        assert _rel(nJ.grad[b], want[b][0]) < 1e-6, "g_node_J"
+        assert _rel(nh.grad[b], want[b][1]) < 1e-6, "g_node_h"
+        assert _rel(nz.grad[b], want[b][2]) < 1e-12, "g_node_logZ"
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("n", [7, 24])
+def test_more_than_16_samples_per_sequence(n):
+    """num_samples is unbounded in the reference (cython_lds_inference.pyx:310-355, 357-409); the kernels take 16
+    sample vectors per launch and the host layer chunks (sampler: independent draws; VJP: linear in the cotangents).
+    Both the register path (n = 7) and the tile path (n = 24) against the compiled reference with 37 samples."""
+    from svae_amd.lds.lds_inference import lds_inference_differentiable
+    T, S, B = 9, 37, 2
+    rng = np.random.default_rng(n)
+    natparam = rand_lds_natparam(n, rng)
+    node = rand_node_potentials((B, T, n), rng, with_logZ=True)
+    g = dict(ln=rng.standard_normal(B), dxx=rng.standard_normal((B, T, n)), x=rng.standard_normal((B, T, n)),
+             s=rng.standard_normal((B, T, S, n)))
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev)
+    want, eps, wsmp = [], np.zeros((B, T, S, n)), []
+    for b in range(B):
+        nb = tuple(x[b] for x in node)
+        (gJ, gh, gz), eps[b] = ref.estep_vjp(natparam, nb, g["ln"][b], (g["dxx"][b], g["x"][b]), g["s"][b], seed=40 + b)
+        want.append((gJ, gh))
+        wsmp.append(ref.sample_backward(natparam, nb, S, seed=40 + b)[0])
+    nJ, nh, nz = (t(x).requires_grad_(True) for x in node)
+    nat = (tuple(t(x) for x in natparam[0]), tuple(t(x) for x in natparam[1]))
+    lognorm, (dxx, ex), samples, _ = lds_inference_differentiable(nat, (nJ, nh, nz), eps=t(eps))
+    loss = (t(g["ln"]) * lognorm).sum() + (t(g["dxx"]) * dxx).sum() + (t(g["x"]) * ex).sum() + (t(g["s"]) * samples).sum()
+    loss.backward()
+    for b in range(B):
+        assert _rel(samples[b], wsmp[b]) < 1e-7
+        assert _rel(nJ.grad[b], want[b][0]) < 1e-6 and _rel(nh.grad[b], want[b][1]) < 1e-6
+
+
 def test_tile_training_step_at_latent_dim_32():
     """examples/lds_svae_synth.py at n = 32: an LDS-SVAE training loop (make_gradfun) on the tile path."""
     import importlib.util
@@ -293,11 +366,14 @@ def test_tile_training_step_at_latent_dim_32():
 
 
 @pytest.mark.parametrize("n,T,B,S,mode", [(16, 7, 3, 2, "homog"), (20, 5, 2, 0, "homog"), (33, 6, 2, 3, "inhomog"),
-                                          (64, 5, 2, 1, "batched"), (48, 1, 2, 1, "homog"), (64, 40, 3, 2, "homog")])
+                                          (64, 5, 2, 1, "batched"), (48, 1, 2, 1, "homog"), (64, 40, 3, 2, "homog"),
+                                          (24, 6, 2, 19, "inhomog"), (16, 2, 2, 0, "batched")])
 def test_tile_vjp_kernels_match_the_torch_adjoint(n, T, B, S, mode):
     """svae_lds_tile_vjp_f64 (three phases, one workgroup per sequence) against the same adjoint written as
-    batched torch products (lds_large.vjp_from_handoff, itself checked against autograd on the CPU), both on the
-    hand-off of ONE tile-kernel launch; cotangents of lognorm, E_node, E_init and the samples."""
+    batched torch products (tests/_lds_large_torch.py: vjp_from_handoff, itself checked against autograd on the CPU),
+    both on the hand-off of ONE tile-kernel launch; cotangents of lognorm, E_node, E_init, the samples (more than 16:
+    chunked) and -- per-step parameters -- of the per-step pair statistics."""
+    import _lds_large_torch as lt
     from svae_amd.lds import lds_large
     from svae_amd.lds.lds_inference import LDSEStepPlan
     rng = np.random.default_rng(5 * n + T)
@@ -320,17 +396,18 @@ def test_tile_vjp_kernels_match_the_torch_adjoint(n, T, B, S, mode):
     eps = t(rng.standard_normal((B, T, S, n))) if S else None
     samples = lds_large.sample_from_handoff(plan, eps) if S else None
     g = dict(ln=t(rng.standard_normal(B)), dxx=t(rng.standard_normal((B, T, n))), x=t(rng.standard_normal((B, T, n))),
-             s=t(rng.standard_normal((B, T, max(S, 1), n))), i=t(rng.standard_normal((B, n * n + n))))
+             s=t(rng.standard_normal((B, T, max(S, 1), n))), i=t(rng.standard_normal((B, n * n + n))),
+             p=t(rng.standard_normal((B, max(T - 1, 0), 3, n, n))) if mode != "homog" else None)
     G, Pinv, c = lds_large.handoff_views(plan)
     ex = plan.E_node_x.clone()
-    want = lds_large.vjp_from_handoff(G, Pinv, c, ex, pair[1], g["ln"], g["dxx"], g["x"], samples, eps,
-                                      g["s"] if S else None, g["i"])
+    want = lt.vjp_from_handoff(G, Pinv, c, ex, pair[1], g["ln"], g["dxx"], g["x"], samples, eps,
+                               g["s"] if S else None, g["i"], g_E_pair=g["p"])
     got = lds_large.vjp_from_handoff_hip(plan, pair[1], mode == "batched", ex, g["ln"], g["dxx"], g["x"], samples, eps,
-                                         g["s"] if S else None, g["i"])
+                                         g["s"] if S else None, g["i"], g["p"])
     for a, b in zip(got, want):
         assert _rel(a, b.cpu().numpy()) < 1e-9
     # without the optional cotangents
-    want = lds_large.vjp_from_handoff(G, Pinv, c, ex, pair[1], g["ln"], None, g["x"])
+    want = lt.vjp_from_handoff(G, Pinv, c, ex, pair[1], g["ln"], None, g["x"])
     got = lds_large.vjp_from_handoff_hip(plan, pair[1], mode == "batched", ex, g["ln"], None, g["x"])
     for a, b in zip(got, want):
         assert _rel(a, b.cpu().numpy()) < 1e-9

@@ -78,6 +78,26 @@ def test_lds_run_inference_against_oracle(n, T, B, S):
     assert float(global_kl) == pytest.approx(want[0][2], rel=1e-8)   # difference of large logZ terms
 
 
+def test_invalid_global_parameters_are_reported_through_the_plan():
+    """The reference asserts is_posdef inside mniw.expectedstats (mniw.py:49-50); here the global-step kernel raises the
+    PLAN's device-side status word, which plan.check_info() reads on request (no synchronisation by default)."""
+    from svae_amd.lds.lds_inference import LDSEStepPlan
+    from svae_amd.models.lds import run_inference
+    from svae_amd.lds.synthetic_data import rand_node_potentials
+    rng = np.random.default_rng(5)
+    n, T, B = 4, 6, 3
+    prior, glob = _lds_globals(n, rng), _lds_globals(n, rng)
+    node = rand_node_potentials((B, T, n), rng)
+    plan = LDSEStepPlan(B, T, n, "cuda:0")
+    run_inference(prior, glob, node, 1, plan=plan)
+    plan.check_info()                                     # valid parameters: silent
+    niw, (A, Bm, C, d) = glob
+    bad = (niw, (-np.asarray(A), Bm, C, d))               # K^-1 negative definite
+    run_inference(prior, bad, node, 1, plan=plan)
+    with pytest.raises(FloatingPointError):
+        plan.check_info()
+
+
 def test_lds_run_inference_unbatched_shapes():
     from svae_amd.models.lds import run_inference
     from svae_amd.lds.synthetic_data import rand_node_potentials

@@ -267,13 +267,12 @@ def test_plan_reuse_before_backward_is_refused():
 
 @pytest.mark.parametrize("n,T,B,S", [(10, 37, 7, 1), (6, 12, 3, 3), (13, 9, 5, 2)])
 def test_producer_wavefront_kernels_agree_with_the_packed_ones(n, T, B, S):
-    """svae_lds_set_prod_max_b(0) sends the sampler and the sweeps through the packed kernels (one wavefront per
+    """SVAE_OPT_PRODUCERS_OFF sends the sampler and the sweeps through the packed kernels (one wavefront per
     four sequences, register prefetch); the default runs them with producer / helper wavefronts and, up to 512
     sequences, with one sequence per wavefront.  Different schedules of the same arithmetic: gradients and samples
     agree to rounding."""
     from svae_amd import _lib
-    from svae_amd.lds.lds_inference import lds_inference_differentiable
-    lib = _lib.load()
+    from svae_amd.lds.lds_inference import lds_inference_differentiable, set_default_options
     init, pair, node, g = _setup(n, T, B, S, 11 * n + T)
     dev = torch.device("cuda:0")
     t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev)
@@ -291,12 +290,11 @@ def test_producer_wavefront_kernels_agree_with_the_packed_ones(n, T, B, S):
         return [nJ.grad.clone(), nh.grad.clone()] + ([samples.detach().clone()] if with_samples else [])
 
     for with_samples in (False, True):
-        old = lib.svae_lds_set_prod_max_b(0)
+        old = set_default_options(_lib.OPT_PRODUCERS_OFF)
         try:
             packed = run(with_samples)
         finally:
-            lib.svae_lds_set_prod_max_b(old)
-        assert lib.svae_lds_set_prod_max_b(old) == old
+            assert set_default_options(old) == _lib.OPT_PRODUCERS_OFF
         default = run(with_samples)
         for x, y in zip(default, packed):
             assert float((x - y).abs().max()) <= 1e-11 * float(y.abs().max()) + 1e-300, float((x - y).abs().max())

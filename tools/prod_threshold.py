@@ -1,5 +1,5 @@
 """Training-path kernels with / without producer wavefronts at several batch sizes (tuning of
-svae_lds_set_prod_max_b).  Usage: python tools/prod_threshold.py [B ...]"""
+the 1024-sequence default behind SVAE_OPT_PRODUCERS_ON / _OFF).  Usage: python tools/prod_threshold.py [B ...]"""
 import os, sys
 import numpy as np
 import torch
@@ -10,8 +10,6 @@ from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials
 
 
 def run(B, T, n, S, prod):
-    lib = _lib.load()
-    lib.svae_lds_set_prod_max_b(1 << 30 if prod else 0)
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(0)
     (J0, h0, z0), (J11, J12, J22, zp) = rand_lds_natparam(n, rng)
@@ -21,7 +19,7 @@ def run(B, T, n, S, prod):
     eps = torch.randn(B, T, S, n, dtype=torch.float64, device=dev)
     g = [torch.randn(B, dtype=torch.float64, device=dev), torch.randn(B, T, n, dtype=torch.float64, device=dev),
          torch.randn(B, T, n, dtype=torch.float64, device=dev), torch.randn(B, T, S, n, dtype=torch.float64, device=dev)]
-    plan = LDSEStepPlan(B, T, n, dev)
+    plan = LDSEStepPlan(B, T, n, dev, options=_lib.OPT_PRODUCERS_ON if prod else _lib.OPT_PRODUCERS_OFF)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     for rep in range(3):
         plan.launch(*args, None, False, True, True)

@@ -1,12 +1,12 @@
 """Randomised cross-check of the small-batch kernels (second wavefront per sequence in the two-ended E-step; producer /
 helper / one-sequence-per-wavefront sampler and VJP kernels) against the packed schedules of the same arithmetic
-(svae_lds_set_twoend(0), svae_lds_set_prod_max_b(0)).  Usage: python tools/stress_small_batch.py [cases]"""
+(SVAE_OPT_TWOEND_OFF | SVAE_OPT_PRODUCERS_OFF).  Usage: python tools/stress_small_batch.py [cases]"""
 import os, sys
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from svae_amd import _lib
-from svae_amd.lds.lds_inference import lds_inference_differentiable, natural_lds_estep_general
+from svae_amd.lds.lds_inference import lds_inference_differentiable, natural_lds_estep_general, set_default_options
 from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials
 
 
@@ -16,7 +16,6 @@ def rel(x, y):
 
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-    lib = _lib.load()
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(2026)
     t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev)
@@ -44,11 +43,11 @@ def main():
             return [nJ.grad, nh.grad] + ([smp.detach()] if with_samples else [])
 
         new = estep() + train(False) + train(True)
-        o1, o2 = lib.svae_lds_set_twoend(0), lib.svae_lds_set_prod_max_b(0)
+        o1 = set_default_options(_lib.OPT_TWOEND_OFF | _lib.OPT_PRODUCERS_OFF)
         try:
             old = estep() + train(False) + train(True)
         finally:
-            lib.svae_lds_set_twoend(o1); lib.svae_lds_set_prod_max_b(o2)
+            set_default_options(o1)
         errs = [rel(x, y) for x, y in zip(new, old)]
         err = max(errs)
         if err >= 1e-9:      # outputs: 8 of the E-step, 2 gradients without samples, 2 gradients + samples with
