@@ -1,0 +1,211 @@
+"""GPU tests of the N > 1 path with REAL kernel outputs in the collective: two ranks (gloo) share the one MI355X of
+the test box -- RCCL refuses two ranks on one device, and the collective's backend is not what is under test: the
+sharding, the per-rank HIP kernels, the packing of their outputs into the ONE all-reduce and the batch-total stopping
+rule of the GMM are.  Each case runs models.*.run_inference on every rank's contiguous shard and compares with the
+single-process result on all the sequences / points (svae/svae.py:33-34 consumes the summed statistics;
+gmm.py:104-105 stops on the minibatch total; the SLDS ascent is per sequence, slds_svae.py:159-175)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _np(x):
+    return x.detach().cpu().numpy()
+
+
+def _leaves(s, out=None):
+    out = [] if out is None else out
+    if isinstance(s, (tuple, list)):
+        for x in s:
+            _leaves(x, out)
+    else:
+        out.append(_np(s) if hasattr(s, "detach") else np.asarray(s, float))
+    return out
+
+
+# ---- problems (seeded: every process rebuilds the same one) ---------------------------------------------------------
+
+def _lds_problem():
+    from oracle import expfam_numpy as ef
+    from svae_amd.lds.synthetic_data import rand_node_potentials
+    n, T, B, S = 6, 15, 11, 2
+    rng = np.random.default_rng(21)
+
+    def glob(scale):
+        S_ = scale * (n + 2.) * np.eye(n)
+        return (ef.niw_standard_to_natural(S_, 0.2 * rng.standard_normal(n), np.array(0.7), np.array(n + 2.5)),
+                ef.mniw_standard_to_natural(n + 3., S_, 0.9 * np.eye(n) + 0.05 * rng.standard_normal((n, n)), 0.5 * np.eye(n)))
+    prior, g = glob(1.0), glob(0.8)
+    node = rand_node_potentials((B, T, n), rng, with_logZ=True)
+    eps = rng.standard_normal((B, T, S, n))
+    return prior, g, node, eps, S
+
+
+def _gmm_problem():
+    from svae_amd.lds.synthetic_data import rand_node_potentials
+    from svae_amd.models import gmm
+    T, N, K, S = 700, 2, 5, 1
+    gen = torch.Generator().manual_seed(3)
+    prior = gmm.init_pgm_param(K, N, alpha=0.05 / K, niw_conc=0.5, generator=gen)
+    glob = gmm.init_pgm_param(K, N, alpha=1.0, niw_conc=1.0, random_scale=3.0, generator=gen)
+    rng = np.random.default_rng(3)
+    node = rand_node_potentials((T, N), rng)
+    init = rng.random((T, K))
+    init /= init.sum(-1, keepdims=True)
+    eps = rng.standard_normal((T, S, N))
+    return prior, glob, node, init, eps, S
+
+
+def _slds_problem():
+    from svae_amd.lds.synthetic_data import rand_slds_global_natparam
+    K, n, T, B, S = 3, 4, 14, 7, 1
+    rng = np.random.default_rng(8)
+    glob, prior = rand_slds_global_natparam(K, n, rng), rand_slds_global_natparam(K, n, rng)
+    node = (-0.5 * (0.5 + rng.random((B, T, n))), 2. * rng.standard_normal((B, T, n)))
+    return prior, glob, node, rng.standard_normal((B, T, 1, n)), rng.standard_normal((B, T, S, n)), S
+
+
+def _run_all(lo_hi=None, group_on=False):
+    """Every model's run_inference on the sequences / points [lo, hi) (None: all) -> dict of numpy results."""
+    from svae_amd.models import gmm, lds, slds_svae
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev)
+    out = {}
+    prior, g, node, eps, S = _lds_problem()
+    sl = slice(None) if lo_hi is None else slice(*lo_hi(node[1].shape[0]))
+    samples, stats, gkl, lkl = lds.run_inference(prior, g, tuple(t(x[sl]) for x in node), S, eps=t(eps[sl]))
+    out["lds"] = dict(samples=_np(samples), stats=_leaves(stats), global_kl=float(gkl), local_kl=float(lkl))
+    nJ, nh, nz = (t(x[sl]).requires_grad_(True) for x in node)
+    samples, stats, gkl, lkl = lds.run_inference_differentiable(prior, g, (nJ, nh, nz), S, eps=t(eps[sl]))
+    (lkl + (samples ** 2).sum()).backward()
+    out["lds_diff"] = dict(stats=_leaves(stats), local_kl=float(lkl.detach()), gJ=_np(nJ.grad), gh=_np(nh.grad))
+
+    prior, g, node, init, eps, S = _gmm_problem()
+    sl = slice(None) if lo_hi is None else slice(*lo_hi(node[1].shape[0]))
+    samples, stats, gkl, lkl = gmm.run_inference(prior, g, tuple(t(x[sl]) for x in node), S, label_init=t(init[sl]),
+                                                 eps=t(eps[sl]))
+    out["gmm"] = dict(samples=_np(samples), stats=_leaves(stats), local_kl=float(lkl))
+    # the fixed point itself (labels, number of sweeps) on this shard with the batch-total rule
+    (ls, _), _, _, _ = gmm.local_meanfield(g, tuple(t(x[sl]) for x in node), label_init=t(init[sl]),
+                                           multi_wg=True if group_on else None)
+    out["gmm"]["labels"] = _np(ls).argmax(1)
+
+    prior, g, node, init_eps, eps, S = _slds_problem()
+    sl = slice(None) if lo_hi is None else slice(*lo_hi(node[1].shape[0]))
+    samples, stats, gvlb, lvlb = slds_svae.run_inference(prior, g, tuple(t(x[sl]) for x in node), S,
+                                                         init_eps=t(init_eps[sl]), eps=t(eps[sl]))
+    out["slds"] = dict(samples=_np(samples), stats=_leaves(stats), local_vlb=float(lvlb))
+    return out
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from svae_amd.parallel import shard_bounds
+        res = _run_all(lambda count: shard_bounds(count, rank, world), group_on=True)
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_on_one_gpu_reproduce_the_single_process_results():
+    import torch.multiprocessing as mp
+    from svae_amd.parallel import shard_bounds
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=500) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = _run_all()
+    close = lambda a, b, tol=1e-9: np.max(np.abs(np.asarray(a) - np.asarray(b))) <= tol * max(1e-300, np.max(np.abs(np.asarray(b))))
+    for rank in range(world):
+        r = got[rank]
+        for model, count in (("lds", 11), ("gmm", 700), ("slds", 7)):
+            lo, hi = shard_bounds(count, rank, world)
+            # per-sequence / per-point outputs: this rank's shard of the single-process result
+            assert close(r[model]["samples"], want[model]["samples"][lo:hi]), model
+            # statistics and local KL / bound: the single-process totals, on EVERY rank
+            for a, b in zip(r[model]["stats"], want[model]["stats"]):
+                assert close(a, b), model
+            key = "local_vlb" if model == "slds" else "local_kl"
+            assert abs(r[model][key] - want[model][key]) <= 1e-9 * abs(want[model][key]), model
+        lo, hi = shard_bounds(11, rank, world)
+        d, w = r["lds_diff"], want["lds_diff"]
+        for a, b in zip(d["stats"], w["stats"]):
+            assert close(a, b)
+        assert abs(d["local_kl"] - w["local_kl"]) <= 1e-9 * abs(w["local_kl"])       # global value ...
+        assert close(d["gJ"], w["gJ"][lo:hi], 1e-8) and close(d["gh"], w["gh"][lo:hi], 1e-8)   # ... this rank's gradient
+        assert abs(r["lds"]["global_kl"] - want["lds"]["global_kl"]) <= 1e-12 * abs(want["lds"]["global_kl"])
+        lo, hi = shard_bounds(700, rank, world)
+        assert np.array_equal(r["gmm"]["labels"], want["gmm"]["labels"][lo:hi])      # bit-exact assignments
+
+
+def test_two_streams_with_different_kernel_selections_are_independent():
+    """The library is re-entrant (ABI 6: the kernel selection travels with each call; helper stream and events are
+    keyed on (device, caller stream)): two training-path passes -- E-step keeping the hand-off (two kernels forked /
+    joined inside the call), sampler, VJP -- on two streams with DIFFERENT selections, launched interleaved so that
+    they overlap on the device, give bit for bit what each gives alone."""
+    from svae_amd import _lib
+    from svae_amd.lds.lds_inference import LDSEStepPlan
+    from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials
+    dev = torch.device("cuda:0")
+    B, T, n, S = 96, 60, 10, 2
+    rng = np.random.default_rng(4)
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev).contiguous()
+    (J0, h0, z0), (J11, J12, J22, zp) = rand_lds_natparam(n, rng)
+    data = []
+    for _ in range(2):
+        nJ, nh = rand_node_potentials((B, T, n), rng)
+        data.append(dict(args=[t(x) for x in (J0, h0, z0, J11, J12, J22, zp, nJ, nh)], eps=t(rng.standard_normal((B, T, S, n))),
+                         g=[t(rng.standard_normal(B)), t(rng.standard_normal((B, T, n))), t(rng.standard_normal((B, T, n))),
+                            t(rng.standard_normal((B, T, S, n)))]))
+    opts = [_lib.OPT_DEFAULT, _lib.OPT_TWOEND_OFF | _lib.OPT_LAYOUT_PACKED | _lib.OPT_PRODUCERS_OFF]
+
+    def one_pass(plan, d, keep):
+        plan.launch(*d["args"], None, False, keep, keep)
+        outs = [plan.lognorm.clone(), plan.E_init.clone(), plan.E_pair.clone(), plan.E_node_x.clone()]
+        if keep:
+            smp = plan.sample(d["eps"])
+            outs += [smp] + list(plan.vjp(d["g"][0], d["g"][1], d["g"][2], d["g"][3], d["eps"], smp))
+        return outs
+
+    for keep in (True, False):
+        alone = []
+        for i in range(2):
+            alone.append(one_pass(LDSEStepPlan(B, T, n, dev, options=opts[i]), data[i], keep))
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+        plans = [LDSEStepPlan(B, T, n, dev, options=opts[i]) for i in range(2)]
+        torch.cuda.synchronize()
+        both = [None, None]
+        for rep in range(3):                                   # interleaved: the two streams' work overlaps
+            for i in range(2):
+                with torch.cuda.stream(streams[i]):
+                    both[i] = one_pass(plans[i], data[i], keep)
+        torch.cuda.synchronize()
+        for i in range(2):
+            for a, b in zip(both[i], alone[i]):
+                assert torch.equal(a, b)
