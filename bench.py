@@ -39,7 +39,7 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x (16x16x4x2 flop / 64 clk, too
 # batch is not specified there: 512 sequences per GPU = two workgroups per CU)
 WORKLOADS = {"lds10": (200, 10, 512), "lds64": (1000, 64, 512)}
 # committed rocprofv3 PMC passes (profiles/run_profile.sh), by (kernel family, sequences per GPU)
-PMC_PROFILES = {("twoend", 512): "r2_twoend", ("twoend", 4096): "r2_twoend_b4096",
+PMC_PROFILES = {("twoend", 512): "r3_twoend", ("twoend_rpc", 4096): "r3_twoend_b4096",
                 ("split", 512): "r1_final", ("packed", 4096): "r1_final_b4096", ("tile", 512): "r1_tile_n64_b512"}
 
 
@@ -76,6 +76,9 @@ def kernel_name(options, B, T, n):
     twoend = 0 if options & _lib.OPT_TWOEND_OFF else (2 if options & _lib.OPT_TWOEND_FULL else 1)
     split_max = (1 << 30) if options & _lib.OPT_LAYOUT_SPLIT else (0 if options & _lib.OPT_LAYOUT_PACKED else 1023)
     if twoend and n <= 10 and T >= 4:
+        layout = 1 if options & _lib.OPT_LAYOUT_SPLIT else (2 if options & _lib.OPT_LAYOUT_PACKED else 0)
+        if twoend == 1 and (layout == 2 or (layout == 0 and B >= 1025)):    # TE_RPC_MIN_B (csrc/lds_args.hpp)
+            return "twoend_rpc", "svae::lds_estep_twoend_rpc_kernel<%d>" % n
         if twoend == 1 and B <= 512:     # TE_S4_MAX_B (csrc/lds_args.hpp): one chain per wavefront in the smoother phase
             return "twoend", "svae::lds_estep_twoend_kernel<%d,false,true,false,false,true>" % n
         return "twoend", "svae::lds_estep_twoend_kernel<%d,false,%s>" % (n, "true" if twoend == 1 else "false")

@@ -103,7 +103,9 @@ int svae_lds_filter_f64(int B, int T, int n, int inhomog, int pair_batched, unsi
  * devices may use different options at the same time.
  *
  * Default dispatch of svae_lds_estep_f64: with keep == 0, n <= 10 and T >= 4 the two-ended kernel (block elimination
- * from both ends of the chain, meeting in the middle: half the serial depth; lean hand-off record).  With keep != 0,
+ * from both ends of the chain, meeting in the middle: half the serial depth; lean hand-off record) -- up to 512
+ * sequences one sequence per workgroup (shortest instruction stream per sequence), above two sequences per wavefront
+ * (fewest instructions per sequence).  With keep != 0,
  * n <= 10, T >= 4 and B <= 1023 the call runs TWO kernels side by side, joined by events before it returns to the
  * caller's stream: the two-ended E-step (statistics, log-normaliser, and the cross moments the VJP reads) and the
  * one-directional filter (hand-off records and LDL' factors for svae_lds_sample_f64 / svae_lds_estep_vjp_f64); the
@@ -118,7 +120,8 @@ int svae_lds_filter_f64(int B, int T, int n, int inhomog, int pair_batched, unsi
 #define SVAE_OPT_TWOEND_OFF     0x01u   /* never the two-ended kernel (one-directional kernels only) */
 #define SVAE_OPT_TWOEND_FULL    0x02u   /* two-ended kernel with the full hand-off record (no lean record) */
 #define SVAE_OPT_LAYOUT_SPLIT   0x04u   /* one sequence per wavefront whatever B */
-#define SVAE_OPT_LAYOUT_PACKED  0x08u   /* four sequences per wavefront whatever B */
+#define SVAE_OPT_LAYOUT_PACKED  0x08u   /* several sequences per wavefront whatever B (two-ended kernel: two, one DPP row
+                                           per elimination chain; one-directional kernels: four) */
 #define SVAE_OPT_PRODUCERS_ON   0x10u   /* producer / helper wavefronts whatever B */
 #define SVAE_OPT_PRODUCERS_OFF  0x20u   /* never */
 #define SVAE_OPT_ALL            0x3fu   /* (contradictory pairs or unknown bits: the call returns -24) */

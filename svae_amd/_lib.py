@@ -21,6 +21,7 @@ OPT_DEFAULT, OPT_TWOEND_OFF, OPT_TWOEND_FULL = 0x00, 0x01, 0x02
 OPT_LAYOUT_SPLIT, OPT_LAYOUT_PACKED, OPT_PRODUCERS_ON, OPT_PRODUCERS_OFF = 0x04, 0x08, 0x10, 0x20
 # names used by tests / tools / bench.py --kernel for the E-step kernel families
 KERNEL_OPTIONS = {"auto": OPT_DEFAULT, "twoend": OPT_DEFAULT, "twoend_full": OPT_TWOEND_FULL,
+                  "twoend_seq": OPT_LAYOUT_SPLIT, "twoend_rpc": OPT_LAYOUT_PACKED,
                   "split": OPT_TWOEND_OFF | OPT_LAYOUT_SPLIT, "packed": OPT_TWOEND_OFF | OPT_LAYOUT_PACKED}
 
 _c_double_p = ctypes.c_void_p   # raw device pointers travel as integers

@@ -29,6 +29,8 @@ constexpr long te_seq_doubles(int n, int T) { return 2 * te_chain_doubles(n, T);
 constexpr int TE_MAX_N = 10;
 constexpr int TE_MIN_T = 4;
 constexpr int TE_S4_MAX_B = 512;     // two-ended kernel: second wavefront per sequence in the smoother phase up to this batch
+constexpr int TE_RPC_MIN_B = 1025;   // two-ended kernel: two sequences per wavefront (row-per-chain layout) from this batch
+                                     // (measured T = 200, n = 10: 1024 sequences 0.200 vs 0.237 ms, 1536: 0.321 vs 0.272 ms)
 // MIX launches of the two-ended kernel (K parameter sets mixed per step, svae_slds_lds_meanfield_f64): LDS
 // tables of 16-byte entries (two states each), see lds_estep_twoend.hpp
 constexpr int te_mix_nxl(int n) { return 15 - n; }                 // right-hand-side lanes n..14

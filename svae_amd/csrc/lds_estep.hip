@@ -12,7 +12,7 @@
 extern "C" {
 #define SVAE_DECL_(NN) int svae_lds_launch_n##NN(const svae::LdsArgs*, int, void*); \
   int svae_lds_launch_split_n##NN(const svae::LdsArgs*, int, void*);           \
-  int svae_lds_launch_twoend_n##NN(const svae::LdsArgs*, int, int, void*);          \
+  int svae_lds_launch_twoend_n##NN(const svae::LdsArgs*, int, int, int, void*);          \
   int svae_lds_launch_twoend_mix_n##NN(const svae::LdsArgs*, void*);          \
   int svae_lds_launch_filter_n##NN(const svae::LdsArgs*, int, void*);          \
   int svae_lds_launch_filter_split_n##NN(const svae::LdsArgs*, int, void*);    \
@@ -73,14 +73,15 @@ extern "C" {
 // stages split across the DPP rows: lds_estep_split.hpp), larger ones the packed kernel (four sequences per
 // wavefront).  Measured crossover split/packed on MI355X (T=200, n=10): B ~ 1024 (one wavefront per SIMD).
 // The selection is a function of the call's arguments only: the library holds no process-global state.
-struct Selection { int twoend; bool split; int prod_max_b; };
+struct Selection { int twoend; bool split; int layout; int prod_max_b; };
 static bool decode_options(unsigned options, int B, Selection* s) {
   if (options & ~SVAE_OPT_ALL) return false;
   if ((options & SVAE_OPT_TWOEND_OFF) && (options & SVAE_OPT_TWOEND_FULL)) return false;
   if ((options & SVAE_OPT_LAYOUT_SPLIT) && (options & SVAE_OPT_LAYOUT_PACKED)) return false;
   if ((options & SVAE_OPT_PRODUCERS_ON) && (options & SVAE_OPT_PRODUCERS_OFF)) return false;
   s->twoend = (options & SVAE_OPT_TWOEND_OFF) ? 0 : (options & SVAE_OPT_TWOEND_FULL) ? 2 : 1;
-  s->split = (options & SVAE_OPT_LAYOUT_SPLIT) ? true : (options & SVAE_OPT_LAYOUT_PACKED) ? false : B <= 1023;
+  s->layout = (options & SVAE_OPT_LAYOUT_SPLIT) ? 1 : (options & SVAE_OPT_LAYOUT_PACKED) ? 2 : 0;
+  s->split = s->layout == 1 || (s->layout == 0 && B <= 1023);
   s->prod_max_b = (options & SVAE_OPT_PRODUCERS_ON) ? 0x7fffffff : (options & SVAE_OPT_PRODUCERS_OFF) ? 0 : 1024;
   return true;
 }
@@ -182,7 +183,7 @@ int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int k
     int rc = -3, rc2 = -3;
     switch (n) {
 #define SVAE_CASE_(NN) case NN: rc = svae_lds_launch_filter_1r_n##NN(&f, inhomog, aux); \
-                                rc2 = svae_lds_launch_twoend_n##NN(&e, inhomog, !inhomog, us); break;
+                                rc2 = svae_lds_launch_twoend_n##NN(&e, inhomog, !inhomog, 1, us); break;
 #define SVAE_CASE(NN) SVAE_CASE_(NN)
 #ifdef SVAE_ONLY_N
       SVAE_CASE(SVAE_ONLY_N)
@@ -198,7 +199,7 @@ int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int k
   }
   if (twoend && !keep && n <= svae::TE_MAX_N && T >= svae::TE_MIN_T) {
     switch (n) {
-#define SVAE_CASE_(NN) case NN: return svae_lds_launch_twoend_n##NN(&a, inhomog, twoend == 1 && !inhomog, stream);
+#define SVAE_CASE_(NN) case NN: return svae_lds_launch_twoend_n##NN(&a, inhomog, twoend == 1 && !inhomog, sel.layout, stream);
 #define SVAE_CASE(NN) SVAE_CASE_(NN)
 #ifdef SVAE_ONLY_N
       SVAE_CASE(SVAE_ONLY_N)

@@ -8,6 +8,7 @@
 #include "lds_estep_kernel.hpp"
 #include "lds_estep_split.hpp"
 #include "lds_estep_twoend.hpp"
+#include "lds_estep_twoend_rpc.hpp"
 #include "lds_filter_1r.hpp"
 
 #ifndef SVAE_N
@@ -28,7 +29,13 @@ extern "C" int SVAE_CAT(svae_lds_launch_split_n, SVAE_N)(const svae::LdsArgs* a,
   return svae::launch_estep_split<SVAE_N>(*a, inhomog != 0, (hipStream_t)stream);
 }
 
-extern "C" int SVAE_CAT(svae_lds_launch_twoend_n, SVAE_N)(const svae::LdsArgs* a, int inhomog, int lean, void* stream) {
+// layout: 0 = by batch size (one sequence per wavefront below TE_RPC_MIN_B, two per wavefront from there), 1 = one sequence
+// per wavefront, 2 = two per wavefront (row-per-chain kernel; homogeneous lean launches without the cross-moment hand-off)
+extern "C" int SVAE_CAT(svae_lds_launch_twoend_n, SVAE_N)(const svae::LdsArgs* a, int inhomog, int lean, int layout,
+                                                          void* stream) {
+  const bool rpc_ok = !inhomog && lean && !a->ws3 && a->T >= svae::TE_MIN_T;
+  if (rpc_ok && (layout == 2 || (layout == 0 && a->B >= svae::TE_RPC_MIN_B)))
+    return svae::launch_estep_twoend_rpc<SVAE_N>(*a, (hipStream_t)stream);
   return svae::launch_estep_twoend<SVAE_N>(*a, inhomog != 0, lean != 0, (hipStream_t)stream);
 }
 

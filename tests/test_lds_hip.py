@@ -18,11 +18,12 @@ from oracle import lds_numpy, ref  # noqa: E402  (checker only)
 LDS_CASES = ["lds_T5_n3", "lds_T20_n10", "lds_T200_n10", "lds_T1_n4", "lds_T2_n15"]
 
 
-@pytest.fixture(params=["twoend", "twoend_full", "split", "packed"], autouse=True)
+@pytest.fixture(params=["twoend", "twoend_full", "twoend_seq", "twoend_rpc", "split", "packed"], autouse=True)
 def kernel_variant(request):
     """Run every test through all E-step kernels: the two-ended one (the default for n <= 10, T >= 4
-    without sampler / VJP hand-off) with its lean and its full hand-off record, and the one-directional
-    small-batch (one sequence per wavefront) and packed (four per wavefront) variants."""
+    without sampler / VJP hand-off) with its lean and its full hand-off record, forced to one sequence per
+    wavefront / to the row-per-chain layout (two sequences per wavefront: the default above 512 sequences), and
+    the one-directional small-batch (one sequence per wavefront) and packed (four per wavefront) variants."""
     from svae_amd import _lib
     from svae_amd.lds.lds_inference import set_default_options
     old = set_default_options(_lib.KERNEL_OPTIONS[request.param])      # (a per-plan word; the library has no state)

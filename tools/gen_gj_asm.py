@@ -14,6 +14,12 @@ The asm template must be a string literal, hence a generator (python tools/gen_g
 import os
 
 DPP = "row_mask:0xf bank_mask:0xf"
+# 1/pn to full fp64 accuracy from the v_rcp_f64 seed t0 (relative error e0 = 1 - pn t0 ~ 2^-23: "2^29 ulp"):
+# ONE cubic step  rn = t0 (1 + e0 + e0^2)  -- error e0^3 ~ 2^-69 -- instead of two Newton steps (4 FMAs, 2^-92)
+RCP_CHAIN = ["v_rcp_f64 %[t0], %[pn]",
+             "v_fma_f64 %[e0], -%[pn], %[t0], 1.0",
+             "v_fma_f64 %[e0], %[e0], %[e0], %[e0]",
+             "v_fma_f64 %[rn], %[t0], %[e0], %[t0]"]
 
 
 def pivot_block(N, k):
@@ -35,11 +41,7 @@ def pivot_block(N, k):
         if len(pre) < 2:
             L.append("s_nop %d" % (1 - len(pre)))
         L.append("v_mov_b64_dpp %[pn], %[m{i}] row_newbcast:{i} {d}".format(i=k + 1, d=DPP))
-        chain = ["v_rcp_f64 %[t0], %[pn]",
-                 "v_fma_f64 %[e0], -%[pn], %[t0], 1.0",
-                 "v_fma_f64 %[t0], %[t0], %[e0], %[t0]",
-                 "v_fma_f64 %[e0], -%[pn], %[t0], 1.0",
-                 "v_fma_f64 %[rn], %[t0], %[e0], %[t0]"]
+        chain = RCP_CHAIN
         for ci, ins in enumerate(chain):
             L.append(ins)
             if ci < len(chain) - 1:
@@ -87,6 +89,71 @@ def emit(N, rows=False):
     return "\n".join(out)
 
 
+def pivot_block2(N, k):
+    """Two registers per row (row-per-chain layout, lds_estep_twoend_rpc.hpp): a_i = [P row | .. | h] (lanes < N, lane
+    15), b_i = right-hand-side columns (lanes < N).  Row update = two DPP FMAs, both broadcasting the multiplier
+    f_i = lane k of a_i: the b update first (the a update rewrites a_i; its lane k keeps f_i because ru lane k = 0).
+    Operands as pivot_block plus %[b0..]; the scaled pivot row of the b set is formed in place (b_k *= 1/p_k)."""
+    L = []
+    L.append("v_fma_f64 %[ru], -%[p], %[e], %[a{k}]".format(k=k))          # lane k -> exactly 0
+    L.append("v_mul_f64 %[b{k}], %[b{k}], %[ri]".format(k=k))               # scaled pivot row, b set (in place)
+    L.append("v_mul_f64 %[ru], %[ru], %[ri]")                               # scaled pivot row, a set
+    L.append("v_fma_f64 %[vf], -%[ri], %[e], %[vf]")
+    L.append("v_fma_f64 %[q], %[a{k}], %[ru], %[q]".format(k=k))
+    updb = lambda i: "v_fmac_f64_dpp %[b{i}], %[a{i}], -%[b{k}] row_newbcast:{k} {d}".format(i=i, k=k, d=DPP)
+    upda = lambda i: "v_fmac_f64_dpp %[a{i}], %[a{i}], -%[ru] row_newbcast:{k} {d}".format(i=i, k=k, d=DPP)
+    others = list(range(k + 2, N)) + list(range(0, k))
+    work = []
+    for i in others:
+        work += [updb(i), upda(i)]
+    if k + 1 < N:
+        L += [updb(k + 1), upda(k + 1)]
+        pre = work[:2]
+        work = work[2:]
+        L += pre
+        if len(pre) < 2:
+            L.append("s_nop %d" % (1 - len(pre)))
+        L.append("v_mov_b64_dpp %[pn], %[a{i}] row_newbcast:{i} {d}".format(i=k + 1, d=DPP))
+        for ci, ins in enumerate(RCP_CHAIN):
+            L.append(ins)
+            if ci < len(RCP_CHAIN) - 1:
+                if work:
+                    L.append(work.pop(0))
+                elif ci == 0:
+                    L.append("s_nop 0")            # trans result -> VALU use
+        L += work
+        L.append("v_add_f64 %[a{k}], %[ru], -%[e]".format(k=k))            # pivot row as kept: lane k = -1
+        return L, True
+    L += work
+    L.append("v_add_f64 %[a{k}], %[ru], -%[e]".format(k=k))
+    return L, False
+
+
+def emit2(N):
+    out = []
+    out.append("template <>")
+    out.append("__device__ __forceinline__ void gauss_jordan_2r_asm<%d>(double (&A)[%d], double (&B)[%d], const double (&E)[%d], "
+               "double& qacc, double& vfull) {" % (N, N, N, N))
+    out.append("  double p = bcast_fenced<0>(A[0]);")
+    out.append("  double rinv = rcp_nr(p);")
+    out.append("  double ru, t0, e0, pn, rn;")
+    out.append("  (void)t0; (void)e0; (void)pn; (void)rn;")
+    for k in range(N):
+        lines, has_next = pivot_block2(N, k)
+        body = "\\n\\t\"\n      \"".join(lines)
+        rowops = ", ".join('[a%d] "+v"(A[%d])' % (i, i) for i in range(N)) + ", " + \
+            ", ".join('[b%d] "+v"(B[%d])' % (i, i) for i in range(N))
+        outs = rowops + ', [q] "+v"(qacc), [vf] "+v"(vfull), [ru] "=&v"(ru)'
+        if has_next:
+            outs += ', [t0] "=&v"(t0), [e0] "=&v"(e0), [pn] "=&v"(pn), [rn] "=&v"(rn)'
+        ins = '[e] "v"(E[%d]), [p] "v"(p), [ri] "v"(rinv)' % k
+        out.append("  asm volatile(\n      \"%s\"\n      : %s\n      : %s);" % (body, outs, ins))
+        if has_next:
+            out.append("  p = pn; rinv = rn;")
+    out.append("}")
+    return "\n".join(out)
+
+
 HEADER = '''// gj1r_gen.hpp -- GENERATED by tools/gen_gj_asm.py; do not edit.
 // In-place Gauss-Jordan on one register per row (see gauss_jordan_1r in lds_estep_twoend.hpp for the
 // algorithm and the meaning of the operands), one hand-scheduled inline-asm block per pivot.
@@ -102,6 +169,10 @@ __device__ __forceinline__ void gauss_jordan_1r_asm(double (&M)[N], const double
 template <int N>
 __device__ __forceinline__ void gauss_jordan_1r_asm_rows(double (&M)[N], const double (&E)[N], double& qacc,
                                                          double& vfull, double (&RU)[N]);
+// two registers per row (row-per-chain layout, lds_estep_twoend_rpc.hpp): A = [P | h], B = right-hand-side columns
+template <int N>
+__device__ __forceinline__ void gauss_jordan_2r_asm(double (&A)[N], double (&B)[N], const double (&E)[N], double& qacc,
+                                                    double& vfull);
 
 '''
 
@@ -111,6 +182,7 @@ def generate():
     for N in range(1, 11):
         parts.append(emit(N) + "\n\n")
         parts.append(emit(N, rows=True) + "\n\n")
+        parts.append(emit2(N) + "\n\n")
     parts.append("}  // namespace svae\n")
     return "".join(parts)
 
