@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SVAE_HIP_ABI_VERSION 6   /* 6: per-call `options` word replaces the process-global svae_lds_set_* selectors (re-entrant library); 5: + svae_lds_set_prod_max_b; 4: + svae_slds_lds_meanfield_f64, svae_gmm_mw_*, svae_lds_global_step_f64, svae_lds_natgrad_f64, svae_lds_tile_vjp_f64; 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
+#define SVAE_HIP_ABI_VERSION 6   /* 6: per-call `options` word replaces the process-global svae_lds_set_* selectors (re-entrant library), + svae_slds_hmm_meanfield_f64, svae_slds_sweep_glue_f64, g_E_pair in svae_lds_tile_vjp_f64; 5: + svae_lds_set_prod_max_b; 4: + svae_slds_lds_meanfield_f64, svae_gmm_mw_*, svae_lds_global_step_f64, svae_lds_natgrad_f64, svae_lds_tile_vjp_f64; 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
 #define SVAE_LDS_MAX_N 15   /* register/DPP path: one 16-lane row per sequence, n+1 <= 16 */
 #define SVAE_LDS_TILE_MAX_N 64   /* 16 <= n <= 64: LDS-tiled MFMA path (E-step only: keep must be 0) */
 
@@ -304,6 +304,32 @@ int svae_hmm_estep_f64(int B, int T, int K, int pair_batched,
                        const double* node_params,
                        double* logZ, double* E_init, double* E_trans, double* E_states,
                        void* workspace, size_t ws_bytes, void* stream);
+
+/* HMM step of the SLDS coordinate ascent on the rows `seq_index` lists (B of `rows`; NULL: rows 0..B-1):
+ *   hmm_meanfield + get_arhmm_local_nodeparams   /root/reference/svae/models/slds_svae.py:108-115, 131-147
+ * Node log-potentials: `node_params` (rows,T,K) if given; else built on the fly from the outputs of
+ * svae_slds_lds_meanfield_f64 --  node[b,0,k] = <E x_0 x_0', init_J_k> + <E x_0, init_h_k> + cinit_k  (lds_E_init
+ * (rows, n*n+n), init_J (K,n,n), init_h (K,n), cinit (K) = the init potential's constants),
+ * node[b,t,k] = pair_contr[b,t-1,0,k] + pair_contr[b,t,1,k] + lz_k  (t >= 1; lz (K) = the pair potentials' constants).
+ * Outputs as svae_hmm_estep_f64, written at the listed rows only; node_out (rows,T,K) or NULL: the potentials used. */
+int svae_slds_hmm_meanfield_f64(int B, int rows, int T, int K, int n,
+                                const double* hmm_init, const double* hmm_pair, const double* node_params,
+                                const double* pair_contr, const double* lds_E_init, const double* init_J,
+                                const double* init_h, const double* cinit, const double* lz,
+                                const int32_t* seq_index,
+                                double* logZ, double* E_init, double* E_trans, double* E_states,
+                                double* node_out, void* workspace, size_t ws_bytes, void* stream);
+
+/* End of one sweep of the SLDS coordinate ascent (optimize_local_meanfield, slds_svae.py:159-175), after the HMM and the
+ * fused LDS kernels, for the B listed rows:  lds_vlb = lognorm + <E z_0, cinit> + sum_{t>=1} <E z_t, lz>;
+ * vlb_new = hmm_vlb + lds_vlb;  iters += 1;  the row keeps iterating unless |vlb_new - vlb| < tol (:170-172);  vlb = vlb_new.
+ * next_index (B) / next_count (1): the rows still iterating, in the order of `seq_index` (a different buffer).
+ * keep_scratch: B int32.  No host arithmetic is needed between two sweeps (the caller reads next_count to size them). */
+int svae_slds_sweep_glue_f64(int B, int T, int K, double tol, const int32_t* seq_index,
+                             const double* E_states, const double* cinit, const double* lz,
+                             const double* lognorm, const double* hmm_vlb, double* lds_vlb, double* vlb,
+                             int32_t* iters, int32_t* keep_scratch, int32_t* next_index, int32_t* next_count,
+                             void* stream);
 
 /* GMM mean-field fixed point + global statistics for one minibatch of T points
  * [local_meanfield, /root/reference/svae/models/gmm.py:62-88; meanfield_fixed_point :90-110;

@@ -55,6 +55,10 @@ SIGNATURES = {
     "svae_hmm_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
     "svae_hmm_estep_f64": (ctypes.c_int, [ctypes.c_int] * 4 + [_c_double_p] * 7
                            + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "svae_slds_hmm_meanfield_f64": (ctypes.c_int, [ctypes.c_int] * 5 + [_c_double_p] * 9 + [_c_int_p] + [_c_double_p] * 5
+                                    + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "svae_slds_sweep_glue_f64": (ctypes.c_int, [ctypes.c_int] * 3 + [ctypes.c_double, _c_int_p] + [_c_double_p] * 7
+                                 + [_c_int_p] * 4 + [ctypes.c_void_p]),
     "svae_gmm_meanfield_f64": (ctypes.c_int, [ctypes.c_int] * 3 + [_c_double_p] * 5
                                + [ctypes.c_double, ctypes.c_int] + [_c_double_p] * 8
                                + [_c_int_p] * 3 + [ctypes.c_void_p]),

@@ -43,17 +43,30 @@ struct HmmArgs {
   double* __restrict__ E_trans;           // (B,K,K)
   double* __restrict__ E_states;          // (B,T,K)
   double* __restrict__ ws;                // (B,T,HMM_WS)
+  // indexed launches (SLDS coordinate ascent): slot i of the launch works on row seq_index[i] of every array
+  const int32_t* __restrict__ seq_index;  // (B) or nullptr
+  // FUSED node potentials (get_arhmm_local_nodeparams, slds_svae.py:131-147, from the fused LDS mean-field kernel's
+  // outputs): node[b,0,k] = <E x0 x0', J_k> + <E x0, h_k> + cinit_k;  node[b,t,k] = pc[b,t-1,0,k] + pc[b,t,1,k] + lz_k
+  int n;                                  // latent dimension of the LDS
+  const double* __restrict__ pair_contr;  // (rows,T,2,K)
+  const double* __restrict__ lds_E_init;  // (rows, n*n+n)
+  const double* __restrict__ init_J;      // (K,n,n)
+  const double* __restrict__ init_h;      // (K,n)
+  const double* __restrict__ cinit;       // (K)
+  const double* __restrict__ lz;          // (K)
+  double* __restrict__ node_out;          // (rows,T,K) or nullptr: the node potentials used
 };
 constexpr int HMM_WS = 34;                // [alpha (16) | e/c or its log-space stand-in (16) | flag | pad]
 constexpr double HMM_TINY = 1e-200;
 
-template <int K>
+template <int K, bool FUSED = false>
 __global__ __launch_bounds__(64) void hmm_estep_kernel(const HmmArgs a) {
   const int lane = threadIdx.x;
   const int c = lane & 15;
   const int brow = blockIdx.x * 4 + (lane >> 4);
   const bool valid = brow < a.B;
-  const int b = valid ? brow : a.B - 1;
+  const int bslot = valid ? brow : a.B - 1;
+  const int b = a.seq_index ? a.seq_index[bslot] : bslot;
   const bool col = c < K;
   const int cc = col ? c : 0;
   const int T = a.T;
@@ -73,7 +86,30 @@ __global__ __launch_bounds__(64) void hmm_estep_kernel(const HmmArgs a) {
   double P[K], PT[K];
   static_for<0, K>([&](auto j) { P[j] = col ? exp(lp[j] - pmax) : 0.0; PT[j] = col ? exp(lpT[j] - pmax) : 0.0; });
 
-  const double* node = a.node_params + ((long)b * T) * K + cc;
+  const double* node = FUSED ? nullptr : a.node_params + ((long)b * T) * K + cc;
+  // FUSED: node potential of step t >= 1 = pc[t-1][0] + pc[t][1] + lz (two loads instead of one)
+  const double* pc = FUSED ? a.pair_contr + ((long)b * T) * 2 * K + cc : nullptr;
+  const double lzc = FUSED ? a.lz[cc] : 0.0;
+  auto node_at = [&](int t) -> double {
+    if constexpr (FUSED) return (pc[(long)(t - 1) * 2 * K] + pc[(long)t * 2 * K + K]) + lzc;     // (t >= 1)
+    else return node[(long)t * K];
+  };
+  double node0;
+  if constexpr (FUSED) {
+    // <E x0 x0', J_c> + <E x0, h_c> + cinit_c: lane c = state (once per sequence)
+    const int n = a.n;
+    const double* ei = a.lds_E_init + (long)b * (n * n + n);
+    const double* Jc = a.init_J + (long)cc * n * n;
+    const double* hc = a.init_h + (long)cc * n;
+    double s0 = 0.0;
+    for (int q = 0; q < n * n; ++q) s0 = __builtin_fma(ei[q], Jc[q], s0);
+    double s1 = 0.0;
+    for (int q = 0; q < n; ++q) s1 = __builtin_fma(ei[n * n + q], hc[q], s1);
+    node0 = (s0 + s1) + a.cinit[cc];
+  } else {
+    node0 = node[0];
+  }
+  double* nout = a.node_out ? a.node_out + ((long)b * T) * K + cc : nullptr;
   double* wsb = a.ws + ((long)b * T) * HMM_WS + c;
   double* wflag = a.ws + ((long)b * T) * HMM_WS + 32;
   double one = 1.0;
@@ -83,10 +119,11 @@ __global__ __launch_bounds__(64) void hmm_estep_kernel(const HmmArgs a) {
   long lzE = 0;                // ... exponent
   double lzS = 0.0;            // sum of the subtracted maxima
   double alpha = 0.0;
-  double nd_n = node[0];
+  double nd_n = node0;
   for (int t = 0; t < T; ++t) {
     double nd = col ? nd_n : NEG_BIG;
-    if (t + 1 < T) nd_n = node[(long)(t + 1) * K];
+    if (nout && valid && col) nout[(long)t * K] = nd_n;
+    if (t + 1 < T) nd_n = node_at(t + 1);
     if (t == 0) nd += col ? a.init_params[cc] : 0.0;
     // m = max_k node[k]  (broadcast-and-max over the row)
     double m = NEG_BIG;
@@ -235,8 +272,74 @@ __global__ __launch_bounds__(64) void hmm_estep_kernel(const HmmArgs a) {
 
 template <int K>
 static int launch_hmm(const HmmArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL((hmm_estep_kernel<K>), dim3((a.B + 3) / 4), dim3(64), 0, s, a);
+  if (a.pair_contr) hipLaunchKernelGGL((hmm_estep_kernel<K, true>), dim3((a.B + 3) / 4), dim3(64), 0, s, a);
+  else hipLaunchKernelGGL((hmm_estep_kernel<K, false>), dim3((a.B + 3) / 4), dim3(64), 0, s, a);
   return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+// ---- glue of one SLDS coordinate-ascent sweep (slds_svae.py:159-175), after the HMM and the fused LDS kernels ----------
+// one wavefront per active slot: lds_vlb = lognorm + <E z_0, cinit> + sum_{t>=1} <E z_t, lz>;  vlb_new = hmm_vlb + lds_vlb;
+// iters += 1;  keep[slot] = |vlb_new - vlb| >= tol;  vlb = vlb_new
+struct SldsGlueArgs {
+  int nrun, T, K;
+  double tol;
+  const int32_t* __restrict__ seq_index;   // (nrun) or nullptr
+  const double* __restrict__ E_states;     // (rows,T,K)
+  const double* __restrict__ cinit;        // (K)
+  const double* __restrict__ lz;           // (K)
+  const double* __restrict__ lognorm;      // (rows) fused LDS kernel
+  const double* __restrict__ hmm_vlb;      // (rows)
+  double* __restrict__ lds_vlb;            // (rows) out
+  double* __restrict__ vlb;                // (rows) in/out
+  int32_t* __restrict__ iters;             // (rows) in/out
+  int32_t* __restrict__ keep;              // (nrun) out: 1 = still iterating
+};
+
+__global__ __launch_bounds__(256) void slds_glue_kernel(const SldsGlueArgs a) {
+  const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (slot >= a.nrun) return;
+  const int r = a.seq_index ? a.seq_index[slot] : slot;
+  const double* es = a.E_states + (long)r * a.T * a.K;
+  const int K = a.K, TK = a.T * K;
+  double acc = 0.0;
+  for (int q = lane; q < TK; q += 64) {
+    const int k = q % K;
+    acc = __builtin_fma(es[q], q < K ? a.cinit[k] : a.lz[k], acc);
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);       // (fixed order: reproducible)
+  if (lane == 0) {
+    const double lv = a.lognorm[r] + acc;
+    const double nv = a.hmm_vlb[r] + lv;
+    a.lds_vlb[r] = lv;
+    a.iters[r] += 1;
+    a.keep[slot] = !(fabs(nv - a.vlb[r]) < a.tol) ? 1 : 0;
+    a.vlb[r] = nv;
+  }
+}
+
+// stable compaction of the active list: out = [seq_index[i] : keep[i]], count[0] = its length (one workgroup)
+__global__ __launch_bounds__(1024) void slds_compact_kernel(int nrun, const int32_t* __restrict__ seq_index,
+                                                            const int32_t* __restrict__ keep, int32_t* __restrict__ out,
+                                                            int32_t* __restrict__ count) {
+  __shared__ int part[1024];
+  const int tid = threadIdx.x;
+  const int per = (nrun + 1023) / 1024;
+  const int lo = tid * per, hi = lo + per < nrun ? lo + per : nrun;
+  int cnt = 0;
+  for (int i = lo; i < hi; ++i) cnt += keep[i] != 0;
+  part[tid] = cnt;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {          // inclusive scan
+    const int v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int pos = part[tid] - cnt;
+  for (int i = lo; i < hi; ++i)
+    if (keep[i] != 0) out[pos++] = seq_index ? seq_index[i] : i;
+  if (tid == 1023) count[0] = part[1023];
 }
 
 }  // namespace svae
@@ -245,6 +348,8 @@ extern "C" size_t svae_hmm_workspace_bytes(int B, int T, int K) {
   if (B <= 0 || T <= 0 || K <= 0 || K > 16) return 0;
   return (size_t)B * T * svae::HMM_WS * sizeof(double);
 }
+
+static int hmm_dispatch(const svae::HmmArgs& a, void* stream);
 
 extern "C" int svae_hmm_estep_f64(int B, int T, int K, int pair_batched,
                                   const double* init_params, const double* pair_params,
@@ -268,6 +373,72 @@ extern "C" int svae_hmm_estep_f64(int B, int T, int K, int pair_batched,
   a.init_params = init_params; a.pair_params = pair_params; a.node_params = node_params;
   a.logZ = logZ; a.E_init = E_init; a.E_trans = E_trans; a.E_states = E_states;
   a.ws = (double*)workspace;
+  a.seq_index = nullptr; a.n = 0; a.pair_contr = nullptr; a.lds_E_init = nullptr; a.init_J = nullptr; a.init_h = nullptr;
+  a.cinit = nullptr; a.lz = nullptr; a.node_out = nullptr;
+  return hmm_dispatch(a, stream);
+}
+
+// HMM step of the SLDS coordinate ascent (hmm_meanfield, /root/reference/svae/models/slds_svae.py:108-115) on the rows
+// `seq_index` lists, the node potentials taken from `node_params` (rows,T,K) if given, else built on the fly from the
+// fused LDS mean-field kernel's outputs (get_arhmm_local_nodeparams, :131-147).
+extern "C" int svae_slds_hmm_meanfield_f64(int B, int rows, int T, int K, int n,
+                                           const double* hmm_init, const double* hmm_pair, const double* node_params,
+                                           const double* pair_contr, const double* lds_E_init, const double* init_J,
+                                           const double* init_h, const double* cinit, const double* lz,
+                                           const int32_t* seq_index,
+                                           double* logZ, double* E_init, double* E_trans, double* E_states,
+                                           double* node_out, void* workspace, size_t ws_bytes, void* stream) {
+  if (B < 0 || B > rows) return -1;
+  if (T < 1) return -3;
+  if (K < 1 || K > 16) return -4;
+  if (n < 1 || n > 64) return -5;
+  if (!hmm_init) return -6;
+  if (!hmm_pair) return -7;
+  if (!node_params && (!pair_contr || !lds_E_init || !init_J || !init_h || !cinit || !lz)) return -8;
+  if (!logZ) return -16;
+  if (!E_init) return -17;
+  if (!E_trans) return -18;
+  if (!E_states) return -19;
+  if (!workspace || ws_bytes < svae_hmm_workspace_bytes(rows, T, K)) return -21;
+  if (B == 0) return 0;
+  svae::HmmArgs a;
+  a.B = B; a.T = T; a.K = K; a.pair_stride = 0;
+  a.init_params = hmm_init; a.pair_params = hmm_pair; a.node_params = node_params;
+  a.logZ = logZ; a.E_init = E_init; a.E_trans = E_trans; a.E_states = E_states;
+  a.ws = (double*)workspace;
+  a.seq_index = seq_index; a.n = n;
+  a.pair_contr = node_params ? nullptr : pair_contr; a.lds_E_init = lds_E_init; a.init_J = init_J; a.init_h = init_h;
+  a.cinit = cinit; a.lz = lz; a.node_out = node_out;
+  return hmm_dispatch(a, stream);
+}
+
+// After the HMM and the fused LDS kernels of a sweep: per listed row the LDS bound with its mixed constants, the
+// stopping test |vlb_new - vlb| < tol of slds_svae.py:170-172, the sweep counter, and the compacted list of the rows
+// still iterating (`next_index`, `next_count[0]`; stable order) -- no host arithmetic between two sweeps.
+extern "C" int svae_slds_sweep_glue_f64(int B, int T, int K, double tol, const int32_t* seq_index,
+                                        const double* E_states, const double* cinit, const double* lz,
+                                        const double* lognorm, const double* hmm_vlb, double* lds_vlb, double* vlb,
+                                        int32_t* iters, int32_t* keep_scratch, int32_t* next_index, int32_t* next_count,
+                                        void* stream) {
+  if (B < 0) return -1;
+  if (T < 1) return -2;
+  if (K < 1 || K > 16) return -3;
+  if (!E_states || !cinit || !lz || !lognorm || !hmm_vlb) return -6;
+  if (!lds_vlb || !vlb || !iters || !keep_scratch || !next_index || !next_count) return -11;
+  hipStream_t s = (hipStream_t)stream;
+  if (B > 0) {
+    svae::SldsGlueArgs g;
+    g.nrun = B; g.T = T; g.K = K; g.tol = tol; g.seq_index = seq_index; g.E_states = E_states; g.cinit = cinit; g.lz = lz;
+    g.lognorm = lognorm; g.hmm_vlb = hmm_vlb; g.lds_vlb = lds_vlb; g.vlb = vlb; g.iters = iters; g.keep = keep_scratch;
+    hipLaunchKernelGGL(svae::slds_glue_kernel, dim3((B + 3) / 4), dim3(256), 0, s, g);
+    if (hipGetLastError() != hipSuccess) return -1000;
+  }
+  hipLaunchKernelGGL(svae::slds_compact_kernel, dim3(1), dim3(1024), 0, s, B, seq_index, keep_scratch, next_index, next_count);
+  return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+static int hmm_dispatch(const svae::HmmArgs& a, void* stream) {
+  const int K = a.K;
   hipStream_t s = (hipStream_t)stream;
   switch (K) {
 #define SVAE_CASE(KK) case KK: return svae::launch_hmm<KK>(a, s);

@@ -145,11 +145,13 @@ class SLDSMeanfieldPlan(object):
         nbytes = int(_lib.load().svae_slds_lds_meanfield_lds_bytes(n, K))
         return 0 < nbytes <= 160 * 1024
 
-    def launch(self, dense_init, dense_pair, weights, node, seq_index=None):
+    def launch(self, dense_init, dense_pair, weights, node, seq_index=None, nrun=None):
         """dense_init = (J (K,n,n), h (K,n), a (K), b (K)), dense_pair = (J11, J12, J22 (K,n,n), logZ (K)),
-        weights (B,T,K), node = (J, h[, logZ]); seq_index: int32 tensor of the rows to process, or None = all."""
+        weights (B,T,K), node = (J, h[, logZ]); seq_index: int32 tensor of the rows to process (its first `nrun`
+        entries; default all of it), or None = all rows."""
         p = _lib.ptr
-        nrun = self.B if seq_index is None else int(seq_index.numel())
+        if nrun is None:
+            nrun = self.B if seq_index is None else int(seq_index.numel())
         rc = self.lib.svae_slds_lds_meanfield_f64(
             nrun, self.B, self.T, self.n, self.K, p(dense_init[0]), p(dense_init[1]),
             p(dense_pair[0]), p(dense_pair[1]), p(dense_pair[2]), p(weights),
@@ -187,42 +189,56 @@ def _arhmm_nodeparams_from_path(dense_init, dense_pair, x):
 
 def _optimize_local_meanfield_fused(hmm_init, hmm_pair, dense_init, dense_pair, node, init_eps, tol, max_iter,
                                     reference_compat=False):
-    """The coordinate ascent of optimize_local_meanfield on the fused kernel.  Same iteration as the
-    materialised path (and the reference): hmm_meanfield -> lds_meanfield -> |delta vlb| < tol per sequence."""
+    """The coordinate ascent of optimize_local_meanfield on the fused kernels.  Same iteration as the materialised path
+    (and the reference): hmm_meanfield -> lds_meanfield -> |delta vlb| < tol per sequence.  A sweep is three launches on
+    the list of sequences still iterating -- the HMM kernel (node potentials built on the fly from the previous LDS
+    step's contracted statistics), the fused LDS kernel, and the glue kernel (bounds, stopping test, sweep counters,
+    compaction of the list) -- with ONE 4-byte read by the host (the length of the next list, which sizes the next
+    launches); no torch arithmetic in the loop."""
     B, T, n = node[1].shape
     K = dense_init[0].shape[0]
     dev = node[1].device
+    lib, p = _lib.load(), _lib.ptr
     plan = SLDSMeanfieldPlan(B, T, n, K, dev)
     dense_init = tuple(x.contiguous() for x in dense_init)
     dense_pair = tuple(x.contiguous() for x in dense_pair)
+    f64 = dict(dtype=torch.float64, device=dev)
+    i32 = dict(dtype=torch.int32, device=dev)
     x = _initial_sample_path(node, init_eps)
-    node_hmm = _arhmm_nodeparams_from_path(dense_init, dense_pair, x)
-    vlb = torch.full((B,), -float("inf"), dtype=torch.float64, device=dev)
-    active = torch.ones(B, dtype=torch.bool, device=dev)
-    iters = torch.zeros(B, dtype=torch.int64, device=dev)
-    st, rows, rows32 = None, None, None      # rows: the sequences still iterating (None = all)
-    for _ in range(max_iter):
-        # both kernels run on the sequences still iterating only; the others keep the state of their last
-        # iteration (the reference's per-sequence `break`)
-        hmm_vlb, (Ei, Et, Es) = hmm_estep((hmm_init, hmm_pair, node_hmm))
-        if st is None:
-            st = dict(Ei=Ei, Et=Et, Es=Es, hmm_vlb=hmm_vlb, node_hmm=node_hmm)
-        else:
-            for name, val in (("Ei", Ei), ("Et", Et), ("Es", Es), ("hmm_vlb", hmm_vlb), ("node_hmm", node_hmm)):
-                st[name].index_copy_(0, rows, val)
-        plan.launch(dense_init, dense_pair, st["Es"], node, rows32)
-        lds_vlb = plan.lds_vlb(dense_init, dense_pair, st["Es"], reference_compat)
-        new_vlb = st["hmm_vlb"] + lds_vlb
-        iters += active.to(torch.int64)
-        done = (new_vlb - vlb).abs() < tol
-        vlb = new_vlb
-        active = active & ~done
-        rows = active.nonzero().squeeze(1)          # (host sync: the launch sizes of the next sweep)
-        if rows.numel() == 0:
+    node_hmm = _arhmm_nodeparams_from_path(dense_init, dense_pair, x).contiguous()      # sweep 0 (:203-226)
+    cinit_hmm = (dense_init[2] + dense_init[3]).contiguous()       # HMM node potential of step 0 (:138: both constants)
+    # ... and of the LDS bound: the compiled reference filter drops the second one (module docstring)
+    cinit_vlb = dense_init[2].contiguous() if reference_compat else cinit_hmm
+    lz = dense_pair[3].contiguous()
+    st = dict(Ei=torch.zeros(B, K, **f64), Et=torch.zeros(B, K, K, **f64), Es=torch.zeros(B, T, K, **f64),
+              hmm_vlb=torch.zeros(B, **f64), node_hmm=node_hmm)
+    lds_vlb = torch.zeros(B, **f64)
+    vlb = torch.full((B,), -float("inf"), **f64)
+    iters = torch.zeros(B, **i32)
+    lists = [torch.arange(B, **i32), torch.empty(B, **i32)]
+    keep, count = torch.empty(B, **i32), torch.empty(1, **i32)
+    hws_bytes = int(lib.svae_hmm_workspace_bytes(max(B, 1), T, K))
+    hws = torch.empty(hws_bytes // 8, **f64)
+    stream = _lib.current_stream(dev)
+    nrun, cur = B, 0
+    for it in range(max_iter):
+        if nrun == 0:
             break
-        rows32 = rows.to(torch.int32)
-        node_hmm = plan.hmm_nodeparams(dense_init, dense_pair, rows)
-    return plan, st, lds_vlb, iters
+        idx = lists[cur]
+        rc = lib.svae_slds_hmm_meanfield_f64(
+            nrun, B, T, K, n, p(hmm_init), p(hmm_pair), p(node_hmm) if it == 0 else None,
+            p(plan.pair_contr), p(plan.E_init), p(dense_init[0]), p(dense_init[1]), p(cinit_hmm), p(lz), p(idx),
+            p(st["hmm_vlb"]), p(st["Ei"]), p(st["Et"]), p(st["Es"]), None if it == 0 else p(st["node_hmm"]),
+            p(hws), hws_bytes, stream)
+        _lib.check(rc, "svae_slds_hmm_meanfield_f64")
+        plan.launch(dense_init, dense_pair, st["Es"], node, idx, nrun)
+        rc = lib.svae_slds_sweep_glue_f64(nrun, T, K, float(tol), p(idx), p(st["Es"]), p(cinit_vlb), p(lz), p(plan.lognorm),
+                                          p(st["hmm_vlb"]), p(lds_vlb), p(vlb), p(iters), p(keep), p(lists[1 - cur]),
+                                          p(count), stream)
+        _lib.check(rc, "svae_slds_sweep_glue_f64")
+        cur = 1 - cur
+        nrun = int(count.item())                    # (the one host read per sweep: sizes the next launches)
+    return plan, st, lds_vlb, iters.to(torch.int64)
 
 
 def _initial_sample_path(node_potentials, eps):
