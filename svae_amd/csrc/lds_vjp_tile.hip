@@ -4,15 +4,18 @@
 // compute in the reference (svae/lds/cython_lds_inference.pyx:92-145, 236-306, 357-409), as the adjoint of THIS
 // library's recursion (derivation and torch restatement: svae_amd/lds/lds_large.py, vjp_from_handoff).
 //
-// Three passes over time, each one workgroup (256 threads) per sequence with the n x n state in LDS:
+// Three passes over time, each one workgroup (four wavefronts) per sequence with the n x n state in LDS:
 //   phase 0 (t = T-1 .. 0)  Sigma_t = Pinv_t + G_t Sigma_{t+1} G_t'                      -> sig (B,T,n,n)
 //   phase 1 (t = 0 .. T-1)  adjoint of the smoother / sampler recursions: Sigma_bar, m_bar, x_bar
 //                           -> pinv_bar (B,T,n,n), g_bar (B,T-1,n,n), c_bar (B,T,n), xbar (B,T,S,n)
 //   [the caller adds the Cholesky adjoint of the noise factor, batched over all (b,t), into pinv_bar]
 //   phase 2 (t = T-1 .. 0)  adjoint of the filter -> g_node_J, g_node_h (B,T,n)
-// Every O(n^3) product is C = A B on LDS-resident operands (row stride 66 doubles), each thread owning a 4 x 4
-// block of C (16 x 16 threads), operands read as 16-byte pairs; transposed operands are produced when a
-// matrix is copied into LDS, never inside the product.  fp64 VALU: v_mfma_f64 has the same rate on MI355X.
+// Every O(n^3) product is a list of 16 x 16 tile products on v_mfma_f64_16x16x4 with fragments read straight from
+// LDS-resident operands (row stride NP + 2 doubles): the NB x NB output tiles are dealt round-robin to the four
+// wavefronts; the fragment addressing makes a transposed operand free (no transposed copies), and a product reads
+// 4x fewer LDS bytes than the register-blocked VALU form it replaces (round 2: 4 x 4 blocks per thread -- LDS-bound
+// at ~7 us per 64^3 product against 2 us of arithmetic).  The global operands of a step (G_t, Sigma_{t+1}, P_t^-1,
+// Pinv_bar_t, J12) are requested one step ahead into registers.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
@@ -22,11 +25,9 @@
 
 namespace svae {
 
-// LDS matrices: row stride ld = n4 + 2 doubles (16-byte aligned rows, 2-way bank conflicts at most), one buffer
-// = n4 * ld doubles (n4 = n rounded up to 4): 33.8 KB at n = 64, 8.7 KB at n = 32 -- sized at launch, so that
-// smaller latent dimensions fit several workgroups per CU
-__host__ __device__ constexpr int tv_ld(int n4) { return n4 + 2; }
-__host__ __device__ constexpr int tv_mat(int n4) { return n4 * (n4 + 2); }
+// LDS matrices: NP x (NP + 2) doubles, NP = n rounded up to 16 (33.8 KB at n = 64, 8.7 KB at n = 32): sized by the
+// instantiation (NB = NP / 16), so that smaller latent dimensions fit several workgroups per CU
+__host__ __device__ constexpr int tv_mat(int np) { return np * (np + 2); }
 constexpr int TV_MAX_S = 16;
 
 struct TileVjpArgs {
@@ -43,126 +44,189 @@ struct TileVjpArgs {
   double* g_node_J; double* g_node_h;
 };
 
-struct Acc { double v[4][4]; };
+typedef double d4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void acc_zero(Acc& a) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) a.v[i][j] = 0.0;
+// D = A(16x16) * B(16x16) + C as four v_mfma_f64_16x16x4; a[kb] / b[kb] = k-chunk kb of the fragments
+__device__ __forceinline__ d4 mma16(const d4 a, const d4 b, d4 c) {
+  c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b[2], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b[3], c, 0, 0, 0);
+  return c;
+}
+// Fragment addressing (lane = 16 kq + r16) for a row-major tile Tl at (row0, col0) of an LDS matrix:
+//   frag_a: A operand of Tl (lane holds Tl[r16][4 kb + kq])  == B operand of Tl'
+//   frag_b: B operand of Tl (lane holds Tl[4 kb + kq][r16])  == A operand of Tl'  == the C/D layout
+// so a transposed operand costs nothing: no transposed copies are ever made.
+__device__ __forceinline__ d4 frag_a(const double* M, int ld, int row0, int col0, int r16, int kq) {
+  const double* p = M + (row0 + r16) * ld + col0 + kq;
+  return d4{p[0], p[4], p[8], p[12]};
+}
+__device__ __forceinline__ d4 frag_b(const double* M, int ld, int row0, int col0, int r16, int kq) {
+  const double* p = M + (row0 + kq) * ld + col0 + r16;
+  return d4{p[0], p[4 * ld], p[8 * ld], p[12 * ld]};
+}
+__device__ __forceinline__ void store_c(double* M, int ld, int row0, int col0, int r16, int kq, const d4 v) {
+  double* p = M + (row0 + kq) * ld + col0 + r16;
+  p[0] = v[0]; p[4 * ld] = v[1]; p[8 * ld] = v[2]; p[12 * ld] = v[3];
 }
 
-// acc += A B for this thread's 4 x 4 block (rows 4 ty.., columns 4 tx..); A, B in LDS; k < n4 (multiple of 4)
-__device__ __forceinline__ void gemm_nn(const double* A, const double* Bm, int n4, int ty, int tx, Acc& acc) {
-  const int TV_LD = tv_ld(n4);
-  if (4 * ty >= n4 || 4 * tx >= n4) return;
-  const double* ap = A + (4 * ty) * TV_LD;
-  const double* bp = Bm + 4 * tx;
-#pragma unroll 4
-  for (int k = 0; k < n4; k += 2) {
-    double2 a[4], b0[2], b1[2];
+// LDS matrices of the MFMA phases: NP x NP (NP = 16 NB), row stride NP + 2 (== 2 mod 32 doubles: the fragment reads
+// are bank-conflict free), zero-padded beyond n.  The NB x NB output tiles of a product are dealt round-robin to the
+// four wavefronts (tile q = wave + 4 j -> (q / NB, q % NB)): every product and every element-wise epilogue of a phase
+// uses the same ownership, so accumulators of different products add up lane by lane.
+template <int NB> constexpr int tv_maxt() { return (NB * NB + 3) / 4; }
+
+template <int NB>
+__device__ __forceinline__ void acc_zero(d4 (&acc)[tv_maxt<NB>()]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const double2*>(ap + i * TV_LD + k);
-    b0[0] = *reinterpret_cast<const double2*>(bp + k * TV_LD);
-    b0[1] = *reinterpret_cast<const double2*>(bp + k * TV_LD + 2);
-    b1[0] = *reinterpret_cast<const double2*>(bp + (k + 1) * TV_LD);
-    b1[1] = *reinterpret_cast<const double2*>(bp + (k + 1) * TV_LD + 2);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      acc.v[i][0] = __builtin_fma(a[i].x, b0[0].x, acc.v[i][0]);
-      acc.v[i][1] = __builtin_fma(a[i].x, b0[0].y, acc.v[i][1]);
-      acc.v[i][2] = __builtin_fma(a[i].x, b0[1].x, acc.v[i][2]);
-      acc.v[i][3] = __builtin_fma(a[i].x, b0[1].y, acc.v[i][3]);
-      acc.v[i][0] = __builtin_fma(a[i].y, b1[0].x, acc.v[i][0]);
-      acc.v[i][1] = __builtin_fma(a[i].y, b1[0].y, acc.v[i][1]);
-      acc.v[i][2] = __builtin_fma(a[i].y, b1[1].x, acc.v[i][2]);
-      acc.v[i][3] = __builtin_fma(a[i].y, b1[1].y, acc.v[i][3]);
-    }
-  }
+  for (int j = 0; j < tv_maxt<NB>(); ++j) acc[j] = d4{0.0, 0.0, 0.0, 0.0};
 }
 
-// global (row stride gld) -> LDS buffer, zero-padded to n4 x n4; TRANS: dst[c][r] = src[r][c]; scaled by `scale`.
-// Thread (ty, tx) copies columns 4 tx .. 4 tx + 3 of rows ty, ty + 16, ty + 32, ty + 48: 16 independent loads in
-// flight per thread, 512 contiguous bytes per row across the 16 tx (no index divisions).
-template <bool TRANS>
-__device__ __forceinline__ void load_mat(double* dst, const double* src, int gld, int n, int n4, double scale) {
-  const int TV_LD = tv_ld(n4);
-  const int ty = threadIdx.x >> 4, c0 = 4 * (threadIdx.x & 15);
-  if (c0 >= n4) return;
-  double v[4][4];
+// acc += op(A) op(B) for this wavefront's tiles (TA / TB: the operand is the TRANSPOSE of the LDS matrix)
+template <int NB, bool TA, bool TB>
+__device__ __forceinline__ void gemm_mfma(const double* A, const double* Bm, int wave, int r16, int kq,
+                                          d4 (&acc)[tv_maxt<NB>()]) {
+  constexpr int LD = 16 * NB + 2;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = ty + 16 * i;
+  for (int j = 0; j < tv_maxt<NB>(); ++j) {
+    const int q = wave + 4 * j;
+    if (q < NB * NB) {
+      const int I = q / NB, J = q % NB;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[i][j] = (r < n && c0 + j < n) ? src[(long)r * gld + c0 + j] : 0.0;
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = ty + 16 * i;
-    if (r < n4) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (TRANS) dst[(c0 + j) * TV_LD + r] = scale * v[i][j]; else dst[r * TV_LD + c0 + j] = scale * v[i][j];
+      for (int K = 0; K < NB; ++K) {
+        const d4 a = TA ? frag_b(A, LD, 16 * K, 16 * I, r16, kq) : frag_a(A, LD, 16 * I, 16 * K, r16, kq);
+        const d4 b = TB ? frag_a(Bm, LD, 16 * J, 16 * K, r16, kq) : frag_b(Bm, LD, 16 * K, 16 * J, r16, kq);
+        acc[j] = mma16(a, b, acc[j]);
       }
     }
   }
 }
 
-// LDS matrix -> global n x n (dense, row stride n), same thread mapping as load_mat
+// f(j, i, row, col, value&) over the accumulator entries this lane owns
+template <int NB, class F>
+__device__ __forceinline__ void for_owned(d4 (&acc)[tv_maxt<NB>()], int wave, int r16, int kq, F&& f) {
+#pragma unroll
+  for (int j = 0; j < tv_maxt<NB>(); ++j) {
+    const int q = wave + 4 * j;
+    if (q < NB * NB) {
+      const int I = q / NB, J = q % NB;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        double v = acc[j][i];
+        f(16 * I + kq + 4 * i, 16 * J + r16, v);
+        acc[j][i] = v;
+      }
+    }
+  }
+}
+
+// this lane's C-layout entries of a global n x n matrix (row stride gld), zero outside: requested a step ahead like the
+// LDS operands (an element-wise epilogue operand loaded after its product would expose the HBM latency every step)
+template <int NB>
+__device__ __forceinline__ void fetch_c(d4 (&v)[tv_maxt<NB>()], const double* src, int gld, int n, int wave, int r16, int kq) {
+#pragma unroll
+  for (int j = 0; j < tv_maxt<NB>(); ++j) {
+    const int q = wave + 4 * j;
+    v[j] = d4{0.0, 0.0, 0.0, 0.0};
+    if (q < NB * NB) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 16 * (q / NB) + kq + 4 * i, c = 16 * (q % NB) + r16;
+        v[j][i] = (r < n && c < n) ? src[(long)r * gld + c] : 0.0;
+      }
+    }
+  }
+}
+
+template <int NB>
+__device__ __forceinline__ void store_acc(double* M, d4 (&acc)[tv_maxt<NB>()], int wave, int r16, int kq) {
+  constexpr int LD = 16 * NB + 2;
+#pragma unroll
+  for (int j = 0; j < tv_maxt<NB>(); ++j) {
+    const int q = wave + 4 * j;
+    if (q < NB * NB) store_c(M, LD, 16 * (q / NB), 16 * (q % NB), r16, kq, acc[j]);
+  }
+}
+
+// A global matrix (row stride gld, n x n valid) travels through 16 registers per thread: fetch (global -> registers,
+// issued a step ahead of its use: the operands come from HBM, ~2 us away) and stage (registers -> LDS, zero-padded to
+// NP x NP, scaled).  Thread (ty, tx) holds columns 4 tx .. 4 tx + 3 of rows ty, ty + 16, ty + 32, ty + 48.
+struct MatRegs { double v[4][4]; };
+__device__ __forceinline__ void fetch_mat(MatRegs& m, const double* src, int gld, int n) {
+  const int ty = threadIdx.x >> 4, c0 = 4 * (threadIdx.x & 15);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = ty + 16 * i;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m.v[i][j] = (r < n && c0 + j < n) ? src[(long)r * gld + c0 + j] : 0.0;
+  }
+}
+template <int NB>
+__device__ __forceinline__ void stage_mat(double* dst, const MatRegs& m) {
+  constexpr int NPL = 16 * NB, LD = NPL + 2;
+  const int ty = threadIdx.x >> 4, c0 = 4 * (threadIdx.x & 15);
+  if (c0 >= NPL) return;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = ty + 16 * i;
+    if (r < NPL) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dst[r * LD + c0 + j] = m.v[i][j];
+    }
+  }
+}
+template <int NB>
+__device__ __forceinline__ void load_mat(double* dst, const double* src, int gld, int n) {
+  MatRegs m;
+  fetch_mat(m, src, gld, n);
+  stage_mat<NB>(dst, m);
+}
+
+// LDS matrix -> global n x n (dense, row stride n), same thread mapping
+template <int NB>
 __device__ __forceinline__ void store_mat(double* dst, const double* src, int n) {
-  const int TV_LD = tv_ld((n + 3) & ~3);
+  constexpr int LD = 16 * NB + 2;
   const int ty = threadIdx.x >> 4, c0 = 4 * (threadIdx.x & 15);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = ty + 16 * i;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      if (r < n && c0 + j < n) dst[(long)r * n + c0 + j] = src[r * TV_LD + c0 + j];
+      if (r < n && c0 + j < n) dst[(long)r * n + c0 + j] = src[r * LD + c0 + j];
   }
 }
 
-__device__ __forceinline__ void store_block(double* dst, const Acc& a, int ty, int tx, int n4, bool trans) {
-  const int TV_LD = tv_ld(n4);
-  if (4 * ty >= n4 || 4 * tx >= n4) return;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (trans) dst[(4 * tx + j) * TV_LD + 4 * ty + i] = a.v[i][j];
-      else dst[(4 * ty + i) * TV_LD + 4 * tx + j] = a.v[i][j];
-    }
-}
-
-// in place: M <- (M + M') / 2 on the n4 x n4 LDS matrix (barriers inside); each thread handles its 4 x 4 block
-__device__ __forceinline__ void symmetrize_lds(double* M, int n4) {
-  const int TV_LD = tv_ld(n4);
+// in place: M <- (M + M') / 2 on the NP x NP LDS matrix (barriers inside); each thread handles a 4 x 4 block
+template <int NB>
+__device__ __forceinline__ void symmetrize_lds(double* M) {
+  constexpr int NPL = 16 * NB, LD = NPL + 2;
   const int r0 = 4 * (threadIdx.x >> 4), c0 = 4 * (threadIdx.x & 15);
-  const bool on = r0 < n4 && c0 < n4;
+  const bool on = r0 < NPL && c0 < NPL;
   __syncthreads();
   double keep[4][4];
   if (on) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) keep[i][j] = 0.5 * (M[(r0 + i) * TV_LD + c0 + j] + M[(c0 + j) * TV_LD + r0 + i]);
+      for (int j = 0; j < 4; ++j) keep[i][j] = 0.5 * (M[(r0 + i) * LD + c0 + j] + M[(c0 + j) * LD + r0 + i]);
   }
   __syncthreads();
   if (on) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) M[(r0 + i) * TV_LD + c0 + j] = keep[i][j];
+      for (int j = 0; j < 4; ++j) M[(r0 + i) * LD + c0 + j] = keep[i][j];
   }
   __syncthreads();
 }
 
-// y[i] = sum_j A[i][j] x[j]  (TRANS: A[j][i]) for i < n; A in LDS; x, y LDS vectors (y != x); barrier after
+// y[i] = sum_j A[i][j] x[j]  (TRANS: A[j][i]) for i < n; A in LDS (row stride LD); x, y LDS vectors (y != x); barrier after
 template <bool TRANS>
-__device__ __forceinline__ void matvec(const double* A, const double* x, double* y, int n) {
-  const int TV_LD = tv_ld((n + 3) & ~3);
+__device__ __forceinline__ void matvec(const double* A, int LD, const double* x, double* y, int n) {
   for (int i = threadIdx.x; i < n; i += 256) {
     double s = 0.0;
-    for (int j = 0; j < n; ++j) s = __builtin_fma(TRANS ? A[j * TV_LD + i] : A[i * TV_LD + j], x[j], s);
+    for (int j = 0; j < n; ++j) s = __builtin_fma(TRANS ? A[j * LD + i] : A[i * LD + j], x[j], s);
     y[i] = s;
   }
   __syncthreads();
@@ -173,71 +237,90 @@ __device__ __forceinline__ const double* handoff(const TileVjpArgs& a, int b, in
 }
 
 // ---- phase 0 ------------------------------------------------------------------------------------------------
+template <int NB>
 __global__ __launch_bounds__(256) void tile_vjp_phase0(const TileVjpArgs a) {
+  constexpr int NPL = 16 * NB, LD = NPL + 2, MAT = NPL * LD;
   extern __shared__ double sm[];
-  const int b = blockIdx.x, n = a.n, n4 = (n + 3) & ~3, NP = a.NP, T = a.T;
-  const int TV_MAT = tv_mat(n4);
-  double *L0 = sm, *L1 = sm + TV_MAT, *L3 = sm + 2 * TV_MAT;
-  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
-  load_mat<false>(L3, handoff(a, b, T - 1) + (long)NP * NP, NP, n, n4, 1.0);
+  const int b = blockIdx.x, n = a.n, NP = a.NP, T = a.T;
+  double *L0 = sm, *L1 = sm + MAT, *L3 = sm + 2 * MAT;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r16 = lane & 15, kq = lane >> 4;
+  for (int e = threadIdx.x; e < 3 * MAT; e += 256) sm[e] = 0.0;
+  __syncthreads();
+  load_mat<NB>(L3, handoff(a, b, T - 1) + (long)NP * NP, NP, n);
+  MatRegs gpre;
+  d4 ppre[tv_maxt<NB>()];
+  if (T > 1) {
+    fetch_mat(gpre, handoff(a, b, T - 2), NP, n);
+    fetch_c<NB>(ppre, handoff(a, b, T - 2) + (long)NP * NP, NP, n, wave, r16, kq);
+  }
   __syncthreads();
   for (int t = T - 1; t >= 0; --t) {
     if (t < T - 1) {
-      const double* h = handoff(a, b, t);
-      load_mat<false>(L0, h, NP, n, n4, 1.0);                     // G_t
-      __syncthreads();
-      Acc acc;
-      acc_zero(acc);
-      gemm_nn(L0, L3, n4, ty, tx, acc);                           // G Sigma
-      store_block(L1, acc, ty, tx, n4, true);                     // (G Sigma)'
-      __syncthreads();
-      acc_zero(acc);
-      gemm_nn(L0, L1, n4, ty, tx, acc);                           // G (G Sigma)' = G Sigma G'
-      const double* P = h + (long)NP * NP;
-      if (4 * ty < n4 && 4 * tx < n4) {
+      stage_mat<NB>(L0, gpre);                                    // G_t, requested one step ago
+      d4 pcur[tv_maxt<NB>()];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int r = 4 * ty + i, c = 4 * tx + j;
-            acc.v[i][j] += (r < n && c < n) ? P[(long)r * NP + c] : 0.0;
-          }
+      for (int j = 0; j < tv_maxt<NB>(); ++j) pcur[j] = ppre[j];  // P_t^-1 in the C layout
+      if (t > 0) {
+        fetch_mat(gpre, handoff(a, b, t - 1), NP, n);
+        fetch_c<NB>(ppre, handoff(a, b, t - 1) + (long)NP * NP, NP, n, wave, r16, kq);
       }
-      __syncthreads();                                            // everyone done reading L3
-      store_block(L3, acc, ty, tx, n4, false);
-      symmetrize_lds(L3, n4);
+      __syncthreads();
+      d4 acc[tv_maxt<NB>()];
+      acc_zero<NB>(acc);
+      gemm_mfma<NB, false, false>(L0, L3, wave, r16, kq, acc);    // G Sigma
+      store_acc<NB>(L1, acc, wave, r16, kq);
+      __syncthreads();                                            // (everyone is done reading L3, too)
+      acc_zero<NB>(acc);
+      gemm_mfma<NB, false, true>(L1, L0, wave, r16, kq, acc);     // (G Sigma) G'
+#pragma unroll
+      for (int j = 0; j < tv_maxt<NB>(); ++j) acc[j] += pcur[j];
+      store_acc<NB>(L3, acc, wave, r16, kq);
+      symmetrize_lds<NB>(L3);
     }
-    store_mat(a.sig + ((long)b * T + t) * n * n, L3, n);
+    store_mat<NB>(a.sig + ((long)b * T + t) * n * n, L3, n);
   }
 }
 
 // ---- phase 1 ------------------------------------------------------------------------------------------------
+template <int NB>
 __global__ __launch_bounds__(256) void tile_vjp_phase1(const TileVjpArgs a) {
+  constexpr int NPL = 16 * NB, LD = NPL + 2, MAT = NPL * LD;
   extern __shared__ double sm[];
-  const int b = blockIdx.x, n = a.n, n4 = (n + 3) & ~3, NP = a.NP, T = a.T, S = a.g_samples ? a.S : 0;
-  const int TV_LD = tv_ld(n4), TV_MAT = tv_mat(n4);
-  double *L0 = sm, *L1 = sm + TV_MAT, *L2 = sm + 2 * TV_MAT, *L3 = sm + 3 * TV_MAT;
-  double* vec = sm + 4 * TV_MAT;          // mb (64) | tmp (64) | mnext (64) | xb (S x 64) | xtmp (S x 64) | xnext (S x 64)
-  double *mb = vec, *tmpv = vec + 64, *mnext = vec + 128, *xb = vec + 192, *xtmp = xb + TV_MAX_S * 64, *xnext = xtmp + TV_MAX_S * 64;
-  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
-  for (int e = threadIdx.x; e < TV_MAT; e += 256) L3[e] = 0.0;                 // Sigma_bar
-  for (int e = threadIdx.x; e < 192 + 3 * TV_MAX_S * 64; e += 256) vec[e] = 0.0;
+  const int b = blockIdx.x, n = a.n, NP = a.NP, T = a.T, S = a.g_samples ? a.S : 0;
+  double *L0 = sm, *L1 = sm + MAT, *L2 = sm + 2 * MAT, *L3 = sm + 3 * MAT;
+  double* vec = sm + 4 * MAT;             // mb (64) | tmp (64) | mnext (64) | xb (S x 64) | xtmp (S x 64) | xnext (S x 64)
+  double *mb = vec, *mnext = vec + 128, *xb = vec + 192, *xnext = xb + 2 * TV_MAX_S * 64;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r16 = lane & 15, kq = lane >> 4;
+  for (int e = threadIdx.x; e < 4 * MAT + 192 + 3 * TV_MAX_S * 64; e += 256) sm[e] = 0.0;     // Sigma_bar = 0, vectors = 0
+  MatRegs gpre, spre;
+  if (T > 1) { fetch_mat(gpre, handoff(a, b, 0), NP, n); fetch_mat(spre, a.sig + ((long)b * T + 1) * n * n, n, n); }
+  // direct cotangents and the mean of step t for thread i < n, requested one step ahead
+  const int ti = threadIdx.x < n ? threadIdx.x : 0;
+  double gdpre = 0.0, gxpre = 0.0, mtpre = 0.0;
+  auto fetch_vec = [&](int t) {
+    const long o = ((long)b * T + t) * n + ti;
+    gdpre = a.g_dxx ? a.g_dxx[o] : 0.0;
+    gxpre = a.g_x ? a.g_x[o] : 0.0;
+    mtpre = a.E_node_x[o];
+  };
+  fetch_vec(0);
   __syncthreads();
   for (int t = 0; t < T; ++t) {
     const long bt = (long)b * T + t;
     const double* mt = a.E_node_x + bt * n;
     // direct cotangents of step t
-    for (int i = threadIdx.x; i < n; i += 256) {
-      const double gd = a.g_dxx ? a.g_dxx[bt * n + i] : 0.0;
-      L3[i * TV_LD + i] += gd;
-      mb[i] += (a.g_x ? a.g_x[bt * n + i] : 0.0) + 2.0 * gd * mt[i];
+    if (threadIdx.x < n) {
+      const int i = threadIdx.x;
+      L3[i * LD + i] += gdpre;
+      mb[i] += gxpre + 2.0 * gdpre * mtpre;
     }
+    if (t + 1 < T) fetch_vec(t + 1);
     if (t == 0 && a.g_E_init) {
       __syncthreads();
       const double* gi = a.g_E_init + (long)b * (n * n + n);
       for (int e = threadIdx.x; e < n * n; e += 256) {
         const int r = e / n, c = e % n;
-        L3[r * TV_LD + c] += 0.5 * (gi[r * n + c] + gi[c * n + r]);
+        L3[r * LD + c] += 0.5 * (gi[r * n + c] + gi[c * n + r]);
       }
       for (int i = threadIdx.x; i < n; i += 256) {
         double s = gi[n * n + i];
@@ -258,7 +341,7 @@ __global__ __launch_bounds__(256) void tile_vjp_phase1(const TileVjpArgs a) {
         double v = 0.0;
         if (A) v += 0.5 * (A[r * n + c] + A[c * n + r]);
         if (Ap) v += 0.5 * (Ap[2 * n * n + r * n + c] + Ap[2 * n * n + c * n + r]);
-        L3[r * TV_LD + c] += v;
+        L3[r * LD + c] += v;
       }
       const double* mnx = a.E_node_x + (bt + 1) * n;
       const double* mpv = a.E_node_x + (bt - 1) * n;
@@ -277,7 +360,7 @@ __global__ __launch_bounds__(256) void tile_vjp_phase1(const TileVjpArgs a) {
     }
     __syncthreads();
     // records for phase 2
-    store_mat(a.pinv_bar + bt * n * n, L3, n);
+    store_mat<NB>(a.pinv_bar + bt * n * n, L3, n);
     for (int i = threadIdx.x; i < n; i += 256) {
       double s = mb[i];
       for (int s_ = 0; s_ < S; ++s_) s += xb[s_ * 64 + i];
@@ -286,154 +369,157 @@ __global__ __launch_bounds__(256) void tile_vjp_phase1(const TileVjpArgs a) {
     for (int e = threadIdx.x; e < S * n; e += 256) a.xbar[(bt * a.S + e / n) * n + e % n] = xb[(e / n) * 64 + e % n];
     if (t == T - 1) break;
     // propagate to t + 1
-    const double* h = handoff(a, b, t);
-    load_mat<false>(L0, h, NP, n, n4, 1.0);                                      // G_t
-    load_mat<false>(L2, a.sig + (bt + 1) * n * n, n, n, n4, 1.0);               // Sigma_{t+1}
+    stage_mat<NB>(L0, gpre);                                                     // G_t
+    stage_mat<NB>(L2, spre);                                                     // Sigma_{t+1}
+    if (t + 2 < T) { fetch_mat(gpre, handoff(a, b, t + 1), NP, n); fetch_mat(spre, a.sig + (bt + 2) * n * n, n, n); }
     __syncthreads();
-    Acc acc;
-    acc_zero(acc);
-    gemm_nn(L3, L0, n4, ty, tx, acc);                                           // SG = Sigma_bar G
-    store_block(L1, acc, ty, tx, n4, false);
-    __syncthreads();
-    acc_zero(acc);
-    gemm_nn(L1, L2, n4, ty, tx, acc);                                           // SG Sigma_{t+1}
-    Acc accp;                                                                    // A1 Sigma_{t+1} (pair-statistic cotangent)
-    acc_zero(accp);
+    d4 acc[tv_maxt<NB>()], accp[tv_maxt<NB>()];
+    acc_zero<NB>(acc);
+    gemm_mfma<NB, false, false>(L3, L0, wave, r16, kq, acc);                     // SG = Sigma_bar G
+    store_acc<NB>(L1, acc, wave, r16, kq);
+    __syncthreads();                                                             // (Sigma_bar in L3 is consumed)
+    acc_zero<NB>(acc);
+    gemm_mfma<NB, false, false>(L1, L2, wave, r16, kq, acc);                     // SG Sigma_{t+1}
+    acc_zero<NB>(accp);
     if (a.g_E_pair) {
       // E x_t x_{t+1}' = G_t Sigma_{t+1} + m_t m_{t+1}':  G_bar += A1 Sigma_{t+1};  Sigma_bar_{t+1} += sym(G_t' A1).
-      // Sigma_bar (L3) has been consumed (SG in L1, pinv_bar stored): A1 takes its buffer until the new one is formed.
-      load_mat<false>(L3, a.g_E_pair + (((long)b * (T - 1) + t) * 3 + 1) * n * n, n, n, n4, 1.0);
+      load_mat<NB>(L3, a.g_E_pair + (((long)b * (T - 1) + t) * 3 + 1) * n * n, n, n);
       __syncthreads();
-      gemm_nn(L3, L2, n4, ty, tx, accp);
+      gemm_mfma<NB, false, false>(L3, L2, wave, r16, kq, accp);
     }
     {
       // G_bar = 2 SG Sigma_{t+1} + A1 Sigma_{t+1} + m_bar m_{t+1}' + sum_s x_bar_s x_{t+1,s}'
       const double* mn = a.E_node_x + (bt + 1) * n;
       double* gb = a.g_bar + ((long)b * (T - 1) + t) * n * n;
-      if (4 * ty < n4 && 4 * tx < n4) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < tv_maxt<NB>(); ++j) {
+        const int q = wave + 4 * j;
+        if (q < NB * NB) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int r = 4 * ty + i, c = 4 * tx + j;
+          for (int i = 0; i < 4; ++i) {
+            const int r = 16 * (q / NB) + kq + 4 * i, c = 16 * (q % NB) + r16;
             if (r < n && c < n) {
-              double v = 2.0 * acc.v[i][j] + accp.v[i][j] + mb[r] * mn[c];
+              double v = 2.0 * acc[j][i] + accp[j][i] + mb[r] * mn[c];
               for (int s_ = 0; s_ < S; ++s_) v = __builtin_fma(xb[s_ * 64 + r], a.samples[((bt + 1) * a.S + s_) * n + c], v);
               gb[r * n + c] = v;
             }
           }
+        }
       }
     }
     // m_bar <- G' m_bar ; x_bar <- x_bar G
-    matvec<true>(L0, mb, mnext, n);
+    matvec<true>(L0, LD, mb, mnext, n);
     for (int e = threadIdx.x; e < S * n; e += 256) {
       const int s_ = e / n, j = e % n;
       double v = 0.0;
-      for (int i = 0; i < n; ++i) v = __builtin_fma(xb[s_ * 64 + i], L0[i * TV_LD + j], v);
+      for (int i = 0; i < n; ++i) v = __builtin_fma(xb[s_ * 64 + i], L0[i * LD + j], v);
       xnext[s_ * 64 + j] = v;
     }
-    __syncthreads();                                                             // L2 (Sigma_{t+1}) and mb / xb no longer read
+    __syncthreads();                                                             // mb / xb no longer read
     for (int i = threadIdx.x; i < n; i += 256) mb[i] = mnext[i];
     for (int e = threadIdx.x; e < S * n; e += 256) xb[(e / n) * 64 + e % n] = xnext[(e / n) * 64 + e % n];
-    load_mat<true>(L2, h, NP, n, n4, 1.0);                                       // G_t'
+    acc_zero<NB>(acc);
+    gemm_mfma<NB, true, false>(L0, L1, wave, r16, kq, acc);                      // G' SG
+    if (a.g_E_pair) gemm_mfma<NB, true, false>(L0, L3, wave, r16, kq, acc);      // + G' A1 (symmetrised below)
     __syncthreads();
-    acc_zero(acc);
-    gemm_nn(L2, L1, n4, ty, tx, acc);                                           // G' SG
-    if (a.g_E_pair) gemm_nn(L2, L3, n4, ty, tx, acc);                           // + G' A1 (symmetrised below)
-    __syncthreads();
-    store_block(L3, acc, ty, tx, n4, false);
-    symmetrize_lds(L3, n4);
+    store_acc<NB>(L3, acc, wave, r16, kq);
+    symmetrize_lds<NB>(L3);
   }
-  (void)tmpv; (void)xtmp;
 }
 
 // ---- phase 2 ------------------------------------------------------------------------------------------------
+template <int NB>
 __global__ __launch_bounds__(256) void tile_vjp_phase2(const TileVjpArgs a) {
+  constexpr int NPL = 16 * NB, LD = NPL + 2, MAT = NPL * LD;
   extern __shared__ double sm[];
-  const int b = blockIdx.x, n = a.n, n4 = (n + 3) & ~3, NP = a.NP, T = a.T;
-  const int TV_LD = tv_ld(n4), TV_MAT = tv_mat(n4);
-  double *L0 = sm, *L1 = sm + TV_MAT, *L2 = sm + 2 * TV_MAT, *L3 = sm + 3 * TV_MAT;
-  double* vec = sm + 4 * TV_MAT;          // hb | cb | Pc | tmp
+  const int b = blockIdx.x, n = a.n, NP = a.NP, T = a.T;
+  double *L0 = sm, *L1 = sm + MAT, *L2 = sm + 2 * MAT, *L3 = sm + 3 * MAT;
+  double* vec = sm + 4 * MAT;             // hb | cb | Pc | tmp
   double *hb = vec, *cb = vec + 64, *Pc = vec + 128, *tmpv = vec + 192;
-  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r16 = lane & 15, kq = lane >> 4;
   const double gl = a.g_lognorm[b];
-  for (int e = threadIdx.x; e < TV_MAT; e += 256) L3[e] = 0.0;                 // J_bar of step t + 1
-  for (int e = threadIdx.x; e < 256; e += 256) vec[e] = 0.0;
+  for (int e = threadIdx.x; e < 4 * MAT + 256; e += 256) sm[e] = 0.0;           // J_bar of step t + 1 = 0, vectors = 0
+  // operands of a step, requested one step ahead: Pinv_t, Pinv_bar_t, G_t, J12 (per-step parameters)
+  MatRegs ppre, bpre, gpre, jpre;
+  d4 gbpre[tv_maxt<NB>()];                  // G_bar_t in the C layout
+  double cbpre = 0.0, ctpre = 0.0;          // c_bar_t[i], c_t[i] for thread i < n
+  double* ctv = vec + 256;                  // (the vector area has 256 + 3 * TV_MAX_S * 64 doubles: c_t lives behind tmp)
+  auto J12_at = [&](int t) { return a.J12 + (long)b * a.pair_seq_stride + (long)t * a.pair_t_stride; };
+  auto fetch_step = [&](int t) {
+    const long bt = (long)b * T + t;
+    const double* h = handoff(a, b, t);
+    fetch_mat(ppre, h + (long)NP * NP, NP, n);
+    fetch_mat(bpre, a.pinv_bar + bt * n * n, n, n);
+    const int i = threadIdx.x < n ? threadIdx.x : 0;
+    cbpre = a.c_bar[bt * n + i];
+    ctpre = h[2L * NP * NP + i];
+    if (t < T - 1) {
+      fetch_mat(gpre, h, NP, n);
+      fetch_mat(jpre, J12_at(t), n, n);
+      fetch_c<NB>(gbpre, a.g_bar + ((long)b * (T - 1) + t) * n * n, n, n, wave, r16, kq);
+    }
+  };
+  fetch_step(T - 1);
   __syncthreads();
   for (int t = T - 1; t >= 0; --t) {
     const long bt = (long)b * T + t;
-    const double* h = handoff(a, b, t);
-    const double* ct = h + 2L * NP * NP;
-    load_mat<false>(L0, h + (long)NP * NP, NP, n, n4, 1.0);                      // Pinv_t
-    for (int i = threadIdx.x; i < n; i += 256) cb[i] = a.c_bar[bt * n + i];
-    Acc pbar;
-    acc_zero(pbar);
+    const double* ct = ctv;
+    stage_mat<NB>(L0, ppre);                                                     // Pinv_t
+    if (threadIdx.x < n) { cb[threadIdx.x] = cbpre; ctv[threadIdx.x] = ctpre; }
+    d4 pbar[tv_maxt<NB>()], gbcur[tv_maxt<NB>()];
+    acc_zero<NB>(pbar);
+#pragma unroll
+    for (int j = 0; j < tv_maxt<NB>(); ++j) gbcur[j] = gbpre[j];
     if (t < T - 1) {
       // R = -J12 (info form):  X_bar = -R J_bar - G_bar = J12 J_bar - G_bar ;  c_bar -= R h_bar = += J12 h_bar
-      const double* J12 = a.J12 + (long)b * a.pair_seq_stride + (long)t * a.pair_t_stride;
-      load_mat<false>(L1, J12, n, n, n4, 1.0);
+      stage_mat<NB>(L1, jpre);
       __syncthreads();
-      matvec<false>(L1, hb, tmpv, n);
+      matvec<false>(L1, LD, hb, tmpv, n);
       for (int i = threadIdx.x; i < n; i += 256) cb[i] += tmpv[i];
-      Acc acc;
-      acc_zero(acc);
-      gemm_nn(L1, L3, n4, ty, tx, acc);                                         // J12 J_bar
-      const double* gb = a.g_bar + ((long)b * (T - 1) + t) * n * n;
-      if (4 * ty < n4 && 4 * tx < n4) {
+      d4 acc[tv_maxt<NB>()];
+      acc_zero<NB>(acc);
+      gemm_mfma<NB, false, false>(L1, L3, wave, r16, kq, acc);                   // J12 J_bar
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int r = 4 * ty + i, c = 4 * tx + j;
-            acc.v[i][j] -= (r < n && c < n) ? gb[r * n + c] : 0.0;
-          }
-      }
-      store_block(L2, acc, ty, tx, n4, false);                                  // X_bar
+      for (int j = 0; j < tv_maxt<NB>(); ++j) acc[j] -= gbcur[j];
+      store_acc<NB>(L2, acc, wave, r16, kq);                                     // X_bar
       __syncthreads();
-      acc_zero(acc);
-      gemm_nn(L0, L2, n4, ty, tx, acc);                                         // PX = Pinv X_bar
+      acc_zero<NB>(acc);
+      gemm_mfma<NB, false, false>(L0, L2, wave, r16, kq, acc);                   // PX = Pinv X_bar
+      __syncthreads();                                                           // (L1 = J12 and L2 = X_bar consumed)
+      store_acc<NB>(L1, acc, wave, r16, kq);
+      stage_mat<NB>(L2, gpre);                                                   // G_t
       __syncthreads();
-      store_block(L1, acc, ty, tx, n4, false);
-      load_mat<true>(L2, h, NP, n, n4, 1.0);                                     // G_t'
-      __syncthreads();
-      gemm_nn(L1, L2, n4, ty, tx, pbar);                                        // P_bar = PX G'
+      gemm_mfma<NB, false, true>(L1, L2, wave, r16, kq, pbar);                   // P_bar = PX G'
       __syncthreads();
     } else {
       __syncthreads();
     }
-    load_mat<false>(L1, a.pinv_bar + bt * n * n, n, n, n4, 1.0);                // Pinv_bar (direct + Cholesky part)
+    stage_mat<NB>(L1, bpre);                                                     // Pinv_bar (direct + Cholesky part)
+    if (t > 0) fetch_step(t - 1);
     __syncthreads();
     {
-      Acc acc;
-      acc_zero(acc);
-      gemm_nn(L0, L1, n4, ty, tx, acc);                                         // Pinv Pinv_bar
-      store_block(L2, acc, ty, tx, n4, false);
+      d4 acc[tv_maxt<NB>()];
+      acc_zero<NB>(acc);
+      gemm_mfma<NB, false, false>(L0, L1, wave, r16, kq, acc);                   // Pinv Pinv_bar
+      store_acc<NB>(L2, acc, wave, r16, kq);
       __syncthreads();
-      acc_zero(acc);
-      gemm_nn(L2, L0, n4, ty, tx, acc);                                         // (Pinv Pinv_bar) Pinv
+      acc_zero<NB>(acc);
+      gemm_mfma<NB, false, false>(L2, L0, wave, r16, kq, acc);                   // (Pinv Pinv_bar) Pinv
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) pbar.v[i][j] -= acc.v[i][j];
+      for (int j = 0; j < tv_maxt<NB>(); ++j) pbar[j] -= acc[j];
     }
-    matvec<false>(L0, cb, Pc, n);                                               // Pc = Pinv c_bar  (barrier inside)
+    matvec<false>(L0, LD, cb, Pc, n);                                           // Pc = Pinv c_bar  (barrier inside)
     // P_bar -= Pc c' + gl/2 c c' + gl/2 Pinv
-    if (4 * ty < n4 && 4 * tx < n4) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int r = 4 * ty + i, c = 4 * tx + j;
-          if (r < n && c < n) pbar.v[i][j] -= Pc[r] * ct[c] + 0.5 * gl * (ct[r] * ct[c] + L0[r * TV_LD + c]);
-          else pbar.v[i][j] = 0.0;
-        }
-    }
+    for_owned<NB>(pbar, wave, r16, kq, [&](int r, int c, double& v) {
+      if (r < n && c < n) v -= Pc[r] * ct[c] + 0.5 * gl * (ct[r] * ct[c] + L0[r * LD + c]);
+      else v = 0.0;
+    });
     __syncthreads();
-    store_block(L3, pbar, ty, tx, n4, false);
-    symmetrize_lds(L3, n4);
+    store_acc<NB>(L3, pbar, wave, r16, kq);
+    symmetrize_lds<NB>(L3);
     for (int i = threadIdx.x; i < n; i += 256) {
       const double hf = Pc[i] + gl * ct[i];
-      a.g_node_J[bt * n + i] = -2.0 * L3[i * TV_LD + i];
+      a.g_node_J[bt * n + i] = -2.0 * L3[i * LD + i];
       a.g_node_h[bt * n + i] = hf;
       hb[i] = hf;
     }
@@ -688,20 +774,29 @@ extern "C" int svae_lds_tile_vjp_f64(int phase, int B, int T, int n, int S, int 
   a.xbar = w;
   a.g_node_J = g_node_J; a.g_node_h = g_node_h;
   hipStream_t s = (hipStream_t)stream;
-  const int n4 = (n + 3) & ~3;
-  const size_t lds0 = (size_t)3 * svae::tv_mat(n4) * sizeof(double);
-  const size_t lds12 = (size_t)(4 * svae::tv_mat(n4) + 192 + 3 * svae::TV_MAX_S * 64) * sizeof(double);
-  const size_t lds0_max = (size_t)3 * svae::tv_mat(64) * sizeof(double);
-  const size_t lds12_max = (size_t)(4 * svae::tv_mat(64) + 192 + 3 * svae::TV_MAX_S * 64) * sizeof(double);
-  static svae::LdsGrant grant0, grant1, grant2;
-  if (!grant0.ensure(reinterpret_cast<const void*>(svae::tile_vjp_phase0), (long)lds0_max) ||
-      !grant1.ensure(reinterpret_cast<const void*>(svae::tile_vjp_phase1), (long)lds12_max) ||
-      !grant2.ensure(reinterpret_cast<const void*>(svae::tile_vjp_phase2), (long)lds12_max))
-    return -1001;
-  if (phase == 0) hipLaunchKernelGGL(svae::tile_vjp_phase0, dim3(B), dim3(256), lds0, s, a);
-  else if (phase == 1) hipLaunchKernelGGL(svae::tile_vjp_phase1, dim3(B), dim3(256), lds12, s, a);
-  else hipLaunchKernelGGL(svae::tile_vjp_phase2, dim3(B), dim3(256), lds12, s, a);
-  return hipGetLastError() == hipSuccess ? 0 : -1000;
+  auto go = [&](auto nb) -> int {
+    constexpr int NB = decltype(nb)::value;
+    const size_t lds0 = (size_t)3 * svae::tv_mat(16 * NB) * sizeof(double);
+    const size_t lds12 = (size_t)(4 * svae::tv_mat(16 * NB) + 256 + 3 * svae::TV_MAX_S * 64) * sizeof(double);
+    static svae::LdsGrant grant0, grant1, grant2;      // (per instantiation, per device inside)
+    if (phase == 0) {
+      if (!grant0.ensure(reinterpret_cast<const void*>(svae::tile_vjp_phase0<NB>), (long)lds0)) return -1001;
+      hipLaunchKernelGGL(svae::tile_vjp_phase0<NB>, dim3(B), dim3(256), lds0, s, a);
+    } else if (phase == 1) {
+      if (!grant1.ensure(reinterpret_cast<const void*>(svae::tile_vjp_phase1<NB>), (long)lds12)) return -1001;
+      hipLaunchKernelGGL(svae::tile_vjp_phase1<NB>, dim3(B), dim3(256), lds12, s, a);
+    } else {
+      if (!grant2.ensure(reinterpret_cast<const void*>(svae::tile_vjp_phase2<NB>), (long)lds12)) return -1001;
+      hipLaunchKernelGGL(svae::tile_vjp_phase2<NB>, dim3(B), dim3(256), lds12, s, a);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+  };
+  switch ((n + 15) / 16) {
+    case 1: return go(std::integral_constant<int, 1>{});
+    case 2: return go(std::integral_constant<int, 2>{});
+    case 3: return go(std::integral_constant<int, 3>{});
+    default: return go(std::integral_constant<int, 4>{});
+  }
 }
 
 // Backward sampling for latent dimension 16 <= n <= 64 from the hand-off of the tiled E-step: `noise` (B,T,S,n) =

@@ -1,6 +1,6 @@
 #!/bin/bash
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-O=$REPO/gpurun_out/prof_r2_tile_train; mkdir -p $O
+O=$REPO/gpurun_out/prof_r3_tile_train; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python $REPO/tools/bench_tile_train.py 64 1000 64 1 > $O/bench.log 2>&1
 grep -v "^[EW]2026" $O/bench.log | tail -2
