@@ -14,6 +14,8 @@ ARGS="--steps 20 --warmup 3 --no-cpu-baseline --no-extra $*"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python $REPO/bench.py $ARGS > $OUT/trace.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- python $REPO/bench.py $ARGS > $OUT/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- python $REPO/bench.py $ARGS > $OUT/pmc_write.log 2>&1
+# 4. --pmc SQ_INSTS_VALU (own pass)  -> VALU instructions issued per launch (bench.py: roofline.valu.issued_over_algorithmic)
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d $OUT/pmc_valu -o bench -- python $REPO/bench.py $ARGS > $OUT/pmc_valu.log 2>&1
 find $OUT -name "*.csv" | head -20
 # keep only the small summaries
 find $OUT -name "*kernel_trace.csv" -size +2M -delete

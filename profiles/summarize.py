@@ -18,16 +18,22 @@ def main():
     shutil.copy(os.path.join(src, "trace", "bench_kernel_stats.csv"), os.path.join(dst, "kernel_stats.csv"))
     out = {}
     disp = {}
-    for counter, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+    for counter, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write"), ("SQ_INSTS_VALU", "pmc_valu")):
         per = {}
         name = None
-        with open(os.path.join(src, d, "bench_counter_collection.csv")) as f:
+        path = os.path.join(src, d, "bench_counter_collection.csv")
+        if not os.path.isfile(path):
+            continue
+        with open(path) as f:
             for row in csv.DictReader(f):
                 if row.get("Counter_Name") != counter or sub not in row.get("Kernel_Name", ""):
                     continue
                 per[row["Dispatch_Id"]] = per.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
                 name = row["Kernel_Name"]
         vals = list(per.values())
+        if counter == "SQ_INSTS_VALU":       # wavefront-level VALU instructions issued per launch (summed over the chip)
+            out["SQ_INSTS_VALU_per_launch_mean"] = sum(vals) / max(1, len(vals))
+            continue
         out[counter + "_KB_per_launch_mean"] = sum(vals) / max(1, len(vals))
         out[counter + "_launches"] = len(vals)
         out["kernel"] = name

@@ -154,7 +154,7 @@ int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int k
   a.ws3 = (keep & 2) ? (double*)workspace + main_ws_doubles(B, T, n) + factor_ws_doubles(B, T, n) : nullptr;
   a.pair_seq_stride = pair_batched ? (long)(T - 1) * n * n : 0;
   a.msg_Jp = a.msg_hp = a.msg_Jf = a.msg_hf = nullptr;
-  a.mix_w = nullptr; a.mix_out = nullptr; a.seq_index = nullptr; a.mix_K = 0;
+  a.mix_w = nullptr; a.mix_out = nullptr; a.seq_index = nullptr; a.mix_K = 0; a.lds_keep = 0;
   if (n > SVAE_LDS_MAX_N) {
     a.ws2 = a.ws3 = nullptr;
     return svae_lds_launch_tile(&a, n, inhomog, stream);
@@ -263,7 +263,7 @@ int svae_lds_filter_f64(int B, int T, int n, int inhomog, int pair_batched, unsi
   a.ws3 = nullptr;
   a.pair_seq_stride = pair_batched ? (long)(T - 1) * n * n : 0;
   a.msg_Jp = J_pred; a.msg_hp = h_pred; a.msg_Jf = J_filt; a.msg_hf = h_filt;
-  a.mix_w = nullptr; a.mix_out = nullptr; a.seq_index = nullptr; a.mix_K = 0;
+  a.mix_w = nullptr; a.mix_out = nullptr; a.seq_index = nullptr; a.mix_K = 0; a.lds_keep = 0;
   // small batches without message outputs: one sequence per wavefront (0.62 -> 0.24 ms at B = 512, T = 200, n = 10)
   const bool fsplit = sel.split && !J_pred && !h_pred && !J_filt && !h_filt;
   switch (n) {
@@ -331,7 +331,7 @@ int svae_slds_lds_meanfield_f64(int B, int rows, int T, int n, int K,
   a.info = info; a.ws = (double*)workspace; a.ws2 = nullptr; a.ws3 = nullptr;
   a.pair_seq_stride = 0;
   a.msg_Jp = a.msg_hp = a.msg_Jf = a.msg_hf = nullptr;
-  a.mix_w = weights; a.mix_out = pair_contr; a.seq_index = seq_index; a.mix_K = K;
+  a.mix_w = weights; a.mix_out = pair_contr; a.seq_index = seq_index; a.mix_K = K; a.lds_keep = 0;
   switch (n) {
 #define SVAE_CASE_(NN) case NN: return svae_lds_launch_twoend_mix_n##NN(&a, stream);
 #define SVAE_CASE(NN) SVAE_CASE_(NN)

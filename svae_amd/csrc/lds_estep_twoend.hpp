@@ -184,11 +184,18 @@ __global__ __launch_bounds__(MIX ? 512 : (S4 ? 128 : 64)) void lds_estep_twoend_
   // MIX: row of every array (and of the workspace) this launch slot works on (surplus slots: any valid row)
   const int b = !MIX ? bslot : (a.seq_index ? a.seq_index[bslot < a.B ? bslot : 0] : bslot);
   double* tab = tab_static;               // (MIX keeps the full hand-off record: no transposition tile)
+  // S4: the last `keep` records of each chain stay in (dynamic) LDS -- the smoother reads them first -- instead of
+  // travelling through HBM: [chain][slot][WS] doubles, slot = local step - (e + 1 - keep)
+  double* const lrecs = reinterpret_cast<double*>(te_dyn);
+  int keep = 0;
   if constexpr (S4) {
+    const int e_ = te_elims(a.T);
+    keep = a.lds_keep < e_ + 1 ? a.lds_keep : e_ + 1;
+    if (keep < 2) keep = 0;
     if (wv == 1) {                        // chain B's smoother wavefront: sleeps until the records are complete
       __syncthreads();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      te_smooth4<N>(a, b, 1, lane, tab_static + 256, xch_static);
+      te_smooth4<N>(a, b, 1, lane, tab_static + 256, xch_static, lrecs, keep);
       return;
     }
   }
@@ -387,11 +394,18 @@ __global__ __launch_bounds__(MIX ? 512 : (S4 ? 128 : 64)) void lds_estep_twoend_
   //   LEAN:  [lower triangle | c | 0.0 | trash]: lane c <= i -> tri(i) + c, lane 15 -> TRI + i
   const bool stp = (gl == 0 && col) || xok || (gl == 0 && c == HL);
   const int stoff = !stp ? 2 * N + 1 : (col ? c : (c == HL ? 2 * N : N + xx));
-  unsigned loff[LEAN ? N : 1];
+  unsigned loff[LEAN ? N : 1], lloff[S4 ? N : 1];
   if constexpr (LEAN) {
     static_for<0, N>([&](auto i) {
-      loff[i] = 8u * (choff + ((gl == 0 && c <= i) ? i * (i + 1) / 2 + c : ((gl == 0 && c == HL) ? TRI + i : LTRASH)));   // bytes
+      const unsigned ent = (gl == 0 && c <= i) ? i * (i + 1) / 2 + c : ((gl == 0 && c == HL) ? TRI + i : LTRASH);
+      loff[i] = 8u * (choff + ent);                              // bytes
+      // (LDS: lanes with nothing to hand over get a dummy slot each behind the records -- fifty lanes storing to one
+      //  trash address would serialise in its bank)
+      if constexpr (S4) lloff[i] = 8u * (ent == (unsigned)LTRASH ? (unsigned)(2 * keep * WS) + lane : (unsigned)(dir * keep * WS) + ent);
     });
+    if constexpr (S4) {
+      for (int r = gl * 16 + c; r < keep; r += 32) lrecs[(long)(dir * keep + r) * WS + LZERO] = 0.0;   // the LDS records' zero entry
+    }
     for (int q = lane; q < 2 * 16 * 16; q += 64) tab[q] = 0.0;     // rows of the transposition tile never written
     for (int r = gl * 16 + c; r <= e; r += 32) rec0[(long)r * WS + LZERO] = 0.0;   // the records' zero entry
   }
@@ -417,8 +431,12 @@ __global__ __launch_bounds__(MIX ? 512 : (S4 ? 128 : 64)) void lds_estep_twoend_
     static_for<0, N>([&](auto i) { Mp[i] = __shfl_xor(An[i], 32); });
     qacc_s = qacc; ldM_s = ldM; ldE_s = ldE;
   };
-  auto hand_off = [&](int s, const double (&M)[N], double vfull) {
-    if constexpr (LEAN) {
+  const int s0 = e + 1 - keep;              // S4: records of local steps >= s0 go to LDS
+  auto hand_off = [&](int s, const double (&M)[N], double vfull, auto to_lds) {
+    if constexpr (S4 && decltype(to_lds)::value) {
+      char* w = reinterpret_cast<char*>(lrecs + (long)(s - s0) * WS);
+      static_for<0, N>([&](auto i) { *reinterpret_cast<double*>(w + lloff[i]) = M[i] * vfull; });
+    } else if constexpr (LEAN) {
       char* w = reinterpret_cast<char*>(wsb + (long)s * WS);     // uniform base + 32-bit lane offset
       // (the offset passes through an empty asm: hipcc otherwise hoists its zero-extension out of the loop and pays
       //  a 64-bit add per store instead of the SGPR-base + 32-bit-offset addressing mode)
@@ -436,14 +454,14 @@ __global__ __launch_bounds__(MIX ? 512 : (S4 ? 128 : 64)) void lds_estep_twoend_
   // pessimistic of the two: a dummy hand-off (N stores into the meeting record, rewritten later) behind the
   // first loads makes both look alike, so the wait at the loop head is vmcnt(N) -- the prefetched node
   // potentials -- instead of a wait for the previous step's hand-off stores.
-  hand_off(e, An, 1.0);
+  hand_off(e, An, 1.0, std::false_type{});
 #ifdef SVAE_PHASE_TIMING
   long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tlast_ = __builtin_readcyclecounter();
 #endif
   // MIX: weights of local pairs s and s + 1 (raw, fetched one step ahead like the node potentials)
   double wr0 = MIX ? wrow[(long)wnode(0) * K] : 0.0, wr1 = MIX ? wrow[(long)wnode(1) * K] : 0.0;
-  for (int s = 0; s < e; ++s) {
+  auto elim_step = [&](int s, auto to_lds) {
     if (s == jx) take_partner();
     const double JoX = col ? -2.0 * Jo_n : 1.0;
     double ho = ho_n;
@@ -514,7 +532,7 @@ __global__ __launch_bounds__(MIX ? 512 : (S4 ? 128 : 64)) void lds_estep_twoend_
       ldE += __builtin_amdgcn_frexp_exp(ldM);
       ldM = __builtin_amdgcn_frexp_mant(ldM);
     }
-    hand_off(s, M, vfull);
+    hand_off(s, M, vfull, to_lds);
 
     dpp_fence(AnD);
     static_for<0, J>([&](auto j) {
@@ -522,6 +540,13 @@ __global__ __launch_bounds__(MIX ? 512 : (S4 ? 128 : 64)) void lds_estep_twoend_
       else { double dummy; pair_split(AnD[j], An[2 * j], dummy); }
     });
     TE_TICK(3)
+  };
+  {
+    // (two loops, not a branch around the stores: a conditional store makes hipcc wait for the previous step's stores)
+    const int s_hbm = keep > 0 ? (s0 < e ? s0 : e) : e;       // steps whose record goes to the HBM workspace
+    int s = 0;
+    for (; s < s_hbm; ++s) elim_step(s, std::false_type{});
+    if constexpr (S4) for (; s < e; ++s) elim_step(s, std::true_type{});
   }
   if (jx == e) take_partner();
 
@@ -560,7 +585,8 @@ __global__ __launch_bounds__(MIX ? 512 : (S4 ? 128 : 64)) void lds_estep_twoend_
     static_for<0, N>([&](auto i) { mac_bc<i>(M[i], ho, EH); });
     dpp_fence(M);
     te_gauss_jordan<N>(M, E, qacc_m, vfull_m);
-    hand_off(e, M, vfull_m);
+    if (S4 && keep > 0) hand_off(e, M, vfull_m, std::true_type{});
+    else hand_off(e, M, vfull_m, std::false_type{});
   }
 
   // ---- log-normaliser --------------------------------------------------------------------------------
@@ -605,7 +631,7 @@ __global__ __launch_bounds__(MIX ? 512 : (S4 ? 128 : 64)) void lds_estep_twoend_
   if constexpr (S4) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
-    te_smooth4<N>(a, b, 0, lane, tab_static, xch_static);
+    te_smooth4<N>(a, b, 0, lane, tab_static, xch_static, lrecs, keep);
     return;
   }
 
@@ -936,8 +962,30 @@ static int launch_estep_twoend(const LdsArgs& a, bool inhomog, bool lean, hipStr
       hipLaunchKernelGGL((lds_estep_twoend_kernel<N, true, true>), grid, block, 0, stream, a);
     else if (inhomog)
       hipLaunchKernelGGL((lds_estep_twoend_kernel<N, true, false>), grid, block, 0, stream, a);
-    else if (lean && a.B <= TE_S4_MAX_B)     // one chain per wavefront in the smoother phase while SIMDs are idle
-      hipLaunchKernelGGL((lds_estep_twoend_kernel<N, false, true, false, false, true>), grid, dim3(128), 0, stream, a);
+    else if (lean && a.B <= TE_S4_MAX_B) {   // one chain per wavefront in the smoother phase while SIMDs are idle
+      // ... and the records the smoother reads first stay in LDS: as many per chain as fit when a CU takes one
+      // workgroup MORE than its even share ceil(B / 256) of the launch (the dispatcher does not balance exactly: sized
+      // for the even share, a few workgroups would wait for a second round and double the kernel time)
+      auto kern = lds_estep_twoend_kernel<N, false, true, false, false, true>;
+      const int wg_per_cu = (a.B + 255) / 256 + 1;
+      const long budget = (160L * 1024) / wg_per_cu - TE_S4_LDS_BYTES - 64 * (long)sizeof(double);
+      const long rec_bytes = 2L * te_lean_step_doubles(N) * sizeof(double);          // one record of each chain
+      // Measured (T = 200, n = 10): with one workgroup per CU (B <= 256) the LDS records cost nothing (0.142 ms either
+      // way) and the HBM traffic per launch falls to 1.6x the algorithmic bytes; with two workgroups per CU (B = 512)
+      // the kernel is 2 % slower with them (0.152 vs 0.149 ms), so they stay in HBM there: time before traffic.
+      long keep = a.B <= 256 ? budget / rec_bytes : 0;
+#ifdef SVAE_S4_KEEP_OVERRIDE
+      keep = SVAE_S4_KEEP_OVERRIDE;      // (experiments: tools/build_variant.sh ... -DSVAE_S4_KEEP_OVERRIDE=<records>)
+#endif
+      if (keep > te_elims(a.T) + 1) keep = te_elims(a.T) + 1;
+      if (keep < 2) keep = 0;
+      LdsArgs a2 = a;
+      a2.lds_keep = (int)keep;
+      const long bytes = keep * rec_bytes + (keep > 0 ? 64 * sizeof(double) : 0);    // + one dummy slot per lane
+      static LdsGrant grant;
+      if (bytes > 0 && !grant.ensure(reinterpret_cast<const void*>(kern), bytes)) return -31;
+      hipLaunchKernelGGL(kern, grid, dim3(128), (size_t)bytes, stream, a2);
+    }
     else if (lean)
       hipLaunchKernelGGL((lds_estep_twoend_kernel<N, false, true>), grid, block, 0, stream, a);
     else

@@ -41,9 +41,11 @@ __device__ __forceinline__ double reg_copy(double x) {       // a copy the compi
 // dir = the chain (0: A, forward in time; 1: B, reversed) = the wavefront's index in the workgroup.
 // tabw: 16 x RSL doubles of LDS of this wavefront, zero-initialised;  xch: exchange buffer of the workgroup.
 // Both wavefronts of the workgroup call this function; it contains ONE __syncthreads().
+// lrecs / keep: the last `keep` records of each chain (local steps e+1-keep .. e, the ones read first) live in LDS
+// ([chain][slot][WS] doubles, written by the elimination phase) instead of the HBM workspace; keep = 0 or >= 2.
 template <int N>
 __device__ __forceinline__ void te_smooth4(const LdsArgs& a, const int b, const int dir, const int lane,
-                                           double* tabw, double* xch) {
+                                           double* tabw, double* xch, const double* lrecs, const int keep) {
   constexpr int ZP = te_page_doubles(N), WS = te_lean_step_doubles(N);
   constexpr int TRI = N * (N + 1) / 2, LZERO = TRI + N;
   constexpr int J = (N + 3) / 4;          // slots holding rows 0..N-1 (row i = 4j + r)
@@ -105,8 +107,10 @@ __device__ __forceinline__ void te_smooth4(const LdsArgs& a, const int b, const 
   // Records are fetched FOUR steps ahead into a ring of register stages (3 registers each): a step is ~200
   // instructions (~0.45 us) and the records, written by the other wavefront during the elimination phase, are an L2
   // round trip away -- one step of lookahead left the loop bound by that latency.
-  const double* lrec = wsb + (long)e * WS;
-  int nextrec = e;                                   // index of the record the next load_ops fetches (.., 1, 0, 0, ..)
+  const int s0 = e + 1 - keep;                       // records s >= s0 are in LDS, records < s0 in the HBM workspace
+  const int g0 = s0 > 0 ? s0 - 1 : 0;                // first record the HBM ring fetches
+  const double* lrec = wsb + (long)g0 * WS;
+  int nextrec = g0;                                  // index of the record the next load_ops fetches (.., 1, 0, 0, ..)
   auto load_ops = [&](Ops& o) {
     // (offsets through an empty asm: keeps the SGPR-base + 32-bit-offset addressing mode, see hand_off in lds_estep_twoend.hpp)
     static_for<0, J1>([&](auto j) {
@@ -118,14 +122,8 @@ __device__ __forceinline__ void te_smooth4(const LdsArgs& a, const int b, const 
   };
 
   // one smoother step.  KIND: 0 generic, 1 first (meeting record: G = 0), 2 second (weight of the repeated pair)
-  auto step = [&](auto kind, int s, Ops& stage) {
+  auto core = [&](auto kind, int s, Ops& cur) {
     constexpr int KIND = decltype(kind)::value;
-    // (an explicit register copy: the stage's live range ends HERE, so the refill below can land in the same
-    //  registers and the loop-carried value needs no copy at the back edge -- a compiler-made copy of a freshly
-    //  loaded register there costs a wait for the youngest load, i.e. the whole prefetch distance)
-    Ops cur;
-    static_for<0, J1>([&](auto j) { cur.Pi[j] = reg_copy(stage.Pi[j]); });
-    load_ops(stage);                         // refill the stage with the record four steps further down
     // G~ rows of this DPP row: X[i][c] = sum_k P^-1[i][k] J12'[k][c] (lanes < N), c_i (lane N); row N = e_N
     double Gc[J1], H[N + 1];
     static_for<0, J1>([&](auto j) { Gc[j] = (j == NS) ? __builtin_fma(EN, cur.Pi[j], CN) : EN * cur.Pi[j]; });
@@ -188,10 +186,54 @@ __device__ __forceinline__ void te_smooth4(const LdsArgs& a, const int b, const 
     else { pdg += dlane ? nstride : 0; pex += xlane ? nstride : 0; }
     static_for<0, J1>([&](auto j) { S[j] = Sn[j]; });
   };
+  // a step on a record of the HBM ring
+  auto step = [&](auto kind, int s, Ops& stage) {
+    // (an explicit register copy: the stage's live range ends HERE, so the refill below can land in the same
+    //  registers and the loop-carried value needs no copy at the back edge -- a compiler-made copy of a freshly
+    //  loaded register there costs a wait for the youngest load, i.e. the whole prefetch distance)
+    Ops cur;
+    static_for<0, J1>([&](auto j) { cur.Pi[j] = reg_copy(stage.Pi[j]); });
+    load_ops(stage);                         // refill the stage with the record four steps further down
+    core(kind, s, cur);
+  };
+  // records kept in LDS: read one step ahead (slot of local step s = s - s0, clamped: the prefetch past the window
+  // is never used)
+  unsigned lpoff[J1];
+  static_for<0, J1>([&](auto j) { lpoff[j] = poff[j] - 8u * choff + 8u * (unsigned)(dir * keep * WS); });
+  auto lds_ops = [&](Ops& o, int s) {
+    const int slot = s > s0 ? s - s0 : 0;
+    const char* base = reinterpret_cast<const char*>(lrecs + (long)slot * WS);
+    static_for<0, J1>([&](auto j) { o.Pi[j] = *reinterpret_cast<const double*>(base + lpoff[j]); });
+  };
 
-  {
+  constexpr std::integral_constant<int, 0> GEN{};
+  if (keep > 0) {
+    Ops R0, R1, R2, R3, LA, LB;
+    if (s0 > 0) { load_ops(R0); load_ops(R1); load_ops(R2); load_ops(R3); }   // HBM records s0-1 .. s0-4: long on their way
+    lds_ops(LA, e);
+    lds_ops(LB, e - 1);
+    core(std::integral_constant<int, 1>{}, e, LA);
+    lds_ops(LA, e - 2);
+    core(std::integral_constant<int, 2>{}, e - 1, LB);
+    int s = e - 2;
+    for (; s - 1 >= s0; s -= 2) {      // LA holds record s
+      lds_ops(LB, s - 1);
+      core(GEN, s, LA);
+      lds_ops(LA, s - 2);
+      core(GEN, s - 1, LB);
+    }
+    if (s >= s0) { core(GEN, s, LA); --s; }
+    for (; s >= 3; s -= 4) {           // s = s0 - 1: the HBM ring (R0 holds record s)
+      step(GEN, s, R0);
+      step(GEN, s - 1, R1);
+      step(GEN, s - 2, R2);
+      step(GEN, s - 3, R3);
+    }
+    if (s >= 0) step(GEN, s, R0);
+    if (s >= 1) step(GEN, s - 1, R1);
+    if (s >= 2) step(GEN, s - 2, R2);
+  } else {
     Ops R0, R1, R2, R3;
-    constexpr std::integral_constant<int, 0> GEN{};
     load_ops(R0); load_ops(R1); load_ops(R2); load_ops(R3);       // records e, e-1, e-2, e-3
     step(std::integral_constant<int, 1>{}, e, R0);
     step(std::integral_constant<int, 2>{}, e - 1, R1);
