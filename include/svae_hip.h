@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SVAE_HIP_ABI_VERSION 6   /* 6: per-call `options` word replaces the process-global svae_lds_set_* selectors (re-entrant library), + svae_slds_hmm_meanfield_f64, svae_slds_sweep_glue_f64, g_E_pair in svae_lds_tile_vjp_f64; 5: + svae_lds_set_prod_max_b; 4: + svae_slds_lds_meanfield_f64, svae_gmm_mw_*, svae_lds_global_step_f64, svae_lds_natgrad_f64, svae_lds_tile_vjp_f64; 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
+#define SVAE_HIP_ABI_VERSION 7   /* 7: + svae_slds_path_nodeparams_f64, svae_slds_mix_pair_natparam_f64; 6: per-call `options` word replaces the process-global svae_lds_set_* selectors (re-entrant library), + svae_slds_hmm_meanfield_f64, svae_slds_sweep_glue_f64, g_E_pair in svae_lds_tile_vjp_f64; 5: + svae_lds_set_prod_max_b; 4: + svae_slds_lds_meanfield_f64, svae_gmm_mw_*, svae_lds_global_step_f64, svae_lds_natgrad_f64, svae_lds_tile_vjp_f64; 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
 #define SVAE_LDS_MAX_N 15   /* register/DPP path: one 16-lane row per sequence, n+1 <= 16 */
 #define SVAE_LDS_TILE_MAX_N 64   /* 16 <= n <= 64: LDS-tiled MFMA path (E-step only: keep must be 0) */
 
@@ -330,6 +330,21 @@ int svae_slds_sweep_glue_f64(int B, int T, int K, double tol, const int32_t* seq
                              const double* lognorm, const double* hmm_vlb, double* lds_vlb, double* vlb,
                              int32_t* iters, int32_t* keep_scratch, int32_t* next_index, int32_t* next_count,
                              void* stream);
+
+/* The two dense contractions at the ends of the ascent, as kernels (they were library GEMMs over materialised outer
+ * products / per-step parameter blocks):
+ *   initialize_local_meanfield + get_arhmm_local_nodeparams  /root/reference/svae/models/slds_svae.py:203-226, 131-147
+ *     HMM node potentials of sweep 0 from ONE sample path x (B,T,n):  node[b,0,k] = x_0' init_J_k x_0 + init_h_k' x_0 +
+ *     cinit_k;  node[b,t,k] = x_{t-1}' J11_k x_{t-1} + x_{t-1}' J12_k x_t + x_t' J22_k x_t + lz_k  (t >= 1).  n <= 15.
+ *   get_var_lds_local_natparam (the pair part)               /root/reference/svae/models/slds_svae.py:92-103
+ *     out_J11/J12/J22 (B,T-1,n,n), out_logZ (B,T-1):  out[b,t] = sum_k E_states[b,t+1,k] P_k.
+ * Parameter blocks carry a leading K axis (K <= 16). */
+int svae_slds_path_nodeparams_f64(int B, int T, int K, int n, const double* x, const double* init_J,
+                                  const double* init_h, const double* cinit, const double* J11, const double* J12,
+                                  const double* J22, const double* lz, double* node_out, void* stream);
+int svae_slds_mix_pair_natparam_f64(int B, int T, int K, int n, const double* E_states, const double* J11,
+                                    const double* J12, const double* J22, const double* lz, double* out_J11,
+                                    double* out_J12, double* out_J22, double* out_logZ, void* stream);
 
 /* GMM mean-field fixed point + global statistics for one minibatch of T points
  * [local_meanfield, /root/reference/svae/models/gmm.py:62-88; meanfield_fixed_point :90-110;

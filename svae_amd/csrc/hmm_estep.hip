@@ -342,6 +342,85 @@ __global__ __launch_bounds__(1024) void slds_compact_kernel(int nrun, const int3
   if (tid == 1023) count[0] = part[1023];
 }
 
+// ---- the two dense contractions at the ends of the SLDS coordinate ascent ------------------------------------------------------
+// Node potentials of the HMM for ONE sample path x (B,T,n) (initialize_local_meanfield + get_arhmm_local_nodeparams,
+// slds_svae.py:203-226, 131-147): the statistics of a path are outer products, so the contraction with state k's
+// parameters is three quadratic forms.  One thread per (sequence, step), loop over the states: the parameters are
+// wave-uniform (scalar loads), the path values sit in registers, each thread writes its K potentials contiguously.
+template <int N>
+__global__ __launch_bounds__(256) void slds_path_nodeparams_kernel(int B, int T, int K, const double* __restrict__ x,
+                                                                   const double* __restrict__ init_J,
+                                                                   const double* __restrict__ init_h,
+                                                                   const double* __restrict__ cinit,
+                                                                   const double* __restrict__ J11,
+                                                                   const double* __restrict__ J12,
+                                                                   const double* __restrict__ J22,
+                                                                   const double* __restrict__ lz,
+                                                                   double* __restrict__ out) {
+  const long q = (long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= (long)B * T) return;
+  const int t = (int)(q % T);
+  double xa[N], xb[N];                       // x_{t-1} (t >= 1), x_t
+  const double* xt = x + q * N;
+  static_for<0, N>([&](auto i) { xb[i] = xt[i]; xa[i] = t > 0 ? xt[i - N] : 0.0; });
+  double* o = out + q * K;
+  for (int k = 0; k < K; ++k) {
+    double acc;
+    if (t == 0) {
+      const double* J = init_J + (long)k * N * N;
+      acc = cinit[k];
+      static_for<0, N>([&](auto i) {
+        double r = init_h[(long)k * N + i];
+        static_for<0, N>([&](auto j) { r = __builtin_fma(J[i * N + j], xb[j], r); });
+        acc = __builtin_fma(xb[i], r, acc);
+      });
+    } else {
+      const double* A = J11 + (long)k * N * N;
+      const double* C = J12 + (long)k * N * N;
+      const double* D = J22 + (long)k * N * N;
+      acc = lz[k];
+      static_for<0, N>([&](auto i) {
+        double ra = 0.0, rb = 0.0;
+        static_for<0, N>([&](auto j) {
+          ra = __builtin_fma(A[i * N + j], xa[j], ra);
+          ra = __builtin_fma(C[i * N + j], xb[j], ra);
+          rb = __builtin_fma(D[i * N + j], xb[j], rb);
+        });
+        acc = __builtin_fma(xa[i], ra, acc);
+        acc = __builtin_fma(xb[i], rb, acc);
+      });
+    }
+    o[k] = acc;
+  }
+}
+
+// Per-step pair parameters of the LDS factor under the HMM marginals (get_var_lds_local_natparam, slds_svae.py:92-103):
+// out_m[b,t,:] = sum_k w[b,t+1,k] P_m[k,:] for the three n x n blocks and the constant.  Bound by the 3 n^2 + 1 doubles
+// written per (sequence, step): thread e of a workgroup owns output element e and keeps its K parameters in
+// registers; the weights of a row are wave-uniform (scalar loads); workgroups stride over the rows.
+__global__ __launch_bounds__(1024) void slds_mix_pair_kernel(int B, int T, int K, int nn, const double* __restrict__ w,
+                                                             const double* __restrict__ J11, const double* __restrict__ J12,
+                                                             const double* __restrict__ J22, const double* __restrict__ lz,
+                                                             double* __restrict__ o11, double* __restrict__ o12,
+                                                             double* __restrict__ o22, double* __restrict__ olz) {
+  const int e = threadIdx.x;
+  const int m = e / nn, ee = e - m * nn;             // block (0..2: the matrices, 3: the constant), element
+  if (m > 3 || (m == 3 && ee > 0)) return;
+  const double* P = m == 0 ? J11 : (m == 1 ? J12 : (m == 2 ? J22 : lz));
+  double* O = m == 0 ? o11 : (m == 1 ? o12 : (m == 2 ? o22 : olz));
+  const int es = m == 3 ? 1 : nn;                    // elements per state / per output row
+  double pk[16];
+  static_for<0, 16>([&](auto k) { pk[k] = k < K ? P[(long)k * es + ee] : 0.0; });
+  const long rows = (long)B * (T - 1);
+  for (long r = blockIdx.x; r < rows; r += gridDim.x) {
+    const long b = r / (T - 1), t = r - b * (T - 1);
+    const double* wr = w + (b * T + t + 1) * K;
+    double acc = 0.0;
+    static_for<0, 16>([&](auto k) { if (k < K) acc = __builtin_fma(wr[k], pk[k], acc); });
+    O[r * es + ee] = acc;
+  }
+}
+
 }  // namespace svae
 
 extern "C" size_t svae_hmm_workspace_bytes(int B, int T, int K) {
@@ -434,6 +513,53 @@ extern "C" int svae_slds_sweep_glue_f64(int B, int T, int K, double tol, const i
     if (hipGetLastError() != hipSuccess) return -1000;
   }
   hipLaunchKernelGGL(svae::slds_compact_kernel, dim3(1), dim3(1024), 0, s, B, seq_index, keep_scratch, next_index, next_count);
+  return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+// Sweep 0 of the ascent: HMM node potentials from one sample path (see slds_path_nodeparams_kernel).
+extern "C" int svae_slds_path_nodeparams_f64(int B, int T, int K, int n, const double* x, const double* init_J,
+                                             const double* init_h, const double* cinit, const double* J11,
+                                             const double* J12, const double* J22, const double* lz, double* node_out,
+                                             void* stream) {
+  if (B < 0) return -1;
+  if (T < 1) return -2;
+  if (K < 1 || K > 16) return -3;
+  if (n < 1 || n > 15) return -4;
+  if (!x) return -5;
+  if (!init_J || !init_h || !cinit) return -6;
+  if (T > 1 && (!J11 || !J12 || !J22 || !lz)) return -9;
+  if (!node_out) return -13;
+  if (B == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)(((long)B * T + 255) / 256)), block(256);
+  switch (n) {
+#define SVAE_CASE(NN) case NN: hipLaunchKernelGGL((svae::slds_path_nodeparams_kernel<NN>), grid, block, 0, s, B, T, K, x, \
+                                                  init_J, init_h, cinit, J11, J12, J22, lz, node_out); break;
+    SVAE_CASE(1) SVAE_CASE(2) SVAE_CASE(3) SVAE_CASE(4) SVAE_CASE(5) SVAE_CASE(6) SVAE_CASE(7) SVAE_CASE(8)
+    SVAE_CASE(9) SVAE_CASE(10) SVAE_CASE(11) SVAE_CASE(12) SVAE_CASE(13) SVAE_CASE(14) SVAE_CASE(15)
+#undef SVAE_CASE
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+// The per-step pair parameters of the converged mean field (see slds_mix_pair_kernel): E_states (B,T,K) ->
+// J11 / J12 / J22 (B,T-1,n,n), logZ (B,T-1).
+extern "C" int svae_slds_mix_pair_natparam_f64(int B, int T, int K, int n, const double* E_states, const double* J11,
+                                               const double* J12, const double* J22, const double* lz, double* out_J11,
+                                               double* out_J12, double* out_J22, double* out_logZ, void* stream) {
+  if (B < 0) return -1;
+  if (T < 1) return -2;
+  if (K < 1 || K > 16) return -3;
+  if (n < 1 || 3 * n * n + 1 > 1024) return -4;
+  if (!E_states) return -5;
+  if (!J11 || !J12 || !J22 || !lz) return -6;
+  if (!out_J11 || !out_J12 || !out_J22 || !out_logZ) return -10;
+  if (B == 0 || T == 1) return 0;
+  const long rows = (long)B * (T - 1);
+  const int threads = ((3 * n * n + 1) + 63) / 64 * 64;
+  const unsigned grid = (unsigned)(rows < 4096 ? rows : 4096);
+  hipLaunchKernelGGL(svae::slds_mix_pair_kernel, dim3(grid), dim3(threads), 0, (hipStream_t)stream, B, T, K, n * n,
+                     E_states, J11, J12, J22, lz, out_J11, out_J12, out_J22, out_logZ);
   return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 

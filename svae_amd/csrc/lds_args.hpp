@@ -115,7 +115,17 @@ struct VjpArgs {
   const double* __restrict__ ws3;        // cross-moment region
   double* __restrict__ adj;              // VJP scratch: vjp_step_doubles(n) per (b,t)
 };
-// per (b,t): [G^ smoother share | G^ sampler share] (n rows x ws_h_stride each), [-P^-1 Pinvbar P^-1 | Pbar(direct)] (n x ws_p_stride each)
-constexpr int vjp_step_doubles(int n) { return n * (2 * ws_h_stride(n) + 2 * ws_p_stride(n)); }
+// VJP scratch per (b,t), written by sweep 1 and read by sweep 2:
+//   [0, n HS)        G^: the smoother share (two-role launches) or the total -- n rows x ws_h_stride
+//   vjp_vec_off      the sampler share of G^ = sum_s xhat_s [x_{t+1,s}' | 1] as its factors (two-role launches, which
+//                    take at most VJP_SPLIT_MAX_S samples): per sample [xhat_s (n) | x_{t+1,s} (n)]
+//   vjp_pbp_off      -P^-1 Pinvbar P^-1: symmetric, lower triangle by rows (entry (i, c <= i) at i (i + 1) / 2 + c)
+//   vjp_pex_off      Pbar(direct) of the sampler's noise factor (not symmetric): n rows x ws_p_stride
+constexpr int VJP_SPLIT_MAX_S = 4;
+constexpr int vjp_tri_doubles(int n) { return (n * (n + 1) / 2 + 1) & ~1; }
+constexpr int vjp_vec_off(int n) { return n * ws_h_stride(n); }
+constexpr int vjp_pbp_off(int n) { return vjp_vec_off(n) + 2 * VJP_SPLIT_MAX_S * n; }
+constexpr int vjp_pex_off(int n) { return vjp_pbp_off(n) + vjp_tri_doubles(n); }
+constexpr int vjp_step_doubles(int n) { return vjp_pex_off(n) + n * ws_p_stride(n); }
 
 }  // namespace svae

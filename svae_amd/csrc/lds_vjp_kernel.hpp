@@ -25,6 +25,10 @@
 //     Bbar = P^-1 [Xbar | cbar];   hfbar = Bbar[:,n] + g c
 //     Pbar = -P^-1 Pinvbar P^-1 - Bbar H' - 1/2 g (c c' + P^-1) + Pbar(direct)
 //     g_node_J_t = -2 diag(Pbar);  g_node_h_t = hfbar;  [Abar | hbar]_t = [Pbar | hfbar]
+// Scratch between the sweeps (lds_args.hpp: vjp_step_doubles per sequence-step): G^ (n x (n+1)); in two-role launches
+// the sampler role's share of G^ as its rank-S factors [xhat_s | x_{t+1,s}] (2 n doubles per sample instead of an
+// n x (n+1) matrix -- sweep 2 forms the product, n DPP multiply-adds per sample); -P^-1 Pinvbar P^-1 as its lower
+// triangle (symmetric); Pbar(direct).  The sweeps are bandwidth-bound at large batches, so the record is what they cost.
 // Layout: as the packed E-step kernel (one DPP row per sequence, lane = column, fused DPP FMAs).
 // Hazards: every product stage fences its DPP-read operand array once (mm_ab / mm_atb), the few
 // stand-alone broadcasts fence theirs; `make audit` checks the ISA of every latent dimension.
@@ -115,6 +119,7 @@ __device__ __forceinline__ void for_samples(int S, F&& f) {
 // Barriers are numbered 0 .. T and every wavefront of the workgroup executes each exactly once:
 //   barrier t (t < T): step t's record is in ring slot t%3;  barrier t+1: the consumer's mailbox of step t is written.
 constexpr int VJP_PROD_MAX_S = 4;
+static_assert(VJP_PROD_MAX_S <= VJP_SPLIT_MAX_S, "the producer variants run as two roles");
 constexpr int VJP_S1_WAVES = 7;              // consumer, 4 producers, up to 2 helpers
 template <int N> constexpr int vjp_s1_pieces() {
   constexpr int HS = ws_h_stride(N), WS = ws_step_doubles(N);
@@ -227,7 +232,10 @@ __device__ __forceinline__ void s1_role0_wg(const VjpArgs& a, double* ring, doub
         static_for<0, J>([&](auto j) { mac_bc<k, true>(Pbp[j], PiD[j], T1R[k]); });
       });
       double* ad = a.adj + (b * T + t) * AS;
-      if (col) static_for<0, J>([&](auto j) { if (4 * j + r < N) ad[2 * N * HS + (4 * j + r) * PS + c] = Pbp[j]; });
+      static_for<0, J>([&](auto j) {                                      // lower triangle (Pbp is symmetric)
+        const int i = 4 * j + r;
+        if (i < N && c <= i) ad[vjp_pbp_off(N) + i * (i + 1) / 2 + c] = Pbp[j];
+      });
     }
     return;
   }
@@ -347,7 +355,7 @@ __device__ __forceinline__ void lds_vjp_sweep1_body(const VjpArgs& a, double* ta
             });
             mm_ab<N, N, false>(T1, Pib, Pi);
             mm_ab<N, N, true>(Pbp, Pi, T1);
-            if (valid && col) static_for<0, N>([&](auto i) { ad[2 * N * HS + i * PS + c] = Pbp[i]; });
+            if (valid) static_for<0, N>([&](auto i) { if (c <= i) ad[vjp_pbp_off(N) + i * (i + 1) / 2 + c] = Pbp[i]; });
           } else {
             // G^ rows i < N:  2 S^ W~'   (lanes 0..N; with samples: this role's share)
             double Sm[N], WT[N + 1], Gb[N];
@@ -403,7 +411,7 @@ __device__ __forceinline__ void lds_vjp_sweep1_body(const VjpArgs& a, double* ta
           transpose_tile<N>(tab, c, K, KT_);          // KT = Lh U'
           mm_ab<N, N, true>(Pex, U, KT_);             // Pex = -U Lh U'
           double* ad = a.adj + (b * T + t) * AS;
-          if (valid && col) static_for<0, N>([&](auto i) { ad[2 * N * HS + N * PS + i * PS + c] = Pex[i]; });
+          if (valid && col) static_for<0, N>([&](auto i) { ad[vjp_pex_off(N) + i * PS + c] = Pex[i]; });
         }
       }
       return;
@@ -640,7 +648,7 @@ __device__ __forceinline__ void lds_vjp_sweep1_body(const VjpArgs& a, double* ta
       });
       mm_ab<N, N, false>(T1, Pib, Pi);
       mm_ab<N, N, true>(Pbp, Pi, T1);
-      if (valid && col) static_for<0, N>([&](auto i) { ad[2 * N * HS + i * PS + c] = Pbp[i]; });
+      if (valid) static_for<0, N>([&](auto i) { if (c <= i) ad[vjp_pbp_off(N) + i * (i + 1) / 2 + c] = Pbp[i]; });
     }
 
     // S^ <- G~' (S^ G~)
@@ -699,6 +707,16 @@ __device__ __forceinline__ void lds_vjp_sweep1_body(const VjpArgs& a, double* ta
       dpp_fence(xh);
       // cbar_t += sum_s xhat (lane N);  Xbar_t -= sum_s xhat x_{t+1}'  (i.e. G^[:, :n] += ...)
       // (x_{t+1} and eps of the first samples were requested at the top of the role: x1r, epr)
+      if constexpr (SPLIT) {
+        // two-role launch (S <= VJP_SPLIT_MAX_S): this role's share of G^ leaves as its factors, per sample
+        // [xhat_s | x_{t+1,s}] -- sweep 2 forms the rank-S product
+        double* vo = ad + vjp_vec_off(N);
+        if (valid && sv) static_for<0, N>([&](auto k) { vo[c * 2 * N + k] = xh[k]; });     // lane s holds xhat_s
+        for_samples<0>(S, [&](auto s) {
+          const double x1 = (s < SPRE) ? x1r[s < SPRE ? (int)s : 0] : x1rec[s * N + ccl];
+          if (valid && col) vo[s * 2 * N + N + c] = (t + 1 < T) ? x1 : 0.0;
+        });
+      } else {
       for_samples<0>(S, [&](auto s) {
         double v = EN;
         if (t + 1 < T) {
@@ -708,6 +726,7 @@ __device__ __forceinline__ void lds_vjp_sweep1_body(const VjpArgs& a, double* ta
         asm volatile("s_nop 1");   // block entry after the branch: two wait states before the DPP reads (audit rule)
         static_for<0, N>([&](auto i) { mac_bc<s>(Gb[i], xh[i], v); });
       });
+      }
       if constexpr (!PROD) {
       // noise adjoint:  Pbar_t(direct) = -U (Lh U')  with  U = L^-T D^-1/2,  Lh from E' = sum_s eps_s z_s'
       double R[N], U[N];
@@ -737,10 +756,10 @@ __device__ __forceinline__ void lds_vjp_sweep1_body(const VjpArgs& a, double* ta
       mm_ab<N, N, false>(K, U, LhT);              // K = U Lh'
       transpose_tile<N>(tab, c, K, KT);           // KT = Lh U'
       mm_ab<N, N, true>(Pex, U, KT);              // Pex = -U Lh U'
-      if (valid && col) static_for<0, N>([&](auto i) { ad[2 * N * HS + N * PS + i * PS + c] = Pex[i]; });
+      if (valid && col) static_for<0, N>([&](auto i) { ad[vjp_pex_off(N) + i * PS + c] = Pex[i]; });
       }
-      // sampler share of G^ (SPLIT), or the total when this workgroup ran both bodies
-      if (valid && colN) static_for<0, N>([&](auto i) { ad[(SPLIT ? N * HS : 0) + i * HS + c] = Gb[i]; });
+      // G^ total when this workgroup ran both bodies
+      if constexpr (!SPLIT) { if (valid && colN) static_for<0, N>([&](auto i) { ad[i * HS + c] = Gb[i]; }); }
       }   // sampler adjoint
     }
   }
@@ -861,14 +880,22 @@ __device__ __forceinline__ void lds_vjp_sweep2_body(const VjpArgs& a) {
   //   * (small batches) the records of a step VJP_AHEAD iterations ahead are touched so that all of these
   //     find their lines in L2 (they were written ~T steps ago by other kernels: HBM otherwise).
   const int cN = colN ? c : 0, cc = col ? c : 0;
-  double gbn[N], gb2n[(SAMP && SPLIT) ? N : 1];
+  constexpr int VS = (SAMP && SPLIT) ? VJP_SPLIT_MAX_S : 1;    // two-role launches: the sampler share of G^ arrives as factors
+  const int S = a.S;
+  double gbn[N], xsn[VS], vsn[VS];
   auto fetch_g = [&](int t) {
     const double* ad = PROD ? ringrow + (t & 1) * SLOT + WS : a.adj + ((long)b * T + t) * AS;
-    static_for<0, N>([&](auto i) {
-      gbn[i] = ad[i * HS + cN];
-      if constexpr (SAMP && SPLIT) gb2n[i] = ad[N * HS + i * HS + cN];
-    });
+    static_for<0, N>([&](auto i) { gbn[i] = ad[i * HS + cN]; });
+    if constexpr (SAMP && SPLIT) {
+      static_for<0, VS>([&](auto s) {
+        const int sq = s < S ? (int)s : 0;                       // (clamped: unconditional loads)
+        xsn[s] = ad[vjp_vec_off(N) + sq * 2 * N + cc];           // xhat_s
+        vsn[s] = ad[vjp_vec_off(N) + sq * 2 * N + N + cc];       // x_{t+1,s}
+      });
+    }
   };
+  int symo[N];                                                 // entry (i, c) of a symmetric matrix kept as its lower triangle
+  static_for<0, N>([&](auto i) { symo[i] = cc <= i ? i * (i + 1) / 2 + cc : cc * (cc + 1) / 2 + i; });
   if constexpr (!PROD) fetch_g(T - 1);
   double warm = 0.0, sink = 0.0;
   for (int t = T - 1; t >= 0; --t) {
@@ -879,11 +906,22 @@ __device__ __forceinline__ void lds_vjp_sweep2_body(const VjpArgs& a) {
     const double* w = PROD ? ringrow + (t & 1) * SLOT : wsb + (long)t * WS;
     const double* ad = PROD ? w + WS : a.adj + ((long)b * T + t) * AS;
     double Xc[N];
-    static_for<0, N>([&](auto i) {
-      double gb = gbn[i];
-      if constexpr (SAMP && SPLIT) gb += gb2n[i];
-      Xc[i] = colN ? gb * sg : 0.0;                            // [Xbar | cbar] = [-G^ | G^[:,n]]
-    });
+    static_for<0, N>([&](auto i) { Xc[i] = colN ? gbn[i] * sg : 0.0; });      // [Xbar | cbar] = [-G^ | G^[:,n]]
+    if constexpr (SAMP && SPLIT) {
+      // sampler share: G^ += sum_s xhat_s [x_{t+1,s}' | 1]  (sign of [Xbar | cbar] folded into the second factor)
+      double xs[VS], vq[VS];
+      static_for<0, VS>([&](auto s) { xs[s] = xsn[s]; vq[s] = col ? -vsn[s] : EN; });
+      dpp_fence(xs);
+      static_for<0, N>([&](auto i) { mac_bc<i>(Xc[i], xs[0], vq[0]); });      // (sample 0 without a branch)
+      if (S > 1) {
+        for_samples<1>(S, [&](auto s) {
+          if constexpr (s < VS) {
+            asm volatile("s_nop 1");   // block entry after the branch: two wait states before the DPP reads (audit rule)
+            static_for<0, N>([&](auto i) { mac_bc<i>(Xc[i], xs[s], vq[s]); });
+          }
+        });
+      }
+    }
     // raw operands: lanes outside the tile read element 0 of the row (finite); they are never a DPP
     // broadcast source and only reach lanes of the results that are masked or not stored
     double Pi[N], Hc[N], HT[N + 1];
@@ -908,8 +946,8 @@ __device__ __forceinline__ void lds_vjp_sweep2_body(const VjpArgs& a) {
     // Bbar = P^-1 [Xbar | cbar]
     double Bb[N], Pb[N], Pxr[SAMP ? N : 1];
     static_for<0, N>([&](auto i) {                             // sweep-1 shares of Pbar: land during the product
-      Pb[i] = ad[2 * N * HS + i * PS + cc];
-      if constexpr (SAMP) Pxr[i] = ad[2 * N * HS + N * PS + i * PS + cc];
+      Pb[i] = ad[vjp_pbp_off(N) + symo[i]];
+      if constexpr (SAMP) Pxr[i] = ad[vjp_pex_off(N) + i * PS + cc];
       Bb[i] = 0.0;
     });
     mm_ab<N, N, false>(Bb, Pi, Xc);
@@ -1035,6 +1073,9 @@ __global__ __launch_bounds__(128) void lds_vjp_sweep2_s4_kernel(const VjpArgs a)
   double AbR[N];                                    // [Abar | hbar] of step t+1, replicated over the DPP rows
   static_for<0, N>([&](auto i) { AbR[i] = 0.0; });
   const bool olane = col && (c & 3) == r;           // lane i of DPP row i & 3 reports node i
+  int so[J];                                        // entry (row, c) of a symmetric matrix kept as its lower triangle
+  static_for<0, J>([&](auto j) { so[j] = cc <= ri[j] ? ri[j] * (ri[j] + 1) / 2 + cc : cc * (cc + 1) / 2 + ri[j]; });
+  const int S = a.S;
 
   for (int t = T - 1; t >= 0; --t) {
     lds_barrier();                                  // step t is in slot t % 2
@@ -1043,12 +1084,25 @@ __global__ __launch_bounds__(128) void lds_vjp_sweep2_s4_kernel(const VjpArgs a)
     double gb[J], Pi[J], Hc[J], Pb[J], HT[N + 1];
     static_for<0, J>([&](auto j) {
       gb[j] = ad[ri[j] * HS + cN];
-      if constexpr (SAMP) gb[j] += ad[N * HS + ri[j] * HS + cN];
       Pi[j] = w[N * HS + ri[j] * PS + cc];
       Hc[j] = w[ri[j] * HS + cN];
-      Pb[j] = ad[2 * N * HS + ri[j] * PS + cc];
-      if constexpr (SAMP) Pb[j] += ad[2 * N * HS + N * PS + ri[j] * PS + cc];
+      Pb[j] = ad[vjp_pbp_off(N) + so[j]];
+      if constexpr (SAMP) Pb[j] += ad[vjp_pex_off(N) + ri[j] * PS + cc];
     });
+    if constexpr (SAMP) {
+      // sampler share of G^ (two-role launch: factors per sample):  G^ += sum_s xhat_s [x_{t+1,s}' | 1]
+      // (sample 0 without a branch: its loads go out with the others of the step)
+      auto add_sample = [&](auto s) {
+        const double* vo = ad + vjp_vec_off(N) + s * 2 * N;
+        const double x1 = vo[N + cc];
+        double xr[J];
+        static_for<0, J>([&](auto j) { xr[j] = vo[ri[j]]; });
+        const double vv = col ? x1 : EN;
+        static_for<0, J>([&](auto j) { gb[j] = __builtin_fma(xr[j], vv, gb[j]); });
+      };
+      add_sample(std::integral_constant<int, 0>{});
+      if (S > 1) static_for<1, VJP_SPLIT_MAX_S>([&](auto s) { if (s < S) add_sample(s); });
+    }
     load_row<N + 1>(w + cc * HS, HT);               // H' (lane c: row c of H), the same in every DPP row
     // [Xbar | cbar] = [-G^ | G^[:,n]] - J12_t [Abar | hbar]_{t+1}      (my rows)
     double Xc[J];
@@ -1119,7 +1173,9 @@ template <int N>
 static int launch_vjp(const VjpArgs& a, hipStream_t stream) {
   dim3 grid((a.B + 3) / 4), grid2(2 * ((a.B + 3) / 4)), block(64);
   const bool statc = a.g_E_init || a.g_E_pair;
-  const bool split = a.B <= 2048;        // two roles while 2 wavefronts per 4 sequences still find idle SIMDs
+  // two roles while 2 wavefronts per 4 sequences still find idle SIMDs (the sampler role hands its share of G^ to
+  // sweep 2 as per-sample factors: room for VJP_SPLIT_MAX_S of them in the scratch record)
+  const bool split = a.B <= 2048 && a.S <= VJP_SPLIT_MAX_S;
   if (a.g_samples) {
     if (statc && split) hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, true, true, true>), grid2, block, 0, stream, a);
     else if (statc) hipLaunchKernelGGL((lds_vjp_sweep1_kernel<N, true, true, false>), grid, block, 0, stream, a);

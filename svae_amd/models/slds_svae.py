@@ -30,7 +30,7 @@ from ..distributions import expfam
 from ..parallel import allreduce_nested
 from ..hmm.hmm_inference import hmm_estep, hmm_logZ_differentiable
 from ..lds.lds_inference import (LDSEStepPlan, lds_inference_differentiable, natural_lds_estep_general,
-                                     natural_lds_inference_general)
+                                     natural_lds_sample)
 
 
 def _dev64(x, device):
@@ -73,6 +73,21 @@ def get_var_lds_local_natparam(dense_init, dense_pair, expected_states):
     """(:92-103) expected_states (B,T,K) -> init params (B,..) and per-step pair params (B,T-1,..)."""
     w0, w1 = expected_states[:, 0], expected_states[:, 1:]
     init = tuple(torch.tensordot(w0, p, dims=1) for p in dense_init)
+    B, T, K = expected_states.shape
+    n = dense_pair[0].shape[-1]
+    if expected_states.is_cuda and T > 1 and K <= 16 and 3 * n * n + 1 <= 1024 \
+            and not any(x.requires_grad for x in (expected_states,) + tuple(dense_pair)):
+        # the (B,T-1) x K x (3 n^2 + 1) mixture in one kernel bound by the output it writes (svae_slds_mix_pair_natparam_f64)
+        dev = expected_states.device
+        f64 = dict(dtype=torch.float64, device=dev)
+        out = tuple(torch.empty(B, T - 1, n, n, **f64) for _ in range(3)) + (torch.empty(B, T - 1, **f64),)
+        p = _lib.ptr
+        params = tuple(_dev64(x, dev).contiguous() for x in dense_pair)
+        rc = _lib.load().svae_slds_mix_pair_natparam_f64(B, T, K, n, p(_dev64(expected_states, dev).contiguous()),
+                                                         *(p(x) for x in params), *(p(x) for x in out),
+                                                         _lib.current_stream(dev))
+        _lib.check(rc, "svae_slds_mix_pair_natparam_f64")
+        return init, out
     pair = tuple(torch.tensordot(w1, p, dims=1) for p in dense_pair)
     return init, pair
 
@@ -180,6 +195,20 @@ class SLDSMeanfieldPlan(object):
 def _arhmm_nodeparams_from_path(dense_init, dense_pair, x):
     """get_arhmm_local_nodeparams (:131-147) for the statistics of ONE sample path x (B,T,n)
     (initialize_local_meanfield, :203-226) as quadratic forms -- without building the outer products."""
+    B, T, n = x.shape
+    K = dense_init[0].shape[0]
+    if x.is_cuda and n <= 15 and K <= 16:
+        # three quadratic forms per (sequence, step, state) in one kernel (svae_slds_path_nodeparams_f64)
+        dev = x.device
+        c = lambda v: _dev64(v, dev).contiguous()
+        out = torch.empty(B, T, K, dtype=torch.float64, device=dev)
+        p = _lib.ptr
+        rc = _lib.load().svae_slds_path_nodeparams_f64(B, T, K, n, p(c(x)), p(c(dense_init[0])), p(c(dense_init[1])),
+                                                       p(c(dense_init[2] + dense_init[3])), p(c(dense_pair[0])),
+                                                       p(c(dense_pair[1])), p(c(dense_pair[2])), p(c(dense_pair[3])),
+                                                       p(out), _lib.current_stream(dev))
+        _lib.check(rc, "svae_slds_path_nodeparams_f64")
+        return out
     x0, xa, xb = x[:, 0], x[:, :-1], x[:, 1:]
     n0 = torch.einsum("bi,kij,bj->bk", x0, dense_init[0], x0) + x0 @ dense_init[1].T + dense_init[2] + dense_init[3]
     q = lambda u, M, v: (torch.einsum("bti,kij->btkj", u, M) * v.unsqueeze(2)).sum(-1)
@@ -250,7 +279,7 @@ def _initial_sample_path(node_potentials, eps):
     A = 0.9 * eye
     natparam = ((-0.5 * eye, torch.zeros(n, dtype=torch.float64, device=dev), torch.zeros((), dtype=torch.float64, device=dev)),
                 (-0.5 * A.T @ A, A.T.contiguous(), -0.5 * eye, torch.zeros((), dtype=torch.float64, device=dev)))
-    x, _, _ = natural_lds_inference_general(natparam, node_potentials, num_samples=1, eps=eps)
+    x = natural_lds_sample(natparam, node_potentials, num_samples=1, eps=eps)     # filter + sampler, no smoother (:222)
     return x[:, :, 0]                                                # (B,T,n)
 
 

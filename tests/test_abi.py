@@ -54,7 +54,10 @@ def test_workspace_size_formula():
     assert lib.svae_lds_workspace_bytes(512, 200, 10) == 512 * (one(200, 10) + two(200, 10) + 1 + 200 * (10 * 10 + 10 + 11 * 12)) * 8
     assert lib.svae_lds_workspace_bytes(3, 7, 5) == 3 * (one(7, 5) + two(7, 5) + 1 + 7 * (5 * 5 + 5 + 6 * 6)) * 8
     assert lib.svae_lds_workspace_bytes(3, 7, 12) == 3 * (one(7, 12) + 1 + 7 * (12 * 12 + 12 + 13 * 14)) * 8
-    assert lib.svae_lds_vjp_workspace_bytes(3, 7, 5) == 3 * 7 * 5 * (2 * 6 + 2 * 6) * 8
+    # VJP scratch per (sequence, step): G^ (n rows, stride even(n+1)) | factors of the sampler share (2 n per sample, 4
+    # samples) | lower triangle of the symmetric share of Pbar (padded to even) | Pbar(direct) (n rows, stride even(n))
+    assert lib.svae_lds_vjp_workspace_bytes(3, 7, 5) == 3 * 7 * (5 * 6 + 2 * 4 * 5 + 16 + 5 * 6) * 8
+    assert lib.svae_lds_vjp_workspace_bytes(512, 200, 10) == 512 * 200 * (10 * 12 + 80 + 56 + 100) * 8
     # n > 15: tiled path, per step X and P^-1 (NP x NP, NP = n rounded up to 16) and c (NP)
     # + the pair parameters re-packed in fragment order: 2 slots (homogeneous) or T-1 per set, 3 NP^2 each
     assert lib.svae_lds_workspace_bytes(1, 1, 16) == (2 * 16 * 16 + 16) * 8

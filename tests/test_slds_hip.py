@@ -419,3 +419,34 @@ def test_run_inference_against_reference_golden(case, golden_dir):
     assert G.rel(_np(g_init[0]), g["run_stat_init_xx"]) < 1e-6 and G.rel(_np(g_init[1]), g["run_stat_init_x"]) < 1e-6
     for i in range(4):
         assert G.rel(_np(g_pair[i]), g["run_stat_pair%d" % i]) < 1e-6
+
+
+@pytest.mark.parametrize("K,n,T,B", [(3, 4, 9, 5), (8, 10, 40, 11), (16, 15, 6, 3), (1, 1, 2, 2), (5, 7, 2, 4)])
+def test_contraction_kernels_against_the_dense_forms(K, n, T, B):
+    """svae_slds_path_nodeparams_f64 / svae_slds_mix_pair_natparam_f64 (the two ends of the ascent) against the dense
+    contractions they replace, evaluated on the CPU: get_arhmm_local_nodeparams on the outer products of a path
+    (slds_svae.py:203-226, 131-147) and the tensordot form of get_var_lds_local_natparam (:92-103)."""
+    from svae_amd.models import slds_svae as S
+    g = torch.Generator().manual_seed(K * 100 + n)
+    r = lambda *s: torch.randn(*s, dtype=torch.float64, generator=g)
+    dense_init = (r(K, n, n), r(K, n), r(K), r(K))
+    dense_pair = (r(K, n, n), r(K, n, n), r(K, n, n), r(K))
+    x = r(B, T, n)
+    w = torch.softmax(r(B, T, K), -1)
+    dev = torch.device("cuda:0")
+    to = lambda t: tuple(v.to(dev) for v in t)
+    # path -> node potentials
+    got = S._arhmm_nodeparams_from_path(to(dense_init), to(dense_pair), x.to(dev))
+    out = lambda a, b: a.unsqueeze(-1) * b.unsqueeze(-2)
+    init_stats = (out(x[:, 0], x[:, 0]), x[:, 0])
+    pair_stats = (out(x[:, :-1], x[:, :-1]), out(x[:, :-1], x[:, 1:]), out(x[:, 1:], x[:, 1:]))
+    want = S.get_arhmm_local_nodeparams(dense_init, dense_pair, init_stats, pair_stats)
+    assert got.shape == (B, T, K)
+    _close(got, _np(want), 1e-11)
+    # marginals -> per-step natural parameters
+    gi, gp = S.get_var_lds_local_natparam(to(dense_init), to(dense_pair), w.to(dev))
+    wi, wp = S.get_var_lds_local_natparam(dense_init, dense_pair, w)
+    for a, b in zip(tuple(gi) + tuple(gp), tuple(wi) + tuple(wp)):
+        assert tuple(a.shape) == tuple(b.shape)
+        if b.numel():
+            _close(a, _np(b), 1e-12)
