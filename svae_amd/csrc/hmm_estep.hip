@@ -59,6 +59,22 @@ struct HmmArgs {
 constexpr int HMM_WS = 34;                // [alpha (16) | e/c or its log-space stand-in (16) | flag | pad]
 constexpr double HMM_TINY = 1e-200;
 
+// Maximum over the 16 lanes of a DPP row, in every lane: four rotate-and-max steps (row_ror:8/4/2/1 on the two halves
+// of the double; compiler-scheduled, hazards padded by hipcc) instead of K broadcasts.
+template <int R>
+__device__ __forceinline__ double row_ror(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x120 + R, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x120 + R, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_max16(double x) {
+  x = __builtin_fmax(x, row_ror<8>(x));
+  x = __builtin_fmax(x, row_ror<4>(x));
+  x = __builtin_fmax(x, row_ror<2>(x));
+  x = __builtin_fmax(x, row_ror<1>(x));
+  return x;
+}
+
 template <int K, bool FUSED = false>
 __global__ __launch_bounds__(64) void hmm_estep_kernel(const HmmArgs a) {
   const int lane = threadIdx.x;
@@ -125,10 +141,7 @@ __global__ __launch_bounds__(64) void hmm_estep_kernel(const HmmArgs a) {
     if (nout && valid && col) nout[(long)t * K] = nd_n;
     if (t + 1 < T) nd_n = node_at(t + 1);
     if (t == 0) nd += col ? a.init_params[cc] : 0.0;
-    // m = max_k node[k]  (broadcast-and-max over the row)
-    double m = NEG_BIG;
-    dpp_fence(nd);
-    static_for<0, K>([&](auto k) { m = fmax(m, bcast_fenced<k>(nd)); });
+    const double m = row_max16(nd);         // m = max_k node[k]
     const double e = col ? exp(nd - m) : 0.0;
     double pred;
     if (t == 0) {
@@ -136,12 +149,12 @@ __global__ __launch_bounds__(64) void hmm_estep_kernel(const HmmArgs a) {
     } else {
       pred = 0.0;
       dpp_fence(alpha);
-      static_for<0, K>([&](auto j) { mac_bc<j, false, true>(pred, alpha, P[j]); });   // sum_j alpha[j] P[j][k]
+      static_for<0, K>([&](auto j) { mac_bc<j>(pred, alpha, P[j]); });   // sum_j alpha[j] P[j][k]
     }
     double al = pred * e;
     double cs = 0.0;
     dpp_fence(al);
-    static_for<0, K>([&](auto k) { mac_bc<k, false, true>(cs, al, one); });            // c_t = sum_k
+    static_for<0, K>([&](auto k) { mac_bc<k>(cs, al, one); });            // c_t = sum_k
     double rc = rcp_nr(cs);                 // (v_rcp_f64 + two Newton steps: no fp64 divide on the serial chain)
     double u_st = e * rc, shift = m + (t > 0 ? pmax : 0.0), flag = 0.0;
     const bool tiny = !(cs > HMM_TINY);
@@ -244,8 +257,8 @@ __global__ __launch_bounds__(64) void hmm_estep_kernel(const HmmArgs a) {
       dpp_fence(w0);
       dpp_fence(al0);
       double bn = 0.0;
-      static_for<0, K>([&](auto k) { mac_bc<k, false, true>(bn, w0, PT[k]); });
-      static_for<0, K>([&](auto j) { mac_bc<j, false, true>(acc[j], al0, w0); });
+      static_for<0, K>([&](auto k) { mac_bc<k>(bn, w0, PT[k]); });
+      static_for<0, K>([&](auto j) { mac_bc<j>(acc[j], al0, w0); });
       beta = slow ? fmin(bn2, 1e300) : bn;
       const double gam = al * beta;
       if (valid && col) oS[(long)t * K] = gam;
@@ -257,8 +270,8 @@ __global__ __launch_bounds__(64) void hmm_estep_kernel(const HmmArgs a) {
     dpp_fence(w);
     dpp_fence(al_f);
     double bn = 0.0;
-    static_for<0, K>([&](auto k) { mac_bc<k, false, true>(bn, w, PT[k]); });            // beta_t[j] = sum_k P[j][k] w[k]
-    static_for<0, K>([&](auto j) { mac_bc<j, false, true>(acc[j], al_f, w); });         // xi sums (without P)
+    static_for<0, K>([&](auto k) { mac_bc<k>(bn, w, PT[k]); });            // beta_t[j] = sum_k P[j][k] w[k]
+    static_for<0, K>([&](auto j) { mac_bc<j>(acc[j], al_f, w); });         // xi sums (without P)
     beta = bn;
     const double gam = al * beta;
     if (valid && col) oS[(long)t * K] = gam;
