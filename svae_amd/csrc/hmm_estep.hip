@@ -424,13 +424,20 @@ __global__ __launch_bounds__(1024) void slds_mix_pair_kernel(int B, int T, int K
   const int es = m == 3 ? 1 : nn;                    // elements per state / per output row
   double pk[16];
   static_for<0, 16>([&](auto k) { pk[k] = k < K ? P[(long)k * es + ee] : 0.0; });
-  const long rows = (long)B * (T - 1);
-  for (long r = blockIdx.x; r < rows; r += gridDim.x) {
-    const long b = r / (T - 1), t = r - b * (T - 1);
-    const double* wr = w + (b * T + t + 1) * K;
-    double acc = 0.0;
-    static_for<0, 16>([&](auto k) { if (k < K) acc = __builtin_fma(wr[k], pk[k], acc); });
-    O[r * es + ee] = acc;
+  constexpr int U = 4;                               // steps in flight per thread (their weight loads and stores overlap)
+  for (long b = blockIdx.y; b < B; b += gridDim.y) {  // (no division in the loops: grid rows stride over the sequences)
+    const double* wb = w + (b * T + 1) * K;
+    double* Ob = O + b * (T - 1) * es + ee;
+    for (int t0 = blockIdx.x * U; t0 < T - 1; t0 += gridDim.x * U) {
+      double acc[U];
+      static_for<0, U>([&](auto u) {
+        const int t = t0 + u < T - 1 ? t0 + u : T - 2;
+        const double* wr = wb + (long)t * K;
+        acc[u] = 0.0;
+        static_for<0, 16>([&](auto k) { if (k < K) acc[u] = __builtin_fma(wr[k], pk[k], acc[u]); });
+      });
+      static_for<0, U>([&](auto u) { if (t0 + u < T - 1) Ob[(long)(t0 + u) * es] = acc[u]; });
+    }
   }
 }
 
@@ -568,10 +575,10 @@ extern "C" int svae_slds_mix_pair_natparam_f64(int B, int T, int K, int n, const
   if (!J11 || !J12 || !J22 || !lz) return -6;
   if (!out_J11 || !out_J12 || !out_J22 || !out_logZ) return -10;
   if (B == 0 || T == 1) return 0;
-  const long rows = (long)B * (T - 1);
   const int threads = ((3 * n * n + 1) + 63) / 64 * 64;
-  const unsigned grid = (unsigned)(rows < 4096 ? rows : 4096);
-  hipLaunchKernelGGL(svae::slds_mix_pair_kernel, dim3(grid), dim3(threads), 0, (hipStream_t)stream, B, T, K, n * n,
+  const int per_seq = (T - 1 + 3) / 4;                                  // four steps per thread and trip
+  const unsigned gx = (unsigned)(per_seq < 8 ? per_seq : 8);
+  hipLaunchKernelGGL(svae::slds_mix_pair_kernel, dim3(gx, (unsigned)(B < 65535 ? B : 65535)), dim3(threads), 0, (hipStream_t)stream, B, T, K, n * n,
                      E_states, J11, J12, J22, lz, out_J11, out_J12, out_J22, out_logZ);
   return hipGetLastError() == hipSuccess ? 0 : -1000;
 }

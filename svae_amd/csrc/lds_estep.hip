@@ -264,8 +264,11 @@ int svae_lds_filter_f64(int B, int T, int n, int inhomog, int pair_batched, unsi
   a.pair_seq_stride = pair_batched ? (long)(T - 1) * n * n : 0;
   a.msg_Jp = J_pred; a.msg_hp = h_pred; a.msg_Jf = J_filt; a.msg_hf = h_filt;
   a.mix_w = nullptr; a.mix_out = nullptr; a.seq_index = nullptr; a.mix_K = 0; a.lds_keep = 0;
-  // small batches without message outputs: one sequence per wavefront (0.62 -> 0.24 ms at B = 512, T = 200, n = 10)
-  const bool fsplit = sel.split && !J_pred && !h_pred && !J_filt && !h_filt;
+  // small batches without message outputs: one sequence per wavefront (0.62 -> 0.24 ms at B = 512, T = 200, n = 10).
+  // The one-register filter (n <= 10) stays ahead of the packed kernel until ~3 wavefronts per SIMD (filter + sampler,
+  // T = 500: 1024 sequences 0.86 vs 1.81 ms, 2048: 1.85 vs 2.53; T = 200, 4096: 1.43 vs 1.27)
+  const bool wide = sel.layout == 1 || (sel.layout == 0 && B <= (n <= svae::TE_MAX_N && twoend ? 3072 : 1023));
+  const bool fsplit = wide && !J_pred && !h_pred && !J_filt && !h_filt;
   switch (n) {
 #define SVAE_CASE_(NN) case NN: return !fsplit ? svae_lds_launch_filter_n##NN(&a, inhomog, stream)          \
                                        : (NN <= svae::TE_MAX_N && twoend) ? svae_lds_launch_filter_1r_n##NN(&a, inhomog, stream) \

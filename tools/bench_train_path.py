@@ -1,5 +1,6 @@
 """Timing of the training-step path of the LDS model at the headline shape: E-step (keeping the sampler /
-VJP hand-off), sampler, VJP.  Usage: python tools/bench_train_path.py [B T n S]"""
+VJP hand-off), sampler, VJP.  Usage: python tools/bench_train_path.py [B T n S] [--options NAME]   (NAME: a key of
+svae_amd._lib.KERNEL_OPTIONS, e.g. twoend_seq)"""
 import os, sys
 import numpy as np
 import torch
@@ -19,7 +20,9 @@ def main():
     eps = torch.randn(B, T, S, n, dtype=torch.float64, device=dev)
     g = [torch.randn(B, dtype=torch.float64, device=dev), torch.randn(B, T, n, dtype=torch.float64, device=dev),
          torch.randn(B, T, n, dtype=torch.float64, device=dev), torch.randn(B, T, S, n, dtype=torch.float64, device=dev)]
-    plan = LDSEStepPlan(B, T, n, dev)
+    from svae_amd import _lib
+    options = _lib.KERNEL_OPTIONS[sys.argv[sys.argv.index("--options") + 1]] if "--options" in sys.argv else None
+    plan = LDSEStepPlan(B, T, n, dev, options=options)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
     for rep in range(3):
         ev[0].record(); plan.launch(*args)
@@ -32,6 +35,8 @@ def main():
     print("B=%d T=%d n=%d S=%d: E-step %.3f ms | E-step keeping factor+cross %.3f | sampler %.3f | VJP %.3f  "
           "=> training path %.3f ms (%.0f seq/s)   [VJP without sample cotangents: %.3f ms]"
           % (B, T, n, S, ms[0], ms[1], ms[2], ms[3], sum(ms[1:4]), B / sum(ms[1:4]) * 1e3, ms[4]))
+    if options is not None:
+        return
     # the same path through the model layer (models.lds.run_inference_differentiable + backward): host wall
     # clock per iteration vs the kernels' sum above = launch / allocation / glue overhead
     import time
