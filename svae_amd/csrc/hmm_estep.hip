@@ -106,9 +106,10 @@ __global__ __launch_bounds__(64) void hmm_estep_kernel(const HmmArgs a) {
   // FUSED: node potential of step t >= 1 = pc[t-1][0] + pc[t][1] + lz (two loads instead of one)
   const double* pc = FUSED ? a.pair_contr + ((long)b * T) * 2 * K + cc : nullptr;
   const double lzc = FUSED ? a.lz[cc] : 0.0;
+  // (callers clamp t to [1, T-1]; with T = 1 the second FUSED read is clamped into the row as well: the value is unused)
   auto node_at = [&](int t) -> double {
-    if constexpr (FUSED) return (pc[(long)(t - 1) * 2 * K] + pc[(long)t * 2 * K + K]) + lzc;     // (t >= 1)
-    else return node[(long)t * K];
+    if constexpr (FUSED) return (pc[(long)(t - 1) * 2 * K] + pc[(long)(t < T ? t : T - 1) * 2 * K + K]) + lzc;
+    else return node[(long)(t < T ? t : T - 1) * K];
   };
   double node0;
   if constexpr (FUSED) {
@@ -139,7 +140,9 @@ __global__ __launch_bounds__(64) void hmm_estep_kernel(const HmmArgs a) {
   for (int t = 0; t < T; ++t) {
     double nd = col ? nd_n : NEG_BIG;
     if (nout && valid && col) nout[(long)t * K] = nd_n;
-    if (t + 1 < T) nd_n = node_at(t + 1);
+    // next step's potentials, UNCONDITIONALLY (clamped): a load inside `if (t + 1 < T)` is waited for at the end of
+    // its block, i.e. every step stalled for the full memory latency (0.55 -> ... us per step)
+    nd_n = node_at(t + 1 < T ? t + 1 : (T > 1 ? T - 1 : 1));
     if (t == 0) nd += col ? a.init_params[cc] : 0.0;
     const double m = row_max16(nd);         // m = max_k node[k]
     const double e = col ? exp(nd - m) : 0.0;
