@@ -121,20 +121,37 @@ __device__ __forceinline__ void for_owned(d4 (&acc)[tv_maxt<NB>()], int wave, in
   }
 }
 
-// this lane's C-layout entries of a global n x n matrix (row stride gld), zero outside: requested a step ahead like the
-// LDS operands (an element-wise epilogue operand loaded after its product would expose the HBM latency every step)
+// Memory schedule of the phases: every global operand of a step is REQUESTED one step ahead and first touched where it
+// is used.  Two things would undo that and are avoided throughout: a load inside a conditional block (hipcc waits for
+// it at the end of the block -- so the requests are unconditional, with clamped indices, and the zero padding /
+// validity mask is applied where the value is consumed), and __syncthreads() (its fences wait for ALL outstanding
+// memory operations: the workgroup only ever exchanges data through LDS, so the barriers here wait for LDS only).
+__device__ __forceinline__ void tile_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// this lane's C-layout entries of a global n x n matrix (row stride gld): raw (clamped addresses), requested a step
+// ahead like the LDS operands; mask_c zeroes the entries outside n x n at the point of use
 template <int NB>
 __device__ __forceinline__ void fetch_c(d4 (&v)[tv_maxt<NB>()], const double* src, int gld, int n, int wave, int r16, int kq) {
 #pragma unroll
   for (int j = 0; j < tv_maxt<NB>(); ++j) {
-    const int q = wave + 4 * j;
-    v[j] = d4{0.0, 0.0, 0.0, 0.0};
-    if (q < NB * NB) {
+    const int q = wave + 4 * j < NB * NB ? wave + 4 * j : 0;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = 16 * (q / NB) + kq + 4 * i, c = 16 * (q % NB) + r16;
-        v[j][i] = (r < n && c < n) ? src[(long)r * gld + c] : 0.0;
-      }
+    for (int i = 0; i < 4; ++i) {
+      const int r = 16 * (q / NB) + kq + 4 * i, c = 16 * (q % NB) + r16;
+      const bool ok = r < n && c < n;
+      v[j][i] = src[(long)(ok ? r : 0) * gld + (ok ? c : 0)];
+    }
+  }
+}
+template <int NB>
+__device__ __forceinline__ void mask_c(d4 (&v)[tv_maxt<NB>()], int n, int wave, int r16, int kq) {
+#pragma unroll
+  for (int j = 0; j < tv_maxt<NB>(); ++j) {
+    const int q = wave + 4 * j;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 16 * (q / NB) + kq + 4 * i, c = 16 * (q % NB) + r16;
+      v[j][i] = (q < NB * NB && r < n && c < n) ? v[j][i] : 0.0;
     }
   }
 }
@@ -152,18 +169,19 @@ __device__ __forceinline__ void store_acc(double* M, d4 (&acc)[tv_maxt<NB>()], i
 // A global matrix (row stride gld, n x n valid) travels through 16 registers per thread: fetch (global -> registers,
 // issued a step ahead of its use: the operands come from HBM, ~2 us away) and stage (registers -> LDS, zero-padded to
 // NP x NP, scaled).  Thread (ty, tx) holds columns 4 tx .. 4 tx + 3 of rows ty, ty + 16, ty + 32, ty + 48.
+// (fetch: raw values from clamped addresses, no branch; stage: zero outside n x n)
 struct MatRegs { double v[4][4]; };
 __device__ __forceinline__ void fetch_mat(MatRegs& m, const double* src, int gld, int n) {
   const int ty = threadIdx.x >> 4, c0 = 4 * (threadIdx.x & 15);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int r = ty + 16 * i;
+    const int r = ty + 16 * i < n ? ty + 16 * i : 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) m.v[i][j] = (r < n && c0 + j < n) ? src[(long)r * gld + c0 + j] : 0.0;
+    for (int j = 0; j < 4; ++j) m.v[i][j] = src[(long)r * gld + (c0 + j < n ? c0 + j : 0)];
   }
 }
 template <int NB>
-__device__ __forceinline__ void stage_mat(double* dst, const MatRegs& m) {
+__device__ __forceinline__ void stage_mat(double* dst, const MatRegs& m, int n) {
   constexpr int NPL = 16 * NB, LD = NPL + 2;
   const int ty = threadIdx.x >> 4, c0 = 4 * (threadIdx.x & 15);
   if (c0 >= NPL) return;
@@ -172,7 +190,7 @@ __device__ __forceinline__ void stage_mat(double* dst, const MatRegs& m) {
     const int r = ty + 16 * i;
     if (r < NPL) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) dst[r * LD + c0 + j] = m.v[i][j];
+      for (int j = 0; j < 4; ++j) dst[r * LD + c0 + j] = (r < n && c0 + j < n) ? m.v[i][j] : 0.0;
     }
   }
 }
@@ -180,7 +198,7 @@ template <int NB>
 __device__ __forceinline__ void load_mat(double* dst, const double* src, int gld, int n) {
   MatRegs m;
   fetch_mat(m, src, gld, n);
-  stage_mat<NB>(dst, m);
+  stage_mat<NB>(dst, m, n);
 }
 
 // LDS matrix -> global n x n (dense, row stride n), same thread mapping
@@ -203,7 +221,7 @@ __device__ __forceinline__ void symmetrize_lds(double* M) {
   constexpr int NPL = 16 * NB, LD = NPL + 2;
   const int r0 = 4 * (threadIdx.x >> 4), c0 = 4 * (threadIdx.x & 15);
   const bool on = r0 < NPL && c0 < NPL;
-  __syncthreads();
+  tile_barrier();
   double keep[4][4];
   if (on) {
 #pragma unroll
@@ -211,25 +229,34 @@ __device__ __forceinline__ void symmetrize_lds(double* M) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) keep[i][j] = 0.5 * (M[(r0 + i) * LD + c0 + j] + M[(c0 + j) * LD + r0 + i]);
   }
-  __syncthreads();
+  tile_barrier();
   if (on) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) M[(r0 + i) * LD + c0 + j] = keep[i][j];
   }
-  __syncthreads();
+  tile_barrier();
 }
 
-// y[i] = sum_j A[i][j] x[j]  (TRANS: A[j][i]) for i < n; A in LDS (row stride LD); x, y LDS vectors (y != x); barrier after
+// y[i] = sum_j A[i][j] x[j]  (TRANS: A[j][i]) for i < n <= 64; A in LDS (row stride LD); x, y LDS vectors (y != x);
+// `part`: 256 doubles of LDS scratch.  All four wavefronts: wavefront w sums the columns j = w, w + 4, .. of every row
+// (lane = row; four independent accumulators so that the LDS reads overlap), the partial sums meet in `part`.  Two
+// barriers inside, the second after y is complete.  (One thread per row and a serial 64-term loop took ~3 us a call.)
 template <bool TRANS>
-__device__ __forceinline__ void matvec(const double* A, int LD, const double* x, double* y, int n) {
-  for (int i = threadIdx.x; i < n; i += 256) {
-    double s = 0.0;
-    for (int j = 0; j < n; ++j) s = __builtin_fma(TRANS ? A[j * LD + i] : A[i * LD + j], x[j], s);
-    y[i] = s;
+__device__ __forceinline__ void matvec(const double* A, int LD, const double* x, double* y, int n, double* part) {
+  const int w = threadIdx.x >> 6, i = threadIdx.x & 63, ii = i < n ? i : 0;
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int j = w + 4 * u, jj = j < n ? j : 0;
+    const double av = TRANS ? A[jj * LD + ii] : A[ii * LD + jj];
+    s[u & 3] = __builtin_fma(j < n ? av : 0.0, x[jj], s[u & 3]);
   }
-  __syncthreads();
+  part[threadIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+  tile_barrier();
+  if (threadIdx.x < n) y[threadIdx.x] = (part[i] + part[64 + i]) + (part[128 + i] + part[192 + i]);
+  tile_barrier();
 }
 
 __device__ __forceinline__ const double* handoff(const TileVjpArgs& a, int b, int t) {
@@ -245,31 +272,34 @@ __global__ __launch_bounds__(256) void tile_vjp_phase0(const TileVjpArgs a) {
   double *L0 = sm, *L1 = sm + MAT, *L3 = sm + 2 * MAT;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r16 = lane & 15, kq = lane >> 4;
   for (int e = threadIdx.x; e < 3 * MAT; e += 256) sm[e] = 0.0;
-  __syncthreads();
+  tile_barrier();
   load_mat<NB>(L3, handoff(a, b, T - 1) + (long)NP * NP, NP, n);
   MatRegs gpre;
   d4 ppre[tv_maxt<NB>()];
-  if (T > 1) {
-    fetch_mat(gpre, handoff(a, b, T - 2), NP, n);
-    fetch_c<NB>(ppre, handoff(a, b, T - 2) + (long)NP * NP, NP, n, wave, r16, kq);
+  {
+    const int tp = T > 1 ? T - 2 : 0;
+    fetch_mat(gpre, handoff(a, b, tp), NP, n);
+    fetch_c<NB>(ppre, handoff(a, b, tp) + (long)NP * NP, NP, n, wave, r16, kq);
   }
-  __syncthreads();
+  tile_barrier();
   for (int t = T - 1; t >= 0; --t) {
     if (t < T - 1) {
-      stage_mat<NB>(L0, gpre);                                    // G_t, requested one step ago
+      stage_mat<NB>(L0, gpre, n);                                    // G_t, requested one step ago
       d4 pcur[tv_maxt<NB>()];
 #pragma unroll
       for (int j = 0; j < tv_maxt<NB>(); ++j) pcur[j] = ppre[j];  // P_t^-1 in the C layout
-      if (t > 0) {
-        fetch_mat(gpre, handoff(a, b, t - 1), NP, n);
-        fetch_c<NB>(ppre, handoff(a, b, t - 1) + (long)NP * NP, NP, n, wave, r16, kq);
+      mask_c<NB>(pcur, n, wave, r16, kq);
+      {
+        const int tp = t > 0 ? t - 1 : 0;                         // (unconditional: see the note on the memory schedule)
+        fetch_mat(gpre, handoff(a, b, tp), NP, n);
+        fetch_c<NB>(ppre, handoff(a, b, tp) + (long)NP * NP, NP, n, wave, r16, kq);
       }
-      __syncthreads();
+      tile_barrier();
       d4 acc[tv_maxt<NB>()];
       acc_zero<NB>(acc);
       gemm_mfma<NB, false, false>(L0, L3, wave, r16, kq, acc);    // G Sigma
       store_acc<NB>(L1, acc, wave, r16, kq);
-      __syncthreads();                                            // (everyone is done reading L3, too)
+      tile_barrier();                                            // (everyone is done reading L3, too)
       acc_zero<NB>(acc);
       gemm_mfma<NB, false, true>(L1, L0, wave, r16, kq, acc);     // (G Sigma) G'
 #pragma unroll
@@ -293,30 +323,35 @@ __global__ __launch_bounds__(256) void tile_vjp_phase1(const TileVjpArgs a) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r16 = lane & 15, kq = lane >> 4;
   for (int e = threadIdx.x; e < 4 * MAT + 192 + 3 * TV_MAX_S * 64; e += 256) sm[e] = 0.0;     // Sigma_bar = 0, vectors = 0
   MatRegs gpre, spre;
-  if (T > 1) { fetch_mat(gpre, handoff(a, b, 0), NP, n); fetch_mat(spre, a.sig + ((long)b * T + 1) * n * n, n, n); }
+  fetch_mat(gpre, handoff(a, b, 0), NP, n);
+  fetch_mat(spre, a.sig + ((long)b * T + (T > 1 ? 1 : 0)) * n * n, n, n);
   // direct cotangents and the mean of step t for thread i < n, requested one step ahead
   const int ti = threadIdx.x < n ? threadIdx.x : 0;
   double gdpre = 0.0, gxpre = 0.0, mtpre = 0.0;
+  const double* gd_src = a.g_dxx ? a.g_dxx : a.E_node_x;      // (absent cotangents: a valid address, the value is dropped)
+  const double* gx_src = a.g_x ? a.g_x : a.E_node_x;
+  const double gd_on = a.g_dxx ? 1.0 : 0.0, gx_on = a.g_x ? 1.0 : 0.0;
   auto fetch_vec = [&](int t) {
     const long o = ((long)b * T + t) * n + ti;
-    gdpre = a.g_dxx ? a.g_dxx[o] : 0.0;
-    gxpre = a.g_x ? a.g_x[o] : 0.0;
+    gdpre = gd_src[o];
+    gxpre = gx_src[o];
     mtpre = a.E_node_x[o];
   };
   fetch_vec(0);
-  __syncthreads();
+  tile_barrier();
   for (int t = 0; t < T; ++t) {
     const long bt = (long)b * T + t;
     const double* mt = a.E_node_x + bt * n;
     // direct cotangents of step t
     if (threadIdx.x < n) {
       const int i = threadIdx.x;
-      L3[i * LD + i] += gdpre;
-      mb[i] += gxpre + 2.0 * gdpre * mtpre;
+      const double gd = gd_on * gdpre, gx = gx_on * gxpre;
+      L3[i * LD + i] += gd;
+      mb[i] += gx + 2.0 * gd * mtpre;
     }
-    if (t + 1 < T) fetch_vec(t + 1);
+    fetch_vec(t + 1 < T ? t + 1 : t);
     if (t == 0 && a.g_E_init) {
-      __syncthreads();
+      tile_barrier();
       const double* gi = a.g_E_init + (long)b * (n * n + n);
       for (int e = threadIdx.x; e < n * n; e += 256) {
         const int r = e / n, c = e % n;
@@ -333,7 +368,7 @@ __global__ __launch_bounds__(256) void tile_vjp_phase1(const TileVjpArgs a) {
       // E x_t x_{t+1}', E x_{t+1} x_{t+1}').  Node t is the FIRST node of pair t (cotangents A0, A1) and the SECOND of
       // pair t-1 (A2', A1'):  Sigma_bar_t += sym(A0) + sym(A2'),  m_bar_t += (A0 + A0' + A2' + A2'') m_t + A1 m_{t+1}
       // + A1'' m_{t-1}.  (The covariance part of the cross statistic, G_t Sigma_{t+1}, is handled below.)
-      __syncthreads();
+      tile_barrier();
       const double* A = t < T - 1 ? a.g_E_pair + ((long)b * (T - 1) + t) * 3 * n * n : nullptr;
       const double* Ap = t > 0 ? a.g_E_pair + ((long)b * (T - 1) + t - 1) * 3 * n * n : nullptr;
       for (int e = threadIdx.x; e < n * n; e += 256) {
@@ -358,7 +393,7 @@ __global__ __launch_bounds__(256) void tile_vjp_phase1(const TileVjpArgs a) {
       const int s_ = e / n, i = e % n;
       xb[s_ * 64 + i] += a.g_samples[(bt * a.S + s_) * n + i];
     }
-    __syncthreads();
+    tile_barrier();
     // records for phase 2
     store_mat<NB>(a.pinv_bar + bt * n * n, L3, n);
     for (int i = threadIdx.x; i < n; i += 256) {
@@ -369,22 +404,26 @@ __global__ __launch_bounds__(256) void tile_vjp_phase1(const TileVjpArgs a) {
     for (int e = threadIdx.x; e < S * n; e += 256) a.xbar[(bt * a.S + e / n) * n + e % n] = xb[(e / n) * 64 + e % n];
     if (t == T - 1) break;
     // propagate to t + 1
-    stage_mat<NB>(L0, gpre);                                                     // G_t
-    stage_mat<NB>(L2, spre);                                                     // Sigma_{t+1}
-    if (t + 2 < T) { fetch_mat(gpre, handoff(a, b, t + 1), NP, n); fetch_mat(spre, a.sig + (bt + 2) * n * n, n, n); }
-    __syncthreads();
+    stage_mat<NB>(L0, gpre, n);                                                     // G_t
+    stage_mat<NB>(L2, spre, n);                                                     // Sigma_{t+1}
+    {
+      const int tq = t + 2 < T ? t + 1 : t;                                      // (unconditional, clamped)
+      fetch_mat(gpre, handoff(a, b, tq), NP, n);
+      fetch_mat(spre, a.sig + ((long)b * T + tq + 1) * n * n, n, n);
+    }
+    tile_barrier();
     d4 acc[tv_maxt<NB>()], accp[tv_maxt<NB>()];
     acc_zero<NB>(acc);
     gemm_mfma<NB, false, false>(L3, L0, wave, r16, kq, acc);                     // SG = Sigma_bar G
     store_acc<NB>(L1, acc, wave, r16, kq);
-    __syncthreads();                                                             // (Sigma_bar in L3 is consumed)
+    tile_barrier();                                                             // (Sigma_bar in L3 is consumed)
     acc_zero<NB>(acc);
     gemm_mfma<NB, false, false>(L1, L2, wave, r16, kq, acc);                     // SG Sigma_{t+1}
     acc_zero<NB>(accp);
     if (a.g_E_pair) {
       // E x_t x_{t+1}' = G_t Sigma_{t+1} + m_t m_{t+1}':  G_bar += A1 Sigma_{t+1};  Sigma_bar_{t+1} += sym(G_t' A1).
       load_mat<NB>(L3, a.g_E_pair + (((long)b * (T - 1) + t) * 3 + 1) * n * n, n, n);
-      __syncthreads();
+      tile_barrier();
       gemm_mfma<NB, false, false>(L3, L2, wave, r16, kq, accp);
     }
     {
@@ -408,20 +447,15 @@ __global__ __launch_bounds__(256) void tile_vjp_phase1(const TileVjpArgs a) {
       }
     }
     // m_bar <- G' m_bar ; x_bar <- x_bar G
-    matvec<true>(L0, LD, mb, mnext, n);
-    for (int e = threadIdx.x; e < S * n; e += 256) {
-      const int s_ = e / n, j = e % n;
-      double v = 0.0;
-      for (int i = 0; i < n; ++i) v = __builtin_fma(xb[s_ * 64 + i], L0[i * LD + j], v);
-      xnext[s_ * 64 + j] = v;
-    }
-    __syncthreads();                                                             // mb / xb no longer read
+    matvec<true>(L0, LD, mb, mnext, n, xb + TV_MAX_S * 64);     // (scratch: the unused middle third of the sample area)
+    for (int s_ = 0; s_ < S; ++s_) matvec<true>(L0, LD, xb + s_ * 64, xnext + s_ * 64, n, xb + TV_MAX_S * 64);
+    // (the barrier that ends the last product: mb / xb are no longer read)
     for (int i = threadIdx.x; i < n; i += 256) mb[i] = mnext[i];
     for (int e = threadIdx.x; e < S * n; e += 256) xb[(e / n) * 64 + e % n] = xnext[(e / n) * 64 + e % n];
     acc_zero<NB>(acc);
     gemm_mfma<NB, true, false>(L0, L1, wave, r16, kq, acc);                      // G' SG
     if (a.g_E_pair) gemm_mfma<NB, true, false>(L0, L3, wave, r16, kq, acc);      // + G' A1 (symmetrised below)
-    __syncthreads();
+    tile_barrier();
     store_acc<NB>(L3, acc, wave, r16, kq);
     symmetrize_lds<NB>(L3);
   }
@@ -444,37 +478,50 @@ __global__ __launch_bounds__(256) void tile_vjp_phase2(const TileVjpArgs a) {
   d4 gbpre[tv_maxt<NB>()];                  // G_bar_t in the C layout
   double cbpre = 0.0, ctpre = 0.0;          // c_bar_t[i], c_t[i] for thread i < n
   double* ctv = vec + 256;                  // (the vector area has 256 + 3 * TV_MAX_S * 64 doubles: c_t lives behind tmp)
-  auto J12_at = [&](int t) { return a.J12 + (long)b * a.pair_seq_stride + (long)t * a.pair_t_stride; };
+  // (loop-invariant bases: a selection inside the loop becomes a branch with the loads duplicated in its arms, whose
+  // merge copies -- and therefore waits for -- the freshly requested registers.  T = 1 has no pair: any valid address)
+  const double* j12_base = T > 1 ? a.J12 + (long)b * a.pair_seq_stride : handoff(a, b, 0);
+  const long j12_step = T > 1 ? a.pair_t_stride : 0;
+  const double* gb_base = T > 1 ? a.g_bar + (long)b * (T - 1) * n * n : handoff(a, b, 0);
+  const long gb_step = T > 1 ? (long)n * n : 0;
+  const int pair_ld = T > 1 ? n : NP;
+  // operands the step STARTS with (Pinv_t, J12, G_bar_t, the vectors): requested during the previous step ...
   auto fetch_step = [&](int t) {
     const long bt = (long)b * T + t;
     const double* h = handoff(a, b, t);
     fetch_mat(ppre, h + (long)NP * NP, NP, n);
-    fetch_mat(bpre, a.pinv_bar + bt * n * n, n, n);
     const int i = threadIdx.x < n ? threadIdx.x : 0;
     cbpre = a.c_bar[bt * n + i];
     ctpre = h[2L * NP * NP + i];
-    if (t < T - 1) {
-      fetch_mat(gpre, h, NP, n);
-      fetch_mat(jpre, J12_at(t), n, n);
-      fetch_c<NB>(gbpre, a.g_bar + ((long)b * (T - 1) + t) * n * n, n, n, wave, r16, kq);
-    }
+    // (the last step has no pair ahead: its requests are clamped to valid addresses and never used)
+    const int tj = t < T - 1 ? t : (T > 1 ? T - 2 : 0);
+    fetch_mat(jpre, j12_base + tj * j12_step, pair_ld, n);
+    fetch_c<NB>(gbpre, gb_base + tj * gb_step, pair_ld, n, wave, r16, kq);
+  };
+  // ... and the ones it needs two products later (G_t, Pinv_bar_t): requested at its top -- they do not live across
+  // the loop's back edge
+  auto fetch_mid = [&](int t) {
+    fetch_mat(gpre, handoff(a, b, t), NP, n);
+    fetch_mat(bpre, a.pinv_bar + ((long)b * T + t) * n * n, n, n);
   };
   fetch_step(T - 1);
-  __syncthreads();
+  tile_barrier();
   for (int t = T - 1; t >= 0; --t) {
     const long bt = (long)b * T + t;
     const double* ct = ctv;
-    stage_mat<NB>(L0, ppre);                                                     // Pinv_t
+    fetch_mid(t);
+    stage_mat<NB>(L0, ppre, n);                                                     // Pinv_t
     if (threadIdx.x < n) { cb[threadIdx.x] = cbpre; ctv[threadIdx.x] = ctpre; }
     d4 pbar[tv_maxt<NB>()], gbcur[tv_maxt<NB>()];
     acc_zero<NB>(pbar);
 #pragma unroll
     for (int j = 0; j < tv_maxt<NB>(); ++j) gbcur[j] = gbpre[j];
     if (t < T - 1) {
+      mask_c<NB>(gbcur, n, wave, r16, kq);
       // R = -J12 (info form):  X_bar = -R J_bar - G_bar = J12 J_bar - G_bar ;  c_bar -= R h_bar = += J12 h_bar
-      stage_mat<NB>(L1, jpre);
-      __syncthreads();
-      matvec<false>(L1, LD, hb, tmpv, n);
+      stage_mat<NB>(L1, jpre, n);
+      tile_barrier();
+      matvec<false>(L1, LD, hb, tmpv, n, vec + 320);
       for (int i = threadIdx.x; i < n; i += 256) cb[i] += tmpv[i];
       d4 acc[tv_maxt<NB>()];
       acc_zero<NB>(acc);
@@ -482,39 +529,39 @@ __global__ __launch_bounds__(256) void tile_vjp_phase2(const TileVjpArgs a) {
 #pragma unroll
       for (int j = 0; j < tv_maxt<NB>(); ++j) acc[j] -= gbcur[j];
       store_acc<NB>(L2, acc, wave, r16, kq);                                     // X_bar
-      __syncthreads();
+      tile_barrier();
       acc_zero<NB>(acc);
       gemm_mfma<NB, false, false>(L0, L2, wave, r16, kq, acc);                   // PX = Pinv X_bar
-      __syncthreads();                                                           // (L1 = J12 and L2 = X_bar consumed)
+      tile_barrier();                                                           // (L1 = J12 and L2 = X_bar consumed)
       store_acc<NB>(L1, acc, wave, r16, kq);
-      stage_mat<NB>(L2, gpre);                                                   // G_t
-      __syncthreads();
+      stage_mat<NB>(L2, gpre, n);                                                   // G_t
+      tile_barrier();
       gemm_mfma<NB, false, true>(L1, L2, wave, r16, kq, pbar);                   // P_bar = PX G'
-      __syncthreads();
+      tile_barrier();
     } else {
-      __syncthreads();
+      tile_barrier();
     }
-    stage_mat<NB>(L1, bpre);                                                     // Pinv_bar (direct + Cholesky part)
-    if (t > 0) fetch_step(t - 1);
-    __syncthreads();
+    stage_mat<NB>(L1, bpre, n);                                                     // Pinv_bar (direct + Cholesky part)
+    fetch_step(t > 0 ? t - 1 : 0);                                               // (unconditional, clamped)
+    tile_barrier();
     {
       d4 acc[tv_maxt<NB>()];
       acc_zero<NB>(acc);
       gemm_mfma<NB, false, false>(L0, L1, wave, r16, kq, acc);                   // Pinv Pinv_bar
       store_acc<NB>(L2, acc, wave, r16, kq);
-      __syncthreads();
+      tile_barrier();
       acc_zero<NB>(acc);
       gemm_mfma<NB, false, false>(L2, L0, wave, r16, kq, acc);                   // (Pinv Pinv_bar) Pinv
 #pragma unroll
       for (int j = 0; j < tv_maxt<NB>(); ++j) pbar[j] -= acc[j];
     }
-    matvec<false>(L0, LD, cb, Pc, n);                                           // Pc = Pinv c_bar  (barrier inside)
+    matvec<false>(L0, LD, cb, Pc, n, vec + 320);                                // Pc = Pinv c_bar  (barriers inside)
     // P_bar -= Pc c' + gl/2 c c' + gl/2 Pinv
     for_owned<NB>(pbar, wave, r16, kq, [&](int r, int c, double& v) {
       if (r < n && c < n) v -= Pc[r] * ct[c] + 0.5 * gl * (ct[r] * ct[c] + L0[r * LD + c]);
       else v = 0.0;
     });
-    __syncthreads();
+    tile_barrier();
     store_acc<NB>(L3, pbar, wave, r16, kq);
     symmetrize_lds<NB>(L3);
     for (int i = threadIdx.x; i < n; i += 256) {
@@ -523,7 +570,7 @@ __global__ __launch_bounds__(256) void tile_vjp_phase2(const TileVjpArgs a) {
       a.g_node_h[bt * n + i] = hf;
       hb[i] = hf;
     }
-    __syncthreads();
+    tile_barrier();
   }
 }
 
@@ -548,7 +595,7 @@ __global__ __launch_bounds__(256) void tile_sample_kernel(int T, int n, int S, i
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int r = ty + 16 * i, cq = c0 + j;
-        pre[i][j] = (r < n && cq < n) ? h[(long)r * NP + cq] : 0.0;
+        pre[i][j] = h[(long)(r < n ? r : 0) * NP + (cq < n ? cq : 0)];       // (raw: stage() stores the valid entries only)
       }
   };
   auto stage = [&]() {
@@ -560,14 +607,12 @@ __global__ __launch_bounds__(256) void tile_sample_kernel(int T, int n, int S, i
         if (r < n && cq < n) Gs[r * ld + cq] = pre[i][j];
       }
   };
-  if (T > 1) fetch(T - 2);
+  fetch(T > 1 ? T - 2 : 0);
   for (int t = T - 1; t >= 0; --t) {
     const double* ct = ws + ((long)b * T + t) * (2L * NP * NP + NP) + 2L * NP * NP;
-    if (t < T - 1) {
-      stage();                           // G_t, requested one step ago
-      if (t > 0) fetch(t - 1);
-    }
-    __syncthreads();
+    if (t < T - 1) stage();              // G_t, requested one step ago
+    fetch(t > 1 ? t - 1 : 0);            // (unconditional, clamped: a load inside a branch is waited for at its end)
+    tile_barrier();
     double out[4];
     int cnt = 0;
     for (int e = threadIdx.x; e < S * n; e += 256) {
@@ -577,14 +622,14 @@ __global__ __launch_bounds__(256) void tile_sample_kernel(int T, int n, int S, i
         for (int j = 0; j < n; ++j) v = __builtin_fma(Gs[i * ld + j], xn[s_ * 64 + j], v);
       out[cnt++] = v;
     }
-    __syncthreads();
+    tile_barrier();
     cnt = 0;
     for (int e = threadIdx.x; e < S * n; e += 256) {
       const int s_ = e / n, i = e % n;
       xn[s_ * 64 + i] = out[cnt];
       samples[(((long)b * T + t) * S + s_) * n + i] = out[cnt++];
     }
-    __syncthreads();
+    tile_barrier();
   }
 }
 
