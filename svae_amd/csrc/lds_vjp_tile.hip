@@ -583,9 +583,12 @@ __global__ __launch_bounds__(256) void tile_sample_kernel(int T, int n, int S, i
   extern __shared__ double sm[];
   double* Gs = sm;                       // n x (n + 1)
   double* xn = sm + 64 * 65;             // S x 64: x_{t+1}
+  double* part = xn + TV_MAX_S * 64;     // S x 256: partial sums of G_t x_{t+1}, one per (sample, wavefront, row)
   const int b = blockIdx.x, ld = n + 1;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane < n ? lane : 0;
   // G_t of the NEXT step travels through registers (16 entries per thread: rows ty + 16 i, columns 4 tx ..) while the
-  // current step computes from LDS: the 32 KB tile comes from HBM, further away than one matrix-vector product
+  // current step computes from LDS: the 32 KB tile comes from HBM, further away than one matrix-vector product.
+  // Every request is unconditional (clamped): a load inside a branch is waited for at its end.
   const int ty = threadIdx.x >> 4, c0 = 4 * (threadIdx.x & 15);
   double pre[4][4];
   auto fetch = [&](int t) {
@@ -607,27 +610,55 @@ __global__ __launch_bounds__(256) void tile_sample_kernel(int T, int n, int S, i
         if (r < n && cq < n) Gs[r * ld + cq] = pre[i][j];
       }
   };
-  fetch(T > 1 ? T - 2 : 0);
-  for (int t = T - 1; t >= 0; --t) {
+  // the additive terms c_t[i] + noise_t[s][i] of the elements e = tid + 256 k this thread finishes, one step ahead
+  const int SN = S * n;
+  int es[4], ei[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int e = threadIdx.x + 256 * k, ee = e < SN ? e : 0;
+    es[k] = ee / n; ei[k] = ee % n;
+  }
+  double cpre[4], npre[4];
+  auto fetch_add = [&](int t) {
     const double* ct = ws + ((long)b * T + t) * (2L * NP * NP + NP) + 2L * NP * NP;
+    const double* nz = noise + ((long)b * T + t) * SN;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { cpre[k] = ct[ei[k]]; npre[k] = nz[es[k] * n + ei[k]]; }
+  };
+  fetch(T > 1 ? T - 2 : 0);
+  fetch_add(T - 1);
+  for (int t = T - 1; t >= 0; --t) {
     if (t < T - 1) stage();              // G_t, requested one step ago
-    fetch(t > 1 ? t - 1 : 0);            // (unconditional, clamped: a load inside a branch is waited for at its end)
+    fetch(t > 1 ? t - 1 : 0);
+    double cc[4], nn[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { cc[k] = cpre[k]; nn[k] = npre[k]; }
+    fetch_add(t > 0 ? t - 1 : 0);
     tile_barrier();
-    double out[4];
-    int cnt = 0;
-    for (int e = threadIdx.x; e < S * n; e += 256) {
-      const int s_ = e / n, i = e % n;
-      double v = ct[i] + noise[(((long)b * T + t) * S + s_) * n + i];
-      if (t < T - 1)
-        for (int j = 0; j < n; ++j) v = __builtin_fma(Gs[i * ld + j], xn[s_ * 64 + j], v);
-      out[cnt++] = v;
+    if (t < T - 1) {
+      // wavefront w: columns j = w, w + 4, .. of every row (lane = row); four accumulators so that the LDS reads overlap
+      for (int s_ = 0; s_ < S; ++s_) {
+        double p[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int j = w + 4 * u, jj = j < n ? j : 0;
+          p[u & 3] = __builtin_fma(j < n ? Gs[li * ld + jj] : 0.0, xn[s_ * 64 + jj], p[u & 3]);
+        }
+        part[s_ * 256 + threadIdx.x] = (p[0] + p[1]) + (p[2] + p[3]);
+      }
     }
     tile_barrier();
-    cnt = 0;
-    for (int e = threadIdx.x; e < S * n; e += 256) {
-      const int s_ = e / n, i = e % n;
-      xn[s_ * 64 + i] = out[cnt];
-      samples[(((long)b * T + t) * S + s_) * n + i] = out[cnt++];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (threadIdx.x + 256 * k < SN) {
+        double v = cc[k] + nn[k];
+        if (t < T - 1) {
+          const double* q = part + es[k] * 256 + ei[k];
+          v += (q[0] + q[64]) + (q[128] + q[192]);
+        }
+        xn[es[k] * 64 + ei[k]] = v;
+        samples[((long)b * T + t) * SN + es[k] * n + ei[k]] = v;
+      }
     }
     tile_barrier();
   }
@@ -715,7 +746,10 @@ extern "C" int svae_lds_tile_sample_f64(int B, int T, int n, int S, const double
   if (!samples) return -6;
   if (!handoff_workspace) return -7;
   if (B == 0) return 0;
-  const size_t lds = (size_t)(64 * 65 + svae::TV_MAX_S * 64) * sizeof(double);
+  // (the partial-sum area is sized by the samples of this launch: one sample stays below the 64 KB default)
+  const size_t lds = (size_t)(64 * 65 + svae::TV_MAX_S * 64 + S * 256) * sizeof(double);
+  static svae::LdsGrant grant;
+  if (!grant.ensure(reinterpret_cast<const void*>(svae::tile_sample_kernel), (long)lds)) return -1001;
   hipLaunchKernelGGL(svae::tile_sample_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, T, n, S,
                      16 * ((n + 15) / 16), (const double*)handoff_workspace, noise, samples);
   return hipGetLastError() == hipSuccess ? 0 : -1000;
