@@ -338,10 +338,38 @@ __global__ __launch_bounds__(256) void tile_vjp_phase1(const TileVjpArgs a) {
     mtpre = a.E_node_x[o];
   };
   fetch_vec(0);
+  // per-sample vectors, elements e = tid + 256 k: the sample cotangents of the NEXT step and the samples x_{t+1} the
+  // epilogue of THIS step multiplies with (staged in LDS next to m_{t+1}: read from global memory inside the epilogue
+  // they cost a round trip each)
+  constexpr int XSL_S = 12;               // samples that fit the LDS staging area (more: read in place)
+  double* mnl = vec + 64;                 // m_{t+1}
+  double* xsl = xb + TV_MAX_S * 64 + 256; // x_{t+1,s}, s < XSL_S (behind the matvec scratch)
+  const int SN = S * n;
+  int eo[4], el[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int e = threadIdx.x + 256 * k, ee = e < SN ? e : 0;
+    eo[k] = ee;                            // offset inside a step's (S, n) block
+    el[k] = n > 0 ? (ee / n) * 64 + ee % n : 0;
+  }
+  const double* gs_src = S ? a.g_samples : a.E_node_x;
+  const double* xs_src = S ? a.samples : a.E_node_x;
+  double gspre[4], xspre[4];
+  auto fetch_smp = [&](int tg, int tx) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      gspre[k] = gs_src[((long)b * T + tg) * SN + eo[k]];
+      xspre[k] = xs_src[((long)b * T + tx) * SN + eo[k]];
+    }
+  };
+  fetch_smp(0, T > 1 ? 1 : 0);
   tile_barrier();
   for (int t = 0; t < T; ++t) {
     const long bt = (long)b * T + t;
     const double* mt = a.E_node_x + bt * n;
+    double gscur[4], xscur[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { gscur[k] = gspre[k]; xscur[k] = xspre[k]; }
     // direct cotangents of step t
     if (threadIdx.x < n) {
       const int i = threadIdx.x;
@@ -350,6 +378,7 @@ __global__ __launch_bounds__(256) void tile_vjp_phase1(const TileVjpArgs a) {
       mb[i] += gx + 2.0 * gd * mtpre;
     }
     fetch_vec(t + 1 < T ? t + 1 : t);
+    fetch_smp(t + 1 < T ? t + 1 : t, t + 2 < T ? t + 2 : T - 1);
     if (t == 0 && a.g_E_init) {
       tile_barrier();
       const double* gi = a.g_E_init + (long)b * (n * n + n);
@@ -389,10 +418,9 @@ __global__ __launch_bounds__(256) void tile_vjp_phase1(const TileVjpArgs a) {
         mb[i] += s;
       }
     }
-    for (int e = threadIdx.x; e < S * n; e += 256) {
-      const int s_ = e / n, i = e % n;
-      xb[s_ * 64 + i] += a.g_samples[(bt * a.S + s_) * n + i];
-    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (threadIdx.x + 256 * k < SN) xb[el[k]] += gscur[k];
     tile_barrier();
     // records for phase 2
     store_mat<NB>(a.pinv_bar + bt * n * n, L3, n);
@@ -404,6 +432,10 @@ __global__ __launch_bounds__(256) void tile_vjp_phase1(const TileVjpArgs a) {
     for (int e = threadIdx.x; e < S * n; e += 256) a.xbar[(bt * a.S + e / n) * n + e % n] = xb[(e / n) * 64 + e % n];
     if (t == T - 1) break;
     // propagate to t + 1
+    if (threadIdx.x < n) mnl[threadIdx.x] = mtpre;                                  // m_{t+1} (requested at the top of the step)
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (threadIdx.x + 256 * k < SN && el[k] < XSL_S * 64) xsl[el[k]] = xscur[k];
     stage_mat<NB>(L0, gpre, n);                                                     // G_t
     stage_mat<NB>(L2, spre, n);                                                     // Sigma_{t+1}
     {
@@ -428,7 +460,6 @@ __global__ __launch_bounds__(256) void tile_vjp_phase1(const TileVjpArgs a) {
     }
     {
       // G_bar = 2 SG Sigma_{t+1} + A1 Sigma_{t+1} + m_bar m_{t+1}' + sum_s x_bar_s x_{t+1,s}'
-      const double* mn = a.E_node_x + (bt + 1) * n;
       double* gb = a.g_bar + ((long)b * (T - 1) + t) * n * n;
 #pragma unroll
       for (int j = 0; j < tv_maxt<NB>(); ++j) {
@@ -438,8 +469,9 @@ __global__ __launch_bounds__(256) void tile_vjp_phase1(const TileVjpArgs a) {
           for (int i = 0; i < 4; ++i) {
             const int r = 16 * (q / NB) + kq + 4 * i, c = 16 * (q % NB) + r16;
             if (r < n && c < n) {
-              double v = 2.0 * acc[j][i] + accp[j][i] + mb[r] * mn[c];
-              for (int s_ = 0; s_ < S; ++s_) v = __builtin_fma(xb[s_ * 64 + r], a.samples[((bt + 1) * a.S + s_) * n + c], v);
+              double v = 2.0 * acc[j][i] + accp[j][i] + mb[r] * mnl[c];
+              for (int s_ = 0; s_ < S; ++s_)
+                v = __builtin_fma(xb[s_ * 64 + r], s_ < XSL_S ? xsl[s_ * 64 + c] : a.samples[((bt + 1) * a.S + s_) * n + c], v);
               gb[r * n + c] = v;
             }
           }
