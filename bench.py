@@ -72,7 +72,9 @@ def kernel_name(options, B, T, n):
     prints it)."""
     from svae_amd import _lib
     if n > _lib.LDS_MAX_N:
-        return "tile", "svae::lds_estep_tile_kernel<%d,false>" % ((n + 15) // 16)
+        # (two register budgets: up to one workgroup per CU the instance without spills, csrc/lds_estep_tile.hip)
+        cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+        return "tile", "svae::lds_estep_tile_kernel<%d,false,%d>" % ((n + 15) // 16, 1 if B <= cus else 2)
     twoend = 0 if options & _lib.OPT_TWOEND_OFF else (2 if options & _lib.OPT_TWOEND_FULL else 1)
     split_max = (1 << 30) if options & _lib.OPT_LAYOUT_SPLIT else (0 if options & _lib.OPT_LAYOUT_PACKED else 1023)
     if twoend and n <= 10 and T >= 4:

@@ -172,8 +172,13 @@ __device__ __forceinline__ void factor_pivot_tile(const double* tile, int ld, do
   }
 }
 
-template <int NB, bool INHOMOG>
-__global__ __launch_bounds__(256, 2) void lds_estep_tile_kernel(const LdsArgs a, const int n,
+// WPC = workgroups per CU the register allocation is sized for.  Two of them (256 registers per lane) is what lets
+// 512 sequences run in one round, at the price of ~570 spilled dwords whose scratch traffic sits between the operand
+// requests of every step; up to one workgroup per CU (B <= 256) the one-per-CU instance (512 registers, no spills) is
+// the faster one: n = 64, T = 1000: 64 sequences 27.2 -> 23.3 ms, 256: 23.5 ms; 512 sequences 42.8 (two per CU) vs
+// 46.8 ms (one per CU, two rounds).
+template <int NB, bool INHOMOG, int WPC>
+__global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs a, const int n,
                                                                 const double* __restrict__ pk_base,
                                                                 const int pk_batched) {
   using Cfg = TileCfg<NB>;
@@ -750,14 +755,18 @@ static int launch_tile(const LdsArgs& a, int n, int inhomog, hipStream_t s) {
                        a.J11, a.J12, a.J22, n, T, inhomog, (long)a.pair_seq_stride, pk);
     if (hipGetLastError() != hipSuccess) return -1000;
   }
-  auto go = [&](auto kern) {
-    static LdsGrant grant;            // per instantiation, per device inside
-    if (!grant.ensure((const void*)kern, (long)lds)) return -1001;
+  static LdsGrant grants[4];          // per kernel instance (and per device inside)
+  auto go = [&](auto kern, int which) {
+    if (!grants[which].ensure((const void*)kern, (long)lds)) return -1001;
     hipLaunchKernelGGL(kern, dim3(a.B), dim3(256), lds, s, a, n, (const double*)pk, batched);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
   };
   (void)NP;
-  return inhomog ? go(lds_estep_tile_kernel<NB, true>) : go(lds_estep_tile_kernel<NB, false>);
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const bool one = a.B <= cus;          // at most one workgroup per CU anyway: the instance without spills
+  if (inhomog) return one ? go(lds_estep_tile_kernel<NB, true, 1>, 0) : go(lds_estep_tile_kernel<NB, true, 2>, 1);
+  return one ? go(lds_estep_tile_kernel<NB, false, 1>, 2) : go(lds_estep_tile_kernel<NB, false, 2>, 3);
 }
 
 }  // namespace svae
