@@ -281,6 +281,10 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
   // They are requested inside the last block pivot of a step and consumed after the hand-off: the
   // L2 latency hides behind the elimination.
   d4 sA[NB], sC[SCOLS], rl[RL4];
+#ifndef SVAE_TILE_LATE_OPERANDS
+#define SVAE_TILE_LATE_OPERANDS 1
+#endif
+  constexpr bool late_operands = SVAE_TILE_LATE_OPERANDS && WPC == 2;
   auto load_operands = [&](const double* pk) {
     if constexpr (schur_on) {
 #pragma unroll
@@ -349,7 +353,11 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
         // operands of the Schur stage / next right-hand side / next node potentials: requested now,
         // used after the hand-off (unconditional, clamped addresses: a load under a branch is waited
         // for at the join)
-        if (!last) load_operands(packed + (long)(INHOMOG ? t : (next_last ? 1 : 0)) * (3 * NP * NP));
+        // (two workgroups per CU, SVAE_TILE_LATE_OPERANDS: requested at the point of use instead -- the other workgroup
+        //  covers the latency and the ~110 registers are not live through the last block pivot and the hand-off)
+        if constexpr (!late_operands) {
+          if (!last) load_operands(packed + (long)(INHOMOG ? t : (next_last ? 1 : 0)) * (3 * NP * NP));
+        }
         const long tn = (long)(last ? t : t + 1) * n;
         njn = nodeJ[tn + (tid < n ? tid : n - 1)];
         if constexpr (schur_on && (NB - sj0) % WPR == 0) {
@@ -433,6 +441,9 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
     __syncthreads();
     TICK(6)
 
+    if constexpr (late_operands) {
+      if (!last) load_operands(packed + (long)(INHOMOG ? t : (next_last ? 1 : 0)) * (3 * NP * NP));
+    }
     if (!last) {
       // ---- Schur step:  P' = -2 (J22 + J11') + diag(-2 node_J') - J12' X   (tile (si,j), j < NB);
       //                   h' = node_h' + J12' c                              (j == NB) ------------
