@@ -163,7 +163,7 @@ def test_tile_estep_full_size_well_conditioned(n, T):
 
 
 @pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
-@pytest.mark.parametrize("n,T,S", [(16, 12, 3), (32, 9, 2), (64, 6, 2), (20, 5, 1)])
+@pytest.mark.parametrize("n,T,S", [(16, 12, 3), (32, 9, 2), (64, 6, 2), (20, 5, 1), (24, 1, 2), (40, 2, 1), (17, 3, 5)])
 def test_tile_sampler_against_reference_build(n, T, S):
     """natural_sample_backward for 16 <= n <= 64 (svae_amd/lds/lds_large.py on the tile kernel's hand-off):
     same noise -> same samples as the reference's compiled sampler."""
@@ -186,7 +186,7 @@ def test_tile_sampler_against_reference_build(n, T, S):
 
 
 @pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
-@pytest.mark.parametrize("n,T,S", [(16, 8, 2), (32, 6, 1), (64, 4, 1)])
+@pytest.mark.parametrize("n,T,S", [(16, 8, 2), (32, 6, 1), (64, 4, 1), (20, 1, 1), (33, 2, 2), (16, 3, 1)])
 @pytest.mark.parametrize("with_samples", [False, True])
 def test_tile_vjp_against_reference_compiled_vjps(n, T, S, with_samples):
     """Gradients w.r.t. the node potentials for 16 <= n <= 64 against the reference's compiled VJPs."""
