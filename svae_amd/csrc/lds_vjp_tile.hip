@@ -15,7 +15,9 @@
 // wavefronts; the fragment addressing makes a transposed operand free (no transposed copies), and a product reads
 // 4x fewer LDS bytes than the register-blocked VALU form it replaces (round 2: 4 x 4 blocks per thread -- LDS-bound
 // at ~7 us per 64^3 product against 2 us of arithmetic).  The global operands of a step (G_t, Sigma_{t+1}, P_t^-1,
-// Pinv_bar_t, J12) are requested one step ahead into registers.
+// Pinv_bar_t, J12, the per-step vectors) are requested ahead of their use into registers -- one step ahead for what a
+// step starts with, at the top of the step for what it needs two products later; see the note on the memory schedule
+// below for what keeps such requests in flight.  The matrix-vector products of a step run on all four wavefronts.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
