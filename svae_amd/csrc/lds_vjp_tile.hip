@@ -172,14 +172,26 @@ __device__ __forceinline__ void store_acc(double* M, d4 (&acc)[tv_maxt<NB>()], i
 // issued a step ahead of its use: the operands come from HBM, ~2 us away) and stage (registers -> LDS, zero-padded to
 // NP x NP, scaled).  Thread (ty, tx) holds columns 4 tx .. 4 tx + 3 of rows ty, ty + 16, ty + 32, ty + 48.
 // (fetch: raw values from clamped addresses, no branch; stage: zero outside n x n)
+// VEC: the row stride is a multiple of 4 doubles and the matrix starts 32-byte aligned (the NP-padded hand-off always;
+// compact n x n arrays when n is a multiple of 4: the kernels' A4 instances) -- one 32-byte request per row instead of
+// four 8-byte ones whose lanes sit 32 bytes apart: the scalar form touches every cache line four times, and the
+// requests of a step (~50 per thread) were bound by the texture addresser, not by the data (phase 2: 5.2 k -> 4.4 k
+// cycles for the section that issues them, tools/tile_vjp_timing.py).
 struct MatRegs { double v[4][4]; };
+template <bool VEC>
 __device__ __forceinline__ void fetch_mat(MatRegs& m, const double* src, int gld, int n) {
   const int ty = threadIdx.x >> 4, c0 = 4 * (threadIdx.x & 15);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = ty + 16 * i < n ? ty + 16 * i : 0;
+    if constexpr (VEC) {
+      const d4 q = *(const d4*)(src + (long)r * gld + (c0 < gld ? c0 : 0));
 #pragma unroll
-    for (int j = 0; j < 4; ++j) m.v[i][j] = src[(long)r * gld + (c0 + j < n ? c0 + j : 0)];
+      for (int j = 0; j < 4; ++j) m.v[i][j] = q[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) m.v[i][j] = src[(long)r * gld + (c0 + j < n ? c0 + j : 0)];
+    }
   }
 }
 template <int NB>
@@ -196,24 +208,31 @@ __device__ __forceinline__ void stage_mat(double* dst, const MatRegs& m, int n) 
     }
   }
 }
-template <int NB>
+template <int NB, bool VEC>
 __device__ __forceinline__ void load_mat(double* dst, const double* src, int gld, int n) {
   MatRegs m;
-  fetch_mat(m, src, gld, n);
+  fetch_mat<VEC>(m, src, gld, n);
   stage_mat<NB>(dst, m, n);
 }
 
-// LDS matrix -> global n x n (dense, row stride n), same thread mapping
-template <int NB>
+// LDS matrix -> global n x n (dense, row stride n), same thread mapping (VEC: n a multiple of 4 -> 32-byte stores)
+template <int NB, bool VEC>
 __device__ __forceinline__ void store_mat(double* dst, const double* src, int n) {
   constexpr int LD = 16 * NB + 2;
   const int ty = threadIdx.x >> 4, c0 = 4 * (threadIdx.x & 15);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = ty + 16 * i;
+    if constexpr (VEC) {
+      if (r < n && c0 < n) {
+        const double* q = src + r * LD + c0;
+        *(d4*)(dst + (long)r * n + c0) = d4{q[0], q[1], q[2], q[3]};
+      }
+    } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (r < n && c0 + j < n) dst[(long)r * n + c0 + j] = src[r * LD + c0 + j];
+      for (int j = 0; j < 4; ++j)
+        if (r < n && c0 + j < n) dst[(long)r * n + c0 + j] = src[r * LD + c0 + j];
+    }
   }
 }
 
@@ -266,7 +285,7 @@ __device__ __forceinline__ const double* handoff(const TileVjpArgs& a, int b, in
 }
 
 // ---- phase 0 ------------------------------------------------------------------------------------------------
-template <int NB>
+template <int NB, bool A4>
 __global__ __launch_bounds__(256) void tile_vjp_phase0(const TileVjpArgs a) {
   constexpr int NPL = 16 * NB, LD = NPL + 2, MAT = NPL * LD;
   extern __shared__ double sm[];
@@ -275,12 +294,12 @@ __global__ __launch_bounds__(256) void tile_vjp_phase0(const TileVjpArgs a) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r16 = lane & 15, kq = lane >> 4;
   for (int e = threadIdx.x; e < 3 * MAT; e += 256) sm[e] = 0.0;
   tile_barrier();
-  load_mat<NB>(L3, handoff(a, b, T - 1) + (long)NP * NP, NP, n);
+  load_mat<NB, true>(L3, handoff(a, b, T - 1) + (long)NP * NP, NP, n);
   MatRegs gpre;
   d4 ppre[tv_maxt<NB>()];
   {
     const int tp = T > 1 ? T - 2 : 0;
-    fetch_mat(gpre, handoff(a, b, tp), NP, n);
+    fetch_mat<true>(gpre, handoff(a, b, tp), NP, n);
     fetch_c<NB>(ppre, handoff(a, b, tp) + (long)NP * NP, NP, n, wave, r16, kq);
   }
   tile_barrier();
@@ -293,7 +312,7 @@ __global__ __launch_bounds__(256) void tile_vjp_phase0(const TileVjpArgs a) {
       mask_c<NB>(pcur, n, wave, r16, kq);
       {
         const int tp = t > 0 ? t - 1 : 0;                         // (unconditional: see the note on the memory schedule)
-        fetch_mat(gpre, handoff(a, b, tp), NP, n);
+        fetch_mat<true>(gpre, handoff(a, b, tp), NP, n);
         fetch_c<NB>(ppre, handoff(a, b, tp) + (long)NP * NP, NP, n, wave, r16, kq);
       }
       tile_barrier();
@@ -309,12 +328,12 @@ __global__ __launch_bounds__(256) void tile_vjp_phase0(const TileVjpArgs a) {
       store_acc<NB>(L3, acc, wave, r16, kq);
       symmetrize_lds<NB>(L3);
     }
-    store_mat<NB>(a.sig + ((long)b * T + t) * n * n, L3, n);
+    store_mat<NB, A4>(a.sig + ((long)b * T + t) * n * n, L3, n);
   }
 }
 
 // ---- phase 1 ------------------------------------------------------------------------------------------------
-template <int NB>
+template <int NB, bool A4>
 __global__ __launch_bounds__(256) void tile_vjp_phase1(const TileVjpArgs a) {
   constexpr int NPL = 16 * NB, LD = NPL + 2, MAT = NPL * LD;
   extern __shared__ double sm[];
@@ -325,8 +344,8 @@ __global__ __launch_bounds__(256) void tile_vjp_phase1(const TileVjpArgs a) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r16 = lane & 15, kq = lane >> 4;
   for (int e = threadIdx.x; e < 4 * MAT + 192 + 3 * TV_MAX_S * 64; e += 256) sm[e] = 0.0;     // Sigma_bar = 0, vectors = 0
   MatRegs gpre, spre;
-  fetch_mat(gpre, handoff(a, b, 0), NP, n);
-  fetch_mat(spre, a.sig + ((long)b * T + (T > 1 ? 1 : 0)) * n * n, n, n);
+  fetch_mat<true>(gpre, handoff(a, b, 0), NP, n);
+  fetch_mat<A4>(spre, a.sig + ((long)b * T + (T > 1 ? 1 : 0)) * n * n, n, n);
   // direct cotangents and the mean of step t for thread i < n, requested one step ahead
   const int ti = threadIdx.x < n ? threadIdx.x : 0;
   double gdpre = 0.0, gxpre = 0.0, mtpre = 0.0;
@@ -425,7 +444,7 @@ __global__ __launch_bounds__(256) void tile_vjp_phase1(const TileVjpArgs a) {
       if (threadIdx.x + 256 * k < SN) xb[el[k]] += gscur[k];
     tile_barrier();
     // records for phase 2
-    store_mat<NB>(a.pinv_bar + bt * n * n, L3, n);
+    store_mat<NB, A4>(a.pinv_bar + bt * n * n, L3, n);
     for (int i = threadIdx.x; i < n; i += 256) {
       double s = mb[i];
       for (int s_ = 0; s_ < S; ++s_) s += xb[s_ * 64 + i];
@@ -442,8 +461,8 @@ __global__ __launch_bounds__(256) void tile_vjp_phase1(const TileVjpArgs a) {
     stage_mat<NB>(L2, spre, n);                                                     // Sigma_{t+1}
     {
       const int tq = t + 2 < T ? t + 1 : t;                                      // (unconditional, clamped)
-      fetch_mat(gpre, handoff(a, b, tq), NP, n);
-      fetch_mat(spre, a.sig + ((long)b * T + tq + 1) * n * n, n, n);
+      fetch_mat<true>(gpre, handoff(a, b, tq), NP, n);
+      fetch_mat<A4>(spre, a.sig + ((long)b * T + tq + 1) * n * n, n, n);
     }
     tile_barrier();
     d4 acc[tv_maxt<NB>()], accp[tv_maxt<NB>()];
@@ -456,7 +475,7 @@ __global__ __launch_bounds__(256) void tile_vjp_phase1(const TileVjpArgs a) {
     acc_zero<NB>(accp);
     if (a.g_E_pair) {
       // E x_t x_{t+1}' = G_t Sigma_{t+1} + m_t m_{t+1}':  G_bar += A1 Sigma_{t+1};  Sigma_bar_{t+1} += sym(G_t' A1).
-      load_mat<NB>(L3, a.g_E_pair + (((long)b * (T - 1) + t) * 3 + 1) * n * n, n, n);
+      load_mat<NB, A4>(L3, a.g_E_pair + (((long)b * (T - 1) + t) * 3 + 1) * n * n, n, n);
       tile_barrier();
       gemm_mfma<NB, false, false>(L3, L2, wave, r16, kq, accp);
     }
@@ -496,7 +515,7 @@ __global__ __launch_bounds__(256) void tile_vjp_phase1(const TileVjpArgs a) {
 }
 
 // ---- phase 2 ------------------------------------------------------------------------------------------------
-template <int NB>
+template <int NB, bool A4>
 __global__ __launch_bounds__(256) void tile_vjp_phase2(const TileVjpArgs a) {
   constexpr int NPL = 16 * NB, LD = NPL + 2, MAT = NPL * LD;
   extern __shared__ double sm[];
@@ -523,23 +542,30 @@ __global__ __launch_bounds__(256) void tile_vjp_phase2(const TileVjpArgs a) {
   auto fetch_step = [&](int t) {
     const long bt = (long)b * T + t;
     const double* h = handoff(a, b, t);
-    fetch_mat(ppre, h + (long)NP * NP, NP, n);
+    fetch_mat<true>(ppre, h + (long)NP * NP, NP, n);
     const int i = threadIdx.x < n ? threadIdx.x : 0;
     cbpre = a.c_bar[bt * n + i];
     ctpre = h[2L * NP * NP + i];
     // (the last step has no pair ahead: its requests are clamped to valid addresses and never used)
     const int tj = t < T - 1 ? t : (T > 1 ? T - 2 : 0);
-    fetch_mat(jpre, j12_base + tj * j12_step, pair_ld, n);
+    fetch_mat<A4>(jpre, j12_base + tj * j12_step, pair_ld, n);
     fetch_c<NB>(gbpre, gb_base + tj * gb_step, pair_ld, n, wave, r16, kq);
   };
   // ... and the ones it needs two products later (G_t, Pinv_bar_t): requested at its top -- they do not live across
   // the loop's back edge
   auto fetch_mid = [&](int t) {
-    fetch_mat(gpre, handoff(a, b, t), NP, n);
-    fetch_mat(bpre, a.pinv_bar + ((long)b * T + t) * n * n, n, n);
+    fetch_mat<true>(gpre, handoff(a, b, t), NP, n);
+    fetch_mat<A4>(bpre, a.pinv_bar + ((long)b * T + t) * n * n, n, n);
   };
   fetch_step(T - 1);
   tile_barrier();
+#ifdef SVAE_TV_TIMING      // per-section cycle counters of a timing build (tools/tile_vjp_timing.py); overwrites g_node_h[b, 0, :16]
+  long long tm[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast_ = __builtin_readcyclecounter();
+#define TV_TICK(i) { const long long now_ = __builtin_readcyclecounter(); tm[i] += now_ - tlast_; tlast_ = now_; }
+#else
+#define TV_TICK(i)
+#endif
   for (int t = T - 1; t >= 0; --t) {
     const long bt = (long)b * T + t;
     const double* ct = ctv;
@@ -555,8 +581,10 @@ __global__ __launch_bounds__(256) void tile_vjp_phase2(const TileVjpArgs a) {
       // R = -J12 (info form):  X_bar = -R J_bar - G_bar = J12 J_bar - G_bar ;  c_bar -= R h_bar = += J12 h_bar
       stage_mat<NB>(L1, jpre, n);
       tile_barrier();
+      TV_TICK(0)
       matvec<false>(L1, LD, hb, tmpv, n, vec + 320);
       for (int i = threadIdx.x; i < n; i += 256) cb[i] += tmpv[i];
+      TV_TICK(1)
       d4 acc[tv_maxt<NB>()];
       acc_zero<NB>(acc);
       gemm_mfma<NB, false, false>(L1, L3, wave, r16, kq, acc);                   // J12 J_bar
@@ -564,40 +592,50 @@ __global__ __launch_bounds__(256) void tile_vjp_phase2(const TileVjpArgs a) {
       for (int j = 0; j < tv_maxt<NB>(); ++j) acc[j] -= gbcur[j];
       store_acc<NB>(L2, acc, wave, r16, kq);                                     // X_bar
       tile_barrier();
+      TV_TICK(2)
       acc_zero<NB>(acc);
       gemm_mfma<NB, false, false>(L0, L2, wave, r16, kq, acc);                   // PX = Pinv X_bar
       tile_barrier();                                                           // (L1 = J12 and L2 = X_bar consumed)
+      TV_TICK(3)
       store_acc<NB>(L1, acc, wave, r16, kq);
       stage_mat<NB>(L2, gpre, n);                                                   // G_t
       tile_barrier();
+      TV_TICK(4)
       gemm_mfma<NB, false, true>(L1, L2, wave, r16, kq, pbar);                   // P_bar = PX G'
       tile_barrier();
+      TV_TICK(5)
     } else {
       tile_barrier();
     }
     stage_mat<NB>(L1, bpre, n);                                                     // Pinv_bar (direct + Cholesky part)
     fetch_step(t > 0 ? t - 1 : 0);                                               // (unconditional, clamped)
     tile_barrier();
+    TV_TICK(6)
     {
       d4 acc[tv_maxt<NB>()];
       acc_zero<NB>(acc);
       gemm_mfma<NB, false, false>(L0, L1, wave, r16, kq, acc);                   // Pinv Pinv_bar
       store_acc<NB>(L2, acc, wave, r16, kq);
       tile_barrier();
+      TV_TICK(7)
       acc_zero<NB>(acc);
       gemm_mfma<NB, false, false>(L2, L0, wave, r16, kq, acc);                   // (Pinv Pinv_bar) Pinv
 #pragma unroll
       for (int j = 0; j < tv_maxt<NB>(); ++j) pbar[j] -= acc[j];
     }
+    TV_TICK(8)
     matvec<false>(L0, LD, cb, Pc, n, vec + 320);                                // Pc = Pinv c_bar  (barriers inside)
+    TV_TICK(9)
     // P_bar -= Pc c' + gl/2 c c' + gl/2 Pinv
     for_owned<NB>(pbar, wave, r16, kq, [&](int r, int c, double& v) {
       if (r < n && c < n) v -= Pc[r] * ct[c] + 0.5 * gl * (ct[r] * ct[c] + L0[r * LD + c]);
       else v = 0.0;
     });
     tile_barrier();
+    TV_TICK(10)
     store_acc<NB>(L3, pbar, wave, r16, kq);
     symmetrize_lds<NB>(L3);
+    TV_TICK(11)
     for (int i = threadIdx.x; i < n; i += 256) {
       const double hf = Pc[i] + gl * ct[i];
       a.g_node_J[bt * n + i] = -2.0 * L3[i * LD + i];
@@ -605,7 +643,12 @@ __global__ __launch_bounds__(256) void tile_vjp_phase2(const TileVjpArgs a) {
       hb[i] = hf;
     }
     tile_barrier();
+    TV_TICK(12)
   }
+#ifdef SVAE_TV_TIMING
+  if (threadIdx.x == 0) for (int q = 0; q < 16; ++q) a.g_node_h[(long)b * T * n + q] = (double)tm[q];
+#endif
+#undef TV_TICK
 }
 
 // ---- backward sampler recursion ----------------------------------------------------------------------------------
@@ -628,12 +671,13 @@ __global__ __launch_bounds__(256) void tile_sample_kernel(int T, int n, int S, i
   auto fetch = [&](int t) {
     const double* h = ws + ((long)b * T + t) * (2L * NP * NP + NP);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
+      const int r = ty + 16 * i;
+      // (raw, 32 bytes per request -- the hand-off rows are NP-padded: stage() stores the valid entries only)
+      const d4 q = *(const d4*)(h + (long)(r < n ? r : 0) * NP + (c0 < NP ? c0 : 0));
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int r = ty + 16 * i, cq = c0 + j;
-        pre[i][j] = h[(long)(r < n ? r : 0) * NP + (cq < n ? cq : 0)];       // (raw: stage() stores the valid entries only)
-      }
+      for (int j = 0; j < 4; ++j) pre[i][j] = q[j];
+    }
   };
   auto stage = [&]() {
 #pragma unroll
@@ -743,22 +787,27 @@ extern "C" int svae_lds_tile_vjp_f64(int phase, int B, int T, int n, int S, int 
   a.xbar = w;
   a.g_node_J = g_node_J; a.g_node_h = g_node_h;
   hipStream_t s = (hipStream_t)stream;
-  auto go = [&](auto nb) -> int {
+  auto go2 = [&](auto nb, auto a4c) -> int {
     constexpr int NB = decltype(nb)::value;
+    constexpr bool A4 = decltype(a4c)::value;
     const size_t lds0 = (size_t)3 * svae::tv_mat(16 * NB) * sizeof(double);
     const size_t lds12 = (size_t)(4 * svae::tv_mat(16 * NB) + 256 + 3 * svae::TV_MAX_S * 64) * sizeof(double);
     static svae::LdsGrant grant0, grant1, grant2;      // (per instantiation, per device inside)
     if (phase == 0) {
-      if (!grant0.ensure(reinterpret_cast<const void*>(svae::tile_vjp_phase0<NB>), (long)lds0)) return -1001;
-      hipLaunchKernelGGL(svae::tile_vjp_phase0<NB>, dim3(B), dim3(256), lds0, s, a);
+      if (!grant0.ensure(reinterpret_cast<const void*>(svae::tile_vjp_phase0<NB, A4>), (long)lds0)) return -1001;
+      hipLaunchKernelGGL((svae::tile_vjp_phase0<NB, A4>), dim3(B), dim3(256), lds0, s, a);
     } else if (phase == 1) {
-      if (!grant1.ensure(reinterpret_cast<const void*>(svae::tile_vjp_phase1<NB>), (long)lds12)) return -1001;
-      hipLaunchKernelGGL(svae::tile_vjp_phase1<NB>, dim3(B), dim3(256), lds12, s, a);
+      if (!grant1.ensure(reinterpret_cast<const void*>(svae::tile_vjp_phase1<NB, A4>), (long)lds12)) return -1001;
+      hipLaunchKernelGGL((svae::tile_vjp_phase1<NB, A4>), dim3(B), dim3(256), lds12, s, a);
     } else {
-      if (!grant2.ensure(reinterpret_cast<const void*>(svae::tile_vjp_phase2<NB>), (long)lds12)) return -1001;
-      hipLaunchKernelGGL(svae::tile_vjp_phase2<NB>, dim3(B), dim3(256), lds12, s, a);
+      if (!grant2.ensure(reinterpret_cast<const void*>(svae::tile_vjp_phase2<NB, A4>), (long)lds12)) return -1001;
+      hipLaunchKernelGGL((svae::tile_vjp_phase2<NB, A4>), dim3(B), dim3(256), lds12, s, a);
     }
     return hipGetLastError() == hipSuccess ? 0 : -1000;
+  };
+  // A4: every compact n x n operand (row stride n) can be moved 32 bytes at a time
+  auto go = [&](auto nb) -> int {
+    return (n & 3) == 0 ? go2(nb, std::true_type{}) : go2(nb, std::false_type{});
   };
   switch ((n + 15) / 16) {
     case 1: return go(std::integral_constant<int, 1>{});

@@ -1,0 +1,11 @@
+#!/bin/bash
+# Build a variant of libsvae_hip.so whose tile-VJP unit is compiled with extra flags:
+#   tools/build_vjp_tile_variant.sh <out.so> [extra hipcc flags...]      (run `make -C svae_amd/csrc` first)
+set -e
+OUT=$(realpath -m "$1"); shift
+cd "$(dirname "$0")/../svae_amd/csrc"
+TMP=$(mktemp -d)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c lds_vjp_tile.hip -o $TMP/vt.o
+OBJS=$(ls build/*.o | grep -v lds_vjp_tile.o)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS $TMP/vt.o -o "$OUT"
+rm -rf $TMP

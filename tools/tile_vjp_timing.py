@@ -1,0 +1,38 @@
+"""Per-section cycle counters of tile VJP phase 2 (a timing build: tools/build_vjp_tile_variant.sh <out.so> -DSVAE_TV_TIMING,
+run with SVAE_AMD_LIB=<out.so>).  Usage: python tools/tile_vjp_timing.py [n T B]"""
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from svae_amd.lds.lds_inference import LDSEStepPlan
+from svae_amd.lds.lds_large import vjp_from_handoff_hip
+from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials
+
+NAMES = ["stage Pinv, J12", "matvec J12 h", "J12 J_bar -> X_bar", "Pinv X_bar", "store PX, stage G", "PX G'",
+         "stage Pinv_bar, requests", "Pinv Pinv_bar", "(..) Pinv", "matvec Pinv c", "epilogue", "store + symmetrise",
+         "outputs"]
+
+
+def main():
+    n, T, B = (int(x) for x in sys.argv[1:4]) if len(sys.argv) > 3 else (64, 1000, 64)
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(0)
+    (J0, h0, z0), (J11, J12, J22, zp) = rand_lds_natparam(n, rng)
+    nJ, nh = rand_node_potentials((B, T, n), rng)
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev).contiguous()
+    args = [t(x) for x in (J0, h0, z0, J11, J12, J22, zp, nJ, nh)]
+    plan = LDSEStepPlan(B, T, n, dev)
+    plan.launch(*args)
+    g = [torch.randn(B, dtype=torch.float64, device=dev), torch.randn(B, T, n, dtype=torch.float64, device=dev),
+         torch.randn(B, T, n, dtype=torch.float64, device=dev)]
+    gJ, gh = vjp_from_handoff_hip(plan, args[4], False, plan.E_node_x.clone(), g[0], g[1], g[2])
+    torch.cuda.synchronize()
+    tm = gh[:, 0, :16].cpu().numpy().mean(0)
+    tot = tm[:13].sum()
+    print("phase 2, n=%d T=%d B=%d: %.0f cycles per step (counter ticks)" % (n, T, B, tot / T))
+    for k, name in enumerate(NAMES):
+        print("  %-28s %8.0f  %5.1f %%" % (name, tm[k] / T, 100 * tm[k] / tot))
+
+
+if __name__ == "__main__":
+    main()
