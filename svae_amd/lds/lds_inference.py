@@ -96,6 +96,10 @@ class LDSEStepPlan(object):
                node_logZ=None, pair_batched=False, keep_factor=False, keep_cross=False):
         """Raw launch on the current stream.  All arguments: contiguous float64 device tensors."""
         p = _lib.ptr
+        ev = getattr(self, "_side_event", None)
+        if ev is not None:       # work on a helper stream still reads the hand-off this launch overwrites (lds_large.py)
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            self._side_event = None
         keep = int(bool(keep_factor)) | (2 if keep_cross else 0)
         if self.n > _lib.LDS_MAX_N:
             keep = 0       # tile kernel: its hand-off always serves the sampler / VJP kernels (lds_large.py)

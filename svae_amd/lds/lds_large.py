@@ -67,12 +67,52 @@ def sample_from_handoff(plan, eps):
     return out
 
 
+_side_streams = {}
+
+
+def _side_stream(dev):
+    """One helper stream per (device, caller stream): work that only depends on the E-step's hand-off runs there, next to
+    the kernels of the caller's stream that leave most of the chip idle (one workgroup per sequence)."""
+    main = torch.cuda.current_stream(dev)
+    key = (dev.index, main.cuda_stream)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=dev)
+    return main, _side_streams[key]
+
+
+def start_phase0(plan, J12, pair_batched, S):
+    """Phase 0 of the VJP (the smoothed covariances Sigma_t: a function of the E-step's hand-off alone) launched on the
+    helper stream right after the E-step, so that it runs NEXT to the noise factor and the sampler recursion of the
+    forward pass instead of in front of the backward pass.  -> (workspace, event) for vjp_from_handoff_hip."""
+    lib, p = _lib.load(), _lib.ptr
+    B, T, n = plan.B, plan.T, plan.n
+    dev = plan.device
+    f64 = dict(dtype=torch.float64, device=dev)
+    nws = int(lib.svae_lds_tile_vjp_workspace_doubles(max(B, 1), T, n, S))
+    ws = torch.empty(nws, **f64)
+    dummy = plan.lognorm                      # (phase 0 reads none of the cotangents; the entry point wants the pointers)
+    gJ = torch.empty(1, **f64)
+    main, side = _side_stream(dev)
+    side.wait_stream(main)                    # the hand-off of the launch just issued
+    ws.record_stream(side)
+    J12c = J12.to(**f64).contiguous()
+    rc = lib.svae_lds_tile_vjp_f64(0, B, T, n, 0, int(J12c.dim() >= 3), int(bool(pair_batched)), p(J12c), p(dummy),
+                                   None, None, None, None, None, None, p(plan.E_node_x), p(gJ), p(gJ), p(plan.ws),
+                                   p(ws), nws, side.cuda_stream)
+    _lib.check(rc, "svae_lds_tile_vjp_f64")
+    ev = torch.cuda.Event()
+    ev.record(side)
+    plan._side_event = ev                     # the next launch on this plan overwrites the hand-off: it waits for this
+    return ws, ev
+
+
 def vjp_from_handoff_hip(plan, J12, pair_batched, ex, g_lognorm, g_dxx, g_x, samples=None, eps=None, g_samples=None,
-                         g_E_init=None, g_E_pair=None):
+                         g_E_init=None, g_E_pair=None, phase0=None):
     """The VJP w.r.t. the node potentials on the device kernels (svae_lds_tile_vjp_f64: three phases, one workgroup
     per sequence, n x n state in LDS; the Cholesky adjoint of the sampler's noise factor -- parallel over all
     (sequence, step) pairs -- is svae_lds_tile_noise_f64 between phases 1 and 2).  Reads the hand-off of the plan's
-    last launch.  -> (g_node_J, g_node_h) (B,T,n)."""
+    last launch.  phase0: (workspace, event) of start_phase0 if phase 0 was started with the forward pass.
+    -> (g_node_J, g_node_h) (B,T,n)."""
     lib = _lib.load()
     B, T, n = plan.B, plan.T, plan.n
     dev = plan.device
@@ -86,7 +126,7 @@ def vjp_from_handoff_hip(plan, J12, pair_batched, ex, g_lognorm, g_dxx, g_x, sam
     if S > MAX_S:
         # linear in the cotangents: the first chunk travels with all the other cotangents, the rest alone
         gJ, gh = vjp_from_handoff_hip(plan, J12, pair_batched, ex, g_lognorm, g_dxx, g_x, samples[:, :, :MAX_S],
-                                      eps[:, :, :MAX_S], g_samples[:, :, :MAX_S], g_E_init, g_E_pair)
+                                      eps[:, :, :MAX_S], g_samples[:, :, :MAX_S], g_E_init, g_E_pair, phase0=phase0)
         zero = torch.zeros_like(g_lognorm)
         for s0 in range(MAX_S, S, MAX_S):
             sl = slice(s0, min(S, s0 + MAX_S))
@@ -96,7 +136,11 @@ def vjp_from_handoff_hip(plan, J12, pair_batched, ex, g_lognorm, g_dxx, g_x, sam
             gh += ah
         return gJ, gh
     nws = int(lib.svae_lds_tile_vjp_workspace_doubles(max(B, 1), T, n, S))
-    ws = torch.empty(nws, **f64)
+    if phase0 is not None and phase0[0].numel() >= nws:
+        ws = phase0[0]
+        torch.cuda.current_stream(dev).wait_event(phase0[1])
+    else:
+        ws, phase0 = torch.empty(nws, **f64), None
     gJ, gh = torch.empty(B, T, n, **f64), torch.empty(B, T, n, **f64)
     J12 = cont(J12)
     inhomog = J12.dim() >= 3
@@ -108,7 +152,8 @@ def vjp_from_handoff_hip(plan, J12, pair_batched, ex, g_lognorm, g_dxx, g_x, sam
                                        p(gh),
                                        p(plan.ws), p(ws), nws, _lib.current_stream(dev))
         _lib.check(rc, "svae_lds_tile_vjp_f64")
-    phase(0)
+    if phase0 is None:
+        phase(0)
     phase(1)
     if has_s:    # Cholesky adjoint of the noise factor, one workgroup per (sequence, step), into pinv_bar
         rc = lib.svae_lds_tile_noise_f64(1, B, T, n, S, p(eps), None, p(plan.ws), p(ws), p(plan.info),
@@ -128,6 +173,10 @@ class LDSInferenceLarge(torch.autograd.Function):
         init_J, init_h, init_logZ, J11, J12, J22, logZ_pair = params
         plan.launch(init_J, init_h, init_logZ, J11, J12, J22, logZ_pair, node_J, node_h, node_logZ,
                     pair_batched, False, False)
+        # a backward pass will follow: its phase 0 depends on the hand-off only -- next to the sampler's kernels
+        ctx.phase0 = None
+        if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) and plan.device.type == "cuda":
+            ctx.phase0 = start_phase0(plan, J12, pair_batched, min(eps.shape[2], MAX_S) if eps is not None else 0)
         samples = sample_from_handoff(plan, eps) if eps is not None else \
             torch.zeros(0, dtype=torch.float64, device=plan.device)
         ctx.set_materialize_grads(False)       # an output nobody differentiated arrives as None, not as zeros
@@ -152,6 +201,7 @@ class LDSInferenceLarge(torch.autograd.Function):
         gs = g_samples if (ctx.has_eps and g_samples is not None) else None
         gJ, gh = vjp_from_handoff_hip(plan, ctx.J12, ctx.pair_batched, ctx.ex, gl, g_dxx, g_x,
                                       samples if gs is not None else None, eps if gs is not None else None, gs,
-                                      g_init if ctx.inhomog else None, g_pair if ctx.inhomog else None)
+                                      g_init if ctx.inhomog else None, g_pair if ctx.inhomog else None,
+                                      phase0=ctx.phase0)
         gz = gl[:, None].expand(B, T).clone() if ctx.has_logZ else None
         return gJ, gh, gz, None, None, None, None
