@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SVAE_HIP_ABI_VERSION 7   /* 7: + svae_slds_path_nodeparams_f64, svae_slds_mix_pair_natparam_f64; 6: per-call `options` word replaces the process-global svae_lds_set_* selectors (re-entrant library), + svae_slds_hmm_meanfield_f64, svae_slds_sweep_glue_f64, g_E_pair in svae_lds_tile_vjp_f64; 5: + svae_lds_set_prod_max_b; 4: + svae_slds_lds_meanfield_f64, svae_gmm_mw_*, svae_lds_global_step_f64, svae_lds_natgrad_f64, svae_lds_tile_vjp_f64; 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
+#define SVAE_HIP_ABI_VERSION 8   /* 8: step ranges (t_begin, t_end) in svae_lds_tile_vjp_f64 / svae_lds_tile_noise_f64, SVAE_OPT_TILE_FORWARD / _BACKWARD; 7: + svae_slds_path_nodeparams_f64, svae_slds_mix_pair_natparam_f64; 6: per-call `options` word replaces the process-global svae_lds_set_* selectors (re-entrant library), + svae_slds_hmm_meanfield_f64, svae_slds_sweep_glue_f64, g_E_pair in svae_lds_tile_vjp_f64; 5: + svae_lds_set_prod_max_b; 4: + svae_slds_lds_meanfield_f64, svae_gmm_mw_*, svae_lds_global_step_f64, svae_lds_natgrad_f64, svae_lds_tile_vjp_f64; 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
 #define SVAE_LDS_MAX_N 15   /* register/DPP path: one 16-lane row per sequence, n+1 <= 16 */
 #define SVAE_LDS_TILE_MAX_N 64   /* 16 <= n <= 64: LDS-tiled MFMA path (E-step only: keep must be 0) */
 
@@ -125,6 +125,13 @@ int svae_lds_filter_f64(int B, int T, int n, int inhomog, int pair_batched, unsi
 #define SVAE_OPT_PRODUCERS_ON   0x10u   /* producer / helper wavefronts whatever B */
 #define SVAE_OPT_PRODUCERS_OFF  0x20u   /* never */
 #define SVAE_OPT_ALL            0x3fu   /* (contradictory pairs or unknown bits: the call returns -24) */
+/* svae_lds_estep_f64 with 16 <= n <= 64 only (any other use: -24): run HALF of the E-step.  The forward half (filter,
+ * hand-off, log-normaliser) and the backward half (smoother + statistics, from the hand-off a forward-only call left
+ * in the same workspace) meet only through the hand-off, so a training step can run the backward half on one stream
+ * NEXT to the kernels that need the hand-off alone (svae_lds_tile_noise_f64 + svae_lds_tile_sample_f64, phase 0 of
+ * svae_lds_tile_vjp_f64) on others -- each is one workgroup per sequence or shorter than the smoother. */
+#define SVAE_OPT_TILE_FORWARD   0x40u
+#define SVAE_OPT_TILE_BACKWARD  0x80u
 
 /* LDS mean-field step of the SLDS-SVAE coordinate ascent with the mixing of the K per-state parameter sets
  * and the contraction of the pair statistics FUSED into the E-step:
@@ -172,11 +179,16 @@ int svae_slds_lds_meanfield_f64(int B, int rows, int T, int n, int K,
  * (sequence, step) pairs, from `xbar` and eps -- into the `pinv_bar` section of `workspace`
  * (layout [sig (B,T,n,n) | pinv_bar (B,T,n,n) | g_bar (B,T-1,n,n) | c_bar (B,T,n) | xbar (B,T,S,n)],
  * svae_lds_tile_vjp_workspace_doubles); without sample cotangents (g_samples NULL) there is nothing to add.
+ * Step ranges: phases 0 and 1 take (t_begin, t_end) = (0, T).  Phase 2 may be split into launches over
+ * [t_begin, t_end), called from the LAST range down to the first (the recursion runs backward in time; its state
+ * travels through the tail of `workspace`): a caller can then run the Cholesky adjoint of the next (earlier) range
+ * (svae_lds_tile_noise_f64, mode 1, same range arguments) on another stream NEXT to phase 2 of the current one -- one
+ * workgroup per sequence leaves most of the chip to it.  Bad ranges: -20.
  * Cotangents: g_lognorm (B); g_E_node_diagxx, g_E_node_x (B,T,n) or NULL; g_E_init (B, n*n+n) or NULL;
  * g_E_pair (B,T-1,3,n,n) or NULL: of the per-step pair statistics (inhomog only; _compute_stats_grad,
  * cython_lds_inference.pyx:212-234); g_samples (B,T,S,n) or NULL with the samples drawn (S <= 16).  J12 as in svae_lds_estep_vjp_ex_f64. */
 size_t svae_lds_tile_vjp_workspace_doubles(int B, int T, int n, int S);
-int svae_lds_tile_vjp_f64(int phase, int B, int T, int n, int S, int inhomog, int pair_batched,
+int svae_lds_tile_vjp_f64(int phase, int B, int T, int n, int S, int t_begin, int t_end, int inhomog, int pair_batched,
                           const double* J12, const double* g_lognorm, const double* g_E_node_diagxx,
                           const double* g_E_node_x, const double* g_E_init, const double* g_E_pair,
                           const double* g_samples,
@@ -197,8 +209,9 @@ int svae_lds_tile_sample_f64(int B, int T, int n, int S, const double* noise, do
  *   mode 0: noise (B,T,S,n) = M_t eps_t   (input of svae_lds_tile_sample_f64)
  *   mode 1: adds the Cholesky-path cotangent sym(M^-T Phi(M' Mbar) M^-1), Mbar = triu(sum_s xbar_s eps_s'), into the
  *           pinv_bar section of `vjp_workspace` -- between phases 1 and 2 of svae_lds_tile_vjp_f64
- *           (the adjoint of cython_gaussian_grads.pxd:456-487 `_natural_sample_grad`).           S <= 16. */
-int svae_lds_tile_noise_f64(int mode, int B, int T, int n, int S, const double* eps, double* noise,
+ *           (the adjoint of cython_gaussian_grads.pxd:456-487 `_natural_sample_grad`).           S <= 16.
+ * Only the steps t_begin <= t < t_end of every sequence are processed ((0, T): all; bad ranges: -20). */
+int svae_lds_tile_noise_f64(int mode, int B, int T, int n, int S, int t_begin, int t_end, const double* eps, double* noise,
                             const void* handoff_workspace, void* vjp_workspace, int32_t* info, void* stream);
 
 /* The once-per-step GLOBAL side of the LDS-SVAE in one launch ("global->local maps

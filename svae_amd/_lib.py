@@ -12,13 +12,14 @@ import torch  # noqa: F401  (must precede CDLL: shares torch's HIP runtime)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVAE_AMD_LIB", os.path.join(_HERE, "libsvae_hip.so"))  # env: experiments only
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 LDS_MAX_N = 15        # register/DPP path (E-step, sampler, VJP)
 LDS_TILE_MAX_N = 64   # LDS-tiled MFMA path (E-step only)
 
 # per-call `options` word of the LDS entry points (include/svae_hip.h, SVAE_OPT_*): 0 = the library's choice
 OPT_DEFAULT, OPT_TWOEND_OFF, OPT_TWOEND_FULL = 0x00, 0x01, 0x02
 OPT_LAYOUT_SPLIT, OPT_LAYOUT_PACKED, OPT_PRODUCERS_ON, OPT_PRODUCERS_OFF = 0x04, 0x08, 0x10, 0x20
+OPT_TILE_FORWARD, OPT_TILE_BACKWARD = 0x40, 0x80     # 16 <= n <= 64 only: one half of the E-step per call
 # names used by tests / tools / bench.py --kernel for the E-step kernel families
 KERNEL_OPTIONS = {"auto": OPT_DEFAULT, "twoend": OPT_DEFAULT, "twoend_full": OPT_TWOEND_FULL,
                   "twoend_seq": OPT_LAYOUT_SPLIT, "twoend_rpc": OPT_LAYOUT_PACKED,
@@ -65,9 +66,9 @@ SIGNATURES = {
                                + [ctypes.c_double, ctypes.c_int] + [_c_double_p] * 8
                                + [_c_int_p] * 3 + [ctypes.c_void_p]),
     "svae_lds_tile_vjp_workspace_doubles": (ctypes.c_size_t, [ctypes.c_int] * 4),
-    "svae_lds_tile_vjp_f64": (ctypes.c_int, [ctypes.c_int] * 7 + [_c_double_p] * 11
+    "svae_lds_tile_vjp_f64": (ctypes.c_int, [ctypes.c_int] * 9 + [_c_double_p] * 11
                               + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
-    "svae_lds_tile_noise_f64": (ctypes.c_int, [ctypes.c_int] * 5 + [_c_double_p] * 2
+    "svae_lds_tile_noise_f64": (ctypes.c_int, [ctypes.c_int] * 7 + [_c_double_p] * 2
                                 + [ctypes.c_void_p, ctypes.c_void_p, _c_int_p, ctypes.c_void_p]),
     "svae_lds_tile_sample_f64": (ctypes.c_int, [ctypes.c_int] * 4 + [_c_double_p] * 2 + [ctypes.c_void_p, ctypes.c_void_p]),
     "svae_lds_global_step_f64": (ctypes.c_int, [ctypes.c_int] + [_c_double_p] * 19 + [_c_int_p, ctypes.c_void_p]),

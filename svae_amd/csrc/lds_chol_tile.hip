@@ -55,7 +55,7 @@ __device__ __forceinline__ double bcast_lane(double x, int src) {
 // (368 us per 64 x 64 matrix and wavefront).  The factorisation needs no LDS at all: the multiplier M[k][j] lane k
 // wants at pivot j is, by the symmetry the running Schur complement keeps, its OWN register j.
 template <int NC, int MODE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void tile_chol_kernel(int n, int S, int NP, const double* ws, const double* eps,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void tile_chol_kernel(int n, int S, int NP, int T, int t0, int tlen, const double* ws, const double* eps,
                                                        const double* xbar, double* noise, double* pinv_bar,
                                                        int32_t* info) {
   using Cfg = CholCfg<NC>;
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   extern __shared__ double sm[];
   double* panM = sm;                       // MODE 0: M (upper), row-major
   double* pan2 = sm + Cfg::PAN;            // MODE 1: transpositions
-  const long bt = blockIdx.x;
+  const long bt = (long)(blockIdx.x / tlen) * T + t0 + blockIdx.x % tlen;   // steps t0 .. t0 + tlen - 1 of every sequence
   const int c = threadIdx.x;               // lane = column
   const bool on = c < NC;
   const double* P = ws + bt * (2L * NP * NP + NP) + (long)NP * NP;
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 // The sampler's noise factor (mode 0: noise (B,T,S,n) = chol(P_t)^-T eps_t) and its adjoint (mode 1: adds the
 // Cholesky-path cotangent into the pinv_bar section of the VJP workspace, between phases 1 and 2 of
 // svae_lds_tile_vjp_f64), from the P_t^-1 of the tiled E-step's hand-off; one workgroup per (sequence, step).
-extern "C" int svae_lds_tile_noise_f64(int mode, int B, int T, int n, int S, const double* eps, double* noise,
+extern "C" int svae_lds_tile_noise_f64(int mode, int B, int T, int n, int S, int t_begin, int t_end, const double* eps, double* noise,
                                        const void* handoff_workspace, void* vjp_workspace, int32_t* info, void* stream) {
   if (mode < 0 || mode > 1) return -1;
   if (B < 0) return -2;
@@ -175,9 +175,11 @@ extern "C" int svae_lds_tile_noise_f64(int mode, int B, int T, int n, int S, con
   if (!handoff_workspace) return -8;
   if (mode == 1 && !vjp_workspace) return -9;
   if (!info) return -10;
+  if (t_begin < 0 || t_end > T || t_begin >= t_end) return -20;
   if (B == 0) return 0;
   const int NP = 16 * ((n + 15) / 16);
   const long BT = (long)B * T;
+  const int tlen = t_end - t_begin;
   double* w = (double*)vjp_workspace;
   double* pinv_bar = mode == 1 ? w + (size_t)BT * n * n : nullptr;
   const double* xbar = mode == 1 ? w + (size_t)BT * n * n * 2 + (size_t)B * (T > 1 ? T - 1 : 0) * n * n + (size_t)BT * n : nullptr;
@@ -188,7 +190,8 @@ extern "C" int svae_lds_tile_noise_f64(int mode, int B, int T, int n, int S, con
     auto kern = svae::tile_chol_kernel<NC, MD>;
     static svae::LdsGrant grant;            // (one per instantiation of this lambda, per device inside)
     if (lds > 64 * 1024 && !grant.ensure(reinterpret_cast<const void*>(kern), (long)lds)) return -1001;
-    hipLaunchKernelGGL(kern, dim3((unsigned)BT), dim3(64), lds, st, n, S, NP, (const double*)handoff_workspace, eps, xbar,
+    hipLaunchKernelGGL(kern, dim3((unsigned)((long)B * tlen)), dim3(64), lds, st, n, S, NP, T, t_begin, tlen,
+                       (const double*)handoff_workspace, eps, xbar,
                        noise, pinv_bar, info);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
   };

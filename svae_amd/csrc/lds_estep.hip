@@ -138,11 +138,14 @@ int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int k
   if (!info) return -21;
   if (!workspace || ws_bytes < svae_lds_workspace_bytes_ex(B, T, n, inhomog, pair_batched)) return -22;
   Selection sel;
-  if (!decode_options(options, B, &sel)) return -24;
+  const unsigned tile_bits = options & (SVAE_OPT_TILE_FORWARD | SVAE_OPT_TILE_BACKWARD);
+  if (tile_bits == (SVAE_OPT_TILE_FORWARD | SVAE_OPT_TILE_BACKWARD) || (tile_bits && n <= SVAE_LDS_MAX_N)) return -24;
+  if (!decode_options(options & ~tile_bits, B, &sel)) return -24;
   if (B == 0) return 0;
   const int twoend = sel.twoend;
 
   svae::LdsArgs a;
+  a.tile_half = (tile_bits & SVAE_OPT_TILE_FORWARD) ? 1 : (tile_bits & SVAE_OPT_TILE_BACKWARD) ? 2 : 0;
   a.B = B; a.T = T;
   a.init_J = init_J; a.init_h = init_h; a.init_logZ = init_logZ;
   a.J11 = J11; a.J12 = J12; a.J22 = J22; a.logZ_pair = logZ_pair;
@@ -263,7 +266,7 @@ int svae_lds_filter_f64(int B, int T, int n, int inhomog, int pair_batched, unsi
   a.ws3 = nullptr;
   a.pair_seq_stride = pair_batched ? (long)(T - 1) * n * n : 0;
   a.msg_Jp = J_pred; a.msg_hp = h_pred; a.msg_Jf = J_filt; a.msg_hf = h_filt;
-  a.mix_w = nullptr; a.mix_out = nullptr; a.seq_index = nullptr; a.mix_K = 0; a.lds_keep = 0;
+  a.mix_w = nullptr; a.mix_out = nullptr; a.seq_index = nullptr; a.mix_K = 0; a.lds_keep = 0; a.tile_half = 0;
   // small batches without message outputs: one sequence per wavefront (0.62 -> 0.24 ms at B = 512, T = 200, n = 10).
   // The one-register filter (n <= 10) stays ahead of the packed kernel until ~3 wavefronts per SIMD (filter + sampler,
   // T = 500: 1024 sequences 0.86 vs 1.81 ms, 2048: 1.85 vs 2.53; T = 200, 4096: 1.43 vs 1.27)
@@ -334,7 +337,7 @@ int svae_slds_lds_meanfield_f64(int B, int rows, int T, int n, int K,
   a.info = info; a.ws = (double*)workspace; a.ws2 = nullptr; a.ws3 = nullptr;
   a.pair_seq_stride = 0;
   a.msg_Jp = a.msg_hp = a.msg_Jf = a.msg_hf = nullptr;
-  a.mix_w = weights; a.mix_out = pair_contr; a.seq_index = seq_index; a.mix_K = K; a.lds_keep = 0;
+  a.mix_w = weights; a.mix_out = pair_contr; a.seq_index = seq_index; a.mix_K = K; a.lds_keep = 0; a.tile_half = 0;
   switch (n) {
 #define SVAE_CASE_(NN) case NN: return svae_lds_launch_twoend_mix_n##NN(&a, stream);
 #define SVAE_CASE(NN) SVAE_CASE_(NN)

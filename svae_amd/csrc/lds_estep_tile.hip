@@ -181,6 +181,11 @@ template <int NB, bool INHOMOG, int WPC>
 __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs a, const int n,
                                                                 const double* __restrict__ pk_base,
                                                                 const int pk_batched) {
+  // a.tile_half: 0 = the whole E-step; 1 = the forward half only (filter, hand-off, log-normaliser); 2 = the backward
+  // half only (smoother and statistics from the hand-off a forward-only launch left).  The halves meet only through
+  // the hand-off in global memory, so a training step runs the backward half NEXT to the kernels that need the
+  // hand-off alone (noise factor + sampler recursion, phase 0 of the VJP): one workgroup per sequence leaves them room.
+  const int half = a.tile_half;
   using Cfg = TileCfg<NB>;
   constexpr int NP = Cfg::NP, LDM = Cfg::LDM, WSTEP = Cfg::WSTEP;
   extern __shared__ double smem[];
@@ -248,6 +253,7 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
   int* flag = (int*)(ubuf + 2 * UBUF);           // look-ahead hand-shake (see below)
   if (tid == 0) *flag = 0;
 
+  if (half != 2) {
   // ---- step 0: P = -2 (init_J + J11) + diag(-2 node_J[0]),  R = J12,  h = init_h + node_h[0] -----
   for (int idx = tid; idx < NP * NP; idx += 256) {
     const int row = idx / NP, col = idx % NP;
@@ -543,6 +549,9 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
     }
   }
 
+  }   // forward half
+  if (half == 1) return;
+  __syncthreads();
 #ifdef SVAE_TILE_FWD_ONLY   // register-pressure experiments
   return;
 #endif
@@ -760,7 +769,7 @@ static int launch_tile(const LdsArgs& a, int n, int inhomog, hipStream_t s) {
   // workspace: [hand-off region: B T WSTEP][packed pair parameters]
   double* pk = a.ws + (size_t)a.B * T * TileCfg<NB>::WSTEP;
   const int batched = a.pair_seq_stride != 0;
-  if (T > 1) {
+  if (T > 1 && a.tile_half != 2) {        // (the backward half reads the hand-off only)
     const int nslots = inhomog ? T - 1 : 2;
     hipLaunchKernelGGL((tile_pack_pairs_kernel<NB>), dim3(nslots, batched ? a.B : 1), dim3(256), 0, s,
                        a.J11, a.J12, a.J22, n, T, inhomog, (long)a.pair_seq_stride, pk);

@@ -43,6 +43,8 @@ struct TileVjpArgs {
   const double* g_E_init;                 // (B, n*n+n) or nullptr
   const double* g_E_pair;                 // (B,T-1,3,n,n) or nullptr: cotangents of the per-step pair statistics
   double* sig; double* pinv_bar; double* g_bar; double* c_bar; double* xbar;   // VJP workspace
+  int t_begin, t_end;                     // phase 2: the steps of this launch, t_end - 1 .. t_begin
+  double* p2state;                        // phase 2: per sequence [J_bar (NP x (NP + 2)) | h_bar (64)] between two ranges
   double* g_node_J; double* g_node_h;
 };
 
@@ -526,6 +528,13 @@ __global__ __launch_bounds__(256) void tile_vjp_phase2(const TileVjpArgs a) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r16 = lane & 15, kq = lane >> 4;
   const double gl = a.g_lognorm[b];
   for (int e = threadIdx.x; e < 4 * MAT + 256; e += 256) sm[e] = 0.0;           // J_bar of step t + 1 = 0, vectors = 0
+  const int t_hi = a.t_end - 1, t_lo = a.t_begin;
+  double* st = a.p2state + (long)b * (MAT + 64);
+  if (a.t_end < T) {                       // a later range ran before: its J_bar / h_bar
+    tile_barrier();
+    for (int e = threadIdx.x; e < MAT; e += 256) L3[e] = st[e];
+    if (threadIdx.x < 64) hb[threadIdx.x] = st[MAT + threadIdx.x];
+  }
   // operands of a step, requested one step ahead: Pinv_t, Pinv_bar_t, G_t, J12 (per-step parameters)
   MatRegs ppre, bpre, gpre, jpre;
   d4 gbpre[tv_maxt<NB>()];                  // G_bar_t in the C layout
@@ -557,7 +566,7 @@ __global__ __launch_bounds__(256) void tile_vjp_phase2(const TileVjpArgs a) {
     fetch_mat<true>(gpre, handoff(a, b, t), NP, n);
     fetch_mat<A4>(bpre, a.pinv_bar + ((long)b * T + t) * n * n, n, n);
   };
-  fetch_step(T - 1);
+  fetch_step(t_hi);
   tile_barrier();
 #ifdef SVAE_TV_TIMING      // per-section cycle counters of a timing build (tools/tile_vjp_timing.py); overwrites g_node_h[b, 0, :16]
   long long tm[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -566,7 +575,7 @@ __global__ __launch_bounds__(256) void tile_vjp_phase2(const TileVjpArgs a) {
 #else
 #define TV_TICK(i)
 #endif
-  for (int t = T - 1; t >= 0; --t) {
+  for (int t = t_hi; t >= t_lo; --t) {
     const long bt = (long)b * T + t;
     const double* ct = ctv;
     fetch_mid(t);
@@ -608,7 +617,7 @@ __global__ __launch_bounds__(256) void tile_vjp_phase2(const TileVjpArgs a) {
       tile_barrier();
     }
     stage_mat<NB>(L1, bpre, n);                                                     // Pinv_bar (direct + Cholesky part)
-    fetch_step(t > 0 ? t - 1 : 0);                                               // (unconditional, clamped)
+    fetch_step(t > t_lo ? t - 1 : t_lo);                                         // (unconditional, clamped to the range)
     tile_barrier();
     TV_TICK(6)
     {
@@ -644,6 +653,10 @@ __global__ __launch_bounds__(256) void tile_vjp_phase2(const TileVjpArgs a) {
     }
     tile_barrier();
     TV_TICK(12)
+  }
+  if (t_lo > 0) {                          // an earlier range follows
+    for (int e = threadIdx.x; e < MAT; e += 256) st[e] = L3[e];
+    if (threadIdx.x < 64) st[MAT + threadIdx.x] = hb[threadIdx.x];
   }
 #ifdef SVAE_TV_TIMING
   if (threadIdx.x == 0) for (int q = 0; q < 16; ++q) a.g_node_h[(long)b * T * n + q] = (double)tm[q];
@@ -746,13 +759,15 @@ __global__ __launch_bounds__(256) void tile_sample_kernel(int T, int n, int S, i
 
 extern "C" size_t svae_lds_tile_vjp_workspace_doubles(int B, int T, int n, int S) {
   if (B <= 0 || T <= 0 || n <= 0 || n > 64 || S < 0) return 0;
-  return (size_t)B * T * n * n * 2 + (size_t)B * (T > 1 ? T - 1 : 0) * n * n + (size_t)B * T * n + (size_t)B * T * (S > 0 ? S : 0) * n;
+  const int NP = 16 * ((n + 15) / 16);
+  return (size_t)B * T * n * n * 2 + (size_t)B * (T > 1 ? T - 1 : 0) * n * n + (size_t)B * T * n +
+         (size_t)B * T * (S > 0 ? S : 0) * n + (size_t)B * (svae::tv_mat(NP) + 64);     // ... | phase-2 state between ranges
 }
 
 // phase 0, 1, 2 as described at the top; `workspace` holds [sig | pinv_bar | g_bar | c_bar | xbar] in that
 // order (svae_lds_tile_vjp_workspace_doubles); between phase 1 and phase 2 the caller adds the Cholesky adjoint
 // of the noise factor into pinv_bar (it is batched over all (sequence, step) pairs and needs xbar).
-extern "C" int svae_lds_tile_vjp_f64(int phase, int B, int T, int n, int S, int inhomog, int pair_batched,
+extern "C" int svae_lds_tile_vjp_f64(int phase, int B, int T, int n, int S, int t_begin, int t_end, int inhomog, int pair_batched,
                                      const double* J12, const double* g_lognorm, const double* g_E_node_diagxx,
                                      const double* g_E_node_x, const double* g_E_init, const double* g_E_pair,
                                      const double* g_samples,
@@ -772,6 +787,7 @@ extern "C" int svae_lds_tile_vjp_f64(int phase, int B, int T, int n, int S, int 
   if (!g_node_J || !g_node_h) return -16;
   if (!handoff_workspace) return -18;
   if (!workspace || ws_doubles < svae_lds_tile_vjp_workspace_doubles(B, T, n, g_samples ? S : 0)) return -19;
+  if (t_begin < 0 || t_end > T || t_begin >= t_end || (phase != 2 && (t_begin != 0 || t_end != T))) return -20;
   if (B == 0) return 0;
   svae::TileVjpArgs a;
   a.B = B; a.T = T; a.n = n; a.S = g_samples ? S : 0; a.NP = 16 * ((n + 15) / 16);
@@ -785,6 +801,9 @@ extern "C" int svae_lds_tile_vjp_f64(int phase, int B, int T, int n, int S, int 
   a.g_bar = w; w += (size_t)B * (T > 1 ? T - 1 : 0) * n * n;
   a.c_bar = w; w += (size_t)B * T * n;
   a.xbar = w;
+  a.p2state = (double*)workspace + svae_lds_tile_vjp_workspace_doubles(B, T, n, g_samples ? S : 0) -
+              (size_t)B * (svae::tv_mat(16 * ((n + 15) / 16)) + 64);
+  a.t_begin = t_begin; a.t_end = t_end;
   a.g_node_J = g_node_J; a.g_node_h = g_node_h;
   hipStream_t s = (hipStream_t)stream;
   auto go2 = [&](auto nb, auto a4c) -> int {

@@ -93,8 +93,10 @@ class LDSEStepPlan(object):
         self.epoch = 0
 
     def launch(self, init_J, init_h, init_logZ, J11, J12, J22, logZ_pair, node_J, node_h,
-               node_logZ=None, pair_batched=False, keep_factor=False, keep_cross=False):
-        """Raw launch on the current stream.  All arguments: contiguous float64 device tensors."""
+               node_logZ=None, pair_batched=False, keep_factor=False, keep_cross=False, half=0):
+        """Raw launch on the current stream.  All arguments: contiguous float64 device tensors.
+        half (16 <= n <= 64 only): 1 = the forward half of the E-step (filter, hand-off, lognorm), 2 = the backward half
+        (smoother + statistics from the hand-off of a preceding half=1 launch); 0 = both."""
         p = _lib.ptr
         ev = getattr(self, "_side_event", None)
         if ev is not None:       # work on a helper stream still reads the hand-off this launch overwrites (lds_large.py)
@@ -103,8 +105,13 @@ class LDSEStepPlan(object):
         keep = int(bool(keep_factor)) | (2 if keep_cross else 0)
         if self.n > _lib.LDS_MAX_N:
             keep = 0       # tile kernel: its hand-off always serves the sampler / VJP kernels (lds_large.py)
+        options = self.options
+        if half:
+            if self.n <= _lib.LDS_MAX_N:
+                raise ValueError("E-step halves: latent dimension > %d only" % _lib.LDS_MAX_N)
+            options |= _lib.OPT_TILE_FORWARD if half == 1 else _lib.OPT_TILE_BACKWARD
         rc = self.lib.svae_lds_estep_f64(
-            self.B, self.T, self.n, int(self.inhomog), int(pair_batched), keep, self.options,
+            self.B, self.T, self.n, int(self.inhomog), int(pair_batched), keep, options,
             p(init_J), p(init_h), p(init_logZ), p(J11), p(J12), p(J22), p(logZ_pair),
             p(node_J), p(node_h), p(node_logZ),
             p(self.lognorm), p(self.E_init), p(self.E_pair), p(self.E_node_diagxx),

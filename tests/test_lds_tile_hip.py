@@ -411,3 +411,29 @@ def test_tile_vjp_kernels_match_the_torch_adjoint(n, T, B, S, mode):
     got = lds_large.vjp_from_handoff_hip(plan, pair[1], mode == "batched", ex, g["ln"], None, g["x"])
     for a, b in zip(got, want):
         assert _rel(a, b.cpu().numpy()) < 1e-9
+
+
+@pytest.mark.parametrize("n,T,B", [(16, 9, 3), (40, 6, 2), (64, 12, 2), (24, 1, 2)])
+def test_tile_estep_halves_equal_the_whole(n, T, B):
+    """SVAE_OPT_TILE_FORWARD then SVAE_OPT_TILE_BACKWARD (filter + hand-off + lognorm, then smoother + statistics from the
+    hand-off) give bit for bit what one launch gives; the halves are rejected below n = 16."""
+    from svae_amd import _lib
+    from svae_amd.lds.lds_inference import LDSEStepPlan
+    rng = np.random.default_rng(n * 7 + T)
+    (J0, h0, z0), (J11, J12, J22, zp) = rand_lds_natparam(n, rng)
+    nJ, nh = rand_node_potentials((B, T, n), rng)
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev).contiguous()
+    args = [t(x) for x in (J0, h0, z0, J11, J12, J22, zp, nJ, nh)]
+    whole, halves = LDSEStepPlan(B, T, n, dev), LDSEStepPlan(B, T, n, dev)
+    whole.launch(*args)
+    halves.launch(*args, half=1)
+    assert torch.equal(halves.lognorm, whole.lognorm)
+    halves.launch(*args, half=2)
+    torch.cuda.synchronize()
+    for name in ("lognorm", "E_init", "E_pair", "E_node_diagxx", "E_node_x"):
+        assert torch.equal(getattr(halves, name), getattr(whole, name)), name
+    small = LDSEStepPlan(2, 5, 4, dev)
+    with pytest.raises(ValueError):
+        small.launch(*[t(x) for x in rand_lds_natparam(4, rng)[0]], *[t(x) for x in rand_lds_natparam(4, rng)[1]],
+                     *[t(x) for x in rand_node_potentials((2, 5, 4), rng)], half=1)
