@@ -31,7 +31,7 @@ import torch
 from .. import _lib
 
 MAX_S = 16       # samples per sequence per kernel launch (csrc/lds_vjp_tile.hip: TV_MAX_S)
-PHASE2_RANGES = 4        # ranges of steps phase 2 and the Cholesky adjoint are split into (see vjp_from_handoff_hip)
+PHASE2_RANGES = 8        # ranges of steps phase 2 and the Cholesky adjoint are split into (see vjp_from_handoff_hip)
 PHASE2_MIN_STEPS = 64    # ... none of them shorter than this
 
 
