@@ -996,7 +996,7 @@ static int launch_estep_twoend(const LdsArgs& a, bool inhomog, bool lean, hipStr
   }
 }
 
-// MIX launch: 8 sequences (wavefronts) per workgroup share the LDS tables
+// MIX launch: up to 8 sequences (wavefronts) per workgroup share the LDS tables
 template <int N>
 static int launch_estep_twoend_mix(const LdsArgs& a, hipStream_t stream) {
   if constexpr (N <= TE_MAX_N) {
@@ -1005,7 +1005,14 @@ static int launch_estep_twoend_mix(const LdsArgs& a, hipStream_t stream) {
     static LdsGrant grant;                 // largest dynamic-LDS size granted so far (this instantiation, per device)
     auto kern = lds_estep_twoend_kernel<N, true, false, true>;
     if (!grant.ensure(reinterpret_cast<const void*>(kern), bytes)) return -31;
-    constexpr int W = 8;
+    // Sequences (wavefronts) per workgroup: the tables are 100+ KB, so a CU holds ONE workgroup, and the mixing's table
+    // reads (195 KB per wavefront-step) share that CU's LDS bandwidth -- eight wavefronts per CU are LDS-bound at twice
+    // the step time of a lone one.  Only as many per workgroup as it takes to place the launch on the chip: the late
+    // sweeps of the SLDS ascent (a few hundred sequences still iterating) then run one wavefront per CU.
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int W = (a.B + cus - 1) / cus;
+    W = W < 1 ? 1 : (W > 8 ? 8 : W);
     dim3 grid((a.B + W - 1) / W), block(64 * W);
     hipLaunchKernelGGL(kern, grid, block, (size_t)bytes, stream, a);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
