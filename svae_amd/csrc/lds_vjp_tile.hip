@@ -197,7 +197,7 @@ __device__ __forceinline__ void fetch_mat(MatRegs& m, const double* src, int gld
   }
 }
 template <int NB>
-__device__ __forceinline__ void stage_mat(double* dst, const MatRegs& m, int n) {
+__device__ __forceinline__ void stage_mat(double* dst, const MatRegs& m, int n, double scale = 1.0) {
   constexpr int NPL = 16 * NB, LD = NPL + 2;
   const int ty = threadIdx.x >> 4, c0 = 4 * (threadIdx.x & 15);
   if (c0 >= NPL) return;
@@ -206,7 +206,7 @@ __device__ __forceinline__ void stage_mat(double* dst, const MatRegs& m, int n) 
     const int r = ty + 16 * i;
     if (r < NPL) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) dst[r * LD + c0 + j] = (r < n && c0 + j < n) ? m.v[i][j] : 0.0;
+      for (int j = 0; j < 4; ++j) dst[r * LD + c0 + j] = (r < n && c0 + j < n) ? scale * m.v[i][j] : 0.0;
     }
   }
 }
@@ -581,8 +581,11 @@ __global__ __launch_bounds__(256) void tile_vjp_phase2(const TileVjpArgs a) {
     fetch_mid(t);
     stage_mat<NB>(L0, ppre, n);                                                     // Pinv_t
     if (threadIdx.x < n) { cb[threadIdx.x] = cbpre; ctv[threadIdx.x] = ctpre; }
-    d4 pbar[tv_maxt<NB>()], gbcur[tv_maxt<NB>()];
+    // P_bar = Pinv X_bar G' - Pinv Pinv_bar Pinv = Pinv (X_bar G' - Pinv_bar Pinv): three products after X_bar instead
+    // of four (the bracket accumulates both terms in the same tiles; -Pinv_bar is staged with its sign)
+    d4 pbar[tv_maxt<NB>()], gbcur[tv_maxt<NB>()], yacc[tv_maxt<NB>()];
     acc_zero<NB>(pbar);
+    acc_zero<NB>(yacc);
 #pragma unroll
     for (int j = 0; j < tv_maxt<NB>(); ++j) gbcur[j] = gbpre[j];
     if (t < T - 1) {
@@ -600,38 +603,26 @@ __global__ __launch_bounds__(256) void tile_vjp_phase2(const TileVjpArgs a) {
 #pragma unroll
       for (int j = 0; j < tv_maxt<NB>(); ++j) acc[j] -= gbcur[j];
       store_acc<NB>(L2, acc, wave, r16, kq);                                     // X_bar
-      tile_barrier();
+      tile_barrier();                                                           // (L1 = J12 and L3 = J_bar consumed)
       TV_TICK(2)
-      acc_zero<NB>(acc);
-      gemm_mfma<NB, false, false>(L0, L2, wave, r16, kq, acc);                   // PX = Pinv X_bar
-      tile_barrier();                                                           // (L1 = J12 and L2 = X_bar consumed)
-      TV_TICK(3)
-      store_acc<NB>(L1, acc, wave, r16, kq);
-      stage_mat<NB>(L2, gpre, n);                                                   // G_t
-      tile_barrier();
-      TV_TICK(4)
-      gemm_mfma<NB, false, true>(L1, L2, wave, r16, kq, pbar);                   // P_bar = PX G'
-      tile_barrier();
-      TV_TICK(5)
+      stage_mat<NB>(L1, gpre, n);                                                   // G_t
     } else {
       tile_barrier();
     }
-    stage_mat<NB>(L1, bpre, n);                                                     // Pinv_bar (direct + Cholesky part)
+    stage_mat<NB>(L3, bpre, n, -1.0);                                               // -Pinv_bar (direct + Cholesky part)
     fetch_step(t > t_lo ? t - 1 : t_lo);                                         // (unconditional, clamped to the range)
     tile_barrier();
+    TV_TICK(3)
+    if (t < T - 1) gemm_mfma<NB, false, true>(L2, L1, wave, r16, kq, yacc);      // X_bar G'
+    TV_TICK(4)
+    gemm_mfma<NB, false, false>(L3, L0, wave, r16, kq, yacc);                     // - Pinv_bar Pinv
+    TV_TICK(5)
+    tile_barrier();                                                             // (L2 = X_bar consumed)
+    store_acc<NB>(L2, yacc, wave, r16, kq);                                      // Y
+    tile_barrier();
     TV_TICK(6)
-    {
-      d4 acc[tv_maxt<NB>()];
-      acc_zero<NB>(acc);
-      gemm_mfma<NB, false, false>(L0, L1, wave, r16, kq, acc);                   // Pinv Pinv_bar
-      store_acc<NB>(L2, acc, wave, r16, kq);
-      tile_barrier();
-      TV_TICK(7)
-      acc_zero<NB>(acc);
-      gemm_mfma<NB, false, false>(L2, L0, wave, r16, kq, acc);                   // (Pinv Pinv_bar) Pinv
-#pragma unroll
-      for (int j = 0; j < tv_maxt<NB>(); ++j) pbar[j] -= acc[j];
-    }
+    gemm_mfma<NB, false, false>(L0, L2, wave, r16, kq, pbar);                    // P_bar = Pinv Y
+    TV_TICK(7)
     TV_TICK(8)
     matvec<false>(L0, LD, cb, Pc, n, vec + 320);                                // Pc = Pinv c_bar  (barriers inside)
     TV_TICK(9)

@@ -8,8 +8,8 @@ from svae_amd.lds.lds_inference import LDSEStepPlan
 from svae_amd.lds.lds_large import vjp_from_handoff_hip
 from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials
 
-NAMES = ["stage Pinv, J12", "matvec J12 h", "J12 J_bar -> X_bar", "Pinv X_bar", "store PX, stage G", "PX G'",
-         "stage Pinv_bar, requests", "Pinv Pinv_bar", "(..) Pinv", "matvec Pinv c", "epilogue", "store + symmetrise",
+NAMES = ["stage Pinv, J12", "matvec J12 h", "J12 J_bar -> X_bar", "stage G, -Pinv_bar, requests", "X_bar G'",
+         "- Pinv_bar Pinv", "store Y", "Pinv Y", "(unused)", "matvec Pinv c", "epilogue", "store + symmetrise",
          "outputs"]
 
 
