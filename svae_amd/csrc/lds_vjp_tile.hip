@@ -238,6 +238,20 @@ __device__ __forceinline__ void store_mat(double* dst, const double* src, int n)
   }
 }
 
+// M <- (A + A') / 2 for the product A held in the wavefronts' accumulators (C layout): A goes to LDS, every lane reads
+// the mirror images of its own 16 entries, averages in registers, and the result goes back -- three barriers, 16 reads
+// (symmetrize_lds below: four barriers with the store in front of it, 32 reads)
+template <int NB>
+__device__ __forceinline__ void symmetrize_acc(double* M, d4 (&acc)[tv_maxt<NB>()], int wave, int r16, int kq) {
+  constexpr int LD = 16 * NB + 2;
+  store_acc<NB>(M, acc, wave, r16, kq);
+  tile_barrier();
+  for_owned<NB>(acc, wave, r16, kq, [&](int r, int c, double& v) { v = 0.5 * (v + M[c * LD + r]); });
+  tile_barrier();
+  store_acc<NB>(M, acc, wave, r16, kq);
+  tile_barrier();
+}
+
 // in place: M <- (M + M') / 2 on the NP x NP LDS matrix (barriers inside); each thread handles a 4 x 4 block
 template <int NB>
 __device__ __forceinline__ void symmetrize_lds(double* M) {
@@ -328,11 +342,22 @@ __global__ __launch_bounds__(256) void tile_vjp_phase0(const TileVjpArgs a) {
 #pragma unroll
       for (int j = 0; j < tv_maxt<NB>(); ++j) acc[j] += pcur[j];
       store_acc<NB>(L3, acc, wave, r16, kq);
-      symmetrize_lds<NB>(L3);
+      // (P^-1 + (G Sigma) G' is symmetric by construction: nothing to symmetrise but rounding, 1e-16 per step)
+      tile_barrier();
     }
     store_mat<NB, A4>(a.sig + ((long)b * T + t) * n * n, L3, n);
   }
 }
+
+// per-section cycle counters of a timing build (-DSVAE_TV_TIMING, tools/tile_vjp_timing.py): phase 1 leaves them in
+// c_bar[b, 0, :16], phase 2 in g_node_h[b, 0, :16] (overwriting results)
+#ifdef SVAE_TV_TIMING
+#define TV_TICK_INIT long long tm[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tlast_ = __builtin_readcyclecounter();
+#define TV_TICK(i) { const long long now_ = __builtin_readcyclecounter(); tm[i] += now_ - tlast_; tlast_ = now_; }
+#else
+#define TV_TICK_INIT
+#define TV_TICK(i)
+#endif
 
 // ---- phase 1 ------------------------------------------------------------------------------------------------
 template <int NB, bool A4>
@@ -387,6 +412,7 @@ __global__ __launch_bounds__(256) void tile_vjp_phase1(const TileVjpArgs a) {
   };
   fetch_smp(0, T > 1 ? 1 : 0);
   tile_barrier();
+  TV_TICK_INIT
   for (int t = 0; t < T; ++t) {
     const long bt = (long)b * T + t;
     const double* mt = a.E_node_x + bt * n;
@@ -445,6 +471,7 @@ __global__ __launch_bounds__(256) void tile_vjp_phase1(const TileVjpArgs a) {
     for (int k = 0; k < 4; ++k)
       if (threadIdx.x + 256 * k < SN) xb[el[k]] += gscur[k];
     tile_barrier();
+    TV_TICK(0)
     // records for phase 2
     store_mat<NB, A4>(a.pinv_bar + bt * n * n, L3, n);
     for (int i = threadIdx.x; i < n; i += 256) {
@@ -453,6 +480,7 @@ __global__ __launch_bounds__(256) void tile_vjp_phase1(const TileVjpArgs a) {
       a.c_bar[bt * n + i] = s;
     }
     for (int e = threadIdx.x; e < S * n; e += 256) a.xbar[(bt * a.S + e / n) * n + e % n] = xb[(e / n) * 64 + e % n];
+    TV_TICK(1)
     if (t == T - 1) break;
     // propagate to t + 1
     if (threadIdx.x < n) mnl[threadIdx.x] = mtpre;                                  // m_{t+1} (requested at the top of the step)
@@ -467,13 +495,16 @@ __global__ __launch_bounds__(256) void tile_vjp_phase1(const TileVjpArgs a) {
       fetch_mat<A4>(spre, a.sig + ((long)b * T + tq + 1) * n * n, n, n);
     }
     tile_barrier();
+    TV_TICK(2)
     d4 acc[tv_maxt<NB>()], accp[tv_maxt<NB>()];
     acc_zero<NB>(acc);
     gemm_mfma<NB, false, false>(L3, L0, wave, r16, kq, acc);                     // SG = Sigma_bar G
     store_acc<NB>(L1, acc, wave, r16, kq);
     tile_barrier();                                                             // (Sigma_bar in L3 is consumed)
+    TV_TICK(3)
     acc_zero<NB>(acc);
     gemm_mfma<NB, false, false>(L1, L2, wave, r16, kq, acc);                     // SG Sigma_{t+1}
+    TV_TICK(4)
     acc_zero<NB>(accp);
     if (a.g_E_pair) {
       // E x_t x_{t+1}' = G_t Sigma_{t+1} + m_t m_{t+1}':  G_bar += A1 Sigma_{t+1};  Sigma_bar_{t+1} += sym(G_t' A1).
@@ -501,19 +532,28 @@ __global__ __launch_bounds__(256) void tile_vjp_phase1(const TileVjpArgs a) {
         }
       }
     }
+    TV_TICK(5)
     // m_bar <- G' m_bar ; x_bar <- x_bar G
     matvec<true>(L0, LD, mb, mnext, n, xb + TV_MAX_S * 64);     // (scratch: the unused middle third of the sample area)
     for (int s_ = 0; s_ < S; ++s_) matvec<true>(L0, LD, xb + s_ * 64, xnext + s_ * 64, n, xb + TV_MAX_S * 64);
     // (the barrier that ends the last product: mb / xb are no longer read)
     for (int i = threadIdx.x; i < n; i += 256) mb[i] = mnext[i];
     for (int e = threadIdx.x; e < S * n; e += 256) xb[(e / n) * 64 + e % n] = xnext[(e / n) * 64 + e % n];
+    TV_TICK(6)
     acc_zero<NB>(acc);
     gemm_mfma<NB, true, false>(L0, L1, wave, r16, kq, acc);                      // G' SG
     if (a.g_E_pair) gemm_mfma<NB, true, false>(L0, L3, wave, r16, kq, acc);      // + G' A1 (symmetrised below)
     tile_barrier();
+    TV_TICK(7)
     store_acc<NB>(L3, acc, wave, r16, kq);
-    symmetrize_lds<NB>(L3);
+    // G' (Sigma_bar G) is symmetric by construction; only the pair-statistic term G' A1 needs its symmetric part taken
+    if (a.g_E_pair) symmetrize_lds<NB>(L3);
+    else tile_barrier();
+    TV_TICK(8)
   }
+#ifdef SVAE_TV_TIMING
+  if (threadIdx.x == 0) for (int q = 0; q < 16; ++q) a.c_bar[(long)b * T * n + q] = (double)tm[q];
+#endif
 }
 
 // ---- phase 2 ------------------------------------------------------------------------------------------------
@@ -568,13 +608,7 @@ __global__ __launch_bounds__(256) void tile_vjp_phase2(const TileVjpArgs a) {
   };
   fetch_step(t_hi);
   tile_barrier();
-#ifdef SVAE_TV_TIMING      // per-section cycle counters of a timing build (tools/tile_vjp_timing.py); overwrites g_node_h[b, 0, :16]
-  long long tm[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  long long tlast_ = __builtin_readcyclecounter();
-#define TV_TICK(i) { const long long now_ = __builtin_readcyclecounter(); tm[i] += now_ - tlast_; tlast_ = now_; }
-#else
-#define TV_TICK(i)
-#endif
+  TV_TICK_INIT
   for (int t = t_hi; t >= t_lo; --t) {
     const long bt = (long)b * T + t;
     const double* ct = ctv;
@@ -633,8 +667,7 @@ __global__ __launch_bounds__(256) void tile_vjp_phase2(const TileVjpArgs a) {
     });
     tile_barrier();
     TV_TICK(10)
-    store_acc<NB>(L3, pbar, wave, r16, kq);
-    symmetrize_lds<NB>(L3);
+    symmetrize_acc<NB>(L3, pbar, wave, r16, kq);
     TV_TICK(11)
     for (int i = threadIdx.x; i < n; i += 256) {
       const double hf = Pc[i] + gl * ct[i];
@@ -652,7 +685,6 @@ __global__ __launch_bounds__(256) void tile_vjp_phase2(const TileVjpArgs a) {
 #ifdef SVAE_TV_TIMING
   if (threadIdx.x == 0) for (int q = 0; q < 16; ++q) a.g_node_h[(long)b * T * n + q] = (double)tm[q];
 #endif
-#undef TV_TICK
 }
 
 // ---- backward sampler recursion ----------------------------------------------------------------------------------

@@ -11,6 +11,8 @@ from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials
 NAMES = ["stage Pinv, J12", "matvec J12 h", "J12 J_bar -> X_bar", "stage G, -Pinv_bar, requests", "X_bar G'",
          "- Pinv_bar Pinv", "store Y", "Pinv Y", "(unused)", "matvec Pinv c", "epilogue", "store + symmetrise",
          "outputs"]
+NAMES1 = ["direct cotangents, x_bar", "records (stores)", "stage G, Sigma, requests", "Sigma_bar G", "SG Sigma",
+          "G_bar epilogue (stores)", "matvecs", "G' SG", "store + symmetrise"]
 
 
 def main():
@@ -32,6 +34,16 @@ def main():
     print("phase 2, n=%d T=%d B=%d: %.0f cycles per step (counter ticks)" % (n, T, B, tot / T))
     for k, name in enumerate(NAMES):
         print("  %-28s %8.0f  %5.1f %%" % (name, tm[k] / T, 100 * tm[k] / tot))
+    # phase 1 leaves its counters in c_bar[b, 0, :16] of the VJP workspace (kept by the timing build of lds_large)
+    from svae_amd.lds import lds_large
+    ws = getattr(lds_large, "_last_ws", None)
+    if ws is not None:
+        off = 2 * B * T * n * n + B * (T - 1) * n * n
+        tm1 = ws[off:off + B * T * n].view(B, T * n)[:, :16].cpu().numpy().mean(0)
+        tot1 = tm1[:9].sum()
+        print("phase 1: %.0f cycles per step" % (tot1 / T))
+        for k, name in enumerate(NAMES1):
+            print("  %-28s %8.0f  %5.1f %%" % (name, tm1[k] / T, 100 * tm1[k] / tot1))
 
 
 if __name__ == "__main__":
