@@ -76,6 +76,7 @@ def sample_from_handoff(plan, eps):
 
 
 _side_streams = {}
+_keep_ws, _last_ws = False, None      # set by tools/tile_vjp_timing.py only
 
 
 def _side_stream(dev, which=0):
@@ -150,8 +151,9 @@ def vjp_from_handoff_hip(plan, J12, pair_batched, ex, g_lognorm, g_dxx, g_x, sam
     else:
         ws, phase0 = torch.empty(nws, **f64), None
     gJ, gh = torch.empty(B, T, n, **f64), torch.empty(B, T, n, **f64)
-    global _last_ws
-    _last_ws = ws                              # (read by tools/tile_vjp_timing.py on a timing build)
+    if _keep_ws:
+        global _last_ws
+        _last_ws = ws                          # (tools/tile_vjp_timing.py reads phase 1's counters from it)
     J12 = cont(J12)
     inhomog = J12.dim() >= 3
     p = _lib.ptr

@@ -5,7 +5,9 @@ import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from svae_amd.lds.lds_inference import LDSEStepPlan
+from svae_amd.lds import lds_large
 from svae_amd.lds.lds_large import vjp_from_handoff_hip
+lds_large._keep_ws = True
 from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials
 
 NAMES = ["stage Pinv, J12", "matvec J12 h", "J12 J_bar -> X_bar", "stage G, -Pinv_bar, requests", "X_bar G'",
@@ -35,7 +37,6 @@ def main():
     for k, name in enumerate(NAMES):
         print("  %-28s %8.0f  %5.1f %%" % (name, tm[k] / T, 100 * tm[k] / tot))
     # phase 1 leaves its counters in c_bar[b, 0, :16] of the VJP workspace (kept by the timing build of lds_large)
-    from svae_amd.lds import lds_large
     ws = getattr(lds_large, "_last_ws", None)
     if ws is not None:
         off = 2 * B * T * n * n + B * (T - 1) * n * n
