@@ -177,7 +177,11 @@ __device__ __forceinline__ void factor_pivot_tile(const double* tile, int ld, do
 // requests of every step; up to one workgroup per CU (B <= 256) the one-per-CU instance (512 registers, no spills) is
 // the faster one: n = 64, T = 1000: 64 sequences 27.2 -> 23.3 ms, 256: 23.5 ms; 512 sequences 42.8 (two per CU) vs
 // 46.8 ms (one per CU, two rounds).
-template <int NB, bool INHOMOG, int WPC>
+// HALF: 0 = the half (or both) a.tile_half names at run time; 1 / 2 = an instance that CONTAINS only the forward /
+// backward half.  Compiled together at 256 registers per lane the two halves spill ~510 dwords; each alone fits (the
+// forward half: 254 registers, no scratch) -- so batches of more than one workgroup per CU run the E-step as two
+// launches of the single-half instances.
+template <int NB, bool INHOMOG, int WPC, int HALF>
 __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs a, const int n,
                                                                 const double* __restrict__ pk_base,
                                                                 const int pk_batched) {
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
   // half only (smoother and statistics from the hand-off a forward-only launch left).  The halves meet only through
   // the hand-off in global memory, so a training step runs the backward half NEXT to the kernels that need the
   // hand-off alone (noise factor + sampler recursion, phase 0 of the VJP): one workgroup per sequence leaves them room.
-  const int half = a.tile_half;
+  const int half = HALF ? HALF : a.tile_half;
   using Cfg = TileCfg<NB>;
   constexpr int NP = Cfg::NP, LDM = Cfg::LDM, WSTEP = Cfg::WSTEP;
   extern __shared__ double smem[];
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
   int* flag = (int*)(ubuf + 2 * UBUF);           // look-ahead hand-shake (see below)
   if (tid == 0) *flag = 0;
 
-  if (half != 2) {
+  if (HALF != 2 && half != 2) {
   // ---- step 0: P = -2 (init_J + J11) + diag(-2 node_J[0]),  R = J12,  h = init_h + node_h[0] -----
   for (int idx = tid; idx < NP * NP; idx += 256) {
     const int row = idx / NP, col = idx % NP;
@@ -550,7 +554,7 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
   }
 
   }   // forward half
-  if (half == 1) return;
+  if (HALF == 1 || half == 1) return;
   __syncthreads();
 #ifdef SVAE_TILE_FWD_ONLY   // register-pressure experiments
   return;
@@ -582,7 +586,10 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
     }
     cpre = w[2 * NP * NP + (tid < NP ? tid : 0)];
   };
-  prefetch_step(wsb + (long)(T - 1) * WSTEP);
+  // Two workgroups per CU (256 registers): the step's X_t / P_t^-1 are requested where they are consumed instead of a
+  // step / a phase ahead -- the other workgroup covers the latency, and ~64 registers are not live through B1 / B2
+  constexpr bool lean_bwd = (WPC == 2);
+  if constexpr (!lean_bwd) prefetch_step(wsb + (long)(T - 1) * WSTEP);
   __syncthreads();
 
   // Like the forward half, instantiated per wavefront index (= tile column J of the wavefront).
@@ -592,6 +599,7 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
   for (int t = T - 1; t >= 0; --t) {
     TICK(9)
     const double* w = wsb + (long)t * WSTEP;
+    if constexpr (lean_bwd) prefetch_step(w);
 #pragma unroll
     for (int u = 0; u < RL4B; ++u) {
       const int c4 = tid + 256 * u;
@@ -605,13 +613,16 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
       oExx[(long)(t + 1) * n + tid] = __builtin_fma(mm, mm, M[tid * LDM + tid]);
     }
     d4 pin[NB];                          // P_t^-1 tiles (i, j): consumed in B2
-    if constexpr (J < NB) {
+    auto load_pin = [&]() {
+      if constexpr (J < NB) {
 #pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        const double* pi = w + NP * NP + (16 * i + kq) * NP + mycol;
-        pin[i] = d4{pi[0], pi[4 * NP], pi[8 * NP], pi[12 * NP]};
+        for (int i = 0; i < NB; ++i) {
+          const double* pi = w + NP * NP + (16 * i + kq) * NP + mycol;
+          pin[i] = d4{pi[0], pi[4 * NP], pi[8 * NP], pi[12 * NP]};
+        }
       }
-    }
+    };
+    if constexpr (!lean_bwd) load_pin();
     TICK(10)
     {  // m_t = c_t + X_t m_{t+1}
       const int row = tid >> 2, part = tid & 3;
@@ -640,24 +651,34 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
     __syncthreads();
     TICK(11)
 
-    prefetch_step(t > 0 ? w - WSTEP : w);        // step t-1, in flight during B2
+    if constexpr (lean_bwd) load_pin();
+    else prefetch_step(t > 0 ? w - WSTEP : w);   // step t-1, in flight during B2
     if constexpr (J < NB) {
       const double mc = mnew[mycol];
       double* oP = INHOMOG && t < T - 1 ? a.E_pair + ((long)b * (T - 1) + t) * 3 * nn : nullptr;
-      d4 fx[NB];                           // A fragments of X tile row i, fetched one row ahead
+      d4 fx[NB];                           // A fragments of X tile row i, fetched one row ahead (lean: in place)
+      if constexpr (!lean_bwd) {
 #pragma unroll
-      for (int kk = 0; kk < NB; ++kk) fx[kk] = frag_a(M, LDM, 0, NP + 16 * kk, r16, kq);
+        for (int kk = 0; kk < NB; ++kk) fx[kk] = frag_a(M, LDM, 0, NP + 16 * kk, r16, kq);
+      }
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
-        d4 fn[NB];
+        d4 fn[lean_bwd ? 1 : NB];
+        if constexpr (lean_bwd) {
 #pragma unroll
-        for (int kk = 0; kk < NB; ++kk) fn[kk] = (i + 1 < NB) ? frag_a(M, LDM, 16 * (i + 1), NP + 16 * kk, r16, kq) : fx[kk];
+          for (int kk = 0; kk < NB; ++kk) fx[kk] = frag_a(M, LDM, 16 * i, NP + 16 * kk, r16, kq);
+        } else {
+#pragma unroll
+          for (int kk = 0; kk < NB; ++kk) fn[kk] = (i + 1 < NB) ? frag_a(M, LDM, 16 * (i + 1), NP + 16 * kk, r16, kq) : fx[kk];
+        }
         d4 c = pin[i];
 #pragma unroll
         for (int kk = 0; kk < NB; ++kk) c = mma16(fx[kk], Wt[kk], c);
         SVAE_SGB(3, 4 * NB, 1, 0)
+        if constexpr (!lean_bwd) {
 #pragma unroll
-        for (int kk = 0; kk < NB; ++kk) fx[kk] = fn[kk];
+          for (int kk = 0; kk < NB; ++kk) fx[kk] = fn[kk];
+        }
         store_c(M, LDM, 16 * i, 16 * J, r16, kq, c);          // Sigma_t tile (i, j)
         d4 exx, ecr;
 #pragma unroll
@@ -775,7 +796,7 @@ static int launch_tile(const LdsArgs& a, int n, int inhomog, hipStream_t s) {
                        a.J11, a.J12, a.J22, n, T, inhomog, (long)a.pair_seq_stride, pk);
     if (hipGetLastError() != hipSuccess) return -1000;
   }
-  static LdsGrant grants[4];          // per kernel instance (and per device inside)
+  static LdsGrant grants[6];          // per kernel instance (and per device inside)
   auto go = [&](auto kern, int which) {
     if (!grants[which].ensure((const void*)kern, (long)lds)) return -1001;
     hipLaunchKernelGGL(kern, dim3(a.B), dim3(256), lds, s, a, n, (const double*)pk, batched);
@@ -784,9 +805,15 @@ static int launch_tile(const LdsArgs& a, int n, int inhomog, hipStream_t s) {
   (void)NP;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  const bool one = a.B <= cus;          // at most one workgroup per CU anyway: the instance without spills
-  if (inhomog) return one ? go(lds_estep_tile_kernel<NB, true, 1>, 0) : go(lds_estep_tile_kernel<NB, true, 2>, 1);
-  return one ? go(lds_estep_tile_kernel<NB, false, 1>, 2) : go(lds_estep_tile_kernel<NB, false, 2>, 3);
+  // at most one workgroup per CU: the 512-register instance (both halves, or the one a.tile_half names); more: the
+  // single-half instances sized for two workgroups per CU, the whole E-step as two launches
+  if (a.B <= cus) return inhomog ? go(lds_estep_tile_kernel<NB, true, 1, 0>, 0) : go(lds_estep_tile_kernel<NB, false, 1, 0>, 1);
+  int rc = 0;
+  if (a.tile_half != 2)
+    rc = inhomog ? go(lds_estep_tile_kernel<NB, true, 2, 1>, 2) : go(lds_estep_tile_kernel<NB, false, 2, 1>, 3);
+  if (rc == 0 && a.tile_half != 1)
+    rc = inhomog ? go(lds_estep_tile_kernel<NB, true, 2, 2>, 4) : go(lds_estep_tile_kernel<NB, false, 2, 2>, 5);
+  return rc;
 }
 
 }  // namespace svae
