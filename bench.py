@@ -74,7 +74,11 @@ def kernel_name(options, B, T, n):
     if n > _lib.LDS_MAX_N:
         # (two register budgets: up to one workgroup per CU the instance without spills, csrc/lds_estep_tile.hip)
         cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
-        return "tile", "svae::lds_estep_tile_kernel<%d,false,%d>" % ((n + 15) // 16, 1 if B <= cus else 2)
+        nb = (n + 15) // 16
+        if B <= cus:
+            return "tile", "svae::lds_estep_tile_kernel<%d,false,1,0>" % nb
+        # beyond one workgroup per CU: two launches of single-half instances (forward half, backward half)
+        return "tile", "svae::lds_estep_tile_kernel<%d,false,2,1> + svae::lds_estep_tile_kernel<%d,false,2,2>" % (nb, nb)
     twoend = 0 if options & _lib.OPT_TWOEND_OFF else (2 if options & _lib.OPT_TWOEND_FULL else 1)
     split_max = (1 << 30) if options & _lib.OPT_LAYOUT_SPLIT else (0 if options & _lib.OPT_LAYOUT_PACKED else 1023)
     if twoend and n <= 10 and T >= 4:
@@ -160,7 +164,7 @@ def roofline(options, T, n, B, kern_ms):
     prof = os.path.join(ROOT, "profiles", tag, "pmc_hbm.json") if tag else None
     if prof and os.path.isfile(prof) and (T, n) in ((200, 10), (1000, 64)):
         p = json.load(open(prof))
-        if kernel.replace(" ", "") in p.get("kernel", "").replace(" ", ""):
+        if all(k.replace(" ", "") in p.get("kernel", "").replace(" ", "") for k in kernel.split(" + ")):
             traffic, traffic_src = p["hbm_bytes_per_launch_corrected"], os.path.relpath(prof, ROOT)
     bytes_launch = B * algorithmic_bytes_per_seq(T, n)
     achieved = bytes_launch / (kern_ms * 1e-3) / 1e9

@@ -19,8 +19,9 @@ def main():
     out = {}
     disp = {}
     for counter, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write"), ("SQ_INSTS_VALU", "pmc_valu")):
+        # per kernel NAME the mean over its dispatches; a launch of the hot path that is several kernels (the tile E-step
+        # beyond one workgroup per CU: forward-half + backward-half instance) counts as their sum
         per = {}
-        name = None
         path = os.path.join(src, d, "bench_counter_collection.csv")
         if not os.path.isfile(path):
             continue
@@ -28,15 +29,16 @@ def main():
             for row in csv.DictReader(f):
                 if row.get("Counter_Name") != counter or sub not in row.get("Kernel_Name", ""):
                     continue
-                per[row["Dispatch_Id"]] = per.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
-                name = row["Kernel_Name"]
-        vals = list(per.values())
+                disp = per.setdefault(row["Kernel_Name"], {})
+                disp[row["Dispatch_Id"]] = disp.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+        total = sum(sum(v.values()) / max(1, len(v)) for v in per.values())
+        launches = min((len(v) for v in per.values()), default=0)
         if counter == "SQ_INSTS_VALU":       # wavefront-level VALU instructions issued per launch (summed over the chip)
-            out["SQ_INSTS_VALU_per_launch_mean"] = sum(vals) / max(1, len(vals))
+            out["SQ_INSTS_VALU_per_launch_mean"] = total
             continue
-        out[counter + "_KB_per_launch_mean"] = sum(vals) / max(1, len(vals))
-        out[counter + "_launches"] = len(vals)
-        out["kernel"] = name
+        out[counter + "_KB_per_launch_mean"] = total
+        out[counter + "_launches"] = launches
+        out["kernel"] = " + ".join(sorted(per))
     out["note"] = ("rocprofv3 --pmc, separate passes (profiles/run_profile.sh); gfx950: FETCH_SIZE counts wide "
                    "coalesced reads at 1/2 (MI355X_MICROARCH.md, HBM) -> hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) KB")
     out["hbm_bytes_per_launch_corrected"] = 1024.0 * (2 * out["FETCH_SIZE_KB_per_launch_mean"]
