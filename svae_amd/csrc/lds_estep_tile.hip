@@ -588,7 +588,10 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
   };
   // Two workgroups per CU (256 registers): the step's X_t / P_t^-1 are requested where they are consumed instead of a
   // step / a phase ahead -- the other workgroup covers the latency, and ~64 registers are not live through B1 / B2
-  constexpr bool lean_bwd = (WPC == 2);
+#ifndef SVAE_TILE_LEAN_BWD
+#define SVAE_TILE_LEAN_BWD 1
+#endif
+  constexpr bool lean_bwd = (WPC == 2) && SVAE_TILE_LEAN_BWD;
   if constexpr (!lean_bwd) prefetch_step(wsb + (long)(T - 1) * WSTEP);
   __syncthreads();
 
@@ -622,6 +625,10 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
         }
       }
     };
+    auto load_pin_i = [&](int i) -> d4 {
+      const double* pi = w + NP * NP + (16 * i + kq) * NP + mycol;
+      return d4{pi[0], pi[4 * NP], pi[8 * NP], pi[12 * NP]};
+    };
     if constexpr (!lean_bwd) load_pin();
     TICK(10)
     {  // m_t = c_t + X_t m_{t+1}
@@ -651,7 +658,8 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
     __syncthreads();
     TICK(11)
 
-    if constexpr (lean_bwd) load_pin();
+    d4 pnext = {0.0, 0.0, 0.0, 0.0};             // lean: P_t^-1 tile (i, j) one tile row ahead
+    if constexpr (lean_bwd) { if constexpr (J < NB) pnext = load_pin_i(0); }
     else prefetch_step(t > 0 ? w - WSTEP : w);   // step t-1, in flight during B2
     if constexpr (J < NB) {
       const double mc = mnew[mycol];
@@ -664,16 +672,20 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         d4 fn[lean_bwd ? 1 : NB];
-        if constexpr (lean_bwd) {
-#pragma unroll
-          for (int kk = 0; kk < NB; ++kk) fx[kk] = frag_a(M, LDM, 16 * i, NP + 16 * kk, r16, kq);
-        } else {
+        if constexpr (!lean_bwd) {
 #pragma unroll
           for (int kk = 0; kk < NB; ++kk) fn[kk] = (i + 1 < NB) ? frag_a(M, LDM, 16 * (i + 1), NP + 16 * kk, r16, kq) : fx[kk];
         }
-        d4 c = pin[i];
+        d4 c;
+        if constexpr (lean_bwd) { c = pnext; if (i + 1 < NB) pnext = load_pin_i(i + 1); }
+        else c = pin[i];
+        if constexpr (lean_bwd) {        // fragments read where they are consumed (one live at a time)
 #pragma unroll
-        for (int kk = 0; kk < NB; ++kk) c = mma16(fx[kk], Wt[kk], c);
+          for (int kk = 0; kk < NB; ++kk) c = mma16(frag_a(M, LDM, 16 * i, NP + 16 * kk, r16, kq), Wt[kk], c);
+        } else {
+#pragma unroll
+          for (int kk = 0; kk < NB; ++kk) c = mma16(fx[kk], Wt[kk], c);
+        }
         SVAE_SGB(3, 4 * NB, 1, 0)
         if constexpr (!lean_bwd) {
 #pragma unroll
@@ -688,27 +700,33 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
           ecr[qq] = __builtin_fma(mold[row], mc, Wt[i][qq]);      // E[x_{t+1} x_t'](row, mycol)
         }
 #ifndef SVAE_TILE_TIMING
+        if (INHOMOG || t == 0 || t == T - 1) {
+          // (homogeneous model: stores at the two ends of the chain only.  The opaque copy of the column index keeps
+          //  their 48 loop-invariant 64-bit addresses from being hoisted out of the time loop into live registers)
+          int mcx = mycol;
+          if constexpr (!INHOMOG) asm volatile("" : "+v"(mcx));
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
-          const int row = 16 * i + 4 * qq + kq;
-          const bool in = row < n && mycol < n;
-          if (INHOMOG) {
-            if (oP && in) {
-              oP[row * n + mycol] = exx[qq];
-              oP[nn + mycol * n + row] = ecr[qq];
-              oP[2 * nn + row * n + mycol] = prevE[i][qq];        // E[x_{t+1} x_{t+1}'] (previous step)
+          for (int qq = 0; qq < 4; ++qq) {
+            const int row = 16 * i + 4 * qq + kq;
+            const bool in = row < n && mcx < n;
+            if (INHOMOG) {
+              if (oP && in) {
+                oP[row * n + mcx] = exx[qq];
+                oP[nn + mcx * n + row] = ecr[qq];
+                oP[2 * nn + row * n + mcx] = prevE[i][qq];        // E[x_{t+1} x_{t+1}'] (previous step)
+              }
+            } else if (in) {
+              // sum_{t>=1} E[x_t x_t'] = sum_{t<=T-2} + last - first: the last term waits in its output slot
+              if (t == T - 1) oPh[2 * nn + row * n + mcx] = exx[qq];
+              if (t == 0) {
+                const double s0 = sxx[i][qq] + (T > 1 ? exx[qq] : 0.0);
+                oPh[row * n + mcx] = s0;
+                oPh[nn + mcx * n + row] = cross[i][qq] + ecr[qq];
+                oPh[2 * nn + row * n + mcx] = s0 + oPh[2 * nn + row * n + mcx] - exx[qq];
+              }
             }
-          } else if (in) {
-            // sum_{t>=1} E[x_t x_t'] = sum_{t<=T-2} + last - first: the last term waits in its output slot
-            if (t == T - 1) oPh[2 * nn + row * n + mycol] = exx[qq];
-            if (t == 0) {
-              const double s0 = sxx[i][qq] + (T > 1 ? exx[qq] : 0.0);
-              oPh[row * n + mycol] = s0;
-              oPh[nn + mycol * n + row] = cross[i][qq] + ecr[qq];
-              oPh[2 * nn + row * n + mycol] = s0 + oPh[2 * nn + row * n + mycol] - exx[qq];
-            }
+            if (t == 0 && in) oI[row * n + mcx] = exx[qq];
           }
-          if (t == 0 && in) oI[row * n + mycol] = exx[qq];
         }
 #endif
         if (INHOMOG) prevE[i] = exx;
