@@ -134,8 +134,12 @@ __device__ __forceinline__ void tile_barrier() { asm volatile("s_waitcnt lgkmcnt
 
 // this lane's C-layout entries of a global n x n matrix (row stride gld): raw (clamped addresses), requested a step
 // ahead like the LDS operands; mask_c zeroes the entries outside n x n at the point of use
+// (the element offsets are computed ONCE per kernel -- COff / MOff below: recomputed per request, with their clamps
+//  and 64-bit multiplies, the ~35 requests of a step cost ~9 instructions each: 2.9 k cycles in phase 2)
+template <int NB> struct COff { int o[tv_maxt<NB>()][4]; };
 template <int NB>
-__device__ __forceinline__ void fetch_c(d4 (&v)[tv_maxt<NB>()], const double* src, int gld, int n, int wave, int r16, int kq) {
+__device__ __forceinline__ COff<NB> c_off(int gld, int n, int wave, int r16, int kq) {
+  COff<NB> f;
 #pragma unroll
   for (int j = 0; j < tv_maxt<NB>(); ++j) {
     const int q = wave + 4 * j < NB * NB ? wave + 4 * j : 0;
@@ -143,9 +147,17 @@ __device__ __forceinline__ void fetch_c(d4 (&v)[tv_maxt<NB>()], const double* sr
     for (int i = 0; i < 4; ++i) {
       const int r = 16 * (q / NB) + kq + 4 * i, c = 16 * (q % NB) + r16;
       const bool ok = r < n && c < n;
-      v[j][i] = src[(long)(ok ? r : 0) * gld + (ok ? c : 0)];
+      f.o[j][i] = (ok ? r : 0) * gld + (ok ? c : 0);
     }
   }
+  return f;
+}
+template <int NB>
+__device__ __forceinline__ void fetch_c(d4 (&v)[tv_maxt<NB>()], const double* src, const COff<NB>& f) {
+#pragma unroll
+  for (int j = 0; j < tv_maxt<NB>(); ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[j][i] = src[f.o[j][i]];
 }
 template <int NB>
 __device__ __forceinline__ void mask_c(d4 (&v)[tv_maxt<NB>()], int n, int wave, int r16, int kq) {
@@ -180,19 +192,34 @@ __device__ __forceinline__ void store_acc(double* M, d4 (&acc)[tv_maxt<NB>()], i
 // requests of a step (~50 per thread) were bound by the texture addresser, not by the data (phase 2: 5.2 k -> 4.4 k
 // cycles for the section that issues them, tools/tile_vjp_timing.py).
 struct MatRegs { double v[4][4]; };
+template <bool VEC> struct MOff { int o[VEC ? 4 : 16]; };
 template <bool VEC>
-__device__ __forceinline__ void fetch_mat(MatRegs& m, const double* src, int gld, int n) {
+__device__ __forceinline__ MOff<VEC> mat_off(int gld, int n) {
+  MOff<VEC> f;
   const int ty = threadIdx.x >> 4, c0 = 4 * (threadIdx.x & 15);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = ty + 16 * i < n ? ty + 16 * i : 0;
     if constexpr (VEC) {
-      const d4 q = *(const d4*)(src + (long)r * gld + (c0 < gld ? c0 : 0));
+      f.o[i] = r * gld + (c0 < gld ? c0 : 0);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f.o[4 * i + j] = r * gld + (c0 + j < n ? c0 + j : 0);
+    }
+  }
+  return f;
+}
+template <bool VEC>
+__device__ __forceinline__ void fetch_mat(MatRegs& m, const double* src, const MOff<VEC>& f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if constexpr (VEC) {
+      const d4 q = *(const d4*)(src + f.o[i]);
 #pragma unroll
       for (int j = 0; j < 4; ++j) m.v[i][j] = q[j];
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) m.v[i][j] = src[(long)r * gld + (c0 + j < n ? c0 + j : 0)];
+      for (int j = 0; j < 4; ++j) m.v[i][j] = src[f.o[4 * i + j]];
     }
   }
 }
@@ -213,7 +240,7 @@ __device__ __forceinline__ void stage_mat(double* dst, const MatRegs& m, int n, 
 template <int NB, bool VEC>
 __device__ __forceinline__ void load_mat(double* dst, const double* src, int gld, int n) {
   MatRegs m;
-  fetch_mat<VEC>(m, src, gld, n);
+  fetch_mat<VEC>(m, src, mat_off<VEC>(gld, n));
   stage_mat<NB>(dst, m, n);
 }
 
@@ -313,10 +340,12 @@ __global__ __launch_bounds__(256) void tile_vjp_phase0(const TileVjpArgs a) {
   load_mat<NB, true>(L3, handoff(a, b, T - 1) + (long)NP * NP, NP, n);
   MatRegs gpre;
   d4 ppre[tv_maxt<NB>()];
+  const MOff<true> offNP = mat_off<true>(NP, n);
+  const COff<NB> coffNP = c_off<NB>(NP, n, wave, r16, kq);
   {
     const int tp = T > 1 ? T - 2 : 0;
-    fetch_mat<true>(gpre, handoff(a, b, tp), NP, n);
-    fetch_c<NB>(ppre, handoff(a, b, tp) + (long)NP * NP, NP, n, wave, r16, kq);
+    fetch_mat<true>(gpre, handoff(a, b, tp), offNP);
+    fetch_c<NB>(ppre, handoff(a, b, tp) + (long)NP * NP, coffNP);
   }
   tile_barrier();
   for (int t = T - 1; t >= 0; --t) {
@@ -328,8 +357,8 @@ __global__ __launch_bounds__(256) void tile_vjp_phase0(const TileVjpArgs a) {
       mask_c<NB>(pcur, n, wave, r16, kq);
       {
         const int tp = t > 0 ? t - 1 : 0;                         // (unconditional: see the note on the memory schedule)
-        fetch_mat<true>(gpre, handoff(a, b, tp), NP, n);
-        fetch_c<NB>(ppre, handoff(a, b, tp) + (long)NP * NP, NP, n, wave, r16, kq);
+        fetch_mat<true>(gpre, handoff(a, b, tp), offNP);
+        fetch_c<NB>(ppre, handoff(a, b, tp) + (long)NP * NP, coffNP);
       }
       tile_barrier();
       d4 acc[tv_maxt<NB>()];
@@ -371,8 +400,10 @@ __global__ __launch_bounds__(256) void tile_vjp_phase1(const TileVjpArgs a) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r16 = lane & 15, kq = lane >> 4;
   for (int e = threadIdx.x; e < 4 * MAT + 192 + 3 * TV_MAX_S * 64; e += 256) sm[e] = 0.0;     // Sigma_bar = 0, vectors = 0
   MatRegs gpre, spre;
-  fetch_mat<true>(gpre, handoff(a, b, 0), NP, n);
-  fetch_mat<A4>(spre, a.sig + ((long)b * T + (T > 1 ? 1 : 0)) * n * n, n, n);
+  const MOff<true> offNP = mat_off<true>(NP, n);
+  const MOff<A4> offN = mat_off<A4>(n, n);
+  fetch_mat<true>(gpre, handoff(a, b, 0), offNP);
+  fetch_mat<A4>(spre, a.sig + ((long)b * T + (T > 1 ? 1 : 0)) * n * n, offN);
   // direct cotangents and the mean of step t for thread i < n, requested one step ahead
   const int ti = threadIdx.x < n ? threadIdx.x : 0;
   double gdpre = 0.0, gxpre = 0.0, mtpre = 0.0;
@@ -489,19 +520,18 @@ __global__ __launch_bounds__(256) void tile_vjp_phase1(const TileVjpArgs a) {
       if (threadIdx.x + 256 * k < SN && el[k] < XSL_S * 64) xsl[el[k]] = xscur[k];
     stage_mat<NB>(L0, gpre, n);                                                     // G_t
     stage_mat<NB>(L2, spre, n);                                                     // Sigma_{t+1}
-    {
-      const int tq = t + 2 < T ? t + 1 : t;                                      // (unconditional, clamped)
-      fetch_mat<true>(gpre, handoff(a, b, tq), NP, n);
-      fetch_mat<A4>(spre, a.sig + ((long)b * T + tq + 1) * n * n, n, n);
-    }
     tile_barrier();
     TV_TICK(2)
+    // next step's matrices: each requested in FRONT of a product (a burst of requests stalls at the issue, phase 2)
+    const int tq = t + 2 < T ? t + 1 : t;                                        // (unconditional, clamped)
+    fetch_mat<true>(gpre, handoff(a, b, tq), offNP);
     d4 acc[tv_maxt<NB>()], accp[tv_maxt<NB>()];
     acc_zero<NB>(acc);
     gemm_mfma<NB, false, false>(L3, L0, wave, r16, kq, acc);                     // SG = Sigma_bar G
     store_acc<NB>(L1, acc, wave, r16, kq);
     tile_barrier();                                                             // (Sigma_bar in L3 is consumed)
     TV_TICK(3)
+    fetch_mat<A4>(spre, a.sig + ((long)b * T + tq + 1) * n * n, offN);
     acc_zero<NB>(acc);
     gemm_mfma<NB, false, false>(L1, L2, wave, r16, kq, acc);                     // SG Sigma_{t+1}
     TV_TICK(4)
@@ -587,24 +617,36 @@ __global__ __launch_bounds__(256) void tile_vjp_phase2(const TileVjpArgs a) {
   const double* gb_base = T > 1 ? a.g_bar + (long)b * (T - 1) * n * n : handoff(a, b, 0);
   const long gb_step = T > 1 ? (long)n * n : 0;
   const int pair_ld = T > 1 ? n : NP;
+  const MOff<true> offNP = mat_off<true>(NP, n);
+  const MOff<A4> offN = mat_off<A4>(n, n), offPair = mat_off<A4>(pair_ld, n);
+  const COff<NB> coffPair = c_off<NB>(pair_ld, n, wave, r16, kq);
   // operands the step STARTS with (Pinv_t, J12, G_bar_t, the vectors): requested during the previous step ...
-  auto fetch_step = [&](int t) {
+  // Three parts, each issued in FRONT of a product of the previous step: 25 KB of requests per wavefront in one burst
+  // fill the CU's texture-addresser queue (64 bytes per clock) and the wavefronts stall at the issue -- 2.9 k cycles per
+  // step; in front of a product the queue drains while the MFMAs run.
+  auto fetch_step_a = [&](int t) {
     const long bt = (long)b * T + t;
     const double* h = handoff(a, b, t);
-    fetch_mat<true>(ppre, h + (long)NP * NP, NP, n);
+    fetch_mat<true>(ppre, h + (long)NP * NP, offNP);
     const int i = threadIdx.x < n ? threadIdx.x : 0;
     cbpre = a.c_bar[bt * n + i];
     ctpre = h[2L * NP * NP + i];
-    // (the last step has no pair ahead: its requests are clamped to valid addresses and never used)
-    const int tj = t < T - 1 ? t : (T > 1 ? T - 2 : 0);
-    fetch_mat<A4>(jpre, j12_base + tj * j12_step, pair_ld, n);
-    fetch_c<NB>(gbpre, gb_base + tj * gb_step, pair_ld, n, wave, r16, kq);
   };
+  // (the last step has no pair ahead: its requests are clamped to valid addresses and never used)
+  auto fetch_step_b = [&](int t) {
+    const int tj = t < T - 1 ? t : (T > 1 ? T - 2 : 0);
+    fetch_mat<A4>(jpre, j12_base + tj * j12_step, offPair);
+  };
+  auto fetch_step_c = [&](int t) {
+    const int tj = t < T - 1 ? t : (T > 1 ? T - 2 : 0);
+    fetch_c<NB>(gbpre, gb_base + tj * gb_step, coffPair);
+  };
+  auto fetch_step = [&](int t) { fetch_step_a(t); fetch_step_b(t); fetch_step_c(t); };
   // ... and the ones it needs two products later (G_t, Pinv_bar_t): requested at its top -- they do not live across
   // the loop's back edge
   auto fetch_mid = [&](int t) {
-    fetch_mat<true>(gpre, handoff(a, b, t), NP, n);
-    fetch_mat<A4>(bpre, a.pinv_bar + ((long)b * T + t) * n * n, n, n);
+    fetch_mat<true>(gpre, handoff(a, b, t), offNP);
+    fetch_mat<A4>(bpre, a.pinv_bar + ((long)b * T + t) * n * n, offN);
   };
   fetch_step(t_hi);
   tile_barrier();
@@ -612,7 +654,6 @@ __global__ __launch_bounds__(256) void tile_vjp_phase2(const TileVjpArgs a) {
   for (int t = t_hi; t >= t_lo; --t) {
     const long bt = (long)b * T + t;
     const double* ct = ctv;
-    fetch_mid(t);
     stage_mat<NB>(L0, ppre, n);                                                     // Pinv_t
     if (threadIdx.x < n) { cb[threadIdx.x] = cbpre; ctv[threadIdx.x] = ctpre; }
     // P_bar = Pinv X_bar G' - Pinv Pinv_bar Pinv = Pinv (X_bar G' - Pinv_bar Pinv): three products after X_bar instead
@@ -628,6 +669,7 @@ __global__ __launch_bounds__(256) void tile_vjp_phase2(const TileVjpArgs a) {
       stage_mat<NB>(L1, jpre, n);
       tile_barrier();
       TV_TICK(0)
+      fetch_mid(t);                                                              // (in front of the first product)
       matvec<false>(L1, LD, hb, tmpv, n, vec + 320);
       for (int i = threadIdx.x; i < n; i += 256) cb[i] += tmpv[i];
       TV_TICK(1)
@@ -642,19 +684,26 @@ __global__ __launch_bounds__(256) void tile_vjp_phase2(const TileVjpArgs a) {
       stage_mat<NB>(L1, gpre, n);                                                   // G_t
     } else {
       tile_barrier();
+      fetch_mid(t);
     }
+    TV_TICK(13)
     stage_mat<NB>(L3, bpre, n, -1.0);                                               // -Pinv_bar (direct + Cholesky part)
-    fetch_step(t > t_lo ? t - 1 : t_lo);                                         // (unconditional, clamped to the range)
+    TV_TICK(14)
+    const int tnx = t > t_lo ? t - 1 : t_lo;                                     // (requests: unconditional, clamped to the range)
+    TV_TICK(15)
     tile_barrier();
     TV_TICK(3)
+    fetch_step_a(tnx);
     if (t < T - 1) gemm_mfma<NB, false, true>(L2, L1, wave, r16, kq, yacc);      // X_bar G'
     TV_TICK(4)
+    fetch_step_b(tnx);
     gemm_mfma<NB, false, false>(L3, L0, wave, r16, kq, yacc);                     // - Pinv_bar Pinv
     TV_TICK(5)
     tile_barrier();                                                             // (L2 = X_bar consumed)
     store_acc<NB>(L2, yacc, wave, r16, kq);                                      // Y
     tile_barrier();
     TV_TICK(6)
+    fetch_step_c(tnx);
     gemm_mfma<NB, false, false>(L0, L2, wave, r16, kq, pbar);                    // P_bar = Pinv Y
     TV_TICK(7)
     TV_TICK(8)

@@ -32,10 +32,12 @@ def main():
     gJ, gh = vjp_from_handoff_hip(plan, args[4], False, plan.E_node_x.clone(), g[0], g[1], g[2])
     torch.cuda.synchronize()
     tm = gh[:, 0, :16].cpu().numpy().mean(0)
-    tot = tm[:13].sum()
+    tot = tm[:16].sum()
     print("phase 2, n=%d T=%d B=%d: %.0f cycles per step (counter ticks)" % (n, T, B, tot / T))
     for k, name in enumerate(NAMES):
         print("  %-28s %8.0f  %5.1f %%" % (name, tm[k] / T, 100 * tm[k] / tot))
+    print("  (of 'stage G, -Pinv_bar, requests': stage G %.0f, stage -Pinv_bar %.0f, requests %.0f, barrier %.0f)"
+          % (tm[13] / T, tm[14] / T, tm[15] / T, tm[3] / T))
     # phase 1 leaves its counters in c_bar[b, 0, :16] of the VJP workspace (kept by the timing build of lds_large)
     ws = getattr(lds_large, "_last_ws", None)
     if ws is not None:
