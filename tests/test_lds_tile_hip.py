@@ -186,7 +186,8 @@ def test_tile_sampler_against_reference_build(n, T, S):
 
 
 @pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
-@pytest.mark.parametrize("n,T,S", [(16, 8, 2), (32, 6, 1), (64, 4, 1), (20, 1, 1), (33, 2, 2), (16, 3, 1)])
+@pytest.mark.parametrize("n,T,S", [(16, 8, 2), (32, 6, 1), (64, 4, 1), (20, 1, 1), (33, 2, 2), (16, 3, 1), (16, 130, 2),
+                                   (24, 200, 1)])
 @pytest.mark.parametrize("with_samples", [False, True])
 def test_tile_vjp_against_reference_compiled_vjps(n, T, S, with_samples):
     """Gradients w.r.t. the node potentials for 16 <= n <= 64 against the reference's compiled VJPs."""
@@ -437,3 +438,34 @@ def test_tile_estep_halves_equal_the_whole(n, T, B):
     with pytest.raises(ValueError):
         small.launch(*[t(x) for x in rand_lds_natparam(4, rng)[0]], *[t(x) for x in rand_lds_natparam(4, rng)[1]],
                      *[t(x) for x in rand_node_potentials((2, 5, 4), rng)], half=1)
+
+
+def test_tile_training_step_repeats_on_one_plan():
+    """A training step at 16 <= n <= 64 runs on three streams (E-step halves, VJP phase 0 early, Cholesky adjoint of the
+    next range of steps next to phase 2): repeated on ONE plan -- each launch overwrites the hand-off the helper streams
+    of the previous step read -- every pass must give the same values and gradients, and the same as a fresh plan."""
+    from svae_amd.lds.lds_inference import LDSEStepPlan, lds_inference_differentiable
+    n, T, B, S = 32, 160, 5, 2
+    rng = np.random.default_rng(5)
+    natparam = rand_lds_natparam(n, rng)
+    node = rand_node_potentials((B, T, n), rng)
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev)
+    nat = (tuple(t(x) for x in natparam[0]), tuple(t(x) for x in natparam[1]))
+    eps, gs = torch.randn(B, T, S, n, dtype=torch.float64, device=dev), torch.randn(B, T, S, n, dtype=torch.float64, device=dev)
+
+    def run(plan):
+        nJ, nh = (t(x).requires_grad_(True) for x in node)
+        lognorm, (dxx, ex), samples, _ = lds_inference_differentiable(nat, (nJ, nh), eps=eps, plan=plan)
+        loss = lognorm.sum() + (dxx * 0.3).sum() + ex.sum() + (samples * gs).sum()
+        gJ, gh = torch.autograd.grad(loss, [nJ, nh])
+        return [x.clone() for x in (lognorm, ex, samples, gJ, gh)]
+    plan = LDSEStepPlan(B, T, n, dev)
+    first = run(plan)
+    for _ in range(3):
+        again = run(plan)
+        for a, b in zip(first, again):
+            assert torch.equal(a, b)
+    fresh = run(LDSEStepPlan(B, T, n, dev))
+    for a, b in zip(first, fresh):
+        assert torch.equal(a, b)
