@@ -98,12 +98,15 @@ def start_phase0(plan, J12, pair_batched, S):
     dev = plan.device
     f64 = dict(dtype=torch.float64, device=dev)
     nws = int(lib.svae_lds_tile_vjp_workspace_doubles(max(B, 1), T, n, S))
-    ws = torch.empty(nws, **f64)
+    # the VJP workspace belongs to the plan (one live autograd graph per plan): no allocation per step, and no second
+    # block while the allocator waits for the helper streams of the previous step to release the first
+    ws = getattr(plan, "_vjp_ws", None)
+    if ws is None or ws.numel() < nws:
+        ws = plan._vjp_ws = torch.empty(nws, **f64)
     dummy = plan.lognorm                      # (phase 0 reads none of the cotangents; the entry point wants the pointers)
     gJ = torch.empty(1, **f64)
     main, side = _side_stream(dev)
-    side.wait_stream(main)                    # the hand-off of the launch just issued
-    ws.record_stream(side)
+    side.wait_stream(main)                    # the hand-off of the launch just issued (and everything before it)
     J12c = J12.to(**f64).contiguous()
     rc = lib.svae_lds_tile_vjp_f64(0, B, T, n, 0, 0, T, int(J12c.dim() >= 3), int(bool(pair_batched)), p(J12c), p(dummy),
                                    None, None, None, None, None, None, p(plan.E_node_x), p(gJ), p(gJ), p(plan.ws),
@@ -149,7 +152,9 @@ def vjp_from_handoff_hip(plan, J12, pair_batched, ex, g_lognorm, g_dxx, g_x, sam
         ws = phase0[0]
         torch.cuda.current_stream(dev).wait_event(phase0[1])
     else:
-        ws, phase0 = torch.empty(nws, **f64), None
+        ws, phase0 = getattr(plan, "_vjp_ws", None), None
+        if ws is None or ws.numel() < nws:
+            ws = plan._vjp_ws = torch.empty(nws, **f64)
     gJ, gh = torch.empty(B, T, n, **f64), torch.empty(B, T, n, **f64)
     if _keep_ws:
         global _last_ws
@@ -185,7 +190,7 @@ def vjp_from_handoff_hip(plan, J12, pair_batched, ex, g_lognorm, g_dxx, g_x, sam
         return gJ, gh
     main, side = _side_stream(dev)
     side.wait_stream(main)                      # phase 1 (xbar, the direct part of pinv_bar)
-    for buf in (ws, eps, gJ, gh):
+    for buf in (eps, gJ, gh):
         buf.record_stream(side)
     done = []
     for k in reversed(range(nr)):
