@@ -35,7 +35,7 @@
 #include "per_device.hpp"
 
 #ifndef SVAE_TILE_SGB
-#define SVAE_TILE_SGB 5
+#define SVAE_TILE_SGB 7
 #endif
 
 // Scheduling hint: NM groups of {1 MFMA, NR LDS reads, NW LDS writes}.  An in-order wavefront stalls
@@ -47,9 +47,11 @@
     if ((NR) > 0) __builtin_amdgcn_sched_group_barrier(0x100, (NR), ID);       \
     if ((NW) > 0) __builtin_amdgcn_sched_group_barrier(0x200, (NW), ID);       \
   }
-// SVAE_TILE_SGB: bit 0 = elimination row updates, bit 2 = backward Sigma update.  (bit 1, the Schur
-// stage, is wired but OFF: with it hipcc 7.2 produces wrong code for the per-step-parameter n = 64
-// instantiation -- caught by tests/test_lds_tile_hip.py; gain would be ~1 %.)
+// SVAE_TILE_SGB: bit 0 = elimination row updates, bit 1 = Schur stage, bit 2 = backward Sigma update.  (Bit 1 was off
+// through round 2 and most of round 3: with it hipcc 7.2 produced wrong code for the per-step-parameter n = 64
+// instantiation of the kernel as it was then -- caught by tests/test_lds_tile_hip.py.  With the register budgets and
+// single-half instances of round 3 every instantiation passes with it; 0.7 % at 512 sequences.  -DSVAE_TILE_SGB=5
+// switches it off again.)
 #define SVAE_SGB(ID, NM, NR, NW) if constexpr (((SVAE_TILE_SGB) >> ((ID) - 1)) & 1) { SVAE_SGB_(ID, NM, NR, NW) }
 
 namespace svae {
