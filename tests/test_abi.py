@@ -89,6 +89,35 @@ def test_bad_arguments_are_rejected_on_the_host():
                                       *([null] * 8), null, null, null, null) == -3
 
 
+def test_round3_entry_points_reject_bad_arguments_on_the_host():
+    """svae_slds_path_nodeparams_f64 / svae_slds_mix_pair_natparam_f64 and the step ranges of svae_lds_tile_vjp_f64 /
+    svae_lds_tile_noise_f64: argument errors come back before any HIP call."""
+    import ctypes as C
+    from svae_amd import _lib
+    lib = _lib.load()
+    buf = (C.c_double * 64)()
+    ptr = C.cast(buf, C.c_void_p)
+    nine = [ptr] * 9
+    assert lib.svae_slds_path_nodeparams_f64(2, 3, 17, 4, *nine, None) == -3       # K > 16
+    assert lib.svae_slds_path_nodeparams_f64(2, 3, 4, 16, *nine, None) == -4       # n > 15: no quadratic-form kernel
+    assert lib.svae_slds_path_nodeparams_f64(2, 0, 4, 4, *nine, None) == -2        # T < 1
+    assert lib.svae_slds_mix_pair_natparam_f64(2, 3, 4, 19, *nine, None) == -4     # 3 n^2 + 1 > 1024 threads
+    assert lib.svae_slds_mix_pair_natparam_f64(2, 3, 17, 4, *nine, None) == -3
+    assert lib.svae_slds_mix_pair_natparam_f64(2, 3, 4, 4, None, *nine[1:], None) == -5
+    nws = lib.svae_lds_tile_vjp_workspace_doubles(1, 4, 16, 0)
+    assert nws == 1 * 4 * 256 * 2 + 3 * 256 + 4 * 16 + 0 + (16 * 18 + 64)           # ... | phase-2 state between ranges
+    big = (C.c_double * nws)()
+    bp = C.cast(big, C.c_void_p)
+    vjp = lambda phase, t0, t1: lib.svae_lds_tile_vjp_f64(phase, 1, 4, 16, 0, t0, t1, 0, 0, ptr, ptr, None, None, None, None,
+                                                         None, None, ptr, ptr, ptr, bp, bp, nws, None)
+    assert vjp(2, 3, 2) == -20 and vjp(2, 0, 5) == -20 and vjp(2, -1, 4) == -20     # bad range
+    assert vjp(0, 1, 4) == -20 and vjp(1, 0, 3) == -20                               # phases 0 / 1: the whole chain only
+    info = (C.c_int32 * 1)()
+    ip = C.cast(info, C.c_void_p)
+    assert lib.svae_lds_tile_noise_f64(0, 1, 4, 16, 1, 2, 2, ptr, ptr, bp, None, ip, None) == -20
+    assert lib.svae_lds_tile_noise_f64(0, 1, 4, 16, 1, 0, 5, ptr, ptr, bp, None, ip, None) == -20
+
+
 def test_contradictory_or_unknown_options_are_rejected():
     """The per-call selection word (SVAE_OPT_*): contradictory pairs and unknown bits return -24 after the pointer
     checks and before any HIP call; the library exports no process-global selectors any more."""
@@ -104,6 +133,9 @@ def test_contradictory_or_unknown_options_are_rejected():
                 _lib.OPT_PRODUCERS_ON | _lib.OPT_PRODUCERS_OFF, 0x40, 0x80000000):
         assert lib.svae_lds_estep_f64(1, 4, 2, 0, 0, 0, bad, *args) == -24
         assert lib.svae_lds_sample_f64(1, 4, 2, 1, bad, ptr, ptr, ptr, ws, None) == -24
+    # one half of the E-step per call: latent dimension 16 .. 64 only, and not both halves at once
+    assert lib.svae_lds_estep_f64(1, 4, 2, 0, 0, 0, _lib.OPT_TILE_FORWARD, *args) == -24
+    assert lib.svae_lds_estep_f64(1, 4, 2, 0, 0, 0, _lib.OPT_TILE_BACKWARD, *args) == -24
     for name in ("svae_lds_set_twoend", "svae_lds_set_split_max_b", "svae_lds_set_prod_max_b"):
         assert not hasattr(lib, name)
 
