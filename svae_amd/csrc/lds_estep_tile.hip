@@ -7,13 +7,15 @@
 // longer fits a 16-lane DPP row.
 //
 // Mapping: one workgroup (4 wavefronts) per sequence, two workgroups per CU.  The per-step
-// matrices live in LDS as ONE row-major panel  M = [ P | R | h ]  of NP x (2 NP + 1) doubles
-// (NP = n rounded up to 16; P = pivot block J_filt + J11, R = J12, h = filtered potential vector),
-// cut in 16x16 tiles (h: a tile column of which only column 0 exists).  Every O(n^3) stage is a
+// matrices live in LDS as ONE row-major panel  M = [ P | R | c ]  of NP x (2 NP + 1) doubles
+// (NP = n rounded up to 16; P = pivot block J_filt + J11, R = J12, last column: c = P^-1 h),
+// cut in 16x16 tiles.  Every O(n^3) stage is a
 // list of tile products on v_mfma_f64_16x16x4_f64 with A/B fragments read straight from the panel
 // (row stride == 2 mod 32 doubles: the A-fragment read is bank-conflict free):
-//   forward   in-place BLOCK Gauss-Jordan of [P | R | h] with 16x16 block pivots: P -> P^-1,
-//             R -> X = P^-1 J12, h -> c = P^-1 h.  The pivot tile A_kk = L D L' is factored by one
+//   forward   in-place BLOCK Gauss-Jordan of [P | R] with 16x16 block pivots: P -> P^-1,
+//             R -> X = P^-1 J12; c = P^-1 h and J12' c are matrix-vector products on the vector ALU
+//             (as a 1-wide tile column of the panel h cost a full tile product per row update and
+//             Schur row).  The pivot tile A_kk = L D L' is factored by one
 //             wavefront with the DPP elimination of the register path (pivots -> log det P), which
 //             leaves U = L^-1 and D^-1; the block row is then A_kk^-1 A_kj = U' D^-1 (U A_kj), two
 //             tile products (applying the explicit inverse tile instead costs 2 digits on
@@ -96,7 +98,7 @@ __device__ __forceinline__ void store_c(double* M, int ld, int row0, int col0, i
 template <int NB>
 struct TileCfg {
   static constexpr int NP = 16 * NB;
-  static constexpr int NTC = 2 * NB + 1;        // tile columns of [P | R | h]; the last one is 1 wide
+  static constexpr int NTC = 2 * NB;            // tile columns of the panel [P | R] (column 2 NP of a row: c = P^-1 h)
   static constexpr int LDM = 2 * NP + 2;        // == 2 (mod 32)
   static constexpr int WSTEP = 2 * NP * NP + NP;   // hand-off per step: X, P^-1 (row-major NP x NP), c
   static constexpr int LDU = 18;                // pivot-factor tile U = L^-1, row stride
@@ -227,22 +229,12 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
 #define TICK(i)
 #endif
 
-  // B/C fragments by tile column jt of the panel; jt == 2 NB is the h column (one physical column:
-  // lanes r16 > 0 see zeros and do not store)
-  const double e0 = (r16 == 0) ? 1.0 : 0.0;
-  auto ld_b = [&](int row0, int jt) -> d4 {
-    if (jt < 2 * NB) return frag_b(M, LDM, row0, 16 * jt, r16, kq);
-    const double* p = M + (row0 + kq) * LDM + 2 * NP;
-    return d4{p[0] * e0, p[4 * LDM] * e0, p[8 * LDM] * e0, p[12 * LDM] * e0};
-  };
-  auto st_c = [&](int row0, int jt, const d4 v) {
-    if (jt < 2 * NB) {
-      store_c(M, LDM, row0, 16 * jt, r16, kq, v);
-    } else if (r16 == 0) {
-      double* p = M + (row0 + kq) * LDM + 2 * NP;
-      p[0] = v[0]; p[4 * LDM] = v[1]; p[8 * LDM] = v[2]; p[12 * LDM] = v[3];
-    }
-  };
+  // B/C fragments by tile column jt < 2 NB of the panel [P | R].  The right-hand side h does NOT ride through the
+  // elimination (as a 1-wide tile column it cost a full 16-wide MFMA product per row update and per Schur row: 1/8 and
+  // 1/5 of those phases): c = P^-1 h is a 4-thread-per-row product with the finished inverse in the hand-off phase,
+  // J12' c a per-lane product with the A fragments the Schur stage holds anyway.  Column 2 NP of M carries c.
+  auto ld_b = [&](int row0, int jt) -> d4 { return frag_b(M, LDM, row0, 16 * jt, r16, kq); };
+  auto st_c = [&](int row0, int jt, const d4 v) { store_c(M, LDM, row0, 16 * jt, r16, kq, v); };
   // A_kk^-1 (.) = U' D^-1 U (.) applied to a B-layout tile
   auto apply_pivot = [&](const double* U, const double* dinv, const d4 fb) -> d4 {
     d4 v = mma16(frag_a(U, LDU, 0, 0, r16, kq), fb, d4{0.0, 0.0, 0.0, 0.0});
@@ -252,9 +244,9 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
   };
   // ---- roles ------------------------------------------------------------------------------------
   // Schur product: tile row si per wavefront (WPR wavefronts share a row when NB <= 2), tile columns
-  // sj0, sj0 + WPR, ... <= NB (column NB is the h column)
+  // sj0, sj0 + WPR, ... < NB; the wavefront with sj0 == WPR - 1 also forms the row's share of J12' c
   constexpr int WPR = NB <= 2 ? 4 / NB : 1;
-  constexpr int SCOLS = (NB + 1 + WPR - 1) / WPR;
+  constexpr int SCOLS = (NB + WPR - 1) / WPR;
   constexpr int RL4 = (NP * NP / 4 + 191) / 192; // 4-double chunks per thread of an NP x NP copy by 3 wavefronts
   int* flag = (int*)(ubuf + 2 * UBUF);           // look-ahead hand-shake (see below)
   if (tid == 0) *flag = 0;
@@ -273,11 +265,7 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
     M[row * LDM + col] = v;
     M[row * LDM + NP + col] = r;
   }
-  if (tid < NP) {
-    const double hv = tid < n ? a.init_h[tid] + nodeh[tid] : 0.0;
-    hvec[tid] = hv;
-    M[tid * LDM + 2 * NP] = hv;
-  }
+  if (tid < NP) hvec[tid] = tid < n ? a.init_h[tid] + nodeh[tid] : 0.0;
   __syncthreads();
 
   // The forward half is instantiated per wavefront index W (wave-uniform switch below): every tile
@@ -286,6 +274,7 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
   constexpr int W = decltype(wc)::value;
   constexpr bool schur_on = W < NB * WPR;
   constexpr int si = W % NB, sj0 = W / NB;
+  constexpr bool h_on = schur_on && sj0 == WPR - 1;
   // Operands taken from the pair parameters come pre-packed (tile_pack_pairs_kernel below) in the
   // exact register order, so each is one coalesced 32-byte load per lane at base + immediate:
   //   sA = -(J12') tiles of row si (A operands of the Schur product), sC = its C input
@@ -322,8 +311,7 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
     const bool last = (t == T - 1);
     const bool next_last = (t + 1 == T - 1);
     TICK(0)
-    double njn = 0.0;
-    d4 nhn = {0.0, 0.0, 0.0, 0.0};
+    double njn = 0.0, nhn = 0.0;
     // ---- in-place block Gauss-Jordan with look-ahead -----------------------------------------------
     // Per block pivot k:  (P1) all wavefronts scale the pivot row with U_k;  (P2) wavefronts 1..3 own
     // the other tile rows (eliminate, then rewrite their pivot-column tile) while wavefront 0 updates
@@ -340,12 +328,12 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
       __syncthreads();
       TICK(2)
       {  // (P1) pivot row:  A[k][j] <- A_kk^-1 A[k][j] = U' D^-1 (U A[k][j])   (j != k), two tiles at a time
-        constexpr int NT1 = (2 * NB + 3) / 4;
+        constexpr int NT1 = (2 * NB - 1 + 3) / 4;           // 2 NB - 1 tiles beside the pivot tile
         static_assert(NT1 <= 2, "at most two pivot-row tiles per wavefront");
         const int q0 = W, q1 = W + 4;
         const int j0 = q0 + (q0 >= k ? 1 : 0), j1 = q1 + (q1 >= k ? 1 : 0);
         const d4 z4 = {0.0, 0.0, 0.0, 0.0};
-        if (q1 < 2 * NB) {
+        if (q1 < 2 * NB - 1) {
           const d4 fu = frag_a(U, LDU, 0, 0, r16, kq), fut = frag_b(U, LDU, 0, 0, r16, kq);
           d4 v0 = z4, v1 = z4;
           mma16x2(fu, ld_b(16 * k, j0), v0, ld_b(16 * k, j1), v1);
@@ -355,7 +343,7 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
           mma16x2(fut, v0, t0, v1, t1);
           st_c(16 * k, j0, t0);
           st_c(16 * k, j1, t1);
-        } else if (q0 < 2 * NB) {
+        } else if (q0 < 2 * NB - 1) {
           st_c(16 * k, j0, apply_pivot(U, dinv, ld_b(16 * k, j0)));
         }
       }
@@ -372,12 +360,9 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
         }
         const long tn = (long)(last ? t : t + 1) * n;
         njn = nodeJ[tn + (tid < n ? tid : n - 1)];
-        if constexpr (schur_on && (NB - sj0) % WPR == 0) {
-#pragma unroll
-          for (int qq = 0; qq < 4; ++qq) {
-            const int row = 16 * si + 4 * qq + kq;
-            nhn[qq] = nodeh[tn + (row < n ? row : n - 1)];
-          }
+        if constexpr (h_on) {
+          const int row = 16 * si + r16;
+          nhn = nodeh[tn + (row < n ? row : n - 1)];
         }
       }
       auto inverse_tile = [&]() {   // A[k][k] <- A_kk^-1 = U' D^-1 U
@@ -402,7 +387,7 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
           constexpr int r = W - 1 + 3 * decltype(rc)::value;
           constexpr int i = r + (r >= k ? 1 : 0);
           constexpr int skipn = (i == k + 1) ? 2 : 1;         // row k+1: tile (k+1,k+1) belongs to wave 0
-          constexpr int cnt = 2 * NB + 1 - skipn;
+          constexpr int cnt = 2 * NB - skipn;
           const d4 fa = frag_a(M, LDM, 16 * i, 16 * k, r16, kq);
           const d4 nfa = -fa;
           auto jmap = [&](int jq) { return jq + (jq >= k ? skipn : 0); };
@@ -440,15 +425,26 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
 
     // ---- hand-off to the backward half: X, P^-1 (row-major NP x NP), c --------------------------
     double* w = wsb + (long)t * WSTEP;
+    {  // c = P^-1 h: four threads per row of the finished inverse
+      const int row = tid >> 2, part = tid & 3;
+      double cv = 0.0;
+      if (row < NP) {
+        const double* prow = M + row * LDM;
+#pragma unroll
+        for (int cc = 0; cc < NP; cc += 4) cv = __builtin_fma(prow[cc + part], hvec[cc + part], cv);
+      }
+      cv += __shfl_xor(cv, 1, 64);
+      cv += __shfl_xor(cv, 2, 64);
+      if (row < NP && part == 0) {
+        M[row * LDM + 2 * NP] = cv;
+        w[2 * NP * NP + row] = cv;
+        qacc = __builtin_fma(hvec[row], cv, qacc);          // h' P^-1 h
+      }
+    }
     for (int c4 = tid; c4 * 4 < NP * NP; c4 += 256) {
       const int row = (c4 * 4) / NP, col = (c4 * 4) % NP;
       *(d4*)(w + c4 * 4) = *(const d4*)(M + row * LDM + NP + col);
       *(d4*)(w + NP * NP + c4 * 4) = *(const d4*)(M + row * LDM + col);
-    }
-    if (tid < NP) {
-      const double cv = M[tid * LDM + 2 * NP];
-      w[2 * NP * NP + tid] = cv;
-      qacc = __builtin_fma(hvec[tid], cv, qacc);            // h' P^-1 h
     }
     __syncthreads();
     TICK(6)
@@ -458,20 +454,20 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
     }
     if (!last) {
       // ---- Schur step:  P' = -2 (J22 + J11') + diag(-2 node_J') - J12' X   (tile (si,j), j < NB);
-      //                   h' = node_h' + J12' c                              (j == NB) ------------
-      if (schur_on) {
+      //                   h' = node_h' + J12' c ------------------------------------------------------
+      if constexpr (schur_on && sj0 < NB) {
         d4 fb[NB];
 #pragma unroll
         for (int kk = 0; kk < NB; ++kk) fb[kk] = ld_b(16 * kk, NB + sj0);
 #pragma unroll
         for (int s2 = 0; s2 < SCOLS; ++s2) {
           const int j = sj0 + s2 * WPR;
-          if (j <= NB) {
+          if (j < NB) {
             d4 fn[NB];
             const int jn = j + WPR;
 #pragma unroll
             for (int kk = 0; kk < NB; ++kk) fn[kk] = fb[kk];
-            if (s2 + 1 < SCOLS && jn <= NB) {
+            if (s2 + 1 < SCOLS && jn < NB) {
 #pragma unroll
               for (int kk = 0; kk < NB; ++kk) fn[kk] = ld_b(16 * kk, NB + jn);
             }
@@ -479,19 +475,29 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
 #pragma unroll
             for (int kk = 0; kk < NB; ++kk) c = mma16(sA[kk], fb[kk], c);
             SVAE_SGB(2, 4 * NB, 1, 0)
-            if (j < NB) {
-              store_c(M, LDM, 16 * si, 16 * j, r16, kq, c);
-            } else if (r16 == 0) {
-#pragma unroll
-              for (int qq = 0; qq < 4; ++qq) {
-                const int row = 16 * si + 4 * qq + kq;
-                mv0[row] = row < n ? nhn[qq] - c[qq] : 0.0;   // c = -J12' c_t
-              }
-            }
+            store_c(M, LDM, 16 * si, 16 * j, r16, kq, c);
 #pragma unroll
             for (int kk = 0; kk < NB; ++kk) fb[kk] = fn[kk];
           }
         }
+      }
+      if constexpr (h_on) {
+        // sA[kk][kb] = (-J12')[16 si + r16][16 kk + 4 kb + kq]: each lane a quarter of its row's product with c, the
+        // four DPP rows summed through the cross-lane network
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < NB; ++kk) {
+          const double* cp = M + (16 * kk + kq) * LDM + 2 * NP;
+          s0 = __builtin_fma(sA[kk][0], cp[0], s0);
+          s1 = __builtin_fma(sA[kk][1], cp[4 * LDM], s1);
+          s0 = __builtin_fma(sA[kk][2], cp[8 * LDM], s0);
+          s1 = __builtin_fma(sA[kk][3], cp[12 * LDM], s1);
+        }
+        double sh = s0 + s1;
+        sh += __shfl_xor(sh, 16, 64);
+        sh += __shfl_xor(sh, 32, 64);
+        const int row = 16 * si + r16;
+        if (kq == 0) mv0[row] = row < n ? nhn - sh : 0.0;     // sh = -(J12' c_t)[row]
       }
       __syncthreads();
       TICK(7)
@@ -507,11 +513,7 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
           const int c4 = t3 + 192 * u;
           if (c4 * 4 < NP * NP) *(d4*)(M + ((c4 * 4) / NP) * LDM + NP + ((c4 * 4) % NP)) = rl[u];
         }
-        if (t3 < NP) {
-          const double hv = mv0[t3];
-          hvec[t3] = hv;
-          M[t3 * LDM + 2 * NP] = hv;
-        }
+        if (t3 < NP) hvec[t3] = mv0[t3];
       }
       __syncthreads();
       TICK(8)
