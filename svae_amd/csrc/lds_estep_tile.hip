@@ -95,6 +95,15 @@ __device__ __forceinline__ void store_c(double* M, int ld, int row0, int col0, i
   p[0] = v[0]; p[4 * ld] = v[1]; p[8 * ld] = v[2]; p[12 * ld] = v[3];
 }
 
+// writes the TRANSPOSE of a C-layout tile at (row0, col0)  (same addressing as frag_a)
+__device__ __forceinline__ void store_ct(double* M, int ld, int row0, int col0, int r16, int kq, const d4 v) {
+  double* p = M + (row0 + r16) * ld + col0 + kq;
+  p[0] = v[0]; p[4] = v[1]; p[8] = v[2]; p[12] = v[3];
+}
+// Symmetric NB x NB tile grid, every unordered pair {i, j} formed once: column j takes the rows (j + q) mod NB,
+// q < sym_cnt(NB, j)
+constexpr int sym_cnt(int NB, int j) { return (NB % 2 == 0 && j >= NB / 2) ? NB / 2 : NB / 2 + 1; }
+
 template <int NB>
 struct TileCfg {
   static constexpr int NP = 16 * NB;
@@ -571,9 +580,11 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
   if (tid < NP) { mv0[tid] = 0.0; mv1[tid] = 0.0; }
   double* mold = mv0;
   double* mnew = mv1;
-  d4 cross[NB], sxx[NB], prevE[NB];
+  d4 cross[NB], sxx[NB / 2 + 1], prevE[NB / 2 + 1];   // sxx / prevE: one per COMPUTED tile of the wavefront's column (B2)
 #pragma unroll
-  for (int i = 0; i < NB; ++i) { cross[i] = d4{0.0, 0.0, 0.0, 0.0}; sxx[i] = cross[i]; prevE[i] = cross[i]; }
+  for (int i = 0; i < NB; ++i) cross[i] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int i = 0; i < NB / 2 + 1; ++i) { sxx[i] = d4{0.0, 0.0, 0.0, 0.0}; prevE[i] = sxx[i]; }
   double* oEx = a.E_node_x + (long)b * T * n;
   double* oExx = a.E_node_diagxx + (long)b * T * n;
   double* oI = a.E_init + (long)b * (nn + n);
@@ -619,21 +630,19 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
       oEx[(long)(t + 1) * n + tid] = mm;
       oExx[(long)(t + 1) * n + tid] = __builtin_fma(mm, mm, M[tid * LDM + tid]);
     }
-    d4 pin[NB];                          // P_t^-1 tiles (i, j): consumed in B2
-    auto load_pin = [&]() {
-      if constexpr (J < NB) {
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-          const double* pi = w + NP * NP + (16 * i + kq) * NP + mycol;
-          pin[i] = d4{pi[0], pi[4 * NP], pi[8 * NP], pi[12 * NP]};
-        }
-      }
-    };
+    // B2 forms each symmetric tile pair of Sigma_t ONCE: wavefront J (= tile column J) computes the tile rows
+    // i = (J + q) mod NB, q < CNT (cyclic assignment: NB = 4 -> 3, 3, 2, 2 tiles instead of 4 each), and stores the
+    // tile at (i, J) and transposed at (J, i).  P_t^-1 is read for those tiles only.
+    constexpr int CNT = J < NB ? sym_cnt(NB, J) : 0;
+    d4 pin[CNT > 0 ? CNT : 1];           // P_t^-1 tiles (i, J): consumed in B2
     auto load_pin_i = [&](int i) -> d4 {
       const double* pi = w + NP * NP + (16 * i + kq) * NP + mycol;
       return d4{pi[0], pi[4 * NP], pi[8 * NP], pi[12 * NP]};
     };
-    if constexpr (!lean_bwd) load_pin();
+    if constexpr (!lean_bwd) {
+#pragma unroll
+      for (int q = 0; q < CNT; ++q) pin[q] = load_pin_i((J + q) % NB);
+    }
     TICK(10)
     {  // m_t = c_t + X_t m_{t+1}
       const int row = tid >> 2, part = tid & 3;
@@ -662,27 +671,29 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
     __syncthreads();
     TICK(11)
 
-    d4 pnext = {0.0, 0.0, 0.0, 0.0};             // lean: P_t^-1 tile (i, j) one tile row ahead
-    if constexpr (lean_bwd) { if constexpr (J < NB) pnext = load_pin_i(0); }
+    d4 pnext = {0.0, 0.0, 0.0, 0.0};             // lean: P_t^-1 tile one computed tile ahead
+    if constexpr (lean_bwd) { if constexpr (J < NB) pnext = load_pin_i(J); }
     else prefetch_step(t > 0 ? w - WSTEP : w);   // step t-1, in flight during B2
     if constexpr (J < NB) {
       const double mc = mnew[mycol];
       double* oP = INHOMOG && t < T - 1 ? a.E_pair + ((long)b * (T - 1) + t) * 3 * nn : nullptr;
-      d4 fx[NB];                           // A fragments of X tile row i, fetched one row ahead (lean: in place)
+      const bool rare = INHOMOG || t == 0 || t == T - 1;
+      d4 fx[NB];                           // A fragments of X tile row i, fetched one tile ahead (lean: in place)
       if constexpr (!lean_bwd) {
 #pragma unroll
-        for (int kk = 0; kk < NB; ++kk) fx[kk] = frag_a(M, LDM, 0, NP + 16 * kk, r16, kq);
+        for (int kk = 0; kk < NB; ++kk) fx[kk] = frag_a(M, LDM, 16 * J, NP + 16 * kk, r16, kq);
       }
-#pragma unroll
-      for (int i = 0; i < NB; ++i) {
+      static_for<0, CNT>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        constexpr int i = (J + q) % NB, inx = (J + q + 1) % NB;
         d4 fn[lean_bwd ? 1 : NB];
         if constexpr (!lean_bwd) {
 #pragma unroll
-          for (int kk = 0; kk < NB; ++kk) fn[kk] = (i + 1 < NB) ? frag_a(M, LDM, 16 * (i + 1), NP + 16 * kk, r16, kq) : fx[kk];
+          for (int kk = 0; kk < NB; ++kk) fn[kk] = (q + 1 < CNT) ? frag_a(M, LDM, 16 * inx, NP + 16 * kk, r16, kq) : fx[kk];
         }
         d4 c;
-        if constexpr (lean_bwd) { c = pnext; if (i + 1 < NB) pnext = load_pin_i(i + 1); }
-        else c = pin[i];
+        if constexpr (lean_bwd) { c = pnext; if constexpr (q + 1 < CNT) pnext = load_pin_i(inx); }
+        else c = pin[q];
         if constexpr (lean_bwd) {        // fragments read where they are consumed (one live at a time)
 #pragma unroll
           for (int kk = 0; kk < NB; ++kk) c = mma16(frag_a(M, LDM, 16 * i, NP + 16 * kk, r16, kq), Wt[kk], c);
@@ -695,18 +706,57 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
 #pragma unroll
           for (int kk = 0; kk < NB; ++kk) fx[kk] = fn[kk];
         }
-        store_c(M, LDM, 16 * i, 16 * J, r16, kq, c);          // Sigma_t tile (i, j)
-        d4 exx, ecr;
+        store_c(M, LDM, 16 * i, 16 * J, r16, kq, c);          // Sigma_t tile (i, J) ...
+        if constexpr (i != J) store_ct(M, LDM, 16 * J, 16 * i, r16, kq, c);   // ... and its mirror image (J, i)
+        d4 exx;
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
-          const int row = 16 * i + 4 * qq + kq;
-          exx[qq] = __builtin_fma(mnew[row], mc, c[qq]);          // E[x_t x_t'](row, mycol)
-          ecr[qq] = __builtin_fma(mold[row], mc, Wt[i][qq]);      // E[x_{t+1} x_t'](row, mycol)
-        }
+        for (int qq = 0; qq < 4; ++qq) exx[qq] = __builtin_fma(mnew[16 * i + 4 * qq + kq], mc, c[qq]);   // E[x_t x_t'](row, mycol)
 #ifndef SVAE_TILE_TIMING
-        if (INHOMOG || t == 0 || t == T - 1) {
+        if (rare) {
           // (homogeneous model: stores at the two ends of the chain only.  The opaque copy of the column index keeps
-          //  their 48 loop-invariant 64-bit addresses from being hoisted out of the time loop into live registers)
+          //  their loop-invariant 64-bit addresses from being hoisted out of the time loop into live registers)
+          int mcx = mycol;
+          if constexpr (!INHOMOG) asm volatile("" : "+v"(mcx));
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) {
+            const int row = 16 * i + 4 * qq + kq;
+            const bool in = row < n && mcx < n;
+            const int p1 = row * n + mcx, p2 = mcx * n + row;       // the element and its mirror image
+            if (INHOMOG) {
+              if (oP && in) {
+                oP[p1] = exx[qq];
+                oP[2 * nn + p1] = prevE[q][qq];                     // E[x_{t+1} x_{t+1}'] (previous step)
+                if constexpr (i != J) { oP[p2] = exx[qq]; oP[2 * nn + p2] = prevE[q][qq]; }
+              }
+            } else if (in) {
+              // sum_{t>=1} E[x_t x_t'] = sum_{t<=T-2} + last - first: the last term waits in its output slot
+              if (t == T - 1) oPh[2 * nn + p1] = exx[qq];
+              if (t == 0) {
+                const double s0 = sxx[q][qq] + (T > 1 ? exx[qq] : 0.0);
+                const double s2 = s0 + oPh[2 * nn + p1] - exx[qq];
+                oPh[p1] = s0;
+                oPh[2 * nn + p1] = s2;
+                if constexpr (i != J) { oPh[p2] = s0; oPh[2 * nn + p2] = s2; }
+              }
+            }
+            if (t == 0 && in) {
+              oI[p1] = exx[qq];
+              if constexpr (i != J) oI[p2] = exx[qq];
+            }
+          }
+        }
+#endif
+        if (INHOMOG) prevE[q] = exx;
+        else if (t < T - 1) sxx[q] += exx;
+      });
+      // cross moments E[x_{t+1} x_t'](row, mycol) = W + m_{t+1} m_t': every tile row of the wavefront's column
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        d4 ecr;
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) ecr[qq] = __builtin_fma(mold[16 * i + 4 * qq + kq], mc, Wt[i][qq]);
+#ifndef SVAE_TILE_TIMING
+        if (rare) {
           int mcx = mycol;
           if constexpr (!INHOMOG) asm volatile("" : "+v"(mcx));
 #pragma unroll
@@ -714,27 +764,14 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
             const int row = 16 * i + 4 * qq + kq;
             const bool in = row < n && mcx < n;
             if (INHOMOG) {
-              if (oP && in) {
-                oP[row * n + mcx] = exx[qq];
-                oP[nn + mcx * n + row] = ecr[qq];
-                oP[2 * nn + row * n + mcx] = prevE[i][qq];        // E[x_{t+1} x_{t+1}'] (previous step)
-              }
-            } else if (in) {
-              // sum_{t>=1} E[x_t x_t'] = sum_{t<=T-2} + last - first: the last term waits in its output slot
-              if (t == T - 1) oPh[2 * nn + row * n + mcx] = exx[qq];
-              if (t == 0) {
-                const double s0 = sxx[i][qq] + (T > 1 ? exx[qq] : 0.0);
-                oPh[row * n + mcx] = s0;
-                oPh[nn + mcx * n + row] = cross[i][qq] + ecr[qq];
-                oPh[2 * nn + row * n + mcx] = s0 + oPh[2 * nn + row * n + mcx] - exx[qq];
-              }
+              if (oP && in) oP[nn + mcx * n + row] = ecr[qq];
+            } else if (in && t == 0) {
+              oPh[nn + mcx * n + row] = cross[i][qq] + ecr[qq];
             }
-            if (t == 0 && in) oI[row * n + mcx] = exx[qq];
           }
         }
 #endif
-        if (INHOMOG) prevE[i] = exx;
-        else if (t < T - 1) { sxx[i] += exx; cross[i] += ecr; }
+        if (!INHOMOG && t < T - 1) cross[i] += ecr;
       }
     }
     double* tmp = mold; mold = mnew; mnew = tmp;
