@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
   // Schur product: tile row si per wavefront (WPR wavefronts share a row when NB <= 2), tile columns
   // sj0, sj0 + WPR, ... < NB; the wavefront with sj0 == WPR - 1 also forms the row's share of J12' c
   constexpr int WPR = NB <= 2 ? 4 / NB : 1;
-  constexpr int SCOLS = (NB + WPR - 1) / WPR;
+  constexpr int SCOLS = WPR == 1 ? NB / 2 + 1 : (NB + WPR - 1) / WPR;   // (WPR == 1: symmetric tile pairs once, see the Schur step)
   constexpr int RL4 = (NP * NP / 4 + 191) / 192; // 4-double chunks per thread of an NP x NP copy by 3 wavefronts
   int* flag = (int*)(ubuf + 2 * UBUF);           // look-ahead hand-shake (see below)
   if (tid == 0) *flag = 0;
@@ -295,15 +295,17 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
 #define SVAE_TILE_LATE_OPERANDS 1
 #endif
   constexpr bool late_operands = SVAE_TILE_LATE_OPERANDS && WPC == 2;
+  constexpr bool lean_schur = WPC == 2 && WPR == 1;   // see the Schur step
   auto load_operands = [&](const double* pk) {
     if constexpr (schur_on) {
 #pragma unroll
       for (int kk = 0; kk < NB; ++kk) sA[kk] = *(const d4*)(pk + ((si * NB + kk) * 64 + lane) * 4);
 #pragma unroll
       for (int s2 = 0; s2 < SCOLS; ++s2) {
-        const int j = sj0 + s2 * WPR;
+        const int j = WPR == 1 ? (si + s2) % NB : sj0 + s2 * WPR;
         sC[s2] = d4{0.0, 0.0, 0.0, 0.0};
-        if (j < NB) sC[s2] = *(const d4*)(pk + NP * NP + ((si * NB + j) * 64 + lane) * 4);
+        if constexpr (lean_schur) continue;           // (requested one tile ahead inside the Schur step)
+        if (WPR == 1 ? s2 < sym_cnt(NB, si) : j < NB) sC[s2] = *(const d4*)(pk + NP * NP + ((si * NB + j) * 64 + lane) * 4);
       }
     }
     if constexpr (W > 0) {
@@ -435,7 +437,11 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
     // ---- hand-off to the backward half: X, P^-1 (row-major NP x NP), c --------------------------
     double* w = wsb + (long)t * WSTEP;
     {  // c = P^-1 h: four threads per row of the finished inverse
-      const int row = tid >> 2, part = tid & 3;
+      // (opaque thread index: the handful of LDS / global addresses below are recomputed every step instead of being
+      //  hoisted out of the time loop -- as loop-invariant registers they end up in scratch in the 256-register instance)
+      int tq = tid;
+      asm volatile("" : "+v"(tq));
+      const int row = tq >> 2, part = tq & 3;
       double cv = 0.0;
       if (row < NP) {
         const double* prow = M + row * LDM;
@@ -464,7 +470,49 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
     if (!last) {
       // ---- Schur step:  P' = -2 (J22 + J11') + diag(-2 node_J') - J12' X   (tile (si,j), j < NB);
       //                   h' = node_h' + J12' c ------------------------------------------------------
-      if constexpr (schur_on && sj0 < NB) {
+      if constexpr (schur_on && WPR == 1) {
+        // P' is symmetric: the wavefront of tile row si forms the tiles (si, (si + q) mod NB), q < CNT, and stores each
+        // also transposed at its mirror position (NB = 4: 3, 3, 2, 2 tiles instead of 4 each)
+        constexpr int CNT = sym_cnt(NB, si);
+        if constexpr (lean_schur) {
+          // two workgroups per CU: B fragments read where they are consumed and the C inputs requested one tile ahead
+          // (the other workgroup covers the latencies; the buffers below are ~90 registers the 256-register instance
+          // does not have: it kept the C inputs in scratch)
+          const double* pkc = packed + (long)(INHOMOG ? t : (next_last ? 1 : 0)) * (3 * NP * NP) + NP * NP
+                              + (si * NB * 64 + lane) * 4;
+          d4 cnx = *(const d4*)(pkc + si * 256);
+          static_for<0, CNT>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            constexpr int j = (si + q) % NB, jn = (si + q + 1) % NB;
+            d4 c = cnx;
+            if constexpr (q + 1 < CNT) cnx = *(const d4*)(pkc + jn * 256);
+#pragma unroll
+            for (int kk = 0; kk < NB; ++kk) c = mma16(sA[kk], ld_b(16 * kk, NB + j), c);
+            store_c(M, LDM, 16 * si, 16 * j, r16, kq, c);
+            if constexpr (j != si) store_ct(M, LDM, 16 * j, 16 * si, r16, kq, c);
+            __builtin_amdgcn_sched_barrier(0);     // (keeps the next tile's fragment reads from being hoisted above: spills)
+          });
+        } else {
+          d4 fb[NB];
+#pragma unroll
+          for (int kk = 0; kk < NB; ++kk) fb[kk] = ld_b(16 * kk, NB + si);
+          static_for<0, CNT>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            constexpr int j = (si + q) % NB, jn = (si + q + 1) % NB;
+            d4 fn[NB];
+#pragma unroll
+            for (int kk = 0; kk < NB; ++kk) fn[kk] = (q + 1 < CNT) ? ld_b(16 * kk, NB + jn) : fb[kk];
+            d4 c = sC[q];
+#pragma unroll
+            for (int kk = 0; kk < NB; ++kk) c = mma16(sA[kk], fb[kk], c);
+            SVAE_SGB(2, 4 * NB, 1, 0)
+            store_c(M, LDM, 16 * si, 16 * j, r16, kq, c);
+            if constexpr (j != si) store_ct(M, LDM, 16 * j, 16 * si, r16, kq, c);
+#pragma unroll
+            for (int kk = 0; kk < NB; ++kk) fb[kk] = fn[kk];
+          });
+        }
+      } else if constexpr (schur_on && sj0 < NB) {
         d4 fb[NB];
 #pragma unroll
         for (int kk = 0; kk < NB; ++kk) fb[kk] = ld_b(16 * kk, NB + sj0);
@@ -494,9 +542,11 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
         // sA[kk][kb] = (-J12')[16 si + r16][16 kk + 4 kb + kq]: each lane a quarter of its row's product with c, the
         // four DPP rows summed through the cross-lane network
         double s0 = 0.0, s1 = 0.0;
+        int kqx = kq;
+        asm volatile("" : "+v"(kqx));               // (as above: no loop-invariant address register)
 #pragma unroll
         for (int kk = 0; kk < NB; ++kk) {
-          const double* cp = M + (16 * kk + kq) * LDM + 2 * NP;
+          const double* cp = M + (16 * kk + kqx) * LDM + 2 * NP;
           s0 = __builtin_fma(sA[kk][0], cp[0], s0);
           s1 = __builtin_fma(sA[kk][1], cp[4 * LDM], s1);
           s0 = __builtin_fma(sA[kk][2], cp[8 * LDM], s0);

@@ -440,6 +440,38 @@ def test_tile_estep_halves_equal_the_whole(n, T, B):
                      *[t(x) for x in rand_node_potentials((2, 5, 4), rng)], half=1)
 
 
+@pytest.mark.parametrize("n,T,inhomog", [(16, 5, False), (32, 6, False), (48, 4, True), (64, 7, False), (64, 3, True), (40, 1, False)])
+def test_tile_estep_two_workgroups_per_cu_instances(n, T, inhomog):
+    """Batches of more than one workgroup per CU run other INSTANCES of the tile kernel (256 registers per lane, the
+    E-step as a forward-half and a backward-half launch): the same sequences must come out as in batches of 3, which
+    the tests above hold against the oracle and the compiled reference; a few are also checked against the oracle."""
+    from svae_amd.lds.lds_inference import natural_lds_estep_general
+    dev = torch.device("cuda:0")
+    B = torch.cuda.get_device_properties(dev).multi_processor_count + 37
+    rng = np.random.default_rng(31 * n + T)
+    init, pair = rand_lds_natparam(n, rng)
+    if inhomog:
+        J11, J12, J22, zp = (np.asarray(x, float) for x in pair)
+        w = 1.0 + 0.2 * rng.random(max(T - 1, 1))
+        pair = (J11[None] * w[:, None, None], J12[None] * w[:, None, None], J22[None] * w[:, None, None],
+                np.full(max(T - 1, 1), float(zp)))
+    node = rand_node_potentials((B, T, n), rng)
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev).contiguous()
+    nat = (tuple(t(x) for x in init), tuple(t(x) for x in pair))
+    nodes = tuple(t(x) for x in node)
+    big = natural_lds_estep_general(nat, nodes)
+    flat = lambda r: [r[0]] + [x for grp in r[1] for x in grp]
+    for b0 in (0, B - 3):
+        small = natural_lds_estep_general(nat, tuple(x[b0:b0 + 3].contiguous() for x in nodes))
+        for got, want in zip(flat(big), flat(small)):
+            assert _rel(got[b0:b0 + 3], want.cpu().numpy()) < 1e-12
+    for b in (1, B - 1):
+        want = lds_numpy.natural_lds_estep_general((init, pair), (node[0][b], node[1][b], np.zeros(T)))
+        lognorm, (Ei, Ep, En) = big
+        got = (lognorm[b], (tuple(x[b] for x in Ei), tuple(x[b] for x in Ep), tuple(x[b] for x in En)))
+        _check(got, want, 1e-7)
+
+
 def test_tile_training_step_repeats_on_one_plan():
     """A training step at 16 <= n <= 64 runs on three streams (E-step halves, VJP phase 0 early, Cholesky adjoint of the
     next range of steps next to phase 2): repeated on ONE plan -- each launch overwrites the hand-off the helper streams
