@@ -130,9 +130,10 @@ def test_non_positive_definite_is_reported():
         _run(init, pair, tuple(node), check=True)
 
 
-@pytest.mark.parametrize("B", [512, 4096])
+@pytest.mark.parametrize("B", [512, 777, 1100, 4096])
 def test_full_size_against_reference_and_properties(B):
-    """BASELINE configs 2/3: T=200, n=10, B = 512 (per GPU) / 4096 (whole job)."""
+    """BASELINE configs 2/3: T=200, n=10, B = 512 (per GPU) / 4096 (whole job); 777 / 1100: the kernel selections in
+    between (one wavefront per sequence without the smoother's second wavefront; row-per-chain from 1025)."""
     from svae_amd.lds.lds_inference import LDSEStepPlan, natural_lds_estep_general, reduce_stats
     from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials
     T, n = 200, 10
