@@ -160,4 +160,23 @@ __device__ __forceinline__ double row_sum16(double x) {
   return x;
 }
 
+// Sum over aligned groups of G = 4, 8 or 16 lanes with DPP lane permutations (quad_perm, row_half_mirror, row_mirror:
+// no LDS crossbar); result valid in every lane of the group.
+template <int CTRL>
+__device__ __forceinline__ double dpp_perm_f64(double x) {
+  const long long b = __builtin_bit_cast(long long, x);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
+template <int G>
+__device__ __forceinline__ double group_sum(double x) {
+  static_assert(G == 4 || G == 8 || G == 16, "group of 4, 8 or 16 lanes");
+  x += dpp_perm_f64<0xB1>(x);                        // quad_perm [1,0,3,2]
+  x += dpp_perm_f64<0x4E>(x);                        // quad_perm [2,3,0,1]
+  if constexpr (G >= 8) x += dpp_perm_f64<0x141>(x); // row_half_mirror
+  if constexpr (G == 16) x += dpp_perm_f64<0x140>(x);// row_mirror
+  return x;
+}
+
 }  // namespace svae

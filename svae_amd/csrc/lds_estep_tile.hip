@@ -436,30 +436,54 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
 
     // ---- hand-off to the backward half: X, P^-1 (row-major NP x NP), c --------------------------
     double* w = wsb + (long)t * WSTEP;
-    {  // c = P^-1 h: four threads per row of the finished inverse
-      // (opaque thread index: the handful of LDS / global addresses below are recomputed every step instead of being
-      //  hoisted out of the time loop -- as loop-invariant registers they end up in scratch in the 256-register instance)
-      int tq = tid;
-      asm volatile("" : "+v"(tq));
-      const int row = tq >> 2, part = tq & 3;
-      double cv = 0.0;
-      if (row < NP) {
-        const double* prow = M + row * LDM;
+    constexpr int TPR = NP / 4;                  // threads per row of the hand-off copy
+    if constexpr (TPR == 4 || TPR == 8 || TPR == 16) {
+      // c = P^-1 h rides on the copy: each thread multiplies the four entries of P^-1 it moves anyway with its four
+      // entries of h; the TPR threads of a row are one aligned lane group, summed with DPP permutations
+      const int col = (tid * 4) % NP;
+      const d4 hv4 = *(const d4*)(hvec + col);
+      for (int c4 = tid; c4 * 4 < NP * NP; c4 += 256) {
+        const int row = (c4 * 4) / NP;
+        const d4 pv = *(const d4*)(M + row * LDM + col);
+        *(d4*)(w + c4 * 4) = *(const d4*)(M + row * LDM + NP + col);
+        *(d4*)(w + NP * NP + c4 * 4) = pv;
+        double cv = pv[0] * hv4[0];
+        cv = __builtin_fma(pv[1], hv4[1], cv);
+        cv = __builtin_fma(pv[2], hv4[2], cv);
+        cv = __builtin_fma(pv[3], hv4[3], cv);
+        cv = group_sum<TPR>(cv);
+        if ((tid & (TPR - 1)) == 0) {
+          M[row * LDM + 2 * NP] = cv;
+          w[2 * NP * NP + row] = cv;
+          qacc = __builtin_fma(hvec[row], cv, qacc);          // h' P^-1 h
+        }
+      }
+    } else {
+      {  // c = P^-1 h: four threads per row of the finished inverse
+        // (opaque thread index: the handful of LDS / global addresses below are recomputed every step instead of being
+        //  hoisted out of the time loop -- as loop-invariant registers they end up in scratch in the 256-register instance)
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
+        const int row = tq >> 2, part = tq & 3;
+        double cv = 0.0;
+        if (row < NP) {
+          const double* prow = M + row * LDM;
 #pragma unroll
-        for (int cc = 0; cc < NP; cc += 4) cv = __builtin_fma(prow[cc + part], hvec[cc + part], cv);
+          for (int cc = 0; cc < NP; cc += 4) cv = __builtin_fma(prow[cc + part], hvec[cc + part], cv);
+        }
+        cv += __shfl_xor(cv, 1, 64);
+        cv += __shfl_xor(cv, 2, 64);
+        if (row < NP && part == 0) {
+          M[row * LDM + 2 * NP] = cv;
+          w[2 * NP * NP + row] = cv;
+          qacc = __builtin_fma(hvec[row], cv, qacc);          // h' P^-1 h
+        }
       }
-      cv += __shfl_xor(cv, 1, 64);
-      cv += __shfl_xor(cv, 2, 64);
-      if (row < NP && part == 0) {
-        M[row * LDM + 2 * NP] = cv;
-        w[2 * NP * NP + row] = cv;
-        qacc = __builtin_fma(hvec[row], cv, qacc);          // h' P^-1 h
+      for (int c4 = tid; c4 * 4 < NP * NP; c4 += 256) {
+        const int row = (c4 * 4) / NP, col = (c4 * 4) % NP;
+        *(d4*)(w + c4 * 4) = *(const d4*)(M + row * LDM + NP + col);
+        *(d4*)(w + NP * NP + c4 * 4) = *(const d4*)(M + row * LDM + col);
       }
-    }
-    for (int c4 = tid; c4 * 4 < NP * NP; c4 += 256) {
-      const int row = (c4 * 4) / NP, col = (c4 * 4) % NP;
-      *(d4*)(w + c4 * 4) = *(const d4*)(M + row * LDM + NP + col);
-      *(d4*)(w + NP * NP + c4 * 4) = *(const d4*)(M + row * LDM + col);
     }
     __syncthreads();
     TICK(6)
