@@ -34,11 +34,28 @@ __device__ __forceinline__ double rdiag(double p) {      // 1/p: v_rcp_f64 + two
   return __builtin_fma(r, e, r);
 }
 
+// 1/sqrt(p) to full fp64 accuracy without the library's sqrt + divide (their slow-path branches cost ~70 instructions
+// per pivot): v_rsq_f64 seed + two coupled Newton steps (cf. rsqrt_nr, dpp.hpp)
+__device__ __forceinline__ double rsq_nr(double p) {
+  double r = __builtin_amdgcn_rsq(p);
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const double pr = p * r;
+    const double e = __builtin_fma(-pr, r, 1.0);
+    const double h = __builtin_fma(0.375, e, 0.5);
+    r = __builtin_fma(r * e, h, r);
+  }
+  return r;
+}
+
 template <int NC>
 struct CholCfg {
   static constexpr int LD = NC + 1;
   static constexpr int PAN = NC * LD;
-  static constexpr int LDS_DOUBLES = 2 * PAN + 2 * NC + TV_MAX_S * NC;     // M panel | transposition panel | pivot column x2 | u_s
+  // ONE panel (mode 0: M row-major; mode 1: the transpositions): 33 KB at NC = 64, so that four one-wavefront workgroups
+  // share a CU, one per SIMD (through round 3 the round-2 layout of 76 KB was still requested: two per CU, half the
+  // SIMDs idle)
+  static constexpr int LDS_DOUBLES = PAN;
 };
 
 // lane `src` (compile-time after unrolling) of a wavefront-wide double, as a wave-uniform value: two v_readlane_b32
@@ -62,7 +79,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   constexpr int LD = Cfg::LD;
   extern __shared__ double sm[];
   double* panM = sm;                       // MODE 0: M (upper), row-major
-  double* pan2 = sm + Cfg::PAN;            // MODE 1: transpositions
+  double* pan2 = sm;                       // MODE 1: transpositions
   const long bt = (long)(blockIdx.x / tlen) * T + t0 + blockIdx.x % tlen;   // steps t0 .. t0 + tlen - 1 of every sequence
   const int c = threadIdx.x;               // lane = column
   const bool on = c < NC;
@@ -80,7 +97,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   for (int j = NC - 1; j >= 0; --j) {
     const double d = bcast_lane(A[j], j);
     bad = bad || !(d > 0.0);
-    const double r = 1.0 / sqrt(d);
+    const double r = rsq_nr(d);
     const double w = (c < j) ? -(A[j] * r) * r : ((c == j) ? r - 1.0 : 0.0);
 #pragma unroll
     for (int i = 0; i <= j; ++i) A[i] = __builtin_fma(bcast_lane(A[i], j), w, A[i]);   // (rows below the diagonal: unused)
@@ -93,14 +110,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       for (int i = 0; i < NC; ++i) panM[i * LD + c] = (i <= c) ? A[i] : 0.0;
     }
     __syncthreads();
-    const int i = c;
-    if (i < n)
-      for (int s_ = 0; s_ < S; ++s_) {
-        const double* ep = eps + (bt * S + s_) * n;
-        double v = 0.0;
-        for (int j = i; j < n; ++j) v = __builtin_fma(panM[i * LD + j], ep[j], v);
-        noise[(bt * S + s_) * n + i] = v;
+    // row c of M into the lane's registers, eps_s[j] as a wave-uniform operand from lane j's register: fully unrolled,
+    // no memory access inside the sums (the first version looped j = i .. n-1 over an LDS read and a global load of
+    // eps[j] each -- a serial chain of ~64 memory latencies per sample that took longer than the factorisation)
+    if (on) {
+#pragma unroll
+      for (int j = 0; j < NC; ++j) A[j] = panM[c * LD + j];
+    }
+    for (int s_ = 0; s_ < S; ++s_) {
+      const double ev = (c < n) ? eps[(bt * S + s_) * n + c] : 0.0;
+      double v0 = 0.0, v1 = 0.0;
+#pragma unroll
+      for (int j = 0; j < NC; j += 2) {
+        v0 = __builtin_fma(A[j], bcast_lane(ev, j), v0);
+        v1 = __builtin_fma(A[j + 1], bcast_lane(ev, j + 1), v1);
       }
+      if (c < n) noise[(bt * S + s_) * n + c] = v0 + v1;
+    }
   } else {
     // u_s = M' xbar_s (own column), then Phi(M' Mbar)[i][c] = sum_s u_s[i] eps_s[c] for i <= c (diagonal halved):
     // Mbar = triu(sum_s xbar_s eps_s') is never formed (its mask k <= j is implied by k <= i <= j)
