@@ -1,12 +1,13 @@
 // lds_chol_tile.hip -- the sampler's noise factor chol(P_t)^-T and its adjoint for latent dimension 16 <= n <= 64, one
 // wavefront per (sequence, step), on the hand-off of the LDS-tiled E-step kernel (svae_lds_tile_noise_f64: what
 // _natural_sample / _natural_sample_grad do with dpotrf / dtrtrs in the reference, cython_gaussian_grads.pxd:431-487).
-// Its own translation unit: the fully unrolled 64 x 64 loops take minutes to compile.
+// Blocked with 16 x 16 tiles: tile products on v_mfma_f64_16x16x4, tile factorisations on a DPP row.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
 
 #include "../../include/svae_hip.h"
+#include "dpp.hpp"
 #include "per_device.hpp"
 
 namespace svae {
@@ -16,24 +17,16 @@ constexpr int TV_MAX_S = 16;
 // ---- the sampler's noise factor and its adjoint, one wavefront per (sequence, step) ----------------------------------
 // The reference's noise map is noise_t = chol(P_t)^-T eps_t (cython_gaussian_grads.pxd:431-454).  From the hand-off
 // only P_t^-1 is at hand: chol(P_t)^-T is the unique UPPER-triangular M with P_t^-1 = M M' (positive diagonal), a
-// "UL" Cholesky factorisation computed from the last column backwards.
-//   MODE 0 (sampler):  noise[s] = M eps[s]
-//   MODE 1 (VJP):      pinv_bar += sym( M^-T Phi(M' Mbar) M^-1 ),  Mbar = triu(sum_s xbar_s eps_s'),
+// "UL" Cholesky factorisation.
+//   mode 0 (sampler):  noise[s] = M eps[s]
+//   mode 1 (VJP):      pinv_bar += sym( M^-T Phi(M' Mbar) M^-1 ),  Mbar = triu(sum_s xbar_s eps_s'),
 //                      Phi = upper triangle with the diagonal halved -- the Cholesky adjoint (Murray 2016) carried
 //                      over to the UL form by the index-reversal permutation.
-// Layout: lane c holds COLUMN c of the matrix being worked on in NC registers (NC = n rounded up to 16, identity
-// padding; every loop fully unrolled), so the factorisation and both triangular solves are register FMAs whose
-// second operand is a wave-uniform LDS read (the other column / the factor entry, at a compile-time offset); a
-// first version on LDS-resident matrices spent 240 .. 780 us per matrix in barriers, index divisions and LDS
-// latency against ~25 us of arithmetic.
-__device__ __forceinline__ double rdiag(double p) {      // 1/p: v_rcp_f64 + two Newton steps
-  double r = __builtin_amdgcn_rcp(p);
-  double e = __builtin_fma(-p, r, 1.0);
-  r = __builtin_fma(r, e, r);
-  e = __builtin_fma(-p, r, 1.0);
-  return __builtin_fma(r, e, r);
-}
-
+// History: round 2 worked on LDS-resident matrices (240 .. 780 us per matrix in barriers and LDS latency); round 3 first
+// held the matrix in registers, lane = column, every wave-uniform operand through a v_readlane pair (64 us per 64 x 64
+// factor, 137 us per adjoint: ~10 cycles per instruction, and minutes of compile time for the unrolled loops) -- at 256
+// sequences x 1000 steps that was 60 ms of a 98 ms training pass.  The blocked form below does the O(n^3) work on the
+// matrix cores.
 // 1/sqrt(p) to full fp64 accuracy without the library's sqrt + divide (their slow-path branches cost ~70 instructions
 // per pivot): v_rsq_f64 seed + two coupled Newton steps (cf. rsqrt_nr, dpp.hpp)
 __device__ __forceinline__ double rsq_nr(double p) {
@@ -48,16 +41,6 @@ __device__ __forceinline__ double rsq_nr(double p) {
   return r;
 }
 
-template <int NC>
-struct CholCfg {
-  static constexpr int LD = NC + 1;
-  static constexpr int PAN = NC * LD;
-  // ONE panel (mode 0: M row-major; mode 1: the transpositions): 33 KB at NC = 64, so that four one-wavefront workgroups
-  // share a CU, one per SIMD (through round 3 the round-2 layout of 76 KB was still requested: two per CU, half the
-  // SIMDs idle)
-  static constexpr int LDS_DOUBLES = PAN;
-};
-
 // lane `src` (compile-time after unrolling) of a wavefront-wide double, as a wave-uniform value: two v_readlane_b32
 // into SGPRs, which the consuming v_fma_f64 takes as a scalar operand -- no LDS round trip
 __device__ __forceinline__ double bcast_lane(double x, int src) {
@@ -66,122 +49,283 @@ __device__ __forceinline__ double bcast_lane(double x, int src) {
   return __hiloint2double(hi, lo);
 }
 
-// Round 3: every wave-uniform operand (an entry of another lane's column) comes from that lane's REGISTER through
-// v_readlane instead of from an LDS panel.  The round-2 form fed each FMA a wave-uniform LDS read; with the two
-// column arrays filling the register file nothing could be batched, and the kernel ran at ~60 cycles per multiply-add
-// (368 us per 64 x 64 matrix and wavefront).  The factorisation needs no LDS at all: the multiplier M[k][j] lane k
-// wants at pivot j is, by the symmetry the running Schur complement keeps, its OWN register j.
-template <int NC, int MODE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void tile_chol_kernel(int n, int S, int NP, int T, int t0, int tlen, const double* ws, const double* eps,
-                                                       const double* xbar, double* noise, double* pinv_bar,
-                                                       int32_t* info) {
-  using Cfg = CholCfg<NC>;
-  constexpr int LD = Cfg::LD;
+// ---- the blocked factorisation ------------------------------------------------------------------------------------------
+// Blocked with 16 x 16 tiles the factorisation of a 64 x 64 matrix is 16 tile products on v_mfma_f64_16x16x4 plus four
+// 16 x 16 tile factorisations on a DPP row (the elimination of the E-step's pivot tiles, lds_estep_tile.hip).
+// The UL factor of P^-1 (M upper triangular, P^-1 = M M') is the ordinary Cholesky factor of the index-reversed matrix:
+// with J the reversal, A~ = J P^-1 J = L L' and M = J L J -- so the kernel reverses on load and store and runs a plain
+// left-to-right blocked LL' in between, one wavefront per matrix, the matrix in a row-major LDS panel (row stride
+// == 2 mod 32 doubles: conflict-free fragment reads):
+//   per block column kb:  tile factor A~_kk = L_kk L_kk' (DPP row; also W = L_kk^-1),  panel L_ik = A~_ik W' (i > kb),
+//                         trailing update A~_ij -= L_ik L_jk' (kb < j <= i)
+//   then  noise~ = L eps~  with the row of L in the lane's registers and eps~_j through v_readlane.
+typedef double d4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ d4 mma16(const d4 a, const d4 b, d4 c) {
+  c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b[2], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b[3], c, 0, 0, 0);
+  return c;
+}
+// lane = 16 kq + r16.  frag_a: A operand of the row-major tile Tl at (row0, col0) == B operand of Tl';
+// frag_b: B operand of Tl == the C/D layout
+__device__ __forceinline__ d4 frag_a(const double* M, int ld, int row0, int col0, int r16, int kq) {
+  const double* p = M + (row0 + r16) * ld + col0 + kq;
+  return d4{p[0], p[4], p[8], p[12]};
+}
+__device__ __forceinline__ d4 frag_b(const double* M, int ld, int row0, int col0, int r16, int kq) {
+  const double* p = M + (row0 + kq) * ld + col0 + r16;
+  return d4{p[0], p[4 * ld], p[8 * ld], p[12 * ld]};
+}
+__device__ __forceinline__ void store_c(double* M, int ld, int row0, int col0, int r16, int kq, const d4 v) {
+  double* p = M + (row0 + kq) * ld + col0 + r16;
+  p[0] = v[0]; p[4 * ld] = v[1]; p[8 * ld] = v[2]; p[12 * ld] = v[3];
+}
+
+// 16 x 16 SPD tile (row-major at `tile`, row stride ld) -> its Cholesky factor L (lower, written back over the tile with
+// zeros above the diagonal) and W = L^-1 (lower, row stride ldw).  Lane r16 = column, one register per row, the four DPP
+// rows work redundantly.  Forward elimination A = Lu D Lu': row i > p gets row_i -= (A[i][p] / d_p) row_p with the
+// multiplier written into lane p, so that lanes c < i of row i end as (Lu^-1)[i][c]; L = Lu D^1/2 leaves column by
+// column (row p of the running Schur complement IS its column p), W = D^-1/2 Lu^-1 at the end.
+__device__ __forceinline__ void chol_tile_factor(double* tile, int ld, double* W, int ldw, int r16, int kq, bool& bad) {
+  double A[16];
+  static_for<0, 16>([&](auto r) { A[r] = tile[r * ld + r16]; });
+  dpp_fence(A);
+  double rs[16];
+  static_for<0, 16>([&](auto pc) {
+    constexpr int p = decltype(pc)::value;
+    const double pv = bcast_fenced<p>(A[p]);
+    bad = bad || !(pv > 0.0);
+    const double rq = rsq_nr(pv);
+    rs[p] = rq;
+    const double Ep = (r16 == p) ? 1.0 : 0.0;
+    const double r = __builtin_fma(Ep, 1.0 - pv, A[p]) * (rq * rq);      // lane p: 1 / d_p; lane c != p: A[p][c] / d_p
+    if (kq == 0) tile[r16 * ld + p] = (r16 >= p) ? A[p] * rq : 0.0;       // L[c][p] = A[p][c] / sqrt(d_p)
+    // row updates in groups of four: the lane-p clears first (compiler code), then the DPP multiply-accumulates
+    // (their DPP-read operand, the old row, was written at least four instructions earlier)
+    auto update = [&](auto i0, auto cnt) {
+      constexpr int I0 = decltype(i0)::value, C = decltype(cnt)::value;
+      double olds[C], accs[C];
+      static_for<0, C>([&](auto j) { olds[j] = A[I0 + j]; accs[j] = __builtin_fma(-olds[j], Ep, olds[j]); });
+      static_for<0, C>([&](auto j) { mac_bc<p, true, (C < 4)>(accs[j], olds[j], r); A[I0 + j] = accs[j]; });
+    };
+    constexpr int REM = 15 - p;
+    static_for<0, (REM + 3) / 4>([&](auto g) {
+      constexpr int i0 = p + 1 + 4 * decltype(g)::value;
+      constexpr int c = (16 - i0) < 4 ? (16 - i0) : 4;
+      update(std::integral_constant<int, i0>{}, std::integral_constant<int, c>{});
+    });
+  });
+  if (kq == 0) {
+    static_for<0, 16>([&](auto r) { W[r * ldw + r16] = r16 < r ? A[r] * rs[r] : (r16 == r ? rs[r] : 0.0); });
+  }
+}
+
+// Where W_kb = L_kk^-1 is kept.  KEEP = false: one 16 x 18 slot behind the panel (the caller does not need the inverses
+// afterwards).  KEEP = true: one slot per block -- for NB >= 3 in the strictly upper tiles of the panel, which nothing else
+// uses ((0,1) .. (0,NB-1), then (1,2)): the panel alone is 33.8 KB at n = 64, four one-wavefront workgroups per CU.
+template <int NB, bool KEEP>
+struct WSlots {
+  static constexpr int LD = 16 * NB + 2;
+  static constexpr bool in_panel = KEEP && NB >= 3;
+  static constexpr int ldw = in_panel ? LD : 18;
+  static constexpr int extra_doubles = in_panel ? 0 : (KEEP ? NB : 1) * 16 * 18;
+  static __device__ __forceinline__ double* at(double* Am, int kb) {
+    if (in_panel) return Am + 16 * (kb < NB - 1 ? 0 : 1) * LD + 16 * (kb < NB - 1 ? kb + 1 : 2);
+    return Am + 16 * NB * LD + (KEEP ? kb : 0) * 16 * 18;
+  }
+};
+
+// Loads A~ = J P^-1 J into the panel Am (NP x LD) and factors it in place: the lower tiles become L, W_kb goes to its slot.
+template <int NB, bool KEEP>
+__device__ __forceinline__ void load_and_factor(const double* P, int n, double* Am, int c, int r16, int kq, bool& bad) {
+  constexpr int NP = 16 * NB, LD = NP + 2;
+  using WS = WSlots<NB, KEEP>;
+  // A~[i][c] = P^-1[n-1-i][n-1-c]; identity on the padding (which stays the TRAILING block: it does not touch L)
+  if (c < NP) {
+    const int cs = c < n ? n - 1 - c : 0;
+#pragma unroll 16
+    for (int i = 0; i < NP; ++i) {
+      const double v = P[(long)(i < n ? n - 1 - i : 0) * NP + cs];
+      Am[i * LD + c] = (i < n && c < n) ? v : (i == c ? 1.0 : 0.0);
+    }
+  }
+  static_for<0, NB>([&](auto kc) {
+    constexpr int kb = decltype(kc)::value;
+    double* W = WS::at(Am, kb);
+    chol_tile_factor(Am + (16 * kb) * LD + 16 * kb, LD, W, WS::ldw, r16, kq, bad);
+    if constexpr (kb + 1 < NB) {
+      const d4 fw = frag_a(W, WS::ldw, 0, 0, r16, kq);                  // B operand of W'
+      static_for<kb + 1, NB>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const d4 l = mma16(frag_a(Am, LD, 16 * i, 16 * kb, r16, kq), fw, d4{0.0, 0.0, 0.0, 0.0});
+        store_c(Am, LD, 16 * i, 16 * kb, r16, kq, l);
+      });
+      static_for<kb + 1, NB>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const d4 nl = -frag_a(Am, LD, 16 * i, 16 * kb, r16, kq);
+        static_for<kb + 1, i + 1>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          const d4 u = mma16(nl, frag_a(Am, LD, 16 * j, 16 * kb, r16, kq), frag_b(Am, LD, 16 * i, 16 * j, r16, kq));
+          store_c(Am, LD, 16 * i, 16 * j, r16, kq, u);
+        });
+      });
+    }
+  });
+}
+
+template <int NB>
+__global__ __launch_bounds__(64) void tile_noise_mfma_kernel(int n, int S, int T, int t0, int tlen, const double* ws,
+                                                             const double* eps, double* noise, int32_t* info) {
+  constexpr int NP = 16 * NB, LD = NP + 2;
   extern __shared__ double sm[];
-  double* panM = sm;                       // MODE 0: M (upper), row-major
-  double* pan2 = sm;                       // MODE 1: transpositions
-  const long bt = (long)(blockIdx.x / tlen) * T + t0 + blockIdx.x % tlen;   // steps t0 .. t0 + tlen - 1 of every sequence
-  const int c = threadIdx.x;               // lane = column
-  const bool on = c < NC;
+  double* Am = sm;                 // NP x LD: A~, its lower tiles become L  (+ one 16 x 18 slot: W of the current block)
+  const long bt = (long)(blockIdx.x / tlen) * T + t0 + blockIdx.x % tlen;
+  const int c = threadIdx.x, r16 = c & 15, kq = c >> 4;
   const double* P = ws + bt * (2L * NP * NP + NP) + (long)NP * NP;
-  double A[NC];
-#pragma unroll
-  for (int i = 0; i < NC; ++i) A[i] = (on && i < n && c < n) ? P[(long)i * NP + (c < n ? c : 0)] : ((i == c) ? 1.0 : 0.0);
   bool bad = false;
-  // UL Cholesky, pivots NC-1 .. 0.  With d = A[j][j], r = 1 / sqrt(d):  column j becomes M[:, j] = a r, and every
-  // column k < j loses M[i][j] M[k][j] = a_ij (r^2 a_kj) in its rows i < j.  Both are ONE fma per row with the
-  // wave-uniform a_ij (lane j's register i) and a per-lane factor w: -(r^2 a_kj) for k < j -- a_kj read from the
-  // lane's own register j (the Schur complement is symmetric and its lower entries are kept up to date by the same
-  // updates) --, r - 1 for lane j itself (a + a (r - 1) = a r), 0 for the finished columns.
-#pragma unroll
-  for (int j = NC - 1; j >= 0; --j) {
-    const double d = bcast_lane(A[j], j);
-    bad = bad || !(d > 0.0);
-    const double r = rsq_nr(d);
-    const double w = (c < j) ? -(A[j] * r) * r : ((c == j) ? r - 1.0 : 0.0);
-#pragma unroll
-    for (int i = 0; i <= j; ++i) A[i] = __builtin_fma(bcast_lane(A[i], j), w, A[i]);   // (rows below the diagonal: unused)
-  }
+  load_and_factor<NB, false>(P, n, Am, c, r16, kq, bad);
   if (bad && c == 0) atomicMax(info, 1);
-  if constexpr (MODE == 0) {
-    // noise[s][i] = sum_{j >= i} M[i][j] eps[s][j]   (lane = row i: M through a row-major LDS panel)
-    if (on) {
+  // noise~ = L eps~: lane = row (the upper tiles of the panel still hold A~: masked), eps~_j = eps[n-1-j] from lane j
+  double Lr[NP];
+  const int cr = c < NP ? c : 0;
 #pragma unroll
-      for (int i = 0; i < NC; ++i) panM[i * LD + c] = (i <= c) ? A[i] : 0.0;
+  for (int j = 0; j < NP; ++j) { const double v = Am[cr * LD + j]; Lr[j] = (j <= (cr | 15)) ? v : 0.0; }
+  for (int s_ = 0; s_ < S; ++s_) {
+    const double ev = (c < n) ? eps[(bt * S + s_) * n + (n - 1 - c)] : 0.0;
+    double v0 = 0.0, v1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < NP; j += 2) {
+      v0 = __builtin_fma(Lr[j], bcast_lane(ev, j), v0);
+      v1 = __builtin_fma(Lr[j + 1], bcast_lane(ev, j + 1), v1);
     }
-    __syncthreads();
-    // row c of M into the lane's registers, eps_s[j] as a wave-uniform operand from lane j's register: fully unrolled,
-    // no memory access inside the sums (the first version looped j = i .. n-1 over an LDS read and a global load of
-    // eps[j] each -- a serial chain of ~64 memory latencies per sample that took longer than the factorisation)
-    if (on) {
-#pragma unroll
-      for (int j = 0; j < NC; ++j) A[j] = panM[c * LD + j];
-    }
-    for (int s_ = 0; s_ < S; ++s_) {
-      const double ev = (c < n) ? eps[(bt * S + s_) * n + c] : 0.0;
-      double v0 = 0.0, v1 = 0.0;
-#pragma unroll
-      for (int j = 0; j < NC; j += 2) {
-        v0 = __builtin_fma(A[j], bcast_lane(ev, j), v0);
-        v1 = __builtin_fma(A[j + 1], bcast_lane(ev, j + 1), v1);
-      }
-      if (c < n) noise[(bt * S + s_) * n + c] = v0 + v1;
-    }
-  } else {
-    // u_s = M' xbar_s (own column), then Phi(M' Mbar)[i][c] = sum_s u_s[i] eps_s[c] for i <= c (diagonal halved):
-    // Mbar = triu(sum_s xbar_s eps_s') is never formed (its mask k <= j is implied by k <= i <= j)
-    double K[NC];
-#pragma unroll
-    for (int i = 0; i < NC; ++i) K[i] = 0.0;
-    for (int s_ = 0; s_ < S; ++s_) {
-      const double* xb = xbar + (bt * S + s_) * n;
-      double v = 0.0;
-#pragma unroll
-      for (int k = 0; k < NC; ++k) v = __builtin_fma(A[k], (k <= c && k < n) ? xb[k < n ? k : 0] : 0.0, v);
-      const double ev = (c < n) ? eps[(bt * S + s_) * n + c] : 0.0;
-#pragma unroll
-      for (int i = 0; i < NC; ++i) K[i] = __builtin_fma(bcast_lane(v, i), ev, K[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < NC; ++i) K[i] = (i < c) ? K[i] : ((i == c) ? 0.5 * K[i] : 0.0);
-    // two passes of:  solve M' X = K column-wise (x_i = K_i / M[i][i];  K_r -= M[i][r] x_i for r > i), then
-    // transpose through LDS:  Q1 = M^-T Phi;  Q' = M^-T Q1'  (Q = Q1 M^-1).  (Written as a loop of two trips so
-    // that the unrolled body exists once and K stays in registers: as lambdas the array went to scratch memory.)
-    for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-      for (int i = 0; i < NC; ++i) {
-        const double x = K[i] * rdiag(bcast_lane(A[i], i));
-        K[i] = x;
-#pragma unroll
-        for (int r = i + 1; r < NC; ++r) K[r] = __builtin_fma(-bcast_lane(A[i], r), x, K[r]);
-      }
-      if (pass == 0) {
-        __syncthreads();
-        if (on) {
-#pragma unroll
-          for (int i = 0; i < NC; ++i) pan2[i * LD + c] = K[i];
-        }
-        __syncthreads();
-        if (on) {
-#pragma unroll
-          for (int i = 0; i < NC; ++i) K[i] = pan2[c * LD + i];
-        }
-      }
-    }
-    // pinv_bar += (Q + Q') / 2
-    __syncthreads();
-    if (on) {
-#pragma unroll
-      for (int i = 0; i < NC; ++i) pan2[i * LD + c] = K[i];
-    }
-    __syncthreads();
-    if (c < n) {
-      double* out = pinv_bar + bt * n * n;
-#pragma unroll
-      for (int i = 0; i < NC; ++i)
-        if (i < n) out[i * n + c] += 0.5 * (K[i] + pan2[c * LD + i]);
-    }
+    if (c < n) noise[(bt * S + s_) * n + (n - 1 - c)] = v0 + v1;
   }
+}
+
+
+// ---- mode 1: the adjoint, every O(n^3) stage a list of tile products with the intermediates in REGISTERS ----------------
+// In the reversed coordinates (L lower, x~_s = J xbar_s, e~_s = J eps_s) the cotangent is
+//     pinv_bar~ += 1/2 Linv' S Linv,   S = K + K',   K = Phi(L' Lbar) = [sum_s u_s e~_s']  (lower triangle, diagonal halved),
+//     u_s = L' x~_s,  Linv = L^-1.
+// What makes it LDS-free beyond the one panel: the MFMA C/D layout of a tile is the B-operand layout of the tile and the
+// A-operand layout of its TRANSPOSE -- so U' = X~' L (C layout) serves as A operand of U and B operand of U'; S is built
+// column by column directly in the layout the next product wants (S symmetric: A operand of S_ik = C layout of S_ki);
+// Y' = S Linv comes out as the A operand of Y = Linv' S, and Q = Y Linv finishes.  x~ and e~ are loaded from global
+// memory straight into operand fragments.  L^-1 overwrites L row by row (L Linv = I:  Linv_ij = -W_i sum_k L_ik Linv_kj).
+// Tile products at n = 64: 16 (factor) + 10 (U') + 16 (Linv) + 20 (S) + 40 (Y') + 40 (Q) = 142.
+template <int NB>
+__global__ __launch_bounds__(64) void tile_noise_adj_mfma_kernel(int n, int S, int T, int t0, int tlen, const double* ws,
+                                                                 const double* eps, const double* xbar, double* pinv_bar,
+                                                                 int32_t* info) {
+  constexpr int NP = 16 * NB, LD = NP + 2;
+  extern __shared__ double sm[];
+  double* Am = sm;                 // NP x LD: A~ -> L (lower tiles) -> Linv;  W_i = L_ii^-1 in their slots (WSlots)
+  using WS = WSlots<NB, true>;
+  const long bt = (long)(blockIdx.x / tlen) * T + t0 + blockIdx.x % tlen;
+  const int c = threadIdx.x, r16 = c & 15, kq = c >> 4;
+  const double* P = ws + bt * (2L * NP * NP + NP) + (long)NP * NP;
+  // operand fragments of x~ and e~ (requested before the factorisation, consumed after it):
+  //   xr[k][kb] = x~_{s = r16}[16 k + 4 kb + kq]      A operand of X~_k'  (X~_k: rows of block k x 16 samples)
+  //   er[j][kb] = e~_{s = 4 kb + kq}[16 j + r16]      A operand of E_j == B operand of E_j'
+  d4 xr[NB], er[NB];
+#pragma unroll
+  for (int k = 0; k < NB; ++k)
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const int rx = 16 * k + 4 * kb + kq, sx = r16;
+      const bool okx = sx < S && rx < n;
+      const double vx = xbar[(bt * S + (okx ? sx : 0)) * n + (okx ? n - 1 - rx : 0)];
+      xr[k][kb] = okx ? vx : 0.0;
+      const int re = 16 * k + r16, se = 4 * kb + kq;
+      const bool oke = se < S && re < n;
+      const double ve = eps[(bt * S + (oke ? se : 0)) * n + (oke ? n - 1 - re : 0)];
+      er[k][kb] = oke ? ve : 0.0;
+    }
+  bool bad = false;
+  load_and_factor<NB, true>(P, n, Am, c, r16, kq, bad);
+  if (bad && c == 0) atomicMax(info, 1);
+  const d4 z4 = {0.0, 0.0, 0.0, 0.0};
+  // U'_i = sum_{k >= i} X~_k' L_ki   (C layout: [sample][row of block i])
+  d4 ut[NB];
+  static_for<0, NB>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    d4 acc = z4;
+    static_for<i, NB>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      acc = mma16(xr[k], frag_b(Am, LD, 16 * k, 16 * i, r16, kq), acc);
+    });
+    ut[i] = acc;
+  });
+  // Linv over L, row by row
+  static_for<0, NB>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    d4 li[i > 0 ? i : 1];
+    const d4 fwa = frag_a(WS::at(Am, i), WS::ldw, 0, 0, r16, kq);
+    static_for<0, i>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      d4 r = z4;
+      static_for<j, i>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        r = mma16(frag_a(Am, LD, 16 * i, 16 * k, r16, kq), frag_b(Am, LD, 16 * k, 16 * j, r16, kq), r);
+      });
+      li[j] = mma16(fwa, -r, z4);
+    });
+    const d4 wd = frag_b(WS::at(Am, i), WS::ldw, 0, 0, r16, kq);
+    static_for<0, i>([&](auto jc) { store_c(Am, LD, 16 * i, 16 * decltype(jc)::value, r16, kq, li[decltype(jc)::value]); });
+    store_c(Am, LD, 16 * i, 16 * i, r16, kq, wd);
+  });
+  // Y' = S Linv, block row i at a time: column i of S (tiles S_ki, C layout) is the A operand of row i of S
+  d4 yt[NB][NB];
+  static_for<0, NB>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    d4 sc[NB];
+    static_for<0, NB>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      if constexpr (k > i) sc[k] = mma16(ut[k], er[i], z4);             // K_ki = U_k E_i'
+      else if constexpr (k < i) sc[k] = mma16(er[k], ut[i], z4);        // K_ik' = E_k U_i'
+      else {
+        const d4 g = mma16(ut[i], er[i], z4), gt = mma16(er[i], ut[i], z4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sc[k][q] = (4 * q + kq >= r16) ? g[q] : gt[q];     // lower + diagonal: G; upper: G'
+      }
+    });
+    static_for<0, NB>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      d4 acc = z4;
+      static_for<j, NB>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        acc = mma16(sc[k], frag_b(Am, LD, 16 * k, 16 * j, r16, kq), acc);
+      });
+      yt[i][j] = acc;
+    });
+  });
+  // Q = Y Linv (A operand of Y_ik = C layout of Y'_ki);  pinv_bar[n-1-row][n-1-col] += Q / 2
+  double* out = pinv_bar + bt * n * n;
+  static_for<0, NB>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    static_for<0, NB>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      // (the old values are requested unconditionally, at clamped addresses, in front of the tile's products: a load
+      //  inside the bounds check would be waited for element by element)
+      double prev[4];
+      int idx[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = 16 * i + 4 * q + kq, col = 16 * j + r16;
+        idx[q] = (row < n && col < n) ? (n - 1 - row) * n + (n - 1 - col) : -1;
+        prev[q] = out[idx[q] < 0 ? 0 : idx[q]];
+      }
+      d4 acc = z4;
+      static_for<j, NB>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        acc = mma16(yt[k][i], frag_b(Am, LD, 16 * k, 16 * j, r16, kq), acc);
+      });
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (idx[q] >= 0) out[idx[q]] = __builtin_fma(0.5, acc[q], prev[q]);
+    });
+  });
 }
 
 }  // namespace svae
@@ -210,21 +354,28 @@ extern "C" int svae_lds_tile_noise_f64(int mode, int B, int T, int n, int S, int
   double* pinv_bar = mode == 1 ? w + (size_t)BT * n * n : nullptr;
   const double* xbar = mode == 1 ? w + (size_t)BT * n * n * 2 + (size_t)B * (T > 1 ? T - 1 : 0) * n * n + (size_t)BT * n : nullptr;
   hipStream_t st = (hipStream_t)stream;
-  auto go = [&](auto nc, auto md) -> int {
-    constexpr int NC = decltype(nc)::value, MD = decltype(md)::value;
-    const size_t lds = (size_t)svae::CholCfg<NC>::LDS_DOUBLES * sizeof(double);
-    auto kern = svae::tile_chol_kernel<NC, MD>;
-    static svae::LdsGrant grant;            // (one per instantiation of this lambda, per device inside)
-    if (lds > 64 * 1024 && !grant.ensure(reinterpret_cast<const void*>(kern), (long)lds)) return -1001;
-    hipLaunchKernelGGL(kern, dim3((unsigned)((long)B * tlen)), dim3(64), lds, st, n, S, NP, T, t_begin, tlen,
-                       (const double*)handoff_workspace, eps, xbar,
-                       noise, pinv_bar, info);
+  auto go0 = [&](auto nb) -> int {        // mode 0: the blocked kernel
+    constexpr int NB = decltype(nb)::value;
+    const size_t lds = (size_t)(16 * NB * (16 * NB + 2) + svae::WSlots<NB, false>::extra_doubles) * sizeof(double);
+    hipLaunchKernelGGL(svae::tile_noise_mfma_kernel<NB>, dim3((unsigned)((long)B * tlen)), dim3(64), lds, st, n, S, T, t_begin,
+                       tlen, (const double*)handoff_workspace, eps, noise, info);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
   };
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-  if (NP == 16) return mode ? go(std::integral_constant<int, 16>{}, I1{}) : go(std::integral_constant<int, 16>{}, I0{});
-  if (NP == 32) return mode ? go(std::integral_constant<int, 32>{}, I1{}) : go(std::integral_constant<int, 32>{}, I0{});
-  if (NP == 48) return mode ? go(std::integral_constant<int, 48>{}, I1{}) : go(std::integral_constant<int, 48>{}, I0{});
-  return mode ? go(std::integral_constant<int, 64>{}, I1{}) : go(std::integral_constant<int, 64>{}, I0{});
+  if (mode == 0) {
+    if (NP == 16) return go0(std::integral_constant<int, 1>{});
+    if (NP == 32) return go0(std::integral_constant<int, 2>{});
+    if (NP == 48) return go0(std::integral_constant<int, 3>{});
+    return go0(std::integral_constant<int, 4>{});
+  }
+  auto go1 = [&](auto nb) -> int {        // mode 1
+    constexpr int NB = decltype(nb)::value;
+    const size_t lds = (size_t)(16 * NB * (16 * NB + 2) + svae::WSlots<NB, true>::extra_doubles) * sizeof(double);
+    hipLaunchKernelGGL(svae::tile_noise_adj_mfma_kernel<NB>, dim3((unsigned)((long)B * tlen)), dim3(64), lds, st, n, S, T,
+                       t_begin, tlen, (const double*)handoff_workspace, eps, xbar, pinv_bar, info);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+  };
+  if (NP == 16) return go1(std::integral_constant<int, 1>{});
+  if (NP == 32) return go1(std::integral_constant<int, 2>{});
+  if (NP == 48) return go1(std::integral_constant<int, 3>{});
+  return go1(std::integral_constant<int, 4>{});
 }
