@@ -376,10 +376,11 @@ def main():
                     extra.append({"workload": what, "error": repr(e)})
                 torch.cuda.empty_cache()
             # the other BASELINE configurations and the training path: measured beside `value`, never instead of it
-            # (order kept across rounds: [2] training path, [3] tile training, [4] SLDS, [5] GMM, [6] training path at 4096)
+            # (order kept across rounds: [2] training path, [3] tile training, [4] SLDS, [5] GMM, [6] training path at 4096,
+            #  [7] tile training at one workgroup per CU)
             for fn in (lambda: measure_training_path(dev, T, n, B), lambda: measure_tile_training(dev),
                        lambda: measure_slds(dev), lambda: measure_gmm(dev),
-                       lambda: measure_training_path(dev, T, n, 4096)):
+                       lambda: measure_training_path(dev, T, n, 4096), lambda: measure_tile_training(dev, B=256)):
                 try:
                     extra.append(fn())
                 except Exception as e:
