@@ -25,9 +25,10 @@
 extern "C" {
 #endif
 
-#define SVAE_HIP_ABI_VERSION 8   /* 8: step ranges (t_begin, t_end) in svae_lds_tile_vjp_f64 / svae_lds_tile_noise_f64, SVAE_OPT_TILE_FORWARD / _BACKWARD; 7: + svae_slds_path_nodeparams_f64, svae_slds_mix_pair_natparam_f64; 6: per-call `options` word replaces the process-global svae_lds_set_* selectors (re-entrant library), + svae_slds_hmm_meanfield_f64, svae_slds_sweep_glue_f64, g_E_pair in svae_lds_tile_vjp_f64; 5: + svae_lds_set_prod_max_b; 4: + svae_slds_lds_meanfield_f64, svae_gmm_mw_*, svae_lds_global_step_f64, svae_lds_natgrad_f64, svae_lds_tile_vjp_f64; 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
+#define SVAE_HIP_ABI_VERSION 9   /* 9: keep bit SVAE_KEEP_SIGMA of svae_lds_estep_f64 (16 <= n <= 64) + svae_lds_tile_sigma_offset_bytes; 8: step ranges (t_begin, t_end) in svae_lds_tile_vjp_f64 / svae_lds_tile_noise_f64, SVAE_OPT_TILE_FORWARD / _BACKWARD; 7: + svae_slds_path_nodeparams_f64, svae_slds_mix_pair_natparam_f64; 6: per-call `options` word replaces the process-global svae_lds_set_* selectors (re-entrant library), + svae_slds_hmm_meanfield_f64, svae_slds_sweep_glue_f64, g_E_pair in svae_lds_tile_vjp_f64; 5: + svae_lds_set_prod_max_b; 4: + svae_slds_lds_meanfield_f64, svae_gmm_mw_*, svae_lds_global_step_f64, svae_lds_natgrad_f64, svae_lds_tile_vjp_f64; 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
 #define SVAE_LDS_MAX_N 15   /* register/DPP path: one 16-lane row per sequence, n+1 <= 16 */
-#define SVAE_LDS_TILE_MAX_N 64   /* 16 <= n <= 64: LDS-tiled MFMA path (E-step only: keep must be 0) */
+#define SVAE_LDS_TILE_MAX_N 64   /* 16 <= n <= 64: LDS-tiled MFMA path (keep: SVAE_KEEP_SIGMA or 0) */
+#define SVAE_KEEP_SIGMA 4         /* keep bit of svae_lds_estep_f64, 16 <= n <= 64 only: see svae_lds_tile_sigma_offset_bytes */
 
 /* Library/ABI version (host only, no GPU needed). */
 int svae_hip_abi_version(void);
@@ -44,6 +45,13 @@ size_t svae_lds_workspace_bytes(int B, int T, int n);
  * (`inhomog`), one set per sequence when `pair_batched`.  Equal to svae_lds_workspace_bytes for
  * n <= SVAE_LDS_MAX_N. */
 size_t svae_lds_workspace_bytes_ex(int B, int T, int n, int inhomog, int pair_batched);
+/* 16 <= n <= 64, keep & SVAE_KEEP_SIGMA: the backward half of the E-step also leaves the smoothed covariances
+ * Sigma_t = Cov(x_t | y) as a compact (B,T,n,n) array at THIS byte offset of the workspace (svae_lds_workspace_bytes_ex
+ * rounded up to 256), which must then be at least offset + B T n n 8 bytes long.  That array is the first section of the
+ * workspace of svae_lds_tile_vjp_f64: a caller that lets its VJP workspace START at workspace + offset (one allocation
+ * of offset + 8 svae_lds_tile_vjp_workspace_doubles(..) bytes) skips phase 0 of the VJP, which would rebuild the same
+ * matrices from the hand-off.  0 for n <= 15. */
+size_t svae_lds_tile_sigma_offset_bytes(int B, int T, int n, int inhomog, int pair_batched);
 
 /* Batched LDS E-step = filter + RTS smoother + expected sufficient statistics + log-normalizer.
  *
@@ -62,7 +70,7 @@ size_t svae_lds_workspace_bytes_ex(int B, int T, int n, int inhomog, int pair_ba
  *          discrete-state marginals)
  *       keep: bit 0 = also write the factor region of the workspace so that svae_lds_sample_f64 can
  *         follow; bit 1 = also write the cross-moment region so that svae_lds_estep_vjp_f64 can
- *         follow (each costs a few % of the E-step)
+ *         follow (each costs a few % of the E-step); 16 <= n <= 64: SVAE_KEEP_SIGMA or 0
  *       node_J (B,T,n) diagonal of -1/2 precision, node_h (B,T,n), node_logZ (B,T) or NULL (=0)
  *  out: lognorm (B)
  *       E_init  (B, n*n + n)      = [E[x0 x0'] (n,n) | E[x0] (n)]   (the two trailing 1's of the

@@ -80,6 +80,8 @@ struct LdsArgs {
   // S4 launches of the two-ended kernel: the last `lds_keep` hand-off records of each chain (the ones the smoother
   // reads first) stay in LDS instead of travelling through HBM (0: all records through HBM)
   int lds_keep;
+  // tiled path (n > 15): smoothed covariances Sigma_t, compact (B,T,n,n), written by the backward half (nullptr: not kept)
+  double* __restrict__ sig_out;
   // tiled path (n > 15): 0 = whole E-step, 1 = forward half only, 2 = backward half only (SVAE_OPT_TILE_FORWARD / _BACKWARD)
   int tile_half;
 };

@@ -98,6 +98,11 @@ static size_t main_ws_doubles(int B, int T, int n) {
 static size_t factor_ws_doubles(int B, int T, int n) { return (size_t)B * T * (n * n + n); }
 static size_t cross_ws_doubles(int B, int T, int n) { return (size_t)B * T * (n + 1) * svae::ws_h_stride(n); }
 
+size_t svae_lds_tile_sigma_offset_bytes(int B, int T, int n, int inhomog, int pair_batched) {
+  if (n <= SVAE_LDS_MAX_N || n > SVAE_LDS_TILE_MAX_N) return 0;
+  return (svae_lds_workspace_bytes_ex(B, T, n, inhomog, pair_batched) + 255) / 256 * 256;
+}
+
 size_t svae_lds_workspace_bytes_ex(int B, int T, int n, int inhomog, int pair_batched) {
   if (B <= 0 || T <= 0 || n <= 0 || n > SVAE_LDS_TILE_MAX_N) return 0;
   if (n <= SVAE_LDS_MAX_N) return svae_lds_workspace_bytes(B, T, n);
@@ -122,7 +127,7 @@ int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int k
   if (B < 0) return -1;
   if (T < 1) return -2;
   if (n < 1 || n > SVAE_LDS_TILE_MAX_N) return -3;
-  if (n > SVAE_LDS_MAX_N && keep) return -23;   /* sampler / VJP hand-off: register path only */
+  if (n > SVAE_LDS_MAX_N ? (keep & ~SVAE_KEEP_SIGMA) != 0 : (keep & ~3) != 0) return -23;   /* factor / cross regions: register path; Sigma: tiled path */
   if (pair_batched && !inhomog) return -5;
   if (!init_J) return -6;
   if (!init_h) return -7;
@@ -158,8 +163,14 @@ int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int k
   a.pair_seq_stride = pair_batched ? (long)(T - 1) * n * n : 0;
   a.msg_Jp = a.msg_hp = a.msg_Jf = a.msg_hf = nullptr;
   a.mix_w = nullptr; a.mix_out = nullptr; a.seq_index = nullptr; a.mix_K = 0; a.lds_keep = 0;
+  a.sig_out = nullptr;
   if (n > SVAE_LDS_MAX_N) {
     a.ws2 = a.ws3 = nullptr;
+    if (keep & SVAE_KEEP_SIGMA) {
+      const size_t off = svae_lds_tile_sigma_offset_bytes(B, T, n, inhomog, pair_batched);
+      if (ws_bytes < off + (size_t)B * T * n * n * sizeof(double)) return -22;
+      a.sig_out = (double*)((char*)workspace + off);
+    }
     return svae_lds_launch_tile(&a, n, inhomog, stream);
   }
   const bool split = sel.split;
@@ -266,7 +277,7 @@ int svae_lds_filter_f64(int B, int T, int n, int inhomog, int pair_batched, unsi
   a.ws3 = nullptr;
   a.pair_seq_stride = pair_batched ? (long)(T - 1) * n * n : 0;
   a.msg_Jp = J_pred; a.msg_hp = h_pred; a.msg_Jf = J_filt; a.msg_hf = h_filt;
-  a.mix_w = nullptr; a.mix_out = nullptr; a.seq_index = nullptr; a.mix_K = 0; a.lds_keep = 0; a.tile_half = 0;
+  a.mix_w = nullptr; a.mix_out = nullptr; a.seq_index = nullptr; a.mix_K = 0; a.lds_keep = 0; a.tile_half = 0; a.sig_out = nullptr;
   // small batches without message outputs: one sequence per wavefront (0.62 -> 0.24 ms at B = 512, T = 200, n = 10).
   // The one-register filter (n <= 10) stays ahead of the packed kernel until ~3 wavefronts per SIMD (filter + sampler,
   // T = 500: 1024 sequences 0.86 vs 1.81 ms, 2048: 1.85 vs 2.53; T = 200, 4096: 1.43 vs 1.27)
@@ -337,7 +348,7 @@ int svae_slds_lds_meanfield_f64(int B, int rows, int T, int n, int K,
   a.info = info; a.ws = (double*)workspace; a.ws2 = nullptr; a.ws3 = nullptr;
   a.pair_seq_stride = 0;
   a.msg_Jp = a.msg_hp = a.msg_Jf = a.msg_hf = nullptr;
-  a.mix_w = weights; a.mix_out = pair_contr; a.seq_index = seq_index; a.mix_K = K; a.lds_keep = 0; a.tile_half = 0;
+  a.mix_w = weights; a.mix_out = pair_contr; a.seq_index = seq_index; a.mix_K = K; a.lds_keep = 0; a.tile_half = 0; a.sig_out = nullptr;
   switch (n) {
 #define SVAE_CASE_(NN) case NN: return svae_lds_launch_twoend_mix_n##NN(&a, stream);
 #define SVAE_CASE(NN) SVAE_CASE_(NN)

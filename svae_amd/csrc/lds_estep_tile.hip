@@ -684,6 +684,25 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
   if constexpr (!lean_bwd) prefetch_step(wsb + (long)(T - 1) * WSTEP);
   __syncthreads();
 
+  // SVAE_KEEP_SIGMA: Sigma_t, compact n x n, for the VJP (svae_lds_tile_sigma_offset_bytes): thread (ty, tx) moves columns
+  // 4 tx .. 4 tx + 3 of rows ty, ty + 16, ..  (32-byte stores when n is a multiple of 4)
+  auto store_sigma = [&](int ts) {
+    double* dst = a.sig_out + ((long)b * T + ts) * nn;
+    const int ty = tid >> 4, c0 = 4 * (tid & 15);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int r = ty + 16 * i;
+      if (r < n && c0 < n) {
+        const d4 v = *(const d4*)(M + r * LDM + c0);
+        if ((n & 3) == 0) {
+          *(d4*)(dst + (long)r * n + c0) = v;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (c0 + j < n) dst[(long)r * n + c0 + j] = v[j];
+        }
+      }
+    }
+  };
   // Like the forward half, instantiated per wavefront index (= tile column J of the wavefront).
   auto backward = [&](auto jc) {
   constexpr int J = decltype(jc)::value;
@@ -699,6 +718,7 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
     }
     if (tid < NP) hvec[tid] = cpre;
     __syncthreads();
+    if (a.sig_out && t + 1 < T) store_sigma(t + 1);     // (the panel's P columns hold Sigma_{t+1} until B2 of this step)
     if (t + 1 < T && tid < n) {          // node statistics of step t+1 (Sigma_{t+1} is complete now)
       const double mm = mold[tid];
       oEx[(long)(t + 1) * n + tid] = mm;
@@ -863,6 +883,7 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
   if (lane == 0 && wave < 2) { for (int q = 0; q < 12; ++q) a.E_init[(long)b * (nn + n) + 12 * wave + q] = (double)tm[q]; }
   return;
 #endif
+  if (a.sig_out) store_sigma(0);
   if (tid < n) {                          // node statistics of step 0, E[x_0]
     const double mm = mold[tid];
     oEx[tid] = mm;

@@ -93,10 +93,12 @@ class LDSEStepPlan(object):
         self.epoch = 0
 
     def launch(self, init_J, init_h, init_logZ, J11, J12, J22, logZ_pair, node_J, node_h,
-               node_logZ=None, pair_batched=False, keep_factor=False, keep_cross=False, half=0):
+               node_logZ=None, pair_batched=False, keep_factor=False, keep_cross=False, half=0, keep_sigma=False):
         """Raw launch on the current stream.  All arguments: contiguous float64 device tensors.
         half (16 <= n <= 64 only): 1 = the forward half of the E-step (filter, hand-off, lognorm), 2 = the backward half
-        (smoother + statistics from the hand-off of a preceding half=1 launch); 0 = both."""
+        (smoother + statistics from the hand-off of a preceding half=1 launch); 0 = both.
+        keep_sigma (16 <= n <= 64 only, after `vjp_tail`): the backward half leaves the smoothed covariances in the
+        first section of the VJP workspace behind the hand-off (SVAE_KEEP_SIGMA), which saves the VJP its phase 0."""
         p = _lib.ptr
         ev = getattr(self, "_side_event", None)
         if ev is not None:       # work on a helper stream still reads the hand-off this launch overwrites (lds_large.py)
@@ -104,7 +106,8 @@ class LDSEStepPlan(object):
             self._side_event = None
         keep = int(bool(keep_factor)) | (2 if keep_cross else 0)
         if self.n > _lib.LDS_MAX_N:
-            keep = 0       # tile kernel: its hand-off always serves the sampler / VJP kernels (lds_large.py)
+            # tile kernel: its hand-off always serves the sampler / VJP kernels (lds_large.py)
+            keep = _lib.KEEP_SIGMA if (keep_sigma and half != 1) else 0
         options = self.options
         if half:
             if self.n <= _lib.LDS_MAX_N:
@@ -123,6 +126,20 @@ class LDSEStepPlan(object):
         self.has_cross = bool(keep_cross) and self.n <= _lib.LDS_MAX_N
         self._J12 = J12
         self._pair_batched = bool(pair_batched)
+
+    def vjp_tail(self, S, pair_batched=False):
+        """16 <= n <= 64: the workspace of svae_lds_tile_vjp_f64 for S sample cotangents as a view BEHIND the hand-off in
+        the plan's own buffer (grown if necessary -- call it before the launch whose hand-off the VJP will read), at
+        svae_lds_tile_sigma_offset_bytes: where a launch with keep_sigma leaves the smoothed covariances."""
+        B, T, n = max(self.B, 1), self.T, self.n
+        off = int(self.lib.svae_lds_tile_sigma_offset_bytes(B, T, n, int(self.inhomog), int(bool(pair_batched)))) // 8
+        nws = int(self.lib.svae_lds_tile_vjp_workspace_doubles(B, T, n, S))
+        if off == 0:
+            raise ValueError("vjp_tail: latent dimension > %d only" % _lib.LDS_MAX_N)
+        if self.ws.numel() < off + nws:
+            self.ws = torch.empty(off + nws, dtype=torch.float64, device=self.device)
+            self.ws_bytes = self.ws.numel() * 8
+        return self.ws[off:off + nws]
 
     def filter(self, init_J, init_h, init_logZ, J11, J12, J22, logZ_pair, node_J, node_h,
                node_logZ=None, pair_batched=False, J_pred=None, h_pred=None, J_filt=None, h_filt=None):

@@ -18,10 +18,12 @@ csrc/lds_vjp_tile.hip:
     the cotangents, so the chunks beyond the first run as further VJPs with only their sample cotangents.
 
 Concurrency of a training step (one workgroup per sequence leaves most of the chip idle at the batch sizes these models
-run at): once the FORWARD half of the E-step has written the hand-off, its backward half (smoother + statistics), phase 0
-of the VJP and the noise factor + sampler recursion run side by side on three streams; in the backward pass the Cholesky
-adjoint and phase 2 are split into ranges of steps, the adjoint of the next range running next to phase 2 of the current
-one.  n = 64, T = 1000, 64 sequences: 88 -> 76 ms per pass with the backward pipeline, -> 69 ms with the forward one.
+run at): once the FORWARD half of the E-step has written the hand-off, its backward half (smoother + statistics) and the
+noise factor + sampler recursion run side by side on two streams; when a backward pass will follow, the backward half also
+leaves the smoothed covariances where the VJP wants them (LDSEStepPlan.vjp_tail / SVAE_KEEP_SIGMA), so that phase 0 is
+only launched by callers that bring a plain E-step launch (start_phase0 / vjp_from_handoff_hip without `phase0`).  In the
+backward pass the Cholesky adjoint and phase 2 are split into ranges of steps, the adjoint of the next range running next
+to phase 2 of the current one.
 
 Torch restatements of the same algebra (the CPU cross-check of the derivation) live in tests/_lds_large_torch.py.
 Everything here is float64 on the GPU; there is no CPU path and no library (rocBLAS / rocSOLVER) call.
@@ -123,7 +125,8 @@ def vjp_from_handoff_hip(plan, J12, pair_batched, ex, g_lognorm, g_dxx, g_x, sam
     """The VJP w.r.t. the node potentials on the device kernels (svae_lds_tile_vjp_f64: three phases, one workgroup
     per sequence, n x n state in LDS; the Cholesky adjoint of the sampler's noise factor -- parallel over all
     (sequence, step) pairs -- is svae_lds_tile_noise_f64 between phases 1 and 2).  Reads the hand-off of the plan's
-    last launch.  phase0: (workspace, event) of start_phase0 if phase 0 was started with the forward pass.
+    last launch.  phase0: (workspace, event) -- the smoothed covariances are (after `event`) in the first section of
+    `workspace`: from start_phase0, or from a forward pass launched with keep_sigma on LDSEStepPlan.vjp_tail.
     -> (g_node_J, g_node_h) (B,T,n)."""
     lib = _lib.load()
     B, T, n = plan.B, plan.T, plan.n
@@ -221,15 +224,19 @@ class LDSInferenceLarge(torch.autograd.Function):
             # Three consumers of the hand-off run side by side once the forward half of the E-step has written it: the
             # backward half (smoother + statistics), phase 0 of the VJP (a backward pass will follow), and the noise
             # factor + sampler recursion -- each one workgroup per sequence, or shorter than the smoother.
+            # (a backward pass will follow: the VJP workspace lives behind the hand-off in the plan's buffer, and the
+            #  backward half leaves the smoothed covariances in its first section -- phase 0 of the VJP, which would
+            #  rebuild them from the hand-off next to the backward half, is not launched at all)
+            vws = plan.vjp_tail(min(eps.shape[2], MAX_S) if eps is not None else 0, pair_batched) if needs_grad else None
             plan.launch(*args, half=1)
             main, side2 = _side_stream(plan.device, 1)
             side2.wait_stream(main)
             with torch.cuda.stream(side2):
-                plan.launch(*args, half=2)
+                plan.launch(*args, half=2, keep_sigma=needs_grad)
             smoothed = torch.cuda.Event()
             smoothed.record(side2)
             if needs_grad:
-                ctx.phase0 = start_phase0(plan, J12, pair_batched, min(eps.shape[2], MAX_S) if eps is not None else 0)
+                ctx.phase0 = (vws, smoothed)
         samples = sample_from_handoff(plan, eps) if eps is not None else \
             torch.zeros(0, dtype=torch.float64, device=plan.device)
         if eps is not None or needs_grad:

@@ -24,7 +24,7 @@ def test_header_declares_the_expected_entry_points():
               "svae_slds_lds_meanfield_lds_bytes", "svae_slds_lds_meanfield_workspace_bytes", "svae_gmm_mw_workspace_bytes", "svae_gmm_mw_begin",
               "svae_gmm_mw_step_f64", "svae_gmm_mw_kl_hist", "svae_gmm_mw_fixed_point_f64", "svae_lds_global_step_f64", "svae_lds_natgrad_f64", "svae_lds_tile_vjp_f64",
               "svae_lds_tile_vjp_workspace_doubles", "svae_lds_tile_sample_f64", "svae_lds_tile_noise_f64",
-              "svae_gmm_meanfield_f64", "svae_hip_abi_version"):
+              "svae_lds_tile_sigma_offset_bytes", "svae_gmm_meanfield_f64", "svae_hip_abi_version"):
         assert s in syms
 
 
@@ -116,6 +116,28 @@ def test_round3_entry_points_reject_bad_arguments_on_the_host():
     ip = C.cast(info, C.c_void_p)
     assert lib.svae_lds_tile_noise_f64(0, 1, 4, 16, 1, 2, 2, ptr, ptr, bp, None, ip, None) == -20
     assert lib.svae_lds_tile_noise_f64(0, 1, 4, 16, 1, 0, 5, ptr, ptr, bp, None, ip, None) == -20
+
+
+def test_keep_sigma_is_a_tile_path_bit_with_its_own_workspace_section():
+    """SVAE_KEEP_SIGMA (ABI 9): accepted for 16 <= n <= 64 only, and only with room for the (B,T,n,n) section at
+    svae_lds_tile_sigma_offset_bytes; the register path's keep bits stay 0..3."""
+    import ctypes as C
+    from svae_amd import _lib
+    lib = _lib.load()
+    assert lib.svae_lds_tile_sigma_offset_bytes(3, 5, 10, 0, 0) == 0
+    base = lib.svae_lds_workspace_bytes_ex(3, 5, 40, 0, 0)
+    off = lib.svae_lds_tile_sigma_offset_bytes(3, 5, 40, 0, 0)
+    assert off >= base and off % 256 == 0 and off - base < 256
+    buf = (C.c_double * 64)()
+    ptr = C.cast(buf, C.c_void_p)
+    info = (C.c_int32 * 1)()
+    ip = C.cast(info, C.c_void_p)
+
+    def estep(n, keep, ws_bytes):
+        return lib.svae_lds_estep_f64(3, 5, n, 0, 0, keep, 0, *([ptr] * 10), *([ptr] * 5), ip, ptr, ws_bytes, None)
+    assert estep(10, _lib.KEEP_SIGMA, 1 << 40) == -23          # register path: bits 0 and 1 only
+    assert estep(40, 1, 1 << 40) == -23                        # tile path: SVAE_KEEP_SIGMA only
+    assert estep(40, _lib.KEEP_SIGMA, off + 3 * 5 * 40 * 40 * 8 - 8) == -22      # no room for the section
 
 
 def test_contradictory_or_unknown_options_are_rejected():

@@ -472,6 +472,35 @@ def test_tile_estep_two_workgroups_per_cu_instances(n, T, inhomog):
         _check(got, want, 1e-7)
 
 
+@pytest.mark.parametrize("n,T,B", [(24, 9, 3), (33, 6, 2), (64, 12, 2), (16, 1, 2)])
+def test_backward_half_leaves_the_smoothed_covariances_of_phase0(n, T, B):
+    """SVAE_KEEP_SIGMA: the (B,T,n,n) section the E-step's backward half writes behind the hand-off (LDSEStepPlan.vjp_tail)
+    holds what phase 0 of the VJP rebuilds from the hand-off -- the same recursion in another kernel."""
+    from svae_amd.lds.lds_inference import LDSEStepPlan
+    from svae_amd.lds.lds_large import start_phase0
+    rng = np.random.default_rng(9 * n + T)
+    (J0, h0, z0), (J11, J12, J22, zp) = rand_lds_natparam(n, rng)
+    nJ, nh = rand_node_potentials((B, T, n), rng)
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev).contiguous()
+    args = [t(x) for x in (J0, h0, z0, J11, J12, J22, zp, nJ, nh)]
+    plan = LDSEStepPlan(B, T, n, dev)
+    tail = plan.vjp_tail(2)
+    tail.fill_(float("nan"))
+    plan.launch(*args, half=1)
+    plan.launch(*args, half=2, keep_sigma=True)
+    kept = tail[:B * T * n * n].clone().reshape(B, T, n, n)
+    ws0, ev = start_phase0(plan, args[4], False, 2)
+    torch.cuda.current_stream(dev).wait_event(ev)
+    torch.cuda.synchronize()
+    want = ws0[:B * T * n * n].reshape(B, T, n, n)
+    assert torch.isfinite(kept).all()
+    assert float((kept - want).abs().max()) <= 1e-11 * float(want.abs().max())
+    # ... and they are the smoothed covariances: diag Sigma_t = E[x_t^2] - E[x_t]^2
+    var = plan.E_node_diagxx - plan.E_node_x ** 2
+    assert float((torch.diagonal(kept, dim1=2, dim2=3) - var).abs().max()) <= 1e-9 * float(var.abs().max())
+
+
 def test_tile_training_step_repeats_on_one_plan():
     """A training step at 16 <= n <= 64 runs on three streams (E-step halves, VJP phase 0 early, Cholesky adjoint of the
     next range of steps next to phase 2): repeated on ONE plan -- each launch overwrites the hand-off the helper streams
