@@ -472,12 +472,15 @@ def test_tile_estep_two_workgroups_per_cu_instances(n, T, inhomog):
         _check(got, want, 1e-7)
 
 
-@pytest.mark.parametrize("n,T,B", [(24, 9, 3), (33, 6, 2), (64, 12, 2), (16, 1, 2)])
+@pytest.mark.parametrize("n,T,B", [(24, 9, 3), (33, 6, 2), (64, 12, 2), (16, 1, 2), (64, 4, -5), (40, 3, -2)])
 def test_backward_half_leaves_the_smoothed_covariances_of_phase0(n, T, B):
     """SVAE_KEEP_SIGMA: the (B,T,n,n) section the E-step's backward half writes behind the hand-off (LDSEStepPlan.vjp_tail)
-    holds what phase 0 of the VJP rebuilds from the hand-off -- the same recursion in another kernel."""
+    holds what phase 0 of the VJP rebuilds from the hand-off -- the same recursion in another kernel.  (B < 0: that many
+    sequences MORE than the chip has CUs -- the two-workgroups-per-CU instance of the backward half.)"""
     from svae_amd.lds.lds_inference import LDSEStepPlan
     from svae_amd.lds.lds_large import start_phase0
+    if B < 0:
+        B = torch.cuda.get_device_properties(0).multi_processor_count - B
     rng = np.random.default_rng(9 * n + T)
     (J0, h0, z0), (J11, J12, J22, zp) = rand_lds_natparam(n, rng)
     nJ, nh = rand_node_potentials((B, T, n), rng)
