@@ -67,10 +67,10 @@ def test_estep_kernel_isa_has_no_dpp_hazards(n, tmp_path):
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 @pytest.mark.parametrize("unit,n,min_dpp", [("lds_vjp_n.hip", 10, 3000), ("lds_estep_tile.hip", None, 2000),
-                                           ("hmm_estep.hip", None, 200)])
+                                           ("hmm_estep.hip", None, 200), ("lds_chol_tile.hip", None, 2000)])
 def test_other_dpp_units_have_no_hazards(unit, n, min_dpp, tmp_path):
-    """The VJP sweeps (one fence per product stage), the pivot-tile factorisation of the tiled path
-    and the HMM kernel use the same inline-asm DPP forms: same audit."""
+    """The VJP sweeps (one fence per product stage), the pivot-tile factorisation of the tiled path, the HMM kernel
+    and the tile factorisations of the blocked Cholesky kernels use the same inline-asm DPP forms: same audit."""
     out = tmp_path / (unit + ".s")
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S",
            os.path.join(ROOT, "svae_amd/csrc", unit), "-o", str(out)]
