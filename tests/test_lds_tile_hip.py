@@ -368,7 +368,8 @@ def test_tile_training_step_at_latent_dim_32():
 
 @pytest.mark.parametrize("n,T,B,S,mode", [(16, 7, 3, 2, "homog"), (20, 5, 2, 0, "homog"), (33, 6, 2, 3, "inhomog"),
                                           (64, 5, 2, 1, "batched"), (48, 1, 2, 1, "homog"), (64, 40, 3, 2, "homog"),
-                                          (24, 6, 2, 19, "inhomog"), (16, 2, 2, 0, "batched")])
+                                          (24, 6, 2, 19, "inhomog"), (16, 2, 2, 0, "batched"), (48, 5, 2, 16, "batched"),
+                                          (40, 130, 2, 2, "homog")])
 def test_tile_vjp_kernels_match_the_torch_adjoint(n, T, B, S, mode):
     """svae_lds_tile_vjp_f64 (three phases, one workgroup per sequence) against the same adjoint written as
     batched torch products (tests/_lds_large_torch.py: vjp_from_handoff, itself checked against autograd on the CPU),
