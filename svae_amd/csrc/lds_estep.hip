@@ -58,6 +58,13 @@ __global__ __launch_bounds__(256) void lds_reduce_stats_kernel(int B, int n, con
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
   if (j < tot) {
     int b = ch;
+    for (; b + 31 * 32 < B; b += 32 * 32) {       // (large batches: 32 requests in flight)
+      double v[32];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) v[u] = src[(long)(b + 32 * u) * stride];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) acc[u & 3] += v[u];
+    }
     for (; b + 15 * 32 < B; b += 16 * 32) {
       double v[16];
 #pragma unroll
