@@ -103,6 +103,14 @@ __device__ __forceinline__ void store_ct(double* M, int ld, int row0, int col0, 
 // Symmetric NB x NB tile grid, every unordered pair {i, j} formed once: column j takes the rows (j + q) mod NB,
 // q < sym_cnt(NB, j)
 constexpr int sym_cnt(int NB, int j) { return (NB % 2 == 0 && j >= NB / 2) ? NB / 2 : NB / 2 + 1; }
+// The Schur stage's variant of the same idea (NB >= 3, one wavefront per tile row): wavefront 0 forms ONLY tile (0, 0) --
+// it factors that tile, the first pivot of the next step, while the others are still busy -- and tile row i >= 1 takes
+// (i, i), its share of the pairs among the rows 1 .. NB-1 (the cyclic assignment on that sub-grid) and (i, 0):
+// NB = 4 -> 1, 3, 3, 3 tiles;  schur_col(NB, i, s) = tile column of the s-th tile of row i.
+constexpr int schur_cnt(int NB, int i) { return i == 0 ? 1 : sym_cnt(NB - 1, i - 1) + 1; }
+constexpr int schur_col(int NB, int i, int s) {
+  return i == 0 ? 0 : (s < sym_cnt(NB - 1, i - 1) ? 1 + (i - 1 + s) % (NB - 1) : 0);
+}
 
 template <int NB>
 struct TileCfg {
@@ -255,7 +263,7 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
   // Schur product: tile row si per wavefront (WPR wavefronts share a row when NB <= 2), tile columns
   // sj0, sj0 + WPR, ... < NB; the wavefront with sj0 == WPR - 1 also forms the row's share of J12' c
   constexpr int WPR = NB <= 2 ? 4 / NB : 1;
-  constexpr int SCOLS = WPR == 1 ? NB / 2 + 1 : (NB + WPR - 1) / WPR;   // (WPR == 1: symmetric tile pairs once, see the Schur step)
+  constexpr int SCOLS = WPR == 1 ? (NB - 1) / 2 + 2 : (NB + WPR - 1) / WPR;   // (WPR == 1: symmetric tile pairs once, see the Schur step)
   constexpr int RL4 = (NP * NP / 4 + 191) / 192; // 4-double chunks per thread of an NP x NP copy by 3 wavefronts
   int* flag = (int*)(ubuf + 2 * UBUF);           // look-ahead hand-shake (see below)
   if (tid == 0) *flag = 0;
@@ -302,10 +310,10 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
       for (int kk = 0; kk < NB; ++kk) sA[kk] = *(const d4*)(pk + ((si * NB + kk) * 64 + lane) * 4);
 #pragma unroll
       for (int s2 = 0; s2 < SCOLS; ++s2) {
-        const int j = WPR == 1 ? (si + s2) % NB : sj0 + s2 * WPR;
+        const int j = WPR == 1 ? schur_col(NB, si, s2) : sj0 + s2 * WPR;
         sC[s2] = d4{0.0, 0.0, 0.0, 0.0};
         if constexpr (lean_schur) continue;           // (requested one tile ahead inside the Schur step)
-        if (WPR == 1 ? s2 < sym_cnt(NB, si) : j < NB) sC[s2] = *(const d4*)(pk + NP * NP + ((si * NB + j) * 64 + lane) * 4);
+        if (WPR == 1 ? s2 < schur_cnt(NB, si) : j < NB) sC[s2] = *(const d4*)(pk + NP * NP + ((si * NB + j) * 64 + lane) * 4);
       }
     }
     if constexpr (W > 0) {
@@ -322,7 +330,7 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
     const bool last = (t == T - 1);
     const bool next_last = (t + 1 == T - 1);
     TICK(0)
-    double njn = 0.0, nhn = 0.0;
+    double njn = 0.0, nhn = 0.0, njd = 0.0;
     // ---- in-place block Gauss-Jordan with look-ahead -----------------------------------------------
     // Per block pivot k:  (P1) all wavefronts scale the pivot row with U_k;  (P2) wavefronts 1..3 own
     // the other tile rows (eliminate, then rewrite their pivot-column tile) while wavefront 0 updates
@@ -374,6 +382,10 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
         if constexpr (h_on) {
           const int row = 16 * si + r16;
           nhn = nodeh[tn + (row < n ? row : n - 1)];
+        }
+        if constexpr (schur_on && WPR == 1) {      // the node diagonal of this wavefront's diagonal tile (added in registers)
+          const int row = 16 * si + r16;
+          njd = nodeJ[tn + (row < n ? row : n - 1)];
         }
       }
       auto inverse_tile = [&]() {   // A[k][k] <- A_kk^-1 = U' D^-1 U
@@ -495,23 +507,31 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
       // ---- Schur step:  P' = -2 (J22 + J11') + diag(-2 node_J') - J12' X   (tile (si,j), j < NB);
       //                   h' = node_h' + J12' c ------------------------------------------------------
       if constexpr (schur_on && WPR == 1) {
-        // P' is symmetric: the wavefront of tile row si forms the tiles (si, (si + q) mod NB), q < CNT, and stores each
-        // also transposed at its mirror position (NB = 4: 3, 3, 2, 2 tiles instead of 4 each)
-        constexpr int CNT = sym_cnt(NB, si);
+        // P' is symmetric: each mirror pair of tiles is formed once and stored at both positions (the mirror image
+        // transposed); the assignment (schur_col: NB = 4 -> 1, 3, 3, 3 tiles instead of 4 each) leaves wavefront 0 time to
+        // factor tile (0, 0) -- the next step's first pivot tile -- BEFORE the barrier instead of behind it, where the
+        // other three waited for it (3.5 k cycles per step).  The node diagonal goes onto the diagonal tile in registers.
+        constexpr int CNT = schur_cnt(NB, si);
+        const double njd2 = (16 * si + r16 < n) ? 2.0 * njd : 0.0;
+        auto add_diag = [&](d4& c) {
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) c[qq] -= (4 * qq + kq == r16) ? njd2 : 0.0;
+        };
         if constexpr (lean_schur) {
           // two workgroups per CU: B fragments read where they are consumed and the C inputs requested one tile ahead
           // (the other workgroup covers the latencies; the buffers below are ~90 registers the 256-register instance
           // does not have: it kept the C inputs in scratch)
           const double* pkc = packed + (long)(INHOMOG ? t : (next_last ? 1 : 0)) * (3 * NP * NP) + NP * NP
                               + (si * NB * 64 + lane) * 4;
-          d4 cnx = *(const d4*)(pkc + si * 256);
+          d4 cnx = *(const d4*)(pkc + schur_col(NB, si, 0) * 256);
           static_for<0, CNT>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
-            constexpr int j = (si + q) % NB, jn = (si + q + 1) % NB;
+            constexpr int j = schur_col(NB, si, q), jn = schur_col(NB, si, q + 1 < CNT ? q + 1 : q);
             d4 c = cnx;
             if constexpr (q + 1 < CNT) cnx = *(const d4*)(pkc + jn * 256);
 #pragma unroll
             for (int kk = 0; kk < NB; ++kk) c = mma16(sA[kk], ld_b(16 * kk, NB + j), c);
+            if constexpr (j == si) add_diag(c);
             store_c(M, LDM, 16 * si, 16 * j, r16, kq, c);
             if constexpr (j != si) store_ct(M, LDM, 16 * j, 16 * si, r16, kq, c);
             __builtin_amdgcn_sched_barrier(0);     // (keeps the next tile's fragment reads from being hoisted above: spills)
@@ -519,10 +539,10 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
         } else {
           d4 fb[NB];
 #pragma unroll
-          for (int kk = 0; kk < NB; ++kk) fb[kk] = ld_b(16 * kk, NB + si);
+          for (int kk = 0; kk < NB; ++kk) fb[kk] = ld_b(16 * kk, NB + schur_col(NB, si, 0));
           static_for<0, CNT>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
-            constexpr int j = (si + q) % NB, jn = (si + q + 1) % NB;
+            constexpr int j = schur_col(NB, si, q), jn = schur_col(NB, si, q + 1 < CNT ? q + 1 : q);
             d4 fn[NB];
 #pragma unroll
             for (int kk = 0; kk < NB; ++kk) fn[kk] = (q + 1 < CNT) ? ld_b(16 * kk, NB + jn) : fb[kk];
@@ -530,6 +550,7 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
 #pragma unroll
             for (int kk = 0; kk < NB; ++kk) c = mma16(sA[kk], fb[kk], c);
             SVAE_SGB(2, 4 * NB, 1, 0)
+            if constexpr (j == si) add_diag(c);
             store_c(M, LDM, 16 * si, 16 * j, r16, kq, c);
             if constexpr (j != si) store_ct(M, LDM, 16 * j, 16 * si, r16, kq, c);
 #pragma unroll
@@ -582,13 +603,18 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
         const int row = 16 * si + r16;
         if (kq == 0) mv0[row] = row < n ? nhn - sh : 0.0;     // sh = -(J12' c_t)[row]
       }
+      // (one wavefront per tile row: wavefront 0 has formed only tile (0, 0), node diagonal included, and factors it
+      //  now -- nothing else reads that tile or the factor buffer of pivot 0 in this stage)
+      if constexpr (W == 0 && WPR == 1) factor_pivot_tile(M, LDM, ubuf, LDU, ubuf + 16 * LDU, r16, kq, pmin, ldM, ldE);
       __syncthreads();
       TICK(7)
-      // ---- next step: wavefront 0 adds the node diagonal and factors the first pivot tile while
-      //      wavefronts 1..3 write the right-hand sides -------------------------------------------------
+      // ---- next step: wavefronts 1..3 write the right-hand sides (latent dimension <= 32, several wavefronts per tile
+      //      row: wavefront 0 adds the node diagonal and factors the first pivot tile here) ------------------------------
       if constexpr (W == 0) {
-        if (tid < n) M[tid * LDM + tid] -= 2.0 * njn;
-        factor_pivot_tile(M, LDM, ubuf, LDU, ubuf + 16 * LDU, r16, kq, pmin, ldM, ldE);
+        if constexpr (WPR > 1) {
+          if (tid < n) M[tid * LDM + tid] -= 2.0 * njn;
+          factor_pivot_tile(M, LDM, ubuf, LDU, ubuf + 16 * LDU, r16, kq, pmin, ldM, ldE);
+        }
       } else {
         const int t3 = tid - 64;
 #pragma unroll
