@@ -23,6 +23,7 @@
 #include <type_traits>
 
 #include "../../include/svae_hip.h"
+#include "dpp.hpp"
 #include "per_device.hpp"
 
 namespace svae {
@@ -742,88 +743,77 @@ __global__ __launch_bounds__(256) void tile_vjp_phase2(const TileVjpArgs a) {
 // One workgroup per sequence, G_t staged in LDS, S <= 16 samples.
 __global__ __launch_bounds__(256) void tile_sample_kernel(int T, int n, int S, int NP, const double* ws,
                                                           const double* noise, double* samples) {
-  extern __shared__ double sm[];
-  double* Gs = sm;                       // n x (n + 1)
-  double* xn = sm + 64 * 65;             // S x 64: x_{t+1}
-  double* part = xn + TV_MAX_S * 64;     // S x 256: partial sums of G_t x_{t+1}, one per (sample, wavefront, row)
-  const int b = blockIdx.x, ld = n + 1;
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane < n ? lane : 0;
-  // G_t of the NEXT step travels through registers (16 entries per thread: rows ty + 16 i, columns 4 tx ..) while the
-  // current step computes from LDS: the 32 KB tile comes from HBM, further away than one matrix-vector product.
-  // Every request is unconditional (clamped): a load inside a branch is waited for at its end.
-  const int ty = threadIdx.x >> 4, c0 = 4 * (threadIdx.x & 15);
-  double pre[4][4];
-  auto fetch = [&](int t) {
-    const double* h = ws + ((long)b * T + t) * (2L * NP * NP + NP);
+  // Four threads per row of G_t: thread (row, part) = (tid >> 2, tid & 3) holds the row's columns 16 part .. 16 part + 15
+  // in registers, requested one step ahead straight from the hand-off (NP-padded with zeros: no masking of columns up to
+  // NP); x_{t+1} of the S samples sits in 512-byte LDS vectors, double-buffered -- ONE barrier per step, no staging of
+  // the matrix.  (The first version staged G_t through LDS behind sixteen per-element branches and took three barriers
+  // per step: 1.6 us per step; it also competed for LDS with the E-step's backward half it runs next to.)
+  __shared__ double xs[2][TV_MAX_S * 64];
+  const int b = blockIdx.x, tid = threadIdx.x, row = tid >> 2, part = tid & 3;
+  const bool rv = row < n;
+  const int rc = rv ? row : 0;
+  const long WS = 2L * NP * NP + NP, SN = (long)S * n;
+  for (int e = tid; e < 2 * TV_MAX_S * 64; e += 256) (&xs[0][0])[e] = 0.0;      // x_T := 0; rows >= n stay 0
+  int coff[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = ty + 16 * i;
-      // (raw, 32 bytes per request -- the hand-off rows are NP-padded: stage() stores the valid entries only)
-      const d4 q = *(const d4*)(h + (long)(r < n ? r : 0) * NP + (c0 < NP ? c0 : 0));
+  for (int v = 0; v < 4; ++v) { const int c = 16 * part + 4 * v; coff[v] = c < NP ? c : 0; }
+  // Requests run PF steps ahead (a step is shorter than the memory latency: one step ahead left every step waiting for
+  // its row): a ring of PF register sets, the time loop unrolled by PF so that the ring index is a compile-time constant.
+  // Lane `part` finishes the samples s = part + 4 k: their noise terms, and c_t[row].
+  constexpr int PF = 2;
+  d4 g[PF][4];
+  double cpre[PF], npre[PF][4];
+  auto fetch = [&](auto slot, int t) {           // every request unconditional, at clamped addresses
+    constexpr int u = decltype(slot)::value;
+    const double* h = ws + ((long)b * T + (t > 0 ? t : 0)) * WS;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) pre[i][j] = q[j];
-    }
+    for (int v = 0; v < 4; ++v) g[u][v] = *(const d4*)(h + (long)rc * NP + coff[v]);
+    cpre[u] = h[2L * NP * NP + rc];
+    const double* nz = noise + ((long)b * T + (t > 0 ? t : 0)) * SN + rc;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) npre[u][k] = nz[(long)(part + 4 * k < S ? part + 4 * k : 0) * n];
   };
-  auto stage = [&]() {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int r = ty + 16 * i, cq = c0 + j;
-        if (r < n && cq < n) Gs[r * ld + cq] = pre[i][j];
-      }
-  };
-  // the additive terms c_t[i] + noise_t[s][i] of the elements e = tid + 256 k this thread finishes, one step ahead
-  const int SN = S * n;
-  int es[4], ei[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int e = threadIdx.x + 256 * k, ee = e < SN ? e : 0;
-    es[k] = ee / n; ei[k] = ee % n;
-  }
-  double cpre[4], npre[4];
-  auto fetch_add = [&](int t) {
-    const double* ct = ws + ((long)b * T + t) * (2L * NP * NP + NP) + 2L * NP * NP;
-    const double* nz = noise + ((long)b * T + t) * SN;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { cpre[k] = ct[ei[k]]; npre[k] = nz[es[k] * n + ei[k]]; }
-  };
-  fetch(T > 1 ? T - 2 : 0);
-  fetch_add(T - 1);
-  for (int t = T - 1; t >= 0; --t) {
-    if (t < T - 1) stage();              // G_t, requested one step ago
-    fetch(t > 1 ? t - 1 : 0);
-    double cc[4], nn[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { cc[k] = cpre[k]; nn[k] = npre[k]; }
-    fetch_add(t > 0 ? t - 1 : 0);
-    tile_barrier();
-    if (t < T - 1) {
-      // wavefront w: columns j = w, w + 4, .. of every row (lane = row); four accumulators so that the LDS reads overlap
+  static_for<0, PF>([&](auto slot) { fetch(slot, T - 1 - decltype(slot)::value); });
+  __syncthreads();
+  int cur = 0;
+  for (int t0 = T - 1; t0 >= 0; t0 -= PF) {
+    static_for<0, PF>([&](auto slot) {
+      constexpr int u = decltype(slot)::value;
+      const int t = t0 - u;
+      const bool live = t >= 0;                    // (steps past the start of the chain compute on clamped data, write nothing)
+      // (no masking of the column chunks beyond NP: their entries of x are zero -- rows >= n of xs are never written --
+      //  and the clamped requests return finite entries of G)
+      const d4 (&gc)[4] = g[u];
+      const double (&nn)[4] = npre[u];
+      const double cc = cpre[u];
+      const double* xc = xs[cur] + 16 * part;
+      double* xw = xs[cur ^ 1];
+      double* out = samples + ((long)b * T + (live ? t : 0)) * SN;
+      // (a runtime loop over the samples, the noise term picked by selects: fully unrolled over the 16 possible samples
+      //  the kernel needed 180 .. 260 registers and no longer fitted beside the E-step's backward half on a SIMD)
       for (int s_ = 0; s_ < S; ++s_) {
-        double p[4] = {0.0, 0.0, 0.0, 0.0};
+        double p0 = 0.0, p1 = 0.0;
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          const int j = w + 4 * u, jj = j < n ? j : 0;
-          p[u & 3] = __builtin_fma(j < n ? Gs[li * ld + jj] : 0.0, xn[s_ * 64 + jj], p[u & 3]);
+        for (int v = 0; v < 4; ++v) {
+          const d4 x4 = *(const d4*)(xc + s_ * 64 + 4 * v);
+          p0 = __builtin_fma(gc[v][0], x4[0], p0);
+          p1 = __builtin_fma(gc[v][1], x4[1], p1);
+          p0 = __builtin_fma(gc[v][2], x4[2], p0);
+          p1 = __builtin_fma(gc[v][3], x4[3], p1);
         }
-        part[s_ * 256 + threadIdx.x] = (p[0] + p[1]) + (p[2] + p[3]);
-      }
-    }
-    tile_barrier();
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (threadIdx.x + 256 * k < SN) {
-        double v = cc[k] + nn[k];
-        if (t < T - 1) {
-          const double* q = part + es[k] * 256 + ei[k];
-          v += (q[0] + q[64]) + (q[128] + q[192]);
+        const double p = group_sum<4>(p0 + p1);      // (G_t x_{t+1,s})[row]  (x_T = 0: nothing at t = T-1)
+        const int k = s_ >> 2;
+        const double nk = k == 0 ? nn[0] : k == 1 ? nn[1] : k == 2 ? nn[2] : nn[3];
+        if ((s_ & 3) == part && rv && live) {
+          const double v = (cc + nk) + p;
+          xw[s_ * 64 + row] = v;
+          out[(long)s_ * n + row] = v;
         }
-        xn[es[k] * 64 + ei[k]] = v;
-        samples[((long)b * T + t) * SN + es[k] * n + ei[k]] = v;
       }
-    }
-    tile_barrier();
+      fetch(slot, t - PF);                           // refill the slot: PF steps ahead
+      tile_barrier();                                // (LDS only: __syncthreads() would wait for the requests just issued)
+      cur ^= 1;
+    });
   }
 }
 
@@ -920,11 +910,7 @@ extern "C" int svae_lds_tile_sample_f64(int B, int T, int n, int S, const double
   if (!samples) return -6;
   if (!handoff_workspace) return -7;
   if (B == 0) return 0;
-  // (the partial-sum area is sized by the samples of this launch: one sample stays below the 64 KB default)
-  const size_t lds = (size_t)(64 * 65 + svae::TV_MAX_S * 64 + S * 256) * sizeof(double);
-  static svae::LdsGrant grant;
-  if (!grant.ensure(reinterpret_cast<const void*>(svae::tile_sample_kernel), (long)lds)) return -1001;
-  hipLaunchKernelGGL(svae::tile_sample_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, T, n, S,
+  hipLaunchKernelGGL(svae::tile_sample_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, T, n, S,
                      16 * ((n + 15) / 16), (const double*)handoff_workspace, noise, samples);
   return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
