@@ -7,7 +7,8 @@ Times `cython_natural_lds_estep_general` (svae/lds/lds_inference.py:232-237) = t
 compiled filter + smoother built by oracle/build_ref.py ("reference"), or, when oracle/_ref is
 absent, the NumPy restatement ("port"), per sequence, on a BOUNDED sample of the bench workload
 (same generator and seeds as bench.py rank 0): first on 1 core, then on all USABLE host cores
-(len(os.sched_getaffinity(0)): what this process may actually run on, not os.cpu_count()) with a
+(min of len(os.sched_getaffinity(0)), the cgroup CPU quota -- cpu.max / cfs_quota, which the affinity mask
+does not show -- and the CPU time a pool of busy processes is MEASURED to get; not os.cpu_count()) with a
 process pool (BLAS pinned to 1 thread per process) in which every process works until a COMMON
 deadline, so that no straggler sets the wall time and the leg takes `budget` seconds whatever the
 scaling.  Reports, next to the aggregate rate, the mean
@@ -69,11 +70,86 @@ def _worker_until(deadline):
     return time.perf_counter() - t0, i
 
 
-def usable_cores():
+def affinity_cores():
     try:
         return len(os.sched_getaffinity(0))
     except AttributeError:
         return os.cpu_count() or 1
+
+
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def _cpuset_count(text):
+    n = 0
+    for part in (text or "").split(","):
+        part = part.strip()
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        n += int(hi or lo) - int(lo) + 1
+    return n or None
+
+
+def quota_cores():
+    """CPU bandwidth this container is granted by its cgroup, in cores (None = no limit visible): cgroup v2
+    `cpu.max` ("<quota> <period>" | "max ..."), cgroup v1 `cpu.cfs_quota_us` / `cpu.cfs_period_us`, and the
+    effective cpuset -- the limits sched_getaffinity does not show."""
+    found = []
+    v2 = _read("/sys/fs/cgroup/cpu.max")
+    if v2:
+        q, _, per = v2.partition(" ")
+        if q != "max":
+            found.append(float(q) / float(per or 100000))
+    q1, p1 = _read("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), _read("/sys/fs/cgroup/cpu/cpu.cfs_period_us")
+    if q1 and p1 and int(q1) > 0:
+        found.append(float(q1) / float(p1))
+    for path in ("/sys/fs/cgroup/cpuset.cpus.effective", "/sys/fs/cgroup/cpuset/cpuset.effective_cpus"):
+        c = _cpuset_count(_read(path))
+        if c:
+            found.append(float(c))
+    return min(found) if found else None
+
+
+def _spin_until(deadline):
+    """busy loop until the common deadline; returns the CPU seconds this process was actually given"""
+    c0 = time.process_time()
+    x = 0
+    while time.perf_counter() < deadline:
+        for _ in range(2000):
+            x += 1
+    return time.process_time() - c0
+
+
+def granted_cores(procs, seconds=1.5):
+    """MEASURED: run `procs` busy processes for `seconds` of wall time and add up the CPU time they were given --
+    the cores the box really grants this container, whatever mechanism limits it (quota of a parent cgroup the
+    container cannot see, SMT siblings counted as cores, other tenants)."""
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(procs) as pool:
+        pool.map(_spin_until, [time.perf_counter() + 0.2] * procs, chunksize=1)         # start every process
+        t0 = time.perf_counter()
+        used = pool.map(_spin_until, [t0 + seconds] * procs, chunksize=1)
+        wall = time.perf_counter() - t0
+    return sum(used) / wall
+
+
+def usable_cores():
+    """(pool size, details): min(affinity, cgroup quota, measured grant) -- one BLAS-bound process per core the box
+    actually delivers, not per hardware thread it lists."""
+    aff = affinity_cores()
+    quota = quota_cores()
+    granted = granted_cores(aff) if aff > 1 else 1.0
+    pool = aff
+    if quota is not None:
+        pool = min(pool, int(quota + 0.999))
+    pool = max(1, min(pool, int(round(granted))))
+    return pool, {"affinity_cores": aff, "quota_cores": quota, "granted_cores_measured": granted}
 
 
 def main():
@@ -95,9 +171,10 @@ def main():
     n1 = int(max(lo, min(a.B, a.budget / probe)))
     dt1 = _worker(n1)[0]
     one_core = n1 / dt1
-    cores = usable_cores()
+    cores, core_info = usable_cores()
     out = {"value": one_core, "unit": "sequences/s", "cores": 1, "kind": kind,
-           "one_core_value": one_core, "host_cores": cores, "os_cpu_count": os.cpu_count(),
+           "one_core_value": one_core, "host_cores": cores, "effective_cores": cores, "os_cpu_count": os.cpu_count(),
+           "core_info": core_info,
            "sample": "%d of the %d bench sequences (T=%d, n=%d), 1 core" % (n1, a.B, a.T, a.n)}
     if cores > 1:
         import multiprocessing as mp
@@ -115,8 +192,8 @@ def main():
                             "scaling_efficiency": allc / (cores * one_core)}   # 1.0 = linear in the process count
         if allc > one_core:
             out.update(value=allc, cores=cores,
-                       sample="%d sequences in %.1f s over %d processes (one per usable host core, "
-                              "sched_getaffinity; common deadline), drawn from the %d bench sequences (T=%d, n=%d); "
+                       sample="%d sequences in %.1f s over %d processes (one per core the box grants: min of "
+                              "sched_getaffinity, the cgroup CPU quota and the measured CPU time of a busy pool; common deadline), drawn from the %d bench sequences (T=%d, n=%d); "
                               "scaling efficiency %.2f vs one core" % (done, wall, cores, a.B, a.T, a.n,
                                                                        allc / (cores * one_core)))
     # the "NumPy/autograd path" north_star names (lds_inference.py:223-229): its NumPy restatement

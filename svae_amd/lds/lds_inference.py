@@ -365,10 +365,14 @@ def natural_lds_sample(natparam, node_params, num_samples=1, eps=None, plan=None
     """Filter + backward sampling WITHOUT the smoother: `cython_natural_lds_sample`
     (lds_inference.py:260-264) -> samples (T,S,n) [(B,T,S,n) batched].  `eps` as in
     natural_lds_inference_general."""
+    nh = node_params[1]
+    if int(nh.shape[-1]) > _lib.LDS_MAX_N:
+        # 16 <= n <= 64: the tile kernels have no filter-only form; the sampler works on the hand-off of the tile
+        # E-step (same eps -> sample map), so this is the E-step + sampler with the statistics dropped
+        return natural_lds_inference_general(natparam, node_params, num_samples=num_samples, eps=eps, plan=plan,
+                                             generator=generator)[0]
     q = _prepare(natparam, node_params, plan)
     plan = q["plan"]
-    if q["n"] > _lib.LDS_MAX_N:
-        raise ValueError("sampler: latent dimension <= %d" % _lib.LDS_MAX_N)
     plan.filter(*q["args"], q["pair_batched"])
     S = int(num_samples)
     if eps is None:

@@ -534,3 +534,124 @@ def test_tile_training_step_repeats_on_one_plan():
     fresh = run(LDSEStepPlan(B, T, n, dev))
     for a, b in zip(first, fresh):
         assert torch.equal(a, b)
+
+
+def _spread(B):
+    """three sequences spread over a batch that runs more than one workgroup per CU: first, one in the second round of
+    workgroups, last"""
+    return sorted({0, (2 * B) // 3, B - 1})
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("n,T,inhomog", [(64, 1000, False), (64, 200, True), (48, 400, False), (32, 500, False),
+                                         (32, 200, True)])
+def test_tile_estep_timed_instances_full_length_against_reference(n, T, inhomog):
+    """The kernel instances `bench.py` times at BASELINE configs[4] -- batches above the CU count run the E-step as a
+    forward-half and a backward-half launch of the two-workgroups-per-CU instances (`lds_estep_tile_kernel<NB, .., 2, 1>`
+    / `<.., 2, 2>`) -- over a LONG recursion (n = 64: T = 1000 homogeneous, T = 200 with per-step parameters), through the
+    default dispatch, against the reference's compiled E-step (cython_lds_inference.pyx:28-90, 149-210) at 1e-8 on the
+    well-conditioned rotation model.  A mis-scheduled dependency in those instances (the Schur-stage
+    sched_group_barrier hint once miscompiled one of them) would accumulate over the steps."""
+    from svae_amd.lds.lds_inference import natural_lds_estep_general
+    dev = torch.device("cuda:0")
+    B = torch.cuda.get_device_properties(dev).multi_processor_count + 37
+    rng = np.random.default_rng(17 * n + T)
+    init, pair = _wellcond_natparam(n, rng)
+    if inhomog:
+        J11, J12, J22, zp = (np.asarray(x, float) for x in pair)
+        w = 1.0 + 0.3 * rng.random(T - 1)
+        pair = (J11[None] * w[:, None, None], J12[None] * w[:, None, None], J22[None] * w[:, None, None],
+                float(zp) + 0.1 * rng.standard_normal(T - 1))
+    node = rand_node_potentials((B, T, n), rng)
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev).contiguous()
+    lognorm, (Ei, Ep, En) = natural_lds_estep_general((tuple(t(x) for x in init), tuple(t(x) for x in pair)),
+                                                      tuple(t(x) for x in node))
+    worst = 0.0
+    for b in _spread(B):
+        want = ref.estep((init, pair), (node[0][b], node[1][b], np.zeros(T)))
+        got = (lognorm[b], (tuple(x[b] for x in Ei), tuple(x[b] for x in Ep), tuple(x[b] for x in En)))
+        worst = max(worst, max(e for _, e, _ in _pairwise_errs(got, want, want)))
+        _check(got, want, 1e-8)
+    print("tile E-step n=%d T=%d inhomog=%s B=%d vs compiled reference: %.2e" % (n, T, inhomog, B, worst))
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("n,T", [(64, 1000), (48, 400)])
+def test_tile_estep_timed_instances_full_length_on_the_reference_generator(n, T):
+    """Same instances and batch on the reference's own generator (`rand_lds`, cond(state noise) ~ n^2): the kernel may be
+    no further from the compiled reference than the reference is from the extended-precision arbiter + 5e-6."""
+    from svae_amd.lds.lds_inference import natural_lds_estep_general
+    dev = torch.device("cuda:0")
+    B = torch.cuda.get_device_properties(dev).multi_processor_count + 37
+    rng = np.random.default_rng(19 * n + T)
+    natparam = rand_lds_natparam(n, rng)
+    node = rand_node_potentials((B, T, n), rng)
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev).contiguous()
+    lognorm, (Ei, Ep, En) = natural_lds_estep_general((tuple(t(x) for x in natparam[0]), tuple(t(x) for x in natparam[1])),
+                                                      tuple(t(x) for x in node))
+    for b in _spread(B)[1:]:
+        r = ref.estep(natparam, (node[0][b], node[1][b], np.zeros(T)))
+        arb = lds_longdouble.estep(natparam, (node[0][b], node[1][b]))
+        got = (lognorm[b], (tuple(x[b] for x in Ei), tuple(x[b] for x in Ep), tuple(x[b] for x in En)))
+        for name, e_kr, e_ra in _pairwise_errs(got, r, arb):
+            assert e_kr <= 1.05 * e_ra + 5e-6, (name, b, e_kr, e_ra)
+
+
+_SGB_SHAPES = [(64, 300, False), (64, 60, True), (48, 100, True), (32, 150, False), (16, 80, True)]
+
+
+def _sgb_case(n, T, inhomog, B):
+    rng = np.random.default_rng(23 * n + T)
+    init, pair = _wellcond_natparam(n, rng)
+    if inhomog:
+        J11, J12, J22, zp = (np.asarray(x, float) for x in pair)
+        w = 1.0 + 0.3 * rng.random(T - 1)
+        pair = (J11[None] * w[:, None, None], J12[None] * w[:, None, None], J22[None] * w[:, None, None],
+                np.full(T - 1, float(zp)))
+    return init, pair, rand_node_potentials((B, T, n), rng)
+
+
+def _sgb_outputs(B):
+    """E-step outputs of every shape of _SGB_SHAPES at batch B and at 3 (both register budgets), flattened"""
+    from svae_amd.lds.lds_inference import natural_lds_estep_general
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev).contiguous()
+    out = {}
+    for n, T, inhomog in _SGB_SHAPES:
+        init, pair, node = _sgb_case(n, T, inhomog, B)
+        nat = (tuple(t(x) for x in init), tuple(t(x) for x in pair))
+        for tag, sl in (("big", slice(None)), ("small", slice(0, 3))):
+            lognorm, (Ei, Ep, En) = natural_lds_estep_general(nat, tuple(t(x[sl]) for x in node))
+            for k, v in enumerate([lognorm] + list(Ei) + list(Ep[:3]) + list(En[:2])):
+                out["%d_%d_%d_%s_%d" % (n, T, inhomog, tag, k)] = v.cpu().numpy()
+    return out
+
+
+def test_tile_estep_schur_scheduling_hint_does_not_change_a_bit():
+    """The Schur stage's sched_group_barrier hint (SVAE_TILE_SGB bit 1) is a SCHEDULING hint: a build of the tile unit
+    without it (-DSVAE_TILE_SGB=5, tests/_variants/libsvae_hip_sgb5.so, made by __graft_entry__.build()) must give the
+    default build's results bit for bit -- every instance (one / two workgroups per CU, homogeneous / per-step
+    parameters, NB = 1 .. 4) over recursions of 60 .. 300 steps.  hipcc 7.2 once emitted wrong code for one instance with
+    the hint on; this is the standing check that it does not do so for the kernels as they are now."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    variant = os.path.join(root, "tests", "_variants", "libsvae_hip_sgb5.so")
+    if not os.path.exists(variant):
+        pytest.skip("tests/_variants/libsvae_hip_sgb5.so not built (python __graft_entry__.py)")
+    B = torch.cuda.get_device_properties(0).multi_processor_count + 37
+    mine = _sgb_outputs(B)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "sgb5.npz")
+        code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_lds_tile_hip as m; "
+                "from svae_amd import _lib; assert _lib.LIB_PATH.endswith('libsvae_hip_sgb5.so'), _lib.LIB_PATH; "
+                "np.savez(%r, **m._sgb_outputs(%d))" % (root, os.path.join(root, "tests"), path, B))
+        env = dict(os.environ, SVAE_AMD_LIB=variant)
+        subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=900)
+        other = np.load(path)
+        assert set(other.files) == set(mine)
+        for k in mine:
+            assert np.array_equal(mine[k], other[k]), k
+            assert np.all(np.isfinite(mine[k])), k

@@ -68,6 +68,27 @@ def test_optimize_local_meanfield_matches_oracle(K, n, T, B, fused):
             _close(got[b], want)
 
 
+def test_optimize_local_meanfield_at_latent_dim_16():
+    """Latent dimension beyond the DPP-row kernels (16 <= n <= 64): the initial sample path comes from the tile
+    E-step + sampler (`natural_lds_sample` has no filter-only form there), the ascent from the materialised path."""
+    from svae_amd.models import slds_svae
+    K, n, T, B = 3, 16, 9, 3
+    rng = np.random.default_rng(1600)
+    glob = _globals(K, n, rng)
+    J, h = _nodes(B, T, n, rng)
+    eps = rng.standard_normal((B, T, 1, n))
+    dev = torch.device("cuda:0")
+    node = (torch.as_tensor(J, device=dev), torch.as_tensor(h, device=dev))
+    (hmm_stats, lds_stats), _, (hmm_vlb, lds_vlb), iters = slds_svae.optimize_local_meanfield(glob, node, eps)
+    for b in range(B):
+        ref = slds_numpy.optimize_local_meanfield(glob, (J[b], h[b]), eps[b])
+        assert int(iters[b]) == ref["iters"]
+        assert float(lds_vlb[b]) == pytest.approx(ref["lds_vlb"], rel=1e-7, abs=1e-7)
+        _close(hmm_stats[2][b], ref["hmm_stats"][2])
+        for got, want in zip(lds_stats[0], ref["init_stats"]):
+            _close(got[b], want)
+
+
 def test_run_inference_and_global_stats():
     from svae_amd.models import slds_svae
     K, n, T, B, S = 3, 4, 20, 4, 2

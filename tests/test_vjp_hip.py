@@ -193,12 +193,13 @@ def test_vjp_homogeneous_summed_pair_statistics_cotangents(n, T, B, S, with_samp
 
 
 @pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
-@pytest.mark.parametrize("B", [512, 700, 1500, 2304, 3200])
+@pytest.mark.parametrize("B", [512, 700, 1500, 2304, 3200, 4096])
 def test_vjp_full_size_against_reference(B):
     """BASELINE configs[1] shape (T=200, n=10): E-step + sampler + VJP of the whole batch, 16 sequences
     spot-checked against the reference's compiled VJPs.  B = 512 runs the role-split sweeps (two
     workgroups per four sequences, B <= 2048) with one sequence per consumer, 700 with producer wavefronts (<= 1024),
-    1500 without, B = 2304 the fused sweeps, 3200 also the forward pass without the one-directional filter (> 3072)."""
+    1500 without, B = 2304 the fused sweeps, 3200 also the forward pass without the one-directional filter (> 3072);
+    4096 = north_star's batch on one GPU, the shape `bench.py` times as extra[6]."""
     from svae_amd.lds.lds_inference import lds_inference_differentiable
     n, T, S = 10, 200, 1
     init, pair, node, g = _setup(n, T, B, S, 4242)
