@@ -291,6 +291,8 @@ def measure_gmm(dev, K=5, N=2, T=1000):
     init = gmm.initialize_meanfield(T, K, dev, torch.Generator(device=dev).manual_seed(1))
     o = gmm.meanfield_from_globals(lg, gg, node, init)
     torch.cuda.synchronize()
+    if T <= gmm.GMM_PERSISTENT_MAX_T and o["path"] != "persistent":
+        raise RuntimeError("GMM fixed point ran on path %r, expected the persistent kernel" % o["path"])
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = 20
     e0.record()
@@ -299,7 +301,7 @@ def measure_gmm(dev, K=5, N=2, T=1000):
     e1.record(); torch.cuda.synchronize()
     us = 1e3 * e0.elapsed_time(e1) / reps
     return {"workload": "BASELINE configs[0]: GMM mean-field fixed point, K=%d, %d-D, %d points" % (K, N, T),
-            "us_per_fixed_point": us, "sweeps": int(o["iters"]), "value": T / us * 1e6, "unit": "points/s"}
+            "us_per_fixed_point": us, "sweeps": int(o["iters"]), "path": o["path"], "value": T / us * 1e6, "unit": "points/s"}
 
 
 def main():

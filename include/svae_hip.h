@@ -422,9 +422,12 @@ int svae_gmm_mw_step_f64(int phase, int sweep, int T, int N, int K,
                          void* workspace, size_t ws_bytes, void* stream);
 double* svae_gmm_mw_kl_hist(void* workspace);
 /* Single GPU: the same sweeps, final pass and statistics as svae_gmm_mw_begin + max_iter x phase 0 + phase 1 + phase 2,
- * in ONE cooperative launch with a grid barrier per sweep (+ the statistics launch): removes the 16-21 us per-sweep
- * launch cost that bounds the fixed point below ~100 k points.  Same results.  Returns -50 when the device cannot
- * co-schedule the grid (use the per-sweep calls). */
+ * in ONE plain launch (+ the statistics launch): per sweep the workgroups exchange their KL partials as data-tagged
+ * 8-byte agent-scope words (no grid barrier, no atomics read-modify-write, no cooperative launch), every workgroup sums
+ * them in index order and takes the same stopping decision; with at most one point per thread and K <= 16 the
+ * responsibilities stay in registers for the whole fixed point.  Removes the 16-21 us per-sweep launch cost that bounds
+ * the fixed point below ~100 k points.  Same results as the per-sweep calls, bit for bit.  Every spin is bounded: a
+ * workgroup that never sees a partner's partial sets *info = -77.  Returns -50 only when the device cannot be queried. */
 int svae_gmm_mw_fixed_point_f64(int T, int N, int K,
                                 const double* label_global, const double* gaussian_globals,
                                 const double* node_J, const double* node_h,

@@ -51,18 +51,28 @@ struct GmmArgs {
 // threads per (single) workgroup: more registers per lane for larger N
 template <int N> constexpr int gmm_block() { return N <= 3 ? 1024 : (N <= 5 ? 512 : 256); }
 
-// fixed-order block reduction (every thread returns the total)
+// Fixed-order sums (the SAME arithmetic in every kernel of this file, so that the KL totals -- and with them the stopping
+// decisions -- agree bit for bit between the one-workgroup kernel's batches, the per-sweep launches and the persistent
+// kernel).  wave_sum64: xor butterfly, every lane returns the same total (a + b == b + a bitwise).
+__device__ __forceinline__ double wave_sum64(double v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+// block total = ((w0 + w1) + w2) + ... over the wavefronts' butterfly sums; every thread returns it.  ONE barrier:
+// `red` holds two sets of wavefront sums, callers alternate `parity` between consecutive calls.
 template <int GMM_BLOCK>
-__device__ __forceinline__ double block_sum(double v, double* red) {
-  const int tid = threadIdx.x;
-  red[tid] = v;
+__device__ __forceinline__ double block_sum(double v, double* red, int parity) {
+  constexpr int W = GMM_BLOCK / 64;
+  v = wave_sum64(v);
+  if constexpr (W == 1) return v;
+  double* r = red + (parity & 1) * W;
+  if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = v;
   __syncthreads();
-  for (int s = GMM_BLOCK / 2; s > 0; s >>= 1) {
-    if (tid < s) red[tid] += red[tid + s];
-    __syncthreads();
-  }
-  const double out = red[0];
-  __syncthreads();
+  double out = r[0];
+#pragma unroll
+  for (int w = 1; w < W; ++w) out += r[w];
   return out;
 }
 
@@ -78,82 +88,190 @@ struct PointGauss {
   bool ok;
 };
 
+// Elementary functions of the per-point update, written out: the fixed point is a chain of ~50 dependent sweeps of one
+// wavefront per 64 points, i.e. bound by the instruction count of ONE sweep, of which the library's exp / log / sqrt /
+// IEEE division expansions were two thirds.  All are accurate to a few ulp (the tests hold reals to 1e-9, labels
+// bit-exact).
+__device__ __forceinline__ double gmm_rcp(double x) {           // 1 / x, x normal: v_rcp_f64 + two Newton steps
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  return r;
+}
+
+// exp(x) for x <= 0 (the max-subtracted label natural parameters): x = n ln2 + r, |r| <= ln2 / 2, Taylor to r^13
+// (remainder < 4e-18), scaled by 2^n; underflows to 0 like exp().
+__device__ __forceinline__ double gmm_exp_nonpos(double x) {
+  x = fmax(x, -746.0);
+  const double n = __builtin_rint(x * 1.4426950408889634074);
+  double r = __builtin_fma(n, -6.93147180369123816490e-01, x);
+  r = __builtin_fma(n, -1.90821492927058770002e-10, r);
+  double p = 1.6059043836821613e-10;                                   // 1/13!
+  p = __builtin_fma(p, r, 2.08767569878680989792e-09);                 // 1/12!
+  p = __builtin_fma(p, r, 2.50521083854417187751e-08);                 // 1/11!
+  p = __builtin_fma(p, r, 2.75573192239858906526e-07);                 // 1/10!
+  p = __builtin_fma(p, r, 2.75573192239858906526e-06);                 // 1/9!
+  p = __builtin_fma(p, r, 2.48015873015873015873e-05);                 // 1/8!
+  p = __builtin_fma(p, r, 1.98412698412698412698e-04);                 // 1/7!
+  p = __builtin_fma(p, r, 1.38888888888888888889e-03);                 // 1/6!
+  p = __builtin_fma(p, r, 8.33333333333333333333e-03);                 // 1/5!
+  p = __builtin_fma(p, r, 4.16666666666666666667e-02);                 // 1/4!
+  p = __builtin_fma(p, r, 1.66666666666666666667e-01);                 // 1/3!
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  return __builtin_amdgcn_ldexp(p, (int)n);
+}
+
+// log(x), x > 0 normal: x = 2^e m, m in [sqrt(1/2), sqrt(2)); log m = 2 atanh(s), s = (m - 1) / (m + 1), |s| <= 0.1716,
+// odd series to s^23 (remainder < 1e-19).
+__device__ __forceinline__ double gmm_log(double x) {
+  int e = __builtin_amdgcn_frexp_exp(x);
+  double m = __builtin_amdgcn_frexp_mant(x);                           // [0.5, 1)
+  const bool lo = m < 0.70710678118654752440;
+  m = lo ? 2.0 * m : m;
+  e = lo ? e - 1 : e;
+  const double f = m - 1.0;
+  const double s = f * gmm_rcp(2.0 + f);
+  const double z = s * s;
+  double p = 1.0 / 23.0;
+  p = __builtin_fma(p, z, 1.0 / 21.0);
+  p = __builtin_fma(p, z, 1.0 / 19.0);
+  p = __builtin_fma(p, z, 1.0 / 17.0);
+  p = __builtin_fma(p, z, 1.0 / 15.0);
+  p = __builtin_fma(p, z, 1.0 / 13.0);
+  p = __builtin_fma(p, z, 1.0 / 11.0);
+  p = __builtin_fma(p, z, 1.0 / 9.0);
+  p = __builtin_fma(p, z, 1.0 / 7.0);
+  p = __builtin_fma(p, z, 1.0 / 5.0);
+  p = __builtin_fma(p, z, 1.0 / 3.0);
+  const double t = (s * z) * p;                                        // atanh(s) - s
+  const double de = (double)e;
+  // e ln2 + 2 s + 2 t, the small terms first
+  return __builtin_fma(de, 6.93147180369123816490e-01,
+                       __builtin_fma(2.0, s, __builtin_fma(2.0, t, de * 1.90821492927058770002e-10)));
+}
+
 template <int N>
 __device__ __forceinline__ void gauss_update(PointGauss<N>& g) {
-  // J = -2 A (SPD); Cholesky J = L L', Sigma = J^-1, Ex = Sigma h   [gaussian.py:11-25]
-  double L[N][N];
+  // J = -2 A (SPD) = L D L' (unit lower L, pivots d_j > 0 <=> SPD); Sigma = J^-1 = L^-T D^-1 L^-1, Ex = Sigma h,
+  // sum_j log chol(J)_jj = 1/2 log prod_j d_j   [gaussian.py:11-25].  No square root, one reciprocal per pivot.
+  double L[N][N], d[N], dinv[N];
   g.ok = true;
-  double sumlog = 0.0;
+  double det = 1.0;       // prod_j d_j (N <= 8 factors of O(1e-3 .. 1e3): no overflow)
 #pragma unroll
   for (int j = 0; j < N; ++j) {
-    double d = -2.0 * g.A[j][j];
+    double v[N];          // v_m = L_jm d_m
+    double dj = -2.0 * g.A[j][j];
 #pragma unroll
-    for (int m = 0; m < j; ++m) d -= L[j][m] * L[j][m];
-    g.ok = g.ok && (d > 0.0);
-    const double l = sqrt(d);
-    L[j][j] = l;
-    sumlog += log(l);
-    const double inv = 1.0 / l;
+    for (int m = 0; m < j; ++m) {
+      v[m] = L[j][m] * d[m];
+      dj = __builtin_fma(-L[j][m], v[m], dj);
+    }
+    g.ok = g.ok && (dj > 0.0);
+    d[j] = dj;
+    dinv[j] = gmm_rcp(dj);
+    det *= dj;
 #pragma unroll
     for (int i = j + 1; i < N; ++i) {
       double s = -2.0 * g.A[i][j];
 #pragma unroll
-      for (int m = 0; m < j; ++m) s -= L[i][m] * L[j][m];
-      L[i][j] = s * inv;
+      for (int m = 0; m < j; ++m) s = __builtin_fma(-L[i][m], v[m], s);
+      L[i][j] = s * dinv[j];
     }
   }
-  // Linv (lower), Sigma = Linv' Linv
+  // Li = L^-1 (unit lower, strict part)
   double Li[N][N];
 #pragma unroll
   for (int j = 0; j < N; ++j) {
-    Li[j][j] = 1.0 / L[j][j];
 #pragma unroll
     for (int i = j + 1; i < N; ++i) {
-      double s = 0.0;
+      double s = -L[i][j];
 #pragma unroll
-      for (int m = j; m < i; ++m) s -= L[i][m] * Li[m][j];
-      Li[i][j] = s / L[i][i];
+      for (int m = j + 1; m < i; ++m) s = __builtin_fma(-L[i][m], Li[m][j], s);
+      Li[i][j] = s;
     }
   }
-  double v[N];   // v = Linv h
+  double u[N];            // u = D^-1 L^-1 h
+  double vv = 0.0;        // h' Sigma h
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    double s = 0.0;
+    double s = g.h[i];
 #pragma unroll
-    for (int m = 0; m <= i; ++m) s += Li[i][m] * g.h[m];
-    v[i] = s;
+    for (int m = 0; m < i; ++m) s = __builtin_fma(Li[i][m], g.h[m], s);
+    u[i] = s * dinv[i];
+    vv = __builtin_fma(s, u[i], vv);
   }
-  double vv = 0.0;
-#pragma unroll
-  for (int i = 0; i < N; ++i) vv += v[i] * v[i];
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    double s = 0.0;
+    double s = u[i];
 #pragma unroll
-    for (int m = i; m < N; ++m) s += Li[m][i] * v[m];
+    for (int m = i + 1; m < N; ++m) s = __builtin_fma(Li[m][i], u[m], s);
     g.Ex[i] = s;
   }
 #pragma unroll
   for (int i = 0; i < N; ++i)
 #pragma unroll
     for (int j = 0; j <= i; ++j) {
-      double s = 0.0;
+      double s = (j == i) ? dinv[i] : dinv[i] * Li[i][j];
 #pragma unroll
-      for (int m = i; m < N; ++m) s += Li[m][i] * Li[m][j];
-      s += g.Ex[i] * g.Ex[j];
+      for (int m = i + 1; m < N; ++m) s = __builtin_fma(Li[m][i] * dinv[m], Li[m][j], s);
+      s = __builtin_fma(g.Ex[i], g.Ex[j], s);
       g.ExxT[i][j] = s;
       g.ExxT[j][i] = s;
     }
-  g.logZ = 0.5 * vv - sumlog + g.ab;
+  g.logZ = 0.5 * vv - 0.5 * gmm_log(det) + g.ab;
 }
 
-// One point of one sweep: Gaussian factor update from the responsibilities `rin` (K), label update,
-// this point's KL term.  final_pass = the extra pass of gmm.py:74-77 (no linear correction term, writes
-// every output).  Shared by the single-workgroup kernel and the multi-workgroup sweeps.
+// The K global potentials as a table in LDS, staged once per launch: per state k the entries the (N+2) x (N+2)
+// dense packing actually holds -- [A (N x N) | b (N) | c | d | E log pi_k] -- padded to an even count (16-byte reads,
+// every lane reads the same address: a broadcast); states K .. KP-1 are zero.  (Read through the kernel-argument
+// pointers hipcc emitted a VECTOR load per entry, point and sweep -- ~400 L2 round trips per sweep.)
+template <int N> constexpr int gmm_tab_stride() { return (N * N + N + 3 + 1) & ~1; }
+__host__ __device__ constexpr int gmm_tab_states(int K) { return K <= 8 ? 8 : (K <= 16 ? 16 : K); }
+template <int N> constexpr size_t gmm_tab_bytes(int K) { return (size_t)gmm_tab_states(K) * gmm_tab_stride<N>() * sizeof(double); }
+
 template <int N>
-__device__ __forceinline__ double gmm_point(const GmmArgs& a, int t, const double* rin, bool final_pass) {
-  constexpr int D = N + 2;
+__device__ __forceinline__ void gmm_stage_table(const GmmArgs& a, double* tab) {
+  constexpr int D = N + 2, TS = gmm_tab_stride<N>();
+  const int KP = gmm_tab_states(a.K);
+  for (int q = threadIdx.x; q < KP * TS; q += blockDim.x) {
+    const int k = q / TS, e = q % TS;
+    double v = 0.0;
+    if (k < a.K) {
+      const double* G = a.gaussian_globals + (long)k * D * D;
+      if (e < N * N) v = G[(e / N) * D + (e % N)];
+      else if (e < N * N + N) v = G[(e - N * N) * D + N];
+      else if (e == N * N + N) v = G[N * D + N];
+      else if (e == N * N + N + 1) v = G[(N + 1) * D + N + 1];
+      else if (e == N * N + N + 2) v = a.label_global[k];
+    }
+    tab[q] = v;
+  }
+  __syncthreads();
+}
+
+// One point of one sweep: Gaussian factor update from the responsibilities r (K), label update, this point's KL
+// term.  final_pass = the extra pass of gmm.py:74-77 (no linear correction term, writes every per-point output).
+// Shared by the single-workgroup kernel, the per-sweep launches and the persistent kernel: per-point results are
+// bit-identical across them.  nJ / nh: the point's node potentials; tab: gmm_stage_table's LDS table.
+//   KR > 0 (K <= KR, KR = 8 / 16): r, the label natural parameters and exp(l - max) live in REGISTERS -- r[] is the
+//          point's state, old on entry (zero beyond K), new on exit; nothing is written unless final_pass (the callers
+//          store r where their protocol needs it).  One exp per state and sweep; the multiply-add loops run over all
+//          KR table rows (zero rows beyond K) without a branch.
+//   KR = 0 (any K <= 64): the same arithmetic with label_natparam (T,K) as scratch between the K-loops and
+//          label_stats as the state (rin -> label_stats[t]).
+template <int N, int KR>
+__device__ __forceinline__ double gmm_point(const GmmArgs& a, const double* tab, const int t, const double (&nJ)[N],
+                                            const double (&nh)[N], double (&r)[KR > 0 ? KR : 1], const double* rin,
+                                            bool final_pass) {
+  constexpr int D = N + 2, TS = gmm_tab_stride<N>();
+  constexpr int KU = KR > 0 ? KR : 1;
   const int K = a.K;
+  // The table reads are loop-invariant and hipcc hoists them out of the sweep loop into registers: welcome while the
+  // table is small (KR = 8, N <= 3: it never leaves the registers), 688 bytes of scratch per lane at KR = 16 -- there
+  // the address passes through an empty asm, so that every sweep reads the LDS table afresh.
+  if constexpr (KR * TS > 96) asm volatile("" : "+v"(tab));
   PointGauss<N> g;
   // eta = pack_dense(node) + sum_k r_k G_k          [gmm.py:113-114]
 #pragma unroll
@@ -163,24 +281,25 @@ __device__ __forceinline__ double gmm_point(const GmmArgs& a, int t, const doubl
     g.h[i] = 0.0;
   }
   double cN = 0.0, dN = 0.0;   // eta[N,N], eta[N+1,N+1]
-  for (int k = 0; k < K; ++k) {
-    const double r = rin[k];
-    const double* G = a.gaussian_globals + (long)k * D * D;
+  auto eta_term = [&](const double* G, double rk) {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
 #pragma unroll
-      for (int j = 0; j < N; ++j) g.A[i][j] = __builtin_fma(r, G[i * D + j], g.A[i][j]);
-      g.h[i] = __builtin_fma(r, G[i * D + N], g.h[i]);
+      for (int j = 0; j < N; ++j) g.A[i][j] = __builtin_fma(rk, G[i * N + j], g.A[i][j]);
+      g.h[i] = __builtin_fma(rk, G[N * N + i], g.h[i]);
     }
-    cN = __builtin_fma(r, G[N * D + N], cN);
-    dN = __builtin_fma(r, G[(N + 1) * D + N + 1], dN);
+    cN = __builtin_fma(rk, G[N * N + N], cN);
+    dN = __builtin_fma(rk, G[N * N + N + 1], dN);
+  };
+  if constexpr (KR > 0) {
+#pragma unroll
+    for (int k = 0; k < KU; ++k) eta_term(tab + k * TS, r[k]);
+  } else {
+    for (int k = 0; k < K; ++k) eta_term(tab + k * TS, rin[k]);
   }
   g.ab = cN + dN;
-  double nJ[N], nh[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    nJ[i] = a.node_J[(long)t * N + i];
-    nh[i] = a.node_h[(long)t * N + i];
     g.A[i][i] += nJ[i];
     g.h[i] += nh[i];
   }
@@ -200,38 +319,71 @@ __device__ __forceinline__ double gmm_point(const GmmArgs& a, int t, const doubl
   double klt = nodedot - g.logZ;
 
   // label update: l_k = <stats, G_k>, natparam = l + label_global, r = softmax   [gmm.py:119-124]
-  double mx = -1.0 / 0.0;
-  for (int k = 0; k < K; ++k) {
-    const double* G = a.gaussian_globals + (long)k * D * D;
-    double l = G[N * D + N] + G[(N + 1) * D + N + 1];
+  auto label_term = [&](const double* G) -> double {
+    double l = G[N * N + N] + G[N * N + N + 1];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
 #pragma unroll
-      for (int j = 0; j < N; ++j) l = __builtin_fma(g.ExxT[i][j], G[i * D + j], l);
-      l = __builtin_fma(g.Ex[i], G[i * D + N], l);
+      for (int j = 0; j < N; ++j) l = __builtin_fma(g.ExxT[i][j], G[i * N + j], l);
+      l = __builtin_fma(g.Ex[i], G[N * N + i], l);
     }
-    const double np_ = l + a.label_global[k];
-    a.label_natparam[(long)t * K + k] = np_;   // scratch between the two k-loops
-    mx = np_ > mx ? np_ : mx;
-  }
-  double se = 0.0;
-  for (int k = 0; k < K; ++k) se += exp(a.label_natparam[(long)t * K + k] - mx);
-  const double lse = mx + log(se);
-  const double inv = 1.0 / se;
-  double lab = 0.0, lin = 0.0;
+    return l + G[N * N + N + 2];
+  };
+  double mx = -1.0 / 0.0;
+  double lab = 0.0, lin = 0.0, se = 0.0;
   int best = 0;
   double bestv = -1.0;
-  for (int k = 0; k < K; ++k) {
-    const double np_ = a.label_natparam[(long)t * K + k];
-    const double l = np_ - a.label_global[k];
-    const double rnew = exp(np_ - mx) * inv;
-    const double rold = rin[k];
-    lab = __builtin_fma(rnew, l, lab);
-    lin = __builtin_fma(rold - rnew, l, lin);     // <eta - sum_k rnew_k G_k - node, stats>, gmm.py:99-102
-    if (rnew > bestv) { bestv = rnew; best = k; }
-    a.label_stats[(long)t * K + k] = rnew;
+  if constexpr (KR > 0) {
+    double np_[KU], ex[KU];
+#pragma unroll
+    for (int k = 0; k < KU; ++k) np_[k] = label_term(tab + k * TS);
+#pragma unroll
+    for (int k = 0; k < KU; ++k) mx = (k < K && np_[k] > mx) ? np_[k] : mx;
+#pragma unroll
+    for (int k = 0; k < KU; ++k) {
+      ex[k] = 0.0;
+      if (k < K) { ex[k] = gmm_exp_nonpos(np_[k] - mx); se += ex[k]; }
+    }
+    const double lse = mx + gmm_log(se);
+    const double inv = gmm_rcp(se);
+#pragma unroll
+    for (int k = 0; k < KU; ++k) {
+      const double l = np_[k] - tab[k * TS + N * N + N + 2];     // (zero rows beyond K: l = 0, r = rnew = 0)
+      const double rnew = ex[k] * inv;
+      lab = __builtin_fma(rnew, l, lab);
+      lin = __builtin_fma(r[k] - rnew, l, lin);     // <eta - sum_k rnew_k G_k - node, stats>, gmm.py:99-102
+      if (k < K && rnew > bestv) { bestv = rnew; best = k; }
+      r[k] = rnew;
+    }
+    if (final_pass) {
+#pragma unroll
+      for (int k = 0; k < KU; ++k) if (k < K) {
+        a.label_natparam[(long)t * K + k] = np_[k];
+        a.label_stats[(long)t * K + k] = r[k];
+      }
+    }
+    klt += lab - lse;
+  } else {
+    for (int k = 0; k < K; ++k) {
+      const double np_ = label_term(tab + k * TS);
+      a.label_natparam[(long)t * K + k] = np_;   // scratch between the two k-loops
+      mx = np_ > mx ? np_ : mx;
+    }
+    for (int k = 0; k < K; ++k) se += gmm_exp_nonpos(a.label_natparam[(long)t * K + k] - mx);
+    const double lse = mx + gmm_log(se);
+    const double inv = gmm_rcp(se);
+    for (int k = 0; k < K; ++k) {
+      const double np_ = a.label_natparam[(long)t * K + k];
+      const double l = np_ - tab[k * TS + N * N + N + 2];
+      const double rnew = gmm_exp_nonpos(np_ - mx) * inv;
+      const double rold = rin[k];
+      lab = __builtin_fma(rnew, l, lab);
+      lin = __builtin_fma(rold - rnew, l, lin);
+      if (rnew > bestv) { bestv = rnew; best = k; }
+      a.label_stats[(long)t * K + k] = rnew;
+    }
+    klt += lab - lse;
   }
-  klt += lab - lse;
   if (!final_pass) klt += lin;
 
   if (final_pass) {
@@ -255,44 +407,104 @@ __device__ __forceinline__ double gmm_point(const GmmArgs& a, int t, const doubl
   return klt;
 }
 
-template <int N>
+// State of a thread's point(s) across the sweeps of a kernel that runs the whole fixed point.  With at most ONE point
+// per thread and K <= KR the responsibilities never leave the registers (loaded from label_init, stored with the final
+// pass); otherwise label_stats in global memory is the state, as in the per-sweep launches.
+template <int N, int KR>
+struct GmmSweeper {
+  static constexpr int KU = KR > 0 ? KR : 1;
+  const GmmArgs& a;
+  const double* tab;            // gmm_stage_table's LDS table
+  const int first, stride;      // this thread's points: first, first + stride, ... < T
+  const bool resident;
+  double r[KU];
+  double nJ[N], nh[N];
+  __device__ GmmSweeper(const GmmArgs& a_, const double* tab_, int first_, int stride_, bool whole_fixed_point)
+      : a(a_), tab(tab_), first(first_), stride(stride_), resident(KR > 0 && whole_fixed_point && a_.T <= stride_) {
+    if (resident && first < a.T) { load(a.label_init, first); node(first); }
+  }
+  __device__ __forceinline__ void node(int t) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) { nJ[i] = a.node_J[(long)t * N + i]; nh[i] = a.node_h[(long)t * N + i]; }
+  }
+  __device__ __forceinline__ void load(const double* src, int t) {
+    if constexpr (KR > 0) {
+#pragma unroll
+      for (int k = 0; k < KU; ++k) r[k] = k < a.K ? src[(long)t * a.K + k] : 0.0;
+    }
+  }
+  __device__ __forceinline__ void store(double* dst, int t) {
+    if constexpr (KR > 0) {
+#pragma unroll
+      for (int k = 0; k < KU; ++k) if (k < a.K) dst[(long)t * a.K + k] = r[k];
+    }
+  }
+  // one fixed-point sweep (from_init: the responsibilities come from label_init) -> this thread's KL partial
+  __device__ __forceinline__ double sweep(bool from_init) {
+    double klpart = 0.0;
+    if (resident) {
+      if (first < a.T) klpart = gmm_point<N, KR>(a, tab, first, nJ, nh, r, nullptr, false);
+      return klpart;
+    }
+    for (int t = first; t < a.T; t += stride) {
+      const double* rin = (from_init ? a.label_init : a.label_stats) + (long)t * a.K;
+      node(t);
+      if constexpr (KR > 0) {
+        load(from_init ? a.label_init : a.label_stats, t);
+        klpart += gmm_point<N, KR>(a, tab, t, nJ, nh, r, nullptr, false);
+        store(a.label_stats, t);
+      } else {
+        klpart += gmm_point<N, KR>(a, tab, t, nJ, nh, r, rin, false);
+      }
+    }
+    return klpart;
+  }
+  // the final pass of gmm.py:74-86 (label_fixed <- the fixed point it starts from) -> this thread's KL partial
+  __device__ __forceinline__ double final_pass(bool from_init) {
+    double klpart = 0.0;
+    for (int t = first; t < a.T; t += stride) {
+      const double* src = from_init ? a.label_init : a.label_stats;
+      if (!resident) node(t);
+      if constexpr (KR > 0) {
+        if (!resident) load(src, t);
+        if (a.label_fixed) store(a.label_fixed, t);
+        klpart += gmm_point<N, KR>(a, tab, t, nJ, nh, r, nullptr, true);
+      } else {
+        const double* rin = src + (long)t * a.K;
+        if (a.label_fixed)
+          for (int k = 0; k < a.K; ++k) a.label_fixed[(long)t * a.K + k] = rin[k];
+        if (from_init)     // gmm_point<.., 0> reads rin and overwrites label_stats
+          for (int k = 0; k < a.K; ++k) a.label_stats[(long)t * a.K + k] = rin[k];
+        klpart += gmm_point<N, KR>(a, tab, t, nJ, nh, r, from_init ? a.label_stats + (long)t * a.K : rin, true);
+      }
+    }
+    return klpart;
+  }
+};
+
+template <int N, int KR>
 __global__ __launch_bounds__(gmm_block<N>()) void gmm_meanfield_kernel(const GmmArgs a) {
   constexpr int D = N + 2;
   constexpr int GMM_BLOCK = gmm_block<N>();
-  __shared__ double red[GMM_BLOCK];
+  __shared__ double red[2 * (GMM_BLOCK / 64)];
   const int tid = threadIdx.x;
   const int T = a.T, K = a.K;
-
-  // one sweep over this thread's points; returns the thread's KL partial
-  auto sweep = [&](bool first, bool final_pass) -> double {
-    double klpart = 0.0;
-    for (int t = tid; t < T; t += GMM_BLOCK)
-      klpart += gmm_point<N>(a, t, first ? a.label_init + (long)t * K : a.label_stats + (long)t * K, final_pass);
-    return klpart;
-  };
+  extern __shared__ __attribute__((aligned(16))) double gmm_tab[];
+  gmm_stage_table<N>(a, gmm_tab);
+  GmmSweeper<N, KR> sw(a, gmm_tab, tid, GMM_BLOCK, true);
 
   // ---- fixed point [gmm.py:90-110] -------------------------------------------------------------
   double kl_prev = 1.0 / 0.0;
   int it = 0;
   for (int i = 0; i < a.max_iter; ++i) {
     it = i + 1;
-    const double kl = block_sum<GMM_BLOCK>(sweep(i == 0, false), red);
+    const double kl = block_sum<GMM_BLOCK>(sw.sweep(i == 0), red, i);
     const bool stop = fabs(kl - kl_prev) < a.tol;
     kl_prev = kl;
     if (stop) break;
   }
-  // label_stats now holds the fixed point (or label_init if max_iter == 0)
-  if (a.max_iter == 0) {
-    for (int j = tid; j < T * K; j += GMM_BLOCK) a.label_stats[j] = a.label_init[j];
-    __syncthreads();
-  }
-  if (a.label_fixed) {   // the responsibilities the final pass starts from (gmm.py:71)
-    for (int t = tid; t < T; t += GMM_BLOCK)
-      for (int k = 0; k < K; ++k) a.label_fixed[(long)t * K + k] = a.label_stats[(long)t * K + k];
-  }
   // ---- final pass + outputs [gmm.py:74-86] -----------------------------------------------------
-  // (reads r from label_stats and overwrites it point by point, by the same thread)
-  const double kl = block_sum<GMM_BLOCK>(sweep(false, true), red);
+  const double kl = block_sum<GMM_BLOCK>(sw.final_pass(a.max_iter == 0), red, it);
   if (tid == 0) { a.kl[0] = kl; a.iters[0] = it; }
   __syncthreads();
   __threadfence_block();
@@ -348,34 +560,29 @@ __device__ __forceinline__ int gmm_converged_at(const double* kl_hist, int upto,
   return -1;
 }
 
-// sum of partials[0..count) in a fixed order (strided per-thread partial sums, then a tree): every thread
-// of the block returns it
-__device__ __forceinline__ double gmm_fixed_order_sum(const double* partials, int count, double* red) {
+// sum of partials[0..count) in a fixed order -- lane l adds partials l, l + 64, .. in ascending order, then the wavefront
+// butterfly: any ONE wavefront computes it alone, every lane returns it
+__device__ __forceinline__ double gmm_fixed_order_sum(const double* partials, int count) {
   double v = 0.0;
-  for (int j = threadIdx.x; j < count; j += GMM_MW_BLOCK) v += partials[j];
-  return block_sum<GMM_MW_BLOCK>(v, red);
+  for (int j = threadIdx.x & 63; j < count; j += 64) v += partials[j];
+  return wave_sum64(v);
 }
 
-template <int N>
+template <int N, int KR>
 __global__ __launch_bounds__(GMM_MW_BLOCK) void gmm_mw_sweep_kernel(const GmmMwArgs m) {
   const GmmArgs& a = m.g;
-  __shared__ double red[GMM_MW_BLOCK];
+  __shared__ double red[2 * (GMM_MW_BLOCK / 64)];
   __shared__ int sh_flag;
-  const int tid = threadIdx.x, K = a.K, T = a.T;
+  const int tid = threadIdx.x;
   const int conv = gmm_converged_at(m.kl_hist, m.sweep, a.tol);     // same answer in every thread / workgroup
   if (m.mode == 0 && conv >= 0) return;                             // fixed point already reached
   const bool final_pass = m.mode == 1;
   const bool from_init = final_pass ? (a.max_iter == 0) : (m.sweep == 0);
-  double klpart = 0.0;
-  for (int t = blockIdx.x * GMM_MW_BLOCK + tid; t < T; t += gridDim.x * GMM_MW_BLOCK) {
-    const double* rin = (from_init ? a.label_init : a.label_stats) + (long)t * K;
-    if (final_pass && a.label_fixed)
-      for (int k = 0; k < K; ++k) a.label_fixed[(long)t * K + k] = rin[k];     // gmm.py:71
-    if (final_pass && from_init)    // max_iter == 0: the "fixed point" is label_init; gmm_point reads rin, writes label_stats
-      for (int k = 0; k < K; ++k) a.label_stats[(long)t * K + k] = rin[k];
-    klpart += gmm_point<N>(a, t, rin, final_pass);
-  }
-  const double wgsum = block_sum<GMM_MW_BLOCK>(klpart, red);
+  extern __shared__ __attribute__((aligned(16))) double gmm_tab[];
+  gmm_stage_table<N>(a, gmm_tab);
+  GmmSweeper<N, KR> sw(a, gmm_tab, blockIdx.x * GMM_MW_BLOCK + tid, gridDim.x * GMM_MW_BLOCK, false);
+  const double klpart = final_pass ? sw.final_pass(from_init) : sw.sweep(from_init);
+  const double wgsum = block_sum<GMM_MW_BLOCK>(klpart, red, 0);
   if (tid == 0) {
     m.partials[blockIdx.x] = wgsum;
     __threadfence();
@@ -385,7 +592,7 @@ __global__ __launch_bounds__(GMM_MW_BLOCK) void gmm_mw_sweep_kernel(const GmmMwA
   __syncthreads();
   if (!sh_flag) return;
   __threadfence();
-  const double total = gmm_fixed_order_sum(m.partials, gridDim.x, red);
+  const double total = gmm_fixed_order_sum(m.partials, gridDim.x);
   if (tid == 0) {
     if (final_pass) {
       a.kl[0] = total;                                   // (this rank's points; the caller sums over ranks)
@@ -396,55 +603,97 @@ __global__ __launch_bounds__(GMM_MW_BLOCK) void gmm_mw_sweep_kernel(const GmmMwA
   }
 }
 
-// The same sweeps in ONE cooperative launch (single GPU): a grid barrier per sweep instead of a launch per sweep
-// (16 .. 21 us each, the whole cost of a sweep below ~100 k points).  Every workgroup sums the per-workgroup KL
-// partials in index order itself (all reach the same total and the same stopping decision); the partials are
-// double-buffered by sweep parity so that one barrier per sweep suffices.
-template <int N>
+// The same sweeps in ONE launch (single GPU): a grid-wide exchange of the workgroups' KL partials per sweep instead of
+// a launch per sweep (16 .. 21 us each, the whole cost of a sweep below ~100 k points).  The exchange is NOT a
+// barrier + reduction but an all-to-all of data-tagged granules (MI355X: per-XCD L2s are not coherent, so every shared
+// word is an agent-scope access): workgroup w publishes its partial as two 8-byte {tag = sweep + 1, half of the double}
+// words with relaxed agent-scope atomic stores (write-through: no release fence, the data is the flag); thread j of
+// every workgroup polls the two words of workgroup j with relaxed agent-scope loads until both tags match -- no
+// atomic read-modify-write, no fence, no cooperative-groups grid sync (software on ROCm 7.2: ~26 us per sync) -- then
+// every workgroup sums the partials in index order with the per-sweep kernels' own gmm_fixed_order_sum arithmetic: all
+// reach the same total, bit for bit, and the same stopping decision.  The slots are double-buffered by sweep parity (a
+// workgroup can be at most one exchange ahead of the slowest), a third set serves the final pass.  A plain launch:
+// the grid (<= 32 workgroups in the window this path serves, capped by the occupancy query) is co-resident on any
+// idle-enough device; every spin is bounded and reports through `info` (-77) instead of hanging.
+// With at most one point per thread and K <= 16 the responsibilities stay in registers for the whole fixed point.
+struct GmmSlot { unsigned long long lo, hi; };          // {tag << 32 | low half}, {tag << 32 | high half}
+constexpr int GMM_SPIN_LIMIT = 1 << 22;
+
+__device__ __forceinline__ void gmm_publish(GmmSlot* slot, unsigned tag, double v) {
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+  __hip_atomic_store(&slot->lo, ((unsigned long long)tag << 32) | (bits & 0xffffffffull), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(&slot->hi, ((unsigned long long)tag << 32) | (bits >> 32), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// total of the G workgroups' partials of exchange `tag`: thread 0 publishes this workgroup's, then EVERY wavefront polls
+// all G slots (lane l: slots l, l + 64, ..) and sums them with gmm_fixed_order_sum's arithmetic -- no workgroup barrier
+// behind the exchange; every thread returns the total.  G == 1: nothing to exchange.
+__device__ __forceinline__ double gmm_exchange(GmmSlot* slots, int G, unsigned tag, double mine, int32_t* info) {
+  if (G == 1) return wave_sum64((threadIdx.x & 63) == 0 ? mine : 0.0);
+  if (threadIdx.x == 0) gmm_publish(slots + blockIdx.x, tag, mine);
+  double v = 0.0;
+  for (int j = threadIdx.x & 63; j < G; j += 64) {
+    unsigned long long lo = 0, hi = 0;
+    int spins = 0;
+    for (;;) {
+      lo = __hip_atomic_load(&slots[j].lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      hi = __hip_atomic_load(&slots[j].hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((unsigned)(lo >> 32) == tag && (unsigned)(hi >> 32) == tag) break;
+      if (++spins > GMM_SPIN_LIMIT) { atomicMin(info, -77); break; }     // never hang the device
+      __builtin_amdgcn_s_sleep(1);
+    }
+    v += __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
+  }
+  return wave_sum64(v);
+}
+
+template <int N, int KR>
 __global__ __launch_bounds__(GMM_MW_BLOCK) void gmm_mw_persistent_kernel(const GmmMwArgs m) {
-  namespace cg = cooperative_groups;
-  cg::grid_group grid = cg::this_grid();
   const GmmArgs& a = m.g;
-  __shared__ double red[GMM_MW_BLOCK];
-  const int tid = threadIdx.x, K = a.K, T = a.T, G = gridDim.x;
+  __shared__ double red[2 * (GMM_MW_BLOCK / 64)];
+  const int tid = threadIdx.x, G = gridDim.x;
+  GmmSlot* slots = reinterpret_cast<GmmSlot*>(m.partials);
+  extern __shared__ __attribute__((aligned(16))) double gmm_tab[];
+  gmm_stage_table<N>(a, gmm_tab);
+  GmmSweeper<N, KR> sw(a, gmm_tab, blockIdx.x * GMM_MW_BLOCK + tid, G * GMM_MW_BLOCK, true);
   double prev = 1.0 / 0.0;
   int iters = 0;
+#ifdef SVAE_GMM_TIMING      // tools/gmm_phase_timing.py: shader cycles per phase, wall clock (100 MHz) of the loop
+  long long tc[3] = {0, 0, 0}, t0_ = __builtin_readcyclecounter();
+  const unsigned long long w0_ = __builtin_amdgcn_s_memrealtime();
+#define GMM_TICK(k) { const long long n_ = __builtin_readcyclecounter(); tc[k] += n_ - t0_; t0_ = n_; }
+#else
+#define GMM_TICK(k)
+#endif
   for (int i = 0; i < a.max_iter; ++i) {
     iters = i + 1;
-    double klpart = 0.0;
-    for (int t = blockIdx.x * GMM_MW_BLOCK + tid; t < T; t += G * GMM_MW_BLOCK)
-      klpart += gmm_point<N>(a, t, (i == 0 ? a.label_init : a.label_stats) + (long)t * K, false);
-    const double wgsum = block_sum<GMM_MW_BLOCK>(klpart, red);
-    double* part = m.partials + (i & 1) * G;
-    if (tid == 0) part[blockIdx.x] = wgsum;
-    __threadfence();
-    grid.sync();
-    const double total = gmm_fixed_order_sum(part, G, red);
+    const double klpart = sw.sweep(i == 0);
+    GMM_TICK(0)
+    const double wgsum = block_sum<GMM_MW_BLOCK>(klpart, red, i);
+    GMM_TICK(1)
+    const double total = gmm_exchange(slots + (i & 1) * G, G, (unsigned)(i + 1), wgsum, a.info);
+    GMM_TICK(2)
     if (blockIdx.x == 0 && tid == 0) m.kl_hist[i] = total;
     const bool stop = fabs(total - prev) < a.tol;
     prev = total;
     if (stop) break;
   }
+#ifdef SVAE_GMM_TIMING
+  if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == G - 1))
+    printf("gmm persistent wg %d/%d: %d sweeps, cycles per sweep: point %lld  block_sum %lld  exchange %lld | loop wall %.2f us per sweep\n",
+           (int)blockIdx.x, G, iters, tc[0] / iters, tc[1] / iters, tc[2] / iters,
+           (double)(__builtin_amdgcn_s_memrealtime() - w0_) / 100.0 / iters);
+#endif
   // final pass (gmm.py:74-86)
-  const bool from_init = a.max_iter == 0;
-  double klpart = 0.0;
-  for (int t = blockIdx.x * GMM_MW_BLOCK + tid; t < T; t += G * GMM_MW_BLOCK) {
-    const double* rin = (from_init ? a.label_init : a.label_stats) + (long)t * K;
-    if (a.label_fixed)
-      for (int k = 0; k < K; ++k) a.label_fixed[(long)t * K + k] = rin[k];
-    if (from_init)
-      for (int k = 0; k < K; ++k) a.label_stats[(long)t * K + k] = rin[k];
-    klpart += gmm_point<N>(a, t, rin, true);
+  const double wgsum = block_sum<GMM_MW_BLOCK>(sw.final_pass(a.max_iter == 0), red, iters);
+  if (blockIdx.x != 0) {
+    if (tid == 0) gmm_publish(slots + 2 * G + blockIdx.x, (unsigned)(a.max_iter + 2), wgsum);
+    return;
   }
-  const double wgsum = block_sum<GMM_MW_BLOCK>(klpart, red);
-  double* part = m.partials + 2 * G;
-  if (tid == 0) part[blockIdx.x] = wgsum;
-  __threadfence();
-  grid.sync();
-  if (blockIdx.x == 0) {
-    const double total = gmm_fixed_order_sum(part, G, red);
-    if (tid == 0) { a.kl[0] = total; a.iters[0] = iters; }
-  }
+  const double total = gmm_exchange(slots + 2 * G, G, (unsigned)(a.max_iter + 2), wgsum, a.info);
+  if (tid == 0) { a.kl[0] = total; a.iters[0] = iters; }
 }
 
 // global statistics  dirichlet_stats = sum_t r_t,  niw_stats_k = sum_t r_tk stats_t  over many workgroups:
@@ -480,10 +729,28 @@ __global__ __launch_bounds__(GMM_MW_BLOCK) void gmm_mw_stats_kernel(const GmmArg
   }
 }
 
-template <int N>
-static int launch_gmm(const GmmArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL((gmm_meanfield_kernel<N>), dim3(1), dim3(gmm_block<N>()), 0, s, a);
-  return hipGetLastError() == hipSuccess ? 0 : -1000;
+// (N, K) -> the kernel instance: N = 1 .. 8 compile-time; KR = 8 / 16 (responsibilities in registers: N <= 4, where
+// that form fits the register file without scratch) / 0 (K <= 64, any N)
+template <bool REG_FORM, typename Fn>
+static int gmm_dispatch(int N, int K, Fn&& fn) {
+  auto byk = [&](auto n) -> int {
+    if constexpr (REG_FORM && decltype(n)::value <= 4) {
+      if (K <= 8) return fn(n, std::integral_constant<int, 8>{});
+      if (K <= 16) return fn(n, std::integral_constant<int, 16>{});
+    }
+    return fn(n, std::integral_constant<int, 0>{});
+  };
+  switch (N) {
+    case 1: return byk(std::integral_constant<int, 1>{});
+    case 2: return byk(std::integral_constant<int, 2>{});
+    case 3: return byk(std::integral_constant<int, 3>{});
+    case 4: return byk(std::integral_constant<int, 4>{});
+    case 5: return byk(std::integral_constant<int, 5>{});
+    case 6: return byk(std::integral_constant<int, 6>{});
+    case 7: return byk(std::integral_constant<int, 7>{});
+    case 8: return byk(std::integral_constant<int, 8>{});
+  }
+  return -2;
 }
 
 }  // namespace svae
@@ -521,17 +788,13 @@ extern "C" int svae_gmm_meanfield_f64(int T, int N, int K,
   a.dirichlet_stats = dirichlet_stats; a.niw_stats = niw_stats;
   a.kl = kl; a.iters = iters; a.assign = assign; a.info = info;
   hipStream_t s = (hipStream_t)stream;
-  switch (N) {
-    case 1: return svae::launch_gmm<1>(a, s);
-    case 2: return svae::launch_gmm<2>(a, s);
-    case 3: return svae::launch_gmm<3>(a, s);
-    case 4: return svae::launch_gmm<4>(a, s);
-    case 5: return svae::launch_gmm<5>(a, s);
-    case 6: return svae::launch_gmm<6>(a, s);
-    case 7: return svae::launch_gmm<7>(a, s);
-    case 8: return svae::launch_gmm<8>(a, s);
-  }
-  return -2;
+  // (one workgroup of up to 1024 threads: 128 registers per lane -- the responsibilities-in-registers form does not fit)
+  return svae::gmm_dispatch<false>(N, K, [&](auto n, auto kr) -> int {
+    constexpr int NN = decltype(n)::value, KR = decltype(kr)::value;
+    hipLaunchKernelGGL((svae::gmm_meanfield_kernel<NN, KR>), dim3(1), dim3(svae::gmm_block<NN>()),
+                       svae::gmm_tab_bytes<NN>(K), s, a);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+  });
 }
 
 // ---- multi-workgroup entry points (see the block comment above gmm_mw_sweep_kernel) ---------------------
@@ -547,21 +810,17 @@ static int gmm_mw_stats_grid(int T) {
 struct GmmMwLayout { double* kl_hist; double* partials; double* spart; int32_t* counters; };
 static size_t gmm_mw_doubles(int T, int N, int K, int max_iter) {
   const int D = N + 2;
-  return (size_t)(max_iter + 1) + 3 * gmm_mw_grid(T) + (size_t)gmm_mw_stats_grid(T) * K * (1 + D * D);
+  // kl_hist (rounded up to an even count: the exchange slots are 16-byte words) | 3 sets of G 16-byte slots | statistics partials
+  return (size_t)((max_iter + 2) & ~1) + 6 * gmm_mw_grid(T) + (size_t)gmm_mw_stats_grid(T) * K * (1 + D * D);
 }
 static GmmMwLayout gmm_mw_layout(void* ws, int T, int N, int K, int max_iter) {
   const int D = N + 2;
   GmmMwLayout l;
   l.kl_hist = (double*)ws;
-  l.partials = l.kl_hist + (max_iter + 1);
-  l.spart = l.partials + 3 * gmm_mw_grid(T);
+  l.partials = l.kl_hist + ((max_iter + 2) & ~1);
+  l.spart = l.partials + 6 * gmm_mw_grid(T);
   l.counters = (int32_t*)(l.spart + (size_t)gmm_mw_stats_grid(T) * K * (1 + D * D));
   return l;
-}
-template <int N>
-static int launch_gmm_mw(const GmmMwArgs& m, hipStream_t s) {
-  hipLaunchKernelGGL((gmm_mw_sweep_kernel<N>), dim3(gmm_mw_grid(m.g.T)), dim3(GMM_MW_BLOCK), 0, s, m);
-  return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 }  // namespace svae
 
@@ -626,25 +885,21 @@ extern "C" int svae_gmm_mw_step_f64(int phase, int sweep, int T, int N, int K,
   }
   m.mode = phase;
   m.sweep = phase == 0 ? sweep : max_iter;
-  switch (N) {
-    case 1: return svae::launch_gmm_mw<1>(m, s);
-    case 2: return svae::launch_gmm_mw<2>(m, s);
-    case 3: return svae::launch_gmm_mw<3>(m, s);
-    case 4: return svae::launch_gmm_mw<4>(m, s);
-    case 5: return svae::launch_gmm_mw<5>(m, s);
-    case 6: return svae::launch_gmm_mw<6>(m, s);
-    case 7: return svae::launch_gmm_mw<7>(m, s);
-    case 8: return svae::launch_gmm_mw<8>(m, s);
-  }
-  return -4;
+  return svae::gmm_dispatch<true>(N, K, [&](auto n, auto kr) -> int {
+    constexpr int NN = decltype(n)::value, KR = decltype(kr)::value;
+    hipLaunchKernelGGL((svae::gmm_mw_sweep_kernel<NN, KR>), dim3(svae::gmm_mw_grid(m.g.T)), dim3(svae::GMM_MW_BLOCK),
+                       svae::gmm_tab_bytes<NN>(K), s, m);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+  });
 }
 
 /* device address of kl_hist[0] inside the workspace (the scalar a multi-GPU caller all-reduces per sweep) */
 extern "C" double* svae_gmm_mw_kl_hist(void* workspace) { return (double*)workspace; }
 
-// The whole fixed point + final pass in ONE cooperative launch (grid barrier per sweep), then the statistics
-// launch: the single-GPU form of the svae_gmm_mw_* sweeps (same per-point code, same fixed-order KL reduction, same
-// results).  Returns -50 if the device cannot co-schedule the grid (fall back to svae_gmm_mw_step_f64).
+// The whole fixed point + final pass in ONE launch (an all-to-all of tagged KL partials per sweep, see
+// gmm_mw_persistent_kernel), then the statistics launch: the single-GPU form of the svae_gmm_mw_* sweeps (same per-point
+// code, same fixed-order KL reduction, same results).  Returns -50 only if the device cannot be queried (callers may
+// then use svae_gmm_mw_step_f64 -- and must say so: the Python layer warns and records the path).
 extern "C" int svae_gmm_mw_fixed_point_f64(int T, int N, int K,
                                            const double* label_global, const double* gaussian_globals,
                                            const double* node_J, const double* node_h,
@@ -679,35 +934,28 @@ extern "C" int svae_gmm_mw_fixed_point_f64(int T, int N, int K,
   const svae::GmmMwLayout l = svae::gmm_mw_layout(workspace, T, N, K, max_iter);
   m.kl_hist = l.kl_hist; m.partials = l.partials; m.counters = l.counters; m.sweep = 0; m.mode = 0;
   hipStream_t s = (hipStream_t)stream;
-  const void* kern = nullptr;
-  switch (N) {
-    case 1: kern = (const void*)svae::gmm_mw_persistent_kernel<1>; break;
-    case 2: kern = (const void*)svae::gmm_mw_persistent_kernel<2>; break;
-    case 3: kern = (const void*)svae::gmm_mw_persistent_kernel<3>; break;
-    case 4: kern = (const void*)svae::gmm_mw_persistent_kernel<4>; break;
-    case 5: kern = (const void*)svae::gmm_mw_persistent_kernel<5>; break;
-    case 6: kern = (const void*)svae::gmm_mw_persistent_kernel<6>; break;
-    case 7: kern = (const void*)svae::gmm_mw_persistent_kernel<7>; break;
-    case 8: kern = (const void*)svae::gmm_mw_persistent_kernel<8>; break;
-  }
-  int per_cu = 0, dev = 0, cus = 0;
-  if (hipGetDevice(&dev) != hipSuccess ||
-      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, svae::GMM_MW_BLOCK, 0) != hipSuccess) {
-    (void)hipGetLastError();      // -50 = "use the per-sweep launches instead": leave no sticky error behind for them
-    return -50;
-  }
-  int G = svae::gmm_mw_grid(T);
-  const int cap = per_cu * cus;
-  if (cap < 1) return -50;
-  if (G > cap) G = cap;
-  // the counters section doubles as the statistics kernel's ticket: zero it (kl_hist needs no reset here)
-  if (hipMemsetAsync(l.counters, 0, (size_t)(max_iter + 3) * sizeof(int32_t), s) != hipSuccess) return -1000;
-  void* params[] = {(void*)&m};
-  if (hipLaunchCooperativeKernel(kern, dim3(G), dim3(svae::GMM_MW_BLOCK), params, 0, s) != hipSuccess) {
-    (void)hipGetLastError();
-    return -50;
-  }
+  // every polled word starts at zero (tags are sweep + 1 .. max_iter + 2); the counters section is the statistics
+  // kernel's ticket
+  if (hipMemsetAsync(workspace, 0, svae_gmm_mw_workspace_bytes(T, N, K, max_iter), s) != hipSuccess) return -1000;
+  const int rc = svae::gmm_dispatch<true>(N, K, [&](auto n, auto kr) -> int {
+    constexpr int NN = decltype(n)::value, KR = decltype(kr)::value;
+    auto kern = svae::gmm_mw_persistent_kernel<NN, KR>;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+      (void)hipGetLastError();      // -50 = "use the per-sweep launches instead": leave no sticky error behind for them
+      return -50;
+    }
+    // co-residency of the grid (the workgroups wait for each other): at most ONE 256-thread workgroup per CU -- far
+    // inside what the device holds (no reliance on the occupancy query, which is one block per CU high at some SGPR counts)
+    const int cap = cus;
+    int G = svae::gmm_mw_grid(T);
+    if (cap < 1) return -50;
+    if (G > cap) G = cap;
+    hipLaunchKernelGGL(kern, dim3(G), dim3(svae::GMM_MW_BLOCK), svae::gmm_tab_bytes<NN>(K), s, m);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+  });
+  if (rc != 0) return rc;
   hipLaunchKernelGGL(svae::gmm_mw_stats_kernel, dim3(svae::gmm_mw_stats_grid(T)), dim3(svae::GMM_MW_BLOCK), 0, s,
                      a, N + 2, l.spart, l.counters + max_iter + 2);
   return hipGetLastError() == hipSuccess ? 0 : -1000;

@@ -31,11 +31,11 @@ def initialize_meanfield(T, K, device, generator=None):
     return r / r.sum(-1, keepdim=True)
 
 
-# Dispatch by minibatch size (measured, tools/bench_gmm.py): one workgroup / one launch up to 512 points (20 us per
-# sweep at 1000 points); several workgroups in ONE cooperative launch with a grid barrier per sweep up to 8192
-# (12 us per sweep at 1000 points; the barrier costs ~20 us on larger grids); beyond, one launch per sweep
-# (16 us at 16 k points, 146 us at 1 M) -- which is also the form that shards over GPUs.
-GMM_SINGLE_WG_MAX_T = 512
+# Dispatch by minibatch size (measured, tools/bench_gmm.py): one workgroup / one launch up to 512 points; several
+# workgroups in ONE launch that exchange tagged KL partials per sweep up to 8192 points (the persistent kernel);
+# beyond, one launch per sweep (16 us at 16 k points, 146 us at 1 M) -- which is also the form that shards over GPUs.
+# `out["path"]` of meanfield_from_globals says which one ran ("single_wg" / "persistent" / "sweeps").
+GMM_SINGLE_WG_MAX_T = 0      # (the one-workgroup kernel is kept for multi_wg=False: it no longer wins at any size)
 GMM_PERSISTENT_MAX_T = 8192
 
 
@@ -136,20 +136,29 @@ def meanfield_from_globals(label_global, gaussian_globals, node_potentials, labe
         raise ValueError("sharded points need the multi-workgroup sweeps (batch-total stopping rule)")
     if multi_wg:
         be = _HipSweeps(lib, (T, N, K), (lg, gg, nJ, nh, li), out, tol, max_iter, dev)
-        rc = -50
-        if not sharded and persistent and T <= GMM_PERSISTENT_MAX_T:
-            # single GPU: one cooperative launch, a grid barrier per sweep (svae_gmm_mw_fixed_point_f64)
+        want_persistent = not sharded and persistent and T <= GMM_PERSISTENT_MAX_T
+        out["path"] = "sweeps"
+        if want_persistent:
+            # single GPU: ONE launch for the whole fixed point, the workgroups exchange tagged KL partials per sweep
+            # (svae_gmm_mw_fixed_point_f64)
             rc = lib.svae_gmm_mw_fixed_point_f64(
                 T, N, K, p(lg), p(gg), p(nJ), p(nh), p(li), float(tol), int(max_iter),
                 p(out["label_stats"]), p(out["label_fixed"]), p(out["gaussian_stats"]), p(out["label_natparam"]),
                 p(out["gaussian_natparam"]), p(out["dirichlet_stats"]), p(out["niw_stats"]),
                 p(out["kl"]), p(out["iters"]), p(out["assign"]), p(out["info"]), p(be.ws), be.ws_bytes,
                 _lib.current_stream(dev))
-            if rc != -50:
+            if rc == -50:
+                # never silently: the per-sweep launches are 1.5x slower at 1000 points (bench.py fails its GMM leg on it)
+                import warnings
+                warnings.warn("svae_gmm_mw_fixed_point_f64: device could not be queried (rc -50); "
+                              "falling back to one launch per sweep", RuntimeWarning)
+            else:
                 _lib.check(rc, "svae_gmm_mw_fixed_point_f64")
-        if rc == -50:       # sharded points, or the device cannot co-schedule the grid: one launch per sweep
+                out["path"] = "persistent"
+        if out["path"] == "sweeps":     # sharded points, large minibatches (or the fallback above): one launch per sweep
             run_sweeps(be, int(max_iter), group)
     else:
+        out["path"] = "single_wg"
         rc = lib.svae_gmm_meanfield_f64(
             T, N, K, p(lg), p(gg), p(nJ), p(nh), p(li), float(tol), int(max_iter),
             p(out["label_stats"]), p(out["label_fixed"]), p(out["gaussian_stats"]), p(out["label_natparam"]),
@@ -158,6 +167,9 @@ def meanfield_from_globals(label_global, gaussian_globals, node_potentials, labe
         _lib.check(rc, "svae_gmm_meanfield_f64")
     if check:
         v = int(out["info"].item())
+        if v < 0:
+            raise RuntimeError("GMM mean field: a workgroup never received a partner's KL partial (info %d): "
+                               "the grid of the persistent kernel was not co-resident" % v)
         if v != 0:
             raise FloatingPointError("GMM mean field: point %d has a non positive definite "
                                      "Gaussian factor" % (v - 1))

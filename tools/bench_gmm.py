@@ -11,8 +11,9 @@ from svae_amd.models import gmm
 
 def main():
     dev = torch.device("cuda:0")
-    for K, N, T, mw in [(5, 2, 1000, False), (15, 2, 500, False), (5, 2, 16384, False), (5, 2, 16384, True),
-                        (5, 2, 16384, "sweeps"), (5, 2, 1000, True), (15, 2, 262144, True), (5, 2, 1048576, True)]:
+    for K, N, T, mw in [(5, 2, 1000, False), (15, 2, 500, False), (15, 2, 500, True), (5, 2, 8192, True), (5, 2, 16384, False),
+                        (5, 2, 16384, True), (5, 2, 1000, True), (5, 2, 1000, "sweeps"), (15, 2, 262144, True),
+                        (5, 2, 1048576, True)]:
         gen = torch.Generator().manual_seed(K)
         d, niws = gmm.init_pgm_param(K, N, alpha=0.05 / K, niw_conc=0.5, random_scale=3., generator=gen)
         label_global = expfam.dirichlet_expectedstats(d).to(dev)
@@ -33,8 +34,7 @@ def main():
         ms = ev[0].elapsed_time(ev[1]) / reps
         it = int(o["iters"])
         print("GMM mean field [%s] K=%d N=%d T=%d: %.1f us per call (host wrapper included), %d sweeps, %.1f us per sweep, "
-              "%.1f M point-sweeps/s, kl %.4f" % (("many workgroups, one cooperative launch" if (mw is True and T <= gmm.GMM_PERSISTENT_MAX_T) else "many workgroups, one launch per sweep") if mw else "one workgroup, one launch",
-                                                  K, N, T, 1e3 * ms, it, 1e3 * ms / max(it, 1), T * it / ms / 1e3, float(o["kl"])))
+              "%.1f M point-sweeps/s, kl %.4f" % (o["path"], K, N, T, 1e3 * ms, it, 1e3 * ms / max(it, 1), T * it / ms / 1e3, float(o["kl"])))
 
 
 if __name__ == "__main__":
