@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SVAE_HIP_ABI_VERSION 9   /* 9: keep bit SVAE_KEEP_SIGMA of svae_lds_estep_f64 (16 <= n <= 64) + svae_lds_tile_sigma_offset_bytes; 8: step ranges (t_begin, t_end) in svae_lds_tile_vjp_f64 / svae_lds_tile_noise_f64, SVAE_OPT_TILE_FORWARD / _BACKWARD; 7: + svae_slds_path_nodeparams_f64, svae_slds_mix_pair_natparam_f64; 6: per-call `options` word replaces the process-global svae_lds_set_* selectors (re-entrant library), + svae_slds_hmm_meanfield_f64, svae_slds_sweep_glue_f64, g_E_pair in svae_lds_tile_vjp_f64; 5: + svae_lds_set_prod_max_b; 4: + svae_slds_lds_meanfield_f64, svae_gmm_mw_*, svae_lds_global_step_f64, svae_lds_natgrad_f64, svae_lds_tile_vjp_f64; 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
+#define SVAE_HIP_ABI_VERSION 10   /* 10: + svae_gmm_sample_f64, svae_gmm_local_vjp_f64 (the differentiable tail of the GMM local step); 9: keep bit SVAE_KEEP_SIGMA of svae_lds_estep_f64 (16 <= n <= 64) + svae_lds_tile_sigma_offset_bytes; 8: step ranges (t_begin, t_end) in svae_lds_tile_vjp_f64 / svae_lds_tile_noise_f64, SVAE_OPT_TILE_FORWARD / _BACKWARD; 7: + svae_slds_path_nodeparams_f64, svae_slds_mix_pair_natparam_f64; 6: per-call `options` word replaces the process-global svae_lds_set_* selectors (re-entrant library), + svae_slds_hmm_meanfield_f64, svae_slds_sweep_glue_f64, g_E_pair in svae_lds_tile_vjp_f64; 5: + svae_lds_set_prod_max_b; 4: + svae_slds_lds_meanfield_f64, svae_gmm_mw_*, svae_lds_global_step_f64, svae_lds_natgrad_f64, svae_lds_tile_vjp_f64; 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
 #define SVAE_LDS_MAX_N 15   /* register/DPP path: one 16-lane row per sequence, n+1 <= 16 */
 #define SVAE_LDS_TILE_MAX_N 64   /* 16 <= n <= 64: LDS-tiled MFMA path (keep: SVAE_KEEP_SIGMA or 0) */
 #define SVAE_KEEP_SIGMA 4         /* keep bit of svae_lds_estep_f64, 16 <= n <= 64 only: see svae_lds_tile_sigma_offset_bytes */
@@ -437,6 +437,25 @@ int svae_gmm_mw_fixed_point_f64(int T, int N, int K,
                                 double* dirichlet_stats, double* niw_stats,
                                 double* kl, int32_t* iters, int32_t* assign, int32_t* info,
                                 void* workspace, size_t ws_bytes, void* stream);
+
+
+/* ---- GMM-SVAE local step, differentiable tail (csrc/gmm_train.hip) -------------------------------------------
+ * Replaces /root/reference/svae/distributions/gaussian.py:27-33 (`natural_sample`) and autograd's reverse pass
+ * through /root/reference/svae/models/gmm.py:74-86 + gmm.py:12-16 (`run_inference`: samples and local_kl are what
+ * svae.py:21-30 differentiates w.r.t. the recognition network's node potentials).
+ *   svae_gmm_sample_f64     samples[t,s,:] = J_t^-1 h_t + chol(J_t)^-T eps[t,s,:], (J_t, h_t) unpacked from the
+ *                           dense (N+2)x(N+2) gaussian_natparam[t] the fixed-point kernels return.
+ *   svae_gmm_local_vjp_f64  cotangents of the node potentials (g_node_J, g_node_h: (T,N)) given g_kl (device scalar,
+ *                           cotangent of the final pass's local KL; NULL = 0) and g_samples ((T,S,N); NULL = none,
+ *                           then eps may be NULL).  gaussian_natparam / label_natparam: the final pass's outputs.
+ * One point per lane, N <= 8, K <= 64; device pointers, asynchronous on `stream`.  0 / -k (argument k). */
+int svae_gmm_sample_f64(int T, int N, int S, const double* gaussian_natparam, const double* eps,
+                        double* samples, void* stream);
+int svae_gmm_local_vjp_f64(int T, int N, int K, int S, const double* label_global,
+                           const double* gaussian_globals, const double* node_J, const double* node_h,
+                           const double* gaussian_natparam, const double* label_natparam,
+                           const double* g_kl, const double* eps, const double* g_samples,
+                           double* g_node_J, double* g_node_h, void* stream);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must precede CDLL: shares torch's HIP runtime)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVAE_AMD_LIB", os.path.join(_HERE, "libsvae_hip.so"))  # env: experiments only
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 LDS_MAX_N = 15        # register/DPP path (E-step, sampler, VJP)
 LDS_TILE_MAX_N = 64   # LDS-tiled MFMA path (E-step only)
 
@@ -82,6 +82,8 @@ SIGNATURES = {
                              + [ctypes.c_double, ctypes.c_int] + [_c_double_p] * 8
                              + [_c_int_p] * 3 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "svae_gmm_mw_kl_hist": (ctypes.c_void_p, [ctypes.c_void_p]),
+    "svae_gmm_sample_f64": (ctypes.c_int, [ctypes.c_int] * 3 + [_c_double_p] * 3 + [ctypes.c_void_p]),
+    "svae_gmm_local_vjp_f64": (ctypes.c_int, [ctypes.c_int] * 4 + [_c_double_p] * 11 + [ctypes.c_void_p]),
     "svae_gmm_mw_fixed_point_f64": (ctypes.c_int, [ctypes.c_int] * 3 + [_c_double_p] * 5
                                     + [ctypes.c_double, ctypes.c_int] + [_c_double_p] * 8
                                     + [_c_int_p] * 3 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),

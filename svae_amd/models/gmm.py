@@ -245,40 +245,55 @@ def run_inference(prior_natparam, global_natparam, nn_potentials, num_samples, l
     T, N = gn.shape[0], gn.shape[-1] - 2
     if eps is None:
         eps = torch.randn(T, num_samples, N, dtype=torch.float64, device=gn.device, generator=generator)
-    samples = expfam.gaussian_natural_sample(gn, _dev64(eps, gn.device))
+    samples = gaussian_sample(gn, eps)
     stats, local_kl = _allreduce_stats_and_kl(stats, local_kl, group)
     return samples, stats, prior_kl(global_natparam, prior_natparam, reference_compat), local_kl
 
 
 # --- differentiable call surface (what make_gradfun drives) ------------------------------------------
 
-def _final_pass_torch(label_global, gaussian_globals, node_dense, label_stats):
-    """gmm.py:74-86 in torch: the ONE pass after the fixed point that the reference keeps on the
-    autograd tape (`gaussian_meanfield` + `label_meanfield` on the boxed node potentials).  The fixed
-    point itself (gmm.py:71, <= 100 sweeps, not differentiated: `getval`) runs in the HIP kernel."""
-    N = node_dense.shape[-1] - 2
-    gaussian_natparam = node_dense + torch.tensordot(label_stats, gaussian_globals, dims=([1], [0]))
-    neghalfJ, h = gaussian_natparam[..., :N, :N], gaussian_natparam[..., :N, N]
-    J = -2 * neghalfJ
-    L = torch.linalg.cholesky(J)
-    # J^-1 [h | I] by two triangular solves (torch.cholesky_solve / cholesky_inverse return wrong results
-    # intermittently on this ROCm build for some sizes, see svae_amd/lds/lds_large.py)
-    eye = torch.eye(N, dtype=J.dtype, device=J.device).expand(J.shape[0], N, N)
-    sol = torch.linalg.solve_triangular(
-        L.transpose(-1, -2), torch.linalg.solve_triangular(L, torch.cat([h.unsqueeze(-1), eye], -1), upper=False),
-        upper=True)
-    Ex = sol[..., 0]
-    ExxT = sol[..., 1:] + Ex.unsqueeze(-1) * Ex.unsqueeze(-2)
-    ones = torch.ones(Ex.shape[0], dtype=Ex.dtype, device=Ex.device)
-    gaussian_stats = expfam.pack_dense(ExxT, Ex, ones, ones)
-    logZ = 0.5 * (h * Ex).sum() - torch.log(torch.diagonal(L, dim1=-1, dim2=-2)).sum() \
-        + (gaussian_natparam[..., N, N] + gaussian_natparam[..., N + 1, N + 1]).sum()
-    gaussian_kl = (node_dense * gaussian_stats).sum() - logZ
-    node_l = torch.tensordot(gaussian_stats, gaussian_globals, dims=([1, 2], [1, 2]))
-    label_natparam = node_l + label_global
-    label_stats_new = torch.softmax(label_natparam, dim=-1)
-    label_kl = (label_stats_new * node_l).sum() - torch.logsumexp(label_natparam, dim=-1).sum()
-    return (label_stats_new, gaussian_stats), (label_natparam, gaussian_natparam), label_kl + gaussian_kl
+def gaussian_sample(gaussian_natparam, eps):
+    """gaussian.py:27-33 on the device: x = J^-1 h + chol(J)^-T eps for the (T, N+2, N+2) dense-packed factors the
+    fixed-point kernels return; eps (T,S,N) -> samples (T,S,N)  (svae_gmm_sample_f64)."""
+    lib = _lib.load()
+    gn = gaussian_natparam.contiguous()
+    T, N = gn.shape[0], gn.shape[-1] - 2
+    eps = _dev64(eps, gn.device)
+    S = eps.shape[1]
+    if tuple(eps.shape) != (T, S, N):
+        raise ValueError("eps must be (T, S, N)")
+    out = torch.empty(T, S, N, dtype=torch.float64, device=gn.device)
+    _lib.check(lib.svae_gmm_sample_f64(T, N, S, _lib.ptr(gn), _lib.ptr(eps), _lib.ptr(out),
+                                       _lib.current_stream(gn.device)), "svae_gmm_sample_f64")
+    return out
+
+
+class _LocalTail(torch.autograd.Function):
+    """(node_J, node_h) -> (samples, local_kl): the one pass of gmm.py:74-86 the reference keeps on the autograd tape
+    + gaussian.natural_sample.  Forward values are the fixed-point kernel's final pass (`o`, on detached potentials)
+    and svae_gmm_sample_f64; backward is svae_gmm_local_vjp_f64 (the adjoint derived in csrc/gmm_train.hip)."""
+
+    @staticmethod
+    def forward(ctx, node_J, node_h, eps, label_global, gaussian_globals, o):
+        samples = gaussian_sample(o["gaussian_natparam"], eps)
+        ctx.save_for_backward(node_J.detach().contiguous(), node_h.detach().contiguous(), eps, label_global,
+                              gaussian_globals, o["gaussian_natparam"], o["label_natparam"])
+        return samples, o["kl"][0].clone()
+
+    @staticmethod
+    def backward(ctx, g_samples, g_kl):
+        nJ, nh, eps, lg, gg, gn, ln = ctx.saved_tensors
+        lib = _lib.load()
+        T, N = nh.shape
+        K, S = lg.shape[0], eps.shape[1]
+        gJ, gh = torch.empty_like(nJ), torch.empty_like(nh)
+        p = _lib.ptr
+        gs = None if g_samples is None else g_samples.to(torch.float64).contiguous()
+        gk = None if g_kl is None else g_kl.to(torch.float64).reshape(1).contiguous()
+        _lib.check(lib.svae_gmm_local_vjp_f64(T, N, K, S, p(lg), p(gg), p(nJ), p(nh), p(gn), p(ln), p(gk), p(eps),
+                                              p(gs), p(gJ), p(gh), _lib.current_stream(nh.device)),
+                   "svae_gmm_local_vjp_f64")
+        return gJ, gh, None, None, None, None
 
 
 def run_inference_differentiable(prior_natparam, global_natparam, nn_potentials, num_samples,
@@ -286,7 +301,8 @@ def run_inference_differentiable(prior_natparam, global_natparam, nn_potentials,
                                  reference_compat=False):
     """run_inference (gmm.py:12-16) with gradients w.r.t. nn_potentials flowing into `samples` and
     `local_kl`, exactly the two quantities the reference differentiates (svae.py:21-24); statistics
-    are returned detached (`unbox(stats)`, gmm.py:16)."""
+    are returned detached (`unbox(stats)`, gmm.py:16).  Kernel launches only: fixed point + final pass, sampler,
+    and -- in backward() -- the derived adjoint of the final pass and the sampler."""
     dev = nn_potentials[1].device
     g = [_dev64(x, dev) for x in global_natparam]
     label_global = expfam.dirichlet_expectedstats(g[0])
@@ -296,16 +312,11 @@ def run_inference_differentiable(prior_natparam, global_natparam, nn_potentials,
     if label_init is None:
         label_init = initialize_meanfield(T, g[0].shape[0], dev, generator)
     o = meanfield_from_globals(label_global, gaussian_globals, (nJ.detach(), nh.detach()), label_init, group=group)
-    label_fixed = o["label_fixed"]          # the fixed point the final pass starts from (gmm.py:71)
-    node_dense = expfam.pack_dense(nJ, nh)
-    (label_stats, gaussian_stats), (label_natparam, gaussian_natparam), local_kl = \
-        _final_pass_torch(label_global, gaussian_globals, node_dense, label_fixed.detach())
     if eps is None:
         eps = torch.randn(T, num_samples, N, dtype=torch.float64, device=dev, generator=generator)
-    samples = expfam.gaussian_natural_sample(gaussian_natparam, _dev64(eps, dev))
-    dirichlet_stats = label_stats.detach().sum(0)
-    niw_stats = torch.tensordot(label_stats.detach(), gaussian_stats.detach(), dims=([0], [0]))
-    stats, local_kl = _allreduce_stats_and_kl((dirichlet_stats, niw_stats), local_kl, group)
+    samples, local_kl = _LocalTail.apply(nJ, nh, _dev64(eps, dev), label_global.contiguous(),
+                                         gaussian_globals.contiguous(), o)
+    stats, local_kl = _allreduce_stats_and_kl((o["dirichlet_stats"], o["niw_stats"]), local_kl, group)
     return samples, stats, prior_kl(global_natparam, prior_natparam, reference_compat), local_kl
 
 

@@ -30,8 +30,9 @@ def test_gmm_differentiable_path_equals_kernel_path(golden_dir):
     assert torch.isfinite(nJ.grad).all() and torch.isfinite(nh.grad).all() and float(nh.grad.abs().sum()) > 0
 
 
-def test_gmm_final_pass_gradcheck():
-    from svae_amd.models.gmm import _final_pass_torch
+def test_gmm_final_pass_reference_gradcheck():
+    """the torch reference of the final pass itself against finite differences"""
+    from _gmm_torch import final_pass_torch
     from svae_amd.distributions import expfam
     rng = np.random.default_rng(0)
     K, N, T = 3, 2, 4
@@ -41,8 +42,45 @@ def test_gmm_final_pass_gradcheck():
     r = t64(rng.random((T, K))); r = r / r.sum(-1, keepdim=True)
     nJ = t64(-0.5 * np.log1p(np.exp(rng.standard_normal((T, N))))).requires_grad_(True)
     nh = t64(rng.standard_normal((T, N))).requires_grad_(True)
-    f = lambda a, b: _final_pass_torch(lg, gg, expfam.pack_dense(a, b), r)[2]
+    f = lambda a, b: final_pass_torch(lg, gg, expfam.pack_dense(a, b), r)[2]
     assert torch.autograd.gradcheck(f, (nJ, nh), eps=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("K,N,T,S", [(5, 2, 300, 1), (3, 1, 7, 2), (15, 2, 50, 3), (4, 3, 33, 2), (6, 5, 20, 1), (2, 8, 9, 2),
+                                     (20, 2, 40, 0)])
+def test_gmm_local_step_kernels_against_torch_autograd(K, N, T, S):
+    """run_inference_differentiable (fixed point + final pass, svae_gmm_sample_f64, and in backward()
+    svae_gmm_local_vjp_f64) against the same tail written in torch on the autograd tape (tests/_gmm_torch.py:
+    gmm.py:74-86 + gaussian.py:27-33): samples, local KL, and the gradients of a random functional of both w.r.t. the
+    node potentials, for N = 1 .. 8, any K, with and without sample cotangents."""
+    from _gmm_torch import final_pass_torch, sample_torch
+    from svae_amd.distributions import expfam
+    from svae_amd.models import gmm
+    rng = np.random.default_rng(100 * K + 10 * N + S)
+    gen = torch.Generator().manual_seed(K + N)
+    prior = gmm.init_pgm_param(K, N, alpha=0.5, niw_conc=1.0, generator=gen)
+    glob = gmm.init_pgm_param(K, N, alpha=1.0, niw_conc=2.0, random_scale=2.0, generator=gen)
+    glob = tuple(x.to(DEV) for x in glob)
+    nJ = t64(-0.5 * np.log1p(np.exp(rng.standard_normal((T, N))))).requires_grad_(True)
+    nh = t64(2 * rng.standard_normal((T, N))).requires_grad_(True)
+    init = t64(rng.random((T, K))); init = init / init.sum(-1, keepdim=True)
+    eps = t64(rng.standard_normal((T, max(S, 1), N)))
+    wS, wk = t64(rng.standard_normal((T, max(S, 1), N))), 0.7
+    samples, stats, gkl, lkl = gmm.run_inference_differentiable(prior, glob, (nJ, nh), max(S, 1), label_init=init, eps=eps)
+    loss = wk * lkl + ((wS * samples).sum() if S else 0.0)
+    gJ, gh = torch.autograd.grad(loss, [nJ, nh])
+    # the same tail on the tape, from the same fixed point
+    lg, gg = expfam.dirichlet_expectedstats(glob[0]), expfam.niw_expectedstats(glob[1])
+    o = gmm.meanfield_from_globals(lg, gg, (nJ.detach(), nh.detach()), init)
+    a, b = nJ.detach().clone().requires_grad_(True), nh.detach().clone().requires_grad_(True)
+    _, (_, natp), kl_t = final_pass_torch(lg, gg, expfam.pack_dense(a, b), o["label_fixed"])
+    smp_t = sample_torch(natp, eps)
+    loss_t = wk * kl_t + ((wS * smp_t).sum() if S else 0.0)
+    wJ, wh = torch.autograd.grad(loss_t, [a, b])
+    rel = lambda x, y: float((x - y).abs().max() / y.abs().max().clamp_min(1e-300))
+    assert rel(samples, smp_t) < 1e-10 and abs(float(lkl) - float(kl_t)) < 1e-9 * max(1.0, abs(float(kl_t)))
+    assert rel(gJ, wJ) < 1e-8, rel(gJ, wJ)
+    assert rel(gh, wh) < 1e-8, rel(gh, wh)
 
 
 def _lds_problem(n=3, p=4, T=6, Bn=2, seed=0):
