@@ -120,6 +120,14 @@ def measure(dev, rank, world, dist, options, T, n, B, steps, warmup):
         if world > 1:
             allreduce_global_stats(packed)
 
+    # Clock spin-up, untimed and outside the driver's warm-up count: a 20-step run of a 0.15 ms kernel is over in 3 ms,
+    # before the shader clock has left its idle state (measured: 148.6 us per launch in such a run, 142 us in a 200-step
+    # one) -- >= 60 ms of the same launches first.
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < 0.06:
+        for _ in range(8):
+            plan.launch(d_init[0], d_init[1], d_init[2], d_pair[0], d_pair[1], d_pair[2], d_pair[3], d_J, d_h, None)
+        torch.cuda.synchronize()
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
@@ -304,6 +312,35 @@ def measure_gmm(dev, K=5, N=2, T=1000):
             "us_per_fixed_point": us, "sweeps": int(o["iters"]), "path": o["path"], "value": T / us * 1e6, "unit": "points/s"}
 
 
+def measure_gmm_training(dev, K=5, N=2, T=1000, S=1):
+    """BASELINE configs[0] through the whole differentiable local step (gmm.run_inference_differentiable + backward):
+    global maps, fixed point + final pass, sampler, and the derived adjoint kernel -- us per step, wall clock."""
+    from svae_amd.models import gmm
+    gen = torch.Generator().manual_seed(K)
+    prior = gmm.init_pgm_param(K, N, alpha=0.05 / K, niw_conc=0.5, generator=gen)
+    glob = tuple(x.to(dev) for x in gmm.init_pgm_param(K, N, alpha=0.05 / K, niw_conc=0.5, random_scale=3., generator=gen))
+    prior = tuple(x.to(dev) for x in prior)
+    rng = np.random.default_rng(0)
+    nJ = torch.as_tensor(-0.5 * np.log1p(np.exp(rng.standard_normal((T, N)))), device=dev).requires_grad_(True)
+    nh = torch.as_tensor(3. * rng.standard_normal((T, N)), device=dev).requires_grad_(True)
+    init = gmm.initialize_meanfield(T, K, dev, torch.Generator(device=dev).manual_seed(1))
+    eps = torch.randn(T, S, N, dtype=torch.float64, device=dev)
+    gs = torch.randn(T, S, N, dtype=torch.float64, device=dev)
+
+    def it():
+        samples, stats, gkl, lkl = gmm.run_inference_differentiable(prior, glob, (nJ, nh), S, label_init=init, eps=eps)
+        return torch.autograd.grad(lkl + (samples * gs).sum(), [nJ, nh])
+    it(); it(); torch.cuda.synchronize()
+    times = []
+    for _ in range(7):
+        t0 = time.perf_counter(); it(); torch.cuda.synchronize()
+        times.append((time.perf_counter() - t0) * 1e6)
+    us = sorted(times)[len(times) // 2]
+    return {"workload": "BASELINE configs[0], training step of the local model: global maps + fixed point + final pass + "
+                        "sampler + adjoint kernel, K=%d, %d-D, %d points, %d sample" % (K, N, T, S),
+            "us_per_step": us, "value": T / us * 1e6, "unit": "points/s"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -379,10 +416,11 @@ def main():
                 torch.cuda.empty_cache()
             # the other BASELINE configurations and the training path: measured beside `value`, never instead of it
             # (order kept across rounds: [2] training path, [3] tile training, [4] SLDS, [5] GMM, [6] training path at 4096,
-            #  [7] tile training at one workgroup per CU)
+            #  [7] tile training at one workgroup per CU, [8] GMM training step)
             for fn in (lambda: measure_training_path(dev, T, n, B), lambda: measure_tile_training(dev),
                        lambda: measure_slds(dev), lambda: measure_gmm(dev),
-                       lambda: measure_training_path(dev, T, n, 4096), lambda: measure_tile_training(dev, B=256)):
+                       lambda: measure_training_path(dev, T, n, 4096), lambda: measure_tile_training(dev, B=256),
+                       lambda: measure_gmm_training(dev)):
                 try:
                     extra.append(fn())
                 except Exception as e:
