@@ -28,7 +28,7 @@ constexpr long te_chain_doubles(int n, int T) {
 constexpr long te_seq_doubles(int n, int T) { return 2 * te_chain_doubles(n, T); }
 constexpr int TE_MAX_N = 10;
 constexpr int TE_MIN_T = 4;
-constexpr int TE_S4_LDS_BYTES = 10 * 1024;   // static LDS of an S4 workgroup (transposition tiles, exchange buffer), rounded up
+constexpr int TE_S4_LDS_BYTES = 14 * 1024;   // static LDS of an S4 workgroup (transposition tiles, exchange buffer), rounded up
 constexpr int TE_S4_MAX_B = 512;     // two-ended kernel: second wavefront per sequence in the smoother phase up to this batch
 constexpr int TE_RPC_MIN_B = 1025;   // two-ended kernel: two sequences per wavefront (row-per-chain layout) from this batch
                                      // (measured T = 200, n = 10: 1024 sequences 0.200 vs 0.237 ms, 1536: 0.321 vs 0.272 ms)

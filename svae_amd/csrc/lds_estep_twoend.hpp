@@ -169,7 +169,7 @@ __global__ __launch_bounds__(MIX ? 512 : (S4 ? 128 : 64)) void lds_estep_twoend_
   constexpr int J1 = (N + 2) / 2;         // slots holding rows 0..N
   constexpr int HL = 15;                  // lane of the h column
   constexpr int RSL = (N + 3) & ~1;       // LDS row stride of the transposition tile (even, >= N + 1)
-  __shared__ double tab_static[MIX ? 2 : 2 * 16 * 16];   // [chain][row 0..15][RSL]: G~ rows for the transposed read
+  __shared__ double tab_static[MIX ? 2 : (S4 ? 4 : 2) * 16 * 16];   // [chain][row 0..15][RSL]: G~ rows for the transposed read (S4: + the gather tiles)
   __shared__ double xch_static[S4 ? 2 * ((N + 3) / 4) * 64 + 256 : 2];   // S4: chain B's sums on their way to chain A
   extern __shared__ double2 te_dyn[];     // MIX: the parameter tables (te_mix_lds_bytes)
 
@@ -191,11 +191,11 @@ __global__ __launch_bounds__(MIX ? 512 : (S4 ? 128 : 64)) void lds_estep_twoend_
   if constexpr (S4) {
     const int e_ = te_elims(a.T);
     keep = a.lds_keep < e_ + 1 ? a.lds_keep : e_ + 1;
-    if (keep < 2) keep = 0;
+    if (keep < 3) keep = 0;
     if (wv == 1) {                        // chain B's smoother wavefront: sleeps until the records are complete
       __syncthreads();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      te_smooth4<N>(a, b, 1, lane, tab_static + 256, xch_static, lrecs, keep);
+      te_smooth4<N>(a, b, 1, lane, tab_static + 256, tab_static + 768, xch_static, lrecs, keep);
       return;
     }
   }
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(MIX ? 512 : (S4 ? 128 : 64)) void lds_estep_twoend_
   if constexpr (S4) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
-    te_smooth4<N>(a, b, 0, lane, tab_static, xch_static, lrecs, keep);
+    te_smooth4<N>(a, b, 0, lane, tab_static, tab_static + 512, xch_static, lrecs, keep);
     return;
   }
 
@@ -978,7 +978,7 @@ static int launch_estep_twoend(const LdsArgs& a, bool inhomog, bool lean, hipStr
       keep = SVAE_S4_KEEP_OVERRIDE;      // (experiments: tools/build_variant.sh ... -DSVAE_S4_KEEP_OVERRIDE=<records>)
 #endif
       if (keep > te_elims(a.T) + 1) keep = te_elims(a.T) + 1;
-      if (keep < 2) keep = 0;
+      if (keep < 3) keep = 0;
       LdsArgs a2 = a;
       a2.lds_keep = (int)keep;
       const long bytes = keep * rec_bytes + (keep > 0 ? 64 * sizeof(double) : 0);    // + one dummy slot per lane

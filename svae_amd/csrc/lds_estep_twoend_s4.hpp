@@ -5,8 +5,10 @@
 // two chains' smoothers are independent, so the workgroup carries a second wavefront that sleeps at a barrier
 // through the elimination phase and then takes chain B's smoother while the first keeps chain A's: each chain now
 // owns all FOUR DPP rows of its wavefront, every product stage is split by output row over four rows instead of
-// two (row i of a tile lives in DPP row i & 3, slot i >> 2): 96 instead of 182 DPP multiply-adds per step, the
-// all-gather of a slot tile is v_permlane16_swap + v_permlane32_swap.  Same recursion, same accumulation order per
+// two (row i of a tile lives in DPP row i & 3, slot i >> 2): 96 instead of 182 DPP multiply-adds per step; the
+// all-gather of the one tile that sits on the recursion's serial chain goes through LDS, its round trip covered by the
+// preparation of the next step (round 4; as v_permlane16/32_swap shuffles it was 36 of 194 instructions).  Same
+// recursion, same accumulation order per
 // output element as the two-row smoother (moment form on homogeneous coordinates:
 // cython_lds_inference.pyx:149-210 is what it replaces), same lean hand-off records.
 // Homogeneous parameters, lean records, statistics summed over time (the headline configuration).
@@ -15,7 +17,8 @@
 
 namespace svae {
 
-// x: one value per DPP row  ->  the four rows' values, each replicated over the wavefront.
+// x: one value per DPP row  ->  the four rows' values, each replicated over the wavefront (register shuffles: used by the
+// reverse-mode sweeps, lds_vjp_kernel.hpp; the smoother below gathers through LDS instead).
 // v_permlane16_swap(x, x) leaves the even rows' values replicated over their row pairs in its first result and the
 // odd rows' in its second; v_permlane32_swap(y, y) replicates the lower / upper half of y.
 __device__ __forceinline__ void quad_gather(double x, double& r0, double& r1, double& r2, double& r3) {
@@ -39,18 +42,20 @@ __device__ __forceinline__ double reg_copy(double x) {       // a copy the compi
 }
 
 // dir = the chain (0: A, forward in time; 1: B, reversed) = the wavefront's index in the workgroup.
-// tabw: 16 x RSL doubles of LDS of this wavefront, zero-initialised;  xch: exchange buffer of the workgroup.
+// tabw: 16 x RSL doubles of LDS of this wavefront, zero-initialised;  wtw: 16 x RSL more (the gather tile of the
+// software-pipelined steps, any contents);  xch: exchange buffer of the workgroup.
 // Both wavefronts of the workgroup call this function; it contains ONE __syncthreads().
 // lrecs / keep: the last `keep` records of each chain (local steps e+1-keep .. e, the ones read first) live in LDS
-// ([chain][slot][WS] doubles, written by the elimination phase) instead of the HBM workspace; keep = 0 or >= 2.
+// ([chain][slot][WS] doubles, written by the elimination phase) instead of the HBM workspace; keep = 0 or >= 3.
 template <int N>
 __device__ __forceinline__ void te_smooth4(const LdsArgs& a, const int b, const int dir, const int lane,
-                                           double* tabw, double* xch, const double* lrecs, const int keep) {
+                                           double* tabw, double* wtw, double* xch, const double* lrecs, const int keep) {
   constexpr int ZP = te_page_doubles(N), WS = te_lean_step_doubles(N);
   constexpr int TRI = N * (N + 1) / 2, LZERO = TRI + N;
   constexpr int J = (N + 3) / 4;          // slots holding rows 0..N-1 (row i = 4j + r)
   constexpr int J1 = (N + 4) / 4;         // slots holding rows 0..N
   constexpr int RSL = (N + 3) & ~1;       // LDS row stride of the transposition tile
+  constexpr int RSW = 4 * ((N + 4) / 4);  // row stride of the gather tile: every slot row 4j + r, j < J1, has its own entry
   constexpr int NS = N >> 2, NR = N & 3;  // row N of the homogeneous tile: slot NS of DPP row NR
   const int c = lane & 15, r = lane >> 4;
   const bool col = c < N;
@@ -121,81 +126,6 @@ __device__ __forceinline__ void te_smooth4(const LdsArgs& a, const int b, const 
     nextrec -= nextrec > 0 ? 1 : 0;
   };
 
-  // one smoother step.  KIND: 0 generic, 1 first (meeting record: G = 0), 2 second (weight of the repeated pair)
-  auto core = [&](auto kind, int s, Ops& cur) {
-    constexpr int KIND = decltype(kind)::value;
-    // G~ rows of this DPP row: X[i][c] = sum_k P^-1[i][k] J12'[k][c] (lanes < N), c_i (lane N); row N = e_N
-    double Gc[J1], H[N + 1];
-    static_for<0, J1>([&](auto j) { Gc[j] = (j == NS) ? __builtin_fma(EN, cur.Pi[j], CN) : EN * cur.Pi[j]; });
-    if (KIND != 1) {
-      dpp_fence(cur.Pi);
-      static_for<0, N>([&](auto k) {
-        static_for<0, J>([&](auto j) { mac_bc<k, true>(Gc[j], cur.Pi[j], NJ12c[k]); });
-      });
-    }
-    // transposed, replicated copy through LDS: H[k][lane c] = G~[c][k]
-    __builtin_amdgcn_wave_barrier();
-    static_for<0, J1>([&](auto j) { tabw[(4 * j + r) * RSL + c] = Gc[j]; });
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    static_for<0, (N + 2) / 2>([&](auto q) {
-      const double2 v = reinterpret_cast<const double2*>(tabw + c * RSL)[q];
-      H[2 * q] = v.x;
-      if constexpr (2 * q + 1 <= N) H[2 * q + 1] = v.y;
-    });
-    __builtin_amdgcn_wave_barrier();
-
-    // W~[i] = S~[i] G~'  for my rows
-    double W[J1];
-    static_for<0, J1>([&](auto j) { W[j] = 0.0; });
-    asm volatile("s_nop 1");
-    static_for<0, N + 1>([&](auto k) {
-      static_for<0, J1>([&](auto j) { mac_bc<k, (k < N)>(W[j], S[j], H[k]); });
-    });
-    dpp_fence(W);
-    if constexpr (KIND == 0) static_for<0, J>([&](auto j) { sumW[j] += W[j]; });
-    double WR[4 * J1];
-    static_for<0, J1>([&](auto j) { quad_gather(W[j], WR[4 * j], WR[4 * j + 1], WR[4 * j + 2], WR[4 * j + 3]); });
-    // S~_t[i] = P^-1[i] + G~[i] W~
-    double Sn[J1];
-    static_for<0, J1>([&](auto j) { Sn[j] = __builtin_fma(-EN, cur.Pi[j], cur.Pi[j]); });
-    asm volatile("s_nop 1");
-    static_for<0, N + 1>([&](auto k) {
-      static_for<0, J1>([&](auto j) { mac_bc<k, (k < N)>(Sn[j], Gc[j], WR[k]); });
-    });
-
-    if constexpr (KIND == 1) {
-      static_for<0, J>([&](auto j) { Stop[j] = Sn[j]; });
-    } else if constexpr (KIND == 2) {
-      static_for<0, J>([&](auto j) {
-        sumS[j] = wsp * Sn[j];
-        sumW[j] = wsp * W[j];
-        Stop[j] = __builtin_fma(wsp, Stop[j], __builtin_fma(-wsp, Sn[j], Sn[j]));
-      });
-    } else {
-      static_for<0, J>([&](auto j) { sumS[j] += Sn[j]; });
-    }
-
-    // node statistics: diag E[x_t x_t'] (lane i of DPP row i & 3), E[x_t] = row N
-    double dg = 0.0;
-    static_for<0, J>([&](auto j) { dg = __builtin_fma(ED[j], Sn[j], dg); });
-    *pdg = dg;
-    *pex = Sn[NS];
-    if constexpr (KIND == 1) node_ptrs(e - 1);
-    else { pdg += dlane ? nstride : 0; pex += xlane ? nstride : 0; }
-    static_for<0, J1>([&](auto j) { S[j] = Sn[j]; });
-  };
-  // a step on a record of the HBM ring
-  auto step = [&](auto kind, int s, Ops& stage) {
-    // (an explicit register copy: the stage's live range ends HERE, so the refill below can land in the same
-    //  registers and the loop-carried value needs no copy at the back edge -- a compiler-made copy of a freshly
-    //  loaded register there costs a wait for the youngest load, i.e. the whole prefetch distance)
-    Ops cur;
-    static_for<0, J1>([&](auto j) { cur.Pi[j] = reg_copy(stage.Pi[j]); });
-    load_ops(stage);                         // refill the stage with the record four steps further down
-    core(kind, s, cur);
-  };
   // records kept in LDS: read one step ahead (slot of local step s = s - s0, clamped: the prefetch past the window
   // is never used)
   unsigned lpoff[J1];
@@ -206,50 +136,152 @@ __device__ __forceinline__ void te_smooth4(const LdsArgs& a, const int b, const 
     static_for<0, J1>([&](auto j) { o.Pi[j] = *reinterpret_cast<const double*>(base + lpoff[j]); });
   };
 
+  // ---- SOFTWARE-PIPELINED steps -------------------------------------------------------------------------------------
+  // The products of a step split its rows over the four DPP rows, so W~ has to be all-gathered between them -- on the
+  // serial chain S~ -> W~ -> S~.  As register shuffles (quad_gather above) that is 36 of the step's 194 instructions.
+  // Here the gather goes through LDS instead (3 stores, 6 16-byte loads: lane c stores W~[i][c] at [c][i] and reads
+  // back row [c][0..N] = column c of every row) and its round trip is covered by work that does not depend on the
+  // recursion: the PREPARATION of the next step -- G~ of record s-1 rebuilt from its lean record (one split product)
+  // and transposed through the other LDS tile -- issued between the stores and the first use of the gathered tile.
+  struct Prep { double Gc[J1], H[N + 1], PiZ[J1]; };
+  // operands of the step on record `pi`: G~ rows (slot layout), its transposed replicated copy H, P^-1 rows
+  auto prep_products = [&](auto first, const Ops& pi, Prep& p) {          // VALU part + the tile stores
+    static_for<0, J1>([&](auto j) { p.Gc[j] = (j == NS) ? __builtin_fma(EN, pi.Pi[j], CN) : EN * pi.Pi[j]; });
+    if constexpr (!decltype(first)::value) {
+      double piv[J1];
+      static_for<0, J1>([&](auto j) { piv[j] = pi.Pi[j]; });
+      dpp_fence(piv);
+      static_for<0, N>([&](auto k) {
+        static_for<0, J>([&](auto j) { mac_bc<k, true>(p.Gc[j], piv[j], NJ12c[k]); });
+      });
+    }
+    static_for<0, J1>([&](auto j) { p.PiZ[j] = __builtin_fma(-EN, pi.Pi[j], pi.Pi[j]); });
+    __builtin_amdgcn_wave_barrier();
+    static_for<0, J1>([&](auto j) { tabw[(4 * j + r) * RSL + c] = p.Gc[j]; });
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  auto prep_read = [&](Prep& p) {
+    static_for<0, (N + 2) / 2>([&](auto q) {
+      const double2 v = reinterpret_cast<const double2*>(tabw + c * RSL)[q];
+      p.H[2 * q] = v.x;
+      if constexpr (2 * q + 1 <= N) p.H[2 * q + 1] = v.y;
+    });
+    __builtin_amdgcn_wave_barrier();
+  };
+  // one step on the prepared operands `p` (record s); on return p holds the operands of record s-1 (from `nxt`)
+  auto pstep = [&](auto kind, int s, Prep& p, const Ops& nxt) {
+    constexpr int KIND = decltype(kind)::value;
+    // W~[i] = S~[i] G~'  for my rows
+    double W[J1];
+    static_for<0, J1>([&](auto j) { W[j] = 0.0; });
+    asm volatile("s_nop 1");
+    static_for<0, N + 1>([&](auto k) {
+      static_for<0, J1>([&](auto j) { mac_bc<k, (k < N)>(W[j], S[j], p.H[k]); });
+    });
+    // all-gather through LDS: store [c][i], read back [c][0..N]
+    __builtin_amdgcn_wave_barrier();
+    static_for<0, J1>([&](auto j) { wtw[c * RSW + 4 * j + r] = W[j]; });
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double WR[N + 2];
+    static_for<0, (N + 2) / 2>([&](auto q) {
+      const double2 v = reinterpret_cast<const double2*>(wtw + c * RSW)[q];
+      WR[2 * q] = v.x;
+      WR[2 * q + 1] = v.y;
+    });
+    __builtin_amdgcn_wave_barrier();
+    if constexpr (KIND == 0) static_for<0, J>([&](auto j) { sumW[j] += W[j]; });
+    double Wk[J];
+    static_for<0, J>([&](auto j) { Wk[j] = W[j]; });
+    // this step's G~ rows / P^-1 rows move out of `p`, which takes the next step's operands while the gather is in flight
+    double Gc[J1], Sn[J1];
+    static_for<0, J1>([&](auto j) { Gc[j] = p.Gc[j]; Sn[j] = p.PiZ[j]; });
+    prep_products(std::false_type{}, nxt, p);
+    prep_read(p);
+    // S~_t[i] = P^-1[i] + G~[i] W~
+    dpp_fence(Gc);
+    static_for<0, N + 1>([&](auto k) {
+      static_for<0, J1>([&](auto j) { mac_bc<k, (k < N)>(Sn[j], Gc[j], WR[k]); });
+    });
+    if constexpr (KIND == 1) {
+      static_for<0, J>([&](auto j) { Stop[j] = Sn[j]; });
+    } else if constexpr (KIND == 2) {
+      static_for<0, J>([&](auto j) {
+        sumS[j] = wsp * Sn[j];
+        sumW[j] = wsp * Wk[j];
+        Stop[j] = __builtin_fma(wsp, Stop[j], __builtin_fma(-wsp, Sn[j], Sn[j]));
+      });
+    } else {
+      static_for<0, J>([&](auto j) { sumS[j] += Sn[j]; });
+    }
+    double dg = 0.0;
+    static_for<0, J>([&](auto j) { dg = __builtin_fma(ED[j], Sn[j], dg); });
+    *pdg = dg;
+    *pex = Sn[NS];
+    if constexpr (KIND == 1) node_ptrs(e - 1);
+    else { pdg += dlane ? nstride : 0; pex += xlane ? nstride : 0; }
+    static_for<0, J1>([&](auto j) { S[j] = Sn[j]; });
+  };
+  // a step whose NEXT record sits in `stage` of the HBM ring (copied out, then the stage is refilled four records on)
+  auto rstep = [&](auto kind, int s, Prep& p, Ops& stage) {
+    Ops nxt;
+    static_for<0, J1>([&](auto j) { nxt.Pi[j] = reg_copy(stage.Pi[j]); });
+    load_ops(stage);
+    pstep(kind, s, p, nxt);
+  };
   constexpr std::integral_constant<int, 0> GEN{};
+  constexpr std::integral_constant<int, 1> FIRST{};
+  constexpr std::integral_constant<int, 2> SECOND{};
+  Ops R0, R1, R2, R3;
+  Prep P;
+  int s;
   if (keep > 0) {
-    Ops R0, R1, R2, R3, LA, LB;
+    // records e .. s0 in LDS (keep >= 3: the first two steps find their next record there), s0-1 .. 0 in the HBM ring
     if (s0 > 0) { load_ops(R0); load_ops(R1); load_ops(R2); load_ops(R3); }   // HBM records s0-1 .. s0-4: long on their way
-    lds_ops(LA, e);
-    lds_ops(LB, e - 1);
-    core(std::integral_constant<int, 1>{}, e, LA);
-    lds_ops(LA, e - 2);
-    core(std::integral_constant<int, 2>{}, e - 1, LB);
-    int s = e - 2;
-    for (; s - 1 >= s0; s -= 2) {      // LA holds record s
-      lds_ops(LB, s - 1);
-      core(GEN, s, LA);
-      lds_ops(LA, s - 2);
-      core(GEN, s - 1, LB);
+    Ops nx;
+    lds_ops(nx, e);
+    prep_products(std::true_type{}, nx, P);                        // the meeting record: G = 0
+    prep_read(P);
+    lds_ops(nx, e - 1);
+    pstep(FIRST, e, P, nx);
+    lds_ops(nx, e - 2);
+    pstep(SECOND, e - 1, P, nx);
+    for (s = e - 2; s - 1 >= s0; --s) {
+      lds_ops(nx, s - 1);
+      pstep(GEN, s, P, nx);
     }
-    if (s >= s0) { core(GEN, s, LA); --s; }
-    for (; s >= 3; s -= 4) {           // s = s0 - 1: the HBM ring (R0 holds record s)
-      step(GEN, s, R0);
-      step(GEN, s - 1, R1);
-      step(GEN, s - 2, R2);
-      step(GEN, s - 3, R3);
+    // s == s0: the next records come from the ring (s0 == 0: none is needed, any valid record will do)
+    if (s0 == 0) {
+      lds_ops(nx, 0);
+      pstep(GEN, 0, P, nx);
+      s = -1;
     }
-    if (s >= 0) step(GEN, s, R0);
-    if (s >= 1) step(GEN, s - 1, R1);
-    if (s >= 2) step(GEN, s - 2, R2);
   } else {
-    Ops R0, R1, R2, R3;
     load_ops(R0); load_ops(R1); load_ops(R2); load_ops(R3);       // records e, e-1, e-2, e-3
-    step(std::integral_constant<int, 1>{}, e, R0);
-    step(std::integral_constant<int, 2>{}, e - 1, R1);
-    step(GEN, e - 2, R2);                                         // (e >= 2: T >= TE_MIN_T)
-    int s = e - 3;
-    if (s >= 0) { step(GEN, s, R3); --s; }
-    for (; s >= 3; s -= 4) {           // four steps per trip, no branch inside (hipcc's wait counts stay exact)
-      step(GEN, s, R0);
-      step(GEN, s - 1, R1);
-      step(GEN, s - 2, R2);
-      step(GEN, s - 3, R3);
+    {
+      Ops first;
+      static_for<0, J1>([&](auto j) { first.Pi[j] = reg_copy(R0.Pi[j]); });
+      load_ops(R0);                                                // record e-4
+      prep_products(std::true_type{}, first, P);                   // the meeting record: G = 0
+      prep_read(P);
     }
-    if (s >= 0) step(GEN, s, R0);
-    if (s >= 1) step(GEN, s - 1, R1);
-    if (s >= 2) step(GEN, s - 2, R2);
+    rstep(FIRST, e, P, R1);                                        // next: record e-1
+    rstep(SECOND, e - 1, P, R2);                                   // (e >= 2: T >= TE_MIN_T)
+    s = e - 2;
+    if (s >= 0) { rstep(GEN, s, P, R3); --s; }                     // next: e-3 (s = 0: the clamped ring re-reads record 0, unused)
   }
+  for (; s >= 3; s -= 4) {             // four steps per trip, no branch inside (hipcc's wait counts stay exact)
+    rstep(GEN, s, P, R0);
+    rstep(GEN, s - 1, P, R1);
+    rstep(GEN, s - 2, P, R2);
+    rstep(GEN, s - 3, P, R3);
+  }
+  if (s >= 0) rstep(GEN, s, P, R0);
+  if (s >= 1) rstep(GEN, s - 1, P, R1);
+  if (s >= 2) rstep(GEN, s - 2, P, R2);
 
   // ---- global statistics: chain B's sums travel to chain A's wavefront through LDS ---------------------------
   // S = S~ at the chain's end node (x_0 for A, x_{T-1} for B).  sumS = sum S~(s) over the chain's counted steps,
