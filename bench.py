@@ -341,6 +341,79 @@ def measure_gmm_training(dev, K=5, N=2, T=1000, S=1):
             "us_per_step": us, "value": T / us * 1e6, "unit": "points/s"}
 
 
+def measure_gradfun_step(dev, B=512, T=200, n=10, p=20, hidden=32, reps=9):
+    """One END-TO-END training step of the LDS-SVAE at the headline shape (BASELINE configs[1]: latent dim 10, obs dim 20,
+    512 sequences x T=200), driven through svae_amd.svae.make_gradfun (/root/reference/svae/svae.py:10-39): recognition
+    MLPs (stock torch) -> global-step kernel -> E-step keeping the hand-off -> sampler -> decoder MLP + ELBO -> autograd
+    backward through the VJP kernels -> natural-gradient kernel.  Wall clock per step, eager and -- if the whole step
+    captures -- replayed as ONE hipGraph (torch.cuda.CUDAGraph: the library's launches, incl. its helper-stream
+    fork / joins, are recorded from the capturing stream)."""
+    import functools
+    from svae_amd import svae
+    from svae_amd.lds.lds_inference import LDSEStepPlan
+    from svae_amd.models import lds
+    gen = torch.Generator(device=dev).manual_seed(0)
+    data = torch.randn(B, T, p, dtype=torch.float64, device=dev, generator=gen)
+    prior = tuple(x.to(dev) if isinstance(x, torch.Tensor) else tuple(y.to(dev) for y in x) for x in lds.make_prior_natparam(n))
+    pgm = tuple(x.clone() if isinstance(x, torch.Tensor) else tuple(y.clone() for y in x) for x in prior)
+    mlp = lambda sizes: [(0.3 * torch.randn(a, b, dtype=torch.float64, device=dev, generator=gen) / np.sqrt(a)).requires_grad_(True)
+                         for a, b in zip(sizes[:-1], sizes[1:])]
+
+    # (svae_amd.nnet.linear: x @ w whose weight gradient avoids rocBLAS's fp64 path for a 10^5-row reduction axis, 11 ms
+    #  per layer at this shape; the networks themselves are stock torch, out of the library's scope)
+    from svae_amd.nnet import gaussian_info, tanh_mlp
+    recogn, decoder = (mlp([p, hidden, n]), mlp([p, hidden, n])), mlp([n, hidden, p])
+    recognize = gaussian_info
+    loglike = lambda params, samples, batch: -0.5 * ((batch.unsqueeze(2) - tanh_mlp(params, samples)) ** 2).sum() / samples.shape[2]
+    plan = LDSEStepPlan(B, T, n, dev)
+    eps = torch.randn(B, T, 1, n, dtype=torch.float64, device=dev, generator=gen)
+    run = functools.partial(lds.run_inference_differentiable, plan=plan, eps=eps)
+    gradfun = svae.make_gradfun(run, recognize, loglike, prior, data, B, 1, natgrad_scale=1e2, callback=None, permute=False)
+    params = (pgm, decoder, recogn)
+    for _ in range(3):
+        gradfun(params, 0)
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); gradfun(params, 0); torch.cuda.synchronize()
+        times.append((time.perf_counter() - t0) * 1e3)
+    eager = sorted(times)[len(times) // 2]
+    out = {"workload": "end-to-end LDS-SVAE training step through make_gradfun: recognition MLPs + global step + E-step + "
+                       "sampler + decoder + backward (VJP kernels) + natural gradient, %d sequences x T=%d, n=%d, obs dim %d"
+                       % (B, T, n, p),
+           "eager_ms_per_step": eager, "graph_ms_per_step": None, "graph_error": None,
+           "value": B / eager * 1e3, "unit": "sequences/s"}
+    try:
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                gradfun(params, 0)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            captured = gradfun(params, 0)
+        graph.replay(); torch.cuda.synchronize()
+        eager_out = gradfun(params, 0)
+        torch.cuda.synchronize()
+        same = all(torch.allclose(a, b, rtol=1e-12, atol=0) for a, b in zip(svae._leaves(captured), svae._leaves(eager_out)))
+        times = []
+        for _ in range(reps):
+            t0 = time.perf_counter(); graph.replay(); torch.cuda.synchronize()
+            times.append((time.perf_counter() - t0) * 1e3)
+        out["graph_ms_per_step"] = sorted(times)[len(times) // 2]
+        out["graph_matches_eager"] = bool(same)
+        out["value"] = B / out["graph_ms_per_step"] * 1e3
+    except Exception as e:      # the eager number stands on its own
+        out["graph_error"] = repr(e)[:300]
+        try:
+            torch.cuda.synchronize()
+        except Exception:
+            pass
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -416,11 +489,11 @@ def main():
                 torch.cuda.empty_cache()
             # the other BASELINE configurations and the training path: measured beside `value`, never instead of it
             # (order kept across rounds: [2] training path, [3] tile training, [4] SLDS, [5] GMM, [6] training path at 4096,
-            #  [7] tile training at one workgroup per CU, [8] GMM training step)
+            #  [7] tile training at one workgroup per CU, [8] GMM training step, [9] end-to-end make_gradfun step, eager and as one hipGraph)
             for fn in (lambda: measure_training_path(dev, T, n, B), lambda: measure_tile_training(dev),
                        lambda: measure_slds(dev), lambda: measure_gmm(dev),
                        lambda: measure_training_path(dev, T, n, 4096), lambda: measure_tile_training(dev, B=256),
-                       lambda: measure_gmm_training(dev)):
+                       lambda: measure_gmm_training(dev), lambda: measure_gradfun_step(dev)):
                 try:
                     extra.append(fn())
                 except Exception as e:

@@ -40,9 +40,8 @@ def mlp(sizes, gen, dev):
 
 
 def forward(ws, x):
-    for w in ws[:-1]:
-        x = torch.tanh(x @ w)
-    return x @ ws[-1]
+    from svae_amd.nnet import tanh_mlp        # x @ w layers whose weight gradient avoids rocBLAS's long-reduction fp64 path
+    return tanh_mlp(ws, x)
 
 
 def main(argv=None):

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SVAE_HIP_ABI_VERSION 10   /* 10: + svae_gmm_sample_f64, svae_gmm_local_vjp_f64 (the differentiable tail of the GMM local step); 9: keep bit SVAE_KEEP_SIGMA of svae_lds_estep_f64 (16 <= n <= 64) + svae_lds_tile_sigma_offset_bytes; 8: step ranges (t_begin, t_end) in svae_lds_tile_vjp_f64 / svae_lds_tile_noise_f64, SVAE_OPT_TILE_FORWARD / _BACKWARD; 7: + svae_slds_path_nodeparams_f64, svae_slds_mix_pair_natparam_f64; 6: per-call `options` word replaces the process-global svae_lds_set_* selectors (re-entrant library), + svae_slds_hmm_meanfield_f64, svae_slds_sweep_glue_f64, g_E_pair in svae_lds_tile_vjp_f64; 5: + svae_lds_set_prod_max_b; 4: + svae_slds_lds_meanfield_f64, svae_gmm_mw_*, svae_lds_global_step_f64, svae_lds_natgrad_f64, svae_lds_tile_vjp_f64; 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
+#define SVAE_HIP_ABI_VERSION 10   /* 10: + svae_gmm_sample_f64, svae_gmm_local_vjp_f64, svae_gmm_global_step_f64 (the differentiable tail and the global side of the GMM local step); 9: keep bit SVAE_KEEP_SIGMA of svae_lds_estep_f64 (16 <= n <= 64) + svae_lds_tile_sigma_offset_bytes; 8: step ranges (t_begin, t_end) in svae_lds_tile_vjp_f64 / svae_lds_tile_noise_f64, SVAE_OPT_TILE_FORWARD / _BACKWARD; 7: + svae_slds_path_nodeparams_f64, svae_slds_mix_pair_natparam_f64; 6: per-call `options` word replaces the process-global svae_lds_set_* selectors (re-entrant library), + svae_slds_hmm_meanfield_f64, svae_slds_sweep_glue_f64, g_E_pair in svae_lds_tile_vjp_f64; 5: + svae_lds_set_prod_max_b; 4: + svae_slds_lds_meanfield_f64, svae_gmm_mw_*, svae_lds_global_step_f64, svae_lds_natgrad_f64, svae_lds_tile_vjp_f64; 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
 #define SVAE_LDS_MAX_N 15   /* register/DPP path: one 16-lane row per sequence, n+1 <= 16 */
 #define SVAE_LDS_TILE_MAX_N 64   /* 16 <= n <= 64: LDS-tiled MFMA path (keep: SVAE_KEEP_SIGMA or 0) */
 #define SVAE_KEEP_SIGMA 4         /* keep bit of svae_lds_estep_f64, 16 <= n <= 64 only: see svae_lds_tile_sigma_offset_bytes */
@@ -448,7 +448,15 @@ int svae_gmm_mw_fixed_point_f64(int T, int N, int K,
  *   svae_gmm_local_vjp_f64  cotangents of the node potentials (g_node_J, g_node_h: (T,N)) given g_kl (device scalar,
  *                           cotangent of the final pass's local KL; NULL = 0) and g_samples ((T,S,N); NULL = none,
  *                           then eps may be NULL).  gaussian_natparam / label_natparam: the final pass's outputs.
- * One point per lane, N <= 8, K <= 64; device pointers, asynchronous on `stream`.  0 / -k (argument k). */
+ * One point per lane, N <= 8, K <= 64; device pointers, asynchronous on `stream`.  0 / -k (argument k).
+ *   svae_gmm_global_step_f64  the global side of a step in ONE launch: label_global (K) = dirichlet.expectedstats
+ *                           (dirichlet.py:5-7), gaussian_globals (K,N+2,N+2) = niw.expectedstats (niw.py:15-25) -- the two
+ *                           potentials svae_gmm_meanfield_f64 / svae_gmm_mw_* take -- and, if `kl` is given, the prior KL
+ *                           of gmm.py:54-58 as the code spells it (full contraction; dirichlet.logZ, niw.logZ).  *info is
+ *                           raised to 1 on a non-positive-definite NIW scale matrix. */
+int svae_gmm_global_step_f64(int K, int N, const double* dirichlet_natparam, const double* niw_natparam,
+                             const double* prior_dirichlet, const double* prior_niw,
+                             double* label_global, double* gaussian_globals, double* kl, int32_t* info, void* stream);
 int svae_gmm_sample_f64(int T, int N, int S, const double* gaussian_natparam, const double* eps,
                         double* samples, void* stream);
 int svae_gmm_local_vjp_f64(int T, int N, int K, int S, const double* label_global,

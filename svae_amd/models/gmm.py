@@ -176,6 +176,35 @@ def meanfield_from_globals(label_global, gaussian_globals, node_potentials, labe
     return out
 
 
+def global_step(global_natparam, prior_natparam=None, info=None):
+    """The global side of a step in ONE launch (svae_gmm_global_step_f64): (label_global (K), gaussian_globals
+    (K,N+2,N+2)) = (dirichlet.expectedstats, niw.expectedstats) of gmm.py:67-68 and, with `prior_natparam`, the prior KL
+    of gmm.py:54-58 (the full contraction the code spells; the reference's shipped first-element value stays in
+    `prior_kl(..., reference_compat=True)`).  -> (label_global, gaussian_globals, kl | None).  `info`: (1,) int32 status
+    word, raised to 1 on an invalid NIW scale matrix (kept as global_step.last_info, never read here)."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    for x in global_natparam:
+        if isinstance(x, torch.Tensor) and x.is_cuda:
+            dev = x.device
+    dn, nn_ = _dev64(global_natparam[0], dev), _dev64(global_natparam[1], dev)
+    K, N = dn.shape[0], nn_.shape[-1] - 2
+    if tuple(nn_.shape) != (K, N + 2, N + 2) or not (1 <= N <= GMM_MAX_N and 1 <= K <= GMM_MAX_K):
+        raise ValueError("GMM global parameters: dirichlet (K), NIW (K, N+2, N+2) with N <= %d, K <= %d" % (GMM_MAX_N, GMM_MAX_K))
+    f64 = dict(dtype=torch.float64, device=dev)
+    lg, gg = torch.empty(K, **f64), torch.empty(K, N + 2, N + 2, **f64)
+    kl, pd, pn = None, None, None
+    if prior_natparam is not None:
+        pd, pn = _dev64(prior_natparam[0], dev), _dev64(prior_natparam[1], dev)
+        kl = torch.empty(1, **f64)
+    if info is None:
+        info = torch.zeros(1, dtype=torch.int32, device=dev)
+    global_step.last_info = info
+    p = _lib.ptr
+    _lib.check(_lib.load().svae_gmm_global_step_f64(K, N, p(dn), p(nn_), p(pd), p(pn), p(lg), p(gg), p(kl), p(info),
+                                                    _lib.current_stream(dev)), "svae_gmm_global_step_f64")
+    return lg, gg, (kl[0] if kl is not None else None)
+
+
 def local_meanfield(global_natparam, node_potentials, label_init=None, tol=1e-3, max_iter=100,
                     generator=None, group=None, multi_wg=None):
     """gmm.py:62-88 -> (local_stats, prior_stats, natparam, kl).  With the points sharded over the ranks of
@@ -187,8 +216,7 @@ def local_meanfield(global_natparam, node_potentials, label_init=None, tol=1e-3,
         if isinstance(x, torch.Tensor) and x.is_cuda:
             dev = x.device
     dn, nn_ = _dev64(dirichlet_natparam, dev), _dev64(niw_natparams, dev)
-    label_global = expfam.dirichlet_expectedstats(dn)          # gmm.py:67
-    gaussian_globals = expfam.niw_expectedstats(nn_)           # gmm.py:68
+    label_global, gaussian_globals, _ = global_step((dn, nn_))  # gmm.py:67-68
     T = node_potentials[1].shape[0]
     if label_init is None:
         label_init = initialize_meanfield(T, dn.shape[0], dev, generator)
@@ -239,15 +267,25 @@ def run_inference(prior_natparam, global_natparam, nn_potentials, num_samples, l
                   eps=None, generator=None, group=None, reference_compat=False):
     """gmm.py:12-16 -> (samples (T,S,N), (dirichlet_stats, niw_stats), global_kl, local_kl).  Under
     torch.distributed the points are this rank's shard; statistics and local_kl are summed over ranks."""
-    _, stats, local_natparam, local_kl = local_meanfield(global_natparam, nn_potentials,
-                                                         label_init=label_init, generator=generator, group=group)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    for x in (global_natparam[1], nn_potentials[0]):
+        if isinstance(x, torch.Tensor) and x.is_cuda:
+            dev = x.device
+    label_global, gaussian_globals, global_kl = global_step(global_natparam, None if reference_compat else prior_natparam)
+    if reference_compat:
+        global_kl = prior_kl(global_natparam, prior_natparam, True)
+    Tn = nn_potentials[1].shape[0]
+    if label_init is None:
+        label_init = initialize_meanfield(Tn, label_global.shape[0], dev, generator)
+    o = meanfield_from_globals(label_global, gaussian_globals, nn_potentials, label_init, group=group)
+    stats, local_natparam, local_kl = (o["dirichlet_stats"], o["niw_stats"]), (o["label_natparam"], o["gaussian_natparam"]), o["kl"][0]
     gn = local_natparam[1]
     T, N = gn.shape[0], gn.shape[-1] - 2
     if eps is None:
         eps = torch.randn(T, num_samples, N, dtype=torch.float64, device=gn.device, generator=generator)
     samples = gaussian_sample(gn, eps)
     stats, local_kl = _allreduce_stats_and_kl(stats, local_kl, group)
-    return samples, stats, prior_kl(global_natparam, prior_natparam, reference_compat), local_kl
+    return samples, stats, global_kl, local_kl
 
 
 # --- differentiable call surface (what make_gradfun drives) ------------------------------------------
@@ -305,8 +343,9 @@ def run_inference_differentiable(prior_natparam, global_natparam, nn_potentials,
     and -- in backward() -- the derived adjoint of the final pass and the sampler."""
     dev = nn_potentials[1].device
     g = [_dev64(x, dev) for x in global_natparam]
-    label_global = expfam.dirichlet_expectedstats(g[0])
-    gaussian_globals = expfam.niw_expectedstats(g[1])
+    label_global, gaussian_globals, global_kl = global_step(g, None if reference_compat else prior_natparam)
+    if reference_compat:
+        global_kl = prior_kl(global_natparam, prior_natparam, True)
     nJ, nh = nn_potentials[0].to(torch.float64), nn_potentials[1].to(torch.float64)
     T, N = nh.shape
     if label_init is None:
@@ -317,7 +356,7 @@ def run_inference_differentiable(prior_natparam, global_natparam, nn_potentials,
     samples, local_kl = _LocalTail.apply(nJ, nh, _dev64(eps, dev), label_global.contiguous(),
                                          gaussian_globals.contiguous(), o)
     stats, local_kl = _allreduce_stats_and_kl((o["dirichlet_stats"], o["niw_stats"]), local_kl, group)
-    return samples, stats, prior_kl(global_natparam, prior_natparam, reference_compat), local_kl
+    return samples, stats, global_kl, local_kl
 
 
 def init_pgm_param(K, N, alpha, niw_conc=10., random_scale=0., generator=None, dtype=torch.float64, device="cpu"):

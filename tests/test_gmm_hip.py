@@ -128,3 +128,24 @@ def test_max_iter_and_determinism():
     ls, it = gmm_numpy.meanfield_fixed_point(lg, gg, ef.pack_dense(*node), init, max_iter=3,
                                              return_iters=True)
     assert it == 3
+
+
+@pytest.mark.parametrize("K,N", [(5, 2), (15, 2), (1, 1), (7, 3), (64, 2), (4, 8), (9, 5)])
+def test_global_step_kernel_against_the_torch_maps(K, N):
+    """svae_gmm_global_step_f64 (dirichlet / niw expectedstats of gmm.py:67-68 + the prior KL of gmm.py:54-58 in one
+    launch) against svae_amd.distributions.expfam, which tests/golden/expfam.npz pins to the reference's Python."""
+    from svae_amd.distributions import expfam
+    from svae_amd.models import gmm
+    gen = torch.Generator().manual_seed(10 * K + N)
+    prior = tuple(x.to("cuda:0") for x in gmm.init_pgm_param(K, N, alpha=0.7, niw_conc=1.5, generator=gen))
+    glob = tuple(x.to("cuda:0") for x in gmm.init_pgm_param(K, N, alpha=1.3, niw_conc=3.0, random_scale=2.0, generator=gen))
+    lg, gg, kl = gmm.global_step(glob, prior)
+    np.testing.assert_allclose(_np(lg), _np(expfam.dirichlet_expectedstats(glob[0])), rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(_np(gg), _np(expfam.niw_expectedstats(glob[1])), rtol=1e-10, atol=1e-12)
+    want = float(gmm.prior_kl(glob, prior))
+    assert float(kl) == pytest.approx(want, rel=1e-9, abs=1e-9)
+    assert int(gmm.global_step.last_info.item()) == 0
+    bad = glob[1].clone()
+    bad[0, :N, :N] = -bad[0, :N, :N]
+    gmm.global_step((glob[0], bad))
+    assert int(gmm.global_step.last_info.item()) == 1

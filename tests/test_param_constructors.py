@@ -55,3 +55,18 @@ def test_slds_global_natparam_constructors():
     (_, _), lds_r = slds_svae.make_slds_global_natparam(K, n, random=True, generator=g)
     init, pair = slds_svae.get_all_lds_local_natparams(lds_r)
     assert tuple(pair[0].shape) == (K, n, n) and torch.isfinite(pair[0]).all()
+
+
+def test_nnet_linear_matches_plain_matmul_and_its_gradients():
+    """svae_amd.nnet.linear = x @ w; its blocked weight gradient equals autograd's (CPU, float64)."""
+    import torch
+    from svae_amd.nnet import gaussian_info, linear
+    gen = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 301, 5, dtype=torch.float64, generator=gen, requires_grad=True)     # 903 rows: 3 blocks + a tail
+    w = torch.randn(5, 4, dtype=torch.float64, generator=gen, requires_grad=True)
+    g = torch.randn(3, 301, 4, dtype=torch.float64, generator=gen)
+    gx, gw = torch.autograd.grad((linear(x, w) * g).sum(), [x, w])
+    hx, hw = torch.autograd.grad(((x @ w) * g).sum(), [x, w])
+    assert torch.allclose(gx, hx, rtol=1e-13, atol=1e-13) and torch.allclose(gw, hw, rtol=1e-12, atol=1e-12)
+    J, h = gaussian_info(([w], [w]), x)
+    assert bool((J <= 0).all()) and J.shape == h.shape == (3, 301, 4)
