@@ -152,6 +152,31 @@ __device__ __forceinline__ double asm_fma(double a, double b, double c) { // a*b
 }
 
 // Sum over the 16 lanes of a DPP row (result valid in every lane of the row).
+// exp(x) for x <= 0 (max-subtracted log-weights): x = n ln2 + r, |r| <= ln2 / 2, Taylor to r^13 (remainder < 4e-18),
+// scaled by 2^n; underflows to 0 like exp().  21 instructions against ~42 of the library's exp(): the kernels that call
+// it once per step (HMM forward pass, GMM label update) are bound by their instruction count.
+__device__ __forceinline__ double exp_nonpos(double x) {
+  x = fmax(x, -746.0);
+  const double n = __builtin_rint(x * 1.4426950408889634074);
+  double r = __builtin_fma(n, -6.93147180369123816490e-01, x);
+  r = __builtin_fma(n, -1.90821492927058770002e-10, r);
+  double p = 1.6059043836821613e-10;                                   // 1/13!
+  p = __builtin_fma(p, r, 2.08767569878680989792e-09);                 // 1/12!
+  p = __builtin_fma(p, r, 2.50521083854417187751e-08);                 // 1/11!
+  p = __builtin_fma(p, r, 2.75573192239858906526e-07);                 // 1/10!
+  p = __builtin_fma(p, r, 2.75573192239858906526e-06);                 // 1/9!
+  p = __builtin_fma(p, r, 2.48015873015873015873e-05);                 // 1/8!
+  p = __builtin_fma(p, r, 1.98412698412698412698e-04);                 // 1/7!
+  p = __builtin_fma(p, r, 1.38888888888888888889e-03);                 // 1/6!
+  p = __builtin_fma(p, r, 8.33333333333333333333e-03);                 // 1/5!
+  p = __builtin_fma(p, r, 4.16666666666666666667e-02);                 // 1/4!
+  p = __builtin_fma(p, r, 1.66666666666666666667e-01);                 // 1/3!
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  return __builtin_amdgcn_ldexp(p, (int)n);
+}
+
 __device__ __forceinline__ double row_sum16(double x) {
   x += __shfl_xor(x, 1, 16);
   x += __shfl_xor(x, 2, 16);

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(64) void hmm_estep_kernel(const HmmArgs a) {
     nd_n = node_at(t + 1 < T ? t + 1 : (T > 1 ? T - 1 : 1));
     if (t == 0) nd += col ? a.init_params[cc] : 0.0;
     const double m = row_max16(nd);         // m = max_k node[k]
-    const double e = col ? exp(nd - m) : 0.0;
+    const double e = col ? exp_nonpos(nd - m) : 0.0;      // (nd - m <= 0: m is the row maximum)
     double pred;
     if (t == 0) {
       pred = col ? 1.0 : 0.0;
