@@ -967,13 +967,23 @@ static int launch_estep_twoend(const LdsArgs& a, bool inhomog, bool lean, hipStr
       // workgroup MORE than its even share ceil(B / 256) of the launch (the dispatcher does not balance exactly: sized
       // for the even share, a few workgroups would wait for a second round and double the kernel time)
       auto kern = lds_estep_twoend_kernel<N, false, true, false, false, true>;
-      const int wg_per_cu = (a.B + 255) / 256 + 1;
-      const long budget = (160L * 1024) / wg_per_cu - TE_S4_LDS_BYTES - 64 * (long)sizeof(double);
+      // (CU count and LDS per CU from the device: a partitioned part -- fewer CUs -- or one with less LDS gets a smaller
+      //  window instead of an oversubscribed one)
+      int dev = 0, cus = 256, lds_cu = 160 * 1024;
+      if (hipGetDevice(&dev) == hipSuccess) {
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        (void)hipDeviceGetAttribute(&lds_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev);
+        if (cus < 1) cus = 256;
+        if (lds_cu < 64 * 1024) lds_cu = 64 * 1024;
+        (void)hipGetLastError();
+      }
+      const int wg_per_cu = (a.B + cus - 1) / cus + 1;
+      const long budget = (long)lds_cu / wg_per_cu - TE_S4_LDS_BYTES - 64 * (long)sizeof(double);
       const long rec_bytes = 2L * te_lean_step_doubles(N) * sizeof(double);          // one record of each chain
       // Measured (T = 200, n = 10): with one workgroup per CU (B <= 256) the LDS records cost nothing (0.142 ms either
       // way) and the HBM traffic per launch falls to 1.6x the algorithmic bytes; with two workgroups per CU (B = 512)
       // the kernel is 2 % slower with them (0.152 vs 0.149 ms), so they stay in HBM there: time before traffic.
-      long keep = a.B <= 256 ? budget / rec_bytes : 0;
+      long keep = (a.B <= cus && budget > 0) ? budget / rec_bytes : 0;
 #ifdef SVAE_S4_KEEP_OVERRIDE
       keep = SVAE_S4_KEEP_OVERRIDE;      // (experiments: tools/build_variant.sh ... -DSVAE_S4_KEEP_OVERRIDE=<records>)
 #endif
@@ -983,7 +993,12 @@ static int launch_estep_twoend(const LdsArgs& a, bool inhomog, bool lean, hipStr
       a2.lds_keep = (int)keep;
       const long bytes = keep * rec_bytes + (keep > 0 ? 64 * sizeof(double) : 0);    // + one dummy slot per lane
       static LdsGrant grant;
-      if (bytes > 0 && !grant.ensure(reinterpret_cast<const void*>(kern), bytes)) return -31;
+      if (bytes > 0 && !grant.ensure(reinterpret_cast<const void*>(kern), bytes)) {
+        // the window was refused: every record through HBM (always valid) instead of an error
+        a2.lds_keep = 0;
+        hipLaunchKernelGGL(kern, grid, dim3(128), 0, stream, a2);
+        return hipGetLastError() == hipSuccess ? 0 : -1000;
+      }
       hipLaunchKernelGGL(kern, grid, dim3(128), (size_t)bytes, stream, a2);
     }
     else if (lean)

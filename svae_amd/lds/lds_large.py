@@ -110,6 +110,10 @@ def start_phase0(plan, J12, pair_batched, S):
     main, side = _side_stream(dev)
     side.wait_stream(main)                    # the hand-off of the launch just issued (and everything before it)
     J12c = J12.to(**f64).contiguous()
+    # temporaries made on the caller's stream and consumed on the helper stream: tell the caching allocator, or their
+    # memory may be handed out again while phase 0 is still running
+    J12c.record_stream(side)
+    gJ.record_stream(side)
     rc = lib.svae_lds_tile_vjp_f64(0, B, T, n, 0, 0, T, int(J12c.dim() >= 3), int(bool(pair_batched)), p(J12c), p(dummy),
                                    None, None, None, None, None, None, p(plan.E_node_x), p(gJ), p(gJ), p(plan.ws),
                                    p(ws), nws, side.cuda_stream)

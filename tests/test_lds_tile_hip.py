@@ -163,6 +163,38 @@ def test_tile_estep_full_size_well_conditioned(n, T):
 
 
 @pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("n,T,S", [(48, 12, 2), (64, 8, 2), (64, 40, 1)])
+def test_tile_sampler_and_vjp_on_the_reference_generator_at_large_latent_dim(n, T, S):
+    """Sampler and VJP at n >= 48 on the reference's OWN generator (`rand_lds`, svae/lds/synthetic_data.py:8-28: state
+    noise B B' with cond ~ n^2) -- the other sampler / VJP tests use the well-conditioned rotation model there -- against
+    the compiled reference at north_star's 1e-5 (observed errors are printed)."""
+    from svae_amd.lds.lds_inference import lds_inference_differentiable
+    rng = np.random.default_rng(31 * n + T)
+    natparam = rand_lds_natparam(n, rng)
+    B = 2
+    node = rand_node_potentials((B, T, n), rng, with_logZ=True)
+    g = dict(ln=rng.standard_normal(B), dxx=rng.standard_normal((B, T, n)), x=rng.standard_normal((B, T, n)),
+             s=rng.standard_normal((B, T, S, n)))
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev)
+    want, wsmp, eps = [], [], np.zeros((B, T, S, n))
+    for b in range(B):
+        nb = tuple(x[b] for x in node)
+        (gJ, gh, gz), eps[b] = ref.estep_vjp(natparam, nb, g["ln"][b], (g["dxx"][b], g["x"][b]), g["s"][b], seed=70 + b)
+        want.append((gJ, gh))
+        wsmp.append(ref.sample_backward(natparam, nb, S, seed=70 + b)[0])
+    nJ, nh, nz = (t(x).requires_grad_(True) for x in node)
+    nat = (tuple(t(x) for x in natparam[0]), tuple(t(x) for x in natparam[1]))
+    lognorm, (dxx, ex), samples, _ = lds_inference_differentiable(nat, (nJ, nh, nz), eps=t(eps))
+    loss = (t(g["ln"]) * lognorm).sum() + (t(g["dxx"]) * dxx).sum() + (t(g["x"]) * ex).sum() + (t(g["s"]) * samples).sum()
+    loss.backward()
+    es = max(_rel(samples[b], wsmp[b]) for b in range(B))
+    eg = max(max(_rel(nJ.grad[b], want[b][0]), _rel(nh.grad[b], want[b][1])) for b in range(B))
+    print("rand_lds n=%d T=%d: samples %.2e, gradients %.2e vs compiled reference" % (n, T, es, eg))
+    assert es < 1e-7 and eg < 1e-7
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
 @pytest.mark.parametrize("n,T,S", [(16, 12, 3), (32, 9, 2), (64, 6, 2), (20, 5, 1), (24, 1, 2), (40, 2, 1), (17, 3, 5)])
 def test_tile_sampler_against_reference_build(n, T, S):
     """natural_sample_backward for 16 <= n <= 64 (svae_amd/lds/lds_large.py on the tile kernel's hand-off):
@@ -362,8 +394,11 @@ def test_tile_training_step_at_latent_dim_32():
     spec = importlib.util.spec_from_file_location("lds_svae_synth", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    vals = mod.main(["--iters", "6", "--seqs", "16", "--T", "20", "--n", "32", "--p", "40", "--batch", "8", "--quiet"])
-    assert len(vals) == 6 and np.all(np.isfinite(vals))
+    vals = mod.main(["--iters", "20", "--seqs", "16", "--T", "20", "--n", "32", "--p", "40", "--batch", "8", "--quiet"])
+    assert len(vals) == 20 and np.all(np.isfinite(vals))
+    # the Monte-Carlo ELBO estimate goes UP under the natural-gradient / SGD steps: the gradients the tile VJP kernels
+    # return point the right way (their values are pinned by the tests above)
+    assert np.mean(vals[-5:]) > np.mean(vals[:5]), vals
 
 
 @pytest.mark.parametrize("n,T,B,S,mode", [(16, 7, 3, 2, "homog"), (20, 5, 2, 0, "homog"), (33, 6, 2, 3, "inhomog"),
@@ -505,12 +540,16 @@ def test_backward_half_leaves_the_smoothed_covariances_of_phase0(n, T, B):
     assert float((torch.diagonal(kept, dim1=2, dim2=3) - var).abs().max()) <= 1e-9 * float(var.abs().max())
 
 
-def test_tile_training_step_repeats_on_one_plan():
+@pytest.mark.parametrize("n,T,B,S", [(32, 160, 5, 2), (32, 130, -9, 1), (64, 40, -3, 2)])
+def test_tile_training_step_repeats_on_one_plan(n, T, B, S):
     """A training step at 16 <= n <= 64 runs on three streams (E-step halves, VJP phase 0 early, Cholesky adjoint of the
     next range of steps next to phase 2): repeated on ONE plan -- each launch overwrites the hand-off the helper streams
-    of the previous step read -- every pass must give the same values and gradients, and the same as a fresh plan."""
+    of the previous step read -- every pass must give the same values and gradients, and the same as a fresh plan.
+    (B < 0: that many sequences MORE than the chip has CUs -- every CU busy, so that the helper streams' kernels really
+    run next to the main stream's, and the two-workgroups-per-CU instances take part.)"""
     from svae_amd.lds.lds_inference import LDSEStepPlan, lds_inference_differentiable
-    n, T, B, S = 32, 160, 5, 2
+    if B < 0:
+        B = torch.cuda.get_device_properties(0).multi_processor_count - B
     rng = np.random.default_rng(5)
     natparam = rand_lds_natparam(n, rng)
     node = rand_node_potentials((B, T, n), rng)
