@@ -272,6 +272,9 @@ def measure_slds(dev, B=2048, T=500, n=10, K=8):
     from svae_amd.models import slds_svae
     rng = np.random.default_rng(0)
     glob = rand_slds_global_natparam(K, n, rng)
+    # (the global parameters live on the device, as in a training loop: the global -> local maps then run as kernels)
+    _d = lambda x: tuple(_d(y) for y in x) if isinstance(x, (tuple, list)) else torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev)
+    glob = _d(glob)
     node = (torch.as_tensor(-0.5 * (0.5 + rng.random((B, T, n))), device=dev),
             torch.as_tensor(2. * rng.standard_normal((B, T, n)), device=dev))
     eps = torch.randn(B, T, 1, n, dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(0))

@@ -55,12 +55,63 @@ def get_all_lds_local_natparams(lds_global_natparams):
     return stack(inits), stack(pairs)          # each: 4 tensors with leading K
 
 
+def _global_to_local_maps_device(global_natparam, device):
+    """global_to_local_maps with the K (NIW, MNIW) factor pairs through the LDS global-step kernel
+    (svae_lds_global_step_f64, one launch per state writing straight into the stacked outputs) and the Dirichlet rows
+    as two digamma expressions on the device: no host arithmetic, no host -> device copies of the results."""
+    from .lds import GLOBAL_STEP_MAX_N
+    hmm_global, lds_global = global_natparam
+    K = len(lds_global)
+    n = int(torch.as_tensor(lds_global[0][0]).shape[-1]) - 2
+    if not (1 <= n <= GLOBAL_STEP_MAX_N):
+        return None
+    f64 = dict(dtype=torch.float64, device=device)
+    c = lambda x: _dev64(x, device).contiguous()
+    hmm_init, hmm_pair = hmm_prior_expectedstats(tuple(c(x) for x in hmm_global))
+    D = n + 2
+    # one block per kind, sliced per state: [J (n,n) | h (n) | logZ (1)], [J11 | J12 | J22 (n,n) | logZ (1)], es (D,D)
+    initb = torch.empty(K, n * n + n + 1, **f64)
+    pairb = torch.empty(K, 3 * n * n + 1, **f64)
+    esb = torch.empty(K, D, D, **f64)
+    info = torch.zeros(1, dtype=torch.int32, device=device)
+    lib, p = _lib.load(), _lib.ptr
+    keep = []
+    stream = _lib.current_stream(device)
+    e8 = 8      # bytes per double
+    for k, (niw, (A, Bm, C, d)) in enumerate(lds_global):
+        t = [c(niw), c(A), c(Bm), c(C), c(d).reshape(1)]
+        keep.append(t)
+        ib, pb = initb[k].data_ptr(), pairb[k].data_ptr()
+        import ctypes
+        q = lambda addr: ctypes.c_void_p(addr)
+        rc = lib.svae_lds_global_step_f64(
+            n, p(t[0]), p(t[1]), p(t[2]), p(t[3]), p(t[4]), None, None, None, None, None,
+            q(ib), q(ib + e8 * n * n), q(ib + e8 * (n * n + n)),
+            q(pb), q(pb + e8 * n * n), q(pb + e8 * 2 * n * n), q(pb + e8 * 3 * n * n), p(esb[k]), None, p(info), stream)
+        _lib.check(rc, "svae_lds_global_step_f64")
+    global_to_local_maps.last_info = info
+    nn = n * n
+    dense_init = (esb[:, :n, :n].contiguous(), esb[:, :n, n].contiguous(), esb[:, n, n].contiguous(),
+                  esb[:, n + 1, n + 1].contiguous())
+    dense_pair = (pairb[:, :nn].reshape(K, n, n), pairb[:, nn:2 * nn].reshape(K, n, n),
+                  pairb[:, 2 * nn:3 * nn].reshape(K, n, n), pairb[:, 3 * nn].contiguous())
+    dense_pair = tuple(x.contiguous() for x in dense_pair)
+    return hmm_init.contiguous(), hmm_pair.contiguous(), dense_init, dense_pair
+
+
 def global_to_local_maps(global_natparam, device):
     """The once-per-step global -> local maps of the SLDS (hmm_prior_expectedstats :124-130 and
-    get_all_lds_local_natparams :86-89): O(K n^3) arithmetic on K small matrices, evaluated in float64 ON THE
-    HOST (a few hundred tiny device launches cost 7 ms; SURVEY section 8a row a9: "keep on host") and moved to
-    `device` as 10 small tensors.  -> (hmm_init (K), hmm_pair (K,K), dense_init 4-tuple, dense_pair 4-tuple)."""
+    get_all_lds_local_natparams :86-89) -> (hmm_init (K), hmm_pair (K,K), dense_init 4-tuple, dense_pair 4-tuple).
+    On a GPU: K launches of the LDS global-step kernel (round 4; _global_to_local_maps_device).  Otherwise (CPU tensors,
+    n > 64) the same maps in float64 torch on the host, moved over as 10 small tensors (as torch device ops they are a
+    few hundred tiny launches, 7 ms)."""
     hmm_global, lds_global = global_natparam
+    if torch.device(device).type == "cuda":
+        # (also for parameters that still live on the host: 5 K small copies in -- the host path's O(K n^3) torch CPU
+        #  operators take anything from 2 to 100+ ms on a box whose core quota is below its hardware thread count)
+        out = _global_to_local_maps_device(global_natparam, torch.device(device))
+        if out is not None:
+            return out
     cpu = torch.device("cpu")
     hmm_init, hmm_pair = hmm_prior_expectedstats(tuple(_dev64(x, cpu) for x in hmm_global))
     lds_cpu = [(_dev64(a, cpu), tuple(_dev64(y, cpu) for y in m)) for a, m in lds_global]
@@ -244,11 +295,15 @@ def _optimize_local_meanfield_fused(hmm_init, hmm_pair, dense_init, dense_pair, 
     lds_vlb = torch.zeros(B, **f64)
     vlb = torch.full((B,), -float("inf"), **f64)
     iters = torch.zeros(B, **i32)
-    lists = [torch.arange(B, **i32), torch.empty(B, **i32)]
-    keep, count = torch.empty(B, **i32), torch.empty(1, **i32)
     hws_bytes = int(lib.svae_hmm_workspace_bytes(max(B, 1), T, K))
     hws = torch.empty(hws_bytes // 8, **f64)
+    lists = [torch.arange(B, **i32), torch.empty(B, **i32)]
+    keep, count = torch.empty(B, **i32), torch.empty(1, **i32)
     stream = _lib.current_stream(dev)
+    # (Measured and not kept, round 4: the batch as two halves on two streams, staggered by one phase so that one half's
+    #  HMM kernel runs under the other's LDS kernel.  The fused LDS kernel on half the batch takes 1.0 ms, not 0.75 -- a
+    #  round of both halves 2.0 ms against 2.2 -- and in the late sweeps, a handful of sequences per half, every half
+    #  waits for the other's latency-bound kernel: 32 ms instead of 26 for the ascent.)
     nrun, cur = B, 0
     for it in range(max_iter):
         if nrun == 0:
