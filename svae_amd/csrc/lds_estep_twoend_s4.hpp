@@ -35,6 +35,11 @@ __device__ __forceinline__ void quad_gather(double x, double& r0, double& r1, do
   r3 = __hiloint2double(oh[1], ol[1]);
 }
 
+// an empty asm that reads x: the compiler waits for its pending load HERE.  Applied to the register a batch of LDS reads
+// fills LAST (LDS returns in order: that wait covers the whole batch) it replaces the one wait per 16-byte read that
+// hipcc otherwise places in front of each read's first use.
+__device__ __forceinline__ void touch(const double& x) { asm volatile("" : : "v"(x)); }
+
 __device__ __forceinline__ double reg_copy(double x) {       // a copy the compiler cannot fold away
   double y;
   asm volatile("v_mov_b64 %0, %1" : "=v"(y) : "v"(x));
@@ -176,6 +181,9 @@ __device__ __forceinline__ void te_smooth4(const LdsArgs& a, const int b, const 
     // W~[i] = S~[i] G~'  for my rows
     double W[J1];
     static_for<0, J1>([&](auto j) { W[j] = 0.0; });
+    // (the LAST register the operand's LDS reads fill is "used" here: one wait for the batch -- issued a whole product
+    //  ago -- instead of one per 16-byte read in front of its first multiply-add: 5 issue slots per product)
+    touch(p.H[N]);
     asm volatile("s_nop 1");
     static_for<0, N + 1>([&](auto k) {
       static_for<0, J1>([&](auto j) { mac_bc<k, (k < N)>(W[j], S[j], p.H[k]); });
@@ -202,6 +210,7 @@ __device__ __forceinline__ void te_smooth4(const LdsArgs& a, const int b, const 
     prep_products(std::false_type{}, nxt, p);
     prep_read(p);
     // S~_t[i] = P^-1[i] + G~[i] W~
+    touch(WR[2 * ((N + 2) / 2) - 1]);
     dpp_fence(Gc);
     static_for<0, N + 1>([&](auto k) {
       static_for<0, J1>([&](auto j) { mac_bc<k, (k < N)>(Sn[j], Gc[j], WR[k]); });
