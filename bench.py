@@ -452,6 +452,10 @@ def main():
 
     from svae_amd import _lib
     _lib.load()                                   # no library, no bench: there is no fallback path
+    if world > 1 and os.environ.get("SVAE_BENCH_ALLREDUCE", "") == "mailbox":
+        # opt-in A/B: the exchange step through the one-shot IPC mailbox kernel instead of the collective backend
+        from svae_amd.parallel import use_mailbox_allreduce
+        use_mailbox_allreduce(4 * 64 * 64 + 64 + 2)
     options = _lib.KERNEL_OPTIONS[args.kernel]    # per-call selection word (A/B measurements); "auto" = 0
     T, n, B = WORKLOADS[args.workload]
     B = args.seqs_per_gpu or B
@@ -472,7 +476,7 @@ def main():
                                                   else "BASELINE configs[4] shape; batch chosen here"),
                        "sequences_per_gpu": B, "T": T, "n": n, "global_sequences": B * world,
                        "parallelism": "dp%d" % world, "collective_backend": (dist.get_backend() if world > 1 else None),
-                       "step": "estep kernel + batch stat reduce" + (" + %s all-reduce" % ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend()) if world > 1 else "")},
+                       "step": "estep kernel + batch stat reduce" + (" + %s all-reduce" % ("IPC mailbox" if os.environ.get("SVAE_BENCH_ALLREDUCE", "") == "mailbox" else ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend())) if world > 1 else "")},
             "roofline": roofline(options, T, n, B, kern_ms),
         }
         if world == 1 and not args.no_extra and args.workload == "lds10" and args.seqs_per_gpu is None:

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SVAE_HIP_ABI_VERSION 10   /* 10: + svae_gmm_sample_f64, svae_gmm_local_vjp_f64, svae_gmm_global_step_f64 (the differentiable tail and the global side of the GMM local step); 9: keep bit SVAE_KEEP_SIGMA of svae_lds_estep_f64 (16 <= n <= 64) + svae_lds_tile_sigma_offset_bytes; 8: step ranges (t_begin, t_end) in svae_lds_tile_vjp_f64 / svae_lds_tile_noise_f64, SVAE_OPT_TILE_FORWARD / _BACKWARD; 7: + svae_slds_path_nodeparams_f64, svae_slds_mix_pair_natparam_f64; 6: per-call `options` word replaces the process-global svae_lds_set_* selectors (re-entrant library), + svae_slds_hmm_meanfield_f64, svae_slds_sweep_glue_f64, g_E_pair in svae_lds_tile_vjp_f64; 5: + svae_lds_set_prod_max_b; 4: + svae_slds_lds_meanfield_f64, svae_gmm_mw_*, svae_lds_global_step_f64, svae_lds_natgrad_f64, svae_lds_tile_vjp_f64; 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
+#define SVAE_HIP_ABI_VERSION 10   /* 10: + svae_ipc_allreduce_f64 / svae_ipc_mailbox_bytes, svae_gmm_sample_f64, svae_gmm_local_vjp_f64, svae_gmm_global_step_f64 (the differentiable tail and the global side of the GMM local step); 9: keep bit SVAE_KEEP_SIGMA of svae_lds_estep_f64 (16 <= n <= 64) + svae_lds_tile_sigma_offset_bytes; 8: step ranges (t_begin, t_end) in svae_lds_tile_vjp_f64 / svae_lds_tile_noise_f64, SVAE_OPT_TILE_FORWARD / _BACKWARD; 7: + svae_slds_path_nodeparams_f64, svae_slds_mix_pair_natparam_f64; 6: per-call `options` word replaces the process-global svae_lds_set_* selectors (re-entrant library), + svae_slds_hmm_meanfield_f64, svae_slds_sweep_glue_f64, g_E_pair in svae_lds_tile_vjp_f64; 5: + svae_lds_set_prod_max_b; 4: + svae_slds_lds_meanfield_f64, svae_gmm_mw_*, svae_lds_global_step_f64, svae_lds_natgrad_f64, svae_lds_tile_vjp_f64; 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
 #define SVAE_LDS_MAX_N 15   /* register/DPP path: one 16-lane row per sequence, n+1 <= 16 */
 #define SVAE_LDS_TILE_MAX_N 64   /* 16 <= n <= 64: LDS-tiled MFMA path (keep: SVAE_KEEP_SIGMA or 0) */
 #define SVAE_KEEP_SIGMA 4         /* keep bit of svae_lds_estep_f64, 16 <= n <= 64 only: see svae_lds_tile_sigma_offset_bytes */
@@ -464,6 +464,18 @@ int svae_gmm_local_vjp_f64(int T, int N, int K, int S, const double* label_globa
                            const double* gaussian_natparam, const double* label_natparam,
                            const double* g_kl, const double* eps, const double* g_samples,
                            double* g_node_J, double* g_node_h, void* stream);
+
+
+/* ---- one-shot all-reduce of a small buffer over IPC-mapped mailboxes (csrc/ipc_allreduce.hip) -----------------------
+ * The exchange step (/root/reference/svae/svae.py:33-34: the batch-summed statistics) as ONE kernel: every rank stores
+ * its n doubles, as tagged 8-byte words, into slot `rank` of EVERY rank's mailbox (fine-grained device memory of
+ * svae_ipc_mailbox_bytes(n, world) bytes, zero-initialised once, IPC-mapped into every peer: mailboxes[q] = rank q's
+ * mailbox as mapped into this process), then sums the words that arrived in its own mailbox in rank order -> out (may
+ * alias in).  epoch: 1, 2, 3, .. per call, the same on every rank.  Bit-identical results on every rank; *info = -78 on
+ * a timeout (a peer never published).  world <= 16.  Opt-in alternative to the RCCL all-reduce (svae_amd/ipc.py). */
+size_t svae_ipc_mailbox_bytes(int n, int world);
+int svae_ipc_allreduce_f64(int n, int rank, int world, unsigned epoch, const double* in, double* out,
+                           void* const* mailboxes, int32_t* info, void* stream);
 
 #ifdef __cplusplus
 }

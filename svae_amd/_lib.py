@@ -82,6 +82,9 @@ SIGNATURES = {
                              + [ctypes.c_double, ctypes.c_int] + [_c_double_p] * 8
                              + [_c_int_p] * 3 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "svae_gmm_mw_kl_hist": (ctypes.c_void_p, [ctypes.c_void_p]),
+    "svae_ipc_mailbox_bytes": (ctypes.c_size_t, [ctypes.c_int] * 2),
+    "svae_ipc_allreduce_f64": (ctypes.c_int, [ctypes.c_int] * 3 + [ctypes.c_uint] + [_c_double_p] * 2
+                               + [ctypes.c_void_p, _c_int_p, ctypes.c_void_p]),
     "svae_gmm_global_step_f64": (ctypes.c_int, [ctypes.c_int] * 2 + [_c_double_p] * 7 + [_c_int_p, ctypes.c_void_p]),
     "svae_gmm_sample_f64": (ctypes.c_int, [ctypes.c_int] * 3 + [_c_double_p] * 3 + [ctypes.c_void_p]),
     "svae_gmm_local_vjp_f64": (ctypes.c_int, [ctypes.c_int] * 4 + [_c_double_p] * 11 + [ctypes.c_void_p]),

@@ -5,16 +5,37 @@ parameters, so the batch is sharded across ranks with no data-path communication
 collective is one all-reduce (sum, fp64) per natural-gradient step of the packed global expected
 statistics (4n^2+n+2 doubles for the LDS: [sum E_init | sum E_pair | sum lognorm | count]) that feed
 svae/svae.py:33-34 in the reference.  At ~3 KB it is latency-bound on xGMI: a single RCCL call on
-one packed buffer (backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests).
+one packed buffer (backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests) -- or, opt-in, the one-shot
+mailbox kernel of svae_amd/ipc.py (use_mailbox_allreduce).
 """
 import torch
 import torch.distributed as dist
 
 
+_mailbox = {}      # group -> svae_amd.ipc.MailboxAllReduce (opt-in, use_mailbox_allreduce)
+
+
+def use_mailbox_allreduce(n_doubles, group=None):
+    """Opt in: route allreduce_global_stats on `group` through the one-shot IPC mailbox kernel (svae_amd/ipc.py: one
+    launch, one xGMI hop, rank-order sum fused in) for buffers of up to `n_doubles` float64 CUDA elements; larger or
+    non-CUDA buffers keep the collective backend.  One node only.  Returns the MailboxAllReduce (its .check() reports a
+    peer that never published).  Validated with several processes on ONE device (tests/test_distributed_hip.py); RCCL
+    stays the default until a multi-GPU run has measured both."""
+    from .ipc import MailboxAllReduce
+    ar = MailboxAllReduce(n_doubles, group)
+    _mailbox[group] = ar
+    return ar
+
+
 def allreduce_global_stats(packed, group=None):
     """In-place sum over ranks of a packed statistics buffer; no-op without a process group."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+        ar = _mailbox.get(group)
+        if ar is not None and packed.is_cuda and packed.dtype == torch.float64 and packed.is_contiguous() \
+                and packed.numel() <= ar.n:
+            ar(packed)
+        else:
+            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
     return packed
 
 

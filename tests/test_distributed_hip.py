@@ -209,3 +209,75 @@ def test_two_streams_with_different_kernel_selections_are_independent():
         for i in range(2):
             for a, b in zip(both[i], alone[i]):
                 assert torch.equal(a, b)
+
+
+# ---- one-shot mailbox all-reduce over IPC-mapped memory (svae_amd/ipc.py, csrc/ipc_allreduce.hip) ---------------------
+
+def _ipc_worker(rank, world, port, q, n, rounds):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from svae_amd.ipc import MailboxAllReduce
+        dev = torch.device("cuda:0")
+        ar = MailboxAllReduce(n, device=dev)
+        gen = torch.Generator(device=dev).manual_seed(100 + rank)
+        worst, same = 0.0, True
+        for it in range(rounds):
+            x = torch.randn(n, dtype=torch.float64, device=dev, generator=gen) * (10.0 ** (it % 7 - 3))
+            want = x.clone().cpu()
+            dist.all_reduce(want)                                  # gloo on the host: the reference sum
+            got = ar(x.clone())
+            if it % 5 == 0:                                        # skew the ranks: one runs ahead of the other
+                torch.cuda.synchronize()
+            worst = max(worst, float((got.cpu() - want).abs().max() / want.abs().max()))
+            # every rank must hold the SAME bits
+            bits = [None] * world
+            dist.all_gather_object(bits, got.cpu().numpy().tobytes())
+            same = same and all(b == bits[0] for b in bits)
+        # a shorter buffer through the same mailbox, and the status word
+        y = torch.full((7,), float(rank + 1), dtype=torch.float64, device=dev)
+        ar(y)
+        ar.check()
+        q.put((rank, worst, same, y.cpu().tolist()))
+        ar.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 3])
+def test_mailbox_allreduce_between_processes_on_one_gpu(world):
+    """The one-shot all-reduce of the packed statistics (4 n^2 + n + 2 = 412 doubles at n = 10; here 415 and a ragged
+    1030) over fine-grained, IPC-mapped mailboxes: `world` processes share the one MI355X of the test box -- the IPC
+    mapping, the tagged-word protocol with its parity double-buffering (ranks deliberately skewed) and the rank-order sum
+    are what is under test; xGMI is not.  Against gloo's all-reduce on the host: equal to rounding, and the SAME bits on
+    every rank."""
+    import torch.multiprocessing as mp
+    for n, rounds in ((415, 60), (1030, 12)):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_ipc_worker, args=(r, world, port, q, n, rounds)) for r in range(world)]
+        for p_ in procs:
+            p_.start()
+        res, waited = [], 0.0
+        while len(res) < world:                      # fail fast if a worker dies (never sit out the queue's timeout)
+            try:
+                res.append(q.get(timeout=1.0))
+            except Exception:
+                waited += 1.0
+                dead = [p_.exitcode for p_ in procs if p_.exitcode not in (None, 0)]
+                if dead or waited > 240:
+                    for p_ in procs:
+                        p_.kill()
+                    pytest.fail("mailbox all-reduce worker failed (exit codes %r, waited %.0f s)" % (dead, waited))
+        for p_ in procs:
+            p_.join(timeout=60)
+            assert p_.exitcode == 0
+        for rank, worst, same, y in res:
+            assert worst < 1e-15 * world, (rank, worst)
+            assert same
+            assert y == [float(world * (world + 1) // 2)] * 7
