@@ -168,3 +168,30 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(ImportError):
         _lib.load()
+
+
+def test_round4_entry_points_reject_bad_arguments():
+    """GMM global step / sampler / adjoint and the IPC mailbox all-reduce: argument checks run before any launch."""
+    from svae_amd import _lib
+    lib = _lib.load()
+    one = 0x1000                 # any non-NULL address: the checks below must fail before it is used
+    assert lib.svae_gmm_global_step_f64(0, 2, one, one, None, None, one, one, None, one, None) == -1
+    assert lib.svae_gmm_global_step_f64(5, 9, one, one, None, None, one, one, None, one, None) == -2
+    assert lib.svae_gmm_global_step_f64(5, 2, None, one, None, None, one, one, None, one, None) == -3
+    assert lib.svae_gmm_global_step_f64(5, 2, one, one, None, None, one, one, one, one, None) == -5      # kl without a prior
+    assert lib.svae_gmm_global_step_f64(5, 2, one, one, None, None, one, one, None, None, None) == -10
+    assert lib.svae_gmm_sample_f64(-1, 2, 1, one, one, one, None) == -1
+    assert lib.svae_gmm_sample_f64(4, 0, 1, one, one, one, None) == -2
+    assert lib.svae_gmm_sample_f64(4, 2, 1, None, one, one, None) == -4
+    assert lib.svae_gmm_sample_f64(4, 2, 1, one, None, one, None) == -5
+    assert lib.svae_gmm_sample_f64(0, 2, 1, None, None, None, None) == 0                                 # nothing to do
+    assert lib.svae_gmm_local_vjp_f64(4, 2, 0, 1, one, one, one, one, one, one, None, None, None, one, one, None) == -3
+    assert lib.svae_gmm_local_vjp_f64(4, 2, 5, 1, None, one, one, one, one, one, None, None, None, one, one, None) == -5
+    assert lib.svae_gmm_local_vjp_f64(4, 2, 5, 1, one, one, one, one, one, one, None, None, one, one, one, None) == -12  # sample cotangents without eps
+    assert lib.svae_gmm_local_vjp_f64(4, 2, 5, 1, one, one, one, one, one, one, None, None, None, None, one, None) == -14
+    assert lib.svae_ipc_mailbox_bytes(415, 8) == 2 * 8 * 2 * 415 * 8 and lib.svae_ipc_mailbox_bytes(415, 17) == 0
+    assert lib.svae_ipc_allreduce_f64(0, 0, 2, 1, one, one, one, one, None) == -1
+    assert lib.svae_ipc_allreduce_f64(4, 2, 2, 1, one, one, one, one, None) == -2
+    assert lib.svae_ipc_allreduce_f64(4, 0, 17, 1, one, one, one, one, None) == -3
+    assert lib.svae_ipc_allreduce_f64(4, 0, 2, 0, one, one, one, one, None) == -4
+    assert lib.svae_ipc_allreduce_f64(4, 0, 2, 1, one, one, None, one, None) == -7
