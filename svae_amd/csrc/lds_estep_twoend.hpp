@@ -184,6 +184,10 @@ __global__ __launch_bounds__(MIX ? 512 : (S4 ? 128 : 64)) void lds_estep_twoend_
   // MIX: row of every array (and of the workspace) this launch slot works on (surplus slots: any valid row)
   const int b = !MIX ? bslot : (a.seq_index ? a.seq_index[bslot < a.B ? bslot : 0] : bslot);
   double* tab = tab_static;               // (MIX keeps the full hand-off record: no transposition tile)
+  // re-replication tile of the elimination phase, [chain][row 0..N][16]: S4 borrows the exchange buffer (used at the very
+  // end), the other variants the transposition tiles (used by the smoother phase only, zeroed again in between)
+  double* const split_tile = S4 ? xch_static : tab_static;
+  static_assert(MIX || 2 * (N + 1) * 16 <= (S4 ? 2 * ((N + 3) / 4) * 64 + 256 : 2 * 16 * 16), "split tile fits");
   // S4: the last `keep` records of each chain stay in (dynamic) LDS -- the smoother reads them first -- instead of
   // travelling through HBM: [chain][slot][WS] doubles, slot = local step - (e + 1 - keep)
   double* const lrecs = reinterpret_cast<double*>(te_dyn);
@@ -525,6 +529,20 @@ __global__ __launch_bounds__(MIX ? 512 : (S4 ? 128 : 64)) void lds_estep_twoend_
     });
     TE_TICK(2)
 
+    // The next pivot block leaves the Schur stage in slot layout (row 2j + gl in DPP row gl of the chain's pair) and
+    // the Gauss-Jordan wants every row in both DPP rows.  Round 4: the re-replication goes through LDS -- J stores of
+    // [row][16 lanes], N reads of a row each -- and its round trip is covered by the hand-off (column scaling +
+    // stores) and the log-determinant bookkeeping, which do not depend on it; as register shuffles (pair_split: two
+    // v_permlane16_swap per register and their copies) it was 33 instructions on the serial chain of the step.
+    // (MIX keeps the shuffles: its LDS is the parameter tables.)
+    if constexpr (!MIX) {
+      double* sp = split_tile + dir * (N + 1) * 16;
+      __builtin_amdgcn_wave_barrier();
+      static_for<0, J>([&](auto j) { sp[(2 * j + gl) * 16 + c] = AnD[j]; });
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
     // scale the inverse's columns, hand the record to the smoother phase
     vworst = fmax(vworst, vfull);
     ldM *= vfull;
@@ -534,11 +552,17 @@ __global__ __launch_bounds__(MIX ? 512 : (S4 ? 128 : 64)) void lds_estep_twoend_
     }
     hand_off(s, M, vfull, to_lds);
 
-    dpp_fence(AnD);
-    static_for<0, J>([&](auto j) {
-      if constexpr (2 * j + 1 < N) pair_split(AnD[j], An[2 * j], An[2 * j + 1]);
-      else { double dummy; pair_split(AnD[j], An[2 * j], dummy); }
-    });
+    if constexpr (!MIX) {
+      const double* sp = split_tile + dir * (N + 1) * 16 + c;
+      static_for<0, N>([&](auto i) { An[i] = sp[i * 16]; });
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      dpp_fence(AnD);
+      static_for<0, J>([&](auto j) {
+        if constexpr (2 * j + 1 < N) pair_split(AnD[j], An[2 * j], An[2 * j + 1]);
+        else { double dummy; pair_split(AnD[j], An[2 * j], dummy); }
+      });
+    }
     TE_TICK(3)
   };
   {
@@ -635,6 +659,12 @@ __global__ __launch_bounds__(MIX ? 512 : (S4 ? 128 : 64)) void lds_estep_twoend_
     return;
   }
 
+  if constexpr (!MIX && !S4) {            // the transposition tiles served as the elimination phase's split tile
+    __builtin_amdgcn_wave_barrier();
+    for (int q = lane; q < 2 * 16 * 16; q += 64) tab[q] = 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
   // ---- smoother phase: moment form on homogeneous coordinates, local steps e, e-1, .., 0 ---------------
   // S~ in slot layout (row i = 2j+gl of the (N+1) x (N+1) tile, lane = column); starts from e_N e_N' so that
   // the generic step at the meeting record (G = 0, c = mu) yields [[Sigma + mu mu', mu], [mu', 1]].
