@@ -34,7 +34,14 @@
 #include "gj1r_gen.hpp"
 #include "lds_estep_twoend_s4.hpp"
 
+#ifndef SVAE_TE_LDS_SPLIT
+#define SVAE_TE_LDS_SPLIT 3     // bit 0: kernels without the cross-moment store, bit 1: CROSS (runs next to the filter kernel)
+#endif
+
 namespace svae {
+
+// which variants re-replicate the next pivot block through LDS (else: v_permlane16_swap shuffles); MIX never does
+template <bool MIX, bool CROSS> constexpr bool TE_LDS_SPLIT() { return !MIX && (((SVAE_TE_LDS_SPLIT) >> (CROSS ? 1 : 0)) & 1); }
 
 // rows 2j (DPP row 0 of the pair) and 2j+1 (DPP row 1) of a slot register -> two registers replicated
 // over the pair.  v_permlane16_swap exchanges the odd rows of its first operand with the even rows of
@@ -535,7 +542,7 @@ __global__ __launch_bounds__(MIX ? 512 : (S4 ? 128 : 64)) void lds_estep_twoend_
     // stores) and the log-determinant bookkeeping, which do not depend on it; as register shuffles (pair_split: two
     // v_permlane16_swap per register and their copies) it was 33 instructions on the serial chain of the step.
     // (MIX keeps the shuffles: its LDS is the parameter tables.)
-    if constexpr (!MIX) {
+    if constexpr (TE_LDS_SPLIT<MIX, CROSS>()) {
       double* sp = split_tile + dir * (N + 1) * 16;
       __builtin_amdgcn_wave_barrier();
       static_for<0, J>([&](auto j) { sp[(2 * j + gl) * 16 + c] = AnD[j]; });
@@ -552,7 +559,7 @@ __global__ __launch_bounds__(MIX ? 512 : (S4 ? 128 : 64)) void lds_estep_twoend_
     }
     hand_off(s, M, vfull, to_lds);
 
-    if constexpr (!MIX) {
+    if constexpr (TE_LDS_SPLIT<MIX, CROSS>()) {
       const double* sp = split_tile + dir * (N + 1) * 16 + c;
       static_for<0, N>([&](auto i) { An[i] = sp[i * 16]; });
       __builtin_amdgcn_wave_barrier();
@@ -659,7 +666,7 @@ __global__ __launch_bounds__(MIX ? 512 : (S4 ? 128 : 64)) void lds_estep_twoend_
     return;
   }
 
-  if constexpr (!MIX && !S4) {            // the transposition tiles served as the elimination phase's split tile
+  if constexpr (TE_LDS_SPLIT<MIX, CROSS>() && !S4) {   // the transposition tiles served as the elimination phase's split tile
     __builtin_amdgcn_wave_barrier();
     for (int q = lane; q < 2 * 16 * 16; q += 64) tab[q] = 0.0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

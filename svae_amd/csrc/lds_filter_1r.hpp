@@ -14,6 +14,10 @@
 #pragma once
 #include "lds_estep_twoend.hpp"
 
+#ifndef SVAE_FILTER_LDS_SPLIT
+#define SVAE_FILTER_LDS_SPLIT 1   // 1: re-replication of the next pivot block through LDS behind the stores; 0: shuffles (A/B)
+#endif
+
 namespace svae {
 
 // gauss_jordan_1r (lds_estep_twoend.hpp) with a hook that receives every scaled pivot row (lanes j > k: L[j][k])
@@ -77,6 +81,7 @@ __global__ __launch_bounds__(64) void lds_filter_1r_kernel(const LdsArgs a) {
   constexpr int HL = 15;                  // lane of the h column
   // one wavefront per SIMD: this kernel runs next to the two-ended E-step kernel (see lds_estep_split.hpp, FILT)
   asm volatile("v_accvgpr_write_b32 a63, 0" ::: "a63");
+  __shared__ double split_tile[2 * (N + 1) * 16];      // [DPP row pair][row 0..N][16 lanes]: re-replication of the next pivot block
 
   const int lane = threadIdx.x;
   const int c = lane & 15;
@@ -187,6 +192,37 @@ __global__ __launch_bounds__(64) void lds_filter_1r_kernel(const LdsArgs a) {
 #else
     gauss_jordan_1r_hook<N>(M, E, qacc, vfull, [&](auto k, double ru) { RU[k] = ru; });
 #endif
+    // Schur stage FIRST (it needs only the eliminated block and Bt), its slot-layout result on its way through LDS
+    // while the step's stores are issued: the re-replication of the next pivot block as in the two-ended kernel
+    // (lds_estep_twoend.hpp, round 4) instead of v_permlane16_swap shuffles behind the stores.
+    if (!last) {
+      double AnD[J];
+      const bool next_last = (t + 1 == T - 1);
+      if (!INHOMOG && next_last) {
+        asm volatile("; next step is the last: its pivot block has no J11 term");
+        static_for<0, J>([&](auto j) { AnD[j] = CcLast[j]; });
+      } else {
+        static_for<0, J>([&](auto j) { AnD[j] = Cc[j]; });
+      }
+      asm volatile("s_nop 1");
+      static_for<0, N>([&](auto k) {
+        static_for<0, J>([&](auto j) { mac_bc<N + j>(AnD[j], M[k], Bt[k]); });
+      });
+#if SVAE_FILTER_LDS_SPLIT
+      double* sp = split_tile + (g >> 1) * (N + 1) * 16;
+      __builtin_amdgcn_wave_barrier();
+      static_for<0, J>([&](auto j) { sp[(2 * j + gl) * 16 + c] = AnD[j]; });
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#else
+      dpp_fence(AnD);
+      static_for<0, J>([&](auto j) {
+        if constexpr (2 * j + 1 < N) pair_split(AnD[j], An[2 * j], An[2 * j + 1]);
+        else { double dummy; pair_split(AnD[j], An[2 * j], dummy); }
+      });
+#endif
+    }
     static_for<0, N>([&](auto k) { fbase[k * fstride] = RU[k]; });
     // pivots d_c = -1 / vfull_c
     {
@@ -201,26 +237,13 @@ __global__ __launch_bounds__(64) void lds_filter_1r_kernel(const LdsArgs a) {
       ldM = __builtin_amdgcn_frexp_mant(ldM);
     }
     static_for<0, N>([&](auto i) { w[off[i]] = M[i] * vfull; });
-
+#if SVAE_FILTER_LDS_SPLIT
     if (!last) {
-      double AnD[J];
-      const bool next_last = (t + 1 == T - 1);
-      if (!INHOMOG && next_last) {
-        asm volatile("; next step is the last: its pivot block has no J11 term");
-        static_for<0, J>([&](auto j) { AnD[j] = CcLast[j]; });
-      } else {
-        static_for<0, J>([&](auto j) { AnD[j] = Cc[j]; });
-      }
-      asm volatile("s_nop 1");
-      static_for<0, N>([&](auto k) {
-        static_for<0, J>([&](auto j) { mac_bc<N + j>(AnD[j], M[k], Bt[k]); });
-      });
-      dpp_fence(AnD);
-      static_for<0, J>([&](auto j) {
-        if constexpr (2 * j + 1 < N) pair_split(AnD[j], An[2 * j], An[2 * j + 1]);
-        else { double dummy; pair_split(AnD[j], An[2 * j], dummy); }
-      });
+      const double* sp = split_tile + (g >> 1) * (N + 1) * 16 + c;
+      static_for<0, N>([&](auto i) { An[i] = sp[i * 16]; });
+      __builtin_amdgcn_wave_barrier();
     }
+#endif
   }
 
   // ---- log-normaliser --------------------------------------------------------------------------------------------

@@ -6,6 +6,6 @@ OUT=$(realpath -m "$1"); shift
 cd "$(dirname "$0")/../svae_amd/csrc"
 TMP=$(mktemp -d)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c lds_estep_tile.hip -o $TMP/tile.o
-OBJS=$(ls build/*.o | grep -v lds_estep_tile.o)
+OBJS=$(ls build/*.o | grep -v "lds_estep_tile" )
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS $TMP/tile.o -o "$OUT"
 rm -rf $TMP

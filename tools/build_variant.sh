@@ -7,6 +7,6 @@ OUT=$(realpath -m "$1"); N=$2; shift 2
 cd "$(dirname "$0")/../svae_amd/csrc"
 TMP=$(mktemp -d)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -DSVAE_N=$N -c lds_estep_n.hip -o $TMP/n.o
-OBJS=$(ls build/*.o | grep -v "lds_estep_n$N.o")
+OBJS=$(ls build/*.o | grep -v "lds_estep_n$N.o" | grep -v sgb5)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS $TMP/n.o -o "$OUT"
 rm -rf $TMP
