@@ -17,6 +17,7 @@ extern "C" {
   int svae_lds_launch_filter_n##NN(const svae::LdsArgs*, int, void*);          \
   int svae_lds_launch_filter_split_n##NN(const svae::LdsArgs*, int, void*);    \
   int svae_lds_launch_filter_1r_n##NN(const svae::LdsArgs*, int, void*);       \
+  int svae_lds_launch_forward_pair_n##NN(const svae::LdsArgs*, const svae::LdsArgs*, int, void*); \
   int svae_lds_sample_n##NN(const svae::SampleArgs*, void*);                   \
   int svae_lds_vjp_n##NN(const svae::VjpArgs*, void*);
 #define SVAE_DECL(NN) SVAE_DECL_(NN)
@@ -206,13 +207,9 @@ int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int k
     // Small batch, hand-off kept: the statistics (and the cross moments the VJP reads: posterior moments, the same
     // whichever way the chain is eliminated) come from the two-ended kernel, while the one-directional FILTER --
     // whose factorisation defines the sampler's eps -> sample map and the records the sweeps differentiate --
-    // runs CONCURRENTLY on a second stream, on the SIMDs the small batch leaves idle (512 + 512 wavefronts on
-    // 1024 SIMDs at B = 512): 0.48 -> 0.25 ms.  Fork / join by events: the caller's stream sees one operation.
-    hipStream_t us = (hipStream_t)stream;
-    svae::ForkJoin fj;
-    if (!svae::fork_join_for(us, &fj)) return -1002;
-    hipStream_t aux = fj.aux;
-    hipEvent_t ev_fork = fj.fork, ev_join = fj.join;
+    // runs NEXT to it on the SIMDs the small batch leaves idle (512 + 512 wavefronts on 1024 SIMDs at B = 512).
+    // Round 4: both in ONE launch (lds_forward_pair_kernel: the first B workgroups take the filter's body, the next
+    // B the E-step's) instead of two kernels on two streams forked and joined by events (0.31 -> 0.27 ms at B = 512).
     svae::LdsArgs f = a;                       // the filter: one-directional layout at the start of the workspace
     f.ws2 = (double*)workspace + main_ws_doubles(B, T, n);
     f.ws3 = nullptr;
@@ -221,11 +218,8 @@ int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int k
     svae::LdsArgs e = a;                       // the E-step: two-ended records behind the one-directional ones
     e.ws = (double*)workspace + one_ws_doubles(B, T, n);
     e.ws2 = nullptr;
-    if (hipEventRecord(ev_fork, us) != hipSuccess || hipStreamWaitEvent(aux, ev_fork, 0) != hipSuccess) return -1002;
-    int rc = -3, rc2 = -3;
     switch (n) {
-#define SVAE_CASE_(NN) case NN: rc = svae_lds_launch_filter_1r_n##NN(&f, inhomog, aux); \
-                                rc2 = svae_lds_launch_twoend_n##NN(&e, inhomog, !inhomog, 1, us); break;
+#define SVAE_CASE_(NN) case NN: return svae_lds_launch_forward_pair_n##NN(&f, &e, inhomog, stream);
 #define SVAE_CASE(NN) SVAE_CASE_(NN)
 #ifdef SVAE_ONLY_N
       SVAE_CASE(SVAE_ONLY_N)
@@ -236,8 +230,7 @@ int svae_lds_estep_f64(int B, int T, int n, int inhomog, int pair_batched, int k
 #undef SVAE_CASE
 #undef SVAE_CASE_
     }
-    if (hipEventRecord(ev_join, aux) != hipSuccess || hipStreamWaitEvent(us, ev_join, 0) != hipSuccess) return -1002;
-    return rc ? rc : rc2;
+    return -3;
   }
   if (twoend && !keep && n <= svae::TE_MAX_N && T >= svae::TE_MIN_T) {
     switch (n) {

@@ -51,6 +51,11 @@ extern "C" int SVAE_CAT(svae_lds_launch_filter_1r_n, SVAE_N)(const svae::LdsArgs
   return svae::launch_filter_1r<SVAE_N>(*a, inhomog != 0, (hipStream_t)stream);
 }
 
+extern "C" int SVAE_CAT(svae_lds_launch_forward_pair_n, SVAE_N)(const svae::LdsArgs* f, const svae::LdsArgs* e, int inhomog,
+                                                                void* stream) {
+  return svae::launch_forward_pair<SVAE_N>(*f, *e, inhomog != 0, (hipStream_t)stream);
+}
+
 extern "C" int SVAE_CAT(svae_lds_launch_filter_split_n, SVAE_N)(const svae::LdsArgs* a, int inhomog, void* stream) {
   return svae::launch_filter_split<SVAE_N>(*a, inhomog != 0, (hipStream_t)stream);
 }

@@ -159,8 +159,10 @@ __device__ __forceinline__ void te_gauss_jordan(double (&M)[N], const double (&E
 // S4 (small batches, homogeneous lean variant): the workgroup has a SECOND wavefront that waits at a barrier through
 // the elimination phase and then runs chain B's smoother while this one runs chain A's, each with four DPP rows per
 // chain (lds_estep_twoend_s4.hpp).
+// (the body as a device function of the workgroup index `blk`: lds_forward_pair_kernel, lds_filter_1r.hpp, runs it next
+//  to the one-directional filter in ONE launch)
 template <int N, bool INHOMOG, bool LEAN, bool MIX = false, bool CROSS = false, bool S4 = false>
-__global__ __launch_bounds__(MIX ? 512 : (S4 ? 128 : 64)) void lds_estep_twoend_kernel(const LdsArgs a) {
+__device__ __forceinline__ void lds_estep_twoend_body(const LdsArgs& a, const int blk) {
   static_assert(!S4 || (LEAN && !INHOMOG && !MIX && !CROSS), "S4: the homogeneous lean variant only");
   static_assert(N >= 1 && N <= TE_MAX_N && N + ((N - 1) >> 1) <= 14,
                 "the right-hand-side columns must fit lanes N..14 of two DPP rows");
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(MIX ? 512 : (S4 ? 128 : 64)) void lds_estep_twoend_
   const int dir = g >> 1;                 // 0: chain A (forward in time), 1: chain B (reversed)
   const int gl = g & 1;                   // DPP row within the chain's pair
   const int nwv = MIX ? (int)(blockDim.x >> 6) : 1;
-  const int bslot = MIX ? blockIdx.x * nwv + wv : blockIdx.x;   // one sequence per wavefront
+  const int bslot = MIX ? blk * nwv + wv : blk;   // one sequence per wavefront
   // MIX: row of every array (and of the workspace) this launch slot works on (surplus slots: any valid row)
   const int b = !MIX ? bslot : (a.seq_index ? a.seq_index[bslot < a.B ? bslot : 0] : bslot);
   double* tab = tab_static;               // (MIX keeps the full hand-off record: no transposition tile)
@@ -982,6 +984,11 @@ __global__ __launch_bounds__(MIX ? 512 : (S4 ? 128 : 64)) void lds_estep_twoend_
     });
     if (col && own_N) a.E_init[(long)b * (N * N + N) + N * N + c] = S[N / 2];
   }
+}
+
+template <int N, bool INHOMOG, bool LEAN, bool MIX = false, bool CROSS = false, bool S4 = false>
+__global__ __launch_bounds__(MIX ? 512 : (S4 ? 128 : 64)) void lds_estep_twoend_kernel(const LdsArgs a) {
+  lds_estep_twoend_body<N, INHOMOG, LEAN, MIX, CROSS, S4>(a, (int)blockIdx.x);
 }
 
 template <int N>

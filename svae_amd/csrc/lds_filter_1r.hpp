@@ -74,7 +74,7 @@ __device__ __forceinline__ void gauss_jordan_1r_hook(double (&M)[N], const doubl
 }
 
 template <int N, bool INHOMOG>
-__global__ __launch_bounds__(64) void lds_filter_1r_kernel(const LdsArgs a) {
+__device__ __forceinline__ void lds_filter_1r_body(const LdsArgs& a, const int blk) {
   static_assert(N >= 1 && N <= TE_MAX_N && N + ((N - 1) >> 1) <= 14, "right-hand-side columns in lanes N..14 of two DPP rows");
   constexpr int HS = ws_h_stride(N), PS = ws_p_stride(N), WS = ws_step_doubles(N);
   constexpr int J = (N + 1) / 2;          // slots holding rows 0..N-1 (row i = 2j + gl)
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(64) void lds_filter_1r_kernel(const LdsArgs a) {
   const int c = lane & 15;
   const int g = lane >> 4;
   const int gl = g & 1;                   // DPP row within its pair; the pairs (0,1) and (2,3) carry the SAME work
-  const int b = blockIdx.x;               // one sequence per wavefront
+  const int b = blk;                      // one sequence per wavefront
   const bool col = c < N;
   const int cc = col ? c : 0;
   const int T = a.T;
@@ -273,6 +273,39 @@ __global__ __launch_bounds__(64) void lds_filter_1r_kernel(const LdsArgs a) {
         old = seen;
       }
     }
+  }
+}
+
+template <int N, bool INHOMOG>
+__global__ __launch_bounds__(64) void lds_filter_1r_kernel(const LdsArgs a) {
+  lds_filter_1r_body<N, INHOMOG>(a, (int)blockIdx.x);
+}
+
+// The forward pass of a training step at small batches in ONE launch: workgroups 0 .. B-1 run the one-directional
+// filter (the longer leg: dispatched first), workgroups B .. 2B-1 the two-ended E-step that also leaves the cross
+// moments (CROSS).  Rounds 2 - 3 ran the two as separate kernels on two streams, forked and joined by events inside
+// svae_lds_estep_f64: 262 us and 200 us of kernels took 0.31 ms on the caller's stream -- ~45 us of event / stream
+// traffic.  One wavefront per SIMD as before (both bodies touch a high AGPR); a workgroup takes one branch, whole.
+// CROSS: the E-step body also stores the cross moments (e.ws3) -- the hand-off of the VJP; without it (factor kept for the
+// sampler only) the plain two-ended body runs.
+template <int N, bool INHOMOG, bool CROSS>
+__global__ __launch_bounds__(64) void lds_forward_pair_kernel(const LdsArgs f, const LdsArgs e) {
+  if ((int)blockIdx.x < f.B) lds_filter_1r_body<N, INHOMOG>(f, (int)blockIdx.x);
+  else lds_estep_twoend_body<N, INHOMOG, !INHOMOG, false, CROSS, false>(e, (int)blockIdx.x - f.B);
+}
+
+template <int N>
+static int launch_forward_pair(const LdsArgs& f, const LdsArgs& e, bool inhomog, hipStream_t stream) {
+  if constexpr (N <= TE_MAX_N) {
+    dim3 grid(f.B + e.B), block(64);
+    const bool cross = e.ws3 != nullptr;
+    if (inhomog && cross) hipLaunchKernelGGL((lds_forward_pair_kernel<N, true, true>), grid, block, 0, stream, f, e);
+    else if (inhomog) hipLaunchKernelGGL((lds_forward_pair_kernel<N, true, false>), grid, block, 0, stream, f, e);
+    else if (cross) hipLaunchKernelGGL((lds_forward_pair_kernel<N, false, true>), grid, block, 0, stream, f, e);
+    else hipLaunchKernelGGL((lds_forward_pair_kernel<N, false, false>), grid, block, 0, stream, f, e);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+  } else {
+    return -3;
   }
 }
 
