@@ -149,3 +149,43 @@ def test_global_step_kernel_against_the_torch_maps(K, N):
     bad[0, :N, :N] = -bad[0, :N, :N]
     gmm.global_step((glob[0], bad))
     assert int(gmm.global_step.last_info.item()) == 1
+
+
+def test_persistent_fixed_point_next_to_a_busy_chip():
+    """The persistent kernel's workgroups WAIT for each other (tagged-partial exchange per sweep): run it on one stream
+    while another stream keeps every CU busy with 4096-sequence E-step launches -- the grid is then not co-scheduled at
+    once -- and compare with the quiet run: same sweep count, bit-identical outputs, no timeout flag."""
+    from svae_amd.lds.lds_inference import LDSEStepPlan
+    from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials
+    from svae_amd.models.gmm import meanfield_from_globals
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(8)
+    K, N, T = 5, 2, 3000
+    niw = np.stack([ef.niw_standard_to_natural(12. * np.eye(N), 2 * rng.standard_normal(N), np.array(10.), np.array(12.))
+                    for _ in range(K)])
+    lg, gg = ef.dirichlet_expectedstats(rng.random(K) + 0.5), ef.niw_expectedstats(niw)
+    node = rand_node_potentials((T, N), rng)
+    init = rng.random((T, K)); init /= init.sum(-1, keepdims=True)
+    quiet = meanfield_from_globals(lg, gg, node, init)
+    assert quiet["path"] == "persistent"
+    # the load: E-step launches on 4096 sequences (two wavefronts per SIMD on the whole chip, ~0.5 ms each)
+    B, TT, n = 4096, 200, 10
+    (J0, h0, z0), (J11, J12, J22, zp) = rand_lds_natparam(n, rng)
+    nJ, nh = rand_node_potentials((B, TT, n), rng)
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev).contiguous()
+    args = [t(x) for x in (J0, h0, z0, J11, J12, J22, zp, nJ, nh)]
+    plan = LDSEStepPlan(B, TT, n, dev)
+    side = torch.cuda.Stream(dev)
+    torch.cuda.synchronize()
+    outs = []
+    for rep in range(6):
+        with torch.cuda.stream(side):
+            for _ in range(4):
+                plan.launch(*args)
+        outs.append(meanfield_from_globals(lg, gg, node, init, check=False))
+    torch.cuda.synchronize()
+    for o in outs:
+        assert int(o["info"].item()) == 0
+        assert int(o["iters"].item()) == int(quiet["iters"].item())
+        for k in ("label_stats", "gaussian_stats", "niw_stats", "dirichlet_stats", "kl"):
+            assert torch.equal(o[k], quiet[k]), k
