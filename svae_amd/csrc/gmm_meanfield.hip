@@ -440,9 +440,13 @@ struct GmmSweeper {
     }
   }
   // one fixed-point sweep (from_init: the responsibilities come from label_init) -> this thread's KL partial
+  // (RES: the caller's compile-time copy of `resident` -- the sweep loops of the kernels that run the whole fixed point
+  //  are written out once per case, so that the register allocation of the resident loop is not the union of both: the
+  //  merged loop carried 120 register moves per sweep)
+  template <bool RES = false>
   __device__ __forceinline__ double sweep(bool from_init) {
     double klpart = 0.0;
-    if (resident) {
+    if constexpr (RES) {
       if (first < a.T) klpart = gmm_point<N, KR>(a, tab, first, nJ, nh, r, nullptr, false);
       return klpart;
     }
@@ -496,13 +500,16 @@ __global__ __launch_bounds__(gmm_block<N>()) void gmm_meanfield_kernel(const Gmm
   // ---- fixed point [gmm.py:90-110] -------------------------------------------------------------
   double kl_prev = 1.0 / 0.0;
   int it = 0;
-  for (int i = 0; i < a.max_iter; ++i) {
-    it = i + 1;
-    const double kl = block_sum<GMM_BLOCK>(sw.sweep(i == 0), red, i);
-    const bool stop = fabs(kl - kl_prev) < a.tol;
-    kl_prev = kl;
-    if (stop) break;
-  }
+  auto run = [&](auto res) {
+    for (int i = 0; i < a.max_iter; ++i) {
+      it = i + 1;
+      const double kl = block_sum<GMM_BLOCK>(sw.template sweep<decltype(res)::value>(i == 0), red, i);
+      const bool stop = fabs(kl - kl_prev) < a.tol;
+      kl_prev = kl;
+      if (stop) break;
+    }
+  };
+  if (KR > 0 && sw.resident) run(std::true_type{}); else run(std::false_type{});
   // ---- final pass + outputs [gmm.py:74-86] -----------------------------------------------------
   const double kl = block_sum<GMM_BLOCK>(sw.final_pass(a.max_iter == 0), red, it);
   if (tid == 0) { a.kl[0] = kl; a.iters[0] = it; }
@@ -667,19 +674,22 @@ __global__ __launch_bounds__(GMM_MW_BLOCK) void gmm_mw_persistent_kernel(const G
 #else
 #define GMM_TICK(k)
 #endif
-  for (int i = 0; i < a.max_iter; ++i) {
-    iters = i + 1;
-    const double klpart = sw.sweep(i == 0);
-    GMM_TICK(0)
-    const double wgsum = block_sum<GMM_MW_BLOCK>(klpart, red, i);
-    GMM_TICK(1)
-    const double total = gmm_exchange(slots + (i & 1) * G, G, (unsigned)(i + 1), wgsum, a.info);
-    GMM_TICK(2)
-    if (blockIdx.x == 0 && tid == 0) m.kl_hist[i] = total;
-    const bool stop = fabs(total - prev) < a.tol;
-    prev = total;
-    if (stop) break;
-  }
+  auto run = [&](auto res) {
+    for (int i = 0; i < a.max_iter; ++i) {
+      iters = i + 1;
+      const double klpart = sw.template sweep<decltype(res)::value>(i == 0);
+      GMM_TICK(0)
+      const double wgsum = block_sum<GMM_MW_BLOCK>(klpart, red, i);
+      GMM_TICK(1)
+      const double total = gmm_exchange(slots + (i & 1) * G, G, (unsigned)(i + 1), wgsum, a.info);
+      GMM_TICK(2)
+      if (blockIdx.x == 0 && tid == 0) m.kl_hist[i] = total;
+      const bool stop = fabs(total - prev) < a.tol;
+      prev = total;
+      if (stop) break;
+    }
+  };
+  if (KR > 0 && sw.resident) run(std::true_type{}); else run(std::false_type{});
 #ifdef SVAE_GMM_TIMING
   if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == G - 1))
     printf("gmm persistent wg %d/%d: %d sweeps, cycles per sweep: point %lld  block_sum %lld  exchange %lld | loop wall %.2f us per sweep\n",
