@@ -40,6 +40,9 @@
 //   one sequence    lds_vjp_sweep2_s4_kernel, lds_vjp_sweep1_s4_kernel (B <= VJP_S4_MAX_B): one sequence per consumer
 //   per wavefront   wavefront, product stages split over its four DPP rows
 #pragma once
+#ifndef SVAE_S2_LDS_GATHER
+#define SVAE_S2_LDS_GATHER 1   // sweep 2, one sequence per consumer: the adjoint for the next step all-gathered through LDS (0: shuffles; A/B)
+#endif
 #include "lds_estep_kernel.hpp"
 #include "lds_estep_twoend_s4.hpp"   // quad_gather
 
@@ -1010,6 +1013,8 @@ __global__ __launch_bounds__(128) void lds_vjp_sweep2_s4_kernel(const VjpArgs a)
   constexpr int J = (N + 3) / 4;                 // slots holding rows 0..N-1 (row i = 4j + r)
   static_assert(WS % 2 == 0 && AS % 2 == 0, "records are copied as 16-byte pairs");
   __shared__ double ring[2 * REC];
+  constexpr int RSG = 4 * J;                      // row stride of the consumer's gather tile
+  __shared__ double gtile[16 * RSG];             // [lane c][row 4j + r]: the adjoint handed to the next step, on its way to every DPP row
   const int lane = threadIdx.x & 63;
   const int T = a.T;
   const long b = blockIdx.x;
@@ -1148,9 +1153,26 @@ __global__ __launch_bounds__(128) void lds_vjp_sweep2_s4_kernel(const VjpArgs a)
     });
     dpp_fence(AbD);
     static_for<0, J>([&](auto j) { mac_bc<N>(gh, AbD[j], ED[j]); });
+    // [Abar | hbar] of this step, all rows in every DPP row, for the next step: through LDS (store [c][row], read back
+    // [c][0..N-1]) -- the round trip runs under the next step's barrier and ring reads, which do not depend on it; as
+    // v_permlane16/32_swap shuffles (quad_gather) it was 36 instructions at the end of every step (round 4)
+#if SVAE_S2_LDS_GATHER
+    __builtin_amdgcn_wave_barrier();
+    static_for<0, J>([&](auto j) { gtile[c * RSG + 4 * j + r] = AbD[j]; });
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    static_for<0, (N + 1) / 2>([&](auto q) {
+      const double2 v = reinterpret_cast<const double2*>(gtile + c * RSG)[q];
+      AbR[2 * q] = v.x;
+      if constexpr (2 * q + 1 < N) AbR[2 * q + 1] = v.y;
+    });
+    __builtin_amdgcn_wave_barrier();
+#else
     double AbG[4 * J];
     static_for<0, J>([&](auto j) { quad_gather(AbD[j], AbG[4 * j], AbG[4 * j + 1], AbG[4 * j + 2], AbG[4 * j + 3]); });
     static_for<0, N>([&](auto i) { AbR[i] = AbG[i]; });
+#endif
     if (olane) {
       a.g_node_J[(b * T + t) * N + c] = -2.0 * gJ;
       a.g_node_h[(b * T + t) * N + c] = gh;
