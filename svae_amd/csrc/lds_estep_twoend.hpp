@@ -61,6 +61,12 @@ __device__ __forceinline__ double asm_sub(double a, double b) {        // a - b,
   return r;
 }
 
+__device__ __forceinline__ double asm_max(double a, double b) {        // fmax as ONE v_max_f64 (hipcc canonicalises both operands first)
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // ---- in-place Gauss-Jordan on one register per row --------------------------------------------------
 // M[i]: lanes < N = row i of P (SPD), other lanes = right-hand-side columns.  On exit lanes < N hold
 // the inverse in "unscaled column" form (true inverse = M[i][c] * v[c], v[c] = -1/p_c accumulated in

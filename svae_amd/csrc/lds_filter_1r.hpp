@@ -146,10 +146,10 @@ __device__ __forceinline__ void lds_filter_1r_body(const LdsArgs& a, const int b
   // lane 15 -> c_i; the right-hand-side lanes of DPP rows 0 and 1 -> X[i][x]; every other lane -> the record's pad
   // entry (the H rows have one when N is even, the P^-1 rows when N is odd).
   constexpr int TRASH = (N % 2 == 0) ? N + 1 : N * HS + N;
-  int off[N];
+  unsigned off[N];                                    // bytes from the step's record (uniform base + 32-bit lane offset)
   static_for<0, N>([&](auto i) {
-    off[i] = (g == 0 && col) ? N * HS + i * PS + c
-             : ((g < 2 && xok) ? i * HS + xx : ((g == 0 && c == HL) ? i * HS + N : TRASH));
+    off[i] = 8u * (unsigned)((g == 0 && col) ? N * HS + i * PS + c
+                             : ((g < 2 && xok) ? i * HS + xx : ((g == 0 && c == HL) ? i * HS + N : TRASH)));
   });
   const int foff = (g == 0 && col) ? c : -1;          // factor rows / pivots: DPP row 0, lanes < N
 
@@ -169,14 +169,15 @@ __device__ __forceinline__ void lds_filter_1r_body(const LdsArgs& a, const int b
 
     double M[N], Bt[N];
     if (last) {
+      // (the operand registers are overwritten in this branch, taken once: selecting E / EX per step costs N moves)
       asm volatile("; last step: no pair potential ahead (G = 0)");
-      static_for<0, N>([&](auto i) { M[i] = __builtin_fma(JoX, E[i], An[i]); });
-    } else {
-      static_for<0, N>([&](auto i) { M[i] = __builtin_fma(JoX, EX[i], An[i]); });
+      static_for<0, N>([&](auto i) { EX[i] = E[i]; });
     }
+    static_for<0, N>([&](auto i) { M[i] = __builtin_fma(JoX, EX[i], An[i]); });
     dpp_fence(ho);
     static_for<0, N>([&](auto i) { mac_bc<i>(M[i], ho, EH); });      // lane 15: h_filt = h_pred + h_node
-    static_for<0, N>([&](auto k) { Bt[k] = __builtin_fma(-EH, M[k], NJ12c[k]); });
+    // (pinned ahead of the elimination: hipcc otherwise sinks these below it and copies M to keep the old values)
+    static_for<0, N>([&](auto k) { Bt[k] = __builtin_fma(-EH, M[k], NJ12c[k]); asm volatile("" : "+v"(Bt[k])); });
     dpp_fence(M);
 
     double* w = wsb + (long)t * WS;
@@ -200,10 +201,9 @@ __device__ __forceinline__ void lds_filter_1r_body(const LdsArgs& a, const int b
       const bool next_last = (t + 1 == T - 1);
       if (!INHOMOG && next_last) {
         asm volatile("; next step is the last: its pivot block has no J11 term");
-        static_for<0, J>([&](auto j) { AnD[j] = CcLast[j]; });
-      } else {
-        static_for<0, J>([&](auto j) { AnD[j] = Cc[j]; });
+        static_for<0, J>([&](auto j) { Cc[j] = CcLast[j]; });
       }
+      static_for<0, J>([&](auto j) { AnD[j] = Cc[j]; });
       asm volatile("s_nop 1");
       static_for<0, N>([&](auto k) {
         static_for<0, J>([&](auto j) { mac_bc<N + j>(AnD[j], M[k], Bt[k]); });
@@ -230,13 +230,20 @@ __device__ __forceinline__ void lds_filter_1r_body(const LdsArgs& a, const int b
       double* pq = foff >= 0 ? w2 + N * N + foff : w + TRASH;
       *pq = pvv;
     }
-    vworst = fmax(vworst, vfull);
+    vworst = asm_max(vworst, vfull);
     ldM *= vfull;
     if ((t & 3) == 3) {
+      asm volatile("; renormalise the determinant product");      // (keeps this a branch: as selects it is 7 instructions per step)
       ldE += __builtin_amdgcn_frexp_exp(ldM);
       ldM = __builtin_amdgcn_frexp_mant(ldM);
     }
-    static_for<0, N>([&](auto i) { w[off[i]] = M[i] * vfull; });
+    {
+      char* wb = reinterpret_cast<char*>(w);            // uniform base + 32-bit lane offset (cf. lds_estep_twoend.hpp hand_off)
+      static_for<0, N>([&](auto i) {
+        asm volatile("" : "+v"(off[i]));
+        *reinterpret_cast<double*>(wb + off[i]) = M[i] * vfull;
+      });
+    }
 #if SVAE_FILTER_LDS_SPLIT
     if (!last) {
       const double* sp = split_tile + (g >> 1) * (N + 1) * 16 + c;

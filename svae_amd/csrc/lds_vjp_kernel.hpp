@@ -40,6 +40,9 @@
 //   one sequence    lds_vjp_sweep2_s4_kernel, lds_vjp_sweep1_s4_kernel (B <= VJP_S4_MAX_B): one sequence per consumer
 //   per wavefront   wavefront, product stages split over its four DPP rows
 #pragma once
+#ifndef SVAE_S2_PROD_PX
+#define SVAE_S2_PROD_PX 1       // sweep 2, one sequence per consumer: the PRODUCER wavefront computes the recursion-free product P^-1 [-G^ | G^[:,n]] (0: consumer; A/B)
+#endif
 #ifndef SVAE_S2_LDS_GATHER
 #define SVAE_S2_LDS_GATHER 1   // sweep 2, one sequence per consumer: the adjoint for the next step all-gathered through LDS (0: shuffles; A/B)
 #endif
@@ -1012,7 +1015,9 @@ __global__ __launch_bounds__(128) void lds_vjp_sweep2_s4_kernel(const VjpArgs a)
   constexpr int KW = (WS / 2 + 63) / 64, KA = (AS / 2 + 63) / 64;
   constexpr int J = (N + 3) / 4;                 // slots holding rows 0..N-1 (row i = 4j + r)
   static_assert(WS % 2 == 0 && AS % 2 == 0, "records are copied as 16-byte pairs");
-  __shared__ double ring[2 * REC];
+  constexpr int PXO = REC;                        // slot: [E-step record | sweep-1 record | PX (J slots x 64 lanes)]
+  constexpr int REC2 = SVAE_S2_PROD_PX ? REC + J * 64 : REC;
+  __shared__ double ring[2 * REC2];
   constexpr int RSG = 4 * J;                      // row stride of the consumer's gather tile
   __shared__ double gtile[16 * RSG];             // [lane c][row 4j + r]: the adjoint handed to the next step, on its way to every DPP row
   const int lane = threadIdx.x & 63;
@@ -1026,19 +1031,63 @@ __global__ __launch_bounds__(128) void lds_vjp_sweep2_s4_kernel(const VjpArgs a)
     static_assert(PD == 6, "six named stages");
     vd2* slot0 = reinterpret_cast<vd2*>(ring);
     auto rec = [&](int t) { return t > 0 ? t : 0; };
+#if SVAE_S2_PROD_PX
+    // PX_t = P^-1 [-G^ | G^[:,n]]_t (G^ with the sampler share), the part of Bbar_t that does not depend on the recursion:
+    // computed here, from the record just published, in the consumer's slot layout (row i = 4j + r in DPP row r) -- the
+    // consumer's serial chain per step is then  Bbar = PX - H Abar_{t+1}  ->  Pbar  ->  Abar_t  with ONE all-gather
+    // (it was  Xbar = Xhat - J12 Abar -> all-gather -> Bbar = P^-1 Xbar -> Pbar -> Abar_t -> all-gather)
+    const int pc = lane & 15, pr = lane >> 4;
+    const bool pcol = pc < N;
+    const int pcN = pc <= N ? pc : 0, pcc = pcol ? pc : 0;
+    const double pEN = (pc == N) ? 1.0 : 0.0;
+    const double psg = pcol ? -1.0 : (pc == N ? 1.0 : 0.0);
+    int pri[J];
+    double prm[J];
+    static_for<0, J>([&](auto j) { const int i = 4 * j + pr; pri[j] = i < N ? i : 0; prm[j] = i < N ? 1.0 : 0.0; });
+    const int pS = a.S;
+    auto publish_px = [&](double* slot) {
+      const double* w = slot;
+      const double* ad = w + WS;
+      double Pi[J], XR[N], PX[J];
+      static_for<0, J>([&](auto j) { Pi[j] = w[N * HS + pri[j] * PS + pcc]; });
+      static_for<0, N>([&](auto k) { XR[k] = ad[k * HS + pcN]; });                 // row k of G^ in every DPP row
+      if constexpr (SAMP) {
+        // sampler share of G^ (two-role launch: factors per sample):  G^ += sum_s xhat_s [x_{t+1,s}' | 1]
+        auto add_sample = [&](auto s) {
+          const double* vo = ad + vjp_vec_off(N) + s * 2 * N;
+          const double x1 = vo[N + pcc];
+          const double vv = pcol ? x1 : pEN;
+          static_for<0, N>([&](auto k) { XR[k] = __builtin_fma(vo[k], vv, XR[k]); });
+        };
+        add_sample(std::integral_constant<int, 0>{});
+        if (pS > 1) static_for<1, VJP_SPLIT_MAX_S>([&](auto s) { if (s < pS) add_sample(s); });
+      }
+      static_for<0, J>([&](auto j) { Pi[j] *= prm[j]; PX[j] = 0.0; });
+      dpp_fence(Pi);
+      static_for<0, N>([&](auto k) {
+        static_for<0, J>([&](auto j) { mac_bc<k>(PX[j], Pi[j], XR[k]); });
+      });
+      static_for<0, J>([&](auto j) { slot[PXO + j * 64 + lane] = PX[j] * psg; });
+    };
+#define SVAE_PUBLISH_PX(slotv) publish_px(reinterpret_cast<double*>(slotv));
+#else
+#define SVAE_PUBLISH_PX(slotv)
+#endif
     prod_issue<WS / 2, AS / 2>(s0, wrec, arec, rec(T - 1), lane);
     prod_issue<WS / 2, AS / 2>(s1, wrec, arec, rec(T - 2), lane);
     prod_issue<WS / 2, AS / 2>(s2, wrec, arec, rec(T - 3), lane);
     prod_issue<WS / 2, AS / 2>(s3, wrec, arec, rec(T - 4), lane);
     prod_issue<WS / 2, AS / 2>(s4, wrec, arec, rec(T - 5), lane);
     prod_issue<WS / 2, AS / 2>(s5, wrec, arec, rec(T - 6), lane);
-    prod_publish<WS / 2, AS / 2>(s0, slot0 + ((T - 1) & 1) * (REC / 2), lane);
+    prod_publish<WS / 2, AS / 2>(s0, slot0 + ((T - 1) & 1) * (REC2 / 2), lane);
     prod_issue<WS / 2, AS / 2>(s0, wrec, arec, rec(T - 7), lane);
+    SVAE_PUBLISH_PX(slot0 + ((T - 1) & 1) * (REC2 / 2))
     lds_barrier();                                     // barrier 0: step T-1 is in its slot
 #define SVAE_PROD_STEP(sg, t)                                                                         \
     {                                                                                                   \
-      prod_publish<WS / 2, AS / 2>(sg, slot0 + (((t) - 1) & 1) * (REC / 2), lane);                      \
+      prod_publish<WS / 2, AS / 2>(sg, slot0 + (((t) - 1) & 1) * (REC2 / 2), lane);                     \
       prod_issue<WS / 2, AS / 2>(sg, wrec, arec, rec((t) - 1 - PD), lane);                              \
+      SVAE_PUBLISH_PX(slot0 + (((t) - 1) & 1) * (REC2 / 2))                                             \
       lds_barrier();                                                                                    \
     }
     int t0 = T - 1;
@@ -1056,6 +1105,7 @@ __global__ __launch_bounds__(128) void lds_vjp_sweep2_s4_kernel(const VjpArgs a)
     if (t0 >= 4) SVAE_PROD_STEP(s4, t0 - 3)
     if (t0 >= 5) SVAE_PROD_STEP(s5, t0 - 4)
 #undef SVAE_PROD_STEP
+#undef SVAE_PUBLISH_PX
     return;
   }
   // ---- consumer wavefront -------------------------------------------------------------------------------------------
@@ -1063,29 +1113,53 @@ __global__ __launch_bounds__(128) void lds_vjp_sweep2_s4_kernel(const VjpArgs a)
   const bool col = c < N, colN = c <= N;
   const int cN = colN ? c : 0, cc = col ? c : 0;
   const double EN = (c == N) ? 1.0 : 0.0;
-  const double sg = col ? -1.0 : (c == N ? 1.0 : 0.0);
+  [[maybe_unused]] const double sg = col ? -1.0 : (c == N ? 1.0 : 0.0);
   double ED[J];                                     // ED[j][c] = (c == 4j + r): the diagonal in slot layout
   static_for<0, J>([&](auto j) { ED[j] = (c == 4 * j + r && c < N) ? 1.0 : 0.0; });
   int ri[J];                                        // this DPP row's tile rows (clamped) and their validity
   double rm[J];
   static_for<0, J>([&](auto j) { const int i = 4 * j + r; ri[j] = i < N ? i : 0; rm[j] = i < N ? 1.0 : 0.0; });
+#if !SVAE_S2_PROD_PX
   double J12c[J];                                   // info form: J12 = -natJ12, my rows
   const double* pJ12 = a.J12 + b * a.pair_seq_stride;
   static_for<0, J>([&](auto j) { J12c[j] = 0.0; });
   if (T > 1 && a.pair_t_stride == 0)
     static_for<0, J>([&](auto j) { const double v = pJ12[ri[j] * N + cc]; J12c[j] = col ? -v * rm[j] : 0.0; });
+#endif
   const double g = a.g_lognorm[b];
   double AbR[N];                                    // [Abar | hbar] of step t+1, replicated over the DPP rows
   static_for<0, N>([&](auto i) { AbR[i] = 0.0; });
   const bool olane = col && (c & 3) == r;           // lane i of DPP row i & 3 reports node i
   int so[J];                                        // entry (row, c) of a symmetric matrix kept as its lower triangle
   static_for<0, J>([&](auto j) { so[j] = cc <= ri[j] ? ri[j] * (ri[j] + 1) / 2 + cc : cc * (cc + 1) / 2 + ri[j]; });
-  const int S = a.S;
+  [[maybe_unused]] const int S = a.S;
 
   for (int t = T - 1; t >= 0; --t) {
     lds_barrier();                                  // step t is in slot t % 2
-    const double* w = ring + (t & 1) * REC;
+    const double* w = ring + (t & 1) * REC2;
     const double* ad = w + WS;
+#if SVAE_S2_PROD_PX
+    double Pi[J], Hc[J], Pb[J], HT[N + 1], Bb[J];
+    static_for<0, J>([&](auto j) {
+      Hc[j] = w[ri[j] * HS + cN];
+      Bb[j] = w[PXO + j * 64 + lane];               // PX_t, from the producer
+      Pi[j] = w[N * HS + ri[j] * PS + cc];
+      Pb[j] = ad[vjp_pbp_off(N) + so[j]];
+      if constexpr (SAMP) Pb[j] += ad[vjp_pex_off(N) + ri[j] * PS + cc];
+    });
+    load_row<N + 1>(w + cc * HS, HT);               // H' (lane c: row c of H), the same in every DPP row
+    // Bbar = P^-1 ([-G^ | G^[:,n]] - J12_t [Abar | hbar]_{t+1}) = PX - H [Abar | hbar]_{t+1}      (my rows; H = P^-1 J12_t
+    // is the forward record's, so the per-step pair parameters are not read again)
+    if (t < T - 1) {
+      double HcM[J];
+      static_for<0, J>([&](auto j) { HcM[j] = Hc[j] * rm[j]; });
+      dpp_fence(HcM);
+      static_for<0, N>([&](auto k) {
+        static_for<0, J>([&](auto j) { mac_bc<k, true>(Bb[j], HcM[j], AbR[k]); });
+      });
+    }
+    static_for<0, J>([&](auto j) { Pi[j] *= rm[j]; });
+#else
     double gb[J], Pi[J], Hc[J], Pb[J], HT[N + 1];
     static_for<0, J>([&](auto j) {
       gb[j] = ad[ri[j] * HS + cN];
@@ -1132,6 +1206,7 @@ __global__ __launch_bounds__(128) void lds_vjp_sweep2_s4_kernel(const VjpArgs a)
     static_for<0, N>([&](auto k) {
       static_for<0, J>([&](auto j) { mac_bc<k>(Bb[j], Pi[j], XcR[k]); });
     });
+#endif
     // Pbar = [sweep-1 shares] - Bbar H' - 1/2 g (c c' + P^-1)
     dpp_fence(Bb);
     static_for<0, N + 1>([&](auto k) {
