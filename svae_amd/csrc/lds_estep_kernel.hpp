@@ -725,7 +725,11 @@ __global__ __launch_bounds__(320) void lds_sample_vec_prod_kernel(const SampleAr
   constexpr int HS = ws_h_stride(N), WS = ws_step_doubles(N);
   constexpr int SMAX = 4, PD = SAMPLE_PD;
   constexpr int R1 = N * HS + N * N + N;
-  constexpr int KT = (R1 + SMAX * N + 63) / 64, REC = KT * 64, SLOT = 4 * REC;
+  // record in a ring slot: [H rows | LDL' factor | pivots | eps (SMAX x N) | zeros (N + 1)]: the consumer's idle lanes
+  // (c >= N) read the zero row instead of masking every operand (2 v_cndmask per double: ~40 of ~145 instructions per step)
+  constexpr int ZO = R1 + SMAX * N;
+  static_assert(ZO % 2 == 0, "the zero row is read as 16-byte pairs");
+  constexpr int KT = (ZO + N + 1 + 63) / 64, REC = KT * 64, SLOT = 4 * REC;
   __shared__ double ring[2 * SLOT];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int T = a.T, S = a.S, SN = S * N;
@@ -737,7 +741,10 @@ __global__ __launch_bounds__(320) void lds_sample_vec_prod_kernel(const SampleAr
     const double* wsq = a.ws + bb * ws_seq_doubles(N, T) + ws_zpage_doubles(N);
     const double* base[KT];
     int stp[KT], off[KT];
-    static_for<0, KT>([&](auto k) { base[k] = wsq; stp[k] = 0; off[k] = 0; });
+    // (pieces outside the three segments -- the unused sample rows and the zero row -- re-read a 0.0 of the sequence's
+    //  constant page, which every forward kernel that keeps the factor writes: [e_n (HS) | zeros])
+    const double* zero = wsq - ws_zpage_doubles(N) + HS;
+    static_for<0, KT>([&](auto k) { base[k] = zero; stp[k] = 0; off[k] = 0; });
     int start = 0;
     auto seg = [&](const double* p, int len, int stride) {
       static_for<0, KT>([&](auto k) {
@@ -803,18 +810,21 @@ __global__ __launch_bounds__(320) void lds_sample_vec_prod_kernel(const SampleAr
   const double* ringrow = ring + (lane >> 4) * REC;
   double X[SMAX];                              // x_{t+1}[c] per sample
   static_for<0, SMAX>([&](auto s) { X[s] = 0.0; });
+  const int hoff = col ? c * HS : ZO;          // this lane's row of H, or the zero row
+  double mL[N];                                // L[i][c] below the diagonal only: the other entries of the stored block are
+  static_for<0, N>([&](auto i) { mL[i] = (c < i && col) ? 1.0 : 0.0; });   // finite by-products of the elimination
+  const double cm = col ? 1.0 : 0.0;
   for (int t = T - 1; t >= 0; --t) {
     lds_barrier();                             // step t is in slot t%2
     const double* rec = ringrow + (t & 1) * SLOT;
     double H[N + 1], Lc[N], Y[SMAX], E[SMAX];
-    load_row<N + 1>(rec + cc * HS, H);                                       // H[j] = [P^-1 J12 | c][c][j]
+    load_row<N + 1>(rec + hoff, H);                                          // H[j] = [P^-1 J12 | c][c][j]
     static_for<0, N>([&](auto i) { Lc[i] = rec[N * HS + cc * N + i]; });     // lane c of register i = L[i][c]
     const double pv = rec[N * HS + N * N + cc];
     static_for<0, SMAX>([&](auto s) { E[s] = rec[R1 + (s < S ? s : S - 1) * N + cc]; });
-    static_for<0, N + 1>([&](auto k) { H[k] = col ? H[k] : 0.0; });
-    static_for<0, N>([&](auto i) { Lc[i] = (c < i && col) ? Lc[i] : 0.0; }); // L[i][c] below the diagonal only
-    const double dis = rsqrt_nr(col ? pv : 1.0);
-    static_for<0, SMAX>([&](auto s) { Y[s] = col ? dis * E[s] : 0.0; });
+    static_for<0, N>([&](auto i) { Lc[i] *= mL[i]; });
+    const double dis = rsqrt_nr(col ? pv : 1.0) * cm;
+    static_for<0, SMAX>([&](auto s) { Y[s] = dis * E[s]; });
     dpp_fence(X);
     dpp_fence(Y);
     static_for<0, SMAX>([&](auto s) {
