@@ -43,18 +43,6 @@ namespace svae {
 // which variants re-replicate the next pivot block through LDS (else: v_permlane16_swap shuffles); MIX never does
 template <bool MIX, bool CROSS> constexpr bool TE_LDS_SPLIT() { return !MIX && (((SVAE_TE_LDS_SPLIT) >> (CROSS ? 1 : 0)) & 1); }
 
-// rows 2j (DPP row 0 of the pair) and 2j+1 (DPP row 1) of a slot register -> two registers replicated
-// over the pair.  v_permlane16_swap exchanges the odd rows of its first operand with the even rows of
-// its second; the compiler pads the VALU -> permlane hazard of the copies it makes (the inputs must
-// already be fenced from asm producers, see dpp_fence).
-__device__ __forceinline__ void pair_split(double x, double& even_row, double& odd_row) {
-  const unsigned lo = __double2loint(x), hi = __double2hiint(x);
-  const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-  const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-  even_row = __hiloint2double(rh[0], rl[0]);
-  odd_row = __hiloint2double(rh[1], rl[1]);
-}
-
 __device__ __forceinline__ double asm_sub(double a, double b) {        // a - b, kept in program order
   double r;
   asm volatile("v_add_f64 %0, %1, -%2" : "=v"(r) : "v"(a), "v"(b));

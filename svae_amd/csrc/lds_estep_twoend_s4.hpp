@@ -17,6 +17,18 @@
 
 namespace svae {
 
+// rows 2j (DPP row 0 of the pair) and 2j+1 (DPP row 1) of a slot register -> two registers replicated
+// over the pair.  v_permlane16_swap exchanges the odd rows of its first operand with the even rows of
+// its second; the compiler pads the VALU -> permlane hazard of the copies it makes (the inputs must
+// already be fenced from asm producers, see dpp_fence).
+__device__ __forceinline__ void pair_split(double x, double& even_row, double& odd_row) {
+  const unsigned lo = __double2loint(x), hi = __double2hiint(x);
+  const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  even_row = __hiloint2double(rh[0], rl[0]);
+  odd_row = __hiloint2double(rh[1], rl[1]);
+}
+
 // x: one value per DPP row  ->  the four rows' values, each replicated over the wavefront (register shuffles: used by the
 // reverse-mode sweeps, lds_vjp_kernel.hpp; the smoother below gathers through LDS instead).
 // v_permlane16_swap(x, x) leaves the even rows' values replicated over their row pairs in its first result and the

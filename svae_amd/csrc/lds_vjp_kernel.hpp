@@ -40,6 +40,12 @@
 //   one sequence    lds_vjp_sweep2_s4_kernel, lds_vjp_sweep1_s4_kernel (B <= VJP_S4_MAX_B): one sequence per consumer
 //   per wavefront   wavefront, product stages split over its four DPP rows
 #pragma once
+#ifndef SVAE_S1_PAIR
+#define SVAE_S1_PAIR 0          // sweep 1, packed producer launch with samples: two role-0 consumer wavefronts in the row-pair layout (0: one, four whole sequences).  Measured, not kept: DESIGN 7.2
+#endif
+#ifndef SVAE_S1_NH1
+#define SVAE_S1_NH1 2           // sweep 1, packed producer launch: helper wavefronts of the sampler-adjoint role (2 or 3).  3: measured, not kept: DESIGN 7.2
+#endif
 #ifndef SVAE_S2_PROD_PX
 #define SVAE_S2_PROD_PX 1       // sweep 2, one sequence per consumer: the PRODUCER wavefront computes the recursion-free product P^-1 [-G^ | G^[:,n]] (0: consumer; A/B)
 #endif
@@ -126,7 +132,9 @@ __device__ __forceinline__ void for_samples(int S, F&& f) {
 //   barrier t (t < T): step t's record is in ring slot t%3;  barrier t+1: the consumer's mailbox of step t is written.
 constexpr int VJP_PROD_MAX_S = 4;
 static_assert(VJP_PROD_MAX_S <= VJP_SPLIT_MAX_S, "the producer variants run as two roles");
-constexpr int VJP_S1_WAVES = 7;              // consumer, 4 producers, up to 2 helpers
+// consumer, 4 producers, 2 helpers (+ 1 with the experimental SVAE_S1_PAIR / SVAE_S1_NH1 = 3 layouts: a second role-0
+// consumer / a third role-1 helper).  Wavefronts w and w + 4 of a workgroup share a SIMD (tools/scratch/hwid.hip).
+constexpr int VJP_S1_WAVES = (SVAE_S1_PAIR || SVAE_S1_NH1 == 3) ? 8 : 7;
 template <int N> constexpr int vjp_s1_pieces() {
   constexpr int HS = ws_h_stride(N), WS = ws_step_doubles(N);
   constexpr int r0 = WS + (N + 1) * HS + 2 * N, r1 = N * HS + N * N + N + 3 * VJP_PROD_MAX_S * N;
@@ -314,6 +322,89 @@ __device__ __forceinline__ void s1_role0_wg(const VjpArgs& a, double* ring, doub
   lds_barrier();                                              // barrier T
 }
 
+// Consumer of the smoother adjoint for TWO of the workgroup's four sequences (packed producer launch with samples: the
+// role-0 workgroup runs two of these, wavefronts 0 and 7): each sequence on a PAIR of DPP rows that split every product
+// stage by output row (row i of a tile in DPP row i & 1 of the pair, slot i >> 1) -- 2 x 66 DPP multiply-adds and one
+// row exchange (v_permlane16_swap) per step instead of the 252 of one wavefront holding four whole sequences, which was
+// the longest instruction stream of the sweep (354 instructions per step).  Ring, mailbox and barrier protocol are
+// those of lds_vjp_sweep1_body (the helpers and producers are unchanged: rows of S^ go to the mailbox of the sequence).
+template <int N>
+__device__ __forceinline__ void s1_role0_pair_consumer(const VjpArgs& a, const double* ring, double* mail, const int grp,
+                                                       const int half) {
+  constexpr int HS = ws_h_stride(N), WS = ws_step_doubles(N);
+  constexpr int W3 = (N + 1) * HS;
+  constexpr int KT = vjp_s1_pieces<N>(), REC = KT * 64, SLOT = 4 * REC, MSLOT = 4 * N * 16;
+  constexpr int J = (N + 1) / 2;             // slots holding rows 0..N-1 (row i = 2j + q)
+  constexpr int J1 = (N + 2) / 2;            // slots holding rows 0..N
+  constexpr int NS = N >> 1, NR = N & 1;     // row N: slot NS of DPP row NR of the pair
+  const int lane = threadIdx.x & 63, c = lane & 15, q = (lane >> 4) & 1, row = 2 * half + (lane >> 5);
+  const int T = a.T;
+  const bool col = c < N, colN = c <= N;
+  const int cN = colN ? c : 0, ccl = col ? c : 0;
+  const double* ringrow = ring + row * REC;
+  double* mailrow = mail + row * N * 16;
+  double rm[J];
+  int ri[J1];
+  static_for<0, J>([&](auto j) { rm[j] = (2 * j + q < N) ? 1.0 : 0.0; });
+  static_for<0, J1>([&](auto j) { const int i = 2 * j + q; ri[j] = i <= N ? i : 0; });
+  const double EN = (c == N) ? 1.0 : 0.0;
+  const double sg = col ? -1.0 : (c == N ? 1.0 : 0.0);
+  const double cm = col ? 1.0 : 0.0;
+  const bool own_N = (q == NR);
+  const bool has_gx = a.g_x != nullptr, has_gd = a.g_diagxx != nullptr;
+  double ED[J], sgi[J1], dN[J1];
+  static_for<0, J>([&](auto j) { ED[j] = (c == 2 * j + q && c < N) ? 1.0 : 0.0; });
+  static_for<0, J1>([&](auto j) {
+    const int i = 2 * j + q;
+    sgi[j] = i < N ? -1.0 : (i == N ? 1.0 : 0.0);       // sign of column i of G~ (0: no such row)
+    dN[j] = (i == N) ? EN : 0.0;                        // row N of G~ is e_N: G~[N][i] = (i == N), in lane N
+  });
+  double Sh[J1];
+  static_for<0, J1>([&](auto j) { Sh[j] = 0.0; });
+  for (int t = 0; t < T; ++t) {
+    lds_barrier();                                            // barrier t: step t is in slot t % 3
+    const double* rec = ringrow + (t % 3) * SLOT;
+    double Gc[N + 1], GcT[J1], gxs[J];
+    static_for<0, N>([&](auto k) { Gc[k] = rec[k * HS + cN]; });
+    static_for<0, J1>([&](auto j) { GcT[j] = rec[ccl * HS + ri[j]]; });        // lane k: H[k][i]
+    static_for<0, J>([&](auto j) { gxs[j] = rec[WS + W3 + (2 * j + q < N ? 2 * j + q : 0)]; });
+    const double gxl = rec[WS + W3 + ccl], gdl = rec[WS + W3 + N + ccl];
+    static_for<0, N>([&](auto k) { Gc[k] *= sg; });                            // G~ row k (replicated)
+    Gc[N] = EN;
+    static_for<0, J1>([&](auto j) { GcT[j] = __builtin_fma(cm * sgi[j], GcT[j], dN[j]); });   // row i of G~'
+    // S^ += direct cotangents, symmetrised: S^[i][N] += g_x[i] / 2, S^[N][c] += g_x[c] / 2, S^[i][i] += g_diagxx[i]
+    const double gx = (has_gx && col) ? 0.5 * gxl : 0.0, gd = (has_gd && col) ? gdl : 0.0;
+    static_for<0, J>([&](auto j) {
+      Sh[j] = __builtin_fma(EN * rm[j], has_gx ? 0.5 * gxs[j] : 0.0, Sh[j]);
+      Sh[j] = __builtin_fma(gd, ED[j], Sh[j]);
+    });
+    Sh[NS] += own_N ? gx : 0.0;
+    // rows 0..N-1 of S^ (before the propagation) for the helper wavefronts: Pinvbar = S^[:n,:n], G^ = 2 S^ W~'
+    {
+      double* mb = mailrow + (t & 1) * MSLOT;
+      static_for<0, J>([&](auto j) { if (2 * j + q < N) mb[(2 * j + q) * 16 + c] = Sh[j]; });
+    }
+    // S^ <- G~' (S^ G~)
+    double M[J1];
+    static_for<0, J1>([&](auto j) { M[j] = 0.0; });
+    dpp_fence(Sh);
+    static_for<0, N + 1>([&](auto k) {
+      static_for<0, J1>([&](auto j) { mac_bc<k>(M[j], Sh[j], Gc[k]); });
+    });
+    dpp_fence(M);
+    double MR[2 * J1];
+    static_for<0, J1>([&](auto j) { pair_split(M[j], MR[2 * j], MR[2 * j + 1]); });
+    double Sn[J1];
+    static_for<0, J1>([&](auto j) { Sn[j] = 0.0; });
+    dpp_fence(GcT);
+    static_for<0, N + 1>([&](auto k) {
+      static_for<0, J1>([&](auto j) { mac_bc<k>(Sn[j], GcT[j], MR[k]); });
+    });
+    static_for<0, J1>([&](auto j) { Sh[j] = Sn[j]; });
+  }
+  lds_barrier();                                              // barrier T
+}
+
 // grp: index of the workgroup's group of four sequences
 template <int N, bool SAMP, bool STATC, bool SPLIT, bool PROD, int ROLE>
 __device__ __forceinline__ void lds_vjp_sweep1_body(const VjpArgs& a, double* tabs, double* ring, double* mail,
@@ -328,11 +419,18 @@ __device__ __forceinline__ void lds_vjp_sweep1_body(const VjpArgs& a, double* ta
   const int lane = threadIdx.x & 63;
   if constexpr (PROD) {
     const int wv = threadIdx.x >> 6;
+    if constexpr (SAMP && ROLE == 0 && SVAE_S1_PAIR) {
+      // two consumer wavefronts (0 and 7), two sequences each, in the row-pair layout
+      if (wv == 0 || wv == 7) { s1_role0_pair_consumer<N>(a, ring, mail, grp, wv == 7 ? 1 : 0); return; }
+    }
     if (wv >= 5) {
       // ---- helper wavefronts ---------------------------------------------------------------------------------------
-      constexpr int NH = 2;              // role 0: Pbar share | G^ rows;  role 1: the noise adjoint of alternate steps
+      constexpr int NH = ROLE == 1 ? SVAE_S1_NH1 : 2;   // role 0: Pbar share | G^ rows;  role 1: the noise adjoint of every NH-th step
       const int h = wv - 5, T = a.T;
       if (h >= NH) return;
+#ifdef SVAE_S1_SKIP_H
+      if (ROLE != 1 && ((SVAE_S1_SKIP_H >> h) & 1)) return;        // (timing experiment)
+#endif
       const int c = lane & 15, row = lane >> 4;
       const int brow = grp * 4 + row;
       const bool valid = brow < a.B;
@@ -379,8 +477,8 @@ __device__ __forceinline__ void lds_vjp_sweep1_body(const VjpArgs& a, double* ta
         double E[N], mU[N];
         static_for<0, N>([&](auto i) { E[i] = (c == i) ? 1.0 : 0.0; });
         static_for<0, N>([&](auto j) { mU[j] = (c > j) ? 1.0 : ((c == j) ? 0.5 : 0.0); });
-        for (int k = 0; k <= h; ++k) lds_barrier();                    // barriers 0 .. h
-        for (int t = h; t < T; t += 2) {
+        for (int k = 0; k <= h && k <= T; ++k) lds_barrier();          // barriers 0 .. h
+        for (int t = h; t < T; t += NH) {
           lds_barrier();                                               // barrier t+1: xhat_t is in the mailbox
           const double* rec = ringrow + (t % 3) * SLOT;
           const double* mb = mailrow + (t & 1) * MSLOT;
@@ -406,15 +504,17 @@ __device__ __forceinline__ void lds_vjp_sweep1_body(const VjpArgs& a, double* ta
             static_for<0, N>([&](auto j) { mac_bc<j>(z[j], U[i], xh[i]); });        // z = U' xhat
           });
           dpp_fence(z);
+          if (NH == 3 && t + 2 <= T) lds_barrier();                    // barrier t+2 (the job spans NH intervals)
           static_for<0, VJP_PROD_MAX_S>([&](auto s) {
             const double ev = (col && s < S) ? epr[s] : 0.0;                         // (S <= 4: no branches)
             static_for<0, N>([&](auto j) { mac_bc<s>(ET[j], z[j], ev); });         // ET[j][c] = E[c][j]
           });
-          if (t + 2 <= T) lds_barrier();                               // barrier t+2 (the job spans two intervals)
+          if (NH == 2 && t + 2 <= T) lds_barrier();                    // barrier t+2
           double LhT[N], K[N], KT_[N], Pex[N];
           static_for<0, N>([&](auto j) { LhT[j] = ET[j] * mU[j]; K[j] = 0.0; Pex[j] = 0.0; });
           mm_ab<N, N, false>(K, U, LhT);              // K = U Lh'
           transpose_tile<N>(tab, c, K, KT_);          // KT = Lh U'
+          if (NH == 3 && t + 3 <= T) lds_barrier();                    // barrier t+3
           mm_ab<N, N, true>(Pex, U, KT_);             // Pex = -U Lh U'
           double* ad = a.adj + (b * T + t) * AS;
           if (valid && col) static_for<0, N>([&](auto i) { ad[vjp_pex_off(N) + i * PS + c] = Pex[i]; });
@@ -786,10 +886,13 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep1_kernel(const VjpArgs a) {
 // consumer wavefront + four producer wavefronts + helper wavefronts
 template <int N, bool SAMP>
 __global__ __launch_bounds__(64 * VJP_S1_WAVES) void lds_vjp_sweep1_prod_kernel(const VjpArgs a) {
-  __shared__ double tabs[2 * 4 * 256];
+  __shared__ double tabs[(SVAE_S1_NH1 == 3 ? 3 : 2) * 4 * 256];
   __shared__ double ring[vjp_s1_ring_doubles<N>()];
   __shared__ double mail[2 * 4 * N * 16];
   if constexpr (SAMP) {
+#ifdef SVAE_S1_SKIP_ROLE
+    if ((blockIdx.x & 1) == SVAE_S1_SKIP_ROLE) return;     // (timing experiment: one role alone)
+#endif
     if ((blockIdx.x & 1) == 0) lds_vjp_sweep1_body<N, true, false, true, true, 0>(a, tabs, ring, mail, blockIdx.x >> 1);
     else lds_vjp_sweep1_body<N, true, false, true, true, 1>(a, tabs, ring, mail, blockIdx.x >> 1);
   } else {
