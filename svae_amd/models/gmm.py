@@ -165,15 +165,29 @@ def meanfield_from_globals(label_global, gaussian_globals, node_potentials, labe
             p(out["gaussian_natparam"]), p(out["dirichlet_stats"]), p(out["niw_stats"]),
             p(out["kl"]), p(out["iters"]), p(out["assign"]), p(out["info"]), _lib.current_stream(dev))
         _lib.check(rc, "svae_gmm_meanfield_f64")
+    global last_info
+    last_info = out["info"]
     if check:
-        v = int(out["info"].item())
-        if v < 0:
-            raise RuntimeError("GMM mean field: a workgroup never received a partner's KL partial (info %d): "
-                               "the grid of the persistent kernel was not co-resident" % v)
-        if v != 0:
-            raise FloatingPointError("GMM mean field: point %d has a non positive definite "
-                                     "Gaussian factor" % (v - 1))
+        check_info(out["info"])
     return out
+
+
+last_info = None     # status word of the most recent fixed point (device tensor; see check_info)
+
+
+def check_info(info=None):
+    """Read a fixed point's status word (default: the most recent call's) -- a host synchronisation -- and raise what
+    it reports."""
+    info = last_info if info is None else info
+    if info is None:
+        return
+    v = int(info.item())
+    if v < 0:
+        raise RuntimeError("GMM mean field: a workgroup never received a partner's KL partial (info %d): "
+                           "the grid of the persistent kernel was not co-resident" % v)
+    if v != 0:
+        raise FloatingPointError("GMM mean field: point %d has a non positive definite "
+                                 "Gaussian factor" % (v - 1))
 
 
 def global_step(global_natparam, prior_natparam=None, info=None):
@@ -264,9 +278,11 @@ def _allreduce_stats_and_kl(stats, local_kl, group):
 
 
 def run_inference(prior_natparam, global_natparam, nn_potentials, num_samples, label_init=None,
-                  eps=None, generator=None, group=None, reference_compat=False):
+                  eps=None, generator=None, group=None, reference_compat=False, check=True):
     """gmm.py:12-16 -> (samples (T,S,N), (dirichlet_stats, niw_stats), global_kl, local_kl).  Under
-    torch.distributed the points are this rank's shard; statistics and local_kl are summed over ranks."""
+    torch.distributed the points are this rank's shard; statistics and local_kl are summed over ranks.
+    check=False: no host synchronisation (hipGraph capture, asynchronous pipelines) -- the fixed point's status word
+    stays on the device as `gmm.last_info`; `gmm.check_info()` reads and raises it when the caller chooses to."""
     dev = torch.device("cuda", torch.cuda.current_device())
     for x in (global_natparam[1], nn_potentials[0]):
         if isinstance(x, torch.Tensor) and x.is_cuda:
@@ -277,7 +293,7 @@ def run_inference(prior_natparam, global_natparam, nn_potentials, num_samples, l
     Tn = nn_potentials[1].shape[0]
     if label_init is None:
         label_init = initialize_meanfield(Tn, label_global.shape[0], dev, generator)
-    o = meanfield_from_globals(label_global, gaussian_globals, nn_potentials, label_init, group=group)
+    o = meanfield_from_globals(label_global, gaussian_globals, nn_potentials, label_init, group=group, check=check)
     stats, local_natparam, local_kl = (o["dirichlet_stats"], o["niw_stats"]), (o["label_natparam"], o["gaussian_natparam"]), o["kl"][0]
     gn = local_natparam[1]
     T, N = gn.shape[0], gn.shape[-1] - 2
@@ -336,11 +352,12 @@ class _LocalTail(torch.autograd.Function):
 
 def run_inference_differentiable(prior_natparam, global_natparam, nn_potentials, num_samples,
                                  label_init=None, eps=None, generator=None, group=None,
-                                 reference_compat=False):
+                                 reference_compat=False, check=True):
     """run_inference (gmm.py:12-16) with gradients w.r.t. nn_potentials flowing into `samples` and
     `local_kl`, exactly the two quantities the reference differentiates (svae.py:21-24); statistics
     are returned detached (`unbox(stats)`, gmm.py:16).  Kernel launches only: fixed point + final pass, sampler,
-    and -- in backward() -- the derived adjoint of the final pass and the sampler."""
+    and -- in backward() -- the derived adjoint of the final pass and the sampler.  check=False: as in run_inference
+    (the whole step then captures into ONE hipGraph: bench.py extra[8])."""
     dev = nn_potentials[1].device
     g = [_dev64(x, dev) for x in global_natparam]
     label_global, gaussian_globals, global_kl = global_step(g, None if reference_compat else prior_natparam)
@@ -350,7 +367,8 @@ def run_inference_differentiable(prior_natparam, global_natparam, nn_potentials,
     T, N = nh.shape
     if label_init is None:
         label_init = initialize_meanfield(T, g[0].shape[0], dev, generator)
-    o = meanfield_from_globals(label_global, gaussian_globals, (nJ.detach(), nh.detach()), label_init, group=group)
+    o = meanfield_from_globals(label_global, gaussian_globals, (nJ.detach(), nh.detach()), label_init, group=group,
+                               check=check)
     if eps is None:
         eps = torch.randn(T, num_samples, N, dtype=torch.float64, device=dev, generator=generator)
     samples, local_kl = _LocalTail.apply(nJ, nh, _dev64(eps, dev), label_global.contiguous(),

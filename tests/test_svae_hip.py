@@ -46,6 +46,47 @@ def test_gmm_final_pass_reference_gradcheck():
     assert torch.autograd.gradcheck(f, (nJ, nh), eps=1e-6, atol=1e-6)
 
 
+def test_gmm_step_without_host_sync_captures_into_one_graph():
+    """check=False leaves the fixed point's status word on the device (gmm.last_info / gmm.check_info()): the whole
+    differentiable step -- global maps, fixed point + final pass, sampler, adjoint -- then records into ONE hipGraph whose
+    replay reproduces the eager results bit for bit; a non-PD point still surfaces through check_info()."""
+    from svae_amd.models import gmm
+    K, N, T, S = 5, 2, 400, 1
+    rng = np.random.default_rng(3)
+    gen = torch.Generator().manual_seed(1)
+    prior = tuple(x.to(DEV) for x in gmm.init_pgm_param(K, N, alpha=0.5, niw_conc=1.0, generator=gen))
+    glob = tuple(x.to(DEV) for x in gmm.init_pgm_param(K, N, alpha=1.0, niw_conc=2.0, random_scale=2.0, generator=gen))
+    nJ = t64(-0.5 * np.log1p(np.exp(rng.standard_normal((T, N))))).requires_grad_(True)
+    nh = t64(2 * rng.standard_normal((T, N))).requires_grad_(True)
+    init = t64(rng.random((T, K))); init = init / init.sum(-1, keepdim=True)
+    eps, gs = t64(rng.standard_normal((T, S, N))), t64(rng.standard_normal((T, S, N)))
+
+    def step(check):
+        samples, stats, gkl, lkl = gmm.run_inference_differentiable(prior, glob, (nJ, nh), S, label_init=init, eps=eps,
+                                                                     check=check)
+        return torch.autograd.grad(lkl + (samples * gs).sum(), [nJ, nh]) + (samples.detach(), lkl.detach())
+    ref = [x.clone() for x in step(True)]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step(False)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = step(False)
+    for _ in range(2):
+        graph.replay()
+    torch.cuda.synchronize()
+    gmm.check_info()
+    for a, b in zip(out, ref):
+        assert torch.equal(a, b)
+    # a point whose Gaussian factor is not positive definite: silent with check=False, raised by check_info()
+    bad = nJ.detach().clone(); bad[7] = 50.0
+    gmm.run_inference(prior, glob, (bad, nh.detach()), S, label_init=init, eps=eps, check=False)
+    with pytest.raises(FloatingPointError):
+        gmm.check_info()
+
+
 @pytest.mark.parametrize("K,N,T,S", [(5, 2, 300, 1), (3, 1, 7, 2), (15, 2, 50, 3), (4, 3, 33, 2), (6, 5, 20, 1), (2, 8, 9, 2),
                                      (20, 2, 40, 0)])
 def test_gmm_local_step_kernels_against_torch_autograd(K, N, T, S):
