@@ -94,6 +94,10 @@ __global__ __launch_bounds__(256) void lds_reduce_stats_kernel(int B, int n, con
 
 }  // namespace svae
 
+#ifndef SVAE_FILTER_WIDE_MAX_B
+#define SVAE_FILTER_WIDE_MAX_B 6144     // filter-only launches without message outputs: the one-register filter (two sequences per wavefront beyond 512) up to this batch; measured 4096: 0.89 vs 0.96 ms packed, 8192: equal
+#endif
+
 extern "C" {
 
 // Kernel selection (include/svae_hip.h, SVAE_OPT_*): keep == 0, n <= 10, T >= 4 -> the two-ended kernel
@@ -302,7 +306,7 @@ int svae_lds_filter_f64(int B, int T, int n, int inhomog, int pair_batched, unsi
   // small batches without message outputs: one sequence per wavefront (0.62 -> 0.24 ms at B = 512, T = 200, n = 10).
   // The one-register filter (n <= 10) stays ahead of the packed kernel until ~3 wavefronts per SIMD (filter + sampler,
   // T = 500: 1024 sequences 0.86 vs 1.81 ms, 2048: 1.85 vs 2.53; T = 200, 4096: 1.43 vs 1.27)
-  const bool wide = sel.layout == 1 || (sel.layout == 0 && B <= (n <= svae::TE_MAX_N && twoend ? 3072 : 1023));
+  const bool wide = sel.layout == 1 || (sel.layout == 0 && B <= (n <= svae::TE_MAX_N && twoend ? SVAE_FILTER_WIDE_MAX_B : 1023));
   const bool fsplit = wide && !J_pred && !h_pred && !J_filt && !h_filt;
   switch (n) {
 #define SVAE_CASE_(NN) case NN: return !fsplit ? svae_lds_launch_filter_n##NN(&a, inhomog, stream)          \

@@ -20,6 +20,11 @@
 
 namespace svae {
 
+#ifndef SVAE_FILTER_DUAL_MIN_B
+#define SVAE_FILTER_DUAL_MIN_B 512
+#endif
+constexpr int FILTER_1R_DUAL_MIN_B = SVAE_FILTER_DUAL_MIN_B;   // one-directional filter: two sequences per wavefront above this batch
+
 // gauss_jordan_1r (lds_estep_twoend.hpp) with a hook that receives every scaled pivot row (lanes j > k: L[j][k])
 template <int N, class StoreR>
 __device__ __forceinline__ void gauss_jordan_1r_hook(double (&M)[N], const double (&E)[N], double& qacc, double& vfull,
@@ -73,21 +78,28 @@ __device__ __forceinline__ void gauss_jordan_1r_hook(double (&M)[N], const doubl
   });
 }
 
-template <int N, bool INHOMOG>
+// DUAL (batches beyond one wavefront per SIMD): the two DPP-row pairs of the wavefront, which otherwise carry the SAME
+// sequence, run sequences 2 blk and 2 blk + 1 -- the instruction stream is unchanged, so a full launch issues half the
+// instructions; the second pair's records are addressed as the first pair's plus a 32-bit per-lane offset (an odd
+// batch's last wavefront repeats sequence B - 1 in its second pair: same values to the same addresses).
+template <int N, bool INHOMOG, bool DUAL = false>
 __device__ __forceinline__ void lds_filter_1r_body(const LdsArgs& a, const int blk) {
   static_assert(N >= 1 && N <= TE_MAX_N && N + ((N - 1) >> 1) <= 14, "right-hand-side columns in lanes N..14 of two DPP rows");
   constexpr int HS = ws_h_stride(N), PS = ws_p_stride(N), WS = ws_step_doubles(N);
   constexpr int J = (N + 1) / 2;          // slots holding rows 0..N-1 (row i = 2j + gl)
   constexpr int HL = 15;                  // lane of the h column
   // one wavefront per SIMD: this kernel runs next to the two-ended E-step kernel (see lds_estep_split.hpp, FILT)
-  asm volatile("v_accvgpr_write_b32 a63, 0" ::: "a63");
+  if constexpr (!DUAL) asm volatile("v_accvgpr_write_b32 a63, 0" ::: "a63");
   __shared__ double split_tile[2 * (N + 1) * 16];      // [DPP row pair][row 0..N][16 lanes]: re-replication of the next pivot block
 
   const int lane = threadIdx.x;
   const int c = lane & 15;
   const int g = lane >> 4;
-  const int gl = g & 1;                   // DPP row within its pair; the pairs (0,1) and (2,3) carry the SAME work
-  const int b = blk;                      // one sequence per wavefront
+  const int gl = g & 1;                   // DPP row within its pair; the pairs (0,1) and (2,3) carry the SAME work (DUAL: two sequences)
+  const int b0 = DUAL ? 2 * blk : blk;    // (uniform) the wavefront's first sequence
+  const int sq = DUAL ? ((b0 + (g >> 1) < a.B) ? (g >> 1) : 0) : 0;
+  const int b = b0 + sq;                  // this DPP-row pair's sequence
+  const bool lead = DUAL ? gl == 0 : g == 0;      // the DPP row of a sequence that reports its P^-1 rows, factor and scalars
   const bool col = c < N;
   const int cc = col ? c : 0;
   const int T = a.T;
@@ -138,20 +150,21 @@ __device__ __forceinline__ void lds_filter_1r_body(const LdsArgs& a, const int b
   const double* nJ = a.node_J + ((long)b * T) * N + cc;
   const double* nh = a.node_h + ((long)b * T) * N + cc;
   double* zpage = a.ws + (long)b * ws_seq_doubles(N, T);   // [e_N | 0] rows the backward kernels' idle lanes read
-  double* wsb = zpage + ws_zpage_doubles(N);
-  if (g == 0 && c < HS) zpage[c] = (c == N) ? 1.0 : 0.0;
-  if (g == 0 && c < PS) zpage[HS + c] = 0.0;
+  double* wsb = a.ws + (long)b0 * ws_seq_doubles(N, T) + ws_zpage_doubles(N);     // (uniform: the first sequence's records)
+  if (lead && c < HS) zpage[c] = (c == N) ? 1.0 : 0.0;
+  if (lead && c < PS) zpage[HS + c] = 0.0;
   double* ws2b = a.ws2 + ((long)b * T) * (N * N + N);
+  const unsigned sqoff = 8u * (unsigned)(sq * ws_seq_doubles(N, T));             // bytes from the first sequence's records
   // hand-off store of register i: ONE unconditional instruction per register.  DPP row 0: lane c < N -> P^-1[i][c],
   // lane 15 -> c_i; the right-hand-side lanes of DPP rows 0 and 1 -> X[i][x]; every other lane -> the record's pad
   // entry (the H rows have one when N is even, the P^-1 rows when N is odd).
   constexpr int TRASH = (N % 2 == 0) ? N + 1 : N * HS + N;
   unsigned off[N];                                    // bytes from the step's record (uniform base + 32-bit lane offset)
   static_for<0, N>([&](auto i) {
-    off[i] = 8u * (unsigned)((g == 0 && col) ? N * HS + i * PS + c
-                             : ((g < 2 && xok) ? i * HS + xx : ((g == 0 && c == HL) ? i * HS + N : TRASH)));
+    off[i] = sqoff + 8u * (unsigned)((lead && col) ? N * HS + i * PS + c
+                                      : (((DUAL || g < 2) && xok) ? i * HS + xx : ((lead && c == HL) ? i * HS + N : TRASH)));
   });
-  const int foff = (g == 0 && col) ? c : -1;          // factor rows / pivots: DPP row 0, lanes < N
+  const int foff = (lead && col) ? c : -1;            // factor rows / pivots: the sequence's leading DPP row, lanes < N
 
   double qacc = 0.0, ldM = 1.0, vworst = -1.0;
   int ldE = 0;
@@ -180,7 +193,7 @@ __device__ __forceinline__ void lds_filter_1r_body(const LdsArgs& a, const int b
     static_for<0, N>([&](auto k) { Bt[k] = __builtin_fma(-EH, M[k], NJ12c[k]); asm volatile("" : "+v"(Bt[k])); });
     dpp_fence(M);
 
-    double* w = wsb + (long)t * WS;
+    double* w = wsb + (long)t * WS;                   // (uniform)
     double* w2 = ws2b + (long)t * (N * N + N);
     double* fbase = foff >= 0 ? w2 + foff : w + TRASH;
     const long fstride = foff >= 0 ? N : 0;
@@ -269,10 +282,12 @@ __device__ __forceinline__ void lds_filter_1r_body(const LdsArgs& a, const int b
     }
     double total = row_sum16(z) + 0.5 * row_sum16(part) + a.init_logZ[0];
     if (!INHOMOG && T > 1) total += (double)(T - 1) * a.logZ_pair[0];
-    if (lane == 0) a.lognorm[b] = total;
+    const bool reporter = DUAL ? (lane & 31) == 0 : lane == 0;             // one lane per sequence
+    if (reporter) a.lognorm[b] = total;
     const bool lane_bad = col && !(vworst < 0.0);
-    const bool bad = __ballot(lane_bad) != 0 || !(total == total);
-    if (bad && lane == 0) {
+    const unsigned long long bal = __ballot(lane_bad);
+    const bool bad = (DUAL ? ((bal >> (lane & 32)) & 0xffffffffull) != 0 : bal != 0) || !(total == total);
+    if (bad && reporter) {
       int old = *(volatile int32_t*)a.info;
       while (old == 0 || old > b + 1) {
         const int seen = atomicCAS(a.info, old, b + 1);
@@ -283,9 +298,9 @@ __device__ __forceinline__ void lds_filter_1r_body(const LdsArgs& a, const int b
   }
 }
 
-template <int N, bool INHOMOG>
+template <int N, bool INHOMOG, bool DUAL = false>
 __global__ __launch_bounds__(64) void lds_filter_1r_kernel(const LdsArgs a) {
-  lds_filter_1r_body<N, INHOMOG>(a, (int)blockIdx.x);
+  lds_filter_1r_body<N, INHOMOG, DUAL>(a, (int)blockIdx.x);
 }
 
 // The forward pass of a training step at small batches in ONE launch: workgroups 0 .. B-1 run the one-directional
@@ -319,8 +334,13 @@ static int launch_forward_pair(const LdsArgs& f, const LdsArgs& e, bool inhomog,
 template <int N>
 static int launch_filter_1r(const LdsArgs& a, bool inhomog, hipStream_t stream) {
   if constexpr (N <= TE_MAX_N) {
-    dim3 grid(a.B), block(64);
-    if (inhomog) hipLaunchKernelGGL((lds_filter_1r_kernel<N, true>), grid, block, 0, stream, a);
+    dim3 grid(a.B), grid2((a.B + 1) / 2), block(64);
+    // beyond one wavefront per SIMD a second wavefront of the same sequence count only adds instructions: two sequences
+    // per wavefront (the latency of a step is the same instruction stream either way)
+    const bool dual = a.B > FILTER_1R_DUAL_MIN_B;
+    if (inhomog && dual) hipLaunchKernelGGL((lds_filter_1r_kernel<N, true, true>), grid2, block, 0, stream, a);
+    else if (dual) hipLaunchKernelGGL((lds_filter_1r_kernel<N, false, true>), grid2, block, 0, stream, a);
+    else if (inhomog) hipLaunchKernelGGL((lds_filter_1r_kernel<N, true>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((lds_filter_1r_kernel<N, false>), grid, block, 0, stream, a);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
   } else {

@@ -318,6 +318,31 @@ def test_lds_sample_without_smoother_against_reference_build():
     assert tuple(got.shape) == (T, S, n) and _rel(got, want) < 1e-7
 
 
+@pytest.mark.parametrize("B,inhomog", [(513, False), (777, True), (1026, False)])
+def test_filter_two_sequences_per_wavefront_matches_one(B, inhomog):
+    """Beyond 512 sequences the one-register filter runs TWO sequences per wavefront (lds_filter_1r.hpp, DUAL; an odd
+    batch's last wavefront repeats its last sequence): log-normaliser and the samples drawn from its hand-off are bit for
+    bit those of the same sequences launched in batches of at most 512 (one sequence per wavefront)."""
+    from svae_amd.lds.lds_inference import cython_natural_lds_sample
+    from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials
+    rng = np.random.default_rng(B)
+    T, n, S = 9, 10, 2
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev).contiguous()
+    init, pair = rand_lds_natparam(n, rng)
+    if inhomog:
+        pair = tuple(np.broadcast_to(np.asarray(x, float), (T - 1,) + np.shape(x)).copy() for x in pair)
+        pair[1][...] *= (1.0 + 0.05 * rng.standard_normal((T - 1, 1, 1)))
+    node = rand_node_potentials((B, T, n), rng)
+    eps = t(rng.standard_normal((B, T, S, n)))
+    natparam = (tuple(t(x) for x in init), tuple(t(x) for x in pair))
+    whole = cython_natural_lds_sample(natparam, tuple(t(x) for x in node), num_samples=S, eps=eps)
+    for lo in range(0, B, 400):
+        hi = min(B, lo + 400)
+        part = cython_natural_lds_sample(natparam, tuple(t(x[lo:hi]) for x in node), num_samples=S, eps=eps[lo:hi].contiguous())
+        assert torch.equal(whole[lo:hi], part)
+
+
 def test_sampler_moments_match_smoother():
     """Size-independent property: over many samples, the sample mean / second moment of x_t
     converge to the smoother's E[x_t], E[x_t x_t'] (loose statistical tolerance)."""

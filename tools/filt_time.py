@@ -2,7 +2,7 @@ import os, sys, numpy as np, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from svae_amd.lds.lds_inference import LDSEStepPlan
 from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials
-B, T, n = 512, 200, 10
+B, T, n = (int(x) for x in (sys.argv[1:4] if len(sys.argv) > 3 else (512, 200, 10)))
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(0)
 (J0, h0, z0), (J11, J12, J22, zp) = rand_lds_natparam(n, rng)
