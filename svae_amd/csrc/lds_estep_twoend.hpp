@@ -426,8 +426,13 @@ __device__ __forceinline__ void lds_estep_twoend_body(const LdsArgs& a, const in
   // entry with the back edge's, so the wait at the loop head also covers the previous step's hand-off
   // stores; loading by inline asm with a hand-placed s_waitcnt vmcnt(N) was tried and is NOT safe: the
   // compiler may copy the destination register before the wait.)
-  double Jo_n = nJb[node_off(0)];
-  double ho_n = nhb[node_off(0)];
+  // (walking per-lane pointers: recomputing node_off(s + 1) per step was two 64-bit multiply-adds and three selects)
+  const double* pJn = nJb + node_off(0);
+  const double* phn = nhb + node_off(0);
+  const long nstep = dir ? -(long)N : (long)N;
+  double Jo_n = *pJn;
+  double ho_n = *phn;
+  const double jm2 = col ? -2.0 : 0.0, jadd = col ? 0.0 : 1.0;      // JoX = col ? -2 Jo : 1 as ONE multiply-add
   double Mp[N];             // partner chain's An at the hand-over point
   static_for<0, N>([&](auto i) { Mp[i] = 0.0; });
   // ... and this chain's log-normaliser accumulators at that point: with even T the partner's last
@@ -470,10 +475,11 @@ __device__ __forceinline__ void lds_estep_twoend_body(const LdsArgs& a, const in
   double wr0 = MIX ? wrow[(long)wnode(0) * K] : 0.0, wr1 = MIX ? wrow[(long)wnode(1) * K] : 0.0;
   auto elim_step = [&](int s, auto to_lds) {
     if (s == jx) take_partner();
-    const double JoX = col ? -2.0 * Jo_n : 1.0;
+    const double JoX = __builtin_fma(Jo_n, jm2, jadd);
     double ho = ho_n;
-    Jo_n = nJb[node_off(s + 1)];           // s + 1 <= e: the meeting node's potentials included
-    ho_n = nhb[node_off(s + 1)];
+    pJn += nstep; phn += nstep;            // node s + 1 <= e: the meeting node's potentials included
+    Jo_n = *pJn;
+    ho_n = *phn;
     if (INHOMOG && !MIX) load_pair(s, true);
     double wq[2] = {wr0 * wmask, wr1 * wmask};     // MIX: lane k = weight of state k (pair s, pair s + 1)
     if constexpr (MIX) {
@@ -547,9 +553,10 @@ __device__ __forceinline__ void lds_estep_twoend_body(const LdsArgs& a, const in
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     // scale the inverse's columns, hand the record to the smoother phase
-    vworst = fmax(vworst, vfull);
+    vworst = asm_max(vworst, vfull);
     ldM *= vfull;
     if ((s & 3) == 3) {
+      asm volatile("; renormalise the determinant product");      // (keeps this a branch: as selects it is 6 instructions per step)
       ldE += __builtin_amdgcn_frexp_exp(ldM);
       ldM = __builtin_amdgcn_frexp_mant(ldM);
     }
