@@ -623,6 +623,9 @@ __global__ __launch_bounds__(GMM_MW_BLOCK) void gmm_mw_sweep_kernel(const GmmMwA
 // the grid (<= 32 workgroups in the window this path serves, capped by the occupancy query) is co-resident on any
 // idle-enough device; every spin is bounded and reports through `info` (-77) instead of hanging.
 // With at most one point per thread and K <= 16 the responsibilities stay in registers for the whole fixed point.
+#ifndef SVAE_GMM_RUN_AHEAD
+#define SVAE_GMM_RUN_AHEAD 1     // persistent kernel: compute the next sweep before collecting the previous exchange (0: A/B)
+#endif
 struct GmmSlot { unsigned long long lo, hi; };          // {tag << 32 | low half}, {tag << 32 | high half}
 constexpr int GMM_SPIN_LIMIT = 1 << 22;
 
@@ -637,6 +640,24 @@ __device__ __forceinline__ void gmm_publish(GmmSlot* slot, unsigned tag, double 
 // total of the G workgroups' partials of exchange `tag`: thread 0 publishes this workgroup's, then EVERY wavefront polls
 // all G slots (lane l: slots l, l + 64, ..) and sums them with gmm_fixed_order_sum's arithmetic -- no workgroup barrier
 // behind the exchange; every thread returns the total.  G == 1: nothing to exchange.
+// (the collecting half alone: every wavefront polls all G slots of exchange `tag`, this workgroup's own included)
+__device__ __forceinline__ double gmm_collect(GmmSlot* slots, int G, unsigned tag, int32_t* info) {
+  double v = 0.0;
+  for (int j = threadIdx.x & 63; j < G; j += 64) {
+    unsigned long long lo = 0, hi = 0;
+    int spins = 0;
+    for (;;) {
+      lo = __hip_atomic_load(&slots[j].lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      hi = __hip_atomic_load(&slots[j].hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((unsigned)(lo >> 32) == tag && (unsigned)(hi >> 32) == tag) break;
+      if (++spins > GMM_SPIN_LIMIT) { atomicMin(info, -77); break; }     // never hang the device
+      __builtin_amdgcn_s_sleep(1);
+    }
+    v += __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
+  }
+  return wave_sum64(v);
+}
+
 __device__ __forceinline__ double gmm_exchange(GmmSlot* slots, int G, unsigned tag, double mine, int32_t* info) {
   if (G == 1) return wave_sum64((threadIdx.x & 63) == 0 ? mine : 0.0);
   if (threadIdx.x == 0) gmm_publish(slots + blockIdx.x, tag, mine);
@@ -689,7 +710,45 @@ __global__ __launch_bounds__(GMM_MW_BLOCK) void gmm_mw_persistent_kernel(const G
       if (stop) break;
     }
   };
-  if (KR > 0 && sw.resident) run(std::true_type{}); else run(std::false_type{});
+  // Responsibilities in registers, several workgroups: the exchange of sweep i - 1 (~0.9 us: a store has to reach the
+  // other XCDs) is collected AFTER sweep i has been computed -- speculatively: a sweep reads and writes only this thread's
+  // registers, its result does not depend on the total, and when the total of sweep i - 1 says "converged" the
+  // registers are put back.  Same sweeps, same totals, same stopping sweep; one discarded sweep of arithmetic at the end
+  // against an exchange latency per sweep (round 4: 3.1 -> ~2.2 us per sweep at 1000 points, four workgroups).
+  auto run_ahead = [&]() {
+    if (a.max_iter <= 0) return;
+    double wgsum = block_sum<GMM_MW_BLOCK>(sw.template sweep<true>(true), red, 0);
+    if (tid == 0) gmm_publish(slots + blockIdx.x, 1u, wgsum);
+    iters = 1;
+    for (int i = 1;; ++i) {
+      const bool more = i < a.max_iter;
+      double keep[KR > 0 ? KR : 1], klnext = 0.0;
+      if (more) {
+#pragma unroll
+        for (int k = 0; k < (KR > 0 ? KR : 1); ++k) keep[k] = sw.r[k];
+        klnext = sw.template sweep<true>(false);
+      }
+      GMM_TICK(0)
+      const double total = gmm_collect(slots + ((i - 1) & 1) * G, G, (unsigned)i, a.info);
+      GMM_TICK(2)
+      if (blockIdx.x == 0 && tid == 0) m.kl_hist[i - 1] = total;
+      const bool stop = fabs(total - prev) < a.tol;
+      prev = total;
+      if (stop || !more) {
+        if (more) {
+#pragma unroll
+          for (int k = 0; k < (KR > 0 ? KR : 1); ++k) sw.r[k] = keep[k];
+        }
+        break;
+      }
+      iters = i + 1;
+      wgsum = block_sum<GMM_MW_BLOCK>(klnext, red, i);
+      GMM_TICK(1)
+      if (tid == 0) gmm_publish(slots + (i & 1) * G + blockIdx.x, (unsigned)(i + 1), wgsum);
+    }
+  };
+  if (KR > 0 && sw.resident) { if (G > 1 && SVAE_GMM_RUN_AHEAD) run_ahead(); else run(std::true_type{}); }
+  else run(std::false_type{});
 #ifdef SVAE_GMM_TIMING
   if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == G - 1))
     printf("gmm persistent wg %d/%d: %d sweeps, cycles per sweep: point %lld  block_sum %lld  exchange %lld | loop wall %.2f us per sweep\n",
