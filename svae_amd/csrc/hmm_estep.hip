@@ -30,6 +30,10 @@
 #include "../../include/svae_hip.h"
 #include "dpp.hpp"
 
+#ifndef SVAE_HMM_TWOEND
+#define SVAE_HMM_TWOEND 1      // two-ended kernel + one-directional fallback for flagged sequences (0: the one-directional kernel alone; A/B)
+#endif
+
 namespace svae {
 
 struct HmmArgs {
@@ -55,8 +59,13 @@ struct HmmArgs {
   const double* __restrict__ cinit;       // (K)
   const double* __restrict__ lz;          // (K)
   double* __restrict__ node_out;          // (rows,T,K) or nullptr: the node potentials used
+  int redo_only;                          // hmm_estep_kernel behind hmm_estep2_kernel: only wavefronts with a flagged sequence run
 };
-constexpr int HMM_WS = 34;                // [alpha (16) | e/c or its log-space stand-in (16) | flag | pad]
+// workspace record per (sequence, step).  One-directional kernel (hmm_estep_kernel): [alpha (16) | e/c or its log-space
+// stand-in (16) | flag | ..].  Two-ended kernel (hmm_estep2_kernel): [alpha^ | e | w = e o beta^] in slots of 8 (K <= 8) or
+// 16 lanes, then the maximum of the node potentials; entry HMM_REDO of the sequence's FIRST record is its REDO flag.
+constexpr int HMM_WS = 50;
+constexpr int HMM_REDO = 49;
 constexpr double HMM_TINY = 1e-200;
 
 // Maximum over the 16 lanes of a DPP row, in every lane: four rotate-and-max steps (row_ror:8/4/2/1 on the two halves
@@ -87,6 +96,11 @@ __global__ __launch_bounds__(64) void hmm_estep_kernel(const HmmArgs a) {
   const int cc = col ? c : 0;
   const int T = a.T;
   const double NEG_BIG = -1.0e300;
+  if (a.redo_only) {
+    // fallback pass behind the two-ended kernel: only for sequences it flagged (a step whose normaliser underflowed)
+    const double redo = a.ws[((long)b * T) * HMM_WS + HMM_REDO];
+    if (!__any(redo != 0.0)) return;
+  }
 
   // transition matrix in both layouts, shifted by its maximum (the shift goes into logZ)
   const double* pp = a.pair_params + (long)b * a.pair_stride;
@@ -286,8 +300,276 @@ __global__ __launch_bounds__(64) void hmm_estep_kernel(const HmmArgs a) {
   }
 }
 
+// ---- two-ended scaled forward-backward (round 4) ----------------------------------------------------------------------
+// The one-directional kernel above runs 2 T dependent steps of ~190 / ~150 instructions on ONE wavefront per four
+// sequences: 0.35 - 0.6 ms at T = 500 whatever the batch (latency-bound: the SLDS ascent launches it a dozen times per
+// step).  Most of a step does not depend on the recursion, and alpha and beta do not depend on each other:
+//   phase 1 (parallel in t, both wavefronts of the workgroup, half of the steps each): node potentials (FUSED: built from
+//            the LDS kernel's contractions), their row maximum m_t, e_t = exp(node_t - m_t)            -> workspace
+//   phase 2 (serial, concurrent): wavefront 0  alpha^_t = normalise((alpha^_{t-1} P) o e_t), log Z     (~55 instructions)
+//                                  wavefront 1  beta^_t = normalise(P w_{t+1}),  w_t = e_t o beta^_t   (~50 instructions)
+//            -- each with its OWN scaling: gamma and xi are normalised per step in phase 3, so the scalings cancel
+//   phase 3 (parallel in t, half each): q = P w_{t+1},  Z_t = <alpha^_t, q>,  gamma_t = alpha^_t o q / Z_t,
+//            xi sums  acc[j][k] += alpha^_t[j] w_{t+1}[k] / Z_t  (E_trans = P o acc), summed over the two wavefronts in LDS.
+// Every phase streams its operands through a register ring HMM2_D steps deep (a serial step is ~0.15 us of arithmetic
+// against 1 - 2 us of memory latency); no branch inside the steady-state loops (hipcc's wait counts degrade to
+// vmcnt(0) across one).  The records are compact -- [alpha^ | e | w] in slots of 8 lanes for K <= 8 -- inside the common
+// record stride: half the traffic of full-width slots at 2048 sequences.
+// A normaliser below HMM_TINY anywhere (the one-directional kernel's log-space case) raises the sequence's REDO flag:
+// the one-directional kernel is launched behind this one with redo_only = 1 and recomputes the flagged wavefronts,
+// log-space steps and all (its wavefronts exit at once otherwise).  Same mapping: one DPP row per sequence, lane = state.
+constexpr int HMM2_D = 8;
+template <int K, bool FUSED>
+__global__ __launch_bounds__(128) void hmm_estep2_kernel(const HmmArgs a) {
+  constexpr int D = HMM2_D;
+  constexpr int KS = K <= 8 ? 8 : 16;                    // slot width
+  constexpr int OA = 0, OE = KS, OW = 2 * KS, OM = 3 * KS;
+  static_assert(OM < HMM_REDO, "record layout");
+  __shared__ double xacc[16 * 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c = lane & 15;
+  const int brow = blockIdx.x * 4 + (lane >> 4);
+  const bool valid = brow < a.B;
+  const int bslot = valid ? brow : a.B - 1;
+  const int b = a.seq_index ? a.seq_index[bslot] : bslot;
+  const bool col = c < K;
+  const int cc = col ? c : 0;
+  const int T = a.T;
+  const double NEG_BIG = -1.0e300;
+  const bool st = valid && col;
+
+  const double* pp = a.pair_params + (long)b * a.pair_stride;
+  double lp[K], lpT[K];
+  static_for<0, K>([&](auto j) {
+    const double v = pp[j * K + cc], vt = pp[cc * K + j];
+    lp[j] = col ? v : NEG_BIG;
+    lpT[j] = col ? vt : NEG_BIG;
+  });
+  double pmax = NEG_BIG;
+  static_for<0, K>([&](auto j) { pmax = fmax(pmax, lp[j]); });
+  static_for<0, 4>([&](auto s) { pmax = fmax(pmax, __shfl_xor(pmax, 1 << s, 16)); });
+  double P[K], PT[K];        // P[j][lane c] = P[j][c];  PT[k][lane c] = P[c][k]   (shifted by the matrix' maximum; 0 in idle lanes)
+  static_for<0, K>([&](auto j) { P[j] = col ? exp(lp[j] - pmax) : 0.0; PT[j] = col ? exp(lpT[j] - pmax) : 0.0; });
+
+  // this lane's column of the records (idle lanes alias lane 0: they only ever load, and what they load is multiplied
+  // by the zero columns of P / PT), and the records' scalars
+  double* wsb = a.ws + ((long)b * T) * HMM_WS + cc;
+  double* wsr = a.ws + ((long)b * T) * HMM_WS;
+  double one = 1.0;
+  bool bad = false;
+  auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+
+  // ---- phase 1: e_t, m_t (and node_out) for this wavefront's half of the steps ---------------------------------------------
+  {
+    const double* node = FUSED ? nullptr : a.node_params + ((long)b * T) * K + cc;
+    const double* pc = FUSED ? a.pair_contr + ((long)b * T) * 2 * K + cc : nullptr;
+    const double lzc = FUSED ? a.lz[cc] : 0.0;
+    double* nout = a.node_out ? a.node_out + ((long)b * T) * K + cc : nullptr;
+    auto emit = [&](int t, double ndraw, double extra) {
+      if (nout && st) nout[(long)t * K] = ndraw;
+      const double nd = col ? ndraw + extra : NEG_BIG;
+      const double m = row_max16(nd);
+      const double e = col ? exp_nonpos(nd - m) : 0.0;
+      if (st) wsb[(long)t * HMM_WS + OE] = e;
+      if (valid && c == 0) wsr[(long)t * HMM_WS + OM] = m;
+    };
+    const int th = (T + 1) / 2;
+    int p0 = wv ? th : 0;
+    const int p1 = wv ? T : th;
+    if (wv == 0) {
+      if (valid && c == 0) wsr[HMM_REDO] = 0.0;
+      double nd0;
+      if constexpr (FUSED) {
+        // <E x0 x0', J_c> + <E x0, h_c> + cinit_c: lane c = state (once per sequence)
+        const int n = a.n;
+        const double* ei = a.lds_E_init + (long)b * (n * n + n);
+        const double* Jc = a.init_J + (long)cc * n * n;
+        const double* hc = a.init_h + (long)cc * n;
+        double s0 = 0.0;
+        for (int q = 0; q < n * n; ++q) s0 = __builtin_fma(ei[q], Jc[q], s0);
+        double s1 = 0.0;
+        for (int q = 0; q < n; ++q) s1 = __builtin_fma(ei[n * n + q], hc[q], s1);
+        nd0 = (s0 + s1) + a.cinit[cc];
+      } else {
+        nd0 = node[0];
+      }
+      emit(0, nd0, a.init_params[cc]);
+      p0 = 1;
+    }
+    // steps p0 .. p1-1 (all >= 1), potentials requested D steps ahead
+    auto node_at = [&](int t, double& x0, double& x1) {
+      if constexpr (FUSED) { x0 = pc[(long)(t - 1) * 2 * K]; x1 = pc[(long)t * 2 * K + K]; }
+      else { x0 = node[(long)t * K]; x1 = 0.0; }
+    };
+    if (p0 < p1) {
+      double r0[D], r1[D];
+      static_for<0, D>([&](auto u) { node_at(clampi(p0 + u, 1, p1 - 1), r0[u], r1[u]); });
+      int t = p0;
+      for (; t + D <= p1; t += D) {
+        static_for<0, D>([&](auto u) {
+          const double x0 = r0[u], x1 = r1[u];
+          node_at(clampi(t + u + D, 1, p1 - 1), r0[u], r1[u]);
+          emit(t + u, FUSED ? (x0 + x1) + lzc : x0, 0.0);
+        });
+      }
+      static_for<0, D>([&](auto u) { if (t + u < p1) emit(t + u, FUSED ? (r0[u] + r1[u]) + lzc : r0[u], 0.0); });
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: the two recursions, concurrently ------------------------------------------------------------------------------
+  if (wv == 0) {
+    double lzM = 1.0, lzS = 0.0, alpha = 0.0;
+    long lzE = 0;
+    const double colone = col ? 1.0 : 0.0;
+    auto fstep = [&](int t, double e, double m, auto renorm) {
+      double p0 = 0.0, p1 = 0.0;                        // two accumulators: half the dependent chain
+      dpp_fence(alpha);
+      static_for<0, K>([&](auto j) { if constexpr (j % 2 == 0) mac_bc<j>(p0, alpha, P[j]); else mac_bc<j>(p1, alpha, P[j]); });
+      const double first = t == 0 ? 1.0 : 0.0;          // (alpha starts at 0: pred_0 = 1 in the live lanes)
+      const double pred = __builtin_fma(first, colone, p0 + p1);
+      double al = pred * e;
+      double c0 = 0.0, c1 = 0.0;
+      dpp_fence(al);
+      static_for<0, K>([&](auto k) { if constexpr (k % 2 == 0) mac_bc<k>(c0, al, one); else mac_bc<k>(c1, al, one); });
+      const double cs = c0 + c1;
+      bad = bad || !(cs > HMM_TINY);
+      alpha = al * rcp_nr(cs);
+      if (st) wsb[(long)t * HMM_WS + OA] = alpha;
+      lzM *= __builtin_amdgcn_frexp_mant(cs);
+      lzE += __builtin_amdgcn_frexp_exp(cs);
+      lzS += m + (t > 0 ? pmax : 0.0);
+      if constexpr (decltype(renorm)::value) { lzE += __builtin_amdgcn_frexp_exp(lzM); lzM = __builtin_amdgcn_frexp_mant(lzM); }
+    };
+    double er[D], mr[D];
+    static_for<0, D>([&](auto u) {
+      const int tt = clampi(u, 0, T - 1);
+      er[u] = wsb[(long)tt * HMM_WS + OE];
+      mr[u] = wsr[(long)tt * HMM_WS + OM];
+    });
+    int t = 0;
+    for (; t + D <= T; t += D) {
+      static_for<0, D>([&](auto u) {
+        const double e = er[u], m = mr[u];
+        const int tn = clampi(t + u + D, 0, T - 1);
+        er[u] = wsb[(long)tn * HMM_WS + OE];
+        mr[u] = wsr[(long)tn * HMM_WS + OM];
+        fstep(t + u, e, m, std::integral_constant<bool, u == D - 1>{});
+      });
+    }
+    static_for<0, D>([&](auto u) { if (t + u < T) fstep(t + u, er[u], mr[u], std::integral_constant<bool, u == D - 1>{}); });
+    if (valid && c == 0) a.logZ[b] = lzS + ::log(lzM) + (double)lzE * 0.6931471805599453094;
+  } else {
+    // w_{T-1} = e_{T-1} (beta_{T-1} = 1);  t = T-2 .. 1:  beta^_t = P w_{t+1} / sum,  w_t = e_t o beta^_t
+    double w = col ? wsb[(long)(T - 1) * HMM_WS + OE] : 0.0;
+    if (st) wsb[(long)(T - 1) * HMM_WS + OW] = w;
+    auto bstep = [&](int t, double e) {
+      double q0 = 0.0, q1 = 0.0;
+      dpp_fence(w);
+      static_for<0, K>([&](auto k) { if constexpr (k % 2 == 0) mac_bc<k>(q0, w, PT[k]); else mac_bc<k>(q1, w, PT[k]); });
+      double q = q0 + q1;                                 // lane j: sum_k P[j][k] w[k]
+      double d0 = 0.0, d1 = 0.0;
+      dpp_fence(q);
+      static_for<0, K>([&](auto j) { if constexpr (j % 2 == 0) mac_bc<j>(d0, q, one); else mac_bc<j>(d1, q, one); });
+      const double d = d0 + d1;
+      bad = bad || !(d > HMM_TINY);
+      w = e * (q * rcp_nr(d));
+      if (st) wsb[(long)t * HMM_WS + OW] = w;
+    };
+    const int nsteps = T - 2 > 0 ? T - 2 : 0;            // step i: t = T-2-i  (t >= 1)
+    if (nsteps > 0) {
+      double er[D];
+      static_for<0, D>([&](auto u) { er[u] = wsb[(long)clampi(T - 2 - u, 1, T - 1) * HMM_WS + OE]; });
+      int i = 0;
+      for (; i + D <= nsteps; i += D) {
+        static_for<0, D>([&](auto u) {
+          const double e = er[u];
+          er[u] = wsb[(long)clampi(T - 2 - (i + u + D), 1, T - 1) * HMM_WS + OE];
+          bstep(T - 2 - (i + u), e);
+        });
+      }
+      static_for<0, D>([&](auto u) { if (i + u < nsteps) bstep(T - 2 - (i + u), er[u]); });
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 3: marginals and transition counts, half of the steps each -----------------------------------------------------------
+  double acc[K];
+  static_for<0, K>([&](auto j) { acc[j] = 0.0; });
+  {
+    const int th = T / 2;
+    const int q0_ = wv ? th : 0;
+    const int p1 = wv ? T : th;
+    const int q1_ = p1 < T - 1 ? p1 : T - 1;             // steps q0_ .. q1_-1 have a successor
+    double* oS = a.E_states + ((long)b * T) * K + cc;
+    double gam0 = 0.0;
+    auto cstep = [&](int t, double al, double w1) {
+      double s0 = 0.0, s1 = 0.0;
+      dpp_fence(w1);
+      static_for<0, K>([&](auto k) { if constexpr (k % 2 == 0) mac_bc<k>(s0, w1, PT[k]); else mac_bc<k>(s1, w1, PT[k]); });
+      double g = al * (s0 + s1);
+      double z0 = 0.0, z1 = 0.0;
+      dpp_fence(g);
+      static_for<0, K>([&](auto j) { if constexpr (j % 2 == 0) mac_bc<j>(z0, g, one); else mac_bc<j>(z1, g, one); });
+      const double Z = z0 + z1;
+      bad = bad || !(Z > HMM_TINY);
+      const double rz = rcp_nr(Z);
+      const double gam = g * rz;
+      if (st) oS[(long)t * K] = gam;
+      gam0 = t == 0 ? gam : gam0;
+      double alz = al * rz;
+      dpp_fence(alz);
+      static_for<0, K>([&](auto j) { mac_bc<j>(acc[j], alz, w1); });     // lane k: alpha^_t[j] w_{t+1}[k] / Z_t
+    };
+    if (q0_ < q1_) {
+      double ar[D], wr[D];
+      static_for<0, D>([&](auto u) {
+        const int tt = clampi(q0_ + u, 0, T - 2);
+        ar[u] = wsb[(long)tt * HMM_WS + OA];
+        wr[u] = wsb[(long)(tt + 1) * HMM_WS + OW];
+      });
+      int t = q0_;
+      for (; t + D <= q1_; t += D) {
+        static_for<0, D>([&](auto u) {
+          const double al = ar[u], w1 = wr[u];
+          const int tn = clampi(t + u + D, 0, T - 2);
+          ar[u] = wsb[(long)tn * HMM_WS + OA];
+          wr[u] = wsb[(long)(tn + 1) * HMM_WS + OW];
+          cstep(t + u, al, w1);
+        });
+      }
+      static_for<0, D>([&](auto u) { if (t + u < q1_) cstep(t + u, ar[u], wr[u]); });
+    }
+    if (wv == 0 && T > 1 && st) a.E_init[(long)b * K + c] = gam0;
+    if (p1 == T && q0_ <= T - 1) {                        // beta_{T-1} = 1: gamma = alpha^ (sums to one)
+      const double al = wsb[(long)(T - 1) * HMM_WS + OA];
+      if (st) oS[(long)(T - 1) * K] = al;
+      if (T == 1 && st) a.E_init[(long)b * K + c] = al;
+    }
+  }
+  if (bad && valid && c == 0) wsr[HMM_REDO] = 1.0;
+  if (wv == 1) static_for<0, K>([&](auto j) { xacc[j * 64 + lane] = acc[j]; });
+  __syncthreads();
+  if (wv == 0 && st)
+    static_for<0, K>([&](auto j) { a.E_trans[(long)b * K * K + j * K + c] = (acc[j] + xacc[j * 64 + lane]) * P[j]; });
+}
+
 template <int K>
 static int launch_hmm(const HmmArgs& a, hipStream_t s) {
+#if SVAE_HMM_TWOEND
+  {
+    HmmArgs r = a;
+    r.redo_only = 1;
+    if (a.pair_contr) {
+      hipLaunchKernelGGL((hmm_estep2_kernel<K, true>), dim3((a.B + 3) / 4), dim3(128), 0, s, a);
+      hipLaunchKernelGGL((hmm_estep_kernel<K, true>), dim3((a.B + 3) / 4), dim3(64), 0, s, r);
+    } else {
+      hipLaunchKernelGGL((hmm_estep2_kernel<K, false>), dim3((a.B + 3) / 4), dim3(128), 0, s, a);
+      hipLaunchKernelGGL((hmm_estep_kernel<K, false>), dim3((a.B + 3) / 4), dim3(64), 0, s, r);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+  }
+#endif
   if (a.pair_contr) hipLaunchKernelGGL((hmm_estep_kernel<K, true>), dim3((a.B + 3) / 4), dim3(64), 0, s, a);
   else hipLaunchKernelGGL((hmm_estep_kernel<K, false>), dim3((a.B + 3) / 4), dim3(64), 0, s, a);
   return hipGetLastError() == hipSuccess ? 0 : -1000;
@@ -476,7 +758,7 @@ extern "C" int svae_hmm_estep_f64(int B, int T, int K, int pair_batched,
   a.logZ = logZ; a.E_init = E_init; a.E_trans = E_trans; a.E_states = E_states;
   a.ws = (double*)workspace;
   a.seq_index = nullptr; a.n = 0; a.pair_contr = nullptr; a.lds_E_init = nullptr; a.init_J = nullptr; a.init_h = nullptr;
-  a.cinit = nullptr; a.lz = nullptr; a.node_out = nullptr;
+  a.cinit = nullptr; a.lz = nullptr; a.node_out = nullptr; a.redo_only = 0;
   return hmm_dispatch(a, stream);
 }
 
@@ -510,7 +792,7 @@ extern "C" int svae_slds_hmm_meanfield_f64(int B, int rows, int T, int K, int n,
   a.ws = (double*)workspace;
   a.seq_index = seq_index; a.n = n;
   a.pair_contr = node_params ? nullptr : pair_contr; a.lds_E_init = lds_E_init; a.init_J = init_J; a.init_h = init_h;
-  a.cinit = cinit; a.lz = lz; a.node_out = node_out;
+  a.cinit = cinit; a.lz = lz; a.node_out = node_out; a.redo_only = 0;
   return hmm_dispatch(a, stream);
 }
 
