@@ -21,7 +21,8 @@ def _problem(B, T, K, rng, scale=1.0):
 
 
 @pytest.mark.parametrize("B,T,K,scale", [(5, 7, 3, 1.0), (9, 50, 8, 3.0), (2, 500, 8, 50.0), (3, 1, 4, 1.0),
-                                         (4, 33, 16, 1.0), (1, 12, 1, 2.0)])
+                                         (4, 33, 16, 1.0), (1, 12, 1, 2.0), (6, 2, 5, 1.0), (7, 3, 9, 2.0),
+                                         (13, 17, 8, 1.0), (5, 16, 2, 4.0), (3, 25, 12, 1.0)])
 def test_hmm_estep_against_oracle_and_reference(B, T, K, scale):
     from svae_amd.hmm.hmm_inference import hmm_estep
     rng = np.random.default_rng(B * 100 + T + K)
@@ -102,3 +103,27 @@ def test_hmm_forced_transition_through_a_tiny_entry():
         np.testing.assert_allclose(_np(Es[b]), os_, rtol=1e-7, atol=1e-10)
         np.testing.assert_allclose(_np(Et[b]), ot, rtol=1e-7, atol=1e-9)
     assert float(logZ[0]) < -790
+
+
+def test_hmm_two_ended_kernel_with_one_flagged_sequence_among_many():
+    """hmm_estep2_kernel (alpha and beta recursions on two wavefronts, each with its own scaling) serves every sequence
+    whose normalisers stay above 1e-200; a sequence that underflows is flagged and redone by the one-directional kernel
+    (log-space steps), wavefront by wavefront: here sequence 6 of 11 (third of its wavefront) is the forced-transition
+    chain of the test above, the others are ordinary -- all of them must match the log-space oracle."""
+    from svae_amd.hmm.hmm_inference import hmm_estep
+    K, T, B = 3, 12, 11
+    init = np.array([0.0, -1e4, -1e4])
+    pair = np.array([[0.0, -800.0, -1e4], [-1e4, 0.0, -1.0], [-1e4, -1.0, 0.0]])
+    rng = np.random.default_rng(4)
+    node = 0.5 * rng.standard_normal((B, T, K))
+    node[6] = 0.0
+    node[6, :6, 1:] = -1e4
+    node[6, 6:, 0] = -1e4
+    logZ, (Ei, Et, Es) = hmm_estep((init, pair, node))
+    for b in range(B):
+        lz, (oi, ot, os_) = hmm_numpy.hmm_estep((init, pair, node[b]))
+        assert np.isfinite(lz) and float(logZ[b]) == pytest.approx(lz, rel=1e-9, abs=1e-9)
+        np.testing.assert_allclose(_np(Ei[b]), oi, rtol=1e-7, atol=1e-10)
+        np.testing.assert_allclose(_np(Es[b]), os_, rtol=1e-7, atol=1e-10)
+        np.testing.assert_allclose(_np(Et[b]), ot, rtol=1e-7, atol=1e-9)
+    assert float(logZ[6]) < -790
