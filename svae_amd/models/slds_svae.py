@@ -196,11 +196,12 @@ class SLDSMeanfieldPlan(object):
         f64 = dict(dtype=torch.float64, device=self.device)
         self.ws_bytes = int(self.lib.svae_slds_lds_meanfield_workspace_bytes(max(B, 1), T, n))
         self.ws = torch.empty(self.ws_bytes // 8, **f64)
-        self.lognorm = torch.zeros(B, **f64)
-        self.E_init = torch.zeros(B, n * n + n, **f64)
-        self.E_node_diagxx = torch.zeros(B, T, n, **f64)
-        self.E_node_x = torch.zeros(B, T, n, **f64)
-        self.pair_contr = torch.zeros(B, T, 2, K, **f64)
+        # (no zero fills: the first launch of an ascent runs on every row and writes all of these)
+        self.lognorm = torch.empty(B, **f64)
+        self.E_init = torch.empty(B, n * n + n, **f64)
+        self.E_node_diagxx = torch.empty(B, T, n, **f64)
+        self.E_node_x = torch.empty(B, T, n, **f64)
+        self.pair_contr = torch.empty(B, T, 2, K, **f64)
         self.info = torch.zeros(1, dtype=torch.int32, device=self.device)
 
     @staticmethod
@@ -290,9 +291,10 @@ def _optimize_local_meanfield_fused(hmm_init, hmm_pair, dense_init, dense_pair, 
     # ... and of the LDS bound: the compiled reference filter drops the second one (module docstring)
     cinit_vlb = dense_init[2].contiguous() if reference_compat else cinit_hmm
     lz = dense_pair[3].contiguous()
-    st = dict(Ei=torch.zeros(B, K, **f64), Et=torch.zeros(B, K, K, **f64), Es=torch.zeros(B, T, K, **f64),
-              hmm_vlb=torch.zeros(B, **f64), node_hmm=node_hmm)
-    lds_vlb = torch.zeros(B, **f64)
+    # (sweep 0 runs on all B rows: every buffer below is written before it is read)
+    st = dict(Ei=torch.empty(B, K, **f64), Et=torch.empty(B, K, K, **f64), Es=torch.empty(B, T, K, **f64),
+              hmm_vlb=torch.empty(B, **f64), node_hmm=node_hmm)
+    lds_vlb = torch.empty(B, **f64)
     vlb = torch.full((B,), -float("inf"), **f64)
     iters = torch.zeros(B, **i32)
     hws_bytes = int(lib.svae_hmm_workspace_bytes(max(B, 1), T, K))
@@ -325,15 +327,28 @@ def _optimize_local_meanfield_fused(hmm_init, hmm_pair, dense_init, dense_pair, 
     return plan, st, lds_vlb, iters.to(torch.int64)
 
 
+_RW_CACHE = {}
+
+
+def _random_walk_natparam(n, dev):
+    """Natural parameters of the random-walk LDS of initialize_local_meanfield (:203-226: x_0 ~ N(0, I), A = 0.9 I,
+    unit noise) -- constants of (n, device), built once (a dozen tiny launches otherwise, every ascent)."""
+    key = (n, str(dev))
+    if key not in _RW_CACHE:
+        eye = torch.eye(n, dtype=torch.float64, device=dev)
+        A = 0.9 * eye
+        zero = torch.zeros((), dtype=torch.float64, device=dev)
+        _RW_CACHE[key] = ((-0.5 * eye, torch.zeros(n, dtype=torch.float64, device=dev), zero),
+                          ((-0.5 * A.T @ A).contiguous(), A.T.contiguous(), -0.5 * eye, zero))
+    return _RW_CACHE[key]
+
+
 def _initial_sample_path(node_potentials, eps):
     """(:203-226) ONE posterior sample path x (B,T,n) of a random-walk LDS given the node potentials."""
     nJ = node_potentials[0]
     B, T, n = nJ.shape
     dev = nJ.device
-    eye = torch.eye(n, dtype=torch.float64, device=dev)
-    A = 0.9 * eye
-    natparam = ((-0.5 * eye, torch.zeros(n, dtype=torch.float64, device=dev), torch.zeros((), dtype=torch.float64, device=dev)),
-                (-0.5 * A.T @ A, A.T.contiguous(), -0.5 * eye, torch.zeros((), dtype=torch.float64, device=dev)))
+    natparam = _random_walk_natparam(n, dev)
     x = natural_lds_sample(natparam, node_potentials, num_samples=1, eps=eps)     # filter + sampler, no smoother (:222)
     return x[:, :, 0]                                                # (B,T,n)
 
