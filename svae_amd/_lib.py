@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must precede CDLL: shares torch's HIP runtime)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVAE_AMD_LIB", os.path.join(_HERE, "libsvae_hip.so"))  # env: experiments only
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 LDS_MAX_N = 15        # register/DPP path (E-step, sampler, VJP)
 LDS_TILE_MAX_N = 64   # LDS-tiled MFMA path (E-step only)
 
@@ -74,6 +74,8 @@ SIGNATURES = {
                                 + [ctypes.c_void_p, ctypes.c_void_p, _c_int_p, ctypes.c_void_p]),
     "svae_lds_tile_sample_f64": (ctypes.c_int, [ctypes.c_int] * 4 + [_c_double_p] * 2 + [ctypes.c_void_p, ctypes.c_void_p]),
     "svae_lds_global_step_f64": (ctypes.c_int, [ctypes.c_int] + [_c_double_p] * 19 + [_c_int_p, ctypes.c_void_p]),
+    "svae_lds_global_step_multi_f64": (ctypes.c_int, [ctypes.c_int] * 2 + [ctypes.POINTER(ctypes.c_void_p)] * 5 +
+                                       [_c_double_p] * 8 + [_c_int_p, ctypes.c_void_p]),
     "svae_lds_natgrad_f64": (ctypes.c_int, [ctypes.c_int] * 2 + [_c_double_p] * 3 + [ctypes.c_double] * 2
                              + [_c_double_p, ctypes.c_void_p]),
     "svae_gmm_mw_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 4),

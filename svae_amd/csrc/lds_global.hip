@@ -133,7 +133,19 @@ struct GlobalArgs {
 // Work arrays in LDS: W0, W1, W2 (n x n each), vectors.
 struct FactorOut { double niw_logZ, mniw_logZ; };
 
-__global__ __launch_bounds__(GL_BLOCK) void lds_global_kernel(const GlobalArgs a) {
+__device__ __forceinline__ void lds_global_body(const GlobalArgs& a, const int pass);
+
+__global__ __launch_bounds__(GL_BLOCK) void lds_global_kernel(const GlobalArgs a) { lds_global_body(a, (int)blockIdx.x); }
+
+// K parameter sets in ONE launch (the SLDS global -> local maps: K launches of 36 us each were a fifth of the start-up of
+// an ascent): workgroup k runs set k.  No priors / KL here (pass 0 only).
+constexpr int GL_MULTI_MAX = 16;
+struct GlobalArgsMulti { GlobalArgs s[GL_MULTI_MAX]; };
+__global__ __launch_bounds__(GL_BLOCK) void lds_global_multi_kernel(const GlobalArgsMulti m) {
+  lds_global_body(m.s[blockIdx.x], 0);
+}
+
+__device__ __forceinline__ void lds_global_body(const GlobalArgs& a, const int pass) {
   extern __shared__ double sm[];
   const int n = a.n, D = n + 2, tid = threadIdx.x;
   double* W0 = sm;                  // n*n
@@ -157,7 +169,7 @@ __global__ __launch_bounds__(GL_BLOCK) void lds_global_kernel(const GlobalArgs a
   double es_dot = 0.0;              // <prior - global, E_global[t]>  partial of this thread
   double logZ_g = 0.0, logZ_p = 0.0;
   {
-    const int q = blockIdx.x;
+    const int q = pass;
     const double* niw = q ? a.p_niw : a.niw;
     const double* mA = q ? a.p_mA : a.mA;
     const double* mB = q ? a.p_mB : a.mB;
@@ -284,7 +296,7 @@ __global__ __launch_bounds__(GL_BLOCK) void lds_global_kernel(const GlobalArgs a
       if (tid < s) red[tid] += red[tid + s];
       __syncthreads();
     }
-    if (tid == 0) atomicAdd(a.global_kl, blockIdx.x == 0 ? -red[0] - logZ_g + kl : logZ_p);   // lds.py:16-20
+    if (tid == 0) atomicAdd(a.global_kl, pass == 0 ? -red[0] - logZ_g + kl : logZ_p);   // lds.py:16-20
   }
   if (tid == 0 && bad) atomicMax(a.info, 1);
 }
@@ -347,6 +359,40 @@ extern "C" int svae_lds_global_step_f64(int n, const double* niw, const double* 
   const bool with_kl = global_kl && prior_niw;
   if (with_kl && hipMemsetAsync(global_kl, 0, sizeof(double), (hipStream_t)stream) != hipSuccess) return -1000;
   hipLaunchKernelGGL(svae::lds_global_kernel, dim3(prior_niw ? 2 : 1), dim3(svae::GL_BLOCK), lds, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+extern "C" int svae_lds_global_step_multi_f64(int K, int n, const double* const* niw, const double* const* mniw_A,
+                                              const double* const* mniw_B, const double* const* mniw_C,
+                                              const double* const* mniw_d,
+                                              double* init_J, double* init_h, double* init_logZ,
+                                              double* J11, double* J12, double* J22, double* logZ_pair,
+                                              double* niw_expectedstats, int32_t* info, void* stream) {
+  if (K < 1 || K > svae::GL_MULTI_MAX) return -1;
+  if (n < 1 || n > svae::GL_MAX_N) return -2;
+  if (!niw || !mniw_A || !mniw_B || !mniw_C || !mniw_d) return -3;
+  if (!init_J || !init_h || !init_logZ) return -8;
+  if (!J11 || !J12 || !J22 || !logZ_pair) return -11;
+  if (!info) return -16;
+  svae::GlobalArgsMulti m;
+  const long nn = (long)n * n, D = n + 2;
+  for (int k = 0; k < svae::GL_MULTI_MAX; ++k) {
+    const int q = k < K ? k : K - 1;                 // (unused entries repeat the last set: never launched)
+    if (!niw[q] || !mniw_A[q] || !mniw_B[q] || !mniw_C[q] || !mniw_d[q]) return -3;
+    svae::GlobalArgs& a = m.s[k];
+    a.n = n; a.niw = niw[q]; a.mA = mniw_A[q]; a.mB = mniw_B[q]; a.mC = mniw_C[q]; a.md = mniw_d[q];
+    a.p_niw = nullptr; a.p_mA = a.p_mB = a.p_mC = a.p_md = nullptr;
+    a.init_J = init_J + q * nn; a.init_h = init_h + q * n; a.init_logZ = init_logZ + q;
+    a.J11 = J11 + q * nn; a.J12 = J12 + q * nn; a.J22 = J22 + q * nn; a.logZ_pair = logZ_pair + q;
+    a.niw_es = niw_expectedstats ? niw_expectedstats + q * D * D : nullptr;
+    a.global_kl = nullptr; a.info = info;
+  }
+  const size_t lds = (size_t)(4 * n * n + 4 * n + 3 * svae::GL_BLOCK) * sizeof(double);
+  static svae::LdsGrant grant;
+  if (!grant.ensure(reinterpret_cast<const void*>(svae::lds_global_multi_kernel),
+                    (long)((4 * svae::GL_MAX_N * svae::GL_MAX_N + 4 * svae::GL_MAX_N + 3 * svae::GL_BLOCK) * sizeof(double))))
+    return -1001;
+  hipLaunchKernelGGL(svae::lds_global_multi_kernel, dim3(K), dim3(svae::GL_BLOCK), lds, (hipStream_t)stream, m);
   return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 

@@ -56,9 +56,9 @@ def get_all_lds_local_natparams(lds_global_natparams):
 
 
 def _global_to_local_maps_device(global_natparam, device):
-    """global_to_local_maps with the K (NIW, MNIW) factor pairs through the LDS global-step kernel
-    (svae_lds_global_step_f64, one launch per state writing straight into the stacked outputs) and the Dirichlet rows
-    as two digamma expressions on the device: no host arithmetic, no host -> device copies of the results."""
+    """global_to_local_maps with the K (NIW, MNIW) factor pairs through the LDS global-step kernel -- ONE launch for all K
+    states (svae_lds_global_step_multi_f64; K > 16: one launch per state) writing the stacked outputs -- and the Dirichlet
+    rows as two digamma expressions on the device: no host arithmetic, no host -> device copies of the results."""
     from .lds import GLOBAL_STEP_MAX_N
     hmm_global, lds_global = global_natparam
     K = len(lds_global)
@@ -69,33 +69,33 @@ def _global_to_local_maps_device(global_natparam, device):
     c = lambda x: _dev64(x, device).contiguous()
     hmm_init, hmm_pair = hmm_prior_expectedstats(tuple(c(x) for x in hmm_global))
     D = n + 2
-    # one block per kind, sliced per state: [J (n,n) | h (n) | logZ (1)], [J11 | J12 | J22 (n,n) | logZ (1)], es (D,D)
-    initb = torch.empty(K, n * n + n + 1, **f64)
-    pairb = torch.empty(K, 3 * n * n + 1, **f64)
-    esb = torch.empty(K, D, D, **f64)
+    # ONE launch for the K factor pairs (svae_lds_global_step_multi_f64): host arrays of K device pointers in, stacked
+    # outputs (K, ...) out
+    import ctypes
+    f = lambda shape: torch.empty(*shape, **f64)
+    init_J, init_h, init_lz = f((K, n, n)), f((K, n)), f((K,))
+    J11, J12, J22, lzp = f((K, n, n)), f((K, n, n)), f((K, n, n)), f((K,))
+    esb = f((K, D, D))
     info = torch.zeros(1, dtype=torch.int32, device=device)
     lib, p = _lib.load(), _lib.ptr
-    keep = []
-    stream = _lib.current_stream(device)
-    e8 = 8      # bytes per double
-    for k, (niw, (A, Bm, C, d)) in enumerate(lds_global):
-        t = [c(niw), c(A), c(Bm), c(C), c(d).reshape(1)]
-        keep.append(t)
-        ib, pb = initb[k].data_ptr(), pairb[k].data_ptr()
-        import ctypes
-        q = lambda addr: ctypes.c_void_p(addr)
-        rc = lib.svae_lds_global_step_f64(
-            n, p(t[0]), p(t[1]), p(t[2]), p(t[3]), p(t[4]), None, None, None, None, None,
-            q(ib), q(ib + e8 * n * n), q(ib + e8 * (n * n + n)),
-            q(pb), q(pb + e8 * n * n), q(pb + e8 * 2 * n * n), q(pb + e8 * 3 * n * n), p(esb[k]), None, p(info), stream)
-        _lib.check(rc, "svae_lds_global_step_f64")
+    keep = [[c(niw), c(A), c(Bm), c(C), c(d).reshape(1)] for niw, (A, Bm, C, d) in lds_global]
+    arrs = [(ctypes.c_void_p * K)(*[t[i].data_ptr() for t in keep]) for i in range(5)]
+    if K <= 16:
+        rc = lib.svae_lds_global_step_multi_f64(K, n, arrs[0], arrs[1], arrs[2], arrs[3], arrs[4],
+                                                p(init_J), p(init_h), p(init_lz), p(J11), p(J12), p(J22), p(lzp), p(esb),
+                                                p(info), _lib.current_stream(device))
+        _lib.check(rc, "svae_lds_global_step_multi_f64")
+    else:
+        for k, t in enumerate(keep):
+            rc = lib.svae_lds_global_step_f64(
+                n, p(t[0]), p(t[1]), p(t[2]), p(t[3]), p(t[4]), None, None, None, None, None,
+                p(init_J[k]), p(init_h[k]), p(init_lz[k:k + 1]), p(J11[k]), p(J12[k]), p(J22[k]), p(lzp[k:k + 1]), p(esb[k]),
+                None, p(info), _lib.current_stream(device))
+            _lib.check(rc, "svae_lds_global_step_f64")
     global_to_local_maps.last_info = info
-    nn = n * n
     dense_init = (esb[:, :n, :n].contiguous(), esb[:, :n, n].contiguous(), esb[:, n, n].contiguous(),
                   esb[:, n + 1, n + 1].contiguous())
-    dense_pair = (pairb[:, :nn].reshape(K, n, n), pairb[:, nn:2 * nn].reshape(K, n, n),
-                  pairb[:, 2 * nn:3 * nn].reshape(K, n, n), pairb[:, 3 * nn].contiguous())
-    dense_pair = tuple(x.contiguous() for x in dense_pair)
+    dense_pair = (J11, J12, J22, lzp)
     return hmm_init.contiguous(), hmm_pair.contiguous(), dense_init, dense_pair
 
 
