@@ -319,13 +319,14 @@ __global__ __launch_bounds__(64) void hmm_estep_kernel(const HmmArgs a) {
 // the one-directional kernel is launched behind this one with redo_only = 1 and recomputes the flagged wavefronts,
 // log-space steps and all (its wavefronts exit at once otherwise).  Same mapping: one DPP row per sequence, lane = state.
 constexpr int HMM2_D = 8;
+constexpr int HMM2_WAVES = 4;     // wavefronts per workgroup: all of them share phases 1 and 3, two run the recursions
 template <int K, bool FUSED>
-__global__ __launch_bounds__(128) void hmm_estep2_kernel(const HmmArgs a) {
-  constexpr int D = HMM2_D;
+__global__ __launch_bounds__(64 * HMM2_WAVES) void hmm_estep2_kernel(const HmmArgs a) {
+  constexpr int D = HMM2_D, NW = HMM2_WAVES;
   constexpr int KS = K <= 8 ? 8 : 16;                    // slot width
   constexpr int OA = 0, OE = KS, OW = 2 * KS, OM = 3 * KS;
   static_assert(OM < HMM_REDO, "record layout");
-  __shared__ double xacc[16 * 64];
+  __shared__ double xacc[(NW - 1) * 16 * 64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int c = lane & 15;
   const int brow = blockIdx.x * 4 + (lane >> 4);
@@ -373,9 +374,8 @@ __global__ __launch_bounds__(128) void hmm_estep2_kernel(const HmmArgs a) {
       if (st) wsb[(long)t * HMM_WS + OE] = e;
       if (valid && c == 0) wsr[(long)t * HMM_WS + OM] = m;
     };
-    const int th = (T + 1) / 2;
-    int p0 = wv ? th : 0;
-    const int p1 = wv ? T : th;
+    int p0 = (int)((long)T * wv / NW);
+    const int p1 = (int)((long)T * (wv + 1) / NW);
     if (wv == 0) {
       if (valid && c == 0) wsr[HMM_REDO] = 0.0;
       double nd0;
@@ -394,8 +394,8 @@ __global__ __launch_bounds__(128) void hmm_estep2_kernel(const HmmArgs a) {
         nd0 = node[0];
       }
       emit(0, nd0, a.init_params[cc]);
-      p0 = 1;
     }
+    if (p0 == 0) p0 = 1;                                 // (step 0 is wavefront 0's, above; T < NW: another range may start at 0)
     // steps p0 .. p1-1 (all >= 1), potentials requested D steps ahead
     auto node_at = [&](int t, double& x0, double& x1) {
       if constexpr (FUSED) { x0 = pc[(long)(t - 1) * 2 * K]; x1 = pc[(long)t * 2 * K + K]; }
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(128) void hmm_estep2_kernel(const HmmArgs a) {
     }
     static_for<0, D>([&](auto u) { if (t + u < T) fstep(t + u, er[u], mr[u], std::integral_constant<bool, u == D - 1>{}); });
     if (valid && c == 0) a.logZ[b] = lzS + ::log(lzM) + (double)lzE * 0.6931471805599453094;
-  } else {
+  } else if (wv == 1) {
     // w_{T-1} = e_{T-1} (beta_{T-1} = 1);  t = T-2 .. 1:  beta^_t = P w_{t+1} / sum,  w_t = e_t o beta^_t
     double w = col ? wsb[(long)(T - 1) * HMM_WS + OE] : 0.0;
     if (st) wsb[(long)(T - 1) * HMM_WS + OW] = w;
@@ -497,9 +497,8 @@ __global__ __launch_bounds__(128) void hmm_estep2_kernel(const HmmArgs a) {
   double acc[K];
   static_for<0, K>([&](auto j) { acc[j] = 0.0; });
   {
-    const int th = T / 2;
-    const int q0_ = wv ? th : 0;
-    const int p1 = wv ? T : th;
+    const int q0_ = (int)((long)T * wv / NW);
+    const int p1 = (int)((long)T * (wv + 1) / NW);
     const int q1_ = p1 < T - 1 ? p1 : T - 1;             // steps q0_ .. q1_-1 have a successor
     double* oS = a.E_states + ((long)b * T) * K + cc;
     double gam0 = 0.0;
@@ -540,18 +539,22 @@ __global__ __launch_bounds__(128) void hmm_estep2_kernel(const HmmArgs a) {
       }
       static_for<0, D>([&](auto u) { if (t + u < q1_) cstep(t + u, ar[u], wr[u]); });
     }
-    if (wv == 0 && T > 1 && st) a.E_init[(long)b * K + c] = gam0;
-    if (p1 == T && q0_ <= T - 1) {                        // beta_{T-1} = 1: gamma = alpha^ (sums to one)
+    if (q0_ == 0 && q0_ < q1_ && st) a.E_init[(long)b * K + c] = gam0;      // (the wavefront whose range holds step 0)
+    if (wv == NW - 1) {                                   // beta_{T-1} = 1: gamma = alpha^ (sums to one)
       const double al = wsb[(long)(T - 1) * HMM_WS + OA];
       if (st) oS[(long)(T - 1) * K] = al;
       if (T == 1 && st) a.E_init[(long)b * K + c] = al;
     }
   }
   if (bad && valid && c == 0) wsr[HMM_REDO] = 1.0;
-  if (wv == 1) static_for<0, K>([&](auto j) { xacc[j * 64 + lane] = acc[j]; });
+  if (wv > 0) static_for<0, K>([&](auto j) { xacc[((wv - 1) * 16 + j) * 64 + lane] = acc[j]; });
   __syncthreads();
   if (wv == 0 && st)
-    static_for<0, K>([&](auto j) { a.E_trans[(long)b * K * K + j * K + c] = (acc[j] + xacc[j * 64 + lane]) * P[j]; });
+    static_for<0, K>([&](auto j) {
+      double s = acc[j];
+      static_for<0, NW - 1>([&](auto w) { s += xacc[(w * 16 + j) * 64 + lane]; });       // (fixed order)
+      a.E_trans[(long)b * K * K + j * K + c] = s * P[j];
+    });
 }
 
 template <int K>
@@ -561,10 +564,10 @@ static int launch_hmm(const HmmArgs& a, hipStream_t s) {
     HmmArgs r = a;
     r.redo_only = 1;
     if (a.pair_contr) {
-      hipLaunchKernelGGL((hmm_estep2_kernel<K, true>), dim3((a.B + 3) / 4), dim3(128), 0, s, a);
+      hipLaunchKernelGGL((hmm_estep2_kernel<K, true>), dim3((a.B + 3) / 4), dim3(64 * HMM2_WAVES), 0, s, a);
       hipLaunchKernelGGL((hmm_estep_kernel<K, true>), dim3((a.B + 3) / 4), dim3(64), 0, s, r);
     } else {
-      hipLaunchKernelGGL((hmm_estep2_kernel<K, false>), dim3((a.B + 3) / 4), dim3(128), 0, s, a);
+      hipLaunchKernelGGL((hmm_estep2_kernel<K, false>), dim3((a.B + 3) / 4), dim3(64 * HMM2_WAVES), 0, s, a);
       hipLaunchKernelGGL((hmm_estep_kernel<K, false>), dim3((a.B + 3) / 4), dim3(64), 0, s, r);
     }
     return hipGetLastError() == hipSuccess ? 0 : -1000;
