@@ -151,6 +151,27 @@ def test_global_step_kernel_matches_the_exponential_family_maps(n):
     assert kl2 is None and torch.equal(init2[0], init[0]) and torch.equal(pair2[1], pair[1])
 
 
+@pytest.mark.parametrize("K,n", [(1, 3), (8, 10), (16, 4)])
+def test_slds_global_maps_in_one_launch_equal_one_launch_per_state(K, n):
+    """svae_lds_global_step_multi_f64 (the K factor pairs of the SLDS global -> local maps in ONE launch) runs the
+    same workgroup code as K calls of svae_lds_global_step_f64: every stacked output is bit for bit the per-state one."""
+    from svae_amd.models import lds as lds_model
+    from svae_amd.models import slds_svae
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(10 * K + n)
+    lds_global = [_rand_lds_global(n, rng, dev) for _ in range(K)]
+    hmm_global = (torch.as_tensor(1.0 + rng.random(K), device=dev), torch.as_tensor(1.0 + rng.random((K, K)), device=dev))
+    _, _, dense_init, dense_pair = slds_svae.global_to_local_maps((hmm_global, lds_global), dev)
+    for k, g in enumerate(lds_global):
+        (init, pair), _, es = lds_model.global_step(g)
+        assert torch.equal(dense_pair[0][k], pair[0]) and torch.equal(dense_pair[1][k], pair[1])
+        assert torch.equal(dense_pair[2][k], pair[2]) and torch.equal(dense_pair[3][k], pair[3].reshape(()))
+        D = n + 2
+        esk = es.reshape(D, D)
+        assert torch.equal(dense_init[0][k], esk[:n, :n]) and torch.equal(dense_init[1][k], esk[:n, n])
+        assert torch.equal(dense_init[2][k], esk[n, n]) and torch.equal(dense_init[3][k], esk[n + 1, n + 1])
+
+
 def test_natural_gradient_kernel_matches_the_flat_expression():
     """svae_lds_natgrad_f64 against make_gradfun's generic expression (svae.py:33-34) on the same statistics."""
     from svae_amd import svae as svae_mod
