@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SVAE_HIP_ABI_VERSION 11   /* 11: + svae_lds_global_step_multi_f64 (K parameter sets in one launch: the SLDS global -> local maps); 10: + svae_ipc_allreduce_f64 / svae_ipc_mailbox_bytes, svae_gmm_sample_f64, svae_gmm_local_vjp_f64, svae_gmm_global_step_f64 (the differentiable tail and the global side of the GMM local step); 9: keep bit SVAE_KEEP_SIGMA of svae_lds_estep_f64 (16 <= n <= 64) + svae_lds_tile_sigma_offset_bytes; 8: step ranges (t_begin, t_end) in svae_lds_tile_vjp_f64 / svae_lds_tile_noise_f64, SVAE_OPT_TILE_FORWARD / _BACKWARD; 7: + svae_slds_path_nodeparams_f64, svae_slds_mix_pair_natparam_f64; 6: per-call `options` word replaces the process-global svae_lds_set_* selectors (re-entrant library), + svae_slds_hmm_meanfield_f64, svae_slds_sweep_glue_f64, g_E_pair in svae_lds_tile_vjp_f64; 5: + svae_lds_set_prod_max_b; 4: + svae_slds_lds_meanfield_f64, svae_gmm_mw_*, svae_lds_global_step_f64, svae_lds_natgrad_f64, svae_lds_tile_vjp_f64; 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
+#define SVAE_HIP_ABI_VERSION 11   /* 11: + svae_lds_global_step_multi_f64 (K parameter sets in one launch: the SLDS global -> local maps), svae_lds_diag_sample_f64 (filter + sampler of an all-diagonal LDS: the SLDS initial path); 10: + svae_ipc_allreduce_f64 / svae_ipc_mailbox_bytes, svae_gmm_sample_f64, svae_gmm_local_vjp_f64, svae_gmm_global_step_f64 (the differentiable tail and the global side of the GMM local step); 9: keep bit SVAE_KEEP_SIGMA of svae_lds_estep_f64 (16 <= n <= 64) + svae_lds_tile_sigma_offset_bytes; 8: step ranges (t_begin, t_end) in svae_lds_tile_vjp_f64 / svae_lds_tile_noise_f64, SVAE_OPT_TILE_FORWARD / _BACKWARD; 7: + svae_slds_path_nodeparams_f64, svae_slds_mix_pair_natparam_f64; 6: per-call `options` word replaces the process-global svae_lds_set_* selectors (re-entrant library), + svae_slds_hmm_meanfield_f64, svae_slds_sweep_glue_f64, g_E_pair in svae_lds_tile_vjp_f64; 5: + svae_lds_set_prod_max_b; 4: + svae_slds_lds_meanfield_f64, svae_gmm_mw_*, svae_lds_global_step_f64, svae_lds_natgrad_f64, svae_lds_tile_vjp_f64; 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
 #define SVAE_LDS_MAX_N 15   /* register/DPP path: one 16-lane row per sequence, n+1 <= 16 */
 #define SVAE_LDS_TILE_MAX_N 64   /* 16 <= n <= 64: LDS-tiled MFMA path (keep: SVAE_KEEP_SIGMA or 0) */
 #define SVAE_KEEP_SIGMA 4         /* keep bit of svae_lds_estep_f64, 16 <= n <= 64 only: see svae_lds_tile_sigma_offset_bytes */
@@ -250,6 +250,21 @@ int svae_lds_global_step_multi_f64(int K, int n, const double* const* niw, const
                                    double* init_J, double* init_h, double* init_logZ,
                                    double* J11, double* J12, double* J22, double* logZ_pair,
                                    double* niw_expectedstats, int32_t* info, void* stream);
+
+/* Filter + backward sampler (cython_natural_lds_sample, /root/reference/svae/lds/lds_inference.py:260-264) of an LDS
+ * whose natural parameters are all DIAGONAL -- the random-walk model of initialize_local_meanfield
+ * (/root/reference/svae/models/slds_svae.py:203-226) under diagonal recognition potentials: n independent scalar
+ * recursions per sequence, one lane each.  Same eps -> sample map as svae_lds_filter_f64 + svae_lds_sample_f64 on the
+ * dense form of the same model (one sample per sequence).
+ *  in : init_J, init_h (n); J11, J12, J22 (n): the diagonals (natural parameters as in svae_lds_estep_f64);
+ *       node_J, node_h (B,T,n); eps (B,T,n)
+ *  out: samples (B,T,n); info: b + 1 of a sequence with a non-positive precision, else untouched
+ *  workspace: svae_lds_diag_sample_workspace_bytes(B,T,n) */
+size_t svae_lds_diag_sample_workspace_bytes(int B, int T, int n);
+int svae_lds_diag_sample_f64(int B, int T, int n, const double* init_J, const double* init_h,
+                             const double* J11, const double* J12, const double* J22,
+                             const double* node_J, const double* node_h, const double* eps,
+                             double* samples, int32_t* info, void* workspace, size_t ws_bytes, void* stream);
 
 /* Natural-gradient expression of /root/reference/svae/svae.py:33-34 for the LDS global parameter, straight from
  * the (all-reduced) buffer of svae_lds_reduce_stats_f64:

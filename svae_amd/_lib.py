@@ -74,6 +74,9 @@ SIGNATURES = {
                                 + [ctypes.c_void_p, ctypes.c_void_p, _c_int_p, ctypes.c_void_p]),
     "svae_lds_tile_sample_f64": (ctypes.c_int, [ctypes.c_int] * 4 + [_c_double_p] * 2 + [ctypes.c_void_p, ctypes.c_void_p]),
     "svae_lds_global_step_f64": (ctypes.c_int, [ctypes.c_int] + [_c_double_p] * 19 + [_c_int_p, ctypes.c_void_p]),
+    "svae_lds_diag_sample_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
+    "svae_lds_diag_sample_f64": (ctypes.c_int, [ctypes.c_int] * 3 + [_c_double_p] * 9 + [_c_int_p, ctypes.c_void_p, ctypes.c_size_t,
+                                                                                   ctypes.c_void_p]),
     "svae_lds_global_step_multi_f64": (ctypes.c_int, [ctypes.c_int] * 2 + [ctypes.POINTER(ctypes.c_void_p)] * 5 +
                                        [_c_double_p] * 8 + [_c_int_p, ctypes.c_void_p]),
     "svae_lds_natgrad_f64": (ctypes.c_int, [ctypes.c_int] * 2 + [_c_double_p] * 3 + [ctypes.c_double] * 2

@@ -348,6 +348,26 @@ def _initial_sample_path(node_potentials, eps):
     nJ = node_potentials[0]
     B, T, n = nJ.shape
     dev = nJ.device
+    if nJ.is_cuda and nJ.dim() == 3 and eps is not None:
+        # every matrix of this model is diagonal: n scalar recursions per sequence (svae_lds_diag_sample_f64), the same
+        # eps -> sample map as the dense filter + sampler below (tests/test_slds_hip.py pins the two against each other)
+        key = ("diag", n, str(dev))
+        if key not in _RW_CACHE:
+            v = lambda c: torch.full((n,), c, dtype=torch.float64, device=dev)
+            _RW_CACHE[key] = (v(-0.5), v(0.0), v(-0.5 * (0.9 * 0.9)), v(0.9), v(-0.5))
+        iJ, ih, j11, j12, j22 = _RW_CACHE[key]
+        lib, p = _lib.load(), _lib.ptr
+        nJc, nhc = _dev64(nJ, dev).contiguous(), _dev64(node_potentials[1], dev).contiguous()
+        e = _dev64(eps, dev).reshape(B, T, n).contiguous()
+        out = torch.empty(B, T, n, dtype=torch.float64, device=dev)
+        wsb = int(lib.svae_lds_diag_sample_workspace_bytes(max(B, 1), T, n))
+        ws = torch.empty(wsb // 8, dtype=torch.float64, device=dev)
+        info = torch.zeros(1, dtype=torch.int32, device=dev)
+        rc = lib.svae_lds_diag_sample_f64(B, T, n, p(iJ), p(ih), p(j11), p(j12), p(j22), p(nJc), p(nhc), p(e), p(out),
+                                          p(info), p(ws), wsb, _lib.current_stream(dev))
+        _lib.check(rc, "svae_lds_diag_sample_f64")
+        _initial_sample_path.last_info = info
+        return out
     natparam = _random_walk_natparam(n, dev)
     x = natural_lds_sample(natparam, node_potentials, num_samples=1, eps=eps)     # filter + sampler, no smoother (:222)
     return x[:, :, 0]                                                # (B,T,n)

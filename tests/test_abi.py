@@ -22,7 +22,7 @@ def test_header_declares_the_expected_entry_points():
               "svae_lds_sample_f64", "svae_lds_estep_vjp_f64", "svae_lds_vjp_workspace_bytes",
               "svae_hmm_estep_f64", "svae_hmm_workspace_bytes", "svae_slds_lds_meanfield_f64",
               "svae_slds_lds_meanfield_lds_bytes", "svae_slds_lds_meanfield_workspace_bytes", "svae_gmm_mw_workspace_bytes", "svae_gmm_mw_begin",
-              "svae_gmm_mw_step_f64", "svae_gmm_mw_kl_hist", "svae_gmm_mw_fixed_point_f64", "svae_lds_global_step_f64", "svae_lds_global_step_multi_f64", "svae_lds_natgrad_f64", "svae_lds_tile_vjp_f64",
+              "svae_gmm_mw_step_f64", "svae_gmm_mw_kl_hist", "svae_gmm_mw_fixed_point_f64", "svae_lds_global_step_f64", "svae_lds_global_step_multi_f64", "svae_lds_diag_sample_f64", "svae_lds_diag_sample_workspace_bytes", "svae_lds_natgrad_f64", "svae_lds_tile_vjp_f64",
               "svae_lds_tile_vjp_workspace_doubles", "svae_lds_tile_sample_f64", "svae_lds_tile_noise_f64",
               "svae_lds_tile_sigma_offset_bytes", "svae_gmm_meanfield_f64", "svae_hip_abi_version"):
         assert s in syms

@@ -471,3 +471,22 @@ def test_contraction_kernels_against_the_dense_forms(K, n, T, B):
         assert tuple(a.shape) == tuple(b.shape)
         if b.numel():
             _close(a, _np(b), 1e-12)
+
+
+@pytest.mark.parametrize("B,T,n", [(5, 9, 3), (37, 70, 10), (3, 1, 4), (2, 33, 1), (130, 40, 6)])
+def test_initial_sample_path_diagonal_kernel_equals_the_dense_filter_and_sampler(B, T, n):
+    """initialize_local_meanfield (slds_svae.py:203-226) samples ONE path of a random-walk LDS whose matrices are all
+    diagonal: svae_lds_diag_sample_f64 (n scalar recursions per sequence) must give the samples of the dense path --
+    svae_lds_filter_f64 + svae_lds_sample_f64 on the same model, i.e. cython_natural_lds_sample -- for the same eps."""
+    from svae_amd.lds.lds_inference import natural_lds_sample
+    from svae_amd.models import slds_svae
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(B + T + n)
+    node = (torch.as_tensor(-0.5 * (0.2 + 3 * rng.random((B, T, n))), device=dev),
+            torch.as_tensor(2.0 * rng.standard_normal((B, T, n)), device=dev))
+    eps = torch.as_tensor(rng.standard_normal((B, T, 1, n)), device=dev)
+    got = slds_svae._initial_sample_path(node, eps)
+    want = natural_lds_sample(slds_svae._random_walk_natparam(n, dev), node, num_samples=1, eps=eps)[:, :, 0]
+    assert tuple(got.shape) == (B, T, n)
+    assert float((got - want).abs().max() / want.abs().max()) < 1e-12
+    assert int(slds_svae._initial_sample_path.last_info.item()) == 0
