@@ -150,7 +150,8 @@ int svae_lds_filter_f64(int B, int T, int n, int inhomog, int pair_batched, unsi
  *  in : init_J (K,n,n), init_h (K,n), J11/J12/J22 (K,n,n) natural parameters per discrete state;
  *       weights (rows,T,K) = E[z_t = k]; node potentials (rows,T,n) as in svae_lds_estep_f64;
  *       seq_index (B) int32 or NULL: the launch processes B <= rows sequences, slot i working on row
- *       seq_index[i] of every array and of the workspace (NULL: row i); rows not listed are left untouched
+ *       seq_index[i] of every array and of the workspace (NULL: row i); rows not listed are left untouched;
+ *       a NEGATIVE entry marks an unused slot (skipped): a caller may launch on more slots than are live
  *       (converged sequences of the coordinate ascent are frozen, slds_svae.py:170-172: the caller lists the
  *       ones still iterating)
  *  out: lognorm (rows) WITHOUT the mixed constants sum_k w[b,0,k] init_logZ_k + sum_t sum_k w[b,t+1,k] logZ_k
@@ -352,7 +353,8 @@ int svae_hmm_estep_f64(int B, int T, int K, int pair_batched,
                        double* logZ, double* E_init, double* E_trans, double* E_states,
                        void* workspace, size_t ws_bytes, void* stream);
 
-/* HMM step of the SLDS coordinate ascent on the rows `seq_index` lists (B of `rows`; NULL: rows 0..B-1):
+/* HMM step of the SLDS coordinate ascent on the rows `seq_index` lists (B of `rows`; NULL: rows 0..B-1; negative
+ * entries = unused slots, which must follow the live ones -- the list svae_slds_sweep_glue_f64 writes):
  *   hmm_meanfield + get_arhmm_local_nodeparams   /root/reference/svae/models/slds_svae.py:108-115, 131-147
  * Node log-potentials: `node_params` (rows,T,K) if given; else built on the fly from the outputs of
  * svae_slds_lds_meanfield_f64 --  node[b,0,k] = <E x_0 x_0', init_J_k> + <E x_0, init_h_k> + cinit_k  (lds_E_init
@@ -370,7 +372,9 @@ int svae_slds_hmm_meanfield_f64(int B, int rows, int T, int K, int n,
 /* End of one sweep of the SLDS coordinate ascent (optimize_local_meanfield, slds_svae.py:159-175), after the HMM and the
  * fused LDS kernels, for the B listed rows:  lds_vlb = lognorm + <E z_0, cinit> + sum_{t>=1} <E z_t, lz>;
  * vlb_new = hmm_vlb + lds_vlb;  iters += 1;  the row keeps iterating unless |vlb_new - vlb| < tol (:170-172);  vlb = vlb_new.
- * next_index (B) / next_count (1): the rows still iterating, in the order of `seq_index` (a different buffer).
+ * next_index (B) / next_count (1): the rows still iterating, in the order of `seq_index` (a different buffer), padded
+ * with -1 up to B: the next sweep may be launched on B slots before the host has read next_count (negative slots are
+ * skipped by the three kernels of a sweep).
  * keep_scratch: B int32.  No host arithmetic is needed between two sweeps (the caller reads next_count to size them). */
 int svae_slds_sweep_glue_f64(int B, int T, int K, double tol, const int32_t* seq_index,
                              const double* E_states, const double* cinit, const double* lz,

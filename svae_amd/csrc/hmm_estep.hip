@@ -89,9 +89,13 @@ __global__ __launch_bounds__(64) void hmm_estep_kernel(const HmmArgs a) {
   const int lane = threadIdx.x;
   const int c = lane & 15;
   const int brow = blockIdx.x * 4 + (lane >> 4);
-  const bool valid = brow < a.B;
-  const int bslot = valid ? brow : a.B - 1;
-  const int b = a.seq_index ? a.seq_index[bslot] : bslot;
+  const int bslot = brow < a.B ? brow : a.B - 1;
+  // (indexed launches: a negative entry marks an unused slot -- the list is compacted, so a wavefront's row 0 is live
+  //  whenever any of its rows is; idle rows repeat it)
+  const int braw = a.seq_index ? a.seq_index[bslot] : bslot;
+  const bool valid = brow < a.B && braw >= 0;
+  if (!__any(valid)) return;
+  const int b = valid ? braw : __shfl(braw, 0);
   const bool col = c < K;
   const int cc = col ? c : 0;
   const int T = a.T;
@@ -330,9 +334,11 @@ __global__ __launch_bounds__(64 * HMM2_WAVES) void hmm_estep2_kernel(const HmmAr
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int c = lane & 15;
   const int brow = blockIdx.x * 4 + (lane >> 4);
-  const bool valid = brow < a.B;
-  const int bslot = valid ? brow : a.B - 1;
-  const int b = a.seq_index ? a.seq_index[bslot] : bslot;
+  const int bslot = brow < a.B ? brow : a.B - 1;
+  const int braw = a.seq_index ? a.seq_index[bslot] : bslot;         // negative: unused slot (see hmm_estep_kernel)
+  const bool valid = brow < a.B && braw >= 0;
+  if (!__any(valid)) return;                                         // (the same rows in every wavefront of the workgroup)
+  const int b = valid ? braw : __shfl(braw, 0);
   const bool col = c < K;
   const int cc = col ? c : 0;
   const int T = a.T;
@@ -601,6 +607,7 @@ __global__ __launch_bounds__(256) void slds_glue_kernel(const SldsGlueArgs a) {
   const int lane = threadIdx.x & 63;
   if (slot >= a.nrun) return;
   const int r = a.seq_index ? a.seq_index[slot] : slot;
+  if (r < 0) { if (lane == 0) a.keep[slot] = 0; return; }            // unused slot
   const double* es = a.E_states + (long)r * a.T * a.K;
   const int K = a.K, TK = a.T * K;
   double acc = 0.0;
@@ -640,7 +647,11 @@ __global__ __launch_bounds__(1024) void slds_compact_kernel(int nrun, const int3
   int pos = part[tid] - cnt;
   for (int i = lo; i < hi; ++i)
     if (keep[i] != 0) out[pos++] = seq_index ? seq_index[i] : i;
-  if (tid == 1023) count[0] = part[1023];
+  // the slots behind the new list are marked unused (-1): a caller may launch the next sweep on `nrun` slots before it
+  // has read the new count (slds_svae.py: the host reads the count one sweep late); the kernels skip negative entries
+  const int total = part[1023];
+  for (int i = total + tid; i < nrun; i += 1024) out[i] = -1;
+  if (tid == 1023) count[0] = total;
 }
 
 // ---- the two dense contractions at the ends of the SLDS coordinate ascent ------------------------------------------------------

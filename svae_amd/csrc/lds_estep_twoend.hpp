@@ -182,10 +182,14 @@ __device__ __forceinline__ void lds_estep_twoend_body(const LdsArgs& a, const in
   const int g = lane >> 4;
   const int dir = g >> 1;                 // 0: chain A (forward in time), 1: chain B (reversed)
   const int gl = g & 1;                   // DPP row within the chain's pair
-  const int nwv = MIX ? (int)(blockDim.x >> 6) : 1;
-  const int bslot = MIX ? blk * nwv + wv : blk;   // one sequence per wavefront
+  // one sequence per wavefront.  MIX: consecutive slots go to DIFFERENT workgroups (slot = wavefront * workgroups +
+  // workgroup): a launch sized for more slots than are live (negative seq_index entries, see below) then leaves one live
+  // wavefront per CU instead of eight sharing a CU's LDS bandwidth
+  const int bslot = MIX ? wv * (int)gridDim.x + blk : blk;
   // MIX: row of every array (and of the workspace) this launch slot works on (surplus slots: any valid row)
-  const int b = !MIX ? bslot : (a.seq_index ? a.seq_index[bslot < a.B ? bslot : 0] : bslot);
+  // (a negative entry of seq_index marks an unused slot: its wavefront helps stage the tables, then leaves)
+  const int braw = !MIX ? bslot : (a.seq_index ? a.seq_index[bslot < a.B ? bslot : 0] : bslot);
+  const int b = braw < 0 ? 0 : braw;
   double* tab = tab_static;               // (MIX keeps the full hand-off record: no transposition tile)
   // re-replication tile of the elimination phase, [chain][row 0..N][16]: S4 borrows the exchange buffer (used at the very
   // end), the other variants the transposition tiles (used by the smoother phase only, zeroed again in between)
@@ -276,7 +280,7 @@ __device__ __forceinline__ void lds_estep_twoend_body(const LdsArgs& a, const in
       ct[q] = make_double2(at(c0), at(c1));
     }
     __syncthreads();
-    if (bslot >= a.B) return;
+    if (bslot >= a.B || braw < 0) return;
   }
 
   // ---- pair parameters in the chain's own orientation ---------------------------------------------

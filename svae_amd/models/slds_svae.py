@@ -306,6 +306,13 @@ def _optimize_local_meanfield_fused(hmm_init, hmm_pair, dense_init, dense_pair, 
     #  HMM kernel runs under the other's LDS kernel.  The fused LDS kernel on half the batch takes 1.0 ms, not 0.75 -- a
     #  round of both halves 2.0 ms against 2.2 -- and in the late sweeps, a handful of sequences per half, every half
     #  waits for the other's latency-bound kernel: 32 ms instead of 26 for the ascent.)
+    # The host learns the length of a sweep's new list ONE SWEEP LATE (an asynchronous 4-byte copy and an event per sweep
+    # instead of a blocking read): sweep i is launched on `nrun` slots = the length known from sweep i - 2, an upper bound
+    # -- the glue kernel pads the compacted list with -1 up to the launch size and every kernel skips negative slots --
+    # so the three launches of consecutive sweeps follow each other without a host round trip (~45 us per sweep).  The
+    # sweep after the last sequence has converged runs on an all-unused list and costs three empty launches.
+    pinned = torch.empty(max_iter + 1, dtype=torch.int32).pin_memory()
+    events = []
     nrun, cur = B, 0
     for it in range(max_iter):
         if nrun == 0:
@@ -323,7 +330,13 @@ def _optimize_local_meanfield_fused(hmm_init, hmm_pair, dense_init, dense_pair, 
                                           p(count), stream)
         _lib.check(rc, "svae_slds_sweep_glue_f64")
         cur = 1 - cur
-        nrun = int(count.item())                    # (the one host read per sweep: sizes the next launches)
+        pinned[it:it + 1].copy_(count, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        events.append(ev)
+        if it >= 1:
+            events[it - 1].synchronize()            # (long complete: the next sweep is already queued behind it)
+            nrun = int(pinned[it - 1])              # list length after sweep it - 1 >= the length sweep it + 1 will find
     return plan, st, lds_vlb, iters.to(torch.int64)
 
 
