@@ -68,6 +68,26 @@ def test_optimize_local_meanfield_matches_oracle(K, n, T, B, fused):
             _close(got[b], want)
 
 
+@pytest.mark.parametrize("max_iter", [1, 2, 3, 5])
+def test_fused_ascent_with_a_sweep_budget_matches_the_materialised_one(max_iter):
+    """The fused ascent queues sweep i + 1 before the host has read the list length after sweep i (slots behind the
+    list are -1 and skipped): stopping at the sweep budget, with sequences still iterating, must leave the same
+    per-sequence sweep counts, bounds and statistics as the materialised loop (one blocking read per sweep)."""
+    from svae_amd.models import slds_svae
+    K, n, T, B = 4, 5, 30, 11
+    rng = np.random.default_rng(max_iter)
+    glob = _globals(K, n, rng)
+    J, h = _nodes(B, T, n, rng)
+    eps = rng.standard_normal((B, T, 1, n))
+    dev = torch.device("cuda:0")
+    node = (torch.as_tensor(J, device=dev), torch.as_tensor(h, device=dev))
+    out = [slds_svae.optimize_local_meanfield(glob, node, eps, fused=f, max_iter=max_iter, tol=1e-6) for f in (True, False)]
+    (sf, _, (hv_f, lv_f), it_f), (sm, _, (hv_m, lv_m), it_m) = out
+    assert torch.equal(it_f.cpu(), it_m.cpu()) and int(it_f.max()) == max_iter
+    assert float((hv_f - hv_m).abs().max()) < 1e-8 and float((lv_f - lv_m).abs().max()) < 1e-7
+    _close(sf[0][2], _np(sm[0][2]))
+
+
 def test_optimize_local_meanfield_at_latent_dim_16():
     """Latent dimension beyond the DPP-row kernels (16 <= n <= 64): the initial sample path comes from the tile
     E-step + sampler (`natural_lds_sample` has no filter-only form there), the ascent from the materialised path."""
