@@ -261,10 +261,13 @@ __device__ __forceinline__ void gmm_stage_table(const GmmArgs& a, double* tab) {
 //          KR table rows (zero rows beyond K) without a branch.
 //   KR = 0 (any K <= 64): the same arithmetic with label_natparam (T,K) as scratch between the K-loops and
 //          label_stats as the state (rin -> label_stats[t]).
-template <int N, int KR>
+struct GmmNoHook { __device__ __forceinline__ void operator()() const {} };
+// (mid: called once in the middle of the point's arithmetic -- the persistent kernel requests its partners' KL partials
+//  there, so that the memory round trip runs under the second half of the sweep)
+template <int N, int KR, class Hook = GmmNoHook>
 __device__ __forceinline__ double gmm_point(const GmmArgs& a, const double* tab, const int t, const double (&nJ)[N],
                                             const double (&nh)[N], double (&r)[KR > 0 ? KR : 1], const double* rin,
-                                            bool final_pass) {
+                                            bool final_pass, Hook&& mid = Hook()) {
   constexpr int D = N + 2, TS = gmm_tab_stride<N>();
   constexpr int KU = KR > 0 ? KR : 1;
   const int K = a.K;
@@ -304,6 +307,7 @@ __device__ __forceinline__ double gmm_point(const GmmArgs& a, const double* tab,
     g.h[i] += nh[i];
   }
   gauss_update<N>(g);
+  mid();
   if (!g.ok) {
     int old = *(volatile int32_t*)a.info;
     while (old == 0 || old > t + 1) {
@@ -443,11 +447,12 @@ struct GmmSweeper {
   // (RES: the caller's compile-time copy of `resident` -- the sweep loops of the kernels that run the whole fixed point
   //  are written out once per case, so that the register allocation of the resident loop is not the union of both: the
   //  merged loop carried 120 register moves per sweep)
-  template <bool RES = false>
-  __device__ __forceinline__ double sweep(bool from_init) {
+  template <bool RES = false, class Hook = GmmNoHook>
+  __device__ __forceinline__ double sweep(bool from_init, Hook&& mid = Hook()) {
     double klpart = 0.0;
     if constexpr (RES) {
-      if (first < a.T) klpart = gmm_point<N, KR>(a, tab, first, nJ, nh, r, nullptr, false);
+      if (first < a.T) klpart = gmm_point<N, KR>(a, tab, first, nJ, nh, r, nullptr, false, mid);
+      else mid();
       return klpart;
     }
     for (int t = first; t < a.T; t += stride) {
@@ -723,13 +728,35 @@ __global__ __launch_bounds__(GMM_MW_BLOCK) void gmm_mw_persistent_kernel(const G
     for (int i = 1;; ++i) {
       const bool more = i < a.max_iter;
       double keep[KR > 0 ? KR : 1], klnext = 0.0;
+      // the partners' partials of exchange i - 1 are REQUESTED in the middle of sweep i (they were published ~1 us
+      // ago: a store needs ~0.9 us to become visible across XCDs) and looked at behind it: the request's own round
+      // trip (~0.35 us) runs under the second half of the sweep; a slot whose tag is still old is polled as before
+      GmmSlot* ex = slots + ((i - 1) & 1) * G;
+      const int myslot = (tid & 63) < G ? (tid & 63) : 0;
+      unsigned long long elo = 0, ehi = 0;
+      auto request = [&]() {
+        elo = __hip_atomic_load(&ex[myslot].lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ehi = __hip_atomic_load(&ex[myslot].hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      };
       if (more) {
 #pragma unroll
         for (int k = 0; k < (KR > 0 ? KR : 1); ++k) keep[k] = sw.r[k];
-        klnext = sw.template sweep<true>(false);
+        klnext = sw.template sweep<true>(false, request);
+      } else {
+        request();
       }
       GMM_TICK(0)
-      const double total = gmm_collect(slots + ((i - 1) & 1) * G, G, (unsigned)i, a.info);
+      double total;
+      {
+        const unsigned tag = (unsigned)i;
+        const bool fresh = (unsigned)(elo >> 32) == tag && (unsigned)(ehi >> 32) == tag;
+        if (G <= 64 && !__any(!fresh)) {
+          const double v = (tid & 63) < G ? __longlong_as_double((long long)((ehi << 32) | (elo & 0xffffffffull))) : 0.0;
+          total = wave_sum64(v);                        // (gmm_collect's arithmetic: lane j holds slot j, ascending butterfly)
+        } else {
+          total = gmm_collect(ex, G, tag, a.info);
+        }
+      }
       GMM_TICK(2)
       if (blockIdx.x == 0 && tid == 0) m.kl_hist[i - 1] = total;
       const bool stop = fabs(total - prev) < a.tol;
