@@ -323,6 +323,11 @@ __global__ __launch_bounds__(64) void hmm_estep_kernel(const HmmArgs a) {
 // the one-directional kernel is launched behind this one with redo_only = 1 and recomputes the flagged wavefronts,
 // log-space steps and all (its wavefronts exit at once otherwise).  Same mapping: one DPP row per sequence, lane = state.
 constexpr int HMM2_D = 8;
+#ifndef SVAE_HMM2_NORM
+#define SVAE_HMM2_NORM 4
+#endif
+constexpr int HMM2_NORM = SVAE_HMM2_NORM;     // renormalise the forward / backward messages every HMM2_NORM-th step (1: every step)
+static_assert(HMM2_D % HMM2_NORM == 0, "ring positions fix the renormalisation steps");
 constexpr int HMM2_WAVES = 4;     // wavefronts per workgroup: all of them share phases 1 and 3, two run the recursions
 template <int K, bool FUSED>
 __global__ __launch_bounds__(64 * HMM2_WAVES) void hmm_estep2_kernel(const HmmArgs a) {
@@ -428,22 +433,28 @@ __global__ __launch_bounds__(64 * HMM2_WAVES) void hmm_estep2_kernel(const HmmAr
     double lzM = 1.0, lzS = 0.0, alpha = 0.0;
     long lzE = 0;
     const double colone = col ? 1.0 : 0.0;
-    auto fstep = [&](int t, double e, double m, auto renorm) {
+    // (the message is renormalised every HMM2_NORM-th step only -- the sum, its reciprocal and the scaling are half of a
+    //  step's dependent chain; phase 3 normalises per step anyway, so any positive scaling of alpha^_t will do.  Between
+    //  two renormalisations the message can shrink by at most (1e-200)^(HMM2_NORM - 1) before the next sum flags the sequence)
+    auto fstep = [&](int t, double e, double m, auto norm, auto renorm) {
       double p0 = 0.0, p1 = 0.0;                        // two accumulators: half the dependent chain
       dpp_fence(alpha);
       static_for<0, K>([&](auto j) { if constexpr (j % 2 == 0) mac_bc<j>(p0, alpha, P[j]); else mac_bc<j>(p1, alpha, P[j]); });
       const double first = t == 0 ? 1.0 : 0.0;          // (alpha starts at 0: pred_0 = 1 in the live lanes)
       const double pred = __builtin_fma(first, colone, p0 + p1);
       double al = pred * e;
-      double c0 = 0.0, c1 = 0.0;
-      dpp_fence(al);
-      static_for<0, K>([&](auto k) { if constexpr (k % 2 == 0) mac_bc<k>(c0, al, one); else mac_bc<k>(c1, al, one); });
-      const double cs = c0 + c1;
-      bad = bad || !(cs > HMM_TINY);
-      alpha = al * rcp_nr(cs);
+      if constexpr (decltype(norm)::value) {
+        double c0 = 0.0, c1 = 0.0;
+        dpp_fence(al);
+        static_for<0, K>([&](auto k) { if constexpr (k % 2 == 0) mac_bc<k>(c0, al, one); else mac_bc<k>(c1, al, one); });
+        const double cs = c0 + c1;
+        bad = bad || !(cs > HMM_TINY);
+        al *= rcp_nr(cs);
+        lzM *= __builtin_amdgcn_frexp_mant(cs);
+        lzE += __builtin_amdgcn_frexp_exp(cs);
+      }
+      alpha = al;
       if (st) wsb[(long)t * HMM_WS + OA] = alpha;
-      lzM *= __builtin_amdgcn_frexp_mant(cs);
-      lzE += __builtin_amdgcn_frexp_exp(cs);
       lzS += m + (t > 0 ? pmax : 0.0);
       if constexpr (decltype(renorm)::value) { lzE += __builtin_amdgcn_frexp_exp(lzM); lzM = __builtin_amdgcn_frexp_mant(lzM); }
     };
@@ -460,26 +471,42 @@ __global__ __launch_bounds__(64 * HMM2_WAVES) void hmm_estep2_kernel(const HmmAr
         const int tn = clampi(t + u + D, 0, T - 1);
         er[u] = wsb[(long)tn * HMM_WS + OE];
         mr[u] = wsr[(long)tn * HMM_WS + OM];
-        fstep(t + u, e, m, std::integral_constant<bool, u == D - 1>{});
+        fstep(t + u, e, m, std::integral_constant<bool, (u % HMM2_NORM) == HMM2_NORM - 1>{}, std::integral_constant<bool, u == D - 1>{});
       });
     }
-    static_for<0, D>([&](auto u) { if (t + u < T) fstep(t + u, er[u], mr[u], std::integral_constant<bool, u == D - 1>{}); });
+    static_for<0, D>([&](auto u) {
+      if (t + u < T) fstep(t + u, er[u], mr[u], std::integral_constant<bool, (u % HMM2_NORM) == HMM2_NORM - 1>{},
+                           std::integral_constant<bool, u == D - 1>{});
+    });
+    {
+      // what the last renormalisation left unscaled
+      double f0 = 0.0, f1 = 0.0;
+      dpp_fence(alpha);
+      static_for<0, K>([&](auto k) { if constexpr (k % 2 == 0) mac_bc<k>(f0, alpha, one); else mac_bc<k>(f1, alpha, one); });
+      const double fs = f0 + f1;
+      bad = bad || !(fs > HMM_TINY);
+      lzM *= __builtin_amdgcn_frexp_mant(fs);
+      lzE += __builtin_amdgcn_frexp_exp(fs);
+    }
     if (valid && c == 0) a.logZ[b] = lzS + ::log(lzM) + (double)lzE * 0.6931471805599453094;
   } else if (wv == 1) {
     // w_{T-1} = e_{T-1} (beta_{T-1} = 1);  t = T-2 .. 1:  beta^_t = P w_{t+1} / sum,  w_t = e_t o beta^_t
     double w = col ? wsb[(long)(T - 1) * HMM_WS + OE] : 0.0;
     if (st) wsb[(long)(T - 1) * HMM_WS + OW] = w;
-    auto bstep = [&](int t, double e) {
+    auto bstep = [&](int t, double e, auto norm) {
       double q0 = 0.0, q1 = 0.0;
       dpp_fence(w);
       static_for<0, K>([&](auto k) { if constexpr (k % 2 == 0) mac_bc<k>(q0, w, PT[k]); else mac_bc<k>(q1, w, PT[k]); });
       double q = q0 + q1;                                 // lane j: sum_k P[j][k] w[k]
-      double d0 = 0.0, d1 = 0.0;
-      dpp_fence(q);
-      static_for<0, K>([&](auto j) { if constexpr (j % 2 == 0) mac_bc<j>(d0, q, one); else mac_bc<j>(d1, q, one); });
-      const double d = d0 + d1;
-      bad = bad || !(d > HMM_TINY);
-      w = e * (q * rcp_nr(d));
+      if constexpr (decltype(norm)::value) {
+        double d0 = 0.0, d1 = 0.0;
+        dpp_fence(q);
+        static_for<0, K>([&](auto j) { if constexpr (j % 2 == 0) mac_bc<j>(d0, q, one); else mac_bc<j>(d1, q, one); });
+        const double d = d0 + d1;
+        bad = bad || !(d > HMM_TINY);
+        q *= rcp_nr(d);
+      }
+      w = e * q;
       if (st) wsb[(long)t * HMM_WS + OW] = w;
     };
     const int nsteps = T - 2 > 0 ? T - 2 : 0;            // step i: t = T-2-i  (t >= 1)
@@ -491,10 +518,12 @@ __global__ __launch_bounds__(64 * HMM2_WAVES) void hmm_estep2_kernel(const HmmAr
         static_for<0, D>([&](auto u) {
           const double e = er[u];
           er[u] = wsb[(long)clampi(T - 2 - (i + u + D), 1, T - 1) * HMM_WS + OE];
-          bstep(T - 2 - (i + u), e);
+          bstep(T - 2 - (i + u), e, std::integral_constant<bool, (u % HMM2_NORM) == HMM2_NORM - 1>{});
         });
       }
-      static_for<0, D>([&](auto u) { if (i + u < nsteps) bstep(T - 2 - (i + u), er[u]); });
+      static_for<0, D>([&](auto u) {
+        if (i + u < nsteps) bstep(T - 2 - (i + u), er[u], std::integral_constant<bool, (u % HMM2_NORM) == HMM2_NORM - 1>{});
+      });
     }
   }
   __syncthreads();
@@ -546,8 +575,14 @@ __global__ __launch_bounds__(64 * HMM2_WAVES) void hmm_estep2_kernel(const HmmAr
       static_for<0, D>([&](auto u) { if (t + u < q1_) cstep(t + u, ar[u], wr[u]); });
     }
     if (q0_ == 0 && q0_ < q1_ && st) a.E_init[(long)b * K + c] = gam0;      // (the wavefront whose range holds step 0)
-    if (wv == NW - 1) {                                   // beta_{T-1} = 1: gamma = alpha^ (sums to one)
-      const double al = wsb[(long)(T - 1) * HMM_WS + OA];
+    if (wv == NW - 1) {                                   // beta_{T-1} = 1: gamma = alpha^ / its sum
+      double al = col ? wsb[(long)(T - 1) * HMM_WS + OA] : 0.0;
+      double f0 = 0.0, f1 = 0.0;
+      dpp_fence(al);
+      static_for<0, K>([&](auto k) { if constexpr (k % 2 == 0) mac_bc<k>(f0, al, one); else mac_bc<k>(f1, al, one); });
+      const double fs = f0 + f1;
+      bad = bad || !(fs > HMM_TINY);
+      al *= rcp_nr(fs);
       if (st) oS[(long)(T - 1) * K] = al;
       if (T == 1 && st) a.E_init[(long)b * K + c] = al;
     }
