@@ -261,18 +261,32 @@ def slds_case(name, K, n, T, B, S, seed):
     print(name, "iters", out["opt_iters"], "vlb", out["opt_hmm_vlb"] + out["opt_lds_vlb"], "local_vlb", lvlb)
 
 
+CASES = [
+    (lds_case, "lds_T5_n3", dict(B=2, T=5, n=3, seed=0)),
+    (lds_case, "lds_T20_n10", dict(B=3, T=20, n=10, seed=1)),
+    (lds_case, "lds_T200_n10", dict(B=2, T=200, n=10, seed=2, with_logZ=False)),
+    (lds_case, "lds_T1_n4", dict(B=2, T=1, n=4, seed=3)),
+    (lds_case, "lds_T2_n15", dict(B=1, T=2, n=15, seed=4)),
+    (lds_case, "lds_T12_n4_inhomog", dict(B=2, T=12, n=4, seed=5, inhomog=True)),
+    (gmm_case, "gmm_K5_N2_T100", dict(K=5, N=2, T=100, seed=0)),
+    (gmm_case, "gmm_K15_N2_T50", dict(K=15, N=2, T=50, seed=1)),
+    (gmm_case, "gmm_K4_N3_T33", dict(K=4, N=3, T=33, seed=2)),
+    # BASELINE configs[0] at its stated size (K = 5, 2-D, 1000 points) and the shipped script's shape
+    # (experiments/gmm_svae_synth.py:29-33: K = 15, 500 points), from the reference's own gmm.py (round 5)
+    (gmm_case, "gmm_K5_N2_T1000", dict(K=5, N=2, T=1000, seed=5)),
+    (gmm_case, "gmm_K15_N2_T500", dict(K=15, N=2, T=500, seed=6)),
+    (gmm_run_case, "gmm_run_K5_N2_T60", dict(K=5, N=2, T=60, S=3, seed=4)),
+    (slds_case, "slds_K3_n4_T12", dict(K=3, n=4, T=12, B=3, S=2, seed=11)),
+    (slds_case, "slds_K8_n10_T40", dict(K=8, n=10, T=40, B=2, S=1, seed=12)),
+]
+
+
 if __name__ == "__main__":
+    # python tests/golden/make_golden.py [case-name ...]   (no names: every fixture, incl. expfam.npz)
     assert build_ref.build(), "reference build failed"
-    lds_case("lds_T5_n3", B=2, T=5, n=3, seed=0)
-    lds_case("lds_T20_n10", B=3, T=20, n=10, seed=1)
-    lds_case("lds_T200_n10", B=2, T=200, n=10, seed=2, with_logZ=False)
-    lds_case("lds_T1_n4", B=2, T=1, n=4, seed=3)
-    lds_case("lds_T2_n15", B=1, T=2, n=15, seed=4)
-    lds_case("lds_T12_n4_inhomog", B=2, T=12, n=4, seed=5, inhomog=True)
-    gmm_case("gmm_K5_N2_T100", K=5, N=2, T=100, seed=0)
-    gmm_case("gmm_K15_N2_T50", K=15, N=2, T=50, seed=1)
-    gmm_case("gmm_K4_N3_T33", K=4, N=3, T=33, seed=2)
-    gmm_run_case("gmm_run_K5_N2_T60", K=5, N=2, T=60, S=3, seed=4)
-    expfam_case()
-    slds_case("slds_K3_n4_T12", K=3, n=4, T=12, B=3, S=2, seed=11)
-    slds_case("slds_K8_n10_T40", K=8, n=10, T=40, B=2, S=1, seed=12)
+    only = set(sys.argv[1:])
+    for fn, name, kw in CASES:
+        if not only or name in only:
+            fn(name, **kw)
+    if not only or "expfam" in only:
+        expfam_case()

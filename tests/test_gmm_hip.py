@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 
 from oracle import expfam_numpy as ef, gmm_numpy  # noqa: E402  (checker only)
 
-GMM_CASES = ["gmm_K5_N2_T100", "gmm_K15_N2_T50", "gmm_K4_N3_T33"]
+GMM_CASES = ["gmm_K5_N2_T100", "gmm_K15_N2_T50", "gmm_K4_N3_T33",
+             "gmm_K5_N2_T1000", "gmm_K15_N2_T500"]    # the last two: BASELINE configs[0] at its stated size, the shipped script's shape
 
 
 def _np(x):

@@ -12,7 +12,8 @@ from oracle import gmm_numpy, lds_numpy, ref
 
 LDS_CASES = ["lds_T5_n3", "lds_T20_n10", "lds_T200_n10", "lds_T1_n4", "lds_T2_n15",
              "lds_T12_n4_inhomog"]
-GMM_CASES = ["gmm_K5_N2_T100", "gmm_K15_N2_T50", "gmm_K4_N3_T33"]
+GMM_CASES = ["gmm_K5_N2_T100", "gmm_K15_N2_T50", "gmm_K4_N3_T33",
+             "gmm_K5_N2_T1000", "gmm_K15_N2_T500"]    # the last two: BASELINE configs[0] at its stated size, the shipped script's shape
 
 
 def _lds_inputs(g, b):

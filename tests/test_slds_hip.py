@@ -13,11 +13,15 @@ def _np(x):
     return x.detach().cpu().numpy()
 
 
-def _close(got, want, tol=1e-6):
+def _err(got, want):
     """relative to max(|want_ij|, 1e-3 max|want|): entries that cancel to ~0 are judged on the array's scale"""
     got, want = _np(got), np.asarray(want, float)
     scale = np.maximum(np.abs(want), 1e-3 * max(np.max(np.abs(want)), 1e-300))
-    err = float(np.max(np.abs(got - want) / scale))
+    return float(np.max(np.abs(got - want) / scale))
+
+
+def _close(got, want, tol=1e-6):
+    err = _err(got, want)
     assert err < tol, err
 
 
@@ -244,7 +248,7 @@ def test_config3_full_size_fused_ascent_against_oracle():
     """BASELINE configs[3] at FULL size (K = 8, latent dim 10, 2048 sequences x T = 500) through the fused LDS
     mean-field kernel: size-independent properties over the whole batch, and parity of the converged mean field
     (iteration counts, HMM marginals, bounds, node statistics) for sequences spread over the batch against the
-    NumPy restatement (1e-5; observed 1e-9 .. 1e-7)."""
+    NumPy restatement (32 sequences at 1e-6, ten times inside north_star's 1e-5; the observed worst is printed)."""
     from svae_amd.models import slds_svae
     K, n, T, B = 8, 10, 500, 2048
     rng = np.random.default_rng(3)
@@ -263,16 +267,23 @@ def test_config3_full_size_fused_ascent_against_oracle():
     assert torch.allclose(Ei, Es[:, 0], atol=1e-12)
     var = lds_stats[2][0] - lds_stats[2][1] ** 2
     assert float(var.min()) > 0 and torch.isfinite(hmm_vlb + lds_vlb).all()
-    for b in (0, 777, 1531, 2047):
-        ref = slds_numpy.optimize_local_meanfield(glob, (J[b], h[b]), eps[b])
-        assert int(iters[b]) == ref["iters"]
-        assert float(hmm_vlb[b]) == pytest.approx(ref["hmm_vlb"], rel=1e-6, abs=1e-6)
-        assert float(lds_vlb[b]) == pytest.approx(ref["lds_vlb"], rel=1e-6, abs=1e-6)
-        _close(Es[b], ref["hmm_stats"][2], 1e-5)
-        for got, want in zip(lds_stats[0], ref["init_stats"]):
-            _close(got[b], want, 1e-5)
-        _close(lds_stats[2][0][b], ref["node_stats"][0], 1e-5)
-        _close(lds_stats[2][1][b], ref["node_stats"][1], 1e-5)
+    # 32 sequences spread over the batch (round 5; rounds 2 - 4: four), the restatement on all host cores
+    # (oracle/ref_batch.py)
+    from oracle import ref_batch
+    picks = sorted(set(np.linspace(0, B - 1, 30).astype(int).tolist()) | {1, B - 2})
+    refs = ref_batch.slds_ascent_select(glob, J, h, eps, picks)
+    worst = 0.0
+    for b in picks:
+        ref = refs[b]
+        assert int(iters[b]) == ref["iters"], b
+        assert float(hmm_vlb[b]) == pytest.approx(ref["hmm_vlb"], rel=1e-8, abs=1e-7)
+        assert float(lds_vlb[b]) == pytest.approx(ref["lds_vlb"], rel=1e-8, abs=1e-7)
+        pairs = [(Es[b], ref["hmm_stats"][2]), (lds_stats[2][0][b], ref["node_stats"][0]),
+                 (lds_stats[2][1][b], ref["node_stats"][1])]
+        pairs += [(got[b], want) for got, want in zip(lds_stats[0], ref["init_stats"])]
+        worst = max(worst, max(_err(got, want) for got, want in pairs))
+    print("configs[3] full size, %d sequences vs the restatement: worst rel err %.2e" % (len(picks), worst))
+    assert worst < 1e-6, worst
 
 
 def test_final_pass_gradient_against_finite_differences():
