@@ -93,9 +93,45 @@ def kernel_name(options, B, T, n):
     return "packed", "svae::lds_estep_kernel<%d,false,false>" % n
 
 
-def measure(dev, rank, world, dist, options, T, n, B, steps, warmup):
+PARITY_TOL = 1e-6        # the gate: bench.py exits non-zero if a timed output is further than this from the reference
+PARITY_SEQUENCES = 8
+
+
+def snapshot_for_parity(plan, natparam, d_J, d_h, count=PARITY_SEQUENCES):
+    """`count` sequences spread over the batch: the global parameters, their node potentials as they sit in HBM and
+    what the timed plan's LAST launch left for them -> dict of NumPy arrays for oracle/bench_parity.py."""
+    init, pair = natparam
+    idx = np.unique(np.linspace(0, plan.B - 1, min(count, plan.B)).astype(int))
+    ix = torch.as_tensor(idx, device=plan.device)
+    g = lambda x: x.index_select(0, ix).cpu().numpy()
+    return dict(index=idx, init_J=np.asarray(init[0], float), init_h=np.asarray(init[1], float),
+                init_logZ=np.asarray(init[2], float), J11=np.asarray(pair[0], float), J12=np.asarray(pair[1], float),
+                J22=np.asarray(pair[2], float), logZ_pair=np.asarray(pair[3], float),
+                node_J=g(d_J), node_h=g(d_h), lognorm=g(plan.lognorm), E_init=g(plan.E_init), E_pair=g(plan.E_pair),
+                E_node_diagxx=g(plan.E_node_diagxx), E_node_x=g(plan.E_node_x))
+
+
+def parity_gate(snapshot, tol=PARITY_TOL):
+    """the timed plan's outputs against the reference's compiled E-step, in a separate
+    process (oracle/bench_parity.py: the checker, never the thing measured) -> {"max_rel", ..., "tol", "ok"}."""
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory(prefix="svae_bench_parity_") as tmp:
+        path = os.path.join(tmp, "snapshot.npz")
+        np.savez(path, **snapshot)
+        r = subprocess.run([sys.executable, "-m", "oracle.bench_parity", path], cwd=ROOT, capture_output=True,
+                           text=True, timeout=600)
+    if r.returncode != 0:
+        raise RuntimeError("oracle.bench_parity failed: " + r.stderr[-400:])
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    out["tol"] = tol
+    out["ok"] = bool(out["max_rel"] < tol)
+    return out
+
+
+def measure(dev, rank, world, dist, options, T, n, B, steps, warmup, parity=0):
     """W untimed + K timed steps of the hot path on B sequences per GPU -> (elapsed s [max over ranks],
-    mean kernel ms from events on the launch stream)."""
+    mean kernel ms from events on the launch stream[, parity snapshot of the timed plan's outputs])."""
     from svae_amd.lds.lds_inference import LDSEStepPlan
     from svae_amd.lds.synthetic_data import rand_node_potentials
     from svae_amd.parallel import allreduce_global_stats
@@ -148,7 +184,31 @@ def measure(dev, rank, world, dist, options, T, n, B, steps, warmup):
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, steps)
+    if parity:
+        return elapsed, kern_ms, snapshot_for_parity(plan, (init, pair), d_J, d_h, parity)
     return elapsed, kern_ms
+
+
+def tile_parity_on_rand_lds(dev, T=1000, n=64, B=2):
+    """Latent dim 64 is TIMED on the well-conditioned rotation model (bench_natparam); this is the parity distance of
+    the same kernels on the reference's own generator `rand_lds` (svae/lds/synthetic_data.py:8-28), whose state noise
+    has cond ~ n^2 -- there the reference's compiled fp64 path is itself 2.5e-6 .. 3e-5 away from extended precision
+    (oracle/lds_longdouble.py; tests/test_lds_tile_hip.py pins kernel-vs-reference <= reference-vs-arbiter + 5e-6)."""
+    from svae_amd.lds.lds_inference import LDSEStepPlan
+    from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials
+    rng = np.random.default_rng(0)
+    init, pair = rand_lds_natparam(n, rng)
+    node_J, node_h = rand_node_potentials((B, T, n), rng)
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev).contiguous()
+    plan = LDSEStepPlan(B, T, n, dev)
+    d_J, d_h = t(node_J), t(node_h)
+    plan.launch(t(init[0]), t(init[1]), t(init[2]).reshape(1), t(pair[0]), t(pair[1]), t(pair[2]), t(pair[3]).reshape(1),
+                d_J, d_h, None)
+    torch.cuda.synchronize()
+    plan.check_info()
+    out = parity_gate(snapshot_for_parity(plan, (init, pair), d_J, d_h, B), tol=1e-5)
+    out["model"] = "rand_lds(n=%d), T=%d, %d sequences (NOT the timed model)" % (n, T, B)
+    return out
 
 
 def bench_natparam(n):
@@ -289,8 +349,9 @@ def measure_slds(dev, B=2048, T=500, n=10, K=8):
             "value": B / best, "unit": "sequences/s", "kernel": "svae::lds_estep_twoend_kernel<10,true,false,true> + svae::hmm_estep2_kernel<8>"}
 
 
-def measure_gmm(dev, K=5, N=2, T=1000):
-    """BASELINE configs[0]: GMM mean-field fixed point, K = 5, 2-D, 1000 points: us per fixed point."""
+def measure_gmm(dev, K=5, N=2, T=1000, what="BASELINE configs[0]"):
+    """GMM mean-field fixed point: us per fixed point.  BASELINE configs[0] says K = 5, 2-D, 1000 points; the script the
+    reference ships (experiments/gmm_svae_synth.py:29-33) runs K = 15 on 500 points -- SURVEY 8d: both, labelled."""
     from svae_amd.distributions import expfam
     from svae_amd.models import gmm
     gen = torch.Generator().manual_seed(K)
@@ -311,7 +372,7 @@ def measure_gmm(dev, K=5, N=2, T=1000):
         o = gmm.meanfield_from_globals(lg, gg, node, init, check=False)
     e1.record(); torch.cuda.synchronize()
     us = 1e3 * e0.elapsed_time(e1) / reps
-    return {"workload": "BASELINE configs[0]: GMM mean-field fixed point, K=%d, %d-D, %d points" % (K, N, T),
+    return {"workload": "%s: GMM mean-field fixed point, K=%d, %d-D, %d points" % (what, K, N, T),
             "us_per_fixed_point": us, "sweeps": int(o["iters"]), "path": o["path"], "value": T / us * 1e6, "unit": "points/s"}
 
 
@@ -482,7 +543,8 @@ def main():
     T, n, B = WORKLOADS[args.workload]
     B = args.seqs_per_gpu or B
 
-    elapsed, kern_ms = measure(dev, rank, world, dist, options, T, n, B, args.steps, args.warmup)
+    elapsed, kern_ms, snap = measure(dev, rank, world, dist, options, T, n, B, args.steps, args.warmup, parity=PARITY_SEQUENCES)
+    parity_failed = False
 
     if rank == 0:
         total_seqs = B * world * args.steps
@@ -501,6 +563,15 @@ def main():
                        "step": "estep kernel + batch stat reduce" + (" + %s all-reduce" % ("IPC mailbox" if os.environ.get("SVAE_BENCH_ALLREDUCE", "") == "mailbox" else ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend())) if world > 1 else "")},
             "roofline": roofline(options, T, n, B, kern_ms),
         }
+        # parity gate: PARITY_SEQUENCES sequences of the batch just timed (rank 0's shard), as the
+        # timed plan left them, against the reference's compiled E-step -- the line carries the distance, and the
+        # process exits non-zero beyond PARITY_TOL
+        try:
+            out["parity"] = parity_gate(snap)
+            parity_failed = not out["parity"]["ok"]
+        except Exception as e:
+            out["parity"] = {"error": repr(e)[:300], "ok": False}
+            parity_failed = True
         if world == 1 and not args.no_extra and args.workload == "lds10" and args.seqs_per_gpu is None:
             # the other single-GPU configurations BASELINE.json names, same measurement, fewer steps
             extra = []
@@ -509,20 +580,31 @@ def main():
                                                (1000, 64, 512, max(3, args.steps // 10),
                                                 "BASELINE configs[4] shape: latent dim 64, T=1000, 512 sequences per GPU")):
                 try:
-                    el, km = measure(dev, 0, 1, None, options, eT, en, eB, esteps, 2)
+                    # (0.16 s per sequence in the reference at n = 64, T = 1000: four of them)
+                    el, km, esnap = measure(dev, 0, 1, None, options, eT, en, eB, esteps, 2,
+                                            parity=PARITY_SEQUENCES if en <= 15 else 4)
                     extra.append({"workload": what, "value": eB * esteps / el, "unit": "sequences/s",
                                   "steps": esteps, "warmup": 2, "ms_per_step": 1e3 * el / esteps,
                                   "roofline": roofline(options, eT, en, eB, km)})
+                    if en > 15:
+                        extra[-1]["model"] = "rotation_lds_natparam (well-conditioned; the timed model)"
+                    extra[-1]["parity"] = parity_gate(esnap)
+                    parity_failed = parity_failed or not extra[-1]["parity"]["ok"]
+                    if en > 15:
+                        extra[-1]["parity_rand_lds"] = tile_parity_on_rand_lds(dev, eT, en)
                 except Exception as e:  # the headline line must survive
                     extra.append({"workload": what, "error": repr(e)})
                 torch.cuda.empty_cache()
             # the other BASELINE configurations and the training path: measured beside `value`, never instead of it
             # (order kept across rounds: [2] training path, [3] tile training, [4] SLDS, [5] GMM, [6] training path at 4096,
-            #  [7] tile training at one workgroup per CU, [8] GMM training step, [9] end-to-end make_gradfun step, eager and as one hipGraph)
+            #  [7] tile training at one workgroup per CU, [8] GMM training step, [9] end-to-end make_gradfun step, eager and as one hipGraph,
+            #  [10] the GMM fixed point at the shipped script's shape K = 15 / 500 points)
             for fn in (lambda: measure_training_path(dev, T, n, B), lambda: measure_tile_training(dev),
                        lambda: measure_slds(dev), lambda: measure_gmm(dev),
                        lambda: measure_training_path(dev, T, n, 4096), lambda: measure_tile_training(dev, B=256),
-                       lambda: measure_gmm_training(dev), lambda: measure_gradfun_step(dev)):
+                       lambda: measure_gmm_training(dev), lambda: measure_gradfun_step(dev),
+                       lambda: measure_gmm(dev, K=15, T=500, what="the reference's shipped script shape "
+                                                                   "(experiments/gmm_svae_synth.py:29-33)")):
                 try:
                     extra.append(fn())
                 except Exception as e:
@@ -542,6 +624,8 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+    if parity_failed:
+        raise SystemExit("bench.py: parity gate failed (see \"parity\" in the line above)")
 
 
 if __name__ == "__main__":
