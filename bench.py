@@ -442,13 +442,13 @@ def measure_gradfun_step(dev, B=512, T=200, n=10, p=20, hidden=32, reps=9):
     data = torch.randn(B, T, p, dtype=torch.float64, device=dev, generator=gen)
     prior = tuple(x.to(dev) if isinstance(x, torch.Tensor) else tuple(y.to(dev) for y in x) for x in lds.make_prior_natparam(n))
     pgm = tuple(x.clone() if isinstance(x, torch.Tensor) else tuple(y.clone() for y in x) for x in prior)
-    mlp = lambda sizes: [(0.3 * torch.randn(a, b, dtype=torch.float64, device=dev, generator=gen) / np.sqrt(a)).requires_grad_(True)
-                         for a, b in zip(sizes[:-1], sizes[1:])]
 
     # (svae_amd.nnet.linear: x @ w whose weight gradient avoids rocBLAS's fp64 path for a 10^5-row reduction axis, 11 ms
     #  per layer at this shape; the networks themselves are stock torch, out of the library's scope)
-    from svae_amd.nnet import gaussian_info, tanh_mlp
-    recogn, decoder = (mlp([p, hidden, n]), mlp([p, hidden, n])), mlp([n, hidden, p])
+    #  The layer form is the reference's: nonlin(x W + b) stacks (nnet.py:23), the recognition network ONE MLP whose
+    #  2 n outputs are split into (J_input, h) (nnet.py:43-47).
+    from svae_amd.nnet import gaussian_info, init_mlp, tanh_mlp
+    recogn, decoder = init_mlp([p, hidden, 2 * n], device=dev, generator=gen), init_mlp([n, hidden, p], device=dev, generator=gen)
     recognize = gaussian_info
     loglike = lambda params, samples, batch: -0.5 * ((batch.unsqueeze(2) - tanh_mlp(params, samples)) ** 2).sum() / samples.shape[2]
     plan = LDSEStepPlan(B, T, n, dev)
@@ -464,7 +464,7 @@ def measure_gradfun_step(dev, B=512, T=200, n=10, p=20, hidden=32, reps=9):
         t0 = time.perf_counter(); gradfun(params, 0); torch.cuda.synchronize()
         times.append((time.perf_counter() - t0) * 1e3)
     eager = sorted(times)[len(times) // 2]
-    out = {"workload": "end-to-end LDS-SVAE training step through make_gradfun: recognition MLPs + global step + E-step + "
+    out = {"workload": "end-to-end LDS-SVAE training step through make_gradfun: recognition MLP (layers with biases, one network split into (J, h) as svae/nnet.py) + global step + E-step + "
                        "sampler + decoder + backward (VJP kernels) + natural gradient, %d sequences x T=%d, n=%d, obs dim %d"
                        % (B, T, n, p),
            "eager_ms_per_step": eager, "graph_ms_per_step": None, "graph_error": None,

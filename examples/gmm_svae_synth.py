@@ -20,7 +20,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from svae_amd import svae                                   # noqa: E402
 from svae_amd.models import gmm                             # noqa: E402
-from svae_amd.nnet import gaussian_info, tanh_mlp           # noqa: E402
+from svae_amd.nnet import gaussian_info_two_heads as gaussian_info, tanh_mlp           # noqa: E402
 
 
 def pinwheel(radial_std, tangential_std, num_classes, num_per_class, rate, rng):

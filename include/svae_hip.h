@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SVAE_HIP_ABI_VERSION 11   /* 11: + svae_lds_global_step_multi_f64 (K parameter sets in one launch: the SLDS global -> local maps), svae_lds_diag_sample_f64 (filter + sampler of an all-diagonal LDS: the SLDS initial path); 10: + svae_ipc_allreduce_f64 / svae_ipc_mailbox_bytes, svae_gmm_sample_f64, svae_gmm_local_vjp_f64, svae_gmm_global_step_f64 (the differentiable tail and the global side of the GMM local step); 9: keep bit SVAE_KEEP_SIGMA of svae_lds_estep_f64 (16 <= n <= 64) + svae_lds_tile_sigma_offset_bytes; 8: step ranges (t_begin, t_end) in svae_lds_tile_vjp_f64 / svae_lds_tile_noise_f64, SVAE_OPT_TILE_FORWARD / _BACKWARD; 7: + svae_slds_path_nodeparams_f64, svae_slds_mix_pair_natparam_f64; 6: per-call `options` word replaces the process-global svae_lds_set_* selectors (re-entrant library), + svae_slds_hmm_meanfield_f64, svae_slds_sweep_glue_f64, g_E_pair in svae_lds_tile_vjp_f64; 5: + svae_lds_set_prod_max_b; 4: + svae_slds_lds_meanfield_f64, svae_gmm_mw_*, svae_lds_global_step_f64, svae_lds_natgrad_f64, svae_lds_tile_vjp_f64; 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
+#define SVAE_HIP_ABI_VERSION 12   /* 12: svae_gmm_global_step_f64 writes kl[0..1] (as spelled | as shipped), svae_ipc_allreduce_f64 takes the mailbox stride and never writes `out` on a timeout, + svae_slds_lds_meanfield options; 11: + svae_lds_global_step_multi_f64 (K parameter sets in one launch: the SLDS global -> local maps), svae_lds_diag_sample_f64 (filter + sampler of an all-diagonal LDS: the SLDS initial path); 10: + svae_ipc_allreduce_f64 / svae_ipc_mailbox_bytes, svae_gmm_sample_f64, svae_gmm_local_vjp_f64, svae_gmm_global_step_f64 (the differentiable tail and the global side of the GMM local step); 9: keep bit SVAE_KEEP_SIGMA of svae_lds_estep_f64 (16 <= n <= 64) + svae_lds_tile_sigma_offset_bytes; 8: step ranges (t_begin, t_end) in svae_lds_tile_vjp_f64 / svae_lds_tile_noise_f64, SVAE_OPT_TILE_FORWARD / _BACKWARD; 7: + svae_slds_path_nodeparams_f64, svae_slds_mix_pair_natparam_f64; 6: per-call `options` word replaces the process-global svae_lds_set_* selectors (re-entrant library), + svae_slds_hmm_meanfield_f64, svae_slds_sweep_glue_f64, g_E_pair in svae_lds_tile_vjp_f64; 5: + svae_lds_set_prod_max_b; 4: + svae_slds_lds_meanfield_f64, svae_gmm_mw_*, svae_lds_global_step_f64, svae_lds_natgrad_f64, svae_lds_tile_vjp_f64; 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
 #define SVAE_LDS_MAX_N 15   /* register/DPP path: one 16-lane row per sequence, n+1 <= 16 */
 #define SVAE_LDS_TILE_MAX_N 64   /* 16 <= n <= 64: LDS-tiled MFMA path (keep: SVAE_KEEP_SIGMA or 0) */
 #define SVAE_KEEP_SIGMA 4         /* keep bit of svae_lds_estep_f64, 16 <= n <= 64 only: see svae_lds_tile_sigma_offset_bytes */
@@ -481,8 +481,10 @@ int svae_gmm_mw_fixed_point_f64(int T, int N, int K,
  * One point per lane, N <= 8, K <= 64; device pointers, asynchronous on `stream`.  0 / -k (argument k).
  *   svae_gmm_global_step_f64  the global side of a step in ONE launch: label_global (K) = dirichlet.expectedstats
  *                           (dirichlet.py:5-7), gaussian_globals (K,N+2,N+2) = niw.expectedstats (niw.py:15-25) -- the two
- *                           potentials svae_gmm_meanfield_f64 / svae_gmm_mw_* take -- and, if `kl` is given, the prior KL
- *                           of gmm.py:54-58 as the code spells it (full contraction; dirichlet.logZ, niw.logZ).  *info is
+ *                           potentials svae_gmm_meanfield_f64 / svae_gmm_mw_* take -- and, if `kl` (TWO doubles, ABI 12) is
+ *                           given, the prior KL of gmm.py:54-58: kl[0] as the code spells it (full contraction;
+ *                           dirichlet.logZ, niw.logZ), kl[1] as the reference AS SHIPPED evaluates it (util.py:39 `flat`
+ *                           after util.py:166 rebinds `flatten`: the contraction keeps its first term only).  *info is
  *                           raised to 1 on a non-positive-definite NIW scale matrix. */
 int svae_gmm_global_step_f64(int K, int N, const double* dirichlet_natparam, const double* niw_natparam,
                              const double* prior_dirichlet, const double* prior_niw,
@@ -499,13 +501,17 @@ int svae_gmm_local_vjp_f64(int T, int N, int K, int S, const double* label_globa
 /* ---- one-shot all-reduce of a small buffer over IPC-mapped mailboxes (csrc/ipc_allreduce.hip) -----------------------
  * The exchange step (/root/reference/svae/svae.py:33-34: the batch-summed statistics) as ONE kernel: every rank stores
  * its n doubles, as tagged 8-byte words, into slot `rank` of EVERY rank's mailbox (fine-grained device memory of
- * svae_ipc_mailbox_bytes(n, world) bytes, zero-initialised once, IPC-mapped into every peer: mailboxes[q] = rank q's
- * mailbox as mapped into this process), then sums the words that arrived in its own mailbox in rank order -> out (may
- * alias in).  epoch: 1, 2, 3, .. per call, the same on every rank.  Bit-identical results on every rank; *info = -78 on
- * a timeout (a peer never published).  world <= 16.  Opt-in alternative to the RCCL all-reduce (svae_amd/ipc.py). */
-size_t svae_ipc_mailbox_bytes(int n, int world);
-int svae_ipc_allreduce_f64(int n, int rank, int world, unsigned epoch, const double* in, double* out,
-                           void* const* mailboxes, int32_t* info, void* stream);
+ * svae_ipc_mailbox_bytes(capacity, world) bytes, zero-initialised once, IPC-mapped into every peer: mailboxes[q] = rank
+ * q's mailbox as mapped into this process), then sums the words that arrived in its own mailbox in rank order -> out
+ * (may alias in).  `capacity` (doubles) fixes the mailbox layout for its lifetime -- the same on every rank and in every
+ * call; a call may reduce any n <= capacity, and consecutive calls may differ in n (ABI 12).  epoch: 1, 2, 3, .. per
+ * call, the same on every rank.  Bit-identical results on every rank.  spin_limit: polls per word before a peer counts
+ * as absent (0 = 2^28, minutes); an element whose words never arrive comes out as NaN and *info = -78 -- a timeout never
+ * passes for a sum.  world <= 16.  Opt-in alternative to the RCCL all-reduce (svae_amd/ipc.py).
+ * Returns 0 / -k (argument k). */
+size_t svae_ipc_mailbox_bytes(int capacity, int world);
+int svae_ipc_allreduce_f64(int n, int capacity, int rank, int world, unsigned epoch, unsigned spin_limit,
+                           const double* in, double* out, void* const* mailboxes, int32_t* info, void* stream);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,8 @@ them in tests/test_oracle.py.
 `cython_init_logZ`: the reference's compiled filter reads init_params[2] only
 (cython_lds_inference.pyx:32), so with the SLDS's 4-tuple init potential (J, h, a, b) the term
 b = 1/2 E log|J| never enters lds_vlb AS SHIPPED; the reference's Python twin sums the tail
-(lds_inference.py:62-63).  True reproduces the shipped value, False (default) the Python twin's.
+(lds_inference.py:62-63).  True (default since round 5: the reference AS SHIPPED) reproduces the shipped value,
+False the Python twin's.
 """
 import numpy as np
 
@@ -50,7 +51,7 @@ def get_arhmm_local_nodeparams(inits, pairs, init_stats, pair_stats):
     return node
 
 
-def lds_meanfield(inits, pairs, node_potentials, expected_states, cython_init_logZ=False):
+def lds_meanfield(inits, pairs, node_potentials, expected_states, cython_init_logZ=True):
     """slds_svae.py:80-84 -> (vlb, init_stats, pair_stats, node_stats, natparam)."""
     natparam = get_var_lds_local_natparam(inits, pairs, expected_states)
     est = (natparam[0][:3], natparam[1]) if cython_init_logZ else natparam
@@ -72,7 +73,7 @@ def initialize_local_meanfield(node_potentials, eps):
 
 
 def optimize_local_meanfield(global_natparam, node_potentials, init_eps, tol=1e-2, max_iter=100,
-                             cython_init_logZ=False):
+                             cython_init_logZ=True):
     """slds_svae.py:159-175."""
     (dir_nat, mdir_nat), lds_global = global_natparam
     hmm_init, hmm_pair = ef.dirichlet_expectedstats(dir_nat), ef.dirichlet_expectedstats(mdir_nat)

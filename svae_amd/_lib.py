@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must precede CDLL: shares torch's HIP runtime)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVAE_AMD_LIB", os.path.join(_HERE, "libsvae_hip.so"))  # env: experiments only
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 LDS_MAX_N = 15        # register/DPP path (E-step, sampler, VJP)
 LDS_TILE_MAX_N = 64   # LDS-tiled MFMA path (E-step only)
 
@@ -88,7 +88,7 @@ SIGNATURES = {
                              + [_c_int_p] * 3 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "svae_gmm_mw_kl_hist": (ctypes.c_void_p, [ctypes.c_void_p]),
     "svae_ipc_mailbox_bytes": (ctypes.c_size_t, [ctypes.c_int] * 2),
-    "svae_ipc_allreduce_f64": (ctypes.c_int, [ctypes.c_int] * 3 + [ctypes.c_uint] + [_c_double_p] * 2
+    "svae_ipc_allreduce_f64": (ctypes.c_int, [ctypes.c_int] * 4 + [ctypes.c_uint] * 2 + [_c_double_p] * 2
                                + [ctypes.c_void_p, _c_int_p, ctypes.c_void_p]),
     "svae_gmm_global_step_f64": (ctypes.c_int, [ctypes.c_int] * 2 + [_c_double_p] * 7 + [_c_int_p, ctypes.c_void_p]),
     "svae_gmm_sample_f64": (ctypes.c_int, [ctypes.c_int] * 3 + [_c_double_p] * 3 + [ctypes.c_void_p]),

@@ -432,8 +432,14 @@ __global__ __launch_bounds__(64) void gmm_global_step_kernel(int K, const double
   const double palpha = prior_dir[kk] + 1.0;
   const double psum = gmm_wave_sum(on ? palpha : 0.0);
   const double lz = (lgamma(alpha) - lgamma(palpha)) + (niw_logZ_one<N>(q) - niw_logZ_one<N>(pq));
-  const double total = gmm_wave_sum(on ? contr - lz : 0.0) + (lgamma(asum) - lgamma(psum));
-  if (k == 0) kl[0] = total;
+  const double mlz = gmm_wave_sum(on ? -lz : 0.0) + (lgamma(asum) - lgamma(psum));   // -(logZ(q) - logZ(p))
+  const double total = gmm_wave_sum(on ? contr : 0.0) + mlz;
+  if (k == 0) {
+    kl[0] = total;
+    // kl[1]: the value the reference AS SHIPPED returns -- gmm.py:55-56 flattens with util.py:39 `flat`, which
+    // (util.py:166 rebinds `flatten`) keeps the FIRST scalar of the nested structure: the contraction is its first term
+    kl[1] = (dir_nat[0] - prior_dir[0]) * es_dir + mlz;
+  }
   const bool pbad = __ballot(on && !pq.ok) != 0;
   if (pbad && k == 0) atomicMax(info, 1);
 }

@@ -4,6 +4,12 @@ latency-minimal alternative to the RCCL all-reduce of svae_amd/parallel.py for t
 
     ar = MailboxAllReduce(n_doubles, group)      # once: fine-grained mailbox, IPC handles exchanged through `group`
     ar(packed)                                   # in place, asynchronous on the current stream; every rank gets the same bits
+    ar.check()                                   # (also every `check_every` calls) raises if a peer never published
+
+`n_doubles` is the mailbox CAPACITY: it fixes the mailbox layout for its lifetime; a call may reduce any shorter
+buffer, and consecutive calls may differ in length.  A peer that does not show up within the spin limit (minutes by
+default) does not pass for a sum: the elements come out as NaN, the status word is raised, and the next check -- the
+caller's, or the automatic one every `check_every` calls -- raises.
 
 One process per GPU of ONE node (or several processes on one GPU: the tests).  The mailbox is fine-grained device
 memory (hipExtMallocWithFlags: remote stores must be visible to the owner's polling loads while its kernel runs, which
@@ -26,11 +32,25 @@ class _IpcHandle(ctypes.Structure):          # hipIpcMemHandle_t: 64 opaque byte
     _fields_ = [("reserved", ctypes.c_char * 64)]
 
 
+def _runtime_path():
+    """path of the libamdhip64 this process has ALREADY mapped (torch's): loading by a versioned soname would fail on
+    another ROCm release and could map a second runtime next to torch's"""
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.rsplit(None, 1)[-1]
+                if "libamdhip64.so" in path:
+                    return path
+    except OSError:
+        pass
+    return "libamdhip64.so"
+
+
 def _runtime():
     """the HIP runtime torch already mapped (one runtime per process)"""
     global _hip
     if _hip is None:
-        _hip = ctypes.CDLL("libamdhip64.so.7")
+        _hip = ctypes.CDLL(_runtime_path())
         _hip.hipExtMallocWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_uint]
         _hip.hipIpcGetMemHandle.argtypes = [ctypes.POINTER(_IpcHandle), ctypes.c_void_p]
         _hip.hipIpcOpenMemHandle.argtypes = [ctypes.POINTER(ctypes.c_void_p), _IpcHandle, ctypes.c_uint]
@@ -46,7 +66,7 @@ def _check(rc, what):
 
 
 class MailboxAllReduce(object):
-    def __init__(self, n_doubles, group=None, device=None):
+    def __init__(self, n_doubles, group=None, device=None, spin_limit=0, check_every=64):
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("MailboxAllReduce needs an initialised torch.distributed process group")
         self.group = group
@@ -84,6 +104,8 @@ class MailboxAllReduce(object):
         self._boxes = (ctypes.c_void_p * self.world)(*ptrs)
         self.info = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.epoch = 0
+        self.spin_limit = int(spin_limit)         # polls per word before a peer counts as absent (0: the library's 2^28)
+        self.check_every = int(check_every)       # every so many calls the status word is read (one host sync); 0: never
 
     def __call__(self, packed):
         """in-place sum over the ranks of `packed` (float64, contiguous, <= n doubles), on the current stream"""
@@ -92,17 +114,21 @@ class MailboxAllReduce(object):
         self.epoch += 1
         if self.epoch >= 1 << 31:
             raise OverflowError("mailbox all-reduce: epoch counter exhausted")
-        rc = self.lib.svae_ipc_allreduce_f64(self.n if packed.numel() == self.n else packed.numel(), self.rank, self.world,
-                                             self.epoch, _lib.ptr(packed), _lib.ptr(packed),
+        # (the mailbox is laid out with its CAPACITY self.n whatever the length of this call: see csrc/ipc_allreduce.hip)
+        rc = self.lib.svae_ipc_allreduce_f64(packed.numel(), self.n, self.rank, self.world, self.epoch, self.spin_limit,
+                                             _lib.ptr(packed), _lib.ptr(packed),
                                              ctypes.cast(self._boxes, ctypes.c_void_p), _lib.ptr(self.info),
                                              _lib.current_stream(self.device))
         _lib.check(rc, "svae_ipc_allreduce_f64")
+        if self.check_every and self.epoch % self.check_every == 0:
+            self.check()
         return packed
 
     def check(self):
         """host synchronisation: raises if a call timed out waiting for a peer"""
-        if int(self.info.item()) != 0:
-            raise RuntimeError("mailbox all-reduce: a peer never published (info %d)" % int(self.info.item()))
+        v = int(self.info.item())
+        if v != 0:
+            raise RuntimeError("mailbox all-reduce: a peer never published (info %d); the affected elements are NaN" % v)
 
     def close(self):
         hip = _runtime()

@@ -190,12 +190,13 @@ def check_info(info=None):
                                  "Gaussian factor" % (v - 1))
 
 
-def global_step(global_natparam, prior_natparam=None, info=None):
+def global_step(global_natparam, prior_natparam=None, info=None, reference_compat=True):
     """The global side of a step in ONE launch (svae_gmm_global_step_f64): (label_global (K), gaussian_globals
     (K,N+2,N+2)) = (dirichlet.expectedstats, niw.expectedstats) of gmm.py:67-68 and, with `prior_natparam`, the prior KL
-    of gmm.py:54-58 (the full contraction the code spells; the reference's shipped first-element value stays in
-    `prior_kl(..., reference_compat=True)`).  -> (label_global, gaussian_globals, kl | None).  `info`: (1,) int32 status
-    word, raised to 1 on an invalid NIW scale matrix (kept as global_step.last_info, never read here)."""
+    of gmm.py:54-58 -- `reference_compat=True` (default): the value the reference AS SHIPPED returns (its `flat`,
+    util.py:39 after util.py:166, keeps the first scalar: the contraction is its first term); False: the full
+    contraction the code spells.  The kernel writes both.  -> (label_global, gaussian_globals, kl | None).  `info`:
+    (1,) int32 status word, raised to 1 on an invalid NIW scale matrix (kept as global_step.last_info, never read here)."""
     dev = torch.device("cuda", torch.cuda.current_device())
     for x in global_natparam:
         if isinstance(x, torch.Tensor) and x.is_cuda:
@@ -209,14 +210,14 @@ def global_step(global_natparam, prior_natparam=None, info=None):
     kl, pd, pn = None, None, None
     if prior_natparam is not None:
         pd, pn = _dev64(prior_natparam[0], dev), _dev64(prior_natparam[1], dev)
-        kl = torch.empty(1, **f64)
+        kl = torch.empty(2, **f64)
     if info is None:
         info = torch.zeros(1, dtype=torch.int32, device=dev)
     global_step.last_info = info
     p = _lib.ptr
     _lib.check(_lib.load().svae_gmm_global_step_f64(K, N, p(dn), p(nn_), p(pd), p(pn), p(lg), p(gg), p(kl), p(info),
                                                     _lib.current_stream(dev)), "svae_gmm_global_step_f64")
-    return lg, gg, (kl[0] if kl is not None else None)
+    return lg, gg, (kl[1 if reference_compat else 0] if kl is not None else None)
 
 
 def local_meanfield(global_natparam, node_potentials, label_init=None, tol=1e-3, max_iter=100,
@@ -242,11 +243,11 @@ def local_meanfield(global_natparam, node_potentials, label_init=None, tol=1e-3,
     return local_stats, prior_stats, natparam, o["kl"][0]
 
 
-def prior_kl(global_natparam, prior_natparam, reference_compat=False):
+def prior_kl(global_natparam, prior_natparam, reference_compat=True):
     """gmm.py:54-58: KL(q(theta) || p(theta)) of the Dirichlet x NIW^K global factors.
 
-    Default: the full contraction <eta_q - eta_p, E_q[t(theta)]> - (logZ(q) - logZ(p)) the code spells.
-    `reference_compat=True` returns what the reference AS SHIPPED computes: svae/util.py:169 rebinds
+    `reference_compat=False`: the full contraction <eta_q - eta_p, E_q[t(theta)]> - (logZ(q) - logZ(p)) the code spells.
+    `reference_compat=True` (the default since round 5) returns what the reference AS SHIPPED computes: svae/util.py:169 rebinds
     `flatten`, so `flat` (util.py:42) keeps only the FIRST scalar of each nested structure and the
     contraction reduces to its first element (checked against the reference run in memory,
     tests/golden/gmm_run_K5_N2_T60.npz `global_kl`)."""
@@ -278,7 +279,7 @@ def _allreduce_stats_and_kl(stats, local_kl, group):
 
 
 def run_inference(prior_natparam, global_natparam, nn_potentials, num_samples, label_init=None,
-                  eps=None, generator=None, group=None, reference_compat=False, check=True):
+                  eps=None, generator=None, group=None, reference_compat=True, check=True):
     """gmm.py:12-16 -> (samples (T,S,N), (dirichlet_stats, niw_stats), global_kl, local_kl).  Under
     torch.distributed the points are this rank's shard; statistics and local_kl are summed over ranks.
     check=False: no host synchronisation (hipGraph capture, asynchronous pipelines) -- the fixed point's status word
@@ -287,9 +288,8 @@ def run_inference(prior_natparam, global_natparam, nn_potentials, num_samples, l
     for x in (global_natparam[1], nn_potentials[0]):
         if isinstance(x, torch.Tensor) and x.is_cuda:
             dev = x.device
-    label_global, gaussian_globals, global_kl = global_step(global_natparam, None if reference_compat else prior_natparam)
-    if reference_compat:
-        global_kl = prior_kl(global_natparam, prior_natparam, True)
+    label_global, gaussian_globals, global_kl = global_step(global_natparam, prior_natparam,
+                                                            reference_compat=reference_compat)
     Tn = nn_potentials[1].shape[0]
     if label_init is None:
         label_init = initialize_meanfield(Tn, label_global.shape[0], dev, generator)
@@ -352,7 +352,7 @@ class _LocalTail(torch.autograd.Function):
 
 def run_inference_differentiable(prior_natparam, global_natparam, nn_potentials, num_samples,
                                  label_init=None, eps=None, generator=None, group=None,
-                                 reference_compat=False, check=True):
+                                 reference_compat=True, check=True):
     """run_inference (gmm.py:12-16) with gradients w.r.t. nn_potentials flowing into `samples` and
     `local_kl`, exactly the two quantities the reference differentiates (svae.py:21-24); statistics
     are returned detached (`unbox(stats)`, gmm.py:16).  Kernel launches only: fixed point + final pass, sampler,
@@ -360,9 +360,7 @@ def run_inference_differentiable(prior_natparam, global_natparam, nn_potentials,
     (the whole step then captures into ONE hipGraph: bench.py extra[8])."""
     dev = nn_potentials[1].device
     g = [_dev64(x, dev) for x in global_natparam]
-    label_global, gaussian_globals, global_kl = global_step(g, None if reference_compat else prior_natparam)
-    if reference_compat:
-        global_kl = prior_kl(global_natparam, prior_natparam, True)
+    label_global, gaussian_globals, global_kl = global_step(g, prior_natparam, reference_compat=reference_compat)
     nJ, nh = nn_potentials[0].to(torch.float64), nn_potentials[1].to(torch.float64)
     T, N = nh.shape
     if label_init is None:

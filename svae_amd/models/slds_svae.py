@@ -18,8 +18,8 @@ are torch ops on the device.
 `reference_compat`: the reference's COMPILED filter reads init_params[2] only
 (cython_lds_inference.pyx:32), so the 4th entry of the SLDS's init potential (b = 1/2 E log|J|, mixed
 over E[z_0]) is missing from lds_vlb / local_vlb as shipped, while its Python twin sums the tail
-(lds_inference.py:62-63).  Default False = the Python twin (the bound that is actually a bound);
-True reproduces the shipped compiled path bit for bit in that term (it also moves the stopping test).
+(lds_inference.py:62-63).  Default True (since round 5) = the reference AS SHIPPED: the compiled path, bit for bit
+in that term (it also moves the stopping test); False = the Python twin (the value that is actually a bound).
 Batched: node potentials (B,T,n); every sequence runs its own coordinate ascent and stops on its own
 |delta vlb| < tol like the reference (converged sequences are frozen).
 """
@@ -31,6 +31,22 @@ from ..parallel import allreduce_nested
 from ..hmm.hmm_inference import hmm_estep, hmm_logZ_differentiable
 from ..lds.lds_inference import (LDSEStepPlan, lds_inference_differentiable, natural_lds_estep_general,
                                      natural_lds_sample)
+
+
+_STATUS = {}     # name -> (1,) int32 device status word of the LAST call of each device path (read by check_info only)
+
+
+def check_info():
+    """Synchronising check of the status words the SLDS device paths leave on the device -- the global -> local maps
+    (a non-positive-definite NIW / MNIW scale), the diagonal initial sample path (a non-positive precision) and the
+    fused LDS mean-field kernel (a non-positive pivot) -- like gmm.check_info(): the ascent itself never reads them
+    (no host synchronisation on the hot path; the reference ignores LAPACK `info` altogether,
+    cython_gaussian_grads.pxd:54-76).  Raises FloatingPointError naming the path."""
+    for name, word in list(_STATUS.items()):
+        v = int(word.item())
+        if v != 0:
+            word.zero_()
+            raise FloatingPointError("SLDS %s: status word %d (parameters / potentials not positive definite)" % (name, v))
 
 
 def _dev64(x, device):
@@ -93,6 +109,7 @@ def _global_to_local_maps_device(global_natparam, device):
                 None, p(info), _lib.current_stream(device))
             _lib.check(rc, "svae_lds_global_step_f64")
     global_to_local_maps.last_info = info
+    _STATUS["global -> local maps"] = info
     dense_init = (esb[:, :n, :n].contiguous(), esb[:, :n, n].contiguous(), esb[:, n, n].contiguous(),
                   esb[:, n + 1, n + 1].contiguous())
     dense_pair = (J11, J12, J22, lzp)
@@ -238,7 +255,7 @@ class SLDSMeanfieldPlan(object):
         nt = pc[:, :-1, 0] + pc[:, 1:, 1] + dense_pair[3]
         return torch.cat([n0[:, None], nt], 1)
 
-    def lds_vlb(self, dense_init, dense_pair, weights, reference_compat=False):
+    def lds_vlb(self, dense_init, dense_pair, weights, reference_compat=True):
         """log-normaliser of the mixed LDS = kernel part + the mixed constants."""
         const0 = dense_init[2] if reference_compat else dense_init[2] + dense_init[3]
         return self.lognorm + weights[:, 0] @ const0 + (weights[:, 1:] @ dense_pair[3]).sum(1)
@@ -269,7 +286,7 @@ def _arhmm_nodeparams_from_path(dense_init, dense_pair, x):
 
 
 def _optimize_local_meanfield_fused(hmm_init, hmm_pair, dense_init, dense_pair, node, init_eps, tol, max_iter,
-                                    reference_compat=False):
+                                    reference_compat=True):
     """The coordinate ascent of optimize_local_meanfield on the fused kernels.  Same iteration as the materialised path
     (and the reference): hmm_meanfield -> lds_meanfield -> |delta vlb| < tol per sequence.  A sweep is three launches on
     the list of sequences still iterating -- the HMM kernel (node potentials built on the fly from the previous LDS
@@ -314,6 +331,8 @@ def _optimize_local_meanfield_fused(hmm_init, hmm_pair, dense_init, dense_pair, 
     pinned = torch.empty(max_iter + 1, dtype=torch.int32).pin_memory()
     events = []
     nrun, cur = B, 0
+    _STATUS["fused LDS mean field"] = plan.info
+    ts = torch.cuda.current_stream(dev)          # the stream the kernels are launched on (dev need not be the current device)
     for it in range(max_iter):
         if nrun == 0:
             break
@@ -330,9 +349,10 @@ def _optimize_local_meanfield_fused(hmm_init, hmm_pair, dense_init, dense_pair, 
                                           p(count), stream)
         _lib.check(rc, "svae_slds_sweep_glue_f64")
         cur = 1 - cur
-        pinned[it:it + 1].copy_(count, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
+        with torch.cuda.stream(ts):
+            pinned[it:it + 1].copy_(count, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(ts)
         events.append(ev)
         if it >= 1:
             events[it - 1].synchronize()            # (long complete: the next sweep is already queued behind it)
@@ -380,6 +400,7 @@ def _initial_sample_path(node_potentials, eps):
                                           p(info), p(ws), wsb, _lib.current_stream(dev))
         _lib.check(rc, "svae_lds_diag_sample_f64")
         _initial_sample_path.last_info = info
+        _STATUS["initial sample path"] = info
         return out
     natparam = _random_walk_natparam(n, dev)
     x = natural_lds_sample(natparam, node_potentials, num_samples=1, eps=eps)     # filter + sampler, no smoother (:222)
@@ -387,7 +408,7 @@ def _initial_sample_path(node_potentials, eps):
 
 
 def optimize_local_meanfield(global_natparam, node_potentials, init_eps, tol=1e-2, max_iter=100, fused=None,
-                             pair_stats=True, reference_compat=False):
+                             pair_stats=True, reference_compat=True):
     """(:159-175).  Returns ((hmm_stats, lds_stats), (hmm_natparam, lds_natparam), (hmm_vlb, lds_vlb), iters).
 
     fused=None picks the fused LDS mean-field kernel (SLDSMeanfieldPlan) when it covers the shape, else the
@@ -485,7 +506,7 @@ def optimize_local_meanfield_withlabels(global_natparam, node_potentials, labels
     return (hmm_stats, lds_stats), (None, (lds_init, lds_pair)), (torch.zeros_like(lds_vlb), lds_vlb.clone())
 
 
-def _lds_estep_batched_init(plan, lds_init, lds_pair, node, keep_factor=False, reference_compat=False):
+def _lds_estep_batched_init(plan, lds_init, lds_pair, node, keep_factor=False, reference_compat=True):
     """LDS E-step with a PER-SEQUENCE init potential (the SLDS mixes K init potentials by E[z_0]):
     run the kernel with a zero shared init potential and add each sequence's (J0, h0) to its first
     node potential's dense block... the kernel's node potentials are diagonal, so instead the init
@@ -538,7 +559,7 @@ def global_stats_as_natparam(stats):
 
 
 def run_inference(prior_natparam, global_natparam, nn_potentials, num_samples, init_eps=None, eps=None,
-                  generator=None, tol=1e-2, group=None, reference_compat=False):
+                  generator=None, tol=1e-2, group=None, reference_compat=True):
     """(:289-310) -> (samples (B,T,S,n), expected_stats, global_vlb, local_vlb); forward values only
     (see run_inference_differentiable).  Under torch.distributed the sequences are this rank's shard (every
     sequence runs its own coordinate ascent: no collective inside it); the statistics and local_vlb are summed
@@ -587,7 +608,7 @@ def slds_prior_vlb(global_natparam, prior_natparam, dev):
 
 
 def final_pass_differentiable(global_natparam, hmm_natparam, lds_natparam, nn_potentials, eps,
-                              reference_compat=False):
+                              reference_compat=True):
     """The part of run_inference that depends on nn_potentials with gradients attached
     (slds_svae.py:295-307, "recompute terms that depend on nn_potentials at optimum"): the LDS
     E-step + sampler on the FIXED mean-field natural parameters, the HMM bound evaluated on its
@@ -617,7 +638,7 @@ def final_pass_differentiable(global_natparam, hmm_natparam, lds_natparam, nn_po
 
 
 def run_inference_differentiable(prior_natparam, global_natparam, nn_potentials, num_samples, init_eps=None,
-                                 eps=None, generator=None, tol=1e-2, group=None, reference_compat=False):
+                                 eps=None, generator=None, tol=1e-2, group=None, reference_compat=True):
     """run_inference (slds_svae.py:289-310) with torch autograd attached to nn_potentials = (J, h),
     each (B,T,n): the local mean field is optimised on detached values (the reference's `unbox`),
     then the final pass is differentiated through the E-step / sampler VJP kernels and the HMM

@@ -18,8 +18,9 @@ _mailbox = {}      # group -> svae_amd.ipc.MailboxAllReduce (opt-in, use_mailbox
 def use_mailbox_allreduce(n_doubles, group=None):
     """Opt in: route allreduce_global_stats on `group` through the one-shot IPC mailbox kernel (svae_amd/ipc.py: one
     launch, one xGMI hop, rank-order sum fused in) for buffers of up to `n_doubles` float64 CUDA elements; larger or
-    non-CUDA buffers keep the collective backend.  One node only.  Returns the MailboxAllReduce (its .check() reports a
-    peer that never published).  Validated with several processes on ONE device (tests/test_distributed_hip.py); RCCL
+    non-CUDA buffers keep the collective backend.  One node only.  Returns the MailboxAllReduce: a peer that never
+    publishes within the spin limit turns the affected elements into NaN (never a plausible-looking sum) and raises
+    the status word, which .check() -- called automatically every `check_every` calls -- reports.  Validated with several processes on ONE device (tests/test_distributed_hip.py); RCCL
     stays the default until a multi-GPU run has measured both."""
     from .ipc import MailboxAllReduce
     ar = MailboxAllReduce(n_doubles, group)

@@ -190,8 +190,10 @@ def test_round4_entry_points_reject_bad_arguments():
     assert lib.svae_gmm_local_vjp_f64(4, 2, 5, 1, one, one, one, one, one, one, None, None, one, one, one, None) == -12  # sample cotangents without eps
     assert lib.svae_gmm_local_vjp_f64(4, 2, 5, 1, one, one, one, one, one, one, None, None, None, None, one, None) == -14
     assert lib.svae_ipc_mailbox_bytes(415, 8) == 2 * 8 * 2 * 415 * 8 and lib.svae_ipc_mailbox_bytes(415, 17) == 0
-    assert lib.svae_ipc_allreduce_f64(0, 0, 2, 1, one, one, one, one, None) == -1
-    assert lib.svae_ipc_allreduce_f64(4, 2, 2, 1, one, one, one, one, None) == -2
-    assert lib.svae_ipc_allreduce_f64(4, 0, 17, 1, one, one, one, one, None) == -3
-    assert lib.svae_ipc_allreduce_f64(4, 0, 2, 0, one, one, one, one, None) == -4
-    assert lib.svae_ipc_allreduce_f64(4, 0, 2, 1, one, one, None, one, None) == -7
+    # (n, capacity, rank, world, epoch, spin_limit, in, out, mailboxes, info, stream)
+    assert lib.svae_ipc_allreduce_f64(0, 4, 0, 2, 1, 0, one, one, one, one, None) == -1
+    assert lib.svae_ipc_allreduce_f64(5, 4, 0, 2, 1, 0, one, one, one, one, None) == -2      # n beyond the mailbox capacity
+    assert lib.svae_ipc_allreduce_f64(4, 4, 2, 2, 1, 0, one, one, one, one, None) == -3
+    assert lib.svae_ipc_allreduce_f64(4, 4, 0, 17, 1, 0, one, one, one, one, None) == -4
+    assert lib.svae_ipc_allreduce_f64(4, 4, 0, 2, 0, 0, one, one, one, one, None) == -5
+    assert lib.svae_ipc_allreduce_f64(4, 4, 0, 2, 1, 0, one, one, None, one, None) == -9

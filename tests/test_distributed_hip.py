@@ -241,7 +241,42 @@ def _ipc_worker(rank, world, port, q, n, rounds):
         y = torch.full((7,), float(rank + 1), dtype=torch.float64, device=dev)
         ar(y)
         ar.check()
-        q.put((rank, worst, same, y.cpu().tolist()))
+        # calls of ALTERNATING lengths back to back, no host collective in between, one rank held back before every
+        # call in turn: a rank runs a call ahead of a peer that has not read the previous one yet (round 4 laid the
+        # parity sets out with the call's length: they overlapped).  Inputs are a function of (call, rank), so every rank
+        # knows the exact rank-order sum.
+        import time
+        lengths = [7, n, 33, max(1, n // 2), n, 1]
+        mk = lambda it, r, L: torch.randn(L, dtype=torch.float64, generator=torch.Generator().manual_seed(7919 * it + r))
+        outs = []
+        for it in range(36):
+            L = lengths[it % len(lengths)]
+            if it % world == rank:
+                time.sleep(0.003)
+            outs.append(ar(mk(it, rank, L).to(dev)))
+        torch.cuda.synchronize()
+        ar.check()
+        alt_ok = True
+        for it, got in enumerate(outs):
+            want = torch.zeros(got.numel(), dtype=torch.float64)
+            for r in range(world):
+                want = want + mk(it, r, got.numel())
+            alt_ok = alt_ok and torch.equal(got.cpu(), want)
+        # a peer that never shows up: NaN, not a plausible sum, and the status word says so
+        dist.barrier()
+        timed_out = None
+        if rank == 0:
+            ar.spin_limit = 3000
+            z = ar(torch.ones(5, dtype=torch.float64, device=dev))
+            torch.cuda.synchronize()
+            try:
+                ar.check()
+                raised = False
+            except RuntimeError:
+                raised = True
+            timed_out = bool(torch.isnan(z).all()) and raised
+        dist.barrier()
+        q.put((rank, worst, same, y.cpu().tolist(), alt_ok, timed_out))
         ar.close()
     finally:
         dist.destroy_process_group()
@@ -254,7 +289,8 @@ def test_mailbox_allreduce_between_processes_on_one_gpu(world):
     1030) over fine-grained, IPC-mapped mailboxes: `world` processes share the one MI355X of the test box -- the IPC
     mapping, the tagged-word protocol with its parity double-buffering (ranks deliberately skewed) and the rank-order sum
     are what is under test; xGMI is not.  Against gloo's all-reduce on the host: equal to rounding, and the SAME bits on
-    every rank."""
+    every rank; then calls of alternating lengths under rank skew (bit-exact rank-order sums), and a call a peer never
+    joins (NaN + status word, never a plausible sum)."""
     import torch.multiprocessing as mp
     for n, rounds in ((415, 60), (1030, 12)):
         ctx = mp.get_context("spawn")
@@ -277,7 +313,9 @@ def test_mailbox_allreduce_between_processes_on_one_gpu(world):
         for p_ in procs:
             p_.join(timeout=60)
             assert p_.exitcode == 0
-        for rank, worst, same, y in res:
+        for rank, worst, same, y, alt_ok, timed_out in res:
             assert worst < 1e-15 * world, (rank, worst)
             assert same
             assert y == [float(world * (world + 1) // 2)] * 7
+            assert alt_ok, "alternating lengths under rank skew: wrong sum on rank %d" % rank
+            assert timed_out in (None, True), "a missing peer must give NaN and a raised status word"

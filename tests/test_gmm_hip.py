@@ -140,11 +140,15 @@ def test_global_step_kernel_against_the_torch_maps(K, N):
     gen = torch.Generator().manual_seed(10 * K + N)
     prior = tuple(x.to("cuda:0") for x in gmm.init_pgm_param(K, N, alpha=0.7, niw_conc=1.5, generator=gen))
     glob = tuple(x.to("cuda:0") for x in gmm.init_pgm_param(K, N, alpha=1.3, niw_conc=3.0, random_scale=2.0, generator=gen))
-    lg, gg, kl = gmm.global_step(glob, prior)
+    lg, gg, kl = gmm.global_step(glob, prior, reference_compat=False)
     np.testing.assert_allclose(_np(lg), _np(expfam.dirichlet_expectedstats(glob[0])), rtol=1e-11, atol=1e-12)
     np.testing.assert_allclose(_np(gg), _np(expfam.niw_expectedstats(glob[1])), rtol=1e-10, atol=1e-12)
-    want = float(gmm.prior_kl(glob, prior))
+    want = float(gmm.prior_kl(glob, prior, reference_compat=False))
     assert float(kl) == pytest.approx(want, rel=1e-9, abs=1e-9)
+    # the value the reference AS SHIPPED returns (first term of the contraction): the default of both entry points
+    _, _, kl_shipped = gmm.global_step(glob, prior)
+    assert float(kl_shipped) == pytest.approx(float(gmm.prior_kl(glob, prior)), rel=1e-9, abs=1e-9)
+    assert float(kl_shipped) == pytest.approx(float(gmm.prior_kl(glob, prior, reference_compat=True)), rel=1e-9, abs=1e-9)
     assert int(gmm.global_step.last_info.item()) == 0
     bad = glob[1].clone()
     bad[0, :N, :N] = -bad[0, :N, :N]

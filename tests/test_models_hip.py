@@ -22,29 +22,32 @@ def _rel(a, b):
     return float(np.max(np.abs(a - b) / scale))
 
 
-def test_gmm_run_inference_golden(golden_dir):
+@pytest.mark.parametrize("reference_compat", [None, True, False])
+def test_gmm_run_inference_golden(golden_dir, reference_compat):
+    """gmm.run_inference against the reference's own run (tests/golden/gmm_run_K5_N2_T60.npz), under both settings of
+    `reference_compat` and with the default (None: nothing passed), which since round 5 is the reference AS SHIPPED."""
     from svae_amd.models.gmm import run_inference
     g = np.load(os.path.join(golden_dir, "gmm_run_K5_N2_T60.npz"))
     prior, glob = (g["prior_dir"], g["prior_niw"]), (g["glob_dir"], g["glob_niw"])
+    kw = {} if reference_compat is None else dict(reference_compat=reference_compat)
     samples, (ds, ns), global_kl, local_kl = run_inference(
         prior, glob, (g["node_J"], g["node_h"]), g["eps"].shape[1], label_init=g["label_init"],
-        eps=g["eps"])
+        eps=g["eps"], **kw)
     np.testing.assert_allclose(_np(samples), g["samples"], rtol=1e-9, atol=1e-10)
     np.testing.assert_allclose(_np(ds), g["dirichlet_stats"], rtol=1e-10)
     np.testing.assert_allclose(_np(ns), g["niw_stats"], rtol=1e-9, atol=1e-10)
     assert float(local_kl) == pytest.approx(float(g["local_kl"]), rel=1e-10)
-    # global KL: the mathematically intended full contraction (oracle).  The reference AS SHIPPED
-    # returns something else: svae/util.py:169 rebinds `flatten`, so `flat` (util.py:42) yields only
-    # the first scalar and gmm.prior_kl (gmm.py:54-58) contracts one element; documented, not copied.
-    assert float(global_kl) == pytest.approx(models_numpy.gmm_prior_kl(glob, prior), rel=1e-10)
+    # global KL.  The reference AS SHIPPED: svae/util.py:169 rebinds `flatten`, so `flat` (util.py:42) yields only
+    # the first scalar and gmm.prior_kl (gmm.py:54-58) contracts one element -- what the golden holds and what the
+    # default returns; reference_compat=False: the full contraction the code spells (oracle).
     es0 = ef.dirichlet_expectedstats(glob[0])[0]
     logZ = lambda q: ef.dirichlet_logZ(q[0]) + ef.niw_logZ(q[1])
     shipped = (glob[0][0] - prior[0][0]) * es0 - (logZ(glob) - logZ(prior))
     assert shipped == pytest.approx(float(g["global_kl"]), rel=1e-12)
-    # ... and the compat switch reproduces the reference as shipped
-    _, _, kl_compat, _ = run_inference(prior, glob, (g["node_J"], g["node_h"]), g["eps"].shape[1],
-                                       label_init=g["label_init"], eps=g["eps"], reference_compat=True)
-    assert float(kl_compat) == pytest.approx(float(g["global_kl"]), rel=1e-10)
+    if reference_compat is False:
+        assert float(global_kl) == pytest.approx(models_numpy.gmm_prior_kl(glob, prior), rel=1e-10)
+    else:
+        assert float(global_kl) == pytest.approx(float(g["global_kl"]), rel=1e-10)
 
 
 def _lds_globals(n, rng, scale=1.0):

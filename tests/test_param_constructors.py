@@ -60,7 +60,7 @@ def test_slds_global_natparam_constructors():
 def test_nnet_linear_matches_plain_matmul_and_its_gradients():
     """svae_amd.nnet.linear = x @ w; its blocked weight gradient equals autograd's (CPU, float64)."""
     import torch
-    from svae_amd.nnet import gaussian_info, linear
+    from svae_amd.nnet import gaussian_info, gaussian_info_two_heads, init_mlp, linear, tanh_mlp
     gen = torch.Generator().manual_seed(0)
     x = torch.randn(3, 301, 5, dtype=torch.float64, generator=gen, requires_grad=True)     # 903 rows: 3 blocks + a tail
     w = torch.randn(5, 4, dtype=torch.float64, generator=gen, requires_grad=True)
@@ -68,5 +68,13 @@ def test_nnet_linear_matches_plain_matmul_and_its_gradients():
     gx, gw = torch.autograd.grad((linear(x, w) * g).sum(), [x, w])
     hx, hw = torch.autograd.grad(((x @ w) * g).sum(), [x, w])
     assert torch.allclose(gx, hx, rtol=1e-13, atol=1e-13) and torch.allclose(gw, hw, rtol=1e-12, atol=1e-12)
-    J, h = gaussian_info(([w], [w]), x)
+    J, h = gaussian_info_two_heads(([w], [w]), x)
     assert bool((J <= 0).all()) and J.shape == h.shape == (3, 301, 4)
+    # the reference's form (nnet.py:23, 43-47): layers nonlin(x W + b), ONE network split into (J_input, h)
+    layers = init_mlp([5, 7, 8], generator=gen)
+    J, h = gaussian_info(layers, x)
+    (W1, b1), (W2, b2) = layers
+    out = torch.tanh(x @ W1 + b1) @ W2 + b2
+    assert torch.allclose(J, -0.5 * torch.log1p(torch.exp(out[..., :4])), rtol=1e-13, atol=1e-14)
+    assert torch.allclose(h, out[..., 4:], rtol=1e-13, atol=1e-14) and torch.allclose(tanh_mlp(layers, x), out)
+    assert all(g is not None for g in torch.autograd.grad((J.sum() + (h * h).sum()), [W1, b1, W2, b2]))

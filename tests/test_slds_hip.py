@@ -47,9 +47,12 @@ def _nodes(B, T, n, rng):
     return J, h
 
 
+@pytest.mark.parametrize("compat", [True, False])
 @pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("K,n,T,B", [(3, 2, 12, 3), (4, 5, 30, 6), (2, 10, 16, 2), (5, 9, 7, 9), (1, 3, 5, 2)])
-def test_optimize_local_meanfield_matches_oracle(K, n, T, B, fused):
+def test_optimize_local_meanfield_matches_oracle(K, n, T, B, fused, compat):
+    """compat = True: the reference as shipped (its compiled filter drops the init potential's 4th entry; the default
+    of both the library and the restatement since round 5); False: the convention of the reference's Python twin."""
     from svae_amd.models import slds_svae
     rng = np.random.default_rng(100 * K + n)
     glob = _globals(K, n, rng)
@@ -57,10 +60,10 @@ def test_optimize_local_meanfield_matches_oracle(K, n, T, B, fused):
     eps = rng.standard_normal((B, T, 1, n))
     dev = torch.device("cuda:0")
     node = (torch.as_tensor(J, device=dev), torch.as_tensor(h, device=dev))
-    (hmm_stats, lds_stats), _, (hmm_vlb, lds_vlb), iters = slds_svae.optimize_local_meanfield(glob, node, eps,
-                                                                                             fused=fused)
+    (hmm_stats, lds_stats), _, (hmm_vlb, lds_vlb), iters = slds_svae.optimize_local_meanfield(
+        glob, node, eps, fused=fused, reference_compat=compat)
     for b in range(B):
-        ref = slds_numpy.optimize_local_meanfield(glob, (J[b], h[b]), eps[b])
+        ref = slds_numpy.optimize_local_meanfield(glob, (J[b], h[b]), eps[b], cython_init_logZ=compat)
         assert int(iters[b]) == ref["iters"]
         assert float(hmm_vlb[b]) == pytest.approx(ref["hmm_vlb"], rel=1e-7, abs=1e-7)
         assert float(lds_vlb[b]) == pytest.approx(ref["lds_vlb"], rel=1e-7, abs=1e-7)
@@ -422,8 +425,8 @@ def test_optimize_local_meanfield_against_reference_golden(case, fused, golden_d
     """The whole coordinate ascent (HMM kernel <-> LDS kernel; fused = svae_slds_lds_meanfield_f64) against the
     reference's own optimize_local_meanfield run (slds_svae.py:159-175 on its compiled kernels): the same
     number of sweeps per sequence, the same statistics, the same bounds (reference_compat: the compiled filter
-    drops the init potential's 4th entry, cython_lds_inference.pyx:32); and the default convention differs from
-    it by exactly that term."""
+    drops the init potential's 4th entry, cython_lds_inference.pyx:32 -- the library's default); and the Python twin's
+    convention (reference_compat=False) differs from it by exactly that term."""
     from svae_amd.models import slds_svae
     import _slds_golden as G
     g = G.load(golden_dir, case)
@@ -432,7 +435,7 @@ def test_optimize_local_meanfield_against_reference_golden(case, fused, golden_d
     node = (_t(g["node_J"], dev), _t(g["node_h"], dev))
     B = node[0].shape[0]
     (hmm_stats, lds_stats), (hmm_nat, _), (hmm_vlb, lds_vlb), iters = slds_svae.optimize_local_meanfield(
-        glob, node, g["opt_init_eps"], fused=fused, reference_compat=True)
+        glob, node, g["opt_init_eps"], fused=fused)       # the default IS the reference as shipped (round 5)
     assert [int(i) for i in iters] == [int(i) for i in g["opt_iters"]]
     assert G.rel(_np(hmm_vlb), g["opt_hmm_vlb"]) < 1e-7 and G.rel(_np(lds_vlb), g["opt_lds_vlb"]) < 1e-7
     worst = 0.
@@ -444,7 +447,8 @@ def test_optimize_local_meanfield_against_reference_golden(case, fused, golden_d
         worst = max(worst, e)
         assert e < 1e-6, (key, e)
     print("SLDS ascent vs reference golden (%s, fused=%s): worst rel err %.2e" % (case, fused, worst))
-    _, _, (_, lds_vlb2), iters2 = slds_svae.optimize_local_meanfield(glob, node, g["opt_init_eps"], fused=fused)
+    _, _, (_, lds_vlb2), iters2 = slds_svae.optimize_local_meanfield(glob, node, g["opt_init_eps"], fused=fused,
+                                                                     reference_compat=False)
     same = (iters2 == iters).cpu().numpy()
     d = _np(lds_vlb2) - (g["opt_lds_vlb"] + g["opt_init_b"])
     assert np.all(np.abs(d[same]) < 1e-6 * np.abs(g["opt_lds_vlb"][same]))
@@ -462,8 +466,7 @@ def test_run_inference_against_reference_golden(case, golden_dir):
     node = (_t(g["node_J"][:1], dev), _t(g["node_h"][:1], dev))
     S = g["run_eps"].shape[1]
     samples, (hmm_g, (g_init, g_pair)), global_vlb, local_vlb = slds_svae.run_inference(
-        prior, glob, node, S, init_eps=g["run_init_eps"][None], eps=_t(g["run_eps"][None], dev),
-        reference_compat=True)
+        prior, glob, node, S, init_eps=g["run_init_eps"][None], eps=_t(g["run_eps"][None], dev))   # default: as shipped
     assert G.rel(_np(samples[0]), g["run_samples"]) < 1e-6
     assert abs(float(global_vlb) - float(g["run_global_vlb"])) < 1e-8 * abs(float(g["run_global_vlb"]))
     assert abs(float(local_vlb) - float(g["run_local_vlb"])) < 1e-7 * abs(float(g["run_local_vlb"]))
@@ -521,3 +524,26 @@ def test_initial_sample_path_diagonal_kernel_equals_the_dense_filter_and_sampler
     assert tuple(got.shape) == (B, T, n)
     assert float((got - want).abs().max() / want.abs().max()) < 1e-12
     assert int(slds_svae._initial_sample_path.last_info.item()) == 0
+
+
+def test_check_info_reports_invalid_global_parameters_and_stays_silent_otherwise():
+    """The device paths of the ascent leave their status words on the device; slds_svae.check_info() is the one host
+    read that reports them (round 5: they used to sit in function attributes nothing read)."""
+    from svae_amd.models import slds_svae
+    K, n, T, B = 3, 4, 9, 2
+    rng = np.random.default_rng(5)
+    glob = _globals(K, n, rng)
+    J, h = _nodes(B, T, n, rng)
+    dev = torch.device("cuda:0")
+    node = (torch.as_tensor(J, device=dev), torch.as_tensor(h, device=dev))
+    eps = rng.standard_normal((B, T, 1, n))
+    slds_svae.optimize_local_meanfield(glob, node, eps, fused=True)
+    slds_svae.check_info()                                            # valid parameters: nothing to report
+    (hmm_g, lds) = glob
+    niw_bad = np.array(lds[1][0], copy=True)
+    niw_bad[:n, :n] = -niw_bad[:n, :n]                                # NIW scale matrix no longer positive definite
+    bad = (hmm_g, [lds[0], (niw_bad, lds[1][1])] + list(lds[2:]))
+    slds_svae.global_to_local_maps(bad, dev)
+    with pytest.raises(FloatingPointError, match="global -> local maps"):
+        slds_svae.check_info()
+    slds_svae.check_info()                                            # the word is cleared once reported

@@ -26,6 +26,7 @@ def test_gmm_differentiable_path_equals_kernel_path(golden_dir):
     np.testing.assert_allclose(_np(samples), g["samples"], rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(_np(ns), g["niw_stats"], rtol=1e-8, atol=1e-10)
     assert float(local_kl) == pytest.approx(float(g["local_kl"]), rel=1e-9)
+    assert float(global_kl) == pytest.approx(float(g["global_kl"]), rel=1e-10)     # the default = the reference as shipped
     (local_kl + samples.sum()).backward()
     assert torch.isfinite(nJ.grad).all() and torch.isfinite(nh.grad).all() and float(nh.grad.abs().sum()) > 0
 
