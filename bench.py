@@ -232,7 +232,12 @@ def roofline(options, T, n, B, kern_ms):
     prof = os.path.join(ROOT, "profiles", tag, "pmc_hbm.json") if tag else None
     if prof and os.path.isfile(prof) and (T, n) in ((200, 10), (1000, 64)):
         p = json.load(open(prof))
-        if all(k.replace(" ", "") in p.get("kernel", "").replace(" ", "") for k in kernel.split(" + ")):
+        if p.get("csrc_sha16") != _lib.source_hash():
+            # the counters were collected on other kernel sources than the ones timed here: not quoted (round 5)
+            traffic_src = "%s is STALE (collected on csrc %s, this build is %s): not quoted" % (
+                os.path.relpath(prof, ROOT), p.get("csrc_sha16"), _lib.source_hash())
+            p = {}
+        elif all(k.replace(" ", "") in p.get("kernel", "").replace(" ", "") for k in kernel.split(" + ")):
             traffic, traffic_src = p["hbm_bytes_per_launch_corrected"], os.path.relpath(prof, ROOT)
     bytes_launch = B * algorithmic_bytes_per_seq(T, n)
     achieved = bytes_launch / (kern_ms * 1e-3) / 1e9
@@ -249,7 +254,8 @@ def roofline(options, T, n, B, kern_ms):
             "issued_over_algorithmic": (valu_insts * 128.0 / flops_launch) if valu_insts else None}
     hbm = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-           "traffic_unit": "bytes per launch (rocprofv3 PMC, 2*FETCH_SIZE+WRITE_SIZE)",
+           "traffic_unit": "bytes per launch (rocprofv3 PMC, 2*FETCH_SIZE+WRITE_SIZE; separate passes of this same "
+                           "command, quoted only if the profile's source hash equals this build's)",
            "traffic_source": traffic_src,
            "traffic_over_algorithmic": (traffic / bytes_launch) if traffic else None,
            "kernel": kernel, "kernel_ms": kern_ms,
@@ -562,6 +568,7 @@ def main():
                        "parallelism": "dp%d" % world, "collective_backend": (dist.get_backend() if world > 1 else None),
                        "step": "estep kernel + batch stat reduce" + (" + %s all-reduce" % ("IPC mailbox" if os.environ.get("SVAE_BENCH_ALLREDUCE", "") == "mailbox" else ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend())) if world > 1 else "")},
             "roofline": roofline(options, T, n, B, kern_ms),
+            "csrc_sha16": _lib.source_hash(),
         }
         # parity gate: PARITY_SEQUENCES sequences of the batch just timed (rank 0's shard), as the
         # timed plan left them, against the reference's compiled E-step -- the line carries the distance, and the

@@ -9,6 +9,7 @@ TAG=${1:-r1}; shift || true
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
+(cd $REPO && python -c "from svae_amd import _lib; print(_lib.source_hash())") > $OUT/csrc_sha16.txt   # what was profiled
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 20 --warmup 3 --no-cpu-baseline --no-extra $*"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python $REPO/bench.py $ARGS > $OUT/trace.log 2>&1

@@ -133,3 +133,20 @@ def ptr(t):
 
 def current_stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def source_hash():
+    """First 16 hex digits of the SHA-256 over the library's sources (svae_amd/csrc/*.hip, *.hpp, the Makefile and
+    include/svae_hip.h, in name order): what bench.py compares with the hash stored in a committed rocprofv3 PMC
+    summary before quoting its traffic figures -- a kernel change without a re-profile must not quote stale counters."""
+    import glob
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "csrc", "*.hip")) + glob.glob(os.path.join(here, "csrc", "*.hpp")))
+    files += [os.path.join(here, "csrc", "Makefile"), os.path.join(os.path.dirname(here), "include", "svae_hip.h")]
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]

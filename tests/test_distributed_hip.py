@@ -319,3 +319,63 @@ def test_mailbox_allreduce_between_processes_on_one_gpu(world):
             assert y == [float(world * (world + 1) // 2)] * 7
             assert alt_ok, "alternating lengths under rank skew: wrong sum on rank %d" % rank
             assert timed_out in (None, True), "a missing peer must give NaN and a raised status word"
+
+
+# ---- RCCL on the device path, single rank (the only RCCL configuration a 1-GPU box can run) ------------------------------
+
+def _rccl_single_rank_worker(port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        from svae_amd.lds.lds_inference import LDSEStepPlan
+        from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials
+        from svae_amd.parallel import allreduce_global_stats, allreduce_lds_stats
+        B, T, n = 37, 20, 10
+        rng = np.random.default_rng(0)
+        init, pair = rand_lds_natparam(n, rng)
+        nJ, nh = rand_node_potentials((B, T, n), rng)
+        t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev).contiguous()
+        plan = LDSEStepPlan(B, T, n, dev)
+        plan.launch(t(init[0]), t(init[1]), t(init[2]).reshape(1), t(pair[0]), t(pair[1]), t(pair[2]), t(pair[3]).reshape(1),
+                    t(nJ), t(nh), None)
+        reduced = plan.reduce().clone()
+        # the product's exchange step with the product's backend: dist.all_reduce on the packed DEVICE buffer through RCCL
+        # (world size 1: the sum is the identity -- what is exercised is the backend's device path, launch and stream
+        # ordering behind the library's kernels, not a reduction)
+        packed = reduced.clone()
+        assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+        out = dist.all_reduce(packed)                      # the collective itself, directly (allreduce_global_stats
+        torch.cuda.synchronize()                           #  short-circuits at world size 1)
+        same = bool(torch.equal(packed, reduced))
+        allreduce_global_stats(packed)
+        lkl = torch.tensor(3.25, dtype=torch.float64, device=dev)
+        niw_stats, mniw_stats, kl = allreduce_lds_stats(reduced, lkl, n, T)
+        ok = same and float(kl) == 3.25 and bool(torch.equal(mniw_stats[1], reduced[n * n + n + n * n:n * n + n + 2 * n * n].reshape(n, n)))
+        q.put(("ok" if ok else "mismatch", dist.get_backend()))
+    except Exception as e:          # pragma: no cover
+        q.put(("error: %r" % (e,), None))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_rccl_allreduce_of_the_packed_statistics_single_rank_on_the_device():
+    """`dist.all_reduce` of the packed statistics buffer through RCCL (backend "nccl") on the GPU, one rank: the
+    configuration of the product's collective that a one-GPU box can execute (tools/rccl_single_rank_check.py promoted
+    into the suite; RCCL refuses two ranks on one device, so the multi-rank GPU tests above use gloo)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p_ = ctx.Process(target=_rccl_single_rank_worker, args=(_free_port(), q))
+    p_.start()
+    try:
+        status, backend = q.get(timeout=240)
+    finally:
+        p_.join(timeout=60)
+        if p_.is_alive():
+            p_.kill()
+    assert status == "ok" and backend == "nccl", status
