@@ -164,7 +164,15 @@ int svae_lds_filter_f64(int B, int T, int n, int inhomog, int pair_batched, unsi
  *          above is defined).
  * n <= 10, T >= 4, K <= 16 and svae_slds_lds_meanfield_lds_bytes(n, K) <= 160 KiB (else -4: use the
  * per-step entry point).  workspace: svae_slds_lds_meanfield_workspace_bytes(rows, T, n) (the two-ended kernel's
- * records only: a third of svae_lds_workspace_bytes). */
+ * records only: a third of svae_lds_workspace_bytes).
+ * options (ABI 12; 0 = the library's choice, a pure function of the arguments):
+ *   SVAE_OPT_LAYOUT_PACKED  row-per-chain consumers (two sequences per wavefront, lean records) + producer wavefronts that
+ *                           form the K-state mixing and the K-state contraction on v_mfma_f64_16x16x4, 8 sequences per
+ *                           workgroup in lock-step (csrc/lds_estep_twoend_rpcmix.hpp): K <= 8 and a workspace below
+ *                           4 GiB, else -24; the default where it applies;
+ *   SVAE_OPT_LAYOUT_SPLIT   one sequence per wavefront, the K parameter sets as LDS tables (rounds 2 - 4; any K <= 16);
+ *   SVAE_OPT_PRODUCERS_OFF  with the packed layout: the producers compute with plain loops instead of MFMA (slow; test
+ *                           infrastructure that separates the lock-step protocol from the MFMA operand layouts). */
 size_t svae_slds_lds_meanfield_lds_bytes(int n, int K);
 size_t svae_slds_lds_meanfield_workspace_bytes(int rows, int T, int n);
 int svae_slds_lds_meanfield_f64(int B, int rows, int T, int n, int K,
@@ -175,7 +183,7 @@ int svae_slds_lds_meanfield_f64(int B, int rows, int T, int n, int K,
                                 const int32_t* seq_index,
                                 double* lognorm, double* E_init, double* E_node_diagxx, double* E_node_x,
                                 double* pair_contr, int32_t* info,
-                                void* workspace, size_t ws_bytes, void* stream);
+                                void* workspace, size_t ws_bytes, unsigned options, void* stream);
 
 /* Reverse-mode derivative of the E-step (+ sampler) w.r.t. the node potentials for latent dimension 16 <= n <= 64,
  * on the hand-off the LDS-tiled E-step kernel leaves in `handoff_workspace` (the workspace of the LAST

@@ -43,7 +43,7 @@ SIGNATURES = {
     "svae_slds_lds_meanfield_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
     "svae_slds_lds_meanfield_f64": (ctypes.c_int, [ctypes.c_int] * 5 + [_c_double_p] * 9 + [_c_int_p]
                                     + [_c_double_p] * 5 + [_c_int_p, ctypes.c_void_p, ctypes.c_size_t,
-                                                           ctypes.c_void_p]),
+                                                           ctypes.c_uint, ctypes.c_void_p]),
     "svae_lds_reduce_stats_f64": (ctypes.c_int, [ctypes.c_int] * 2 + [_c_double_p] * 4
                                   + [ctypes.c_void_p]),
     "svae_lds_vjp_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),

@@ -14,6 +14,7 @@ extern "C" {
   int svae_lds_launch_split_n##NN(const svae::LdsArgs*, int, void*);           \
   int svae_lds_launch_twoend_n##NN(const svae::LdsArgs*, int, int, int, void*);          \
   int svae_lds_launch_twoend_mix_n##NN(const svae::LdsArgs*, void*);          \
+  int svae_lds_launch_slds_rpc_n##NN(const svae::LdsArgs*, int, void*);       \
   int svae_lds_launch_filter_n##NN(const svae::LdsArgs*, int, void*);          \
   int svae_lds_launch_filter_split_n##NN(const svae::LdsArgs*, int, void*);    \
   int svae_lds_launch_filter_1r_n##NN(const svae::LdsArgs*, int, void*);       \
@@ -344,7 +345,7 @@ int svae_slds_lds_meanfield_f64(int B, int rows, int T, int n, int K,
                                 const int32_t* seq_index,
                                 double* lognorm, double* E_init, double* E_node_diagxx, double* E_node_x,
                                 double* pair_contr, int32_t* info,
-                                void* workspace, size_t ws_bytes, void* stream) {
+                                void* workspace, size_t ws_bytes, unsigned options, void* stream) {
   if (B < 0 || B > rows) return -1;
   if (T < svae::TE_MIN_T) return -2;
   if (n < 1 || n > svae::TE_MAX_N) return -3;
@@ -362,6 +363,15 @@ int svae_slds_lds_meanfield_f64(int B, int rows, int T, int n, int K,
   if (!pair_contr) return -19;
   if (!info) return -20;
   if (!workspace || ws_bytes < svae_slds_lds_meanfield_workspace_bytes(rows, T, n)) return -21;
+  // kernel selection (a pure function of the arguments): SVAE_OPT_LAYOUT_SPLIT = one sequence per wavefront, the K
+  // parameter sets as LDS tables (rounds 2 - 4); SVAE_OPT_LAYOUT_PACKED = row-per-chain consumers + MFMA producer
+  // wavefronts (round 5; K <= 8, workspace below 4 GiB: 32-bit lane offsets); 0 = the latter where it applies.
+  // SVAE_OPT_PRODUCERS_OFF with the packed layout: reference producers (plain loops, no MFMA: test infrastructure).
+  if (options & ~(SVAE_OPT_LAYOUT_SPLIT | SVAE_OPT_LAYOUT_PACKED | SVAE_OPT_PRODUCERS_OFF)) return -24;
+  if ((options & SVAE_OPT_LAYOUT_SPLIT) && (options & SVAE_OPT_LAYOUT_PACKED)) return -24;
+  const bool rpc_ok = K <= 8 && svae_slds_lds_meanfield_workspace_bytes(rows, T, n) < (1ull << 32);
+  if ((options & SVAE_OPT_LAYOUT_PACKED) && !rpc_ok) return -24;
+  const bool rpc = rpc_ok && !(options & SVAE_OPT_LAYOUT_SPLIT);
   if (B == 0) return 0;
   svae::LdsArgs a;
   a.B = B; a.T = T;
@@ -375,7 +385,8 @@ int svae_slds_lds_meanfield_f64(int B, int rows, int T, int n, int K,
   a.msg_Jp = a.msg_hp = a.msg_Jf = a.msg_hf = nullptr;
   a.mix_w = weights; a.mix_out = pair_contr; a.seq_index = seq_index; a.mix_K = K; a.lds_keep = 0; a.tile_half = 0; a.sig_out = nullptr;
   switch (n) {
-#define SVAE_CASE_(NN) case NN: return svae_lds_launch_twoend_mix_n##NN(&a, stream);
+#define SVAE_CASE_(NN) case NN: return rpc ? svae_lds_launch_slds_rpc_n##NN(&a, (options & SVAE_OPT_PRODUCERS_OFF) ? 1 : 0, stream) \
+                                        : svae_lds_launch_twoend_mix_n##NN(&a, stream);
 #define SVAE_CASE(NN) SVAE_CASE_(NN)
 #ifdef SVAE_ONLY_N
     SVAE_CASE(SVAE_ONLY_N)

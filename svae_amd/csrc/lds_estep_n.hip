@@ -9,6 +9,7 @@
 #include "lds_estep_split.hpp"
 #include "lds_estep_twoend.hpp"
 #include "lds_estep_twoend_rpc.hpp"
+#include "lds_estep_twoend_rpcmix.hpp"
 #include "lds_filter_1r.hpp"
 
 #ifndef SVAE_N
@@ -41,6 +42,11 @@ extern "C" int SVAE_CAT(svae_lds_launch_twoend_n, SVAE_N)(const svae::LdsArgs* a
 
 extern "C" int SVAE_CAT(svae_lds_launch_twoend_mix_n, SVAE_N)(const svae::LdsArgs* a, void* stream) {
   return svae::launch_estep_twoend_mix<SVAE_N>(*a, (hipStream_t)stream);
+}
+
+// the SLDS mean-field step in the row-per-chain layout with producer wavefronts (refprod != 0: reference producers)
+extern "C" int SVAE_CAT(svae_lds_launch_slds_rpc_n, SVAE_N)(const svae::LdsArgs* a, int refprod, void* stream) {
+  return svae::launch_slds_meanfield_rpc<SVAE_N>(*a, refprod, (hipStream_t)stream);
 }
 
 extern "C" int SVAE_CAT(svae_lds_launch_filter_n, SVAE_N)(const svae::LdsArgs* a, int inhomog, void* stream) {

@@ -206,9 +206,13 @@ class SLDSMeanfieldPlan(object):
     are the persistent state of the coordinate ascent: a launch with a `seq_index` list rewrites only the
     rows of the sequences still iterating (and costs only their share of the work)."""
 
-    def __init__(self, B, T, n, K, device):
+    def __init__(self, B, T, n, K, device, options=0):
         self.lib = _lib.load()
         self.B, self.T, self.n, self.K = B, T, n, K
+        # kernel-selection word of svae_slds_lds_meanfield_f64 (0 = the library's choice: row-per-chain consumers + MFMA
+        # producer wavefronts for K <= 8; _lib.OPT_LAYOUT_SPLIT = the one-sequence-per-wavefront table kernel of rounds
+        # 2 - 4; OPT_LAYOUT_PACKED | OPT_PRODUCERS_OFF = reference producers, test infrastructure)
+        self.options = int(options)
         self.device = torch.device(device)
         f64 = dict(dtype=torch.float64, device=self.device)
         self.ws_bytes = int(self.lib.svae_slds_lds_meanfield_workspace_bytes(max(B, 1), T, n))
@@ -241,7 +245,7 @@ class SLDSMeanfieldPlan(object):
             p(dense_pair[0]), p(dense_pair[1]), p(dense_pair[2]), p(weights),
             p(node[0]), p(node[1]), p(node[2]) if len(node) > 2 else None, p(seq_index),
             p(self.lognorm), p(self.E_init), p(self.E_node_diagxx), p(self.E_node_x), p(self.pair_contr),
-            p(self.info), p(self.ws), self.ws_bytes, _lib.current_stream(self.device))
+            p(self.info), p(self.ws), self.ws_bytes, self.options, _lib.current_stream(self.device))
         _lib.check(rc, "svae_slds_lds_meanfield_f64")
 
     def hmm_nodeparams(self, dense_init, dense_pair, rows=None):

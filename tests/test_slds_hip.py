@@ -167,8 +167,19 @@ def test_withlabels_matches_oracle():
             _close(got[b], want)
 
 
-@pytest.mark.parametrize("K,n,T,B", [(3, 4, 9, 5), (8, 10, 40, 11), (7, 10, 5, 3), (16, 6, 12, 4), (2, 2, 4, 2)])
-def test_fused_lds_meanfield_step_matches_materialised(K, n, T, B):
+def _fused_options(kernel):
+    """kernel-selection word of svae_slds_lds_meanfield_f64: the library's choice; the table kernel of rounds 2 - 4 (one
+    sequence per wavefront); the round-5 kernel (row-per-chain consumers + producer wavefronts) with reference producers
+    (plain loops) and with the MFMA producers"""
+    from svae_amd import _lib
+    return {"default": 0, "tables": _lib.OPT_LAYOUT_SPLIT, "rpc_ref": _lib.OPT_LAYOUT_PACKED | _lib.OPT_PRODUCERS_OFF,
+            "rpc_mfma": _lib.OPT_LAYOUT_PACKED}[kernel]
+
+
+@pytest.mark.parametrize("kernel", ["tables", "rpc_ref", "rpc_mfma", "default"])
+@pytest.mark.parametrize("K,n,T,B", [(3, 4, 9, 5), (8, 10, 40, 11), (7, 10, 5, 3), (16, 6, 12, 4), (2, 2, 4, 2),
+                                     (5, 7, 13, 21), (8, 10, 6, 9), (8, 9, 4, 17), (1, 3, 7, 8), (8, 10, 31, 40)])
+def test_fused_lds_meanfield_step_matches_materialised(K, n, T, B, kernel):
     """One LDS mean-field step through svae_slds_lds_meanfield_f64 (K parameter sets in LDS, mixed per step
     by the HMM marginals, pair statistics contracted in the kernel) against the path that materialises the
     per-step pair parameters and statistics (get_var_lds_local_natparam / get_arhmm_local_nodeparams,
@@ -189,12 +200,17 @@ def test_fused_lds_meanfield_step_matches_materialised(K, n, T, B):
     w = rng.random((B, T, K)) ** 3 + 1e-3
     w = t(w / w.sum(-1, keepdims=True))
     assert slds_svae.SLDSMeanfieldPlan.supported(n, T, K)
-    plan = slds_svae.SLDSMeanfieldPlan(B, T, n, K, dev)
+    if K > 8 and kernel.startswith("rpc"):
+        pytest.skip("the producer-wavefront kernel covers K <= 8")
+    plan = slds_svae.SLDSMeanfieldPlan(B, T, n, K, dev, options=_fused_options(kernel))
     sentinel = -7.25
     for buf in (plan.lognorm, plan.E_init, plan.E_node_diagxx, plan.E_node_x, plan.pair_contr):
         buf.fill_(sentinel)
     rows = [b for b in range(B) if b != B // 2]
-    rows = torch.tensor(rows[1::2] + rows[0::2], dtype=torch.int32, device=dev)      # any order
+    rows = rows[1::2] + rows[0::2]                                                   # any order
+    if B >= 8:                       # unused slots (negative entries) in the middle and at the end of an oversized launch
+        rows = rows[:3] + [-1] + rows[3:] + [-1, -1]
+    rows = torch.tensor(rows, dtype=torch.int32, device=dev)
     plan.launch(dense_init, dense_pair, w, node, rows)
     torch.cuda.synchronize()
     assert int(plan.info.item()) == 0
