@@ -352,7 +352,8 @@ def measure_slds(dev, B=2048, T=500, n=10, K=8):
         best = dt if best is None else min(best, dt)
     return {"workload": "BASELINE configs[3]: SLDS-SVAE local mean field, K=%d, n=%d, %d sequences x T=%d" % (K, n, B, T),
             "ms_per_ascent": 1e3 * best, "sweeps_max": int(iters.max()), "sweeps_mean": float(iters.double().mean()),
-            "value": B / best, "unit": "sequences/s", "kernel": "svae::lds_estep_twoend_kernel<10,true,false,true> + svae::hmm_estep2_kernel<8>"}
+            "value": B / best, "unit": "sequences/s",
+            "kernel": "svae::slds_meanfield_rpc_kernel<10,false> (row-per-chain consumers + MFMA producer wavefronts) + svae::hmm_estep2_kernel<8>"}
 
 
 def measure_gmm(dev, K=5, N=2, T=1000, what="BASELINE configs[0]"):

@@ -25,9 +25,13 @@
 //     producers 0 - 2 take one slot each in turn: two 16 x 16 x n^2 products (rows: [J11_k ; J22_k] on S~, [J12_k^T ;
 //     J12_k] on W~ -- a chain-A column keeps the first half of the second product, a chain-B column the second), spread
 //     over the two steps that follow, then the (T,2,K) outputs straight from the accumulators.
-// The parameter tables live in the producers' REGISTERS (they are the A operands: 12 + 50 doubles per lane).
-// LDS per workgroup (n = 10): 2 x 26.5 KB mixing ring + 3 x 25.7 KB tile ring + 24.6 KB transposition tiles = 155 KB
-// (one workgroup per CU: 8 sequences, 8 wavefronts, two per SIMD -- a consumer and its producer).
+// Symmetry is used where it is free: C and S~ travel as lower triangles (the ring columns have the layout of a lean
+// hand-off record, so the consumer lanes' symmetric reads / in-order overwriting stores need no selects), which cuts the
+// products from 42 + 14 + 50 to 30 + 14 + 39 MFMAs per step pair -- fp64 MFMAs and the consumers' fp64 vector
+// instructions contend for the SIMD (measured), so every MFMA saved is consumer time.
+// The parameter tables live in the producers' REGISTERS (they are the A operands: <= 22 + 39 doubles per lane).
+// LDS per workgroup (n = 10): 2 x 21.4 KB mixing ring + 3 x 21.6 KB tile ring + 24.6 KB transposition tiles = 132 KB
+// (one workgroup per CU: up to 8 sequences, 8 wavefronts, two per SIMD -- a consumer and its producer).
 // REFPROD: the producers compute the same ring contents / outputs with plain loops from global memory (no MFMA) -- slow,
 // test infrastructure: isolates the lock-step protocol and the consumer side from the MFMA operand layouts.
 // K <= 8 (the 2 K output rows of the contraction are one MFMA tile), n <= 10, T >= 4.
@@ -41,14 +45,19 @@ typedef double rm_d4 __attribute__((ext_vector_type(4)));
 template <int N>
 struct RpcMixCfg {
   static constexpr int NN = N * N;
-  static constexpr int NT = (NN + 15) / 16;             // 16-entry tiles per n x n matrix
-  static constexpr int NKB = (NN + 3) / 4;              // 4-entry k-blocks per n x n matrix (contraction)
-  static constexpr int CS = (2 * NN + 1) | 1;           // mixing ring: column stride (odd: conflict-free tile stores);
-  static constexpr int ZE = 2 * NN;                     //   entry 2 n^2 of a column stays zero
-  static constexpr int ZBLK = (NN + 1) & ~1;            //   + a block of zeros behind the 16 columns of a slot
-  static constexpr int MIXSLOT = 16 * CS + ZBLK;
-  static constexpr int SS = (2 * NN + 1) | 1;           // tile ring: column stride
+  static constexpr int TRI = N * (N + 1) / 2;
+  static constexpr int NT = (NN + 15) / 16;             // 16-entry tiles of J12 (n^2 entries)
+  static constexpr int NTC = (TRI + 15) / 16;           // 16-entry tiles of C (symmetric: its lower triangle)
+  // mixing ring, one column: [ nat J12 (n^2) | C, lower triangle by rows (TRI) | zeros (n + 1) ] -- the C part has the
+  // layout of a lean hand-off record: lane N reads entry TRI + i, lanes > N entry TRI + N, both zero
+  static constexpr int CS = (NN + TRI + N + 1) | 1;     // column stride (odd: conflict-free tile stores)
+  static constexpr int MIXSLOT = 16 * CS;
+  // tile ring, one column: [ S~ lower triangle (TRI) | junk (n + 2: what lanes >= n store) | pad | W~ (n^2) ]
+  static constexpr int WOFF = (TRI + N + 2 + 3) & ~3;   // W~ starts on a k-block boundary
+  static constexpr int SS = (WOFF + NN) | 1;
   static constexpr int SSLOT = 16 * SS;
+  static constexpr int NKB1 = (TRI + 3) / 4;            // 4-entry k-blocks of the first product (S~ triangle)
+  static constexpr int NKB2 = (NN + 3) / 4;             //   ... of the second (W~)
   static constexpr int RSL = (N + 3) & ~1;              // row stride of a consumer's transposition tile
   static constexpr int TAB = 4 * 16 * RSL;              // per consumer wavefront
   static constexpr int OFF_S = 2 * MIXSLOT;
@@ -56,8 +65,15 @@ struct RpcMixCfg {
   static constexpr int LDS_DOUBLES = OFF_TAB + 4 * TAB;
 };
 constexpr long rpcmix_lds_bytes(int n) {
-  const int nn = n * n, cs = (2 * nn + 1) | 1, zb = (nn + 1) & ~1, rsl = (n + 3) & ~1;
-  return 8L * (2 * (16 * cs + zb) + 3 * 16 * cs + 4 * 4 * 16 * rsl);
+  const int nn = n * n, tri = n * (n + 1) / 2, cs = (nn + tri + n + 1) | 1, woff = (tri + n + 2 + 3) & ~3;
+  const int ss = (woff + nn) | 1, rsl = (n + 3) & ~1;
+  return 8L * (2 * 16 * cs + 3 * 16 * ss + 4 * 4 * 16 * rsl);
+}
+// (row, column) of entry e of a lower triangle stored by rows
+__device__ __forceinline__ void rm_tri_rc(int e, int& i, int& c) {
+  i = 0;
+  while ((i + 1) * (i + 2) / 2 <= e) ++i;
+  c = e - i * (i + 1) / 2;
 }
 constexpr int RPCMIX_MAX_K = 8;
 
@@ -69,11 +85,18 @@ __device__ __forceinline__ int rm_row_of(const LdsArgs& a, int pos, int blk, int
   return a.seq_index ? a.seq_index[slot] : slot;
 }
 
+// which wavefronts of the workgroup have work: bit w = consumer wavefront w has a live sequence
+__device__ __forceinline__ int rm_live_waves(const LdsArgs& a, int blk, int G) {
+  int m = 0;
+  for (int pos = 0; pos < 8; ++pos) m |= (rm_row_of(a, pos, blk, G) >= 0) ? (1 << (pos >> 1)) : 0;
+  return m;
+}
+
 // ---- producers, reference form (plain loops; test infrastructure) ------------------------------------------------------
 template <int N>
 __device__ void rm_producer_ref(const LdsArgs& a, double* mring, double* sring, const int pt, const int blk, const int G) {
   using C = RpcMixCfg<N>;
-  constexpr int NN = C::NN;
+  constexpr int NN = C::NN, TRI = C::TRI;
   const int T = a.T, K = a.mix_K, e = te_elims(T);
   const bool oddT = (T & 1) != 0;
   auto erow_of = [&](int j) { int r = rm_row_of(a, j >> 1, blk, G); if (r < 0) r = rm_row_of(a, (j >> 1) ^ 1, blk, G); return r; };
@@ -85,14 +108,16 @@ __device__ void rm_producer_ref(const LdsArgs& a, double* mring, double* sring, 
   };
   auto mix = [&](int m, bool withC) {                       // E_m -> slot m & 1
     double* slot = mring + (m & 1) * C::MIXSLOT;
-    for (int o = pt; o < 16 * 2 * NN; o += 256) {
+    for (int o = pt; o < 16 * (NN + TRI); o += 256) {
       const int j = o & 15, ee = o >> 4, dirj = j & 1;
       const double* w0 = wvec(j, m), *w1 = wvec(j, m + 1);
       double v = 0.0;
       if (ee < NN) {
         for (int k = 0; k < K; ++k) v = __builtin_fma(a.J12[(long)k * NN + ee], w0[k], v);
       } else if (withC) {
-        const int e2 = ee - NN;
+        int i, cq;
+        rm_tri_rc(ee - NN, i, cq);
+        const int e2 = i * N + cq;
         const double* x = dirj ? w1 : w0, *y = dirj ? w0 : w1;
         for (int k = 0; k < K; ++k)
           v = __builtin_fma(-2.0 * a.J22[(long)k * NN + e2], x[k], __builtin_fma(-2.0 * a.J11[(long)k * NN + e2], y[k], v));
@@ -111,11 +136,15 @@ __device__ void rm_producer_ref(const LdsArgs& a, double* mring, double* sring, 
     const double* Pq = (q ? a.J22 : a.J11) + (long)k * NN;
     const double* Px = a.J12 + (long)k * NN;
     double acc = 0.0;
-    for (int ee = 0; ee < NN; ++ee) acc = __builtin_fma(src[ee], Pq[ee], acc);
+    for (int ee = 0; ee < TRI; ++ee) {
+      int i, cq;
+      rm_tri_rc(ee, i, cq);
+      acc = __builtin_fma(src[ee], i == cq ? Pq[i * N + i] : Pq[i * N + cq] + Pq[cq * N + i], acc);
+    }
     if (q == dirj) {
       for (int ee = 0; ee < NN; ++ee) {
         const int i = ee / N, cq = ee % N;
-        acc = __builtin_fma(src[NN + ee], dirj ? Px[ee] : Px[cq * N + i], acc);
+        acc = __builtin_fma(src[C::WOFF + ee], dirj ? Px[ee] : Px[cq * N + i], acc);
       }
     }
     const int s = e - kk, t = dirj ? T - 1 - s : s;
@@ -138,13 +167,22 @@ __device__ void rm_producer_ref(const LdsArgs& a, double* mring, double* sring, 
 }
 
 // ---- producers on the matrix cores ------------------------------------------------------------------------------------
+// p: producer index 0 .. 3 (it shares a SIMD with consumer wavefront p).  `live_waves` = 1 (only consumer 0 has work: small
+// launches, the late sweeps of the coordinate ascent): producers 1 - 3 share everything and producer 0 only keeps the
+// barrier count -- fp64 MFMAs and the consumer's fp64 vector instructions contend for the SIMD (measured), so the one
+// chain that is the launch's latency keeps its SIMD to itself.
 template <int N>
 __device__ void rm_producer_mfma(const LdsArgs& a, double* mring, double* sring, const int p, const int lane, const int blk,
-                                 const int G) {
+                                 const int G, const int live_waves) {
   using C = RpcMixCfg<N>;
-  constexpr int NN = C::NN, NT = C::NT, NKB = C::NKB, NU = (NT + 3) / 4;
+  constexpr int NN = C::NN, TRI = C::TRI, NT = C::NT, NTC = C::NTC, NKB1 = C::NKB1, NKB2 = C::NKB2;
+  constexpr int NUC = (NTC + 2) / 3;                        // C tiles of one producer, at most (three or four share them)
   const int T = a.T, K = a.mix_K, e = te_elims(T);
   const bool oddT = (T & 1) != 0;
+  const bool solo = live_waves == 1;
+  const int np = solo ? 3 : 4;                              // producers sharing the mixing tiles
+  const int pr = solo ? p - 1 : p;                          // my rank among them (-1: none of it)
+  const int cr = solo ? p - 1 : (p < 3 ? p : -1);           // my rank among the three contraction producers (-1: none)
   const int kq = lane >> 4, r16 = lane & 15;
   const int j = r16, dirj = j & 1;                          // this lane's column (B operand / C-D layout: column = lane % 16)
   const int row = rm_row_of(a, j >> 1, blk, G);
@@ -152,7 +190,7 @@ __device__ void rm_producer_mfma(const LdsArgs& a, double* mring, double* sring,
   const int erow = row >= 0 ? row : (sib >= 0 ? sib : 0);
   // ---- A operands (lane holds A[r16][4 kb + kq]) ------------------------------------------------------------------------
   double tj[NT][2];                                         // J12 tiles:  A[e][k] = nat J12_k[e]
-  double tc[NU][4];                                         // my C tiles (ti = p + 4 u): A[e][0..7] = -2 J22_k[e], [8..15] = -2 J11_k[e]
+  double tc[NUC][4];                                        // my C tiles (ti = pr + np u): A[e][0..7] = -2 J22_k, [8..15] = -2 J11_k
   static_for<0, NT>([&](auto ti) {
     const int ee = ti * 16 + r16;
     static_for<0, 2>([&](auto kb) {
@@ -161,25 +199,35 @@ __device__ void rm_producer_mfma(const LdsArgs& a, double* mring, double* sring,
       tj[ti][kb] = ok ? a.J12[ok ? (long)k * NN + ee : 0] : 0.0;
     });
   });
-  static_for<0, NU>([&](auto u) {
-    const int ti = p + 4 * u, ee = ti * 16 + r16;
+  static_for<0, NUC>([&](auto u) {
+    const int ti = pr + np * u, ee = ti * 16 + r16;
+    int i = 0, cq = 0;
+    rm_tri_rc(ee < TRI && pr >= 0 ? ee : 0, i, cq);
     static_for<0, 4>([&](auto kb) {
       const int k = (kb & 1) * 4 + kq;
       const double* base = kb < 2 ? a.J22 : a.J11;
-      const bool ok = ti < NT && ee < NN && k < K;
-      tc[u][kb] = ok ? -2.0 * base[ok ? (long)k * NN + ee : 0] : 0.0;
+      const bool ok = pr >= 0 && ti < NTC && ee < TRI && k < K;
+      tc[u][kb] = ok ? -2.0 * base[ok ? (long)k * NN + i * N + cq : 0] : 0.0;
     });
   });
-  // contraction (producers 0 - 2): rows r16 = (q, k): tile 1 [J11_k ; J22_k] on S~, tile 2 [J12_k^T ; J12_k] on W~
-  double a1[NKB], a2[NKB];
+  // contraction: rows r16 = (q, k).  First product [J11_k ; J22_k] on the lower triangle of S~ (off-diagonal entries
+  // count twice: J[i][c] + J[c][i]); second [J12_k^T ; J12_k] on W~
+  double a1[NKB1], a2[NKB2];
   {
     const int q = r16 >> 3, k = r16 & 7;
-    static_for<0, NKB>([&](auto kb) {
+    const double* Pq = q ? a.J22 : a.J11;
+    static_for<0, NKB1>([&](auto kb) {
+      const int ee = kb * 4 + kq;
+      const bool ok = cr >= 0 && ee < TRI && k < K;
+      int i = 0, cq = 0;
+      rm_tri_rc(ok ? ee : 0, i, cq);
+      const long b0 = ok ? (long)k * NN : 0;
+      a1[kb] = ok ? (i == cq ? Pq[b0 + i * N + i] : Pq[b0 + i * N + cq] + Pq[b0 + cq * N + i]) : 0.0;
+    });
+    static_for<0, NKB2>([&](auto kb) {
       const int ee = kb * 4 + kq, i = ee / N, cq = ee % N;
-      const bool ok = p < 3 && ee < NN && k < K;
-      const long i1 = ok ? (long)k * NN + ee : 0, i2 = ok ? (long)k * NN + (q ? ee : cq * N + i) : 0;
-      a1[kb] = ok ? (q ? a.J22 : a.J11)[i1] : 0.0;
-      a2[kb] = ok ? a.J12[i2] : 0.0;
+      const bool ok = cr >= 0 && ee < NN && k < K;
+      a2[kb] = ok ? a.J12[ok ? (long)k * NN + (q ? ee : cq * N + i) : 0] : 0.0;
     });
   }
   // ---- weights: B operand, lane holds w[k = 4 kb + kq] of ITS column's node -------------------------------------------------
@@ -195,7 +243,7 @@ __device__ void rm_producer_mfma(const LdsArgs& a, double* mring, double* sring,
   auto mix = [&](int m, const W2 wa, const W2 wb, bool withC, bool all_j) {
     double* dst = dstl + (m & 1) * C::MIXSLOT;
     static_for<0, NT>([&](auto ti) {
-      if (all_j || (ti & 3) == p) {
+      if (all_j || (ti % np) == pr) {
         rm_d4 d = zero4;
         d = __builtin_amdgcn_mfma_f64_16x16x4f64(tj[ti][0], wa.v0, d, 0, 0, 0);
         d = __builtin_amdgcn_mfma_f64_16x16x4f64(tj[ti][1], wa.v1, d, 0, 0, 0);
@@ -204,19 +252,19 @@ __device__ void rm_producer_mfma(const LdsArgs& a, double* mring, double* sring,
         });
       }
     });
-    if (withC) {
+    if (withC && pr >= 0) {
       const double f0 = dirj ? wb.v0 : wa.v0, f1 = dirj ? wb.v1 : wa.v1;     // multiplies -2 J22
       const double g0 = dirj ? wa.v0 : wb.v0, g1 = dirj ? wa.v1 : wb.v1;     // multiplies -2 J11
-      static_for<0, NU>([&](auto u) {
-        const int ti = p + 4 * u;
-        if (ti < NT) {
+      static_for<0, NUC>([&](auto u) {
+        const int ti = pr + np * u;
+        if (ti < NTC) {
           rm_d4 d = zero4;
           d = __builtin_amdgcn_mfma_f64_16x16x4f64(tc[u][0], f0, d, 0, 0, 0);
           d = __builtin_amdgcn_mfma_f64_16x16x4f64(tc[u][1], f1, d, 0, 0, 0);
           d = __builtin_amdgcn_mfma_f64_16x16x4f64(tc[u][2], g0, d, 0, 0, 0);
           d = __builtin_amdgcn_mfma_f64_16x16x4f64(tc[u][3], g1, d, 0, 0, 0);
           static_for<0, 4>([&](auto rr) {
-            if (ti * 16 + 4 * rr + kq < NN) dst[NN + ti * 16 + 4 * rr] = d[(int)rr];
+            if (ti * 16 + 4 * rr + kq < TRI) dst[NN + ti * 16 + 4 * rr] = d[(int)rr];
           });
         }
       });
@@ -227,13 +275,13 @@ __device__ void rm_producer_mfma(const LdsArgs& a, double* mring, double* sring,
   auto chunk1 = [&](int kk) {
     const double* src = srcl + (kk % 3) * C::SSLOT;
     rm_d4 d = zero4;
-    static_for<0, NKB>([&](auto kb) { d = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kb], src[kb * 4], d, 0, 0, 0); });
+    static_for<0, NKB1>([&](auto kb) { d = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kb], src[kb * 4], d, 0, 0, 0); });
     D1 = d;
   };
   auto chunk2 = [&](int kk) {
-    const double* src = srcl + (kk % 3) * C::SSLOT + NN;
+    const double* src = srcl + (kk % 3) * C::SSLOT + C::WOFF;
     rm_d4 d = zero4;
-    static_for<0, NKB>([&](auto kb) { d = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[kb], src[kb * 4], d, 0, 0, 0); });
+    static_for<0, NKB2>([&](auto kb) { d = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[kb], src[kb * 4], d, 0, 0, 0); });
     D2 = d;
     // rows: register rr holds row 4 rr + kq = (q = rr >> 1, k = 4 (rr & 1) + kq); the cross term of a chain-A column is
     // rows 0 .. 7 of the second product (-> q = 0), of a chain-B column rows 8 .. 15 (-> q = 1)
@@ -249,32 +297,33 @@ __device__ void rm_producer_mfma(const LdsArgs& a, double* mring, double* sring,
 
   lds_barrier();                                            // #0: the rings are zeroed
   W2 w_0 = wload(0), w_1 = wload(1), w_2 = wload(2), w_3 = wload(3);      // weights of local pairs m, m+1, m+2, m+3
-  mix(0, w_0, w_1, true, false);
+  if (pr >= 0) mix(0, w_0, w_1, true, false);
   lds_barrier();                                            // #1: E_0 is in slot 0
   for (int s = 0; s < e; ++s) {
     const W2 w_4 = wload(s + 4 <= e ? s + 4 : e);           // (pairs beyond e are never used)
-    if (s + 1 <= e - 1) mix(s + 1, w_1, w_2, true, false);
+    if (pr >= 0 && s + 1 <= e - 1) mix(s + 1, w_1, w_2, true, false);
     w_0 = w_1; w_1 = w_2; w_2 = w_3; w_3 = w_4;
     lds_barrier();
   }
-  // smoother phase: step k works on local step s = e - k.  Producer 3: the J12 mix of step s - 1; producers 0 - 2: the
-  // contraction of tile-ring slot k - 1 (first product) / k - 2 (second product + outputs) when it is their turn
+  // smoother phase: step k works on local step s = e - k.  The J12 mix of step s - 1: producer 3 (solo: whichever of the
+  // three has no product this step); the contraction of tile-ring slot k - 1 (first product) / k - 2 (second product +
+  // outputs): the producer whose turn it is
   W2 v_0 = wload(e >= 2 ? e - 2 : 0), v_1 = wload(e >= 3 ? e - 3 : 0), v_2 = wload(e >= 4 ? e - 4 : 0);
   for (int k = 0; k <= e; ++k) {
     const int s = e - k;
-    if (p == 3) {
-      const W2 v_3 = wload(s - 4 >= 0 ? s - 4 : 0);         // pair (s - 1) - 3
-      if (k >= 1 && s >= 1) mix(s - 1, v_0, v_0, false, true);
-      if (k >= 1) { v_0 = v_1; v_1 = v_2; v_2 = v_3; }
-    } else {
-      if (k >= 2 && (k - 2) % 3 == p) chunk2(k - 2);
-      if (k >= 1 && (k - 1) % 3 == p) chunk1(k - 1);
+    const W2 v_3 = wload(s - 4 >= 0 ? s - 4 : 0);           // pair (s - 1) - 3
+    const bool jturn = solo ? (pr >= 0 && k % 3 == pr) : p == 3;
+    if (jturn && k >= 1 && s >= 1) mix(s - 1, v_0, v_0, false, true);
+    if (cr >= 0) {
+      if (k >= 2 && (k - 2) % 3 == cr) chunk2(k - 2);
+      if (k >= 1 && (k - 1) % 3 == cr) chunk1(k - 1);
     }
+    if (k >= 1) { v_0 = v_1; v_1 = v_2; v_2 = v_3; }
     lds_barrier();
   }
-  if (p < 3) {
-    if (e >= 1 && (e - 1) % 3 == p) chunk2(e - 1);
-    if (e % 3 == p) { chunk1(e); chunk2(e); }
+  if (cr >= 0) {
+    if (e >= 1 && (e - 1) % 3 == cr) chunk2(e - 1);
+    if (e % 3 == cr) { chunk1(e); chunk2(e); }
   }
 }
 
@@ -300,11 +349,13 @@ __global__ __launch_bounds__(512) void slds_meanfield_rpc_kernel(const LdsArgs a
   const int e = te_elims(T);              // eliminations per chain; the meeting node is local index e
   const int NBAR = 2 * e + 3;             // barriers every wavefront of the workgroup executes
 
+  const int live_waves = rm_live_waves(a, blk, G);
+  if (live_waves == 0) return;            // an oversized launch: nothing listed for this workgroup (no barrier executed yet)
   for (int q = threadIdx.x; q < C::LDS_DOUBLES; q += 512) rm_lds[q] = 0.0;   // (NaN bit patterns left by an earlier kernel
                                                                              //  must not meet the zero table entries)
   if (wv >= 4) {
     if constexpr (REFPROD) rm_producer_ref<N>(a, mring, sring, (wv - 4) * 64 + lane, blk, G);
-    else rm_producer_mfma<N>(a, mring, sring, wv - 4, lane, blk, G);
+    else rm_producer_mfma<N>(a, mring, sring, wv - 4, lane, blk, G, live_waves);
     return;
   }
 
@@ -332,19 +383,20 @@ __global__ __launch_bounds__(512) void slds_meanfield_rpc_kernel(const LdsArgs a
   const double EN = (c == N) ? 1.0 : 0.0;
 
   // ring addresses of this lane (bytes from the start of a mixing-ring slot):
-  //   offJ[k]: nat J12'[k][c] -- chain A entry k n + c, chain B (J12' = J12^T) entry c n + k; lanes >= n: the column's zero entry
-  //   offC:    C[i][c] at + i n; lanes >= n: the slot's zero block
-  unsigned offJ[N];
+  //   offJ[k]: nat J12'[k][c] -- chain A entry k n + c, chain B (J12' = J12^T) entry c n + k; lanes >= n: a zero entry
+  //   offC[i]: C[i][c] = C[c][i]: entry tri(max, min) of the column's triangle; lane n: TRI + i, lanes > n: TRI + n (zeros)
+  unsigned offJ[N], offC[N];
   static_for<0, N>([&](auto k) {
-    offJ[k] = 8u * (unsigned)(colj * C::CS + (col ? (dir ? c * N + k : k * N + c) : C::ZE));
+    offJ[k] = 8u * (unsigned)(colj * C::CS + (col ? (dir ? c * N + k : k * N + c) : NN + TRI));
+    const int hi = k > c ? k : c, lo = k > c ? c : k;
+    offC[k] = 8u * (unsigned)(colj * C::CS + NN + (col ? hi * (hi + 1) / 2 + lo : ((c == N) ? TRI + k : TRI + N)));
   });
-  const unsigned offC = 8u * (unsigned)(col ? colj * C::CS + NN + c : 16 * C::CS);
   const char* const mbase = reinterpret_cast<const char*>(mring);
   auto ringJ = [&](unsigned slotbytes, double (&dst)[N]) {
     static_for<0, N>([&](auto k) { dst[k] = *reinterpret_cast<const double*>(mbase + slotbytes + offJ[k]); });
   };
   auto ringC = [&](unsigned slotbytes, double (&dst)[N]) {
-    static_for<0, N>([&](auto i) { dst[i] = *reinterpret_cast<const double*>(mbase + slotbytes + offC + 8u * (i * N)); });
+    static_for<0, N>([&](auto i) { dst[i] = *reinterpret_cast<const double*>(mbase + slotbytes + offC[i]); });
   };
 
   // An: lanes < N = pivot block of the next node without its node potential (incoming message + J11' of the pair
@@ -561,8 +613,18 @@ __global__ __launch_bounds__(512) void slds_meanfield_rpc_kernel(const LdsArgs a
   if (c <= N) tb[N * RSL + c] = EN;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  // tile ring: this lane's entries of its column (lanes < N only): S~[i][c] at i n + c, W~[i][c] at n^2 + i n + c
-  char* const sbase = reinterpret_cast<char*>(sring) + 8u * (unsigned)(colj * C::SS + cc);
+  // tile ring, this lane's entries of its column:  S~[i][c] -> entry tri(max, min) of the triangle -- the stores of
+  // register i hit row i of the triangle from lanes c <= i and, from lanes c > i, the mirror entries of rows c, which
+  // the LATER store of register c overwrites with its own (lower-triangle) value: a wavefront's LDS stores retire in
+  // order, so the ring ends up holding the lower triangle, deterministically; lane n -> TRI + i, lanes > n -> TRI + n
+  // (junk the products multiply by zero).  W~[i][c] (lanes < n) -> WOFF + i n + c.
+  unsigned soff[N];
+  static_for<0, N>([&](auto i) {
+    const int hi = i > c ? i : c, lo = i > c ? c : i;
+    soff[i] = 8u * (unsigned)(colj * C::SS + (col ? hi * (hi + 1) / 2 + lo : ((c == N) ? TRI + i : TRI + N)));
+  });
+  char* const sring_b = reinterpret_cast<char*>(sring);
+  char* const wbase = sring_b + 8u * (unsigned)(colj * C::SS + C::WOFF + cc);
 
   // one smoother step.  KIND: 0 generic, 1 first (meeting record: G = 0), 2 second (weight of the repeated pair);
   // kidx = e - s: its index in the phase (tile-ring slot kidx % 3), s: the local step (J12 ring slot s & 1)
@@ -617,12 +679,14 @@ __global__ __launch_bounds__(512) void slds_meanfield_rpc_kernel(const LdsArgs a
 
     // this node's tiles for the contraction with the K parameter sets (producers): S~ rows < N, and the cross moment
     // W~ rows < N -- zero where the pair is not this chain's to count (the meeting record: G = 0 gives W~ rows < N = 0)
-    if (col) {
-      char* w = sbase + 8u * (unsigned)(kslot * C::SSLOT);
-      static_for<0, N>([&](auto i) { *reinterpret_cast<double*>(w + 8 * (i * N)) = Sn[i]; });
-      static_for<0, N>([&](auto i) {
-        *reinterpret_cast<double*>(w + 8 * (NN + i * N)) = (KIND == 2) ? wsp * W[i] : W[i];
-      });
+    {
+      const unsigned sb = 8u * (unsigned)(kslot * C::SSLOT);
+      static_for<0, N>([&](auto i) { *reinterpret_cast<double*>(sring_b + sb + soff[i]) = Sn[i]; });
+      if (col) {
+        static_for<0, N>([&](auto i) {
+          *reinterpret_cast<double*>(wbase + sb + 8 * (i * N)) = (KIND == 2) ? wsp * W[i] : W[i];
+        });
+      }
     }
 
     *pdg = dg;
@@ -665,7 +729,14 @@ static int launch_slds_meanfield_rpc(const LdsArgs& a, int refprod, hipStream_t 
     const long bytes = rpcmix_lds_bytes(N);
     static_assert(rpcmix_lds_bytes(N) == 8L * RpcMixCfg<N>::LDS_DOUBLES, "LDS size");
     static LdsGrant grant_mfma, grant_ref;
-    const int grid = (a.B + 7) / 8;
+    // sequences per workgroup: only as many as it takes to place the launch on the chip (a workgroup always carries its
+    // four producers; a lone sequence on a CU runs at the latency of its own chain -- the late sweeps of the ascent)
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus < 1) cus = 256;
+    int W = (a.B + cus - 1) / cus;
+    W = W < 1 ? 1 : (W > 8 ? 8 : W);
+    const int grid = (a.B + W - 1) / W;
     if (refprod) {
       auto kern = slds_meanfield_rpc_kernel<N, true>;
       if (!grant_ref.ensure(reinterpret_cast<const void*>(kern), bytes)) return -31;

@@ -208,8 +208,8 @@ def test_fused_lds_meanfield_step_matches_materialised(K, n, T, B, kernel):
         buf.fill_(sentinel)
     rows = [b for b in range(B) if b != B // 2]
     rows = rows[1::2] + rows[0::2]                                                   # any order
-    if B >= 8:                       # unused slots (negative entries) in the middle and at the end of an oversized launch
-        rows = rows[:3] + [-1] + rows[3:] + [-1, -1]
+    if B >= 8:                       # an unused slot (negative entry) in the middle of the list
+        rows = rows[:3] + [-1] + rows[3:]
     rows = torch.tensor(rows, dtype=torch.int32, device=dev)
     plan.launch(dense_init, dense_pair, w, node, rows)
     torch.cuda.synchronize()
@@ -267,7 +267,7 @@ def test_config3_full_size_fused_ascent_against_oracle():
     """BASELINE configs[3] at FULL size (K = 8, latent dim 10, 2048 sequences x T = 500) through the fused LDS
     mean-field kernel: size-independent properties over the whole batch, and parity of the converged mean field
     (iteration counts, HMM marginals, bounds, node statistics) for sequences spread over the batch against the
-    NumPy restatement (32 sequences at 1e-6, ten times inside north_star's 1e-5; the observed worst is printed)."""
+    NumPy restatement (32 sequences at 1e-8: observed 4e-10; north_star asks 1e-5)."""
     from svae_amd.models import slds_svae
     K, n, T, B = 8, 10, 500, 2048
     rng = np.random.default_rng(3)
@@ -302,7 +302,7 @@ def test_config3_full_size_fused_ascent_against_oracle():
         pairs += [(got[b], want) for got, want in zip(lds_stats[0], ref["init_stats"])]
         worst = max(worst, max(_err(got, want) for got, want in pairs))
     print("configs[3] full size, %d sequences vs the restatement: worst rel err %.2e" % (len(picks), worst))
-    assert worst < 1e-6, worst
+    assert worst < 1e-8, worst               # observed 3.8e-10 (round 5); north_star asks 1e-5
 
 
 def test_final_pass_gradient_against_finite_differences():

@@ -85,7 +85,7 @@ def main():
     print("ALL OK" if ok else "MISMATCHES ABOVE")
     if "--time" in sys.argv and ok:
         K, n, T = 8, 10, 500
-        for B in (8, 256, 2048):
+        for B in (1, 8, 64, 256, 512, 1024, 2048):
             dense_init, dense_pair, node, w = setup(K, n, T, B, seed=1)
             for kern in ("tables", "rpc_mfma"):
                 plan = slds_svae.SLDSMeanfieldPlan(B, T, n, K, dev, options=OPTS[kern])
