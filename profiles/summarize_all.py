@@ -48,7 +48,9 @@ def main():
             for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS"):
                 if c + "_per_launch_mean" in r:
                     r[c + "_frac_of_wave_cycles"] = r[c + "_per_launch_mean"] / w
-    out = {"note": "rocprofv3 --pmc, one counter family per pass (tools/prof_generic.sh); FETCH / WRITE in KiB; hbm_bytes = "
+    sha = os.path.join(src, "csrc_sha16.txt")
+    out = {"csrc_sha16": open(sha).read().strip() if os.path.isfile(sha) else None,
+           "note": "rocprofv3 --pmc, one counter family per pass (tools/prof_generic.sh); FETCH / WRITE in KiB; hbm_bytes = "
                    "(2*FETCH_SIZE + WRITE_SIZE) KiB (gfx950 FETCH_SIZE factor 2, profiles/r3_fetch_calibration)",
            "kernels": dict(sorted(res.items()))}
     json.dump(out, open(os.path.join(dst, "pmc.json"), "w"), indent=1)

@@ -6,6 +6,7 @@ TAG=$1; shift
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
+(cd $REPO && python -c "from svae_amd import _lib; print(_lib.source_hash())") > $OUT/csrc_sha16.txt   # the sources profiled
 cd /tmp && export TMPDIR=/tmp
 timeout 400 "$@" > $OUT/bench.log 2>&1; tail -2 $OUT/bench.log | cut -c1-200
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- "$@" > $OUT/trace.log 2>&1
