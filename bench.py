@@ -241,7 +241,7 @@ def roofline(options, T, n, B, kern_ms):
             traffic, traffic_src = p["hbm_bytes_per_launch_corrected"], os.path.relpath(prof, ROOT)
     bytes_launch = B * algorithmic_bytes_per_seq(T, n)
     achieved = bytes_launch / (kern_ms * 1e-3) / 1e9
-    # The honest bound at n <= 15 is fp64 vector issue, reported beside the HBM figure north_star asks
+    # The honest bound at n <= 15 is fp64 vector issue (docs/DESIGN_HISTORY.md 3.5), reported beside the HBM figure north_star asks
     # for: algorithmic flops (T (35/3) n^3 per sequence) over the kernel time against the vector fp64 FMA
     # peak (256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz = the MFMA fp64 peak), and how many flops the kernel ISSUES
     # for each algorithmic one (SQ_INSTS_VALU of the committed PMC pass x 64 lanes x 2; an upper bound: not every
