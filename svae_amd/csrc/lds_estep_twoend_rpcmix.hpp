@@ -61,13 +61,14 @@ struct RpcMixCfg {
   static constexpr int RSL = (N + 3) & ~1;              // row stride of a consumer's transposition tile
   static constexpr int TAB = 4 * 16 * RSL;              // per consumer wavefront
   static constexpr int OFF_S = 2 * MIXSLOT;
-  static constexpr int OFF_TAB = OFF_S + 3 * SSLOT;
+  static constexpr int SDEPTH = 4;                      // tile-ring slots (a launch uses 3 or 4: one per contraction producer)
+  static constexpr int OFF_TAB = OFF_S + SDEPTH * SSLOT;
   static constexpr int LDS_DOUBLES = OFF_TAB + 4 * TAB;
 };
 constexpr long rpcmix_lds_bytes(int n) {
   const int nn = n * n, tri = n * (n + 1) / 2, cs = (nn + tri + n + 1) | 1, woff = (tri + n + 2 + 3) & ~3;
   const int ss = (woff + nn) | 1, rsl = (n + 3) & ~1;
-  return 8L * (2 * 16 * cs + 3 * 16 * ss + 4 * 4 * 16 * rsl);
+  return 8L * (2 * 16 * cs + 4 * 16 * ss + 4 * 4 * 16 * rsl);
 }
 // (row, column) of entry e of a lower triangle stored by rows
 __device__ __forceinline__ void rm_tri_rc(int e, int& i, int& c) {
@@ -94,7 +95,8 @@ __device__ __forceinline__ int rm_live_waves(const LdsArgs& a, int blk, int G) {
 
 // ---- producers, reference form (plain loops; test infrastructure) ------------------------------------------------------
 template <int N>
-__device__ void rm_producer_ref(const LdsArgs& a, double* mring, double* sring, const int pt, const int blk, const int G) {
+__device__ void rm_producer_ref(const LdsArgs& a, double* mring, double* sring, const int pt, const int blk, const int G,
+                                const int ncp) {
   using C = RpcMixCfg<N>;
   constexpr int NN = C::NN, TRI = C::TRI;
   const int T = a.T, K = a.mix_K, e = te_elims(T);
@@ -127,10 +129,10 @@ __device__ void rm_producer_ref(const LdsArgs& a, double* mring, double* sring, 
       slot[j * C::CS + ee] = v;
     }
   };
-  auto contract = [&](int kk) {                             // tile-ring slot kk % 3 -> pair_contr rows of step s = e - kk
+  auto contract = [&](int kk) {                             // tile-ring slot kk % ncp -> pair_contr rows of step s = e - kk
     const int j = pt & 15, r = pt >> 4, q = r >> 3, k = r & 7, dirj = j & 1;
     const int row = rm_row_of(a, j >> 1, blk, G);
-    const double* src = sring + (kk % 3) * C::SSLOT + j * C::SS;
+    const double* src = sring + (kk % ncp) * C::SSLOT + j * C::SS;
     if (k >= K || row < 0) return;
     if (kk == 0 && !(oddT && dirj == 0)) return;            // the meeting node is reported by chain A, odd T only
     const double* Pq = (q ? a.J22 : a.J11) + (long)k * NN;
@@ -182,7 +184,8 @@ __device__ void rm_producer_mfma(const LdsArgs& a, double* mring, double* sring,
   const bool solo = live_waves == 1;
   const int np = solo ? 3 : 4;                              // producers sharing the mixing tiles
   const int pr = solo ? p - 1 : p;                          // my rank among them (-1: none of it)
-  const int cr = solo ? p - 1 : (p < 3 ? p : -1);           // my rank among the three contraction producers (-1: none)
+  const int ncp = solo ? 3 : 4;                             // contraction producers = tile-ring slots in use
+  const int cr = solo ? p - 1 : p;                          // my rank among them (-1: none)
   const int kq = lane >> 4, r16 = lane & 15;
   const int j = r16, dirj = j & 1;                          // this lane's column (B operand / C-D layout: column = lane % 16)
   const int row = rm_row_of(a, j >> 1, blk, G);
@@ -270,29 +273,45 @@ __device__ void rm_producer_mfma(const LdsArgs& a, double* mring, double* sring,
       });
     }
   };
+  // ---- contraction of one tile-ring slot = NKB1 + NKB2 MFMAs in a fixed order (first product, then second), cut into
+  // ncp - 1 segments that the slot's producer runs in the ncp - 1 steps after the slot was filled; outputs after the last
   rm_d4 D1 = zero4, D2 = zero4;
   const double* const srcl = sring + j * C::SS + kq;
-  auto chunk1 = [&](int kk) {
-    const double* src = srcl + (kk % 3) * C::SSLOT;
-    rm_d4 d = zero4;
-    static_for<0, NKB1>([&](auto kb) { d = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kb], src[kb * 4], d, 0, 0, 0); });
-    D1 = d;
-  };
-  auto chunk2 = [&](int kk) {
-    const double* src = srcl + (kk % 3) * C::SSLOT + C::WOFF;
-    rm_d4 d = zero4;
-    static_for<0, NKB2>([&](auto kb) { d = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[kb], src[kb * 4], d, 0, 0, 0); });
-    D2 = d;
-    // rows: register rr holds row 4 rr + kq = (q = rr >> 1, k = 4 (rr & 1) + kq); the cross term of a chain-A column is
-    // rows 0 .. 7 of the second product (-> q = 0), of a chain-B column rows 8 .. 15 (-> q = 1)
-    const bool own = kk != 0 || (oddT && dirj == 0);
-    const int s = e - kk, t = dirj ? T - 1 - s : s;
-    double* out = a.mix_out + ((long)(row < 0 ? 0 : row) * T + t) * 2 * K;
-    static_for<0, 4>([&](auto rr) {
-      const int q = rr >> 1, k = 4 * (rr & 1) + kq;
-      const double v = D1[(int)rr] + ((q == dirj) ? D2[(int)rr] : 0.0);
-      if (row >= 0 && own && k < K) out[q * K + k] = v;
+  constexpr int NKBT = NKB1 + NKB2;
+  auto seg_run = [&](int kk, auto m0_c, auto m1_c) {
+    constexpr int M0 = decltype(m0_c)::value, M1 = decltype(m1_c)::value;
+    const double* src = srcl + (kk % ncp) * C::SSLOT;
+    if constexpr (M0 == 0) { D1 = zero4; D2 = zero4; }
+    static_for<M0, M1>([&](auto m) {
+      if constexpr (m < NKB1) D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[m], src[m * 4], D1, 0, 0, 0);
+      else D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[m - NKB1], src[C::WOFF + (m - NKB1) * 4], D2, 0, 0, 0);
     });
+    if constexpr (M1 == NKBT) {
+      // rows: register rr holds row 4 rr + kq = (q = rr >> 1, k = 4 (rr & 1) + kq); the cross term of a chain-A column is
+      // rows 0 .. 7 of the second product (-> q = 0), of a chain-B column rows 8 .. 15 (-> q = 1)
+      const bool own = kk != 0 || (oddT && dirj == 0);
+      const int s = e - kk, t = dirj ? T - 1 - s : s;
+      double* out = a.mix_out + ((long)(row < 0 ? 0 : row) * T + t) * 2 * K;
+      static_for<0, 4>([&](auto rr) {
+        const int q = rr >> 1, k = 4 * (rr & 1) + kq;
+        const double v = D1[(int)rr] + ((q == dirj) ? D2[(int)rr] : 0.0);
+        if (row >= 0 && own && k < K) out[q * K + k] = v;
+      });
+    }
+  };
+  // segment g (0-based) of slot kk; three producers: two segments per slot, four: three
+  constexpr int B3_1 = NKBT / 2, B4_1 = NKBT / 3, B4_2 = 2 * NKBT / 3;
+  using I0 = std::integral_constant<int, 0>;
+  using IT = std::integral_constant<int, NKBT>;
+  auto segment = [&](int kk, int g) {
+    if (ncp == 3) {
+      if (g == 0) seg_run(kk, I0{}, std::integral_constant<int, B3_1>{});
+      else seg_run(kk, std::integral_constant<int, B3_1>{}, IT{});
+    } else {
+      if (g == 0) seg_run(kk, I0{}, std::integral_constant<int, B4_1>{});
+      else if (g == 1) seg_run(kk, std::integral_constant<int, B4_1>{}, std::integral_constant<int, B4_2>{});
+      else seg_run(kk, std::integral_constant<int, B4_2>{}, IT{});
+    }
   };
 
   lds_barrier();                                            // #0: the rings are zeroed
@@ -305,25 +324,29 @@ __device__ void rm_producer_mfma(const LdsArgs& a, double* mring, double* sring,
     w_0 = w_1; w_1 = w_2; w_2 = w_3; w_3 = w_4;
     lds_barrier();
   }
-  // smoother phase: step k works on local step s = e - k.  The J12 mix of step s - 1: producer 3 (solo: whichever of the
-  // three has no product this step); the contraction of tile-ring slot k - 1 (first product) / k - 2 (second product +
-  // outputs): the producer whose turn it is
+  // smoother phase: step k works on local step s = e - k
   W2 v_0 = wload(e >= 2 ? e - 2 : 0), v_1 = wload(e >= 3 ? e - 3 : 0), v_2 = wload(e >= 4 ? e - 4 : 0);
   for (int k = 0; k <= e; ++k) {
     const int s = e - k;
     const W2 v_3 = wload(s - 4 >= 0 ? s - 4 : 0);           // pair (s - 1) - 3
-    const bool jturn = solo ? (pr >= 0 && k % 3 == pr) : p == 3;
-    if (jturn && k >= 1 && s >= 1) mix(s - 1, v_0, v_0, false, true);
     if (cr >= 0) {
-      if (k >= 2 && (k - 2) % 3 == cr) chunk2(k - 2);
-      if (k >= 1 && (k - 1) % 3 == cr) chunk1(k - 1);
+      // slot k - 1 - g is in its segment g now (g = 0 .. ncp - 2): at most one of them is mine; the producer that has
+      // none this step (rank k % ncp) forms the J12 mix of local step s - 1 -- every step the same load on every SIMD
+      for (int g = ncp - 2; g >= 0; --g) {
+        const int kk = k - 1 - g;
+        if (kk >= 0 && kk % ncp == cr) segment(kk, g);
+      }
+      if (k % ncp == cr && k >= 1 && s >= 1) mix(s - 1, v_0, v_0, false, true);
     }
     if (k >= 1) { v_0 = v_1; v_1 = v_2; v_2 = v_3; }
     lds_barrier();
   }
-  if (cr >= 0) {
-    if (e >= 1 && (e - 1) % 3 == cr) chunk2(e - 1);
-    if (e % 3 == cr) { chunk1(e); chunk2(e); }
+  if (cr >= 0) {                                            // the last slots' remaining segments (nobody overwrites them)
+    for (int k = e + 1; k <= e + ncp - 1; ++k)
+      for (int g = ncp - 2; g >= 0; --g) {
+        const int kk = k - 1 - g;
+        if (kk >= 0 && kk <= e && kk % ncp == cr) segment(kk, g);
+      }
   }
 }
 
@@ -354,7 +377,7 @@ __global__ __launch_bounds__(512) void slds_meanfield_rpc_kernel(const LdsArgs a
   for (int q = threadIdx.x; q < C::LDS_DOUBLES; q += 512) rm_lds[q] = 0.0;   // (NaN bit patterns left by an earlier kernel
                                                                              //  must not meet the zero table entries)
   if (wv >= 4) {
-    if constexpr (REFPROD) rm_producer_ref<N>(a, mring, sring, (wv - 4) * 64 + lane, blk, G);
+    if constexpr (REFPROD) rm_producer_ref<N>(a, mring, sring, (wv - 4) * 64 + lane, blk, G, live_waves == 1 ? 3 : 4);
     else rm_producer_mfma<N>(a, mring, sring, wv - 4, lane, blk, G, live_waves);
     return;
   }
@@ -627,7 +650,7 @@ __global__ __launch_bounds__(512) void slds_meanfield_rpc_kernel(const LdsArgs a
   char* const wbase = sring_b + 8u * (unsigned)(colj * C::SS + C::WOFF + cc);
 
   // one smoother step.  KIND: 0 generic, 1 first (meeting record: G = 0), 2 second (weight of the repeated pair);
-  // kidx = e - s: its index in the phase (tile-ring slot kidx % 3), s: the local step (J12 ring slot s & 1)
+  // kslot: tile-ring slot of this step (its index in the phase modulo the ring depth), s: the local step (J12 ring slot s & 1)
   auto step = [&](auto kind, int s, int kslot, Ops& cur, Ops& fill) {
     constexpr int KIND = decltype(kind)::value;
     load_ops(fill);                          // the next record, into the stage the previous step used
@@ -702,7 +725,8 @@ __global__ __launch_bounds__(512) void slds_meanfield_rpc_kernel(const LdsArgs a
     constexpr std::integral_constant<int, 0> GEN{};
     load_ops(R0);                                                 // record e
     int kslot = 0;
-    auto nxt = [&]() { const int r = kslot; kslot = kslot == 2 ? 0 : kslot + 1; return r; };
+    const int sdepth = live_waves == 1 ? 3 : 4;                   // tile-ring slots in use (= contraction producers)
+    auto nxt = [&]() { const int r = kslot; kslot = kslot == sdepth - 1 ? 0 : kslot + 1; return r; };
     step(std::integral_constant<int, 1>{}, e, nxt(), R0, R1);     // local step e (fetches record e - 1)
     step(std::integral_constant<int, 2>{}, e - 1, nxt(), R1, R0); // e - 1
     int s = e - 2;                                                // (e >= 2: T >= TE_MIN_T)
