@@ -25,6 +25,11 @@
 //     producers 0 - 2 take one slot each in turn: two 16 x 16 x n^2 products (rows: [J11_k ; J22_k] on S~, [J12_k^T ;
 //     J12_k] on W~ -- a chain-A column keeps the first half of the second product, a chain-B column the second), spread
 //     over the two steps that follow, then the (T,2,K) outputs straight from the accumulators.
+// Load balance: with four live consumers every producer shares a SIMD with one, and a step ends when the slowest SIMD
+// is done -- so a tile-ring slot is contracted by ONE producer over the three steps after it was filled (13 MFMAs a
+// step; four slots in flight, one per producer) and the producer that has no segment in a step forms the J12 mix (14):
+// 13 | 13 | 13 | 14 MFMAs per smoother step instead of 14 | 25 | 14 | 0 (same-box A/B: 0.964 -> 0.91 ms at 2048 sequences).
+// (Issue priorities, s_setprio 3 on the producers or on the consumers: +1 - 2 %, off.)
 // Symmetry is used where it is free: C and S~ travel as lower triangles (the ring columns have the layout of a lean
 // hand-off record, so the consumer lanes' symmetric reads / in-order overwriting stores need no selects), which cuts the
 // products from 42 + 14 + 50 to 30 + 14 + 39 MFMAs per step pair -- fp64 MFMAs and the consumers' fp64 vector
@@ -173,18 +178,18 @@ __device__ void rm_producer_ref(const LdsArgs& a, double* mring, double* sring, 
 // launches, the late sweeps of the coordinate ascent): producers 1 - 3 share everything and producer 0 only keeps the
 // barrier count -- fp64 MFMAs and the consumer's fp64 vector instructions contend for the SIMD (measured), so the one
 // chain that is the launch's latency keeps its SIMD to itself.
-template <int N>
+template <int N, bool SOLO>
 __device__ void rm_producer_mfma(const LdsArgs& a, double* mring, double* sring, const int p, const int lane, const int blk,
-                                 const int G, const int live_waves) {
+                                 const int G) {
   using C = RpcMixCfg<N>;
   constexpr int NN = C::NN, TRI = C::TRI, NT = C::NT, NTC = C::NTC, NKB1 = C::NKB1, NKB2 = C::NKB2;
   constexpr int NUC = (NTC + 2) / 3;                        // C tiles of one producer, at most (three or four share them)
   const int T = a.T, K = a.mix_K, e = te_elims(T);
   const bool oddT = (T & 1) != 0;
-  const bool solo = live_waves == 1;
-  const int np = solo ? 3 : 4;                              // producers sharing the mixing tiles
+  constexpr bool solo = SOLO;
+  constexpr int np = solo ? 3 : 4;                          // producers sharing the mixing tiles
   const int pr = solo ? p - 1 : p;                          // my rank among them (-1: none of it)
-  const int ncp = solo ? 3 : 4;                             // contraction producers = tile-ring slots in use
+  constexpr int ncp = solo ? 3 : 4;                         // contraction producers = tile-ring slots in use
   const int cr = solo ? p - 1 : p;                          // my rank among them (-1: none)
   const int kq = lane >> 4, r16 = lane & 15;
   const int j = r16, dirj = j & 1;                          // this lane's column (B operand / C-D layout: column = lane % 16)
@@ -299,12 +304,12 @@ __device__ void rm_producer_mfma(const LdsArgs& a, double* mring, double* sring,
       });
     }
   };
-  // segment g (0-based) of slot kk; three producers: two segments per slot, four: three
-  constexpr int B3_1 = NKBT / 2, B4_1 = NKBT / 3, B4_2 = 2 * NKBT / 3;
+  // segment g (0-based) of slot kk; three producers: two segments per slot (the first product | the second), four: three
+  constexpr int B3_1 = NKB1, B4_1 = NKBT / 3, B4_2 = 2 * NKBT / 3;
   using I0 = std::integral_constant<int, 0>;
   using IT = std::integral_constant<int, NKBT>;
   auto segment = [&](int kk, int g) {
-    if (ncp == 3) {
+    if constexpr (ncp == 3) {
       if (g == 0) seg_run(kk, I0{}, std::integral_constant<int, B3_1>{});
       else seg_run(kk, std::integral_constant<int, B3_1>{}, IT{});
     } else {
@@ -377,11 +382,18 @@ __global__ __launch_bounds__(512) void slds_meanfield_rpc_kernel(const LdsArgs a
   for (int q = threadIdx.x; q < C::LDS_DOUBLES; q += 512) rm_lds[q] = 0.0;   // (NaN bit patterns left by an earlier kernel
                                                                              //  must not meet the zero table entries)
   if (wv >= 4) {
+#ifdef SVAE_RM_PRODPRIO
+    __builtin_amdgcn_s_setprio(SVAE_RM_PRODPRIO);      // (experiment: the producers' issue priority against their SIMD's consumer)
+#endif
     if constexpr (REFPROD) rm_producer_ref<N>(a, mring, sring, (wv - 4) * 64 + lane, blk, G, live_waves == 1 ? 3 : 4);
-    else rm_producer_mfma<N>(a, mring, sring, wv - 4, lane, blk, G, live_waves);
+    else if (live_waves == 1) rm_producer_mfma<N, true>(a, mring, sring, wv - 4, lane, blk, G);
+    else rm_producer_mfma<N, false>(a, mring, sring, wv - 4, lane, blk, G);
     return;
   }
 
+#ifdef SVAE_RM_CONSPRIO
+  __builtin_amdgcn_s_setprio(SVAE_RM_CONSPRIO);        // (experiment: the consumers' issue priority against their SIMD's producer)
+#endif
   // ---- consumers: lds_estep_twoend_rpc.hpp with per-step parameters from the ring -----------------------------------------------
   const int c = lane & 15;
   const int g = lane >> 4;

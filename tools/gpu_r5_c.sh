@@ -1,0 +1,12 @@
+#!/bin/bash
+# Round 5, call C: a changed SLDS producer kernel -- parity vs the table kernel (both producer forms), timing, SLDS tests, ascent
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+cd $REPO; mkdir -p gpurun_out/r5c
+timeout 240 python tools/slds_rpc_debug.py --only rpc_ref > gpurun_out/r5c/debug_ref.log 2>&1; echo "debug ref rc=$?"; grep -E "MISMATCH|ALL OK|Error|error" gpurun_out/r5c/debug_ref.log | head
+timeout 300 python tools/slds_rpc_debug.py --only rpc_mfma --time > gpurun_out/r5c/debug_mfma.log 2>&1; echo "debug mfma rc=$?"; grep -E "MISMATCH|ALL OK|Error|error|ms per" gpurun_out/r5c/debug_mfma.log | head -40
+timeout 900 python -m pytest tests/test_slds_hip.py tests/test_distributed_hip.py -m gpu -q 2>&1 | tail -4
+timeout 300 python - <<'PY'
+import json, torch, bench
+dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
+print(json.dumps(bench.measure_slds(dev)))
+PY
