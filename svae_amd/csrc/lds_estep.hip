@@ -14,7 +14,7 @@ extern "C" {
   int svae_lds_launch_split_n##NN(const svae::LdsArgs*, int, void*);           \
   int svae_lds_launch_twoend_n##NN(const svae::LdsArgs*, int, int, int, void*);          \
   int svae_lds_launch_twoend_mix_n##NN(const svae::LdsArgs*, void*);          \
-  int svae_lds_launch_slds_rpc_n##NN(const svae::LdsArgs*, int, void*);       \
+  int svae_lds_launch_slds_rpc_n##NN(const svae::LdsArgs*, int, int, void*);  \
   int svae_lds_launch_filter_n##NN(const svae::LdsArgs*, int, void*);          \
   int svae_lds_launch_filter_split_n##NN(const svae::LdsArgs*, int, void*);    \
   int svae_lds_launch_filter_1r_n##NN(const svae::LdsArgs*, int, void*);       \
@@ -385,7 +385,8 @@ int svae_slds_lds_meanfield_f64(int B, int rows, int T, int n, int K,
   a.msg_Jp = a.msg_hp = a.msg_Jf = a.msg_hf = nullptr;
   a.mix_w = weights; a.mix_out = pair_contr; a.seq_index = seq_index; a.mix_K = K; a.lds_keep = 0; a.tile_half = 0; a.sig_out = nullptr;
   switch (n) {
-#define SVAE_CASE_(NN) case NN: return rpc ? svae_lds_launch_slds_rpc_n##NN(&a, (options & SVAE_OPT_PRODUCERS_OFF) ? 1 : 0, stream) \
+#define SVAE_CASE_(NN) case NN: return rpc ? svae_lds_launch_slds_rpc_n##NN(&a, (options & SVAE_OPT_PRODUCERS_OFF) ? 1 : 0, \
+                                                                              (options & SVAE_OPT_LAYOUT_PACKED) ? 0 : 1, stream) \
                                         : svae_lds_launch_twoend_mix_n##NN(&a, stream);
 #define SVAE_CASE(NN) SVAE_CASE_(NN)
 #ifdef SVAE_ONLY_N

@@ -45,8 +45,8 @@ extern "C" int SVAE_CAT(svae_lds_launch_twoend_mix_n, SVAE_N)(const svae::LdsArg
 }
 
 // the SLDS mean-field step in the row-per-chain layout with producer wavefronts (refprod != 0: reference producers)
-extern "C" int SVAE_CAT(svae_lds_launch_slds_rpc_n, SVAE_N)(const svae::LdsArgs* a, int refprod, void* stream) {
-  return svae::launch_slds_meanfield_rpc<SVAE_N>(*a, refprod, (hipStream_t)stream);
+extern "C" int SVAE_CAT(svae_lds_launch_slds_rpc_n, SVAE_N)(const svae::LdsArgs* a, int refprod, int seq_ok, void* stream) {
+  return svae::launch_slds_meanfield_rpc<SVAE_N>(*a, refprod, seq_ok, (hipStream_t)stream);
 }
 
 extern "C" int SVAE_CAT(svae_lds_launch_filter_n, SVAE_N)(const svae::LdsArgs* a, int inhomog, void* stream) {

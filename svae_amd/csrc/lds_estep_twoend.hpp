@@ -155,9 +155,22 @@ __device__ __forceinline__ void te_gauss_jordan(double (&M)[N], const double (&E
 // chain (lds_estep_twoend_s4.hpp).
 // (the body as a device function of the workgroup index `blk`: lds_forward_pair_kernel, lds_filter_1r.hpp, runs it next
 //  to the one-directional filter in ONE launch)
-template <int N, bool INHOMOG, bool LEAN, bool MIX = false, bool CROSS = false, bool S4 = false>
-__device__ __forceinline__ void lds_estep_twoend_body(const LdsArgs& a, const int blk) {
+// RING (round 5; the one-sequence consumer of lds_estep_twoend_rpcmix.hpp's producer wavefronts): per-step parameters of
+// the SLDS mean field as in MIX, but mixed by PRODUCER wavefronts of the same workgroup into an LDS ring (`ring_m`: per
+// column [nat J12 (n^2) | C lower triangle | zeros], columns 0 / 1 = chain A / B, slot = local step & 1), the node's
+// tiles for the K-state contraction left in a second ring (`ring_s`, `ring_depth` slots: [S~ lower triangle | junk | W~]);
+// lean records; one LDS-only barrier per step, 2 e + 3 in all (the producers execute the same count).
+struct TeRing {
+  double* m; double* s;      // mixing ring, tile ring (LDS)
+  int cs, mixslot;           // doubles: column stride / slot stride of the mixing ring
+  int ss, sslot, woff;       // ... of the tile ring; offset of W~ in a column
+  int depth;                 // tile-ring slots in use
+};
+
+template <int N, bool INHOMOG, bool LEAN, bool MIX = false, bool CROSS = false, bool S4 = false, bool RING = false>
+__device__ __forceinline__ void lds_estep_twoend_body(const LdsArgs& a, const int blk, const TeRing ring = TeRing{}) {
   static_assert(!S4 || (LEAN && !INHOMOG && !MIX && !CROSS), "S4: the homogeneous lean variant only");
+  static_assert(!RING || (INHOMOG && LEAN && !MIX && !CROSS && !S4), "RING: per-step parameters from the ring, lean records");
   static_assert(N >= 1 && N <= TE_MAX_N && N + ((N - 1) >> 1) <= 14,
                 "the right-hand-side columns must fit lanes N..14 of two DPP rows");
   static_assert(!MIX || (INHOMOG && !LEAN), "MIX: per-step parameters, full hand-off record");
@@ -188,7 +201,7 @@ __device__ __forceinline__ void lds_estep_twoend_body(const LdsArgs& a, const in
   const int bslot = MIX ? wv * (int)gridDim.x + blk : blk;
   // MIX: row of every array (and of the workspace) this launch slot works on (surplus slots: any valid row)
   // (a negative entry of seq_index marks an unused slot: its wavefront helps stage the tables, then leaves)
-  const int braw = !MIX ? bslot : (a.seq_index ? a.seq_index[bslot < a.B ? bslot : 0] : bslot);
+  const int braw = (!MIX && !RING) ? bslot : (a.seq_index ? a.seq_index[bslot < a.B ? bslot : 0] : bslot);
   const int b = braw < 0 ? 0 : braw;
   double* tab = tab_static;               // (MIX keeps the full hand-off record: no transposition tile)
   // re-replication tile of the elimination phase, [chain][row 0..N][16]: S4 borrows the exchange buffer (used at the very
@@ -233,7 +246,7 @@ __device__ __forceinline__ void lds_estep_twoend_body(const LdsArgs& a, const in
   constexpr int NXL = te_mix_nxl(N);
   constexpr int ENT_J = te_mix_ent_j(N), ENT_C = te_mix_ent_c(N);
   constexpr int NC2 = (N + 1) / 2;
-  const int K = MIX ? a.mix_K : 0, KP2 = (K + 1) >> 1;
+  const int K = (MIX || RING) ? a.mix_K : 0, KP2 = (K + 1) >> 1;
   double2* t_j = te_dyn;
   double2* t_22 = t_j + KP2 * N * ENT_J;
   double2* t_11 = t_22 + KP2 * J * ENT_C;
@@ -354,13 +367,40 @@ __device__ __forceinline__ void lds_estep_twoend_body(const LdsArgs& a, const in
     });
   };
   if (!INHOMOG) load_pair(0, true);
+  // RING: this lane's ring entries (bytes within a mixing-ring slot; column = the chain).  rJ[i]: J12'[i][x] in the
+  // right-hand-side lanes, J12'[i][c] in lanes < N (chain B: J12' = J12^T), a zero entry elsewhere; rC[j]: C[2j+gl][c]
+  // from the triangle (lanes < N of real rows), else a zero entry
+  constexpr int RTRI = N * (N + 1) / 2;
+  unsigned rJ[RING ? N : 1], rC[RING ? J : 1];
+  if constexpr (RING) {
+    const unsigned cb = (unsigned)(dir * ring.cs), zero_e = (unsigned)(N * N + RTRI);
+    static_for<0, N>([&](auto i) {
+      const unsigned ent = xok ? (unsigned)(dir ? xx * N + i : i * N + xx) : (col ? (unsigned)(dir ? c * N + i : i * N + c) : zero_e);
+      rJ[i] = 8u * (cb + ent);
+    });
+    static_for<0, J>([&](auto j) {
+      const int i = 2 * j + gl, hi = i > c ? i : c, lo = i > c ? c : i;
+      rC[j] = 8u * (cb + (unsigned)((col && i < N) ? N * N + hi * (hi + 1) / 2 + lo : N * N + RTRI));
+    });
+  }
+  auto ring_pair = [&](int slot, bool with_cc) {      // what load_pair does, from ring slot `slot`
+    const char* base = reinterpret_cast<const char*>(ring.m) + 8u * (unsigned)(slot * ring.mixslot);
+    static_for<0, N>([&](auto i) {
+      const double v = *reinterpret_cast<const double*>(base + rJ[RING ? (int)i : 0]);
+      EX[i] = __builtin_fma(-rmask, v, E[i]);         // right-hand-side lanes: info-form J12' = -nat; lanes < N: identity row
+      NJ12c[i] = jcmask * v;
+    });
+    if (with_cc) static_for<0, J>([&](auto j) {
+      Cc[j] = *reinterpret_cast<const double*>(base + rC[RING ? (int)j : 0]);
+    });
+  };
 
   // ---- elimination (filter) phase -------------------------------------------------------------------
   // An (replicated over the chain's two DPP rows): lanes < N = pivot block of the next node without its
   // node potential (incoming message + J11' of the pair ahead), lane 15 = incoming potential vector,
   // lanes N..14 zero.
   double An[N];
-  if constexpr (MIX) {
+  if constexpr (MIX || RING) {
     // init potential mixed by E[z_0], J11' of the chain's pair 0 by its own node's weights (once per sequence:
     // straight from global memory)
     const double* w0 = a.mix_w + (long)b * T * K;
@@ -484,7 +524,8 @@ __device__ __forceinline__ void lds_estep_twoend_body(const LdsArgs& a, const in
     pJn += nstep; phn += nstep;            // node s + 1 <= e: the meeting node's potentials included
     Jo_n = *pJn;
     ho_n = *phn;
-    if (INHOMOG && !MIX) load_pair(s, true);
+    if constexpr (RING) ring_pair(s & 1, true);
+    else if (INHOMOG && !MIX) load_pair(s, true);
     double wq[2] = {wr0 * wmask, wr1 * wmask};     // MIX: lane k = weight of state k (pair s, pair s + 1)
     if constexpr (MIX) {
       wr0 = wr1;
@@ -577,8 +618,13 @@ __device__ __forceinline__ void lds_estep_twoend_body(const LdsArgs& a, const in
         else { double dummy; pair_split(AnD[j], An[2 * j], dummy); }
       });
     }
+    if constexpr (RING) lds_barrier();     // the next step's parameters are in the other ring slot
     TE_TICK(3)
   };
+  if constexpr (RING) {
+    lds_barrier();                          // #0: the rings are zeroed
+    lds_barrier();                          // #1: the producers have left step 0's parameters in slot 0
+  }
   {
     // (two loops, not a branch around the stores: a conditional store makes hipcc wait for the previous step's stores)
     const int s_hbm = keep > 0 ? (s0 < e ? s0 : e) : e;       // steps whose record goes to the HBM workspace
@@ -611,6 +657,15 @@ __device__ __forceinline__ void lds_estep_twoend_body(const LdsArgs& a, const in
       }
       static_for<0, N>([&](auto i) {
         M[i] = __builtin_fma(JoX, E[i], (An[i] + Mp[i]) - (col ? -2.0 * dbl[i] : 0.0));
+      });
+    } else if constexpr (RING) {
+      // C of the last elimination step (ring slot (e - 1) & 1, untouched since), every row in every DPP row
+      const char* base = reinterpret_cast<const char*>(ring.m) + 8u * (unsigned)(((e - 1) & 1) * ring.mixslot);
+      static_for<0, N>([&](auto i) {
+        const int hi = i > c ? i : c, lo = i > c ? c : i;
+        const unsigned ent = (unsigned)(dir * ring.cs) + (unsigned)(col ? N * N + hi * (hi + 1) / 2 + lo : N * N + RTRI);
+        const double dbl = *reinterpret_cast<const double*>(base + 8u * ent);
+        M[i] = __builtin_fma(JoX, E[i], (An[i] + Mp[i]) - dbl);
       });
     } else {
       static_for<0, N>([&](auto i) {
@@ -646,12 +701,12 @@ __device__ __forceinline__ void lds_estep_twoend_body(const LdsArgs& a, const in
     if (a.node_logZ) {
       for (int t = c; t < T; t += 16) z += a.node_logZ[(long)b * T + t];
     }
-    if (INHOMOG && !MIX) {
+    if (INHOMOG && !MIX && !RING) {
       const double* lz = a.logZ_pair + (a.pair_seq_stride ? (long)b * (T - 1) : 0);
       for (int t = c; t < T - 1; t += 16) z += lz[t];
     }
     // (MIX: the mixed log-normaliser constants sum_k w_k logZ_k are the caller's, a (B,T,K) x (K) product)
-    double total = row_sum16(z) + chain_total + meet_total + (MIX ? 0.0 : a.init_logZ[0]);
+    double total = row_sum16(z) + chain_total + meet_total + ((MIX || RING) ? 0.0 : a.init_logZ[0]);
     if (!INHOMOG) total += (double)(T - 1) * a.logZ_pair[0];
     if (lane == 0) a.lognorm[b] = total;
     const bool lane_bad = col && (!(vworst < 0.0) || !(vfull_m < 0.0));
@@ -712,6 +767,7 @@ __device__ __forceinline__ void lds_estep_twoend_body(const LdsArgs& a, const in
   //   full:  H[k] = [X | c][c][k] (row c of the record; lane N: e_N; lanes > N: 0), Gc[j][c] = [X | c][2j+gl][c]
   //          (row N: e_N), Pi[j][c] = P^-1[2j+gl][c]
   //   LEAN:  Pi[j] = [P^-1 | c][2j+gl][c] (lane N: c_i; rows >= N, lanes > N: the record's zero entry)
+  int rslot = 0;                          // RING: tile-ring slot of the current smoother step
   struct Ops { double H[LEAN ? 1 : N + 1]; double Gc[LEAN ? 1 : J1]; double Pi[J1]; };
   const double* hp_ = col ? rec0 + c * RW + N : (c == N ? zpage : zpage + N + 2);
   const long hstride = col ? WS : 0;
@@ -756,7 +812,8 @@ __device__ __forceinline__ void lds_estep_twoend_body(const LdsArgs& a, const in
   auto step = [&](auto kind, int s, Ops& cur, Ops& nxt) {
     constexpr int KIND = decltype(kind)::value;
     load_ops(nxt, s > 1);                    // prefetch record s-1 (s = 0: re-reads record 0, unused)
-    if (INHOMOG && LEAN && KIND != 1) load_pair(s, false);   // G~ of step s uses pair s (the meeting record: G = 0)
+    if constexpr (RING) { if (KIND != 1) ring_pair(s & 1, false); }
+    else if (INHOMOG && LEAN && KIND != 1) load_pair(s, false);   // G~ of step s uses pair s (the meeting record: G = 0)
 
     double Gc[J1], H[N + 1];
     if constexpr (LEAN) {
@@ -873,6 +930,21 @@ __device__ __forceinline__ void lds_estep_twoend_body(const LdsArgs& a, const in
       double* q3 = wr ? q1 + K : trash + 1;
       *q1 = e1 + d1;
       *q3 = e3 + d3;
+    } else if constexpr (RING) {
+      // this node's tiles for the producers' contraction with the K parameter sets: S~ rows < N as a lower triangle,
+      // the cross moment W~ rows < N -- zero where the pair is not this chain's to count (the meeting record has G = 0,
+      // hence W~ rows < N = 0); everything else of the slot registers goes to the column's junk entries
+      char* base = reinterpret_cast<char*>(ring.s) + 8u * (unsigned)(rslot * ring.sslot + dir * ring.ss);
+      const double fX = (KIND == 2 && skip2nd) ? 0.0 : 1.0;
+      static_for<0, J>([&](auto j) {
+        const int i = 2 * j + gl;
+        const int junk = RTRI + (c <= N ? c : N + 1);               // the column's n + 2 junk entries
+        const unsigned es = (unsigned)((i < N && c <= i) ? i * (i + 1) / 2 + c : junk);
+        const unsigned ew = (unsigned)((i < N && col) ? ring.woff + i * N + c : junk);
+        *reinterpret_cast<double*>(base + 8u * es) = Sn[j];
+        *reinterpret_cast<double*>(base + 8u * ew) = fX * W[j];
+      });
+      rslot = rslot + 1 == ring.depth ? 0 : rslot + 1;
     } else if (INHOMOG) {
       // per-step pair blocks [E x_t x_t' | E x_t x_{t+1}' | E x_{t+1} x_{t+1}'] for pair index p:
       // the owner of node t writes S~_t into pair t (first block) and pair t-1 (third block); the
@@ -913,6 +985,7 @@ __device__ __forceinline__ void lds_estep_twoend_body(const LdsArgs& a, const in
     if constexpr (KIND == 1) node_ptrs(e - 1);
     else { pdg += dlane ? nstride : 0; pex += xlane ? nstride : 0; }
     static_for<0, J1>([&](auto j) { S[j] = Sn[j]; });
+    if constexpr (RING) lds_barrier();       // the tiles are in the ring; the next step's J12 is in its slot
   };
 
   {
@@ -922,11 +995,19 @@ __device__ __forceinline__ void lds_estep_twoend_body(const LdsArgs& a, const in
     step(std::integral_constant<int, 1>{}, e, A, Bq);
     step(std::integral_constant<int, 2>{}, e - 1, Bq, A);
     int s = e - 2;
-    for (; s >= 2; s -= 2) {          // two steps per trip: the prefetch buffers ping-pong
-      step(GEN, s, A, Bq);
-      step(GEN, s - 1, Bq, A);
+    if constexpr (RING) {
+      // one step per trip, the stage copied.  (The two-steps-per-trip form below gave WRONG results from the second call
+      // site on for N = 4, and only N = 4, in this instantiation -- every other N, the same body without RING, and the
+      // row-per-chain consumer with the same structure are right; hipcc 7.2, not understood.  tools/slds_rpc_debug.py
+      // --sweep runs every N against the table kernel.)
+      for (; s >= 1; --s) { step(GEN, s, A, Bq); A = Bq; }
+    } else {
+      for (; s >= 2; s -= 2) {          // two steps per trip: the prefetch buffers ping-pong
+        step(GEN, s, A, Bq);
+        step(GEN, s - 1, Bq, A);
+      }
+      if (s == 1) { step(GEN, 1, A, Bq); A = Bq; }     // (copy: no swapped call sites, the buffers stay in registers)
     }
-    if (s == 1) { step(GEN, 1, A, Bq); A = Bq; }     // (copy: no swapped call sites, the buffers stay in registers)
     step(GEN, 0, A, Bq);
   }
 #ifdef SVAE_PHASE_TIMING

@@ -304,8 +304,9 @@ __device__ void rm_producer_mfma(const LdsArgs& a, double* mring, double* sring,
       });
     }
   };
-  // segment g (0-based) of slot kk; three producers: two segments per slot (the first product | the second), four: three
-  constexpr int B3_1 = NKB1, B4_1 = NKBT / 3, B4_2 = 2 * NKBT / 3;
+  // segment g (0-based) of slot kk; three producers: two segments per slot (halves: with the one-sequence consumer the
+  // producers ARE the step's critical path -- 19 | 20 | 14 MFMAs instead of 14 | 25 | 14: 0.544 -> 0.504 ms), four: three
+  constexpr int B3_1 = NKBT / 2, B4_1 = NKBT / 3, B4_2 = 2 * NKBT / 3;
   using I0 = std::integral_constant<int, 0>;
   using IT = std::integral_constant<int, NKBT>;
   auto segment = [&](int kk, int g) {
@@ -757,9 +758,38 @@ __global__ __launch_bounds__(512) void slds_meanfield_rpc_kernel(const LdsArgs a
   }
 }
 
-// options: 0 = MFMA producers; 1 = reference producers (plain loops: test infrastructure)
+// ---- one sequence per workgroup (launches of at most one sequence per CU: the late sweeps of the coordinate ascent) ------
+// The row-per-chain consumer issues every instruction for TWO sequences; a lone sequence pays for both (1070 instructions
+// per step pair).  Here the consumer is the ONE-sequence two-ended body (lds_estep_twoend.hpp, RING: both chains in one
+// instruction stream, one-register Gauss-Jordan, lean records) -- wavefront 0 -- next to three producers (wavefronts 1 - 3,
+// the solo split of rm_producer_mfma): four wavefronts on four SIMDs, the consumer alone on its own.
 template <int N>
-static int launch_slds_meanfield_rpc(const LdsArgs& a, int refprod, hipStream_t stream) {
+__global__ __launch_bounds__(256) void slds_meanfield_seq_kernel(const LdsArgs a) {
+  static_assert(N >= 1 && N <= TE_MAX_N, "latent dimension");
+  using C = RpcMixCfg<N>;
+  extern __shared__ double rm_lds[];
+  double* const mring = rm_lds;
+  double* const sring = rm_lds + C::OFF_S;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int blk = blockIdx.x, G = gridDim.x;             // G = a.B: position 0 of workgroup blk is slot blk, the rest unused
+  if (rm_row_of(a, 0, blk, G) < 0) return;               // unused slot: the whole workgroup leaves before its first barrier
+  for (int q = threadIdx.x; q < C::OFF_TAB; q += 256) rm_lds[q] = 0.0;
+  if (wv >= 1) {
+    rm_producer_mfma<N, true>(a, mring, sring, wv, lane, blk, G);
+    return;
+  }
+  TeRing ring;
+  ring.m = mring; ring.s = sring;
+  ring.cs = C::CS; ring.mixslot = C::MIXSLOT;
+  ring.ss = C::SS; ring.sslot = C::SSLOT; ring.woff = C::WOFF;
+  ring.depth = 3;
+  lds_estep_twoend_body<N, true, true, false, false, false, true>(a, blk, ring);
+}
+
+// refprod: 0 = MFMA producers; 1 = reference producers (plain loops: test infrastructure).  seq_ok: launches of at most
+// one sequence per CU may take the one-sequence consumer (0: always the row-per-chain consumers)
+template <int N>
+static int launch_slds_meanfield_rpc(const LdsArgs& a, int refprod, int seq_ok, hipStream_t stream) {
   if constexpr (N <= TE_MAX_N) {
     if (a.mix_K < 1 || a.mix_K > RPCMIX_MAX_K || a.T < TE_MIN_T) return -30;
     const long bytes = rpcmix_lds_bytes(N);
@@ -770,6 +800,14 @@ static int launch_slds_meanfield_rpc(const LdsArgs& a, int refprod, hipStream_t 
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (cus < 1) cus = 256;
+    if (!refprod && seq_ok && a.B <= cus) {                // at most one sequence per CU: the one-sequence consumer
+      static LdsGrant grant_seq;
+      auto kern = slds_meanfield_seq_kernel<N>;
+      const long sbytes = 8L * RpcMixCfg<N>::OFF_TAB;
+      if (!grant_seq.ensure(reinterpret_cast<const void*>(kern), sbytes)) return -31;
+      hipLaunchKernelGGL(kern, dim3(a.B), dim3(256), (size_t)sbytes, stream, a);
+      return hipGetLastError() == hipSuccess ? 0 : -1000;
+    }
     int W = (a.B + cus - 1) / cus;
     W = W < 1 ? 1 : (W > 8 ? 8 : W);
     const int grid = (a.B + W - 1) / W;

@@ -16,7 +16,7 @@ from svae_amd.lds.synthetic_data import rand_slds_global_natparam  # noqa: E402
 from svae_amd.models import slds_svae                        # noqa: E402
 
 OPTS = {"tables": _lib.OPT_LAYOUT_SPLIT, "rpc_ref": _lib.OPT_LAYOUT_PACKED | _lib.OPT_PRODUCERS_OFF,
-        "rpc_mfma": _lib.OPT_LAYOUT_PACKED}
+        "rpc_mfma": _lib.OPT_LAYOUT_PACKED, "default": 0}      # default: one-sequence consumer up to one sequence per CU
 dev = torch.device("cuda:0")
 
 
@@ -62,9 +62,25 @@ def compare(a, b, tag):
     return worst
 
 
+def sweep():
+    """which shapes the default dispatch (one-sequence consumer for small launches) gets right"""
+    for K in (3, 8):
+        for n in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10):
+            for T in (9, 12):
+                args = setup(K, n, T, 5, seed=K + T + n)
+                base = run("tables", K, n, T, 5, args)
+                got = run("default", K, n, T, 5, args)
+                rel = max(float((base[k] - got[k]).abs().max()) / (float(base[k].abs().max()) + 1e-300) for k in ("lognorm", "x", "dxx", "nodep", "E_init"))
+                d = (base["nodep"] - got["nodep"]).abs().amax(dim=(0, 2))
+                print("K=%d n=%2d T=%2d  %s  %.1e  nodep steps off: %s" % (K, n, T, "ok      " if rel < 1e-9 else "MISMATCH", rel,
+                      (d > 1e-9 * float(base["nodep"].abs().max())).nonzero().flatten().tolist()), flush=True)
+
+
 def main():
+    if "--sweep" in sys.argv:
+        return sweep()
     only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
-    kernels = [k for k in ("rpc_ref", "rpc_mfma") if only in (None, k)]
+    kernels = [k for k in ("rpc_ref", "rpc_mfma", "default") if only in (None, k)]
     ok = True
     for (K, n, T, B, rows) in ((8, 10, 12, 8, None), (8, 10, 13, 8, None), (3, 4, 9, 5, None), (8, 10, 40, 21, "idx"),
                                (5, 7, 4, 16, None), (8, 10, 101, 70, "idx"), (8, 10, 500, 16, None)):
@@ -87,7 +103,7 @@ def main():
         K, n, T = 8, 10, 500
         for B in (1, 8, 64, 256, 512, 1024, 2048):
             dense_init, dense_pair, node, w = setup(K, n, T, B, seed=1)
-            for kern in ("tables", "rpc_mfma"):
+            for kern in ("tables", "rpc_mfma", "default"):
                 plan = slds_svae.SLDSMeanfieldPlan(B, T, n, K, dev, options=OPTS[kern])
                 for _ in range(3):
                     plan.launch(dense_init, dense_pair, w, node)
