@@ -61,7 +61,14 @@ def test_estep_kernel_isa_has_no_dpp_hazards(n, tmp_path):
         txt = out.read_text()
         # (the one AGPR instruction allowed is the occupancy marker `v_accvgpr_write_b32 a63, 0` of the kernels that
         #  run two at a time, one wavefront per SIMD: lds_estep_split.hpp FILT, lds_estep_twoend.hpp CROSS, lds_filter_1r.hpp)
-        acc = [l for l in txt.splitlines() if "v_accvgpr" in l and "v_accvgpr_write_b32 a63, 0" not in l]
+        # (... and the SLDS producer-wavefront kernels, whose MFMA accumulators may legitimately live in AGPRs: their
+        #  sections are judged on scratch alone)
+        acc, fn = [], ""
+        for l in txt.splitlines():
+            if l.startswith("_Z") and l.rstrip().split(";")[0].strip().endswith(":"):
+                fn = l
+            if "v_accvgpr" in l and "v_accvgpr_write_b32 a63, 0" not in l and "slds_meanfield" not in fn:
+                acc.append(l)
         assert "scratch_" not in txt and acc == [], acc[:5]
 
 

@@ -168,8 +168,9 @@ def test_withlabels_matches_oracle():
 
 
 def _fused_options(kernel):
-    """kernel-selection word of svae_slds_lds_meanfield_f64: the library's choice; the table kernel of rounds 2 - 4 (one
-    sequence per wavefront); the round-5 kernel (row-per-chain consumers + producer wavefronts) with reference producers
+    """kernel-selection word of svae_slds_lds_meanfield_f64: the library's choice (K <= 8: up to one sequence per CU the
+    one-sequence consumer next to three MFMA producers, above the row-per-chain consumers with four); the table kernel of
+    rounds 2 - 4 (one sequence per wavefront); the row-per-chain kernel whatever the batch, with reference producers
     (plain loops) and with the MFMA producers"""
     from svae_amd import _lib
     return {"default": 0, "tables": _lib.OPT_LAYOUT_SPLIT, "rpc_ref": _lib.OPT_LAYOUT_PACKED | _lib.OPT_PRODUCERS_OFF,
@@ -178,7 +179,8 @@ def _fused_options(kernel):
 
 @pytest.mark.parametrize("kernel", ["tables", "rpc_ref", "rpc_mfma", "default"])
 @pytest.mark.parametrize("K,n,T,B", [(3, 4, 9, 5), (8, 10, 40, 11), (7, 10, 5, 3), (16, 6, 12, 4), (2, 2, 4, 2),
-                                     (5, 7, 13, 21), (8, 10, 6, 9), (8, 9, 4, 17), (1, 3, 7, 8), (8, 10, 31, 40)])
+                                     (5, 7, 13, 21), (8, 10, 6, 9), (8, 9, 4, 17), (1, 3, 7, 8), (8, 10, 31, 40),
+                                     (8, 4, 16, 6), (3, 1, 8, 3), (8, 5, 10, 4), (8, 8, 11, 7), (6, 4, 8, 300)])
 def test_fused_lds_meanfield_step_matches_materialised(K, n, T, B, kernel):
     """One LDS mean-field step through svae_slds_lds_meanfield_f64 (K parameter sets in LDS, mixed per step
     by the HMM marginals, pair statistics contracted in the kernel) against the path that materialises the
