@@ -180,7 +180,7 @@ def _fused_options(kernel):
 @pytest.mark.parametrize("kernel", ["tables", "rpc_ref", "rpc_mfma", "default"])
 @pytest.mark.parametrize("K,n,T,B", [(3, 4, 9, 5), (8, 10, 40, 11), (7, 10, 5, 3), (16, 6, 12, 4), (2, 2, 4, 2),
                                      (5, 7, 13, 21), (8, 10, 6, 9), (8, 9, 4, 17), (1, 3, 7, 8), (8, 10, 31, 40),
-                                     (8, 4, 16, 6), (3, 1, 8, 3), (8, 5, 10, 4), (8, 8, 11, 7), (6, 4, 8, 300)])
+                                     (8, 4, 16, 6), (3, 2, 8, 3), (8, 5, 10, 4), (8, 8, 11, 7), (6, 4, 8, 300)])
 def test_fused_lds_meanfield_step_matches_materialised(K, n, T, B, kernel):
     """One LDS mean-field step through svae_slds_lds_meanfield_f64 (K parameter sets in LDS, mixed per step
     by the HMM marginals, pair statistics contracted in the kernel) against the path that materialises the
