@@ -667,6 +667,11 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
   }
 
   }   // forward half
+#ifdef SVAE_TILE_TIMING
+  if ((HALF == 1 || half == 1) && lane == 0 && wave < 2) {
+    for (int q = 0; q < 12; ++q) a.E_init[(long)b * (nn + n) + 12 * wave + q] = (double)tm[q];
+  }
+#endif
   if (HALF == 1 || half == 1) return;
   __syncthreads();
 #ifdef SVAE_TILE_FWD_ONLY   // register-pressure experiments
