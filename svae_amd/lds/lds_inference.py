@@ -13,6 +13,7 @@ are obtained with `reduce_stats`).
 All arithmetic happens in libsvae_hip.so (svae_lds_estep_f64); this file only validates, lays out
 buffers and launches.  No CPU fallback.
 """
+import numpy as np
 import torch
 
 from .. import _lib
@@ -250,6 +251,83 @@ class LDSEStepPlan(object):
                                      "global natural parameters are not valid)" % (v - 1))
 
 
+def _is_dense_nodes(node_params):
+    if not isinstance(node_params, (tuple, list)) or len(node_params) < 2:
+        return False
+    nd = lambda x: x.dim() if isinstance(x, torch.Tensor) else np.ndim(x)
+    return nd(node_params[0]) == nd(node_params[1]) + 1
+
+
+def _fold_dense_nodes(natparam, node_params):
+    """Dense node potentials J (T,n,n) / (B,T,n,n) of the reference's Python path (`natural_condition_on_general`,
+    svae/lds/gaussian.py:46-49; `_canonical_node_params`, lds_inference.py:65-82 -- the compiled path takes diagonal ones
+    only, cython_lds_inference.pyx:43).  Every step of the filter, the smoother and the sampler sees the node potential of
+    step t only in the sum J_pred[t] + Jo[t] (+ J11[t]) -- `natural_predict`, `natural_rts_backward_step`,
+    `natural_condition_on(J_filt, ., ., J11, J12)` -- so the off-diagonal part of Jo[t] is exactly a contribution to the
+    pair block of x_t: J11[t] += offdiag(Jo[t]) for t < T-1 and J22[T-2] += offdiag(Jo[T-1]) (init_J for T = 1), with
+    per-step, per-sequence pair parameters.  The kernels then run with the diagonal of Jo; only the forward MESSAGES differ
+    by these terms (put back in `natural_filter_forward_general`).
+    -> (natparam', node_params' batched (B,T,n), info)"""
+    init_params, pair_params = natparam
+    dev = None
+    for x in list(node_params) + list(init_params[:2]):
+        if isinstance(x, torch.Tensor) and x.is_cuda:
+            dev = x.device
+            break
+    if dev is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    node_J, node_h = _as_dev(node_params[0], dev), _as_dev(node_params[1], dev)
+    node_logZ = _as_dev(node_params[2], dev) if len(node_params) == 3 else None
+    batched = node_h.dim() == 3
+    if node_h.dim() not in (2, 3) or node_J.shape[:-1] != node_h.shape or node_J.shape[-1] != node_h.shape[-1]:
+        raise ValueError("dense node potentials must be J (T,n,n), h (T,n) or J (B,T,n,n), h (B,T,n)")
+    if not batched:
+        node_J, node_h = node_J[None], node_h[None]
+        node_logZ = None if node_logZ is None else node_logZ[None]
+    B, T, n = node_h.shape
+    diag = torch.diagonal(node_J, dim1=-2, dim2=-1).contiguous()
+    off = node_J - torch.diag_embed(diag)
+    off = 0.5 * (off + off.transpose(-1, -2))          # (the factorisations read one triangle: symmetric part)
+    J11, J12, J22 = (_as_dev(x, dev) for x in pair_params[:3])
+    lz = _as_dev(pair_params[3], dev).reshape(-1)
+    homog = J11.dim() == 2
+    if T == 1:
+        if B != 1:
+            raise ValueError("dense node potentials with T = 1: one sequence per call (the initial potential is shared)")
+        init_params = (_as_dev(init_params[0], dev) + off[0, 0],) + tuple(init_params[1:])
+        pair = (J11, J12, J22, lz)
+    else:
+        def per_seq(x):
+            x = x if x.dim() == 4 else (x[None] if x.dim() == 3 else x[None, None])
+            return x.expand(B, T - 1, n, n).clone()
+        J11, J12, J22 = per_seq(J11), per_seq(J12), per_seq(J22)
+        lz = (lz.reshape(1, -1) if lz.numel() in (1, T - 1) else lz.reshape(B, T - 1)).expand(B, T - 1).contiguous().reshape(-1)
+        J11 += off[:, :T - 1]
+        J22[:, T - 2] += off[:, T - 1]
+        pair = (J11, J12, J22, lz)
+    nodes = (diag, node_h.contiguous()) + ((node_logZ,) if node_logZ is not None else ())
+    return (init_params, pair), nodes, dict(off=off, homog=homog, batched=batched, B=B, T=T, n=n)
+
+
+def _dense_stats(stats, info):
+    """Statistics of a folded launch in the reference's dense form: E_node = (E[x x'] (T,n,n), E[x], 1) --
+    `make_node_stats`, lds_inference.py:163-166 -- and, for homogeneous pair parameters, the pair statistics summed over
+    time (:172-173)."""
+    Ei, Ep, En = stats
+    B, T, n = info["B"], info["T"], info["n"]
+    if T > 1:
+        ExxT = torch.cat([Ep[0], Ep[2][:, -1:]], dim=1)
+        if info["homog"]:
+            Ep = (Ep[0].sum(1), Ep[1].sum(1), Ep[2].sum(1), Ep[3].sum(1))
+    else:
+        ExxT = Ei[0][:, None].clone()
+    En = (ExxT, En[1], En[2])
+    if not info["batched"]:
+        sq = lambda tup: tuple(x[0] for x in tup)
+        Ei, Ep, En = sq(Ei), sq(Ep), sq(En)
+    return Ei, Ep, En
+
+
 def _prepare(natparam, node_params, plan):
     """Shape checks / canonical device tensors shared by the E-step, filter and sampler wrappers
     (`_canonical_node_params`, `_canonical_init_params`, lds_inference.py:59-82)."""
@@ -266,8 +344,10 @@ def _prepare(natparam, node_params, plan):
     node_J, node_h = _as_dev(node_params[0], dev), _as_dev(node_params[1], dev)
     node_logZ = _as_dev(node_params[2], dev) if len(node_params) == 3 else None
     if node_J.dim() == 3 and node_h.dim() == 2:
-        raise ValueError("dense (T,n,n) node potentials are not supported by the compiled path "
-                         "(as in the reference, cython_lds_inference.pyx:43)")
+        raise ValueError("dense (T,n,n) node potentials: through natural_lds_estep_general / natural_lds_sample / "
+                         "natural_lds_inference_general / natural_filter_forward_general (folded into per-step pair "
+                         "parameters there); the kernels and the differentiable path take diagonal ones, like the "
+                         "reference's compiled path (cython_lds_inference.pyx:43)")
     batched = node_h.dim() == 3
     if node_J.shape != node_h.shape or node_h.dim() not in (2, 3):
         raise ValueError("node potentials must both be (T,n) or (B,T,n)")
@@ -315,6 +395,12 @@ def natural_lds_estep_general(natparam, node_params, plan=None, check=False, kee
     definite (the reference ignores LAPACK `info`, cython_gaussian_grads.pxd:54-76); `plan.check_info()`
     does the same later.  The returned tensors are views of the plan's buffers: valid until its next launch.
     """
+    if _is_dense_nodes(node_params):
+        if plan is not None:
+            raise ValueError("dense node potentials: the plan is built internally (per-step, per-sequence pair layout)")
+        natparam, node_params, info = _fold_dense_nodes(natparam, node_params)
+        lognorm, stats = natural_lds_estep_general(natparam, node_params, check=check, keep_factor=keep_factor)
+        return (lognorm if info["batched"] else lognorm[0]), _dense_stats(stats, info)
     q = _prepare(natparam, node_params, plan)
     plan, batched, B, T, n, inhomog = q["plan"], q["batched"], q["B"], q["T"], q["n"], q["inhomog"]
     dev = plan.device
@@ -345,6 +431,17 @@ def natural_filter_forward_general(init_params, pair_params, node_params, plan=N
     reference's scaling (natural parameters: J = -1/2 precision), shapes (T,n,n) / (T,n) [(B,...) when
     the nodes are batched] -- `natural_filter_forward_general` (cython_lds_inference.pyx:28-90, result
     :84-87; Python twin lds_inference.py:86-106).  The plan's workspace afterwards serves `plan.sample`."""
+    if _is_dense_nodes(node_params):
+        if plan is not None:
+            raise ValueError("dense node potentials: the plan is built internally")
+        (ip, pp), nodes, info = _fold_dense_nodes((init_params, pair_params), node_params)
+        ((Jp, hp), (Jf, hf)), lognorm = natural_filter_forward_general(ip, pp, nodes, check=check)
+        off, T = info["off"], info["T"]
+        Jf[:, :T - 1] += off[:, :T - 1]        # J_filt[t] = J_pred[t] + Jo[t]: the part that was folded into J11[t]
+        Jp[:, T - 1] -= off[:, T - 1]          # ... and the part the last prediction (or the initial potential) carried
+        if not info["batched"]:
+            return ((Jp[0], hp[0]), (Jf[0], hf[0])), lognorm[0]
+        return ((Jp, hp), (Jf, hf)), lognorm
     q = _prepare((init_params, pair_params), node_params, plan)
     plan, B, T, n = q["plan"], q["B"], q["T"], q["n"]
     if n > _lib.LDS_MAX_N:
@@ -365,6 +462,14 @@ def natural_lds_sample(natparam, node_params, num_samples=1, eps=None, plan=None
     """Filter + backward sampling WITHOUT the smoother: `cython_natural_lds_sample`
     (lds_inference.py:260-264) -> samples (T,S,n) [(B,T,S,n) batched].  `eps` as in
     natural_lds_inference_general."""
+    if _is_dense_nodes(node_params):
+        if plan is not None:
+            raise ValueError("dense node potentials: the plan is built internally")
+        natparam, node_params, info = _fold_dense_nodes(natparam, node_params)
+        if eps is not None and not info["batched"]:
+            eps = torch.as_tensor(eps, dtype=torch.float64)[None]
+        samples = natural_lds_sample(natparam, node_params, num_samples, eps, None, generator)
+        return samples if info["batched"] else samples[0]
     nh = node_params[1]
     if int(nh.shape[-1]) > _lib.LDS_MAX_N:
         # 16 <= n <= 64: the tile kernels have no filter-only form; the sampler works on the hand-off of the tile
@@ -395,13 +500,23 @@ def natural_lds_inference_general(natparam, node_params, num_samples=None, eps=N
     The reference draws its noise from the global NumPy RNG inside the sampler
     (cython_lds_inference.pyx:333); here `eps` (B,T,S,n) / (T,S,n) may be passed in, else it is drawn
     from `generator` on the device."""
+    if _is_dense_nodes(node_params):
+        if plan is not None:
+            raise ValueError("dense node potentials: the plan is built internally")
+        natparam, node_params, info = _fold_dense_nodes(natparam, node_params)
+        if eps is not None and not info["batched"]:
+            eps = torch.as_tensor(eps, dtype=torch.float64)[None]
+        samples, stats, lognorm = natural_lds_inference_general(natparam, node_params, num_samples, eps, None, generator)
+        if not info["batched"]:
+            samples, lognorm = samples[0], lognorm[0]
+        return samples, _dense_stats(stats, info), lognorm
     batched = (node_params[1].ndim if hasattr(node_params[1], "ndim") else torch.as_tensor(node_params[1]).dim()) == 3
     S = 1 if num_samples is None else int(num_samples)
     if plan is None:
         nh = torch.as_tensor(node_params[1])
         B, T, n = (nh.shape if batched else (1,) + tuple(nh.shape))
-        inhomog = torch.as_tensor(natparam[1][0]).dim() >= 3
-        plan = LDSEStepPlan(B, T, n, "cuda", inhomog)
+        pdim = torch.as_tensor(natparam[1][0]).dim()
+        plan = LDSEStepPlan(B, T, n, "cuda", pdim >= 3, pdim == 4)
     lognorm, stats = natural_lds_estep_general(natparam, node_params, plan=plan, keep_factor=True)
     if eps is None:
         eps = torch.randn(plan.B, plan.T, S, plan.n, dtype=torch.float64, device=plan.device,
@@ -494,6 +609,10 @@ def lds_inference_differentiable(natparam, node_params, eps=None, plan=None, pai
     node_J, node_h = node_params[0], node_params[1]
     node_logZ = node_params[2] if len(node_params) == 3 else None
     dev = node_h.device
+    if node_h.dim() != 3 or node_J.shape != node_h.shape:
+        raise ValueError("lds_inference_differentiable: diagonal node potentials J, h of shape (B,T,n) (dense (B,T,n,n) "
+                         "ones go through the non-differentiable entry points: the VJP kernels return no pair-parameter "
+                         "gradients, which the off-diagonal part would need)")
     B, T, n = node_h.shape
     init_J, init_h, init_logZ = _canonical_init_params(init_params, dev)
     J11, J12, J22 = (_as_dev(x, dev) for x in pair_params[:3])

@@ -58,6 +58,40 @@ def lds_case(name, B, T, n, seed, inhomog=False, with_logZ=True):
     print(name, {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
 
 
+def lds_dense_case(name, B, T, n, seed, inhomog=False):
+    """DENSE node potentials (T,n,n) through the reference's Python path -- natural_lds_estep_general,
+    svae/lds/lds_inference.py:223-229 (natural_condition_on_general, gaussian.py:46-49; dense node statistics,
+    lds_inference.py:163-166) -- which the compiled path does not take (cython_lds_inference.pyx:43)."""
+    ref_py2.load_reference()
+    import svae.lds.lds_inference as li
+    rng = np.random.default_rng(seed)
+    init, pair = rand_lds_natparam(n, rng)
+    if inhomog:
+        pairs = [rand_lds_natparam(n, rng)[1] for _ in range(T - 1)]
+        pair = tuple(np.stack([p[i] for p in pairs]) for i in range(4))
+    nJ, nh, nz = rand_node_potentials((B, T, n), rng, with_logZ=True)
+    A = 0.3 * np.abs(nJ).mean() * rng.standard_normal((B, T, n, n)) / n
+    A = A + np.swapaxes(A, -1, -2)
+    idx = np.arange(n)
+    A[..., idx, idx] = nJ                      # diagonal as drawn (negative), small symmetric off-diagonal part
+    out = dict(init_J=init[0], init_h=init[1], init_logZ=init[2], J11=pair[0], J12=pair[1], J22=pair[2],
+               logZ_pair=np.asarray(pair[3]), node_J=A, node_h=nh, node_logZ=nz)
+    res = [li.natural_lds_estep_general((init, pair), (A[b], nh[b], nz[b])) for b in range(B)]
+    out["lognorm"] = np.array([float(r[0]) for r in res])
+    out["ExxT0"] = np.stack([np.asarray(r[1][0][0]) for r in res])
+    out["Ex0"] = np.stack([np.asarray(r[1][0][1]) for r in res])
+    if inhomog:
+        for i, k in enumerate(("Epair_xx", "Epair_xxn", "Epair_xnxn")):
+            out[k] = np.stack([np.stack([np.asarray(st[i]) for st in r[1][1]]) for r in res])
+    else:
+        for i, k in enumerate(("Epair_xx", "Epair_xxn", "Epair_xnxn")):
+            out[k] = np.stack([np.asarray(r[1][1][i]) for r in res])
+    out["Enode_xx"] = np.stack([np.asarray(r[1][2][0]) for r in res])
+    out["Enode_x"] = np.stack([np.asarray(r[1][2][1]) for r in res])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
+
+
 def gmm_case(name, K, N, T, seed, alpha=1.0, random_scale=1.0):
     ref_py2.load_reference()
     from svae.models import gmm
@@ -262,6 +296,8 @@ def slds_case(name, K, n, T, B, S, seed):
 
 
 CASES = [
+    (lds_dense_case, "lds_dense_T7_n4", dict(B=2, T=7, n=4, seed=11)),
+    (lds_dense_case, "lds_dense_T6_n3_inhomog", dict(B=2, T=6, n=3, seed=12, inhomog=True)),
     (lds_case, "lds_T5_n3", dict(B=2, T=5, n=3, seed=0)),
     (lds_case, "lds_T20_n10", dict(B=3, T=20, n=10, seed=1)),
     (lds_case, "lds_T200_n10", dict(B=2, T=200, n=10, seed=2, with_logZ=False)),

@@ -135,7 +135,7 @@ def test_shape_errors_like_reference():
     with pytest.raises(ValueError):
         natural_lds_estep_general(natparam, (np.zeros((4, 3)), np.zeros((5, 3))))
     with pytest.raises(ValueError):
-        natural_lds_estep_general(natparam, (np.zeros((4, 3, 3)), np.zeros((4, 3))))
+        natural_lds_estep_general(natparam, (np.zeros((4, 3, 2)), np.zeros((4, 3))))   # (dense (T,n,n): tests/test_lds_dense_hip.py)
     with pytest.raises(ValueError):
         natural_lds_estep_general(natparam, (np.zeros((4, 2)), np.zeros((4, 2))))
 

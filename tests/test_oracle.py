@@ -240,3 +240,21 @@ def test_slds_glue_oracle_matches_reference_golden(case, golden_dir):
                                                  cython_init_logZ=False)
         if r2["iters"] == r["iters"]:
             assert abs(r2["lds_vlb"] - (g["opt_lds_vlb"][b] + g["opt_init_b"][b])) < 1e-8 * abs(g["opt_lds_vlb"][b])
+
+
+@pytest.mark.parametrize("name", ["lds_dense_T7_n4", "lds_dense_T6_n3_inhomog"])
+def test_oracle_dense_node_potentials_against_the_reference_python_path(name, golden_dir):
+    """Dense (T,n,n) node potentials: oracle/lds_numpy.py vs what the reference's Python path returned
+    (svae/lds/lds_inference.py:223-229 with gaussian.py:46-49; fixtures from tests/golden/make_golden.py)."""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    natparam = ((g["init_J"], g["init_h"], g["init_logZ"]), (g["J11"], g["J12"], g["J22"], g["logZ_pair"]))
+    for b in range(g["node_h"].shape[0]):
+        lognorm, (Ei, Ep, En) = lds_numpy.natural_lds_estep_general(
+            natparam, (g["node_J"][b], g["node_h"][b], g["node_logZ"][b]))
+        assert abs(lognorm - g["lognorm"][b]) < 1e-11 * max(1.0, abs(g["lognorm"][b]))
+        np.testing.assert_allclose(Ei[0], g["ExxT0"][b], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(Ei[1], g["Ex0"][b], rtol=0, atol=1e-11)
+        for x, k in zip(Ep, ("Epair_xx", "Epair_xxn", "Epair_xnxn")):
+            np.testing.assert_allclose(x, g[k][b], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(En[0], g["Enode_xx"][b], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(En[1], g["Enode_x"][b], rtol=0, atol=1e-11)
