@@ -34,7 +34,10 @@ def _globals(K, n, rng):
         mu, kappa = 0.3 * rng.standard_normal(n), 0.5
         th = 0.4 * (k + 1)
         M = 0.95 * np.eye(n)
-        M[:2, :2] = 0.95 * np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        if n >= 2:
+            M[:2, :2] = 0.95 * np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        else:
+            M[0, 0] = 0.95 * np.cos(th)
         Kmat = 0.2 * np.eye(n)
         lds.append((ef.niw_standard_to_natural(S, mu, np.array(kappa), np.array(nu)),
                     ef.mniw_standard_to_natural(nu, S, M, Kmat)))
@@ -180,7 +183,8 @@ def _fused_options(kernel):
 @pytest.mark.parametrize("kernel", ["tables", "rpc_ref", "rpc_mfma", "default"])
 @pytest.mark.parametrize("K,n,T,B", [(3, 4, 9, 5), (8, 10, 40, 11), (7, 10, 5, 3), (16, 6, 12, 4), (2, 2, 4, 2),
                                      (5, 7, 13, 21), (8, 10, 6, 9), (8, 9, 4, 17), (1, 3, 7, 8), (8, 10, 31, 40),
-                                     (8, 4, 16, 6), (3, 2, 8, 3), (8, 5, 10, 4), (8, 8, 11, 7), (6, 4, 8, 300)])
+                                     (8, 4, 16, 6), (3, 2, 8, 3), (8, 5, 10, 4), (8, 8, 11, 7), (6, 4, 8, 300),
+                                     (4, 1, 6, 3), (8, 1, 9, 20), (8, 3, 12, 5), (8, 6, 12, 5), (8, 7, 12, 5)])
 def test_fused_lds_meanfield_step_matches_materialised(K, n, T, B, kernel):
     """One LDS mean-field step through svae_slds_lds_meanfield_f64 (K parameter sets in LDS, mixed per step
     by the HMM marginals, pair statistics contracted in the kernel) against the path that materialises the
