@@ -9,6 +9,8 @@ bash profiles/run_profile.sh r5_twoend 2>&1 | tail -1
   timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_sq -o bench -- python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra > $OUT/pmc_sq.log 2>&1 )
 bash profiles/run_profile.sh r5_twoend_b4096 --seqs-per-gpu 4096 2>&1 | tail -1
 bash profiles/run_profile.sh r5_tile_n64_b512 --workload lds64 --steps 3 --warmup 1 2>&1 | tail -1
+( cd /tmp && export TMPDIR=/tmp; OUT=$REPO/gpurun_out/prof_r5_tile_n64_b512
+  timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_sq -o bench -- python $REPO/bench.py --workload lds64 --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $OUT/pmc_sq.log 2>&1 )
 bash tools/prof_generic.sh r5_slds python $REPO/tools/bench_slds.py 2048 500 10 8 --fused-only 2>&1 | tail -2
 bash tools/prof_generic.sh r5_train python $REPO/tools/bench_train_path.py 512 200 10 1 2>&1 | tail -2
 bash tools/prof_generic.sh r5_train_b4096 python $REPO/tools/bench_train_path.py 4096 200 10 1 2>&1 | tail -2
