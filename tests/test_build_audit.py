@@ -47,13 +47,40 @@ def test_generated_gauss_jordan_header_is_what_the_generator_emits():
     assert gen_gj_asm.generate() == committed, "regenerate: python tools/gen_gj_asm.py"
 
 
+_ESTEP_NS = [2, 10, 12, 15]
+_OTHER_UNITS = [("lds_vjp_n.hip", 10, 3000), ("lds_estep_tile.hip", None, 2000), ("hmm_estep.hip", None, 200),
+                ("lds_chol_tile.hip", None, 2000)]
+
+
+@pytest.fixture(scope="session")
+def asm_files(tmp_path_factory):
+    """Every assembly file the audits below read, compiled CONCURRENTLY on first use (eight hipcc -S runs of 6 .. 100 s
+    each: ~6 minutes one after the other, under 2 in parallel); asm_files(unit, n) waits for its own."""
+    d = tmp_path_factory.mktemp("asm")
+    jobs = {}
+    for unit, n in [("lds_estep_n.hip", n) for n in _ESTEP_NS] + [(u, n) for u, n, _ in _OTHER_UNITS]:
+        out = d / ("%s.%s.s" % (unit, n))
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S",
+               os.path.join(ROOT, "svae_amd/csrc", unit), "-o", str(out)]
+        if n is not None:
+            cmd.insert(4, "-DSVAE_N=%d" % n)
+        log = open(str(out) + ".log", "wb")          # (a file, not a pipe: nobody reads while the others compile)
+        jobs[(unit, n)] = (subprocess.Popen(cmd, stdout=log, stderr=subprocess.STDOUT), out)
+
+    def get(unit, n):
+        proc, out = jobs[(unit, n)]
+        assert proc.wait() == 0, open(str(out) + ".log").read()[-2000:]
+        return out
+    yield get
+    for proc, _ in jobs.values():
+        if proc.poll() is None:
+            proc.kill()
+
+
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
-@pytest.mark.parametrize("n", [2, 10, 12, 15])
-def test_estep_kernel_isa_has_no_dpp_hazards(n, tmp_path):
-    out = tmp_path / ("n%d.s" % n)
-    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-DSVAE_N=%d" % n,
-                    "--cuda-device-only", "-S", os.path.join(ROOT, "svae_amd/csrc/lds_estep_n.hip"),
-                    "-o", str(out)], check=True, capture_output=True)
+@pytest.mark.parametrize("n", _ESTEP_NS)
+def test_estep_kernel_isa_has_no_dpp_hazards(n, asm_files):
+    out = asm_files("lds_estep_n.hip", n)
     ndpp, probs = audit_dpp_hazards.audit(str(out))
     assert ndpp > 50 * n, "fused v_fmac_f64_dpp path not generated"
     assert probs == [], "\n".join(probs[:10])
@@ -73,17 +100,11 @@ def test_estep_kernel_isa_has_no_dpp_hazards(n, tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
-@pytest.mark.parametrize("unit,n,min_dpp", [("lds_vjp_n.hip", 10, 3000), ("lds_estep_tile.hip", None, 2000),
-                                           ("hmm_estep.hip", None, 200), ("lds_chol_tile.hip", None, 2000)])
-def test_other_dpp_units_have_no_hazards(unit, n, min_dpp, tmp_path):
+@pytest.mark.parametrize("unit,n,min_dpp", _OTHER_UNITS)
+def test_other_dpp_units_have_no_hazards(unit, n, min_dpp, asm_files):
     """The VJP sweeps (one fence per product stage), the pivot-tile factorisation of the tiled path, the HMM kernel
     and the tile factorisations of the blocked Cholesky kernels use the same inline-asm DPP forms: same audit."""
-    out = tmp_path / (unit + ".s")
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S",
-           os.path.join(ROOT, "svae_amd/csrc", unit), "-o", str(out)]
-    if n is not None:
-        cmd.insert(4, "-DSVAE_N=%d" % n)
-    subprocess.run(cmd, check=True, capture_output=True)
+    out = asm_files(unit, n)
     ndpp, probs = audit_dpp_hazards.audit(str(out))
     assert ndpp > min_dpp, ndpp
     assert probs == [], "\n".join(probs[:10])
