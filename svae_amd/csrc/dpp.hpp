@@ -204,4 +204,16 @@ __device__ __forceinline__ double group_sum(double x) {
   return x;
 }
 
+// Streaming stores.  The per-step records of the large-batch kernels (hand-off, LDL' factor, cross moments, adjoint
+// records: GBs per launch, read once by a LATER phase or kernel) gain nothing from being allocated in L2 / MALL on the
+// way out; written with the non-temporal hint they leave the cache to the operands being read.  Measured on
+// slds_mix_pair_kernel (2.45 GB written in full 800-byte rows): 2.3 -> 3.8 TB/s.  NOT for the 88-byte row pieces the
+// register kernels store per DPP row: as partial lines without the L2 to merge them the packed E-step's hand-off went
+// 1.62 -> 2.2 ms at 4096 sequences (the adjoint records of sweep 1: -3 %, within the box-to-box spread; not kept).
+template <bool NT>
+__device__ __forceinline__ void st_stream(double* p, double v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
 }  // namespace svae

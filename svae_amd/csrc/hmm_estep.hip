@@ -758,7 +758,13 @@ __global__ __launch_bounds__(1024) void slds_mix_pair_kernel(int B, int T, int K
   const int es = m == 3 ? 1 : nn;                    // elements per state / per output row
   double pk[16];
   static_for<0, 16>([&](auto k) { pk[k] = k < K ? P[(long)k * es + ee] : 0.0; });
-  constexpr int U = 4;                               // steps in flight per thread (their weight loads and stores overlap)
+#ifndef SVAE_MIXPAIR_U
+#define SVAE_MIXPAIR_U 4
+#endif
+#ifndef SVAE_MIXPAIR_NT
+#define SVAE_MIXPAIR_NT 1
+#endif
+  constexpr int U = SVAE_MIXPAIR_U;                  // steps in flight per thread (their weight loads and stores overlap)
   for (long b = blockIdx.y; b < B; b += gridDim.y) {  // (no division in the loops: grid rows stride over the sequences)
     const double* wb = w + (b * T + 1) * K;
     double* Ob = O + b * (T - 1) * es + ee;
@@ -770,7 +776,8 @@ __global__ __launch_bounds__(1024) void slds_mix_pair_kernel(int B, int T, int K
         acc[u] = 0.0;
         static_for<0, 16>([&](auto k) { if (k < K) acc[u] = __builtin_fma(wr[k], pk[k], acc[u]); });
       });
-      static_for<0, U>([&](auto u) { if (t0 + u < T - 1) Ob[(long)(t0 + u) * es] = acc[u]; });
+      // (non-temporal: 2.45 GB at configs[3], read by a later kernel -- 1.07 -> 0.64 ms)
+      static_for<0, U>([&](auto u) { if (t0 + u < T - 1) st_stream<SVAE_MIXPAIR_NT != 0>(&Ob[(long)(t0 + u) * es], acc[u]); });
     }
   }
 }
@@ -910,8 +917,11 @@ extern "C" int svae_slds_mix_pair_natparam_f64(int B, int T, int K, int n, const
   if (!out_J11 || !out_J12 || !out_J22 || !out_logZ) return -10;
   if (B == 0 || T == 1) return 0;
   const int threads = ((3 * n * n + 1) + 63) / 64 * 64;
-  const int per_seq = (T - 1 + 3) / 4;                                  // four steps per thread and trip
-  const unsigned gx = (unsigned)(per_seq < 8 ? per_seq : 8);
+  const int per_seq = (T - 1 + SVAE_MIXPAIR_U - 1) / SVAE_MIXPAIR_U;    // U steps per thread and trip
+#ifndef SVAE_MIXPAIR_GX
+#define SVAE_MIXPAIR_GX 8
+#endif
+  const unsigned gx = (unsigned)(per_seq < SVAE_MIXPAIR_GX ? per_seq : SVAE_MIXPAIR_GX);
   hipLaunchKernelGGL(svae::slds_mix_pair_kernel, dim3(gx, (unsigned)(B < 65535 ? B : 65535)), dim3(threads), 0, (hipStream_t)stream, B, T, K, n * n,
                      E_states, J11, J12, J22, lz, out_J11, out_J12, out_J22, out_logZ);
   return hipGetLastError() == hipSuccess ? 0 : -1000;
