@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SVAE_HIP_ABI_VERSION 12   /* 12: svae_gmm_global_step_f64 writes kl[0..1] (as spelled | as shipped), svae_ipc_allreduce_f64 takes the mailbox stride and never writes `out` on a timeout, + svae_slds_lds_meanfield options; 11: + svae_lds_global_step_multi_f64 (K parameter sets in one launch: the SLDS global -> local maps), svae_lds_diag_sample_f64 (filter + sampler of an all-diagonal LDS: the SLDS initial path); 10: + svae_ipc_allreduce_f64 / svae_ipc_mailbox_bytes, svae_gmm_sample_f64, svae_gmm_local_vjp_f64, svae_gmm_global_step_f64 (the differentiable tail and the global side of the GMM local step); 9: keep bit SVAE_KEEP_SIGMA of svae_lds_estep_f64 (16 <= n <= 64) + svae_lds_tile_sigma_offset_bytes; 8: step ranges (t_begin, t_end) in svae_lds_tile_vjp_f64 / svae_lds_tile_noise_f64, SVAE_OPT_TILE_FORWARD / _BACKWARD; 7: + svae_slds_path_nodeparams_f64, svae_slds_mix_pair_natparam_f64; 6: per-call `options` word replaces the process-global svae_lds_set_* selectors (re-entrant library), + svae_slds_hmm_meanfield_f64, svae_slds_sweep_glue_f64, g_E_pair in svae_lds_tile_vjp_f64; 5: + svae_lds_set_prod_max_b; 4: + svae_slds_lds_meanfield_f64, svae_gmm_mw_*, svae_lds_global_step_f64, svae_lds_natgrad_f64, svae_lds_tile_vjp_f64; 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
+#define SVAE_HIP_ABI_VERSION 13   /* 13: + svae_slds_pair_contract_f64 (the two contractions of the SLDS final pass over the per-step pair statistics in one pass); 12: svae_gmm_global_step_f64 writes kl[0..1] (as spelled | as shipped), svae_ipc_allreduce_f64 takes the mailbox stride and never writes `out` on a timeout, + svae_slds_lds_meanfield options; 11: + svae_lds_global_step_multi_f64 (K parameter sets in one launch: the SLDS global -> local maps), svae_lds_diag_sample_f64 (filter + sampler of an all-diagonal LDS: the SLDS initial path); 10: + svae_ipc_allreduce_f64 / svae_ipc_mailbox_bytes, svae_gmm_sample_f64, svae_gmm_local_vjp_f64, svae_gmm_global_step_f64 (the differentiable tail and the global side of the GMM local step); 9: keep bit SVAE_KEEP_SIGMA of svae_lds_estep_f64 (16 <= n <= 64) + svae_lds_tile_sigma_offset_bytes; 8: step ranges (t_begin, t_end) in svae_lds_tile_vjp_f64 / svae_lds_tile_noise_f64, SVAE_OPT_TILE_FORWARD / _BACKWARD; 7: + svae_slds_path_nodeparams_f64, svae_slds_mix_pair_natparam_f64; 6: per-call `options` word replaces the process-global svae_lds_set_* selectors (re-entrant library), + svae_slds_hmm_meanfield_f64, svae_slds_sweep_glue_f64, g_E_pair in svae_lds_tile_vjp_f64; 5: + svae_lds_set_prod_max_b; 4: + svae_slds_lds_meanfield_f64, svae_gmm_mw_*, svae_lds_global_step_f64, svae_lds_natgrad_f64, svae_lds_tile_vjp_f64; 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
 #define SVAE_LDS_MAX_N 15   /* register/DPP path: one 16-lane row per sequence, n+1 <= 16 */
 #define SVAE_LDS_TILE_MAX_N 64   /* 16 <= n <= 64: LDS-tiled MFMA path (keep: SVAE_KEEP_SIGMA or 0) */
 #define SVAE_KEEP_SIGMA 4         /* keep bit of svae_lds_estep_f64, 16 <= n <= 64 only: see svae_lds_tile_sigma_offset_bytes */
@@ -404,6 +404,17 @@ int svae_slds_path_nodeparams_f64(int B, int T, int K, int n, const double* x, c
 int svae_slds_mix_pair_natparam_f64(int B, int T, int K, int n, const double* E_states, const double* J11,
                                     const double* J12, const double* J22, const double* lz, double* out_J11,
                                     double* out_J12, double* out_J22, double* out_logZ, void* stream);
+
+/* The two contractions of the SLDS final pass (run_inference, /root/reference/svae/models/slds_svae.py:289-310) over the
+ * per-step pair statistics pair_stats (B,T-1,3,n,n) of the last LDS E-step, in ONE pass over them:
+ *   get_arhmm_local_nodeparams :131-147   node_out[b,t+1,k] = <pair_stats[b,t], P_k> + lz_k   (rows 1..T-1 of (B,T,K);
+ *                                         row 0 -- the init statistics -- is the caller's)
+ *   get_global_stats :229-243             sum_{b,t} weights[b,t+1,k] pair_stats[b,t]: `blocks` partial sums
+ *                                         gpart (blocks, 8, 3 n^2), to be added in index order (rows k >= K are zero);
+ *                                         the buffer holds ONE more double behind them (scratch word of the kernel)
+ * P (K, 3 n^2) = [J11_k | J12_k | J22_k] flattened, lz (K), weights (B,T,K) = the HMM marginals.  n <= 10, K <= 8, T >= 2. */
+int svae_slds_pair_contract_f64(int B, int T, int K, int n, const double* pair_stats, const double* P, const double* lz,
+                                const double* weights, double* node_out, double* gpart, int blocks, void* stream);
 
 /* GMM mean-field fixed point + global statistics for one minibatch of T points
  * [local_meanfield, /root/reference/svae/models/gmm.py:62-88; meanfield_fixed_point :90-110;

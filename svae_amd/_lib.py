@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must precede CDLL: shares torch's HIP runtime)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVAE_AMD_LIB", os.path.join(_HERE, "libsvae_hip.so"))  # env: experiments only
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 LDS_MAX_N = 15        # register/DPP path (E-step, sampler, VJP)
 LDS_TILE_MAX_N = 64   # LDS-tiled MFMA path (E-step only)
 
@@ -64,6 +64,7 @@ SIGNATURES = {
                                  + [_c_int_p] * 4 + [ctypes.c_void_p]),
     "svae_slds_path_nodeparams_f64": (ctypes.c_int, [ctypes.c_int] * 4 + [_c_double_p] * 9 + [ctypes.c_void_p]),
     "svae_slds_mix_pair_natparam_f64": (ctypes.c_int, [ctypes.c_int] * 4 + [_c_double_p] * 9 + [ctypes.c_void_p]),
+    "svae_slds_pair_contract_f64": (ctypes.c_int, [ctypes.c_int] * 4 + [_c_double_p] * 6 + [ctypes.c_int, ctypes.c_void_p]),
     "svae_gmm_meanfield_f64": (ctypes.c_int, [ctypes.c_int] * 3 + [_c_double_p] * 5
                                + [ctypes.c_double, ctypes.c_int] + [_c_double_p] * 8
                                + [_c_int_p] * 3 + [ctypes.c_void_p]),

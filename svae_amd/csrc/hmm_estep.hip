@@ -782,6 +782,123 @@ __global__ __launch_bounds__(1024) void slds_mix_pair_kernel(int B, int T, int K
   }
 }
 
+
+// The two contractions of the SLDS final pass over the per-step pair statistics S (B, T-1, E = 3 n^2) of the last LDS
+// E-step (run_inference, /root/reference/svae/models/slds_svae.py:289-310), in ONE pass over the 2.45 GB they are at
+// configs[3] (they were two library GEMMs, each reading S: 2.2 + 1.0 ms):
+//   node[b, t+1, k] = <S[b,t], P_k> + lz_k           get_arhmm_local_nodeparams  :131-147
+//   G[k]           += w[b, t+1, k] S[b,t]            get_global_stats            :229-243 (summed over b and t)
+// A wavefront takes one step at a time: lane l holds the entries l, l + 64, .. of S[b,t] (coalesced 512-byte rows, two
+// steps prefetched), the K parameter rows of its entries and the K x EJ accumulators of G in registers; the K inner
+// products are reduced across the wavefront by ONE multi-value butterfly (7 shuffles for 8 sums: each exchange halves the
+// number of sums a lane still carries); the weights of a step are wave-uniform scalars.  Workgroups stride over the
+// sequences and leave one (KK, E) partial of G each (summed by the caller in index order: deterministic).
+#ifndef SVAE_PC_WPC
+#define SVAE_PC_WPC 2
+#endif
+template <int EJ, int KK>
+__global__ __launch_bounds__(256, SVAE_PC_WPC) void slds_pair_contract_kernel(int B, int T, int K, int E, const double* __restrict__ S,
+                                                                   const double* __restrict__ P, const double* __restrict__ lz,
+                                                                   const double* __restrict__ w, double* __restrict__ node,
+                                                                   double* __restrict__ gpart, double* __restrict__ dummy) {
+  static_assert(KK == 8, "the butterfly below is written for eight sums");
+  __shared__ double red[EJ * KK * 64];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  double pk[EJ][KK], ga[EJ][KK];
+  int eo[EJ];
+  static_for<0, EJ>([&](auto j) {
+    const int e = lane + 64 * j;
+    eo[j] = 8 * (e < E ? e : E - 1);                 // byte offset inside a row of S
+    static_for<0, KK>([&](auto k) { pk[j][k] = (e < E && k < K) ? P[(long)(k < K ? k : 0) * E + eo[j] / 8] : 0.0; ga[j][k] = 0.0; });
+  });
+  const double lzl = lz[lane < K ? lane : 0];
+  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+  // (no branch inside the time loop -- across one hipcc's wait counts degrade to vmcnt(0) and the prefetched rows are
+  //  waited for at once: state indices are clamped and masked, and the lanes without a state store to a dummy word)
+  int kx[KK];
+  double mk[KK];
+  static_for<0, KK>([&](auto k) { kx[k] = k < K ? k : K - 1; mk[k] = k < K ? 1.0 : 0.0; });
+  const bool writer = lane < K;
+  const int steps = T - 1;
+  for (long b = blockIdx.x; b < B; b += gridDim.x) {
+    const double* Sb = S + b * steps * E;
+    const double* wb = w + (b * T + 1) * K;
+    double* nb = node + (b * T + 1) * K + (writer ? lane : 0);
+    // register ring of D rows, every slot with a fixed role in the unrolled body (a rotation by moves would make each
+    // move wait for the load it forwards): slot r is consumed and at once re-requested D steps further on
+#ifndef SVAE_PC_D
+#define SVAE_PC_D 2
+#endif
+    constexpr int D = SVAE_PC_D;
+    double ring[D][EJ], wring[D];          // wring: the step's K weights, one per lane (read back with v_readlane:
+    const int wl = 8 * (lane < K ? lane : K - 1);     // as eight scalar loads they were waited for one by one)
+    // (row base through readfirstlane: a scalar base + the lane's 32-bit offset per load; left to itself hipcc keeps one
+    //  64-bit pointer per (slot, chunk) in vector registers -- 30 of them -- and spills)
+    auto load = [&](int t, double (&v)[EJ], double& wv_) {
+      const uint64_t a = (uint64_t)(Sb + (long)(t < steps ? t : steps - 1) * E);
+      const char* r = (const char*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                                    (uint32_t)__builtin_amdgcn_readfirstlane((int)a));
+      static_for<0, EJ>([&](auto j) { v[j] = *(const double*)(r + eo[j]); });
+      const uint64_t aw = (uint64_t)(wb + (long)(t < steps ? t : steps - 1) * K);
+      const char* rw = (const char*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(aw >> 32)) << 32) |
+                                     (uint32_t)__builtin_amdgcn_readfirstlane((int)aw));
+      wv_ = *(const double*)(rw + wl);
+    };
+    static_for<0, D>([&](auto r) { load(wv + 4 * r, ring[r], wring[r]); });
+    for (int t0 = wv; t0 < steps; t0 += 4 * D) {
+      static_for<0, D>([&](auto r) {
+        const int t = t0 + 4 * r;
+        const bool live = t < steps;                       // (wave-uniform; a dead step computes on a clamped row)
+        const double lv = live ? 1.0 : 0.0;
+        double acc[KK];
+        static_for<0, KK>([&](auto k) { acc[k] = 0.0; });
+        static_for<0, KK>([&](auto k) {
+          const double wk = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(wring[r]), kx[k]),
+                                             __builtin_amdgcn_readlane(__double2loint(wring[r]), kx[k])) * (mk[k] * lv);
+          static_for<0, EJ>([&](auto j) {
+            acc[k] = __builtin_fma(ring[r][j], pk[j][k], acc[k]);
+            ga[j][k] = __builtin_fma(wk, ring[r][j], ga[j][k]);
+          });
+        });
+        load(t + 4 * D, ring[r], wring[r]);
+        double r4[4], r2[2];
+        static_for<0, 4>([&](auto i) {
+          const double send = b0 ? acc[2 * i] : acc[2 * i + 1], keep = b0 ? acc[2 * i + 1] : acc[2 * i];
+          r4[i] = keep + __shfl_xor(send, 1, 64);
+        });
+        static_for<0, 2>([&](auto i) {
+          const double send = b1 ? r4[2 * i] : r4[2 * i + 1], keep = b1 ? r4[2 * i + 1] : r4[2 * i];
+          r2[i] = keep + __shfl_xor(send, 2, 64);
+        });
+        double tot = (b2 ? r2[1] : r2[0]) + __shfl_xor(b2 ? r2[0] : r2[1], 4, 64);     // lane: the sum of state (lane & 7)
+        tot += __shfl_xor(tot, 8, 64);
+        tot += __shfl_xor(tot, 16, 64);
+        tot += __shfl_xor(tot, 32, 64);
+        double* dst = (writer && live) ? nb + (long)t * K : dummy;
+        *dst = tot + lzl;
+      });
+    }
+  }
+  // the workgroup's partial of G: the four wavefronts' accumulators added in index order through LDS
+  for (int q = 0; q < 4; ++q) {
+    if (wv == q) {
+      static_for<0, EJ>([&](auto j) {
+        static_for<0, KK>([&](auto k) {
+          double* r = red + (j * KK + k) * 64 + lane;
+          *r = q == 0 ? ga[j][k] : *r + ga[j][k];
+        });
+      });
+    }
+    __syncthreads();
+  }
+  double* gp = gpart + (long)blockIdx.x * KK * E;
+  for (int idx = threadIdx.x; idx < EJ * KK * 64; idx += 256) {
+    const int l = idx & 63, k = (idx >> 6) % KK, j = idx / (64 * KK);
+    const int e = l + 64 * j;
+    if (e < E) gp[(long)k * E + e] = red[idx];
+  }
+}
+
 }  // namespace svae
 
 extern "C" size_t svae_hmm_workspace_bytes(int B, int T, int K) {
@@ -924,6 +1041,36 @@ extern "C" int svae_slds_mix_pair_natparam_f64(int B, int T, int K, int n, const
   const unsigned gx = (unsigned)(per_seq < SVAE_MIXPAIR_GX ? per_seq : SVAE_MIXPAIR_GX);
   hipLaunchKernelGGL(svae::slds_mix_pair_kernel, dim3(gx, (unsigned)(B < 65535 ? B : 65535)), dim3(threads), 0, (hipStream_t)stream, B, T, K, n * n,
                      E_states, J11, J12, J22, lz, out_J11, out_J12, out_J22, out_logZ);
+  return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+// One pass over the per-step pair statistics of the SLDS final pass (see slds_pair_contract_kernel): node_out (B,T,K) rows
+// 1 .. T-1 and `blocks` partials (blocks, 8, 3 n^2) of the weighted sums (gpart holds ONE more double behind them).  n <= 10, K <= 8.
+extern "C" int svae_slds_pair_contract_f64(int B, int T, int K, int n, const double* pair_stats, const double* P,
+                                           const double* lz, const double* weights, double* node_out, double* gpart,
+                                           int blocks, void* stream) {
+  if (B < 0) return -1;
+  if (T < 2) return -2;
+  if (K < 1 || K > 8) return -3;
+  if (n < 1 || n > 10) return -4;
+  if (!pair_stats) return -5;
+  if (!P || !lz) return -6;
+  if (!weights) return -8;
+  if (!node_out || !gpart) return -9;
+  if (blocks < 1) return -11;
+  const int E = 3 * n * n;
+  hipStream_t s = (hipStream_t)stream;
+  if (B == 0) {
+    (void)hipMemsetAsync(gpart, 0, sizeof(double) * (size_t)blocks * 8 * E, s);
+    return 0;
+  }
+  double* dummy = gpart + (size_t)blocks * 8 * E;      // one word behind the partials: the idle lanes' store target
+  if (blocks > B) {       // (workgroups without a sequence would leave their partial unwritten)
+    (void)hipMemsetAsync(gpart + (size_t)B * 8 * E, 0, sizeof(double) * (size_t)(blocks - B) * 8 * E, s);
+    blocks = B;
+  }
+  hipLaunchKernelGGL((svae::slds_pair_contract_kernel<5, 8>), dim3(blocks), dim3(256), 0, s, B, T, K, E, pair_stats, P, lz,
+                     weights, node_out, gpart, dummy);
   return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 

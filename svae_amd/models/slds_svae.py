@@ -189,6 +189,39 @@ def get_arhmm_local_nodeparams(dense_init, dense_pair, init_stats, pair_stats):
     return torch.cat([n0[:, None], nt], 1)
 
 
+def final_pass_contractions(dense_init, dense_pair, init_stats, pair_stats, expected_states):
+    """The pair part of get_arhmm_local_nodeparams (:131-147) and of get_global_stats (:229-243) on the per-step pair
+    statistics of the final LDS E-step in ONE pass over them (svae_slds_pair_contract_f64; they are 2.45 GB at configs[3]
+    and were read by two library GEMMs).  pair_stats: the kernels' packed (B,T-1,3,n,n) tensor.
+    -> (node_hmm (B,T,K), g_pair_sums (K,3,n,n)), or None where the kernel does not apply (the callers then use the two
+    functions above)."""
+    if not (isinstance(pair_stats, torch.Tensor) and pair_stats.is_cuda and pair_stats.dim() == 5
+            and pair_stats.is_contiguous() and not pair_stats.requires_grad):
+        return None
+    B, Tm1, _, n, _ = pair_stats.shape
+    K = dense_init[0].shape[0]
+    if n > 10 or K > 8 or Tm1 < 1 or B < 1:
+        return None
+    dev = pair_stats.device
+    T = Tm1 + 1
+    ExxT0, Ex0 = init_stats
+    f64 = dict(dtype=torch.float64, device=dev)
+    P = torch.cat([_dev64(dense_pair[i], dev).reshape(K, -1) for i in range(3)], 1).contiguous()
+    lz = _dev64(dense_pair[3], dev).contiguous()
+    Es = _dev64(expected_states, dev).contiguous()
+    node = torch.empty(B, T, K, **f64)
+    blocks = min(B, 2 * torch.cuda.get_device_properties(dev).multi_processor_count)
+    gbuf = torch.empty(blocks * 8 * 3 * n * n + 1, **f64)          # (+ the kernel's scratch word)
+    gpart = gbuf[:-1].view(blocks, 8, 3 * n * n)
+    p = _lib.ptr
+    rc = _lib.load().svae_slds_pair_contract_f64(B, T, K, n, p(pair_stats), p(P), p(lz), p(Es), p(node), p(gbuf), blocks,
+                                                 _lib.current_stream(dev))
+    _lib.check(rc, "svae_slds_pair_contract_f64")
+    node[:, 0] = ExxT0.reshape(B, -1) @ dense_init[0].reshape(K, -1).T + Ex0 @ dense_init[1].T \
+        + dense_init[2] + dense_init[3]
+    return node, gpart.sum(0)[:K].reshape(K, 3, n, n)
+
+
 def initialize_local_meanfield(node_potentials, eps):
     """(:203-226) statistics of ONE posterior sample path of a random-walk LDS; eps (B,T,1,n)."""
     x = _initial_sample_path(node_potentials, eps)
@@ -412,19 +445,22 @@ def _initial_sample_path(node_potentials, eps):
 
 
 def optimize_local_meanfield(global_natparam, node_potentials, init_eps, tol=1e-2, max_iter=100, fused=None,
-                             pair_stats=True, reference_compat=True):
+                             pair_stats=True, reference_compat=True, local_maps=None):
     """(:159-175).  Returns ((hmm_stats, lds_stats), (hmm_natparam, lds_natparam), (hmm_vlb, lds_vlb), iters).
 
     fused=None picks the fused LDS mean-field kernel (SLDSMeanfieldPlan) when it covers the shape, else the
     path that materialises per-step pair parameters and statistics; True / False force one.  On the fused
     path the per-step pair statistics of the reference's `lds_stats` tuple exist only if `pair_stats` (one
     extra E-step on the converged mean field): callers that run their own final pass (run_inference) skip it
-    and get `None` in that slot."""
+    and get `None` in that slot.  local_maps: the result of global_to_local_maps(global_natparam, device) where the caller
+    has it already (run_inference needs it again behind the ascent: rebuilt there, its small host-to-device copies queue
+    behind the final pass's kernels and block the host for their duration)."""
     hmm_global, lds_global = global_natparam
     dev = node_potentials[0].device
     node = tuple(_dev64(x, dev) for x in node_potentials)
     B, T, n = node[1].shape
-    hmm_init, hmm_pair, dense_init, dense_pair = global_to_local_maps(global_natparam, dev)
+    hmm_init, hmm_pair, dense_init, dense_pair = local_maps if local_maps is not None else \
+        global_to_local_maps(global_natparam, dev)
     K = dense_init[0].shape[0]
     if fused is None:
         fused = SLDSMeanfieldPlan.supported(n, T, K)
@@ -534,8 +570,9 @@ def _lds_estep_batched_init(plan, lds_init, lds_pair, node, keep_factor=False, r
     raise NotImplementedError("SLDS needs T > 1")
 
 
-def get_global_stats(hmm_stats, init_stats, pair_stats):
-    """(:229-243) -> (hmm (E_init, E_trans) summed over the batch, per state k: (init stats, pair stats))."""
+def get_global_stats(hmm_stats, init_stats, pair_stats, pair_sums=None):
+    """(:229-243) -> (hmm (E_init, E_trans) summed over the batch, per state k: (init stats, pair stats)).
+    pair_sums: the weighted sums of the pair statistics (K,3,n,n) where final_pass_contractions has formed them."""
     Ei, Et, Es = hmm_stats
     w0, w1 = Es[:, 0], Es[:, 1:]
     ExxT0, Ex0 = init_stats
@@ -545,7 +582,8 @@ def get_global_stats(hmm_stats, init_stats, pair_stats):
     g_init = ((w0.T @ ExxT0.reshape(B, n * n)).reshape(K, n, n), w0.T @ Ex0, w0.sum(0), w0.sum(0))
     # sum_{b,t} w1[b,t,k] * stats[b,t]: per sequence (K x T-1)(T-1 x 3n^2), then the batch sum (one long
     # reduction axis as a single GEMM is pathological in rocBLAS: 110 ms at B T = 1e6)
-    gp = torch.bmm(w1.transpose(1, 2), _packed_pair_stats(pair_stats)).sum(0).reshape(K, 3, n, n)
+    gp = pair_sums if pair_sums is not None else \
+        torch.bmm(w1.transpose(1, 2), _packed_pair_stats(pair_stats)).sum(0).reshape(K, 3, n, n)
     g_pair = (gp[:, 0], gp[:, 1], gp[:, 2], w1.sum((0, 1)))
     return (Ei.sum(0), Et.sum(0)), (g_init, g_pair)
 
@@ -573,8 +611,9 @@ def run_inference(prior_natparam, global_natparam, nn_potentials, num_samples, i
     B, T, n = node[1].shape
     if init_eps is None:
         init_eps = torch.randn(B, T, 1, n, dtype=torch.float64, device=dev, generator=generator)
+    maps = global_to_local_maps(global_natparam, dev)
     (hmm_stats, _), (hmm_nat, (lds_init, lds_pair)), _, _ = optimize_local_meanfield(
-        global_natparam, node, init_eps, tol, pair_stats=False, reference_compat=reference_compat)
+        global_natparam, node, init_eps, tol, pair_stats=False, reference_compat=reference_compat, local_maps=maps)
     plan = LDSEStepPlan(B, T, n, dev, inhomog=True, pair_batched=True)
     lognorm, (Ei, Ep, En) = _lds_estep_batched_init(plan, lds_init, lds_pair, node, keep_factor=True,
                                                     reference_compat=reference_compat)
@@ -582,10 +621,12 @@ def run_inference(prior_natparam, global_natparam, nn_potentials, num_samples, i
     if eps is None:
         eps = torch.randn(B, T, S, n, dtype=torch.float64, device=dev, generator=generator)
     samples = plan.sample(_dev64(eps, dev))
-    _, _, dense_init, dense_pair = global_to_local_maps(global_natparam, dev)
-    node_hmm = get_arhmm_local_nodeparams(dense_init, dense_pair, (Ei[0], Ei[1]), plan.E_pair)
+    _, _, dense_init, dense_pair = maps
+    fused = final_pass_contractions(dense_init, dense_pair, (Ei[0], Ei[1]), plan.E_pair, hmm_stats[2])
+    node_hmm, pair_sums = fused if fused is not None else \
+        (get_arhmm_local_nodeparams(dense_init, dense_pair, (Ei[0], Ei[1]), plan.E_pair), None)
     hmm_vlb, _ = hmm_estep((hmm_nat[0], hmm_nat[1], node_hmm))
-    expected_stats = get_global_stats(hmm_stats, (Ei[0], Ei[1]), plan.E_pair)
+    expected_stats = get_global_stats(hmm_stats, (Ei[0], Ei[1]), plan.E_pair, pair_sums)
     lds_vlb = lognorm - ((node[0] * En[0]).sum((1, 2)) + (node[1] * En[1]).sum((1, 2)))
     local_vlb = (hmm_vlb + lds_vlb).sum()
     expected_stats, local_vlb = allreduce_nested(expected_stats, local_vlb, group)
@@ -612,7 +653,7 @@ def slds_prior_vlb(global_natparam, prior_natparam, dev):
 
 
 def final_pass_differentiable(global_natparam, hmm_natparam, lds_natparam, nn_potentials, eps,
-                              reference_compat=True):
+                              reference_compat=True, local_maps=None):
     """The part of run_inference that depends on nn_potentials with gradients attached
     (slds_svae.py:295-307, "recompute terms that depend on nn_potentials at optimum"): the LDS
     E-step + sampler on the FIXED mean-field natural parameters, the HMM bound evaluated on its
@@ -632,7 +673,7 @@ def final_pass_differentiable(global_natparam, hmm_natparam, lds_natparam, nn_po
                 (J11.contiguous(), J12.contiguous(), J22.contiguous(), lz.contiguous()))
     lognorm, (dxx, ex), samples, (E_init, E_pair) = lds_inference_differentiable(natparam, (nJ, nh_eff), eps=eps)
     lognorm = lognorm + a0 if reference_compat else lognorm + a0 + b0
-    _, _, dense_init, dense_pair = global_to_local_maps(global_natparam, dev)
+    _, _, dense_init, dense_pair = local_maps if local_maps is not None else global_to_local_maps(global_natparam, dev)
     init_stats = (E_init[:, :n * n].reshape(B, n, n), E_init[:, n * n:])
     pair_stats = (E_pair[:, :, 0], E_pair[:, :, 1], E_pair[:, :, 2])
     node_hmm = get_arhmm_local_nodeparams(dense_init, dense_pair, init_stats, E_pair)
@@ -652,12 +693,13 @@ def run_inference_differentiable(prior_natparam, global_natparam, nn_potentials,
     B, T, n = node_d[1].shape
     if init_eps is None:
         init_eps = torch.randn(B, T, 1, n, dtype=torch.float64, device=dev, generator=generator)
+    maps = global_to_local_maps(global_natparam, dev)
     (hmm_stats, _), (hmm_nat, lds_nat), _, _ = optimize_local_meanfield(
-        global_natparam, node_d, init_eps, tol, pair_stats=False, reference_compat=reference_compat)
+        global_natparam, node_d, init_eps, tol, pair_stats=False, reference_compat=reference_compat, local_maps=maps)
     if eps is None:
         eps = torch.randn(B, T, int(num_samples), n, dtype=torch.float64, device=dev, generator=generator)
     samples, (init_stats, pair_stats), local_vlb = final_pass_differentiable(
-        global_natparam, hmm_nat, lds_nat, (nn_potentials[0], nn_potentials[1]), _dev64(eps, dev), reference_compat)
+        global_natparam, hmm_nat, lds_nat, (nn_potentials[0], nn_potentials[1]), _dev64(eps, dev), reference_compat, maps)
     expected_stats = get_global_stats(hmm_stats, tuple(x.detach() for x in init_stats),
                                       tuple(x.detach() for x in pair_stats))
     expected_stats, local_vlb = allreduce_nested(expected_stats, local_vlb, group)

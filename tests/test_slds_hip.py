@@ -569,3 +569,36 @@ def test_check_info_reports_invalid_global_parameters_and_stays_silent_otherwise
     with pytest.raises(FloatingPointError, match="global -> local maps"):
         slds_svae.check_info()
     slds_svae.check_info()                                            # the word is cleared once reported
+
+
+@pytest.mark.parametrize("K,n,T,B", [(8, 10, 40, 11), (3, 4, 9, 5), (1, 1, 2, 1), (5, 7, 2, 4), (8, 3, 130, 700), (7, 10, 6, 3),
+                                     (8, 9, 5, 1200)])
+def test_final_pass_contractions_against_the_two_library_forms(K, n, T, B):
+    """svae_slds_pair_contract_f64 (ONE pass over the per-step pair statistics of the final LDS E-step) against
+    get_arhmm_local_nodeparams and get_global_stats (slds_svae.py:131-147, 229-243; themselves pinned on the reference's
+    goldens above): HMM node potentials and the weighted sums of the pair statistics."""
+    from svae_amd.models import slds_svae
+    rng = np.random.default_rng(77 * K + 5 * n + T + B)
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev)
+    (_, _), lds = _globals(K, n, rng)
+    dense_init, dense_pair = slds_svae.get_all_lds_local_natparams([(t(a), tuple(t(y) for y in m)) for a, m in lds])
+    dense_init = tuple(x.to(dev) for x in dense_init)
+    dense_pair = tuple(x.to(dev) for x in dense_pair)
+    E_pair = t(rng.standard_normal((B, T - 1, 3, n, n)))
+    init_stats = (t(rng.standard_normal((B, n, n))), t(rng.standard_normal((B, n))))
+    w = rng.random((B, T, K)) ** 2 + 1e-3
+    Es = t(w / w.sum(-1, keepdims=True))
+    hmm_stats = (Es[:, 0].clone(), t(rng.random((B, K, K))), Es)
+    got = slds_svae.final_pass_contractions(dense_init, dense_pair, init_stats, E_pair, Es)
+    assert got is not None
+    node, pair_sums = got
+    want_node = slds_svae.get_arhmm_local_nodeparams(dense_init, dense_pair, init_stats, E_pair)
+    assert tuple(node.shape) == (B, T, K)
+    _close(node, _np(want_node), 1e-11)
+    want = slds_svae.get_global_stats(hmm_stats, init_stats, E_pair)
+    have = slds_svae.get_global_stats(hmm_stats, init_stats, E_pair, pair_sums)
+    for a, b in zip(have[1][1], want[1][1]):
+        _close(a, _np(b), 1e-11)
+    # shapes the kernel does not cover fall back to the library forms
+    assert slds_svae.final_pass_contractions(dense_init, dense_pair, init_stats, E_pair.cpu(), Es) is None
