@@ -19,7 +19,7 @@ d = json.loads(open("gpurun_out/r5_final/bench.json").read().strip().splitlines(
 print("value", d["value"], "ms", d["ms_per_step"], "parity", d["parity"]["max_rel"], d["parity"]["ok"])
 print("roofline", {k: d["roofline"][k] for k in ("frac", "kernel_ms", "traffic", "traffic_source", "traffic_over_algorithmic")})
 for i, e in enumerate(d.get("extra", [])):
-    print(i, {k: (round(v, 4) if isinstance(v, float) else v) for k, v in e.items() if k in ("value", "ms_per_step", "ms_per_pass", "ms_per_ascent", "us_per_fixed_point", "us_per_step", "us_per_step_graph", "eager_ms_per_step", "graph_ms_per_step", "error")},
+    print(i, {k: (round(v, 4) if isinstance(v, float) else v) for k, v in e.items() if k in ("value", "ms_per_step", "ms_per_pass", "ms_per_ascent", "ms_per_run_inference", "us_per_fixed_point", "us_per_step", "us_per_step_graph", "eager_ms_per_step", "graph_ms_per_step", "error")},
           (e.get("roofline") or {}).get("traffic"), (e.get("parity") or {}).get("max_rel"))
 print("cpu", {k: d["cpu_baseline"].get(k) for k in ("value", "cores", "kind")})
 PY
