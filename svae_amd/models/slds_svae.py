@@ -222,6 +222,29 @@ def final_pass_contractions(dense_init, dense_pair, init_stats, pair_stats, expe
     return node, gpart.sum(0)[:K].reshape(K, 3, n, n)
 
 
+class _PairContract(torch.autograd.Function):
+    """final_pass_contractions with the gradient of the HMM node potentials w.r.t. the pair statistics attached:
+    node[b,t+1,k] = <S[b,t], P_k> + lz_k  =>  dL/dS[b,t] = sum_k g[b,t+1,k] P_k (one library GEMM in the backward pass);
+    the weighted sums are formed from the values only (the reference detaches the statistics it returns)."""
+
+    @staticmethod
+    def forward(ctx, pair_stats, ExxT0, Ex0, dense_init, dense_pair, expected_states):
+        node, sums = final_pass_contractions(dense_init, dense_pair, (ExxT0.detach(), Ex0.detach()), pair_stats.detach(),
+                                             expected_states)
+        K = dense_init[0].shape[0]
+        ctx.P = torch.cat([dense_pair[i].reshape(K, -1) for i in range(3)], 1)
+        ctx.Jk, ctx.hk = dense_init[0].reshape(K, -1), dense_init[1]
+        ctx.shapes = (pair_stats.shape, ExxT0.shape)
+        ctx.mark_non_differentiable(sums)
+        return node, sums
+
+    @staticmethod
+    def backward(ctx, g_node, _g_sums):
+        g_pair = (g_node[:, 1:] @ ctx.P).reshape(ctx.shapes[0])
+        g0 = g_node[:, 0]
+        return g_pair, (g0 @ ctx.Jk).reshape(ctx.shapes[1]), g0 @ ctx.hk, None, None, None
+
+
 def initialize_local_meanfield(node_potentials, eps):
     """(:203-226) statistics of ONE posterior sample path of a random-walk LDS; eps (B,T,1,n)."""
     x = _initial_sample_path(node_potentials, eps)
@@ -663,11 +686,13 @@ def slds_prior_vlb(global_natparam, prior_natparam, dev):
 
 
 def final_pass_differentiable(global_natparam, hmm_natparam, lds_natparam, nn_potentials, eps,
-                              reference_compat=True, local_maps=None):
+                              reference_compat=True, local_maps=None, expected_states=None):
     """The part of run_inference that depends on nn_potentials with gradients attached
     (slds_svae.py:295-307, "recompute terms that depend on nn_potentials at optimum"): the LDS
     E-step + sampler on the FIXED mean-field natural parameters, the HMM bound evaluated on its
-    statistics, and the local bound.  Returns (samples, (E_init, E_pair) per sequence, local_vlb)."""
+    statistics, and the local bound.  Returns (samples, (E_init, E_pair) per sequence, local_vlb); with
+    `expected_states` (the HMM marginals of the ascent) a fourth entry: the pair statistics summed with those weights
+    (K,3,n,n) for get_global_stats, or None -- formed by the kernel that also builds the HMM node potentials."""
     dev = nn_potentials[1].device
     nJ, nh = nn_potentials[0], nn_potentials[1]
     B, T, n = nh.shape
@@ -686,9 +711,17 @@ def final_pass_differentiable(global_natparam, hmm_natparam, lds_natparam, nn_po
     _, _, dense_init, dense_pair = local_maps if local_maps is not None else global_to_local_maps(global_natparam, dev)
     init_stats = (E_init[:, :n * n].reshape(B, n, n), E_init[:, n * n:])
     pair_stats = (E_pair[:, :, 0], E_pair[:, :, 1], E_pair[:, :, 2])
-    node_hmm = get_arhmm_local_nodeparams(dense_init, dense_pair, init_stats, E_pair)
+    pair_sums = None
+    K = dense_init[0].shape[0]
+    if expected_states is not None and E_pair.is_cuda and E_pair.is_contiguous() and n <= 10 and K <= 8 and T > 1:
+        node_hmm, pair_sums = _PairContract.apply(E_pair, init_stats[0], init_stats[1], dense_init, dense_pair,
+                                                  expected_states)
+    else:
+        node_hmm = get_arhmm_local_nodeparams(dense_init, dense_pair, init_stats, E_pair)
     hmm_vlb = hmm_logZ_differentiable((hmm_natparam[0], hmm_natparam[1], node_hmm))
     lds_vlb = lognorm - ((nJ * dxx).sum((1, 2)) + (nh * ex).sum((1, 2)))
+    if expected_states is not None:
+        return samples, (init_stats, pair_stats), (hmm_vlb + lds_vlb).sum(), pair_sums
     return samples, (init_stats, pair_stats), (hmm_vlb + lds_vlb).sum()
 
 
@@ -709,10 +742,11 @@ def run_inference_differentiable(prior_natparam, global_natparam, nn_potentials,
         global_natparam, node_d, init_eps, tol, pair_stats=False, reference_compat=reference_compat, local_maps=maps)
     if eps is None:
         eps = torch.randn(B, T, int(num_samples), n, dtype=torch.float64, device=dev, generator=generator)
-    samples, (init_stats, pair_stats), local_vlb = final_pass_differentiable(
-        global_natparam, hmm_nat, lds_nat, (nn_potentials[0], nn_potentials[1]), _dev64(eps, dev), reference_compat, maps)
+    samples, (init_stats, pair_stats), local_vlb, pair_sums = final_pass_differentiable(
+        global_natparam, hmm_nat, lds_nat, (nn_potentials[0], nn_potentials[1]), _dev64(eps, dev), reference_compat, maps,
+        hmm_stats[2])
     expected_stats = get_global_stats(hmm_stats, tuple(x.detach() for x in init_stats),
-                                      tuple(x.detach() for x in pair_stats))
+                                      tuple(x.detach() for x in pair_stats), pair_sums)
     expected_stats, local_vlb = allreduce_nested(expected_stats, local_vlb, group)
     global_vlb = slds_prior_vlb(host_params[0], host_params[1], dev)
     return samples, expected_stats, global_vlb, local_vlb

@@ -311,9 +311,12 @@ def test_config3_full_size_fused_ascent_against_oracle():
     assert worst < 1e-8, worst               # observed 3.8e-10 (round 5); north_star asks 1e-5
 
 
-def test_final_pass_gradient_against_finite_differences():
+@pytest.mark.parametrize("fused_contraction", [False, True])
+def test_final_pass_gradient_against_finite_differences(fused_contraction):
     """d(local_vlb + <g, samples>)/d(nn_potentials) through the VJP kernels (per-step pair parameters,
-    cotangents of E_init / E_pair from the HMM bound) against central differences of the forward."""
+    cotangents of E_init / E_pair from the HMM bound) against central differences of the forward.
+    fused_contraction: the HMM node potentials through svae_slds_pair_contract_f64 with its hand-written backward
+    (models.slds_svae._PairContract: what run_inference_differentiable runs) instead of the library GEMM under autograd."""
     from svae_amd.models import slds_svae
     K, n, T, B, S = 3, 3, 6, 2, 2
     rng = np.random.default_rng(21)
@@ -322,12 +325,17 @@ def test_final_pass_gradient_against_finite_differences():
     dev = torch.device("cuda:0")
     t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev)
     node = (t(J), t(h))
-    (_, _), (hmm_nat, lds_nat), _, _ = slds_svae.optimize_local_meanfield(glob, node, t(rng.standard_normal((B, T, 1, n))))
+    (hmm_stats, _), (hmm_nat, lds_nat), _, _ = slds_svae.optimize_local_meanfield(glob, node, t(rng.standard_normal((B, T, 1, n))))
     eps = t(rng.standard_normal((B, T, S, n)))
     gs = t(rng.standard_normal((B, T, S, n)))
 
     def f(nJ, nh):
-        samples, _, local_vlb = slds_svae.final_pass_differentiable(glob, hmm_nat, lds_nat, (nJ, nh), eps)
+        if fused_contraction:
+            samples, _, local_vlb, sums = slds_svae.final_pass_differentiable(glob, hmm_nat, lds_nat, (nJ, nh), eps,
+                                                                             expected_states=hmm_stats[2])
+            assert sums is not None and tuple(sums.shape) == (K, 3, n, n)
+        else:
+            samples, _, local_vlb = slds_svae.final_pass_differentiable(glob, hmm_nat, lds_nat, (nJ, nh), eps)
         return local_vlb + (gs * samples).sum()
 
     nJ, nh = node[0].clone().requires_grad_(True), node[1].clone().requires_grad_(True)
