@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SVAE_HIP_ABI_VERSION 13   /* 13: + svae_slds_pair_contract_f64 (the two contractions of the SLDS final pass over the per-step pair statistics in one pass); 12: svae_gmm_global_step_f64 writes kl[0..1] (as spelled | as shipped), svae_ipc_allreduce_f64 takes the mailbox stride and never writes `out` on a timeout, + svae_slds_lds_meanfield options; 11: + svae_lds_global_step_multi_f64 (K parameter sets in one launch: the SLDS global -> local maps), svae_lds_diag_sample_f64 (filter + sampler of an all-diagonal LDS: the SLDS initial path); 10: + svae_ipc_allreduce_f64 / svae_ipc_mailbox_bytes, svae_gmm_sample_f64, svae_gmm_local_vjp_f64, svae_gmm_global_step_f64 (the differentiable tail and the global side of the GMM local step); 9: keep bit SVAE_KEEP_SIGMA of svae_lds_estep_f64 (16 <= n <= 64) + svae_lds_tile_sigma_offset_bytes; 8: step ranges (t_begin, t_end) in svae_lds_tile_vjp_f64 / svae_lds_tile_noise_f64, SVAE_OPT_TILE_FORWARD / _BACKWARD; 7: + svae_slds_path_nodeparams_f64, svae_slds_mix_pair_natparam_f64; 6: per-call `options` word replaces the process-global svae_lds_set_* selectors (re-entrant library), + svae_slds_hmm_meanfield_f64, svae_slds_sweep_glue_f64, g_E_pair in svae_lds_tile_vjp_f64; 5: + svae_lds_set_prod_max_b; 4: + svae_slds_lds_meanfield_f64, svae_gmm_mw_*, svae_lds_global_step_f64, svae_lds_natgrad_f64, svae_lds_tile_vjp_f64; 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
+#define SVAE_HIP_ABI_VERSION 14   /* 14: + svae_lds_inference_f64 (E-step + sampler in one call; lean per-step records for large homogeneous batches), svae_lds_inference_is_lean, SVAE_OPT_LEAN_ON / _OFF / SVAE_OPT_INFER_RECORDS; 13: + svae_slds_pair_contract_f64 (the two contractions of the SLDS final pass over the per-step pair statistics in one pass); 12: svae_gmm_global_step_f64 writes kl[0..1] (as spelled | as shipped), svae_ipc_allreduce_f64 takes the mailbox stride and never writes `out` on a timeout, + svae_slds_lds_meanfield options; 11: + svae_lds_global_step_multi_f64 (K parameter sets in one launch: the SLDS global -> local maps), svae_lds_diag_sample_f64 (filter + sampler of an all-diagonal LDS: the SLDS initial path); 10: + svae_ipc_allreduce_f64 / svae_ipc_mailbox_bytes, svae_gmm_sample_f64, svae_gmm_local_vjp_f64, svae_gmm_global_step_f64 (the differentiable tail and the global side of the GMM local step); 9: keep bit SVAE_KEEP_SIGMA of svae_lds_estep_f64 (16 <= n <= 64) + svae_lds_tile_sigma_offset_bytes; 8: step ranges (t_begin, t_end) in svae_lds_tile_vjp_f64 / svae_lds_tile_noise_f64, SVAE_OPT_TILE_FORWARD / _BACKWARD; 7: + svae_slds_path_nodeparams_f64, svae_slds_mix_pair_natparam_f64; 6: per-call `options` word replaces the process-global svae_lds_set_* selectors (re-entrant library), + svae_slds_hmm_meanfield_f64, svae_slds_sweep_glue_f64, g_E_pair in svae_lds_tile_vjp_f64; 5: + svae_lds_set_prod_max_b; 4: + svae_slds_lds_meanfield_f64, svae_gmm_mw_*, svae_lds_global_step_f64, svae_lds_natgrad_f64, svae_lds_tile_vjp_f64; 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
 #define SVAE_LDS_MAX_N 15   /* register/DPP path: one 16-lane row per sequence, n+1 <= 16 */
 #define SVAE_LDS_TILE_MAX_N 64   /* 16 <= n <= 64: LDS-tiled MFMA path (keep: SVAE_KEEP_SIGMA or 0) */
 #define SVAE_KEEP_SIGMA 4         /* keep bit of svae_lds_estep_f64, 16 <= n <= 64 only: see svae_lds_tile_sigma_offset_bytes */
@@ -133,6 +133,11 @@ int svae_lds_filter_f64(int B, int T, int n, int inhomog, int pair_batched, unsi
 #define SVAE_OPT_PRODUCERS_ON   0x10u   /* producer / helper wavefronts whatever B */
 #define SVAE_OPT_PRODUCERS_OFF  0x20u   /* never */
 #define SVAE_OPT_ALL            0x3fu   /* (contradictory pairs or unknown bits: the call returns -24) */
+/* Record format of svae_lds_inference_f64 (below); accepted and ignored by the other entry points, so that a caller can
+ * pass one word with every call of a plan. */
+#define SVAE_OPT_LEAN_ON        0x100u  /* lean per-step records whatever B (where they apply: see svae_lds_inference_f64) */
+#define SVAE_OPT_LEAN_OFF       0x200u  /* never */
+#define SVAE_OPT_INFER_RECORDS  0x400u  /* svae_lds_estep_vjp_ex_f64 only: `workspace` was written by svae_lds_inference_f64 */
 /* svae_lds_estep_f64 with 16 <= n <= 64 only (any other use: -24): run HALF of the E-step.  The forward half (filter,
  * hand-off, log-normaliser) and the backward half (smoother + statistics, from the hand-off a forward-only call left
  * in the same workspace) meet only through the hand-off, so a training step can run the backward half on one stream
@@ -300,6 +305,32 @@ int svae_lds_reduce_stats_f64(int B, int n, const double* E_init, const double* 
  */
 int svae_lds_sample_f64(int B, int T, int n, int S, unsigned options, const double* eps, double* samples,
                         const void* workspace, size_t ws_bytes, void* stream);
+
+/* E-step + backward sampling in ONE call: the composite the reference's model layer uses,
+ *   cython_natural_lds_inference_general(natparam, node_params, num_samples) -> (samples, expected_stats, lognorm)
+ *     /root/reference/svae/lds/lds_inference.py:196-202  (= natural_filter_forward_general, natural_smoother_general,
+ *     natural_sample_backward: /root/reference/svae/lds/cython_lds_inference.pyx:28-90, 149-210, 310-355),
+ * keeping in `workspace` what svae_lds_estep_vjp_ex_f64 needs (called with SVAE_OPT_INFER_RECORDS, the same B, T, n, S,
+ * inhomog and `options`).  Arguments as svae_lds_estep_f64 (n <= SVAE_LDS_MAX_N) plus eps, samples (B,T,S,n) as
+ * svae_lds_sample_f64; S = 0: no sampling (eps, samples may be NULL).  Same results as svae_lds_estep_f64 with keep = 3
+ * followed by svae_lds_sample_f64 -- and in general exactly those two calls.  What the single entry point buys: for
+ * homogeneous pair parameters, n <= 10, T >= 2, S <= 4 and batches of more than 2048 sequences (or SVAE_OPT_LEAN_ON)
+ * the per-step records that travel through HBM shrink from (4n+3)n + (n+1)(n+2) doubles to n(n+1)/2 + n (+ the cross
+ * moments): the forward pass keeps only U_t = chol(P_t)^-T and c_t, every reader rebuilds P_t^-1 = U U' and P_t^-1 J12,
+ * the sampler runs inside the smoother's loop, and the first VJP sweep hands the second one symmetric triangle
+ * (csrc/lds_lean_estep.hpp, lds_lean_vjp.hpp).  After a lean call svae_lds_sample_f64 cannot follow (the samples were
+ * drawn here) and the VJP takes no cotangents of E_init / E_pair.  svae_lds_inference_is_lean: which format a call with
+ * these arguments uses (1 = lean; host only, a pure function of its arguments).
+ * Return values as svae_lds_estep_f64; -4: bad S / missing eps or samples; -100 + k: the sampler stage returned k. */
+int svae_lds_inference_is_lean(int B, int T, int n, int S, int inhomog, unsigned options);
+int svae_lds_inference_f64(int B, int T, int n, int S, int inhomog, int pair_batched, unsigned options,
+                           const double* init_J, const double* init_h, const double* init_logZ,
+                           const double* J11, const double* J12, const double* J22, const double* logZ_pair,
+                           const double* node_J, const double* node_h, const double* node_logZ,
+                           const double* eps, double* samples,
+                           double* lognorm, double* E_init, double* E_pair,
+                           double* E_node_diagxx, double* E_node_x,
+                           int32_t* info, void* workspace, size_t ws_bytes, void* stream);
 
 /* Bytes of scratch svae_lds_estep_vjp_f64 needs in addition to the E-step workspace. */
 size_t svae_lds_vjp_workspace_bytes(int B, int T, int n);

@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must precede CDLL: shares torch's HIP runtime)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVAE_AMD_LIB", os.path.join(_HERE, "libsvae_hip.so"))  # env: experiments only
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 LDS_MAX_N = 15        # register/DPP path (E-step, sampler, VJP)
 LDS_TILE_MAX_N = 64   # LDS-tiled MFMA path (E-step only)
 
@@ -20,6 +20,7 @@ LDS_TILE_MAX_N = 64   # LDS-tiled MFMA path (E-step only)
 OPT_DEFAULT, OPT_TWOEND_OFF, OPT_TWOEND_FULL = 0x00, 0x01, 0x02
 OPT_LAYOUT_SPLIT, OPT_LAYOUT_PACKED, OPT_PRODUCERS_ON, OPT_PRODUCERS_OFF = 0x04, 0x08, 0x10, 0x20
 OPT_TILE_FORWARD, OPT_TILE_BACKWARD = 0x40, 0x80     # 16 <= n <= 64 only: one half of the E-step per call
+OPT_LEAN_ON, OPT_LEAN_OFF, OPT_INFER_RECORDS = 0x100, 0x200, 0x400   # record format of svae_lds_inference_f64 / its VJP
 KEEP_SIGMA = 4                                       # keep bit of svae_lds_estep_f64, 16 <= n <= 64 only (SVAE_KEEP_SIGMA)
 # names used by tests / tools / bench.py --kernel for the E-step kernel families
 KERNEL_OPTIONS = {"auto": OPT_DEFAULT, "twoend": OPT_DEFAULT, "twoend_full": OPT_TWOEND_FULL,
@@ -53,6 +54,9 @@ SIGNATURES = {
     "svae_lds_estep_vjp_ex_f64": (ctypes.c_int, [ctypes.c_int] * 6 + [ctypes.c_uint] + [_c_double_p] * 13
                                   + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
                                      ctypes.c_void_p]),
+    "svae_lds_inference_is_lean": (ctypes.c_int, [ctypes.c_int] * 5 + [ctypes.c_uint]),
+    "svae_lds_inference_f64": (ctypes.c_int, [ctypes.c_int] * 6 + [ctypes.c_uint] + [_c_double_p] * 17
+                               + [_c_int_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "svae_lds_sample_f64": (ctypes.c_int, [ctypes.c_int] * 4 + [ctypes.c_uint] + [_c_double_p] * 2
                             + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "svae_hmm_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),

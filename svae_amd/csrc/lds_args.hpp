@@ -132,4 +132,29 @@ constexpr int vjp_pbp_off(int n) { return vjp_vec_off(n) + 2 * VJP_SPLIT_MAX_S *
 constexpr int vjp_pex_off(int n) { return vjp_pbp_off(n) + vjp_tri_doubles(n); }
 constexpr int vjp_step_doubles(int n) { return vjp_pex_off(n) + n * ws_p_stride(n); }
 
+// ---- LEAN records of the large-batch training path (lds_lean_estep.hpp / lds_lean_vjp.hpp; round 6) -----------------
+// svae_lds_inference_f64 with homogeneous pair parameters, n <= LEAN_MAX_N, 1 <= T, S <= LEAN_MAX_S and a batch the packed
+// kernels serve: per (sequence, step) the forward pass keeps ONLY
+//   [ U = chol(P_t)^-T = L^-T D^-1/2, upper triangle packed by rows (row k at lean_row_off(k), entries c = k .. n-1)
+//   | c_t = P_t^-1 h_filt,t (n) | trash / pad ]                                              = lean_rec_doubles(n)
+// (66 doubles at n = 10 against 330 of the full hand-off + factor region).  Every reader rebuilds P^-1 = U U' (n(n+1)/2
+// DPP multiply-adds) and P^-1 J12 (n^2) from it; the sampler's noise is U eps.  The cross-moment region (W~_t) is
+// unchanged.  Sweep 1 leaves [G^ (n rows x ws_h_stride) | lower triangle of -P^-1 Pinvbar P^-1 + sym(Pbar(direct))]:
+// only the symmetric part of the sampler's direct share reaches the gradients (every map it goes through is a
+// congruence, and the outputs take the diagonal), so the two shares travel as ONE triangle.
+constexpr int LEAN_MAX_N = 10;
+constexpr int LEAN_MAX_S = 4;
+constexpr int LEAN_MIN_B = 2049;        // default dispatch: batches the two-role (split) sweeps do not serve
+constexpr int lean_tri(int n) { return n * (n + 1) / 2; }
+constexpr int lean_row_off(int n, int k) { return k * n - k * (k - 1) / 2; }
+constexpr int lean_trash(int n) { return lean_tri(n) + n; }
+constexpr int lean_rec_doubles(int n) { return (lean_tri(n) + n + 2) & ~1; }
+constexpr int lean_adj_tri_off(int n) { return n * ws_h_stride(n); }
+constexpr int lean_adj_doubles(int n) { return lean_adj_tri_off(n) + vjp_tri_doubles(n); }
+struct LeanSample {
+  int S;                              // 0: no sampling
+  const double* __restrict__ eps;     // (B, T, S, n)
+  double* __restrict__ samples;       // (B, T, S, n)
+};
+
 }  // namespace svae

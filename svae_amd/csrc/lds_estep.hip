@@ -20,7 +20,9 @@ extern "C" {
   int svae_lds_launch_filter_1r_n##NN(const svae::LdsArgs*, int, void*);       \
   int svae_lds_launch_forward_pair_n##NN(const svae::LdsArgs*, const svae::LdsArgs*, int, void*); \
   int svae_lds_sample_n##NN(const svae::SampleArgs*, void*);                   \
-  int svae_lds_vjp_n##NN(const svae::VjpArgs*, void*);
+  int svae_lds_vjp_n##NN(const svae::VjpArgs*, void*);                         \
+  int svae_lds_infer_lean_n##NN(const svae::LdsArgs*, const svae::LeanSample*, void*); \
+  int svae_lds_vjp_lean_n##NN(const svae::VjpArgs*, void*);
 #define SVAE_DECL(NN) SVAE_DECL_(NN)
 #ifdef SVAE_ONLY_N   /* experimental single-n builds (tools/build_variant.sh) */
 SVAE_DECL(SVAE_ONLY_N)
@@ -109,6 +111,8 @@ extern "C" {
 // The selection is a function of the call's arguments only: the library holds no process-global state.
 struct Selection { int twoend; bool split; int layout; int prod_max_b; };
 static bool decode_options(unsigned options, int B, Selection* s) {
+  if ((options & SVAE_OPT_LEAN_ON) && (options & SVAE_OPT_LEAN_OFF)) return false;
+  options &= ~(SVAE_OPT_LEAN_ON | SVAE_OPT_LEAN_OFF | SVAE_OPT_INFER_RECORDS);   /* (record format: lean_applies) */
   if (options & ~SVAE_OPT_ALL) return false;
   if ((options & SVAE_OPT_TWOEND_OFF) && (options & SVAE_OPT_TWOEND_FULL)) return false;
   if ((options & SVAE_OPT_LAYOUT_SPLIT) && (options & SVAE_OPT_LAYOUT_PACKED)) return false;
@@ -121,6 +125,20 @@ static bool decode_options(unsigned options, int B, Selection* s) {
 }
 
 int svae_hip_abi_version(void) { return SVAE_HIP_ABI_VERSION; }
+
+// Record format of svae_lds_inference_f64 (and of the svae_lds_estep_vjp_ex_f64 call that reads its workspace with
+// SVAE_OPT_INFER_RECORDS): a pure function of the arguments both calls share -- the library keeps no state.
+static bool lean_applies(int B, int T, int n, int S, int inhomog, unsigned options) {
+  if (inhomog || n > svae::LEAN_MAX_N || T < 2 || S < 0 || S > svae::LEAN_MAX_S) return false;
+  if ((long)T * svae::lean_rec_doubles(n) * 8 * 4 >= (1l << 31)) return false;     // 32-bit lane offsets inside a wavefront's records
+  if (options & SVAE_OPT_LEAN_OFF) return false;
+  if (options & SVAE_OPT_LEAN_ON) return true;
+  if (options & (SVAE_OPT_LAYOUT_SPLIT | SVAE_OPT_PRODUCERS_ON)) return false;
+  return B >= svae::LEAN_MIN_B;
+}
+int svae_lds_inference_is_lean(int B, int T, int n, int S, int inhomog, unsigned options) {
+  return lean_applies(B, T, n, S, inhomog, options) ? 1 : 0;
+}
 
 // main region: the one-directional layout (lds_args.hpp), then -- n <= 10 -- the two-ended one (a launch that
 // keeps the sampler / VJP hand-off runs BOTH kernels, see svae_lds_estep_f64), then B doubles of scratch
@@ -450,6 +468,75 @@ extern "C" int svae_lds_sample_f64(int B, int T, int n, int S, unsigned options,
   return -3;
 }
 
+extern "C" int svae_lds_inference_f64(int B, int T, int n, int S, int inhomog, int pair_batched, unsigned options,
+                                      const double* init_J, const double* init_h, const double* init_logZ,
+                                      const double* J11, const double* J12, const double* J22, const double* logZ_pair,
+                                      const double* node_J, const double* node_h, const double* node_logZ,
+                                      const double* eps, double* samples,
+                                      double* lognorm, double* E_init, double* E_pair,
+                                      double* E_node_diagxx, double* E_node_x,
+                                      int32_t* info, void* workspace, size_t ws_bytes, void* stream) {
+  if (n < 1 || n > SVAE_LDS_MAX_N) return -3;
+  if (S < 0 || (S > 0 && (!eps || !samples))) return -4;
+  if (!lean_applies(B, T, n, S, inhomog, options)) {
+    // the general path: E-step keeping the hand-off, the factor and the cross moments, then the sampler
+    const unsigned o = options & SVAE_OPT_ALL;
+    const int rc = svae_lds_estep_f64(B, T, n, inhomog, pair_batched, 3, o, init_J, init_h, init_logZ, J11, J12, J22,
+                                      logZ_pair, node_J, node_h, node_logZ, lognorm, E_init, E_pair, E_node_diagxx,
+                                      E_node_x, info, workspace, ws_bytes, stream);
+    if (rc != 0 || S == 0 || B == 0) return rc;
+    const int rs = svae_lds_sample_f64(B, T, n, S, o, eps, samples, workspace, ws_bytes, stream);
+    return rs == 0 ? 0 : -100 + rs;
+  }
+  if (B < 0) return -1;
+  if (!init_J) return -6;
+  if (!init_h) return -7;
+  if (!init_logZ) return -8;
+  if (!J11 || !J12 || !J22 || !logZ_pair) return -9;
+  if (!node_J) return -13;
+  if (!node_h) return -14;
+  if (!lognorm) return -16;
+  if (!E_init) return -17;
+  if (!E_pair) return -18;
+  if (!E_node_diagxx) return -19;
+  if (!E_node_x) return -20;
+  if (!info) return -21;
+  if (!workspace || ws_bytes < svae_lds_workspace_bytes(B, T, n)) return -22;
+  Selection sel;
+  if (!decode_options(options, B, &sel)) return -24;
+  if (B == 0) return 0;
+  svae::LdsArgs a;
+  a.tile_half = 0;
+  a.B = B; a.T = T;
+  a.init_J = init_J; a.init_h = init_h; a.init_logZ = init_logZ;
+  a.J11 = J11; a.J12 = J12; a.J22 = J22; a.logZ_pair = logZ_pair;
+  a.node_J = node_J; a.node_h = node_h; a.node_logZ = node_logZ;
+  a.lognorm = lognorm; a.E_init = E_init; a.E_pair = E_pair;
+  a.E_node_diagxx = E_node_diagxx; a.E_node_x = E_node_x;
+  a.info = info; a.ws = (double*)workspace;        // lean records at the start of the main region
+  a.ws2 = nullptr;
+  a.ws3 = (double*)workspace + main_ws_doubles(B, T, n) + factor_ws_doubles(B, T, n);   // cross moments: where the VJP looks
+  a.pair_seq_stride = 0;
+  a.msg_Jp = a.msg_hp = a.msg_Jf = a.msg_hf = nullptr;
+  a.mix_w = nullptr; a.mix_out = nullptr; a.seq_index = nullptr; a.mix_K = 0; a.lds_keep = 0;
+  a.sig_out = nullptr;
+  svae::LeanSample ls;
+  ls.S = S; ls.eps = eps; ls.samples = samples;
+  switch (n) {
+#define SVAE_CASE_(NN) case NN: return svae_lds_infer_lean_n##NN(&a, &ls, stream);
+#define SVAE_CASE(NN) SVAE_CASE_(NN)
+#ifdef SVAE_ONLY_N
+    SVAE_CASE(SVAE_ONLY_N)
+#else
+    SVAE_CASE(1) SVAE_CASE(2) SVAE_CASE(3) SVAE_CASE(4) SVAE_CASE(5) SVAE_CASE(6) SVAE_CASE(7)
+    SVAE_CASE(8) SVAE_CASE(9) SVAE_CASE(10)
+#endif
+#undef SVAE_CASE
+#undef SVAE_CASE_
+  }
+  return -3;
+}
+
 extern "C" size_t svae_lds_vjp_workspace_bytes(int B, int T, int n) {
   if (B <= 0 || T <= 0 || n <= 0 || n > SVAE_LDS_MAX_N) return 0;
   return (size_t)B * T * svae::vjp_step_doubles(n) * sizeof(double);
@@ -493,6 +580,22 @@ extern "C" int svae_lds_estep_vjp_ex_f64(int B, int T, int n, int S, int inhomog
   a.ws2 = a.ws + main_ws_doubles(B, T, n);
   a.ws3 = a.ws2 + factor_ws_doubles(B, T, n);
   a.adj = (double*)vjp_workspace;
+  if ((options & SVAE_OPT_INFER_RECORDS) && lean_applies(B, T, n, S, inhomog, options)) {
+    if (g_E_init || g_E_pair) return -8;        /* lean records: cotangents of the node statistics, lognorm and samples */
+    switch (n) {
+#define SVAE_CASE_(NN) case NN: return svae_lds_vjp_lean_n##NN(&a, stream);
+#define SVAE_CASE(NN) SVAE_CASE_(NN)
+#ifdef SVAE_ONLY_N
+      SVAE_CASE(SVAE_ONLY_N)
+#else
+      SVAE_CASE(1) SVAE_CASE(2) SVAE_CASE(3) SVAE_CASE(4) SVAE_CASE(5) SVAE_CASE(6) SVAE_CASE(7)
+      SVAE_CASE(8) SVAE_CASE(9) SVAE_CASE(10)
+#endif
+#undef SVAE_CASE
+#undef SVAE_CASE_
+    }
+    return -3;
+  }
   switch (n) {
 #define SVAE_CASE_(NN) case NN: return svae_lds_vjp_n##NN(&a, stream);
 #define SVAE_CASE(NN) SVAE_CASE_(NN)

@@ -11,6 +11,7 @@
 #include "lds_estep_twoend_rpc.hpp"
 #include "lds_estep_twoend_rpcmix.hpp"
 #include "lds_filter_1r.hpp"
+#include "lds_lean_estep.hpp"
 
 #ifndef SVAE_N
 #error "compile with -DSVAE_N=<latent dim>"
@@ -64,4 +65,9 @@ extern "C" int SVAE_CAT(svae_lds_launch_forward_pair_n, SVAE_N)(const svae::LdsA
 
 extern "C" int SVAE_CAT(svae_lds_launch_filter_split_n, SVAE_N)(const svae::LdsArgs* a, int inhomog, void* stream) {
   return svae::launch_filter_split<SVAE_N>(*a, inhomog != 0, (hipStream_t)stream);
+}
+
+// E-step + sampler in one launch on lean records (lds_lean_estep.hpp): homogeneous pair parameters, n <= LEAN_MAX_N
+extern "C" int SVAE_CAT(svae_lds_infer_lean_n, SVAE_N)(const svae::LdsArgs* a, const svae::LeanSample* ls, void* stream) {
+  return svae::launch_infer_lean<SVAE_N>(*a, *ls, (hipStream_t)stream);
 }

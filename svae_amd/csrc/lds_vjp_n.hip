@@ -7,6 +7,7 @@
 #define SVAE_DPP_ALWAYS_FENCED 0
 #endif
 #include "lds_vjp_kernel.hpp"
+#include "lds_lean_vjp.hpp"
 
 #ifndef SVAE_N
 #error "compile with -DSVAE_N=<latent dim>"
@@ -16,4 +17,9 @@
 
 extern "C" int SVAE_CAT(svae_lds_vjp_n, SVAE_N)(const svae::VjpArgs* a, void* stream) {
   return svae::launch_vjp<SVAE_N>(*a, (hipStream_t)stream);
+}
+
+// the two sweeps on the lean records of svae_lds_inference_f64 (lds_lean_vjp.hpp)
+extern "C" int SVAE_CAT(svae_lds_vjp_lean_n, SVAE_N)(const svae::VjpArgs* a, void* stream) {
+  return svae::launch_vjp_lean<SVAE_N>(*a, (hipStream_t)stream);
 }

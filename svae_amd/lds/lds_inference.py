@@ -125,8 +125,44 @@ class LDSEStepPlan(object):
         self.epoch += 1
         self.has_factor = bool(keep_factor) and self.n <= _lib.LDS_MAX_N
         self.has_cross = bool(keep_cross) and self.n <= _lib.LDS_MAX_N
+        self.lean, self._infer_S = False, None
         self._J12 = J12
         self._pair_batched = bool(pair_batched)
+
+    def infer(self, init_J, init_h, init_logZ, J11, J12, J22, logZ_pair, node_J, node_h, node_logZ=None,
+              pair_batched=False, eps=None, out=None):
+        """E-step + backward sampler in ONE call (svae_lds_inference_f64 = cython_natural_lds_inference_general,
+        lds_inference.py:196-202), keeping what `vjp()` needs.  eps (B,T,S,n) or None (no sampling) -> samples or None.
+        For large homogeneous batches (n <= 10, S <= 4, B > 2048, or OPT_LEAN_ON) the library keeps LEAN per-step
+        records (csrc/lds_lean_estep.hpp): the same results with a fifth of the hand-off traffic; `sample()` cannot
+        follow such a launch (`self.lean`)."""
+        if self.n > _lib.LDS_MAX_N:
+            raise ValueError("infer(): latent dimension <= %d (the tile path runs its stages separately)" % _lib.LDS_MAX_N)
+        p = _lib.ptr
+        S = 0
+        if eps is not None:
+            if eps.dim() != 4 or eps.shape[0] != self.B or eps.shape[1] != self.T or eps.shape[3] != self.n \
+                    or eps.shape[2] < 1:
+                raise ValueError("eps must be (B,T,S,n) with S >= 1")
+            eps = eps.to(device=self.device, dtype=torch.float64).contiguous()
+            S = eps.shape[2]
+            if out is None:
+                out = torch.empty_like(eps)
+        rc = self.lib.svae_lds_inference_f64(
+            self.B, self.T, self.n, S, int(self.inhomog), int(pair_batched), self.options,
+            p(init_J), p(init_h), p(init_logZ), p(J11), p(J12), p(J22), p(logZ_pair),
+            p(node_J), p(node_h), p(node_logZ), p(eps), p(out),
+            p(self.lognorm), p(self.E_init), p(self.E_pair), p(self.E_node_diagxx), p(self.E_node_x),
+            p(self.info), p(self.ws), self.ws_bytes, _lib.current_stream(self.device))
+        _lib.check(rc, "svae_lds_inference_f64")
+        self.epoch += 1
+        self.lean = bool(self.lib.svae_lds_inference_is_lean(self.B, self.T, self.n, S, int(self.inhomog), self.options))
+        self.has_factor = not self.lean
+        self.has_cross = True
+        self._infer_S = S
+        self._J12 = J12
+        self._pair_batched = bool(pair_batched)
+        return out if eps is not None else None
 
     def vjp_tail(self, S, pair_batched=False):
         """16 <= n <= 64: the workspace of svae_lds_tile_vjp_f64 for S sample cotangents as a view BEHIND the hand-off in
@@ -155,6 +191,7 @@ class LDSEStepPlan(object):
         _lib.check(rc, "svae_lds_filter_f64")
         self.epoch += 1
         self.has_factor, self.has_cross = True, False
+        self.lean, self._infer_S = False, None
         self._J12 = J12
         self._pair_batched = bool(pair_batched)
 
@@ -171,6 +208,8 @@ class LDSEStepPlan(object):
             if self.epoch == 0:
                 raise RuntimeError("sample() needs a preceding launch()")
             return sample_from_handoff(self, eps.to(device=self.device, dtype=torch.float64))
+        if getattr(self, "lean", False):
+            raise RuntimeError("sample(): the last launch was infer() on lean records -- its samples were drawn there")
         if not getattr(self, "has_factor", False):
             raise RuntimeError("sample() needs a preceding launch(..., keep_factor=True)")
         eps = eps.to(device=self.device, dtype=torch.float64).contiguous()
@@ -192,8 +231,11 @@ class LDSEStepPlan(object):
         (cython_lds_inference.pyx:92-145, 236-306, 357-409).  g_E_init (B, n*n+n) and, with per-step
         pair parameters, g_E_pair (B,T-1,3,n,n) are the cotangents of the remaining statistics
         (_compute_stats_grad, :212-234) -- what the SLDS-SVAE differentiates."""
-        if not (getattr(self, "has_cross", False) and getattr(self, "has_factor", False)):
-            raise RuntimeError("vjp() needs a preceding launch(..., keep_factor=True, keep_cross=True)")
+        lean = getattr(self, "lean", False)
+        if not (getattr(self, "has_cross", False) and (lean or getattr(self, "has_factor", False))):
+            raise RuntimeError("vjp() needs a preceding launch(..., keep_factor=True, keep_cross=True) or infer()")
+        if lean and (g_E_init is not None or g_E_pair is not None):
+            raise ValueError("lean records (infer() on a large homogeneous batch): no cotangents of E_init / E_pair")
         if g_E_pair is not None and not self.inhomog:
             raise ValueError("a homogeneous plan keeps only the SUMMED pair statistics; their cotangents go through "
                              "the per-step layout: lds_inference_differentiable(..., pair_stats_grad=True)")
@@ -203,6 +245,14 @@ class LDSEStepPlan(object):
         g_samples, eps, samples = c(g_samples), c(eps), c(samples)
         g_E_init, g_E_pair = c(g_E_init), c(g_E_pair)
         S = 0 if g_samples is None else g_samples.shape[2]
+        options = self.options
+        infer_S = getattr(self, "_infer_S", None)
+        if infer_S is not None:
+            # the workspace was written by infer(): the VJP is told so and takes the S of that call (it fixes the format)
+            if g_samples is not None and S != infer_S:
+                raise ValueError("vjp(): %d sample cotangents for an infer() call that drew %d" % (S, infer_S))
+            options |= _lib.OPT_INFER_RECORDS
+            S = infer_S
         if S > 16:
             # the kernels take 16 sample cotangents per launch; the VJP is linear in the cotangents: the first chunk
             # travels with all the others, the remaining chunks alone
@@ -222,7 +272,7 @@ class LDSEStepPlan(object):
         gh = torch.empty(self.B, self.T, self.n, **f64)
         p = _lib.ptr
         rc = self.lib.svae_lds_estep_vjp_ex_f64(
-            self.B, self.T, self.n, S, int(self.inhomog), int(self._pair_batched), self.options,
+            self.B, self.T, self.n, S, int(self.inhomog), int(self._pair_batched), options,
             p(self._J12), p(g_lognorm), p(g_E_node_diagxx), p(g_E_node_x), p(g_E_init), p(g_E_pair),
             p(g_samples), p(eps), p(samples), p(self.E_pair), p(self.E_node_x), p(gJ), p(gh),
             p(self.ws), self.ws_bytes, p(self.vjp_ws), self.vjp_ws_bytes, _lib.current_stream(self.device))
@@ -560,9 +610,16 @@ class _LDSInference(torch.autograd.Function):
     @staticmethod
     def forward(ctx, node_J, node_h, node_logZ, eps, plan, params, pair_batched):
         init_J, init_h, init_logZ, J11, J12, J22, logZ_pair = params
-        plan.launch(init_J, init_h, init_logZ, J11, J12, J22, logZ_pair, node_J, node_h, node_logZ,
-                    pair_batched, True, True)
-        samples = plan.sample(eps) if eps is not None else torch.zeros(0, dtype=torch.float64, device=plan.device)
+        if eps is None or eps.shape[2] <= 16:
+            # one call: E-step + sampler (lean per-step records for large homogeneous batches)
+            samples = plan.infer(init_J, init_h, init_logZ, J11, J12, J22, logZ_pair, node_J, node_h, node_logZ,
+                                 pair_batched, eps)
+            if samples is None:
+                samples = torch.zeros(0, dtype=torch.float64, device=plan.device)
+        else:
+            plan.launch(init_J, init_h, init_logZ, J11, J12, J22, logZ_pair, node_J, node_h, node_logZ,
+                        pair_batched, True, True)
+            samples = plan.sample(eps)
         ctx.plan, ctx.has_logZ, ctx.has_samples = plan, node_logZ is not None, eps is not None
         ctx.epoch = plan.epoch
         ctx.set_materialize_grads(False)       # an output nobody differentiated arrives as None, not as zeros

@@ -14,9 +14,36 @@ parameters from the expected statistics the E-step left in `saved.stats` (:33-34
 `recognize(recogn_params, batch) -> nn_potentials` and `loglike(loglike_params, samples, batch) ->
 scalar` are the user's torch functions (the reference's svae/nnet.py is out of scope: stock PyTorch);
 `run_inference` is svae_amd.models.{lds,gmm}.run_inference_differentiable or anything with the
-same signature.  `functools.partial` replaces toolz.curry.
+same signature.  `make_gradfun` is CURRIED like the reference's (`@curry`, svae.py:10; toolz is not a
+dependency: `curry` below): a call that leaves required arguments open returns a function waiting for
+the rest, so the shipped training scripts' two-stage form works verbatim
+(experiments/gmm_svae_synth.py:57-61):
+    gradfun = make_gradfun(run_inference, recognize, loglike, pgm_prior_params, data)
+    sgd(gradfun(batch_size=50, num_samples=1, natgrad_scale=1e4, callback=plot), params, ...)
 """
+import functools
+import inspect
+
 import torch
+
+
+def curry(fn):
+    """toolz.curry for the one use the reference makes of it (svae.py:2,10): calling with some required arguments
+    still missing returns a curried function holding the ones given (positional and keyword); a call that binds
+    every required parameter runs `fn`.  A call that could never bind (unknown keyword, too many positionals)
+    raises TypeError at once, as toolz does."""
+    sig = inspect.signature(fn)
+
+    @functools.wraps(fn)
+    def curried(*args, **kwargs):
+        try:
+            sig.bind(*args, **kwargs)
+        except TypeError:
+            sig.bind_partial(*args, **kwargs)          # (raises for calls no further argument can complete)
+            return curry(functools.partial(fn, *args, **kwargs))
+        return fn(*args, **kwargs)
+
+    return curried
 
 callback = lambda i, val, params, grad: print("{}: {}".format(i, val))
 
@@ -62,6 +89,7 @@ def split_into_batches(data, batch_size, permute=True, generator=None):
     return chunks, k
 
 
+@curry
 def make_gradfun(run_inference, recognize, loglike, pgm_prior, data, batch_size, num_samples,
                  natgrad_scale=1., callback=callback, permute=True, generator=None):
     # number of data points = rows (time steps / points), as get_num_datapoints(data) in the reference
