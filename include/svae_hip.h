@@ -314,7 +314,7 @@ int svae_lds_sample_f64(int B, int T, int n, int S, unsigned options, const doub
  * inhomog and `options`).  Arguments as svae_lds_estep_f64 (n <= SVAE_LDS_MAX_N) plus eps, samples (B,T,S,n) as
  * svae_lds_sample_f64; S = 0: no sampling (eps, samples may be NULL).  Same results as svae_lds_estep_f64 with keep = 3
  * followed by svae_lds_sample_f64 -- and in general exactly those two calls.  What the single entry point buys: for
- * homogeneous pair parameters, n <= 10, T >= 2, S <= 4 and batches of more than 2048 sequences (or SVAE_OPT_LEAN_ON)
+ * homogeneous pair parameters, n <= 10, T >= 2, S <= 2 and batches of more than 2048 sequences (or SVAE_OPT_LEAN_ON)
  * the per-step records that travel through HBM shrink from (4n+3)n + (n+1)(n+2) doubles to n(n+1)/2 + n (+ the cross
  * moments): the forward pass keeps only U_t = chol(P_t)^-T and c_t, every reader rebuilds P_t^-1 = U U' and P_t^-1 J12,
  * the sampler runs inside the smoother's loop, and the first VJP sweep hands the second one symmetric triangle

@@ -30,6 +30,19 @@ def _rel(a, b):
     return float(np.max(np.abs(a - b) / scale)) if b.size else 0.0
 
 
+GUARD = 1e-12
+
+
+def _rel_plain(a, b):
+    """plain element-wise |a - b| / |b| (no absolute floor) over the entries with |b| > GUARD * max|b| -- the guard only
+    removes exact zeros and values at the level of rounding noise of the array (north_star: "1e-5 relative")"""
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    if not b.size:
+        return 0.0
+    m = np.abs(b) > GUARD * max(np.max(np.abs(b)), 1e-300)
+    return float(np.max(np.abs(a - b)[m] / np.abs(b)[m])) if m.any() else 0.0
+
+
 def check(path):
     from oracle import lds_numpy, ref
     d = np.load(path)
@@ -38,6 +51,7 @@ def check(path):
                 (d["J11"], d["J12"], d["J22"], float(d["logZ_pair"])))
     m, T, n = d["node_h"].shape
     worst = dict(lognorm=0.0, E_init=0.0, E_pair=0.0, E_node=0.0)
+    plain = 0.0
     z = np.zeros(T)
     for j in range(m):
         ln, (Ei, Ep, En) = est(natparam, (d["node_J"][j], d["node_h"][j], z))
@@ -46,7 +60,12 @@ def check(path):
                               _rel(d["E_init"][j, n * n:], Ei[1]))
         worst["E_pair"] = max([worst["E_pair"]] + [_rel(d["E_pair"][j, i], np.asarray(Ep[i])) for i in range(3)])
         worst["E_node"] = max(worst["E_node"], _rel(d["E_node_diagxx"][j], En[0]), _rel(d["E_node_x"][j], En[1]))
-    return {"max_rel": max(worst.values()), "per_quantity": worst, "sequences": int(m),
+        plain = max([plain, _rel_plain(d["lognorm"][j], ln), _rel_plain(d["E_init"][j, :n * n].reshape(n, n), Ei[0]),
+                     _rel_plain(d["E_init"][j, n * n:], Ei[1]), _rel_plain(d["E_node_diagxx"][j], En[0]),
+                     _rel_plain(d["E_node_x"][j], En[1])] + [_rel_plain(d["E_pair"][j, i], np.asarray(Ep[i])) for i in range(3)])
+    return {"max_rel": max(worst.values()), "max_rel_note": "|a-b| / max(|b|, 1e-3 max|b|) per array",
+            "max_rel_elementwise": plain, "max_rel_elementwise_note": "|a-b| / |b| over entries with |b| > %g max|b|" % GUARD,
+            "per_quantity": worst, "sequences": int(m),
             "sequence_index": [int(i) for i in d["index"]], "checker": kind,
             "against": "oracle/_ref: the reference's compiled cython_natural_lds_estep_general" if kind == "reference"
                        else "oracle/lds_numpy.py (NumPy restatement; oracle/_ref not built)"}

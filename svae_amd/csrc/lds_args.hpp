@@ -143,7 +143,7 @@ constexpr int vjp_step_doubles(int n) { return vjp_pex_off(n) + n * ws_p_stride(
 // only the symmetric part of the sampler's direct share reaches the gradients (every map it goes through is a
 // congruence, and the outputs take the diagonal), so the two shares travel as ONE triangle.
 constexpr int LEAN_MAX_N = 10;
-constexpr int LEAN_MAX_S = 4;
+constexpr int LEAN_MAX_S = 2;
 constexpr int LEAN_MIN_B = 2049;        // default dispatch: batches the two-role (split) sweeps do not serve
 constexpr int lean_tri(int n) { return n * (n + 1) / 2; }
 constexpr int lean_row_off(int n, int k) { return k * n - k * (k - 1) / 2; }

@@ -23,7 +23,7 @@
 
 namespace svae {
 
-// SM: samples per sequence the instantiation holds registers for (0: no sampling; 1: the training step's S = 1; 4)
+// SM: samples per sequence the instantiation holds registers for (0: no sampling; 1: the training step's S = 1; 2)
 template <int N, int SM>
 __global__ __launch_bounds__(64) void lds_infer_lean_kernel(const LdsArgs a, const LeanSample ls) {
   static_assert(N >= 1 && N <= LEAN_MAX_N, "lean records: n <= 10");
@@ -48,15 +48,13 @@ __global__ __launch_bounds__(64) void lds_infer_lean_kernel(const LdsArgs a, con
   double E[N];
   static_for<0, N>([&](auto i) { E[i] = (c == i) ? 1.0 : 0.0; });
   const double EN = (c == N) ? 1.0 : 0.0;
-  const double cm = col ? 1.0 : 0.0;
 
   // ---- pair parameters (info form: J = -2 natJ, J12 = -natJ12), column c per lane: as lds_estep_kernel ---------------
-  double NJ12T[N], J12c[N], Cc[N];
+  double NJ12T[N], Cc[N];                   // (info-form J12 rows: re-read from L1 per step -- 20 registers)
   static_for<0, N>([&](auto i) {
-    const double r12t = T > 1 ? a.J12[cc * N + i] : 0.0, r12 = T > 1 ? a.J12[i * N + cc] : 0.0;
+    const double r12t = T > 1 ? a.J12[cc * N + i] : 0.0;
     const double r22 = T > 1 ? a.J22[i * N + cc] : 0.0, r11 = T > 1 ? a.J11[i * N + cc] : 0.0;
     NJ12T[i] = col ? r12t : 0.0;            // lane j of register k: nat J12[j][k] = -(info) J12[j][k]
-    J12c[i] = col ? -r12 : 0.0;
     Cc[i] = col ? -2.0 * (r22 + r11) : 0.0;
   });
   dpp_fence(NJ12T);
@@ -99,7 +97,7 @@ __global__ __launch_bounds__(64) void lds_infer_lean_kernel(const LdsArgs a, con
       asm volatile("; last step: no pair potential, G = 0");   // keep this a branch
       static_for<0, N>([&](auto i) { X[i] = EN * An[i]; });
     } else {
-      static_for<0, N>([&](auto i) { X[i] = __builtin_fma(EN, An[i], J12c[i]); });
+      static_for<0, N>([&](auto i) { const double r = a.J12[i * N + cc]; X[i] = __builtin_fma(EN, An[i], col ? -r : 0.0); });
     }
     dpp_fence(ho);
     static_for<0, N>([&](auto i) { mac_bc<i>(X[i], ho, EN); });
@@ -180,8 +178,7 @@ __global__ __launch_bounds__(64) void lds_infer_lean_kernel(const LdsArgs a, con
   static_for<0, N>([&](auto k) { M[k] = (col && c <= k) ? 1.0 : 0.0; });
 
   double* oEx = a.E_node_x + ((long)b * T) * N + cc;
-  double* oExx = a.E_node_diagxx + ((long)b * T) * N + cc;
-  double* const ep3 = a.E_pair + (long)b * 3 * N * N + 2 * N * N;     // S~_{T-1} waits in its output slot
+  const long dxx_delta = a.E_node_diagxx - a.E_node_x;               // (uniform: one per-lane pointer serves both outputs)
 
   // operands of a step, fetched one step ahead (raw: no arithmetic before their step; every load unconditional)
   struct Ops { double Ur[N], Ut[N], cv, ep[SMAX]; };
@@ -206,7 +203,7 @@ __global__ __launch_bounds__(64) void lds_infer_lean_kernel(const LdsArgs a, con
     load_ops(nxt, t > 1 ? 1 : 0);               // unconditional prefetch of step t-1 (t = 0: re-reads record 0, unused)
     double Ut[N];
     static_for<0, N>([&](auto k) { Ut[k] = cur.Ut[k] * M[k]; });
-    const double cvm = cur.cv * cm;
+    const double cvm = cur.cv * M[N - 1];         // (M[N-1] = (c < N))
     // the recursion-free part of the samples: noise + c_t  (y = c + U eps)
     double Y[SMAX];
     if constexpr (SAMP) {
@@ -243,10 +240,14 @@ __global__ __launch_bounds__(64) void lds_infer_lean_kernel(const LdsArgs a, con
     // S~_t = G~ W~ + diag(P^-1, 0) through its transpose
     static_for<0, N>([&](auto i) { S_[i] = Pi[i]; });
     S_[N] = 0.0;
+    asm volatile("s_nop 1");   // block entry behind the conditional stores: two wait states before the DPP reads (audit rule)
     static_for<0, (N + 1 + IL - 1) / IL>([&](auto g) { rows_lane_bcast<IL, g * IL, N + 1, N>(S_, W, H); });
 
     if (t < T - 1) static_for<0, N>([&](auto i) { sumA[i] += S_[i]; sumW[i] += W[i]; });
-    else { if (st) static_for<0, N>([&](auto i) { ep3[i * N + cc] = S_[i]; }); }
+    else if (st) {                                                     // S~_{T-1} waits in its output slot
+      double* const ep3 = a.E_pair + (long)b * 3 * N * N + 2 * N * N;
+      static_for<0, N>([&](auto i) { ep3[i * N + cc] = S_[i]; });
+    }
 
     // diag E[x_t x_t'] = sum_i (c == i) S~[i] with (c == i) = M[i] - M[i-1] (summed by parts: the identity tile of the
     // forward half is not kept alive through this loop -- 20 registers)
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(64) void lds_infer_lean_kernel(const LdsArgs a, con
     });
     if (st) {
       oEx[(long)t * N] = S_[N];
-      oExx[(long)t * N] = dg + dg1;
+      oEx[(long)t * N + dxx_delta] = dg + dg1;
     }
 
     if constexpr (SAMP) {

@@ -133,7 +133,7 @@ class LDSEStepPlan(object):
               pair_batched=False, eps=None, out=None):
         """E-step + backward sampler in ONE call (svae_lds_inference_f64 = cython_natural_lds_inference_general,
         lds_inference.py:196-202), keeping what `vjp()` needs.  eps (B,T,S,n) or None (no sampling) -> samples or None.
-        For large homogeneous batches (n <= 10, S <= 4, B > 2048, or OPT_LEAN_ON) the library keeps LEAN per-step
+        For large homogeneous batches (n <= 10, S <= 2, B > 2048, or OPT_LEAN_ON) the library keeps LEAN per-step
         records (csrc/lds_lean_estep.hpp): the same results with a fifth of the hand-off traffic; `sample()` cannot
         follow such a launch (`self.lean`)."""
         if self.n > _lib.LDS_MAX_N:

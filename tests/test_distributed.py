@@ -281,3 +281,35 @@ def test_two_rank_nested_allreduce_of_the_slds_statistics():
         assert all(m == 3.0 for m in mins)                       # 1 + 2 in every entry
         assert shapes == [(3,), (3, 3), (3, 2, 2), (3, 2), (3,), (3,), (3, 2, 2), (3, 2, 2), (3, 2, 2), (3,)]
         assert vlb == 21.0 and grad == 10.0 + rank               # global value, this rank's gradient
+
+
+def test_bench_gpus_flag_launches_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher (the form of the driver's N = 1 command) must run two ranks -- or
+    fail -- never print an N = 1 number under an N = 2 label: bench.py re-executes itself under torch.distributed.run
+    and reports the observed world size and the devices of the ranks.  CPU rehearsal with gloo (`--launch-check` stops
+    after rendezvous + barrier + all-gather; the measurement itself needs a GPU: tests/test_distributed_hip.py)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SVAE_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    got = json.loads(line)
+    assert got["n_gpus"] == 2 and got["world_size_observed"] == 2 and len(got["rank_devices"]) == 2
+    assert got["backend"] == "gloo" and got["launcher"] == "torch.distributed.run"
+    # RCCL with fewer visible devices than ranks: refuse (non-zero), do not fall back to one rank
+    env["SVAE_BENCH_BACKEND"] = "nccl"
+    env["CUDA_VISIBLE_DEVICES"] = env["HIP_VISIBLE_DEVICES"] = ""
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "GPU(s) visible" in (out.stderr + out.stdout)
+    # a WORLD_SIZE that contradicts --gpus (a launcher mis-invocation) is refused as well
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", SVAE_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"],
+                         env=env2, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "WORLD_SIZE" in (out.stderr + out.stdout)

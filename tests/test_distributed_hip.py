@@ -379,3 +379,28 @@ def test_rccl_allreduce_of_the_packed_statistics_single_rank_on_the_device():
         if p_.is_alive():
             p_.kill()
     assert status == "ok" and backend == "nccl", status
+
+
+def test_bench_gpus_2_without_a_launcher_runs_two_ranks():
+    """`python bench.py --gpus 2` (no torchrun): bench.py launches its own two ranks and the line says so -- here both
+    on the one GPU of the box through gloo (SVAE_BENCH_BACKEND; RCCL refuses ranks that share a device, and bench.py
+    refuses RCCL with fewer devices than ranks instead of running one rank)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SVAE_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--no-extra", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    got = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert got["n_gpus"] == 2 and got["world_size_observed"] == 2 and len(got["rank_devices"]) == 2
+    assert got["config"]["global_sequences"] == 2 * got["config"]["sequences_per_gpu"]
+    assert got["parity"]["ok"]
+    if torch.cuda.device_count() < 2:
+        env["SVAE_BENCH_BACKEND"] = "nccl"
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--no-extra"],
+                             env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode != 0 and "GPU(s) visible" in (out.stderr + out.stdout)

@@ -44,8 +44,8 @@ def _plan(B, T, n, lean):
     return LDSEStepPlan(B, T, n, "cuda:0", options=_lib.OPT_LEAN_ON if lean else _lib.OPT_LEAN_OFF)
 
 
-CASES = [(10, 25, 5, 1), (10, 40, 3, 4), (3, 6, 2, 2), (1, 4, 2, 1), (7, 2, 5, 2), (10, 3, 9, 3), (5, 17, 13, 1),
-         (9, 8, 4, 4), (2, 5, 1, 1), (8, 31, 6, 2)]
+CASES = [(10, 25, 5, 1), (10, 40, 3, 2), (3, 6, 2, 2), (1, 4, 2, 1), (7, 2, 5, 2), (10, 3, 9, 3), (5, 17, 13, 1),
+         (9, 8, 4, 2), (2, 5, 1, 1), (8, 31, 6, 2), (4, 11, 7, 1), (6, 200, 4, 1)]
 
 
 @pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
@@ -70,12 +70,13 @@ def test_lean_path_against_reference_compiled_code(n, T, B, S, with_samples):
             assert np.array_equal(e, e2)
             want_s[b] = smp
     plan = _plan(B, T, n, lean=True)
-    assert plan.lib.svae_lds_inference_is_lean(B, T, n, S if with_samples else 0, 0, plan.options) == 1
+    lean = (not with_samples) or S <= 2            # at most two samples are drawn inside the smoother's loop
+    assert plan.lib.svae_lds_inference_is_lean(B, T, n, S if with_samples else 0, 0, plan.options) == int(lean)
     nJ, nh, nz = (t(x).requires_grad_(True) for x in node)
     lognorm, (dxx, ex), samples, (E_init, E_pair) = lds_inference_differentiable(
         (tuple(t(x) for x in init), tuple(t(x) for x in pair)), (nJ, nh, nz),
         eps=t(eps) if with_samples else None, plan=plan)
-    assert plan.lean
+    assert plan.lean == lean
     loss = (t(g["ln"]) * lognorm).sum() + (t(g["dxx"]) * dxx).sum() + (t(g["x"]) * ex).sum()
     if with_samples:
         loss = loss + (t(g["s"]) * samples).sum()
@@ -95,7 +96,7 @@ def test_lean_path_against_reference_compiled_code(n, T, B, S, with_samples):
         assert _rel(nz.grad[b], want[b][2]) < 1e-12, "g_node_logZ"
 
 
-@pytest.mark.parametrize("n,T,B,S", [(10, 60, 37, 1), (10, 33, 9, 4), (6, 20, 21, 2), (4, 2, 3, 1)])
+@pytest.mark.parametrize("n,T,B,S", [(10, 60, 37, 1), (10, 33, 9, 2), (6, 20, 21, 2), (4, 2, 3, 1), (10, 200, 16, 1)])
 @pytest.mark.parametrize("with_samples", [False, True])
 def test_lean_and_full_records_agree(n, T, B, S, with_samples):
     """The lean path is a different storage format of the same recursions: outputs, samples and gradients agree with
@@ -112,7 +113,7 @@ def test_lean_and_full_records_agree(n, T, B, S, with_samples):
         nJ, nh = t(node[0]).requires_grad_(True), t(node[1]).requires_grad_(True)
         lognorm, (dxx, ex), samples, (Ei, Ep) = lds_inference_differentiable(
             natparam, (nJ, nh), eps=eps if with_samples else None, plan=plan)
-        assert plan.lean == lean
+        assert plan.lean == (lean and (not with_samples or S <= 2))
         loss = (t(g["ln"]) * lognorm).sum() + (t(g["dxx"]) * dxx).sum() + (t(g["x"]) * ex).sum()
         if with_samples:
             loss = loss + (t(g["s"]) * samples).sum()
