@@ -120,7 +120,10 @@ class MailboxAllReduce(object):
                                              ctypes.cast(self._boxes, ctypes.c_void_p), _lib.ptr(self.info),
                                              _lib.current_stream(self.device))
         _lib.check(rc, "svae_ipc_allreduce_f64")
-        if self.check_every and self.epoch % self.check_every == 0:
+        if self.check_every and self.epoch % self.check_every == 0 \
+                and not torch.cuda.is_current_stream_capturing():
+            # (a blocking read of the status word: skipped under hipGraph capture, where it is illegal -- a captured
+            #  loop checks through `check()` between replays; pass check_every=0 for fully asynchronous pipelines)
             self.check()
         return packed
 

@@ -19,7 +19,8 @@ import torch
 from .. import _lib
 
 __all__ = ["LDSEStepPlan", "natural_lds_estep_general", "cython_natural_lds_estep_general",
-           "natural_filter_forward_general", "natural_lds_sample", "cython_natural_lds_sample",
+           "natural_filter_forward_general", "natural_smoother_general", "natural_sample_backward",
+           "natural_lds_sample", "cython_natural_lds_sample",
            "natural_lds_inference_general", "cython_natural_lds_inference_general", "reduce_stats",
            "lds_inference_differentiable"]
 
@@ -506,6 +507,54 @@ def natural_filter_forward_general(init_params, pair_params, node_params, plan=N
     if not q["batched"]:
         return ((Jp[0], hp[0]), (Jf[0], hf[0])), lognorm[0]
     return ((Jp, hp), (Jf, hf)), lognorm
+
+
+def _model_from_messages(forward_messages, pair_params):
+    """The LDS whose forward filter reproduces the given messages: init = the first predicted message, node potential of
+    step t = filtered - predicted message of step t.  For messages that came out of a forward filter with these pair
+    parameters -- every call site of the reference (lds_inference.py:196-202, 232-237, 260-264) -- the smoother / sampler
+    of this model IS the reference's smoother / sampler on the messages."""
+    (Jp, hp), (Jf, hf) = forward_messages
+    dev = hf.device if isinstance(hf, torch.Tensor) and hf.is_cuda else torch.device("cuda")
+    Jp, hp, Jf, hf = (_as_dev(x, dev) for x in (Jp, hp, Jf, hf))
+    batched = hf.dim() == 3
+    if not batched:
+        Jp, hp, Jf, hf = Jp[None], hp[None], Jf[None], hf[None]
+    if Jp.dim() != 4 or Jp.shape != Jf.shape or hp.shape != hf.shape or Jp.shape[:3] != hp.shape:
+        raise ValueError("forward_messages = ((J_pred, h_pred), (J_filt, h_filt)) with J (T,n,n) and h (T,n) [or a leading B axis]")
+    dJ, dh = Jf - Jp, hf - hp
+    if Jp.shape[0] > 1:             # one initial potential for the batch: differences of the first predictions join the node
+        dJ[1:, 0] += Jp[1:, 0] - Jp[0, 0]
+        dh[1:, 0] += hp[1:, 0] - hp[0, 0]
+    dg = torch.diagonal(dJ, dim1=-2, dim2=-1)
+    off = float((dJ - torch.diag_embed(dg)).abs().max())
+    dense = off > 1e-12 * max(float(dJ.abs().max()), 1e-300)
+    natparam = ((Jp[0, 0].contiguous(), hp[0, 0].contiguous(), torch.zeros((), dtype=torch.float64, device=dev)),
+                pair_params)
+    nodes = (dJ if dense else dg.contiguous(), dh)
+    if not batched:
+        nodes = tuple(x[0] for x in nodes)
+    return natparam, nodes
+
+
+def natural_smoother_general(forward_messages, pair_params):
+    """RTS smoother + expected statistics on CALLER-SUPPLIED forward messages: (E_init, E_pair, E_node) as the
+    reference's tuples -- `natural_smoother_general(forward_messages, pair_params)`, the second of the functions the
+    reference imports from its compiled module (lds_inference.py:18-24; cython_lds_inference.pyx:149-210).
+    forward_messages = ((J_pred, h_pred), (J_filt, h_filt)) in the reference's scaling (natural parameters), as
+    `natural_filter_forward_general` returns them [(B,T,...) batched].  See _model_from_messages for what is assumed of
+    the messages."""
+    natparam, nodes = _model_from_messages(forward_messages, pair_params)
+    return natural_lds_estep_general(natparam, nodes)[1]
+
+
+def natural_sample_backward(forward_messages, pair_params, num_samples, eps=None, generator=None):
+    """Backward sampling on caller-supplied forward messages -> samples (T,S,n) [(B,T,S,n)]:
+    `natural_sample_backward(forward_messages, pair_params, num_samples)` (lds_inference.py:18-24;
+    cython_lds_inference.pyx:310-355).  `eps` (T,S,n) as in natural_lds_inference_general (the reference draws
+    flipud(randn(T,S,n)) inside, :333)."""
+    natparam, nodes = _model_from_messages(forward_messages, pair_params)
+    return natural_lds_sample(natparam, nodes, num_samples, eps=eps, generator=generator)
 
 
 def natural_lds_sample(natparam, node_params, num_samples=1, eps=None, plan=None, generator=None):

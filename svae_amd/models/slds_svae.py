@@ -33,7 +33,19 @@ from ..lds.lds_inference import (LDSEStepPlan, lds_inference_differentiable, nat
                                      natural_lds_sample)
 
 
-_STATUS = {}     # name -> (1,) int32 device status word of the LAST call of each device path (read by check_info only)
+_STATUS = {}     # (path name, device) -> (1,) int32 status word, PERSISTENT per device: every call of the path ORs into it
+
+
+def _status_word(name, device):
+    """The persistent (1,) int32 status word of (path, device), handed to the kernels as their `info` pointer: they write
+    it only on failure (atomicMax / compare-and-swap, never a clear), so a failure of an EARLIER call survives later
+    successful ones whatever the number of devices, streams and plans in flight -- and the hot path pays nothing for it
+    (the dict used to keep only the last call's freshly allocated word)."""
+    key = (name, str(torch.device(device)))
+    word = _STATUS.get(key)
+    if word is None:
+        _STATUS[key] = word = torch.zeros(1, dtype=torch.int32, device=device)
+    return word
 
 
 def check_info():
@@ -42,11 +54,14 @@ def check_info():
     fused LDS mean-field kernel (a non-positive pivot) -- like gmm.check_info(): the ascent itself never reads them
     (no host synchronisation on the hot path; the reference ignores LAPACK `info` altogether,
     cython_gaussian_grads.pxd:54-76).  Raises FloatingPointError naming the path."""
-    for name, word in list(_STATUS.items()):
+    bad = []
+    for (name, device), word in list(_STATUS.items()):
         v = int(word.item())
         if v != 0:
-            word.zero_()
-            raise FloatingPointError("SLDS %s: status word %d (parameters / potentials not positive definite)" % (name, v))
+            word.zero_()                       # (every word is read and cleared before anything is raised)
+            bad.append("%s on %s: status word %d" % (name, device, v))
+    if bad:
+        raise FloatingPointError("SLDS " + "; ".join(bad) + " (parameters / potentials not positive definite)")
 
 
 def _dev64(x, device):
@@ -92,7 +107,7 @@ def _global_to_local_maps_device(global_natparam, device):
     init_J, init_h, init_lz = f((K, n, n)), f((K, n)), f((K,))
     J11, J12, J22, lzp = f((K, n, n)), f((K, n, n)), f((K, n, n)), f((K,))
     esb = f((K, D, D))
-    info = torch.zeros(1, dtype=torch.int32, device=device)
+    info = _status_word("global -> local maps", device)
     lib, p = _lib.load(), _lib.ptr
     keep = [[c(niw), c(A), c(Bm), c(C), c(d).reshape(1)] for niw, (A, Bm, C, d) in lds_global]
     arrs = [(ctypes.c_void_p * K)(*[t[i].data_ptr() for t in keep]) for i in range(5)]
@@ -109,7 +124,6 @@ def _global_to_local_maps_device(global_natparam, device):
                 None, p(info), _lib.current_stream(device))
             _lib.check(rc, "svae_lds_global_step_f64")
     global_to_local_maps.last_info = info
-    _STATUS["global -> local maps"] = info
     dense_init = (esb[:, :n, :n].contiguous(), esb[:, :n, n].contiguous(), esb[:, n, n].contiguous(),
                   esb[:, n + 1, n + 1].contiguous())
     dense_pair = (J11, J12, J22, lzp)
@@ -189,19 +203,25 @@ def get_arhmm_local_nodeparams(dense_init, dense_pair, init_stats, pair_stats):
     return torch.cat([n0[:, None], nt], 1)
 
 
+def _pair_contract_applies(dense_init, pair_stats):
+    """where svae_slds_pair_contract_f64 serves: the kernels' packed (B,T-1,3,n,n) statistics on the device, n <= 10, K <= 8"""
+    if not (isinstance(pair_stats, torch.Tensor) and pair_stats.is_cuda and pair_stats.dim() == 5
+            and pair_stats.is_contiguous()):
+        return False
+    B, Tm1, _, n, _ = pair_stats.shape
+    return n <= 10 and dense_init[0].shape[0] <= 8 and Tm1 >= 1 and B >= 1
+
+
 def final_pass_contractions(dense_init, dense_pair, init_stats, pair_stats, expected_states):
     """The pair part of get_arhmm_local_nodeparams (:131-147) and of get_global_stats (:229-243) on the per-step pair
     statistics of the final LDS E-step in ONE pass over them (svae_slds_pair_contract_f64; they are 2.45 GB at configs[3]
     and were read by two library GEMMs).  pair_stats: the kernels' packed (B,T-1,3,n,n) tensor.
     -> (node_hmm (B,T,K), g_pair_sums (K,3,n,n)), or None where the kernel does not apply (the callers then use the two
     functions above)."""
-    if not (isinstance(pair_stats, torch.Tensor) and pair_stats.is_cuda and pair_stats.dim() == 5
-            and pair_stats.is_contiguous() and not pair_stats.requires_grad):
+    if not _pair_contract_applies(dense_init, pair_stats) or pair_stats.requires_grad:
         return None
     B, Tm1, _, n, _ = pair_stats.shape
     K = dense_init[0].shape[0]
-    if n > 10 or K > 8 or Tm1 < 1 or B < 1:
-        return None
     dev = pair_stats.device
     T = Tm1 + 1
     ExxT0, Ex0 = init_stats
@@ -225,7 +245,11 @@ def final_pass_contractions(dense_init, dense_pair, init_stats, pair_stats, expe
 class _PairContract(torch.autograd.Function):
     """final_pass_contractions with the gradient of the HMM node potentials w.r.t. the pair statistics attached:
     node[b,t+1,k] = <S[b,t], P_k> + lz_k  =>  dL/dS[b,t] = sum_k g[b,t+1,k] P_k (one library GEMM in the backward pass);
-    the weighted sums are formed from the values only (the reference detaches the statistics it returns)."""
+    the weighted sums are formed from the values only (the reference detaches the statistics it returns).
+    The K parameter sets (dense_init, dense_pair) are CONSTANTS of this node: no gradient flows to the global
+    parameters through it (the SVAE never asks for one -- the global step is the closed-form natural gradient,
+    svae.py:33-34); the caller checks that they do not require grad and that the kernel applies
+    (_pair_contract_applies), and otherwise takes get_arhmm_local_nodeparams."""
 
     @staticmethod
     def forward(ctx, pair_stats, ExxT0, Ex0, dense_init, dense_pair, expected_states):
@@ -279,7 +303,7 @@ class SLDSMeanfieldPlan(object):
         self.E_node_diagxx = torch.empty(B, T, n, **f64)
         self.E_node_x = torch.empty(B, T, n, **f64)
         self.pair_contr = torch.empty(B, T, 2, K, **f64)
-        self.info = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.info = _status_word("fused LDS mean field", self.device)     # (shared by the plans of a device)
 
     @staticmethod
     def supported(n, T, K):
@@ -391,7 +415,6 @@ def _optimize_local_meanfield_fused(hmm_init, hmm_pair, dense_init, dense_pair, 
     pinned = torch.empty(max_iter + 1, dtype=torch.int32).pin_memory()
     events = []
     nrun, cur = B, 0
-    _STATUS["fused LDS mean field"] = plan.info
     ts = torch.cuda.current_stream(dev)          # the stream the kernels are launched on (dev need not be the current device)
     for it in range(max_iter):
         if nrun == 0:
@@ -455,12 +478,11 @@ def _initial_sample_path(node_potentials, eps):
         out = torch.empty(B, T, n, dtype=torch.float64, device=dev)
         wsb = int(lib.svae_lds_diag_sample_workspace_bytes(max(B, 1), T, n))
         ws = torch.empty(wsb // 8, dtype=torch.float64, device=dev)
-        info = torch.zeros(1, dtype=torch.int32, device=dev)
+        info = _status_word("initial sample path", dev)
         rc = lib.svae_lds_diag_sample_f64(B, T, n, p(iJ), p(ih), p(j11), p(j12), p(j22), p(nJc), p(nhc), p(e), p(out),
                                           p(info), p(ws), wsb, _lib.current_stream(dev))
         _lib.check(rc, "svae_lds_diag_sample_f64")
         _initial_sample_path.last_info = info
-        _STATUS["initial sample path"] = info
         return out
     natparam = _random_walk_natparam(n, dev)
     x = natural_lds_sample(natparam, node_potentials, num_samples=1, eps=eps)     # filter + sampler, no smoother (:222)
@@ -713,7 +735,8 @@ def final_pass_differentiable(global_natparam, hmm_natparam, lds_natparam, nn_po
     pair_stats = (E_pair[:, :, 0], E_pair[:, :, 1], E_pair[:, :, 2])
     pair_sums = None
     K = dense_init[0].shape[0]
-    if expected_states is not None and E_pair.is_cuda and E_pair.is_contiguous() and n <= 10 and K <= 8 and T > 1:
+    no_global_grad = not any(isinstance(x, torch.Tensor) and x.requires_grad for x in tuple(dense_init) + tuple(dense_pair))
+    if expected_states is not None and no_global_grad and _pair_contract_applies(dense_init, E_pair):
         node_hmm, pair_sums = _PairContract.apply(E_pair, init_stats[0], init_stats[1], dense_init, dense_pair,
                                                   expected_states)
     else:

@@ -335,6 +335,41 @@ def test_filter_messages_against_reference_build(n, T, inhomog):
 
 
 @pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("n,T,inhomog", [(10, 40, False), (3, 1, False), (4, 9, True), (7, 2, False)])
+def test_smoother_and_sampler_on_caller_supplied_messages(n, T, inhomog):
+    """natural_smoother_general(forward_messages, pair_params) and natural_sample_backward(forward_messages,
+    pair_params, num_samples) as their own entry points (lds_inference.py:18-24 imports them separately;
+    cython_lds_inference.pyx:149, 310): on the messages of the REFERENCE's compiled filter, against the reference's
+    compiled smoother / sampler on the same messages."""
+    from svae_amd.lds.lds_inference import natural_sample_backward, natural_smoother_general
+    from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials
+    rng = np.random.default_rng(5 * n + T)
+    S = 2
+    init, pair = rand_lds_natparam(n, rng)
+    if inhomog:
+        ps = [rand_lds_natparam(n, rng)[1] for _ in range(T - 1)]
+        pair = tuple(np.stack([p_[i] for p_ in ps]) for i in range(4))
+    node = rand_node_potentials((T, n), rng, with_logZ=True)
+    messages, _, _ = ref.filter_forward(init, pair, node)
+    (want_i, want_p, want_n), _ = ref.smoother(messages, pair)
+    want_s, eps = ref.sample_backward((init, pair), node, S, seed=5)
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev)
+    msgs = tuple(tuple(t(np.asarray(x)) for x in m) for m in messages)
+    Ei, Ep, En = natural_smoother_general(msgs, tuple(t(x) for x in pair))
+    assert _rel(Ei[0], want_i[0]) < 1e-8 and _rel(Ei[1], want_i[1]) < 1e-8
+    for i in range(3):
+        assert _rel(Ep[i], np.asarray(want_p[i])) < 1e-8
+    assert _rel(En[0], want_n[0]) < 1e-8 and _rel(En[1], want_n[1]) < 1e-8
+    got_s = natural_sample_backward(msgs, tuple(t(x) for x in pair), S, eps=t(eps))
+    assert tuple(got_s.shape) == (T, S, n) and _rel(got_s, want_s) < 1e-7
+    # batched messages (a leading B axis, as natural_filter_forward_general returns them for batched nodes)
+    msgs2 = tuple(tuple(torch.stack([x, x]) for x in m) for m in msgs)
+    Ei2, _, En2 = natural_smoother_general(msgs2, tuple(t(x) for x in pair))
+    assert tuple(En2[1].shape) == (2, T, n) and _rel(En2[1][1], want_n[1]) < 1e-8 and _rel(Ei2[0][0], want_i[0]) < 1e-8
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
 def test_lds_sample_without_smoother_against_reference_build():
     """cython_natural_lds_sample (lds_inference.py:260-264): filter + backward sampler only."""
     from svae_amd.lds.lds_inference import cython_natural_lds_sample

@@ -610,3 +610,42 @@ def test_final_pass_contractions_against_the_two_library_forms(K, n, T, B):
         _close(a, _np(b), 1e-11)
     # shapes the kernel does not cover fall back to the library forms
     assert slds_svae.final_pass_contractions(dense_init, dense_pair, init_stats, E_pair.cpu(), Es) is None
+
+
+@pytest.mark.parametrize("K", [1, 3, 8])
+def test_one_sequence_consumer_sweep_every_latent_dim_against_the_table_kernel(K):
+    """The default SLDS mean-field step for small launches (slds_meanfield_seq_kernel: one-sequence consumer + three
+    producer wavefronts) carries a workaround for a loop form that was wrong at n = 4 only (csrc/lds_estep_twoend.hpp,
+    "one step per trip"; cause not pinned: suspected compiler scheduling).  Until it is explained this sweep runs on
+    every GPU test pass: EVERY latent dimension 1..10, odd and even T, against the table kernel (a different
+    consumer, no ring, no producers), so that a toolchain change that re-opens it cannot pass silently
+    (tests/test_build_audit.py pins the hipcc version the sweep was last green on)."""
+    from svae_amd import _lib
+    from svae_amd.models import slds_svae
+    from svae_amd.lds.synthetic_data import rand_slds_global_natparam
+    dev = torch.device("cuda:0")
+    B = 5
+    d = lambda x: tuple(d(y) for y in x) if isinstance(x, (tuple, list)) else \
+        torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev)
+    for n in range(1, 11):
+        for T in (9, 12, 4):
+            rng = np.random.default_rng(100 * K + 10 * n + T)
+            glob = rand_slds_global_natparam(K, n, rng)
+            _, _, dense_init, dense_pair = slds_svae.global_to_local_maps(d(glob), dev)
+            dense_init = tuple(x.contiguous() for x in dense_init)
+            dense_pair = tuple(x.contiguous() for x in dense_pair)
+            node = (torch.as_tensor(-0.5 * (0.5 + rng.random((B, T, n))), device=dev),
+                    torch.as_tensor(2. * rng.standard_normal((B, T, n)), device=dev))
+            w = rng.random((B, T, K)) ** 3 + 1e-3
+            w = torch.as_tensor(w / w.sum(-1, keepdims=True), device=dev)
+            out = {}
+            for name, opt in (("tables", _lib.OPT_LAYOUT_SPLIT), ("default", 0)):
+                plan = slds_svae.SLDSMeanfieldPlan(B, T, n, K, dev, options=opt)
+                plan.launch(dense_init, dense_pair, w, node, None)
+                torch.cuda.synchronize()
+                assert int(plan.info.item()) == 0
+                out[name] = [x.clone() for x in (plan.lognorm, plan.E_init, plan.E_node_diagxx, plan.E_node_x,
+                                                 plan.hmm_nodeparams(dense_init, dense_pair))]
+            for a, b in zip(out["default"], out["tables"]):
+                rel = float((a - b).abs().max()) / (float(b.abs().max()) + 1e-300)
+                assert rel < 1e-10, "K=%d n=%d T=%d: %.2e" % (K, n, T, rel)
