@@ -188,7 +188,9 @@ def _slds_globals(K, n, rng):
     return (dir_nat, mdir_nat), lds
 
 
-def slds_case(name, K, n, T, B, S, seed):
+def slds_case(name, K, n, T, B, S, seed, compact=False):
+    # compact (BASELINE configs[3]'s T = 500): without the per-step (T-1,n,n) arrays -- the glue functions' fixed-input
+    # cases and the per-step pair statistics of the ascent (2.4 MB per sequence); everything else as the small cases
     slds = ref_py2.load_reference_slds()
     rng = np.random.default_rng(seed)
     glob = _slds_globals(K, n, rng)
@@ -212,29 +214,30 @@ def slds_case(name, K, n, T, B, S, seed):
         out["dense_init%d" % i] = np.stack([np.asarray(p[i], float) for p in all_init])
         out["dense_pair%d" % i] = np.stack([np.asarray(p[i], float) for p in all_pair])
     w = rng.random((T, K)); w /= w.sum(1, keepdims=True)
-    out["glue_states"] = w
-    gi, gp = slds.get_var_lds_local_natparam(lds, (None, None, w))
-    for i in range(4):
-        out["glue_init%d" % i], out["glue_pair%d" % i] = np.asarray(gi[i], float), np.asarray(gp[i], float)
-    x = rng.standard_normal((T, n))
-    o = lambda a, b: a[..., :, None] * b[..., None, :]
-    A = rng.standard_normal((T - 1, n, n)) * 0.1
-    init_stats = (o(x[0], x[0]) + 0.3 * np.eye(n), x[0], 1., 1.)
-    pair_stats = [o(x[:-1], x[:-1]) + A @ A.transpose(0, 2, 1), o(x[:-1], x[1:]) + A,
-                  o(x[1:], x[1:]) + A.transpose(0, 2, 1) @ A, np.ones(T - 1)]
-    out["glue_ExxT0"], out["glue_Ex0"] = init_stats[0], init_stats[1]
-    for i in range(3):
-        out["glue_pairstat%d" % i] = pair_stats[i]
-    out["glue_node_hmm"] = slds.get_arhmm_local_nodeparams(lds, (init_stats, pair_stats))
-    Etrans = rng.random((K, K))
-    (ghi, ght), glds = slds.get_global_stats((w[0], Etrans, w), (init_stats, pair_stats))
-    glds = list(glds)
-    out["glue_gstat_hmm_init"], out["glue_gstat_hmm_trans"] = ghi, ght
-    out["glue_gstat_init_xx"] = np.stack([g[0][0] for g in glds])
-    out["glue_gstat_init_x"] = np.stack([g[0][1] for g in glds])
-    out["glue_gstat_init_1"] = np.array([[g[0][2], g[0][3]] for g in glds])
-    for i in range(4):
-        out["glue_gstat_pair%d" % i] = np.stack([np.asarray(list(g[1])[i], float) for g in glds])
+    if not compact:
+      out["glue_states"] = w
+      gi, gp = slds.get_var_lds_local_natparam(lds, (None, None, w))
+      for i in range(4):
+          out["glue_init%d" % i], out["glue_pair%d" % i] = np.asarray(gi[i], float), np.asarray(gp[i], float)
+      x = rng.standard_normal((T, n))
+      o = lambda a, b: a[..., :, None] * b[..., None, :]
+      A = rng.standard_normal((T - 1, n, n)) * 0.1
+      init_stats = (o(x[0], x[0]) + 0.3 * np.eye(n), x[0], 1., 1.)
+      pair_stats = [o(x[:-1], x[:-1]) + A @ A.transpose(0, 2, 1), o(x[:-1], x[1:]) + A,
+                    o(x[1:], x[1:]) + A.transpose(0, 2, 1) @ A, np.ones(T - 1)]
+      out["glue_ExxT0"], out["glue_Ex0"] = init_stats[0], init_stats[1]
+      for i in range(3):
+          out["glue_pairstat%d" % i] = pair_stats[i]
+      out["glue_node_hmm"] = slds.get_arhmm_local_nodeparams(lds, (init_stats, pair_stats))
+      Etrans = rng.random((K, K))
+      (ghi, ght), glds = slds.get_global_stats((w[0], Etrans, w), (init_stats, pair_stats))
+      glds = list(glds)
+      out["glue_gstat_hmm_init"], out["glue_gstat_hmm_trans"] = ghi, ght
+      out["glue_gstat_init_xx"] = np.stack([g[0][0] for g in glds])
+      out["glue_gstat_init_x"] = np.stack([g[0][1] for g in glds])
+      out["glue_gstat_init_1"] = np.array([[g[0][2], g[0][3]] for g in glds])
+      for i in range(4):
+          out["glue_gstat_pair%d" % i] = np.stack([np.asarray(list(g[1])[i], float) for g in glds])
 
     # --- the coordinate ascent, as shipped ---------------------------------------------------
     # The compiled filter reads init_params[2] only (cython_lds_inference.pyx:32): with the
@@ -273,6 +276,8 @@ def slds_case(name, K, n, T, B, S, seed):
         acc["node_hmm"].append(hmm_nat[2])
     slds.hmm_estep = estep0
     for k in keys:
+        if compact and k.startswith("Epair"):
+            continue
         out["opt_" + k] = np.stack([np.asarray(v, float) for v in acc[k]])
 
     # --- run_inference (:289-310), forward values, one sequence --------------------------------
@@ -314,6 +319,8 @@ CASES = [
     (gmm_run_case, "gmm_run_K5_N2_T60", dict(K=5, N=2, T=60, S=3, seed=4)),
     (slds_case, "slds_K3_n4_T12", dict(K=3, n=4, T=12, B=3, S=2, seed=11)),
     (slds_case, "slds_K8_n10_T40", dict(K=8, n=10, T=40, B=2, S=1, seed=12)),
+    # BASELINE configs[3]'s shape per sequence (K = 8, latent dim 10, T = 500), from the reference's own slds_svae.py (round 6)
+    (slds_case, "slds_K8_n10_T500", dict(K=8, n=10, T=500, B=4, S=1, seed=13, compact=True)),
 ]
 
 

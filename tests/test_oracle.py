@@ -242,6 +242,29 @@ def test_slds_glue_oracle_matches_reference_golden(case, golden_dir):
             assert abs(r2["lds_vlb"] - (g["opt_lds_vlb"][b] + g["opt_init_b"][b])) < 1e-8 * abs(g["opt_lds_vlb"][b])
 
 
+def test_slds_oracle_matches_reference_golden_at_config3_size(golden_dir):
+    """BASELINE configs[3]'s per-sequence shape (K = 8, latent dim 10, T = 500): oracle/slds_numpy.py -- the checker of the
+    full-size GPU test (tests/test_slds_hip.py::test_config3_full_size_fused_ascent_against_oracle) -- against whole
+    optimize_local_meanfield runs of the reference's OWN slds_svae.py at that size (tests/golden/slds_K8_n10_T500.npz,
+    make_golden.py:slds_case(compact=True)): same sweep counts, statistics and bounds.  Two of the fixture's four
+    sequences here (the CPU suite's time budget); the GPU tests check all four against the fixture directly."""
+    from oracle import slds_numpy
+    import _slds_golden as G
+    g = G.load(golden_dir, "slds_K8_n10_T500")
+    glob = G.global_natparam(g)
+    for b in (0, 3):
+        r = slds_numpy.optimize_local_meanfield(glob, (g["node_J"][b], g["node_h"][b]), g["opt_init_eps"][b],
+                                                cython_init_logZ=True)
+        assert r["iters"] == int(g["opt_iters"][b])
+        assert abs(r["hmm_vlb"] - g["opt_hmm_vlb"][b]) < 1e-8 * abs(g["opt_hmm_vlb"][b])
+        assert abs(r["lds_vlb"] - g["opt_lds_vlb"][b]) < 1e-8 * abs(g["opt_lds_vlb"][b])
+        for got, key in ((r["hmm_stats"][0], "E_hmm_init"), (r["hmm_stats"][1], "E_hmm_trans"),
+                         (r["hmm_stats"][2], "E_states"), (r["init_stats"][0], "ExxT0"), (r["init_stats"][1], "Ex0"),
+                         (r["node_stats"][0], "Enode_diagxx"), (r["node_stats"][1], "Enode_x"),
+                         (r["node_hmm"], "node_hmm")):
+            assert G.rel(got, g["opt_" + key][b]) < 1e-8, key
+
+
 @pytest.mark.parametrize("name", ["lds_dense_T7_n4", "lds_dense_T6_n3_inhomog"])
 def test_oracle_dense_node_potentials_against_the_reference_python_path(name, golden_dir):
     """Dense (T,n,n) node potentials: oracle/lds_numpy.py vs what the reference's Python path returned

@@ -450,7 +450,9 @@ def test_glue_functions_against_reference_golden(case, golden_dir):
 
 
 @pytest.mark.parametrize("fused", [False, True])
-@pytest.mark.parametrize("case", ["slds_K3_n4_T12", "slds_K8_n10_T40"])
+# (slds_K8_n10_T500: BASELINE configs[3]'s shape per sequence -- K = 8, latent dim 10, T = 500 -- from the reference's OWN
+#  slds_svae.py, round 6; the fixture leaves out the per-step (T-1,n,n) pair statistics)
+@pytest.mark.parametrize("case", ["slds_K3_n4_T12", "slds_K8_n10_T40", "slds_K8_n10_T500"])
 def test_optimize_local_meanfield_against_reference_golden(case, fused, golden_dir):
     """The whole coordinate ascent (HMM kernel <-> LDS kernel; fused = svae_slds_lds_meanfield_f64) against the
     reference's own optimize_local_meanfield run (slds_svae.py:159-175 on its compiled kernels): the same
@@ -473,6 +475,8 @@ def test_optimize_local_meanfield_against_reference_golden(case, fused, golden_d
                      (lds_stats[0][0], "ExxT0"), (lds_stats[0][1], "Ex0"), (lds_stats[1][0], "Epair0"),
                      (lds_stats[1][1], "Epair1"), (lds_stats[1][2], "Epair2"), (lds_stats[2][0], "Enode_diagxx"),
                      (lds_stats[2][1], "Enode_x"), (hmm_nat[2], "node_hmm")):
+        if "opt_" + key not in g:            # (compact fixture: no per-step pair statistics)
+            continue
         e = G.rel(_np(got), g["opt_" + key])
         worst = max(worst, e)
         assert e < 1e-6, (key, e)
@@ -484,7 +488,7 @@ def test_optimize_local_meanfield_against_reference_golden(case, fused, golden_d
     assert np.all(np.abs(d[same]) < 1e-6 * np.abs(g["opt_lds_vlb"][same]))
 
 
-@pytest.mark.parametrize("case", ["slds_K3_n4_T12", "slds_K8_n10_T40"])
+@pytest.mark.parametrize("case", ["slds_K3_n4_T12", "slds_K8_n10_T40", "slds_K8_n10_T500"])
 def test_run_inference_against_reference_golden(case, golden_dir):
     """run_inference (slds_svae.py:289-310) forward values: samples (the reference's RNG draws replayed),
     the global statistics, global_vlb (slds_prior_vlb :248-286) and local_vlb of the reference's own run."""

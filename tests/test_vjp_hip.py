@@ -227,8 +227,15 @@ def test_vjp_full_size_against_reference(B):
     loss.backward()
     eJ, eh = _rel_rows(nJ.grad, want["gJ"]), _rel_rows(nh.grad, want["gh"])
     worst = float(max(eJ.max(), eh.max()))
-    print("B=%d: all %d sequences vs the compiled reference's VJPs, worst rel err %.2e (sequence %d)"
-          % (B, B, worst, int(np.maximum(eJ, eh).argmax())))
+
+    def plain(a, b, guard=1e-9):     # element-wise |a-b|/|b| without an absolute floor (entries above 1e-9 of the maximum:
+        a, b = a.detach().cpu().numpy(), np.asarray(b, float)       # a gradient entry is a sum of T x n^2 terms)
+        m = np.abs(b) > guard * np.max(np.abs(b))
+        return float(np.max(np.abs(a - b)[m] / np.abs(b)[m]))
+    pl = max(plain(nJ.grad, want["gJ"]), plain(nh.grad, want["gh"]))
+    print("B=%d: all %d sequences vs the compiled reference's VJPs, worst rel err %.2e (sequence %d); plain "
+          "element-wise |a-b|/|b| (no floor, entries > 1e-9 max): %.2e" % (B, B, worst, int(np.maximum(eJ, eh).argmax()), pl))
+    assert pl < 1e-3, pl             # (reported; cancellation in near-zero gradient entries: the bound is loose)
     assert float(_rel_rows(nz.grad, want["gz"]).max()) < 1e-12
     assert worst < 1e-6, worst
 
