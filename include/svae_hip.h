@@ -26,6 +26,7 @@ extern "C" {
 #endif
 
 #define SVAE_HIP_ABI_VERSION 14   /* 14: + svae_lds_inference_f64 (E-step + sampler in one call; lean per-step records for large homogeneous batches), svae_lds_inference_is_lean, SVAE_OPT_LEAN_ON / _OFF / SVAE_OPT_INFER_RECORDS; 13: + svae_slds_pair_contract_f64 (the two contractions of the SLDS final pass over the per-step pair statistics in one pass); 12: svae_gmm_global_step_f64 writes kl[0..1] (as spelled | as shipped), svae_ipc_allreduce_f64 takes the mailbox stride and never writes `out` on a timeout, + svae_slds_lds_meanfield options; 11: + svae_lds_global_step_multi_f64 (K parameter sets in one launch: the SLDS global -> local maps), svae_lds_diag_sample_f64 (filter + sampler of an all-diagonal LDS: the SLDS initial path); 10: + svae_ipc_allreduce_f64 / svae_ipc_mailbox_bytes, svae_gmm_sample_f64, svae_gmm_local_vjp_f64, svae_gmm_global_step_f64 (the differentiable tail and the global side of the GMM local step); 9: keep bit SVAE_KEEP_SIGMA of svae_lds_estep_f64 (16 <= n <= 64) + svae_lds_tile_sigma_offset_bytes; 8: step ranges (t_begin, t_end) in svae_lds_tile_vjp_f64 / svae_lds_tile_noise_f64, SVAE_OPT_TILE_FORWARD / _BACKWARD; 7: + svae_slds_path_nodeparams_f64, svae_slds_mix_pair_natparam_f64; 6: per-call `options` word replaces the process-global svae_lds_set_* selectors (re-entrant library), + svae_slds_hmm_meanfield_f64, svae_slds_sweep_glue_f64, g_E_pair in svae_lds_tile_vjp_f64; 5: + svae_lds_set_prod_max_b; 4: + svae_slds_lds_meanfield_f64, svae_gmm_mw_*, svae_lds_global_step_f64, svae_lds_natgrad_f64, svae_lds_tile_vjp_f64; 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
+#define SVAE_HMM_MAX_K 64   /* svae_hmm_estep_f64 / svae_slds_hmm_meanfield_f64: K <= 16 one DPP row per sequence; 17 <= K <= 64 one wavefront per sequence (round 6) */
 #define SVAE_LDS_MAX_N 15   /* register/DPP path: one 16-lane row per sequence, n+1 <= 16 */
 #define SVAE_LDS_TILE_MAX_N 64   /* 16 <= n <= 64: LDS-tiled MFMA path (keep: SVAE_KEEP_SIGMA or 0) */
 #define SVAE_KEEP_SIGMA 4         /* keep bit of svae_lds_estep_f64, 16 <= n <= 64 only: see svae_lds_tile_sigma_offset_bytes */
@@ -375,7 +376,9 @@ int svae_lds_estep_vjp_ex_f64(int B, int T, int n, int S, int inhomog, int pair_
                               const void* workspace, size_t ws_bytes,
                               void* vjp_workspace, size_t vjp_ws_bytes, void* stream);
 
-/* Batched HMM E-step: log-normaliser and expected statistics of B chains with K <= 16 states
+/* Batched HMM E-step: log-normaliser and expected statistics of B chains with K <= SVAE_HMM_MAX_K = 64 states
+ * (K <= 16: one 16-lane DPP row per sequence, two-ended scaled recursions; 17 <= K <= 64, round 6: one wavefront per
+ * sequence, lane = state, scaled recursions with a log-space redo of flagged sequences -- csrc/hmm_estep_wide.hip)
  * [hmm_logZ  /root/reference/svae/hmm/cython_hmm_inference.pyx:93-121 and hmm_logZ_grad :126-166 at
  *  g = 1, i.e. `hmm_estep_slow = vgrad(hmm_logZ)` /root/reference/svae/hmm/hmm_inference.py:65; the
  *  reference's hmm_estep (:21-41) delegates to the un-vendored pyhsmm].

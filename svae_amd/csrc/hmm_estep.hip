@@ -29,6 +29,7 @@
 
 #include "../../include/svae_hip.h"
 #include "dpp.hpp"
+#include "hmm_args.hpp"
 
 #ifndef SVAE_HMM_TWOEND
 #define SVAE_HMM_TWOEND 1      // two-ended kernel + one-directional fallback for flagged sequences (0: the one-directional kernel alone; A/B)
@@ -36,31 +37,6 @@
 
 namespace svae {
 
-struct HmmArgs {
-  int B, T, K;
-  long pair_stride;                       // doubles between sequences' pair params (0 = shared)
-  const double* __restrict__ init_params; // (K)      log pi_0 (unnormalised ok)
-  const double* __restrict__ pair_params; // (K,K) or (B,K,K)   log P[j][k]  (j -> k)
-  const double* __restrict__ node_params; // (B,T,K)  log-likelihood potentials
-  double* __restrict__ logZ;              // (B)
-  double* __restrict__ E_init;            // (B,K)
-  double* __restrict__ E_trans;           // (B,K,K)
-  double* __restrict__ E_states;          // (B,T,K)
-  double* __restrict__ ws;                // (B,T,HMM_WS)
-  // indexed launches (SLDS coordinate ascent): slot i of the launch works on row seq_index[i] of every array
-  const int32_t* __restrict__ seq_index;  // (B) or nullptr
-  // FUSED node potentials (get_arhmm_local_nodeparams, slds_svae.py:131-147, from the fused LDS mean-field kernel's
-  // outputs): node[b,0,k] = <E x0 x0', J_k> + <E x0, h_k> + cinit_k;  node[b,t,k] = pc[b,t-1,0,k] + pc[b,t,1,k] + lz_k
-  int n;                                  // latent dimension of the LDS
-  const double* __restrict__ pair_contr;  // (rows,T,2,K)
-  const double* __restrict__ lds_E_init;  // (rows, n*n+n)
-  const double* __restrict__ init_J;      // (K,n,n)
-  const double* __restrict__ init_h;      // (K,n)
-  const double* __restrict__ cinit;       // (K)
-  const double* __restrict__ lz;          // (K)
-  double* __restrict__ node_out;          // (rows,T,K) or nullptr: the node potentials used
-  int redo_only;                          // hmm_estep_kernel behind hmm_estep2_kernel: only wavefronts with a flagged sequence run
-};
 // workspace record per (sequence, step).  One-directional kernel (hmm_estep_kernel): [alpha (16) | e/c or its log-space
 // stand-in (16) | flag | ..].  Two-ended kernel (hmm_estep2_kernel): [alpha^ | e | w = e o beta^] in slots of 8 (K <= 8) or
 // 16 lanes, then the maximum of the node potentials; entry HMM_REDO of the sequence's FIRST record is its REDO flag.
@@ -901,8 +877,11 @@ __global__ __launch_bounds__(256, SVAE_PC_WPC) void slds_pair_contract_kernel(in
 
 }  // namespace svae
 
+extern "C" int svae_hmm_wide_launch(const svae::HmmArgs* a, void* stream);     // hmm_estep_wide.hip: 17 <= K <= 64
+
 extern "C" size_t svae_hmm_workspace_bytes(int B, int T, int K) {
-  if (B <= 0 || T <= 0 || K <= 0 || K > 16) return 0;
+  if (B <= 0 || T <= 0 || K <= 0 || K > SVAE_HMM_MAX_K) return 0;
+  if (K > 16) return (size_t)B * T * svae::hmm_wide_rec(svae::hmm_wide_kp(K)) * sizeof(double);
   return (size_t)B * T * svae::HMM_WS * sizeof(double);
 }
 
@@ -915,7 +894,7 @@ extern "C" int svae_hmm_estep_f64(int B, int T, int K, int pair_batched,
                                   void* workspace, size_t ws_bytes, void* stream) {
   if (B < 0) return -1;
   if (T < 1) return -2;
-  if (K < 1 || K > 16) return -3;
+  if (K < 1 || K > SVAE_HMM_MAX_K) return -3;
   if (!init_params) return -5;
   if (!pair_params) return -6;
   if (!node_params) return -7;
@@ -947,11 +926,11 @@ extern "C" int svae_slds_hmm_meanfield_f64(int B, int rows, int T, int K, int n,
                                            double* node_out, void* workspace, size_t ws_bytes, void* stream) {
   if (B < 0 || B > rows) return -1;
   if (T < 1) return -3;
-  if (K < 1 || K > 16) return -4;
+  if (K < 1 || K > SVAE_HMM_MAX_K) return -4;
   if (n < 1 || n > 64) return -5;
   if (!hmm_init) return -6;
   if (!hmm_pair) return -7;
-  if (!node_params && (!pair_contr || !lds_E_init || !init_J || !init_h || !cinit || !lz)) return -8;
+  if (!node_params && (K > 16 || !pair_contr || !lds_E_init || !init_J || !init_h || !cinit || !lz)) return -8;   /* K > 16: node potentials given */
   if (!logZ) return -16;
   if (!E_init) return -17;
   if (!E_trans) return -18;
@@ -1077,6 +1056,7 @@ extern "C" int svae_slds_pair_contract_f64(int B, int T, int K, int n, const dou
 static int hmm_dispatch(const svae::HmmArgs& a, void* stream) {
   const int K = a.K;
   hipStream_t s = (hipStream_t)stream;
+  if (K > 16) return svae_hmm_wide_launch(&a, stream);
   switch (K) {
 #define SVAE_CASE(KK) case KK: return svae::launch_hmm<KK>(a, s);
     SVAE_CASE(1) SVAE_CASE(2) SVAE_CASE(3) SVAE_CASE(4) SVAE_CASE(5) SVAE_CASE(6) SVAE_CASE(7)

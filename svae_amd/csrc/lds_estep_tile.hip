@@ -238,6 +238,16 @@ __global__ __launch_bounds__(256, WPC) void lds_estep_tile_kernel(const LdsArgs 
 
   double ldM = 1.0, pmin = 1.0e300, qacc = 0.0;
   int ldE = 0;
+#ifdef SVAE_TILE_SKEW_NS
+  // Round-6 experiment ("two sequences skewed by half a step"): with two workgroups per CU
+  // blocks b and b + gridDim/2 share a CU (profiles/r5_tile_n64_b512/wave_placement_hwid.txt); the second one starts
+  // SVAE_TILE_SKEW_NS later, so that its DPP pivot factorisations fall into the first one's MFMA phases (and vice versa)
+  // for as long as the two keep their distance.  Measured: DESIGN.md section 8.  Not compiled in by default.
+  if (WPC == 2 && blockIdx.x >= (gridDim.x + 1) / 2) {
+    const long long t0_ = __builtin_amdgcn_s_memrealtime();          // 100 MHz
+    while (__builtin_amdgcn_s_memrealtime() - t0_ < (SVAE_TILE_SKEW_NS) / 10) __builtin_amdgcn_s_sleep(8);
+  }
+#endif
 #ifdef SVAE_TILE_TIMING   // per-phase cycle counts of wave 0 (tools/tile_timing.py); results are not written
   long long tm[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long tlast_ = __builtin_readcyclecounter();

@@ -11,7 +11,7 @@ import torch
 
 from .. import _lib
 
-HMM_MAX_K = 16
+HMM_MAX_K = 64      # (K <= 16: DPP-row kernels; 17 .. 64: one wavefront per sequence, csrc/hmm_estep_wide.hip)
 
 
 def _dev64(x, device):

@@ -127,3 +127,63 @@ def test_hmm_two_ended_kernel_with_one_flagged_sequence_among_many():
         np.testing.assert_allclose(_np(Es[b]), os_, rtol=1e-7, atol=1e-10)
         np.testing.assert_allclose(_np(Et[b]), ot, rtol=1e-7, atol=1e-9)
     assert float(logZ[6]) < -790
+
+
+# ---- 17 <= K <= 64: one wavefront per sequence (csrc/hmm_estep_wide.hip, round 6) -------------------------------------
+@pytest.mark.parametrize("B,T,K,scale", [(5, 7, 17, 1.0), (3, 50, 20, 3.0), (2, 120, 32, 2.0), (4, 9, 33, 1.0),
+                                         (3, 1, 40, 1.0), (2, 2, 64, 1.0), (6, 31, 48, 4.0), (2, 500, 64, 20.0)])
+def test_hmm_wide_kernel_against_oracle_and_reference(B, T, K, scale):
+    """The reference's compiled kernels take any number of states (cython_hmm_inference.pyx:93-166); the DPP-row kernels
+    stop at 16.  17 <= K <= 64 run one wavefront per sequence, lane = state: against the reference's hmm_logZ /
+    hmm_logZ_grad and the NumPy restatement, every sequence."""
+    from svae_amd.hmm.hmm_inference import hmm_estep
+    rng = np.random.default_rng(B * 100 + T + K)
+    init, pair, node = _problem(B, T, K, rng, scale)
+    logZ, (Ei, Et, Es) = hmm_estep((init, pair, node))
+    for b in range(B):
+        lz, (oi, ot, os_) = hmm_numpy.hmm_estep((init, pair, node[b]))
+        assert float(logZ[b]) == pytest.approx(lz, rel=1e-10, abs=1e-10)
+        np.testing.assert_allclose(_np(Ei[b]), oi, rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(_np(Et[b]), ot, rtol=1e-8, atol=1e-11)
+        np.testing.assert_allclose(_np(Es[b]), os_, rtol=1e-8, atol=1e-12)
+        if ref.available():
+            rz, aux = ref.hmm_logZ((init, pair, node[b]))
+            gi, gp, gn = ref.hmm_logZ_grad(1.0, aux)
+            assert float(logZ[b]) == pytest.approx(rz, rel=1e-10, abs=1e-10)
+            np.testing.assert_allclose(_np(Et[b]), gp, rtol=1e-8, atol=1e-11)
+            np.testing.assert_allclose(_np(Es[b]), gn, rtol=1e-8, atol=1e-12)
+            np.testing.assert_allclose(_np(Ei[b]), gi, rtol=1e-8, atol=1e-12)
+    assert float((Es.sum(-1) - 1).abs().max()) < 1e-12
+    assert float((Et.sum((-1, -2)) - (T - 1)).abs().max()) < 1e-10 * max(1, T)
+
+
+def test_hmm_wide_kernel_log_space_redo_of_a_flagged_sequence_and_batched_pairs():
+    """A forced transition through a log-potential of -800 underflows the scaled recursion: that sequence (1 of 5) is
+    flagged and redone in log space -- the reference's own arithmetic --, the others keep the scaled pass; per-sequence
+    transition matrices (pair_batched) at K = 24."""
+    from svae_amd.hmm.hmm_inference import hmm_estep
+    K, T, B = 24, 14, 5
+    rng = np.random.default_rng(8)
+    init = np.full(K, -1e4); init[0] = 0.0
+    pair = -2.0 + 0.3 * rng.standard_normal((K, K))
+    pair[0, :] = -1e4; pair[0, 0] = 0.0; pair[0, 1] = -800.0
+    pair[1:, 0] = -1e4
+    node = 0.5 * rng.standard_normal((B, T, K))
+    node[3] = 0.0
+    node[3, :7, 1:] = -1e4
+    node[3, 7:, 0] = -1e4
+    logZ, (Ei, Et, Es) = hmm_estep((init, pair, node))
+    for b in range(B):
+        lz, (oi, ot, os_) = hmm_numpy.hmm_estep((init, pair, node[b]))
+        assert np.isfinite(lz) and float(logZ[b]) == pytest.approx(lz, rel=1e-9, abs=1e-9)
+        np.testing.assert_allclose(_np(Ei[b]), oi, rtol=1e-7, atol=1e-10)
+        np.testing.assert_allclose(_np(Es[b]), os_, rtol=1e-7, atol=1e-10)
+        np.testing.assert_allclose(_np(Et[b]), ot, rtol=1e-7, atol=1e-9)
+    assert float(logZ[3]) < -790
+    pairs = np.stack([_problem(1, 1, K, rng)[1] for _ in range(B)])
+    init2 = np.log(rng.dirichlet(np.ones(K)))
+    logZ, (Ei, Et, Es) = hmm_estep((init2, pairs, node))
+    for b in range(B):
+        lz, (oi, ot, os_) = hmm_numpy.hmm_estep((init2, pairs[b], node[b]))
+        assert float(logZ[b]) == pytest.approx(lz, rel=1e-10)
+        np.testing.assert_allclose(_np(Et[b]), ot, rtol=1e-8, atol=1e-11)
