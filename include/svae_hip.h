@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SVAE_HIP_ABI_VERSION 14   /* 14: + svae_lds_inference_f64 (E-step + sampler in one call; lean per-step records for large homogeneous batches), svae_lds_inference_is_lean, SVAE_OPT_LEAN_ON / _OFF / SVAE_OPT_INFER_RECORDS; 13: + svae_slds_pair_contract_f64 (the two contractions of the SLDS final pass over the per-step pair statistics in one pass); 12: svae_gmm_global_step_f64 writes kl[0..1] (as spelled | as shipped), svae_ipc_allreduce_f64 takes the mailbox stride and never writes `out` on a timeout, + svae_slds_lds_meanfield options; 11: + svae_lds_global_step_multi_f64 (K parameter sets in one launch: the SLDS global -> local maps), svae_lds_diag_sample_f64 (filter + sampler of an all-diagonal LDS: the SLDS initial path); 10: + svae_ipc_allreduce_f64 / svae_ipc_mailbox_bytes, svae_gmm_sample_f64, svae_gmm_local_vjp_f64, svae_gmm_global_step_f64 (the differentiable tail and the global side of the GMM local step); 9: keep bit SVAE_KEEP_SIGMA of svae_lds_estep_f64 (16 <= n <= 64) + svae_lds_tile_sigma_offset_bytes; 8: step ranges (t_begin, t_end) in svae_lds_tile_vjp_f64 / svae_lds_tile_noise_f64, SVAE_OPT_TILE_FORWARD / _BACKWARD; 7: + svae_slds_path_nodeparams_f64, svae_slds_mix_pair_natparam_f64; 6: per-call `options` word replaces the process-global svae_lds_set_* selectors (re-entrant library), + svae_slds_hmm_meanfield_f64, svae_slds_sweep_glue_f64, g_E_pair in svae_lds_tile_vjp_f64; 5: + svae_lds_set_prod_max_b; 4: + svae_slds_lds_meanfield_f64, svae_gmm_mw_*, svae_lds_global_step_f64, svae_lds_natgrad_f64, svae_lds_tile_vjp_f64; 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
+#define SVAE_HIP_ABI_VERSION 14   /* 14: + svae_lds_estep_vjp_dense_f64 (cotangent of dense node potentials), svae_hmm_* up to K = 64, svae_lds_inference_f64 (E-step + sampler in one call; lean per-step records for large homogeneous batches), svae_lds_inference_is_lean, SVAE_OPT_LEAN_ON / _OFF / SVAE_OPT_INFER_RECORDS; 13: + svae_slds_pair_contract_f64 (the two contractions of the SLDS final pass over the per-step pair statistics in one pass); 12: svae_gmm_global_step_f64 writes kl[0..1] (as spelled | as shipped), svae_ipc_allreduce_f64 takes the mailbox stride and never writes `out` on a timeout, + svae_slds_lds_meanfield options; 11: + svae_lds_global_step_multi_f64 (K parameter sets in one launch: the SLDS global -> local maps), svae_lds_diag_sample_f64 (filter + sampler of an all-diagonal LDS: the SLDS initial path); 10: + svae_ipc_allreduce_f64 / svae_ipc_mailbox_bytes, svae_gmm_sample_f64, svae_gmm_local_vjp_f64, svae_gmm_global_step_f64 (the differentiable tail and the global side of the GMM local step); 9: keep bit SVAE_KEEP_SIGMA of svae_lds_estep_f64 (16 <= n <= 64) + svae_lds_tile_sigma_offset_bytes; 8: step ranges (t_begin, t_end) in svae_lds_tile_vjp_f64 / svae_lds_tile_noise_f64, SVAE_OPT_TILE_FORWARD / _BACKWARD; 7: + svae_slds_path_nodeparams_f64, svae_slds_mix_pair_natparam_f64; 6: per-call `options` word replaces the process-global svae_lds_set_* selectors (re-entrant library), + svae_slds_hmm_meanfield_f64, svae_slds_sweep_glue_f64, g_E_pair in svae_lds_tile_vjp_f64; 5: + svae_lds_set_prod_max_b; 4: + svae_slds_lds_meanfield_f64, svae_gmm_mw_*, svae_lds_global_step_f64, svae_lds_natgrad_f64, svae_lds_tile_vjp_f64; 2: + svae_lds_workspace_bytes_ex, svae_lds_estep_vjp_ex_f64, svae_hmm_*, tiled path (n <= 64) */
 #define SVAE_HMM_MAX_K 64   /* svae_hmm_estep_f64 / svae_slds_hmm_meanfield_f64: K <= 16 one DPP row per sequence; 17 <= K <= 64 one wavefront per sequence (round 6) */
 #define SVAE_LDS_MAX_N 15   /* register/DPP path: one 16-lane row per sequence, n+1 <= 16 */
 #define SVAE_LDS_TILE_MAX_N 64   /* 16 <= n <= 64: LDS-tiled MFMA path (keep: SVAE_KEEP_SIGMA or 0) */
@@ -375,6 +375,23 @@ int svae_lds_estep_vjp_ex_f64(int B, int T, int n, int S, int inhomog, int pair_
                               double* g_node_J, double* g_node_h,
                               const void* workspace, size_t ws_bytes,
                               void* vjp_workspace, size_t vjp_ws_bytes, void* stream);
+
+/* The same with one more output: g_node_J_dense (B,T,n,n) = -2 Pbar_t, the cotangent of a DENSE node potential J_t --
+ * the (T,n,n) node potentials of the reference's Python path (natural_condition_on_general,
+ * /root/reference/svae/lds/gaussian.py:46-49; lds_inference.py:65-82, 205-218), which the host folds into per-step
+ * pair parameters (svae_amd/lds/lds_inference.py:_fold_dense_nodes): J_t enters the recursion only through the pivot
+ * block P_t = J_pred,t + J_t (+ J11,t), so its cotangent is the whole of P_t's, of which g_node_J is the diagonal.  Not
+ * symmetrised (the caller takes the symmetric part); runs the packed sweeps whatever B (only they write it).  -27: NULL
+ * g_node_J_dense; -8 also with SVAE_OPT_INFER_RECORDS on lean records. */
+int svae_lds_estep_vjp_dense_f64(int B, int T, int n, int S, int inhomog, int pair_batched, unsigned options,
+                                 const double* J12, const double* g_lognorm,
+                                 const double* g_E_node_diagxx, const double* g_E_node_x,
+                                 const double* g_E_init, const double* g_E_pair,
+                                 const double* g_samples, const double* eps, const double* samples,
+                                 const double* E_pair, const double* E_node_x,
+                                 double* g_node_J, double* g_node_h, double* g_node_J_dense,
+                                 const void* workspace, size_t ws_bytes,
+                                 void* vjp_workspace, size_t vjp_ws_bytes, void* stream);
 
 /* Batched HMM E-step: log-normaliser and expected statistics of B chains with K <= SVAE_HMM_MAX_K = 64 states
  * (K <= 16: one 16-lane DPP row per sequence, two-ended scaled recursions; 17 <= K <= 64, round 6: one wavefront per

@@ -118,6 +118,7 @@ struct VjpArgs {
   const double* __restrict__ ws2;        // factor region
   const double* __restrict__ ws3;        // cross-moment region
   double* __restrict__ adj;              // VJP scratch: vjp_step_doubles(n) per (b,t)
+  double* __restrict__ g_P;              // (B,T,n,n) or nullptr: -2 Pbar_t = the cotangent of a DENSE node potential J_t (packed sweep 2 only)
 };
 // VJP scratch per (b,t), written by sweep 1 and read by sweep 2:
 //   [0, n HS)        G^: the smoother share (two-role launches) or the total -- n rows x ws_h_stride

@@ -542,15 +542,15 @@ extern "C" size_t svae_lds_vjp_workspace_bytes(int B, int T, int n) {
   return (size_t)B * T * svae::vjp_step_doubles(n) * sizeof(double);
 }
 
-extern "C" int svae_lds_estep_vjp_ex_f64(int B, int T, int n, int S, int inhomog, int pair_batched, unsigned options,
-                                         const double* J12, const double* g_lognorm,
-                                         const double* g_E_node_diagxx, const double* g_E_node_x,
-                                         const double* g_E_init, const double* g_E_pair,
-                                         const double* g_samples, const double* eps,
-                                         const double* samples, const double* E_pair,
-                                         const double* E_node_x, double* g_node_J, double* g_node_h,
-                                         const void* workspace, size_t ws_bytes,
-                                         void* vjp_workspace, size_t vjp_ws_bytes, void* stream) {
+static int vjp_impl(int B, int T, int n, int S, int inhomog, int pair_batched, unsigned options,
+                    const double* J12, const double* g_lognorm,
+                    const double* g_E_node_diagxx, const double* g_E_node_x,
+                    const double* g_E_init, const double* g_E_pair,
+                    const double* g_samples, const double* eps,
+                    const double* samples, const double* E_pair,
+                    const double* E_node_x, double* g_node_J, double* g_node_h, double* g_node_J_dense,
+                    const void* workspace, size_t ws_bytes,
+                    void* vjp_workspace, size_t vjp_ws_bytes, void* stream) {
   if (B < 0) return -1;
   if (T < 1) return -2;
   if (n < 1 || n > SVAE_LDS_MAX_N) return -3;
@@ -580,8 +580,10 @@ extern "C" int svae_lds_estep_vjp_ex_f64(int B, int T, int n, int S, int inhomog
   a.ws2 = a.ws + main_ws_doubles(B, T, n);
   a.ws3 = a.ws2 + factor_ws_doubles(B, T, n);
   a.adj = (double*)vjp_workspace;
+  a.g_P = g_node_J_dense;
+  if (g_node_J_dense) a.prod_max_b = 0;          /* the packed sweeps write it */
   if ((options & SVAE_OPT_INFER_RECORDS) && lean_applies(B, T, n, S, inhomog, options)) {
-    if (g_E_init || g_E_pair) return -8;        /* lean records: cotangents of the node statistics, lognorm and samples */
+    if (g_E_init || g_E_pair || g_node_J_dense) return -8;        /* lean records: cotangents of the node statistics, lognorm and samples */
     switch (n) {
 #define SVAE_CASE_(NN) case NN: return svae_lds_vjp_lean_n##NN(&a, stream);
 #define SVAE_CASE(NN) SVAE_CASE_(NN)
@@ -610,6 +612,36 @@ extern "C" int svae_lds_estep_vjp_ex_f64(int B, int T, int n, int S, int inhomog
 #undef SVAE_CASE_
   }
   return -3;
+}
+
+extern "C" int svae_lds_estep_vjp_ex_f64(int B, int T, int n, int S, int inhomog, int pair_batched, unsigned options,
+                                         const double* J12, const double* g_lognorm,
+                                         const double* g_E_node_diagxx, const double* g_E_node_x,
+                                         const double* g_E_init, const double* g_E_pair,
+                                         const double* g_samples, const double* eps,
+                                         const double* samples, const double* E_pair,
+                                         const double* E_node_x, double* g_node_J, double* g_node_h,
+                                         const void* workspace, size_t ws_bytes,
+                                         void* vjp_workspace, size_t vjp_ws_bytes, void* stream) {
+  return vjp_impl(B, T, n, S, inhomog, pair_batched, options, J12, g_lognorm, g_E_node_diagxx, g_E_node_x, g_E_init, g_E_pair,
+                  g_samples, eps, samples, E_pair, E_node_x, g_node_J, g_node_h, nullptr, workspace, ws_bytes,
+                  vjp_workspace, vjp_ws_bytes, stream);
+}
+
+extern "C" int svae_lds_estep_vjp_dense_f64(int B, int T, int n, int S, int inhomog, int pair_batched, unsigned options,
+                                            const double* J12, const double* g_lognorm,
+                                            const double* g_E_node_diagxx, const double* g_E_node_x,
+                                            const double* g_E_init, const double* g_E_pair,
+                                            const double* g_samples, const double* eps,
+                                            const double* samples, const double* E_pair,
+                                            const double* E_node_x, double* g_node_J, double* g_node_h,
+                                            double* g_node_J_dense,
+                                            const void* workspace, size_t ws_bytes,
+                                            void* vjp_workspace, size_t vjp_ws_bytes, void* stream) {
+  if (!g_node_J_dense) return -27;
+  return vjp_impl(B, T, n, S, inhomog, pair_batched, options, J12, g_lognorm, g_E_node_diagxx, g_E_node_x, g_E_init, g_E_pair,
+                  g_samples, eps, samples, E_pair, E_node_x, g_node_J, g_node_h, g_node_J_dense, workspace, ws_bytes,
+                  vjp_workspace, vjp_ws_bytes, stream);
 }
 
 extern "C" int svae_lds_estep_vjp_f64(int B, int T, int n, int S, const double* J12,

@@ -1085,6 +1085,12 @@ __device__ __forceinline__ void lds_vjp_sweep2_body(const VjpArgs& a) {
       a.g_node_J[((long)b * T + t) * N + c] = -2.0 * gJ;
       a.g_node_h[((long)b * T + t) * N + c] = gh;
     }
+    if (a.g_P) {
+      // dense node potentials (the reference's Python path, lds_inference.py:65-82): J_node,t enters P_t alone, so its
+      // cotangent is the whole of -2 Pbar_t, not just the diagonal (the caller symmetrises)
+      double* gp = a.g_P + (((long)b * T + t) * N) * N + c;
+      if (valid && col) static_for<0, N>([&](auto i) { gp[i * N] = -2.0 * Pb[i]; });
+    }
   }
 }
 
@@ -1373,6 +1379,7 @@ template <int N>
 static int launch_vjp(const VjpArgs& a, hipStream_t stream) {
   dim3 grid((a.B + 3) / 4), grid2(2 * ((a.B + 3) / 4)), block(64);
   const bool statc = a.g_E_init || a.g_E_pair;
+  if (a.g_P && a.prod_max_b > 0) return -1001;       // (the dispatcher asks for the packed sweeps: only they write g_P)
   // two roles while 2 wavefronts per 4 sequences still find idle SIMDs (the sampler role hands its share of G^ to
   // sweep 2 as per-sample factors: room for VJP_SPLIT_MAX_S of them in the scratch record)
   const bool split = a.B <= 2048 && a.S <= VJP_SPLIT_MAX_S;

@@ -224,14 +224,15 @@ class LDSEStepPlan(object):
         return out
 
     def vjp(self, g_lognorm, g_E_node_diagxx=None, g_E_node_x=None, g_samples=None, eps=None,
-            samples=None, g_E_init=None, g_E_pair=None):
+            samples=None, g_E_init=None, g_E_pair=None, dense_out=None):
         """Vector-Jacobian product w.r.t. the node potentials of the last
         `launch(..., keep_factor=True, keep_cross=True)` [+ `sample`]: returns (g_node_J, g_node_h)
         (B,T,n) each; g_node_logZ[b,t] = g_lognorm[b].  Replaces the reference's natural_filter_grad /
         natural_smoother_general_grad / natural_sample_backward_grad
         (cython_lds_inference.pyx:92-145, 236-306, 357-409).  g_E_init (B, n*n+n) and, with per-step
         pair parameters, g_E_pair (B,T-1,3,n,n) are the cotangents of the remaining statistics
-        (_compute_stats_grad, :212-234) -- what the SLDS-SVAE differentiates."""
+        (_compute_stats_grad, :212-234) -- what the SLDS-SVAE differentiates.  dense_out (B,T,n,n): also receives
+        -2 Pbar_t, the (unsymmetrised) cotangent of a DENSE node potential J_t (svae_lds_estep_vjp_dense_f64)."""
         lean = getattr(self, "lean", False)
         if not (getattr(self, "has_cross", False) and (lean or getattr(self, "has_factor", False))):
             raise RuntimeError("vjp() needs a preceding launch(..., keep_factor=True, keep_cross=True) or infer()")
@@ -272,6 +273,16 @@ class LDSEStepPlan(object):
         gJ = torch.empty(self.B, self.T, self.n, **f64)
         gh = torch.empty(self.B, self.T, self.n, **f64)
         p = _lib.ptr
+        if dense_out is not None:
+            if S > 16 or lean:
+                raise ValueError("dense node-potential cotangents: at most 16 sample cotangents, full records")
+            rc = self.lib.svae_lds_estep_vjp_dense_f64(
+                self.B, self.T, self.n, S, int(self.inhomog), int(self._pair_batched), options,
+                p(self._J12), p(g_lognorm), p(g_E_node_diagxx), p(g_E_node_x), p(g_E_init), p(g_E_pair),
+                p(g_samples), p(eps), p(samples), p(self.E_pair), p(self.E_node_x), p(gJ), p(gh), p(dense_out),
+                p(self.ws), self.ws_bytes, p(self.vjp_ws), self.vjp_ws_bytes, _lib.current_stream(self.device))
+            _lib.check(rc, "svae_lds_estep_vjp_dense_f64")
+            return gJ, gh
         rc = self.lib.svae_lds_estep_vjp_ex_f64(
             self.B, self.T, self.n, S, int(self.inhomog), int(self._pair_batched), options,
             p(self._J12), p(g_lognorm), p(g_E_node_diagxx), p(g_E_node_x), p(g_E_init), p(g_E_pair),
@@ -698,9 +709,72 @@ class _LDSInference(torch.autograd.Function):
         return gJ, gh, gz, None, None, None, None
 
 
+class _LDSInferenceDense(torch.autograd.Function):
+    """E-step + sampler with DENSE node potentials J (B,T,n,n) -- the reference's Python path, differentiable end to end
+    there (lds_inference.py:65-82, 205-218) -- differentiable w.r.t. (J, h[, logZ]).  Forward: the off-diagonal part of
+    J_t is folded into per-step, per-sequence pair parameters (_fold_dense_nodes) and the kernels run on its diagonal;
+    backward: J_t enters the recursions only through the pivot block P_t, so its cotangent is the whole of P_t's,
+    -2 Pbar_t, which the second VJP sweep holds in registers (svae_lds_estep_vjp_dense_f64) -- symmetrised here, because
+    the forward pass reads the symmetric part of J_t.  Outputs are the per-step launch's: (lognorm, E[x] (B,T,n),
+    samples, E_init, per-step E_pair (B,T-1,3,n,n)); the caller assembles E[x x'] (B,T,n,n) from E_pair with torch ops."""
+
+    @staticmethod
+    def forward(ctx, node_J, node_h, node_logZ, eps, natparam):
+        nodes_in = (node_J.detach(), node_h.detach()) + ((node_logZ.detach(),) if node_logZ is not None else ())
+        (ip, pp), nodes, info = _fold_dense_nodes(natparam, nodes_in)
+        B, T, n = info["B"], info["T"], info["n"]
+        if T < 2:
+            raise ValueError("differentiable dense node potentials: T >= 2")
+        dev = nodes[1].device
+        plan = LDSEStepPlan(B, T, n, dev, inhomog=True, pair_batched=True)
+        init_J, init_h, init_logZ = _canonical_init_params(ip, dev)
+        J11, J12, J22 = (x.contiguous() for x in pp[:3])
+        samples = plan.infer(init_J, init_h, init_logZ, J11, J12, J22, pp[3].reshape(-1).contiguous(),
+                             nodes[0].contiguous(), nodes[1].contiguous(), nodes[2].contiguous() if len(nodes) == 3 else None,
+                             True, eps)
+        ctx.plan, ctx.epoch, ctx.has_logZ, ctx.has_samples = plan, plan.epoch, node_logZ is not None, eps is not None
+        if samples is None:
+            samples = torch.zeros(0, dtype=torch.float64, device=dev)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(eps if eps is not None else samples, samples)
+        return plan.lognorm.clone(), plan.E_node_x.clone(), samples, plan.E_init.clone(), plan.E_pair.clone()
+
+    @staticmethod
+    def backward(ctx, g_lognorm, g_x, g_samples, g_init, g_pair):
+        plan = ctx.plan
+        if plan.epoch != ctx.epoch:
+            raise RuntimeError("the plan of this forward pass was launched again before backward()")
+        eps, samples = ctx.saved_tensors
+        g_lognorm = torch.zeros_like(plan.lognorm) if g_lognorm is None else g_lognorm
+        gs = g_samples if (ctx.has_samples and g_samples is not None) else None
+        dense = torch.empty(plan.B, plan.T, plan.n, plan.n, dtype=torch.float64, device=plan.device)
+        _, gh = plan.vjp(g_lognorm, None, g_x, gs, eps if gs is not None else None, samples if gs is not None else None,
+                         g_init, g_pair, dense_out=dense)
+        gJ = 0.5 * (dense + dense.transpose(-1, -2))
+        gz = g_lognorm[:, None].expand(plan.B, plan.T).clone() if ctx.has_logZ else None
+        return gJ, gh, gz, None, None
+
+
+def _dense_inference_differentiable(natparam, node_params, eps):
+    node_J, node_h = node_params[0], node_params[1]
+    node_logZ = node_params[2] if len(node_params) == 3 else None
+    if node_h.dim() != 3 or node_J.dim() != 4:
+        raise ValueError("dense node potentials: J (B,T,n,n), h (B,T,n)")
+    cont = lambda x: None if x is None else x.to(torch.float64).contiguous()
+    homog = torch.as_tensor(natparam[1][0]).dim() == 2
+    lognorm, ex, samples, E_init, E_pair = _LDSInferenceDense.apply(cont(node_J), cont(node_h), cont(node_logZ), cont(eps),
+                                                                    natparam)
+    ExxT = torch.cat([E_pair[:, :, 0], E_pair[:, -1:, 2]], dim=1)          # E[x_t x_t'] (B,T,n,n): make_node_stats, :163-166
+    if homog:
+        E_pair = E_pair.sum(1)                                           # (B,3,n,n), differentiable (:172-173)
+    return lognorm, (ExxT, ex), (samples if eps is not None else None), (E_init, E_pair)
+
+
 def lds_inference_differentiable(natparam, node_params, eps=None, plan=None, pair_stats_grad=False):
     """(lognorm (B), (E_node_diagxx, E_node_x) (B,T,n), samples (B,T,S,n) | None, (E_init, E_pair)):
     differentiable w.r.t. node_params = (J (B,T,n), h (B,T,n)[, logZ (B,T)]) through torch autograd.
+    Dense node potentials J (B,T,n,n) (the reference's Python path) are accepted too: the first statistic is then the full
+    E[x x'] (B,T,n,n), and the gradient w.r.t. J is the symmetric (B,T,n,n) matrix (_LDSInferenceDense).
     Pair parameters (n,n), (T-1,n,n) or (B,T-1,n,n); in the per-step cases E_init (B, n*n+n) and
     E_pair (B,T-1,3,n,n) are differentiable too.
 
@@ -715,10 +789,14 @@ def lds_inference_differentiable(natparam, node_params, eps=None, plan=None, pai
     node_J, node_h = node_params[0], node_params[1]
     node_logZ = node_params[2] if len(node_params) == 3 else None
     dev = node_h.device
+    if node_h.dim() == 3 and node_J.dim() == 4:
+        # DENSE node potentials (the reference's Python path, lds_inference.py:65-82): differentiable since round 6 --
+        # returns E[x x'] (B,T,n,n) in place of its diagonal, like the reference's make_node_stats (:163-166)
+        if plan is not None or pair_stats_grad:
+            raise ValueError("dense node potentials: the plan is built internally; the pair statistics are differentiable as they are")
+        return _dense_inference_differentiable(natparam, node_params, eps)
     if node_h.dim() != 3 or node_J.shape != node_h.shape:
-        raise ValueError("lds_inference_differentiable: diagonal node potentials J, h of shape (B,T,n) (dense (B,T,n,n) "
-                         "ones go through the non-differentiable entry points: the VJP kernels return no pair-parameter "
-                         "gradients, which the off-diagonal part would need)")
+        raise ValueError("lds_inference_differentiable: node potentials J, h of shape (B,T,n), or dense J (B,T,n,n)")
     B, T, n = node_h.shape
     init_J, init_h, init_logZ = _canonical_init_params(init_params, dev)
     J11, J12, J22 = (_as_dev(x, dev) for x in pair_params[:3])

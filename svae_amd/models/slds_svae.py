@@ -507,8 +507,8 @@ def optimize_local_meanfield(global_natparam, node_potentials, init_eps, tol=1e-
     hmm_init, hmm_pair, dense_init, dense_pair = local_maps if local_maps is not None else \
         global_to_local_maps(global_natparam, dev)
     K = dense_init[0].shape[0]
-    if fused is None:
-        fused = SLDSMeanfieldPlan.supported(n, T, K)
+    if fused is None or (fused and not SLDSMeanfieldPlan.supported(n, T, K)):
+        fused = SLDSMeanfieldPlan.supported(n, T, K)       # (a forced fused=True outside the kernel's coverage: the materialised path)
     if fused:
         fplan, st, lds_vlb, iters = _optimize_local_meanfield_fused(
             hmm_init, hmm_pair, dense_init, dense_pair, node, _dev64(init_eps, dev), tol, max_iter, reference_compat)
