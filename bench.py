@@ -39,8 +39,8 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x (16x16x4x2 flop / 64 clk, too
 # batch is not specified there: 512 sequences per GPU = two workgroups per CU)
 WORKLOADS = {"lds10": (200, 10, 512), "lds64": (1000, 64, 512)}
 # committed rocprofv3 PMC passes (profiles/run_profile.sh), by (kernel family, sequences per GPU)
-PMC_PROFILES = {("twoend", 512): "r5_twoend", ("twoend_rpc", 4096): "r5_twoend_b4096",
-                ("split", 512): "r1_final", ("packed", 4096): "r1_final_b4096", ("tile", 512): "r5_tile_n64_b512"}
+PMC_PROFILES = {("twoend", 512): "r6_twoend", ("twoend_rpc", 4096): "r6_twoend_b4096",
+                ("split", 512): "r1_final", ("packed", 4096): "r1_final_b4096", ("tile", 512): "r6_tile_n64_b512"}
 
 
 def algorithmic_bytes_per_seq(T, n):

@@ -461,8 +461,7 @@ int svae_slds_mix_pair_natparam_f64(int B, int T, int K, int n, const double* E_
  *   get_arhmm_local_nodeparams :131-147   node_out[b,t+1,k] = <pair_stats[b,t], P_k> + lz_k   (rows 1..T-1 of (B,T,K);
  *                                         row 0 -- the init statistics -- is the caller's)
  *   get_global_stats :229-243             sum_{b,t} weights[b,t+1,k] pair_stats[b,t]: `blocks` partial sums
- *                                         gpart (blocks, 8, 3 n^2), to be added in index order (rows k >= K are zero);
- *                                         the buffer holds ONE more double behind them (scratch word of the kernel)
+ *                                         gpart (blocks, 8, 3 n^2), to be added in index order (rows k >= K are zero)
  * P (K, 3 n^2) = [J11_k | J12_k | J22_k] flattened, lz (K), weights (B,T,K) = the HMM marginals.  n <= 10, K <= 8, T >= 2. */
 int svae_slds_pair_contract_f64(int B, int T, int K, int n, const double* pair_stats, const double* P, const double* lz,
                                 const double* weights, double* node_out, double* gpart, int blocks, void* stream);

@@ -776,7 +776,7 @@ template <int EJ, int KK>
 __global__ __launch_bounds__(256, SVAE_PC_WPC) void slds_pair_contract_kernel(int B, int T, int K, int E, const double* __restrict__ S,
                                                                    const double* __restrict__ P, const double* __restrict__ lz,
                                                                    const double* __restrict__ w, double* __restrict__ node,
-                                                                   double* __restrict__ gpart, double* __restrict__ dummy) {
+                                                                   double* __restrict__ gpart) {
   static_assert(KK == 8, "the butterfly below is written for eight sums");
   __shared__ double red[EJ * KK * 64];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -796,6 +796,10 @@ __global__ __launch_bounds__(256, SVAE_PC_WPC) void slds_pair_contract_kernel(in
   static_for<0, KK>([&](auto k) { kx[k] = k < K ? k : K - 1; mk[k] = k < K ? 1.0 : 0.0; });
   const bool writer = lane < K;
   const int steps = T - 1;
+  // store target of the lanes without a state: one word per WAVEFRONT inside this workgroup's own partial block (entries
+  // e = wv of row k = 0), which the reduction below overwrites after its barriers -- no word shared between workgroups,
+  // nothing the caller has to over-allocate
+  double* const dummy = gpart + (long)blockIdx.x * KK * E + (wv < E ? wv : 0);
   for (long b = blockIdx.x; b < B; b += gridDim.x) {
     const double* Sb = S + b * steps * E;
     const double* wb = w + (b * T + 1) * K;
@@ -1024,7 +1028,7 @@ extern "C" int svae_slds_mix_pair_natparam_f64(int B, int T, int K, int n, const
 }
 
 // One pass over the per-step pair statistics of the SLDS final pass (see slds_pair_contract_kernel): node_out (B,T,K) rows
-// 1 .. T-1 and `blocks` partials (blocks, 8, 3 n^2) of the weighted sums (gpart holds ONE more double behind them).  n <= 10, K <= 8.
+// 1 .. T-1 and `blocks` partials (blocks, 8, 3 n^2) of the weighted sums.  n <= 10, K <= 8.
 extern "C" int svae_slds_pair_contract_f64(int B, int T, int K, int n, const double* pair_stats, const double* P,
                                            const double* lz, const double* weights, double* node_out, double* gpart,
                                            int blocks, void* stream) {
@@ -1043,13 +1047,12 @@ extern "C" int svae_slds_pair_contract_f64(int B, int T, int K, int n, const dou
     (void)hipMemsetAsync(gpart, 0, sizeof(double) * (size_t)blocks * 8 * E, s);
     return 0;
   }
-  double* dummy = gpart + (size_t)blocks * 8 * E;      // one word behind the partials: the idle lanes' store target
   if (blocks > B) {       // (workgroups without a sequence would leave their partial unwritten)
     (void)hipMemsetAsync(gpart + (size_t)B * 8 * E, 0, sizeof(double) * (size_t)(blocks - B) * 8 * E, s);
     blocks = B;
   }
   hipLaunchKernelGGL((svae::slds_pair_contract_kernel<5, 8>), dim3(blocks), dim3(256), 0, s, B, T, K, E, pair_stats, P, lz,
-                     weights, node_out, gpart, dummy);
+                     weights, node_out, gpart);
   return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 

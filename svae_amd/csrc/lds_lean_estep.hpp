@@ -82,7 +82,15 @@ __global__ __launch_bounds__(64) void lds_infer_lean_kernel(const LdsArgs a, con
   double Jo_n = nJ[0];
   double ho_n = nh[0];
 
+  // Lanes N+1 .. 15 of every DPP row carry nothing: the two time loops run with them switched off (EXEC) -- 5 of 16
+  // lanes of every fp64 operation not toggling; at these batch sizes every SIMD is busy and the chip is power-limited
+  // (lds_estep_twoend_rpc.hpp, SVAE_RPC_LANEMASK: the shader clock sags with all 64 lanes live).  -DSVAE_LEAN_LANEMASK=0: A/B.
+#ifndef SVAE_LEAN_LANEMASK
+#define SVAE_LEAN_LANEMASK 1
+#endif
+  const bool live = !SVAE_LEAN_LANEMASK || c <= N;
   // ---- forward filter ------------------------------------------------------------------------------------------------
+  if (live) {
   for (int t = 0; t < T; ++t) {
     const bool last = (t == T - 1);
     const double Jo = -2.0 * Jo_n;
@@ -142,6 +150,7 @@ __global__ __launch_bounds__(64) void lds_infer_lean_kernel(const LdsArgs a, con
       static_for<0, (N + IL - 1) / IL>([&](auto g) { rows_src_bcast<IL, g * IL, N, 0>(An, NJ12T, X); });
     }
   }
+  }   // live
 
   // ---- log-normaliser ------------------------------------------------------------------------------------------------
   {
@@ -278,7 +287,7 @@ __global__ __launch_bounds__(64) void lds_infer_lean_kernel(const LdsArgs a, con
     }
   };
 
-  {
+  if (live) {
     Ops Ra, Rb;
     load_ops(Ra, T > 1 ? 1 : 0);
     int t = T - 1;

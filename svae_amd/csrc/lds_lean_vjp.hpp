@@ -77,6 +77,11 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep1_lean_kernel(const VjpArgs a
     gxn = has_gx ? a.g_x[o] : 0.0;
     gdn = has_gd ? a.g_diagxx[o] : 0.0;
   };
+  // (lanes N+1 .. 15 of every DPP row switched off through the time loop: see lds_lean_estep.hpp, SVAE_LEAN_LANEMASK)
+#ifndef SVAE_LEAN_LANEMASK
+#define SVAE_LEAN_LANEMASK 1
+#endif
+  if (SVAE_LEAN_LANEMASK && !colN) return;
   fetch_next(0);
   for (int t = 0; t < T; ++t) {
     double* ad = a.adj + ((long)b * T + t) * AS;
@@ -263,6 +268,7 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep2_lean_kernel(const VjpArgs a
     const double* ad = a.adj + ((long)b * T + t) * AS;
     static_for<0, N>([&](auto i) { gbn[i] = ad[i * HS + cN]; });
   };
+  if (SVAE_LEAN_LANEMASK && !colN) return;   // (lanes N+1 .. 15 of every DPP row: nothing to do in this kernel)
   fetch_g(T - 1);
   for (int t = T - 1; t >= 0; --t) {
     const double* ad = a.adj + ((long)b * T + t) * AS;

@@ -441,7 +441,7 @@ def _prepare(natparam, node_params, plan):
                 args=(init_J, init_h, init_logZ, J11, J12, J22, logZ_pair, node_J, node_h, node_logZ))
 
 
-def natural_lds_estep_general(natparam, node_params, plan=None, check=False, keep_factor=False):
+def natural_lds_estep_general(natparam, node_params, plan=None, check=False, keep_factor=False, _infer_eps=None):
     """E-step = filter + smoother (lds_inference.py:223-237).
 
     natparam = (init_params, pair_params); init_params = (-1/2 J0, h0, logZ...) and
@@ -466,7 +466,11 @@ def natural_lds_estep_general(natparam, node_params, plan=None, check=False, kee
     q = _prepare(natparam, node_params, plan)
     plan, batched, B, T, n, inhomog = q["plan"], q["batched"], q["B"], q["T"], q["n"], q["inhomog"]
     dev = plan.device
-    plan.launch(*q["args"], q["pair_batched"], keep_factor)
+    if _infer_eps is not None:
+        # (natural_lds_inference_general: E-step + sampler in one call -- lean records for large homogeneous batches)
+        plan._infer_samples = plan.infer(*q["args"], q["pair_batched"], _infer_eps)
+    else:
+        plan.launch(*q["args"], q["pair_batched"], keep_factor)
     if check:
         plan.check_info()
 
@@ -627,14 +631,19 @@ def natural_lds_inference_general(natparam, node_params, num_samples=None, eps=N
         B, T, n = (nh.shape if batched else (1,) + tuple(nh.shape))
         pdim = torch.as_tensor(natparam[1][0]).dim()
         plan = LDSEStepPlan(B, T, n, "cuda", pdim >= 3, pdim == 4)
-    lognorm, stats = natural_lds_estep_general(natparam, node_params, plan=plan, keep_factor=True)
     if eps is None:
         eps = torch.randn(plan.B, plan.T, S, plan.n, dtype=torch.float64, device=plan.device,
                           generator=generator)
     else:
         eps = torch.as_tensor(eps, dtype=torch.float64)
         eps = eps if batched else eps[None]
-    samples = plan.sample(eps)
+    if plan.n <= _lib.LDS_MAX_N and eps.dim() == 4 and eps.shape[2] <= 16:
+        # ONE call (svae_lds_inference_f64 = the reference's composite, lds_inference.py:196-202)
+        lognorm, stats = natural_lds_estep_general(natparam, node_params, plan=plan, keep_factor=True, _infer_eps=eps)
+        samples = plan._infer_samples
+    else:
+        lognorm, stats = natural_lds_estep_general(natparam, node_params, plan=plan, keep_factor=True)
+        samples = plan.sample(eps)
     if num_samples is None:
         samples = samples[:, :, 0]
     if not batched:

@@ -20,7 +20,7 @@ import torch
 
 from .. import _lib
 from ..distributions import expfam
-from ..lds.lds_inference import LDSEStepPlan, natural_lds_estep_general, reduce_stats
+from ..lds.lds_inference import LDSEStepPlan, natural_lds_estep_general, natural_lds_inference_general, reduce_stats
 from ..parallel import allreduce_lds_stats
 
 
@@ -161,14 +161,15 @@ def run_inference(prior_natparam, global_natparam, nn_potentials, num_samples, e
         plan = LDSEStepPlan(B, T, n, dev)
     # (invalid global parameters raise the PLAN's status word: plan.check_info() / check=True report them)
     local_natparam, global_kl = _globals_on_device(prior_natparam, global_natparam, dev, plan.info)
-    lognorm, (Ei, Ep, En) = natural_lds_estep_general(local_natparam, nodeb, plan=plan, keep_factor=True)
     S = 1 if num_samples is None else int(num_samples)
     if eps is None:
         eps = torch.randn(B, T, S, n, dtype=torch.float64, device=dev, generator=generator)
     else:
         eps = _dev64(eps, dev)
         eps = eps if batched else eps[None]
-    samples = plan.sample(eps)
+    # E-step + sampler as the reference's composite (cython_natural_lds_inference_general, lds_inference.py:196-202): one
+    # library call for n <= 15 (lean per-step records above 1024 sequences)
+    samples, (Ei, Ep, En), lognorm = natural_lds_inference_general(local_natparam, nodeb, num_samples=S, eps=eps, plan=plan)
     # local KL: <nn_potentials, E_node> - lognorm  (lds.py:40), summed over the batch
     local_kl = (nodeb[0] * En[0]).sum() + (nodeb[1] * En[1]).sum() - lognorm.sum()
     if len(nodeb) == 3:

@@ -231,8 +231,8 @@ def final_pass_contractions(dense_init, dense_pair, init_stats, pair_stats, expe
     Es = _dev64(expected_states, dev).contiguous()
     node = torch.empty(B, T, K, **f64)
     blocks = min(B, 2 * torch.cuda.get_device_properties(dev).multi_processor_count)
-    gbuf = torch.empty(blocks * 8 * 3 * n * n + 1, **f64)          # (+ the kernel's scratch word)
-    gpart = gbuf[:-1].view(blocks, 8, 3 * n * n)
+    gbuf = torch.empty(blocks * 8 * 3 * n * n, **f64)
+    gpart = gbuf.view(blocks, 8, 3 * n * n)
     p = _lib.ptr
     rc = _lib.load().svae_slds_pair_contract_f64(B, T, K, n, p(pair_stats), p(P), p(lz), p(Es), p(node), p(gbuf), blocks,
                                                  _lib.current_stream(dev))

@@ -1,4 +1,5 @@
-"""HMM E-step launch time by batch size (K = 8, T = 500: the SLDS configuration): python tools/bench_hmm.py [B ...]"""
+"""HMM E-step launch time by batch size (K = 8, T = 500: the SLDS configuration): python tools/bench_hmm.py [B ...]
+   python tools/bench_hmm.py --K 64 [B ...]: another number of states (17 .. 64: the one-wavefront-per-sequence kernel)"""
 import os, sys
 import numpy as np
 import torch
@@ -8,8 +9,12 @@ from svae_amd import _lib
 
 dev = torch.device("cuda:0")
 K, T = 8, 500
+argv = sys.argv[1:]
+if "--K" in argv:
+    K = int(argv[argv.index("--K") + 1])
+    del argv[argv.index("--K"):argv.index("--K") + 2]
 rng = np.random.default_rng(0)
-for B in [int(x) for x in sys.argv[1:]] or [8, 128, 512, 2048]:
+for B in [int(x) for x in argv] or [8, 128, 512, 2048]:
     init = torch.as_tensor(rng.standard_normal(K), device=dev)
     pair = torch.as_tensor(rng.standard_normal((K, K)), device=dev)
     node = torch.as_tensor(3.0 * rng.standard_normal((B, T, K)), device=dev)
