@@ -351,7 +351,7 @@ def measure_slds(dev, B=2048, T=500, n=10, K=8):
             torch.as_tensor(2. * rng.standard_normal((B, T, n)), device=dev))
     eps = torch.randn(B, T, 1, n, dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(0))
     best = None
-    for rep in range(3):
+    for rep in range(5):        # (best of five: the first repetitions behind an empty_cache() also pay for the allocator's warm-up)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         _, _, _, iters = slds_svae.optimize_local_meanfield(glob, node, eps, pair_stats=False)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
@@ -361,7 +361,7 @@ def measure_slds(dev, B=2048, T=500, n=10, K=8):
     prior = _d(rand_slds_global_natparam(K, n, rng))
     eps2 = torch.randn(B, T, 1, n, dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
     best_ri = None
-    for rep in range(3):
+    for rep in range(6):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         out = slds_svae.run_inference(prior, glob, node, 1, init_eps=eps, eps=eps2)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0

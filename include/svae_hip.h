@@ -311,8 +311,9 @@ int svae_lds_sample_f64(int B, int T, int n, int S, unsigned options, const doub
  *   cython_natural_lds_inference_general(natparam, node_params, num_samples) -> (samples, expected_stats, lognorm)
  *     /root/reference/svae/lds/lds_inference.py:196-202  (= natural_filter_forward_general, natural_smoother_general,
  *     natural_sample_backward: /root/reference/svae/lds/cython_lds_inference.pyx:28-90, 149-210, 310-355),
- * keeping in `workspace` what svae_lds_estep_vjp_ex_f64 needs (called with SVAE_OPT_INFER_RECORDS, the same B, T, n, S,
- * inhomog and `options`).  Arguments as svae_lds_estep_f64 (n <= SVAE_LDS_MAX_N) plus eps, samples (B,T,S,n) as
+ * keeping in `workspace` -- keep_vjp != 0 -- what svae_lds_estep_vjp_ex_f64 needs (called with SVAE_OPT_INFER_RECORDS, the
+ * same B, T, n, S, inhomog and `options`); keep_vjp = 0: forward values only (no cross-moment record; lean records then
+ * also serve per-step / per-sequence pair parameters: the final pass of the SLDS's run_inference, slds_svae.py:289-310).  Arguments as svae_lds_estep_f64 (n <= SVAE_LDS_MAX_N) plus eps, samples (B,T,S,n) as
  * svae_lds_sample_f64; S = 0: no sampling (eps, samples may be NULL).  Same results as svae_lds_estep_f64 with keep = 3
  * followed by svae_lds_sample_f64 -- and in general exactly those two calls.  What the single entry point buys: for
  * homogeneous pair parameters, n <= 10, T >= 2, S <= 2 and batches of more than 2048 sequences (or SVAE_OPT_LEAN_ON)
@@ -323,8 +324,8 @@ int svae_lds_sample_f64(int B, int T, int n, int S, unsigned options, const doub
  * drawn here) and the VJP takes no cotangents of E_init / E_pair.  svae_lds_inference_is_lean: which format a call with
  * these arguments uses (1 = lean; host only, a pure function of its arguments).
  * Return values as svae_lds_estep_f64; -4: bad S / missing eps or samples; -100 + k: the sampler stage returned k. */
-int svae_lds_inference_is_lean(int B, int T, int n, int S, int inhomog, unsigned options);
-int svae_lds_inference_f64(int B, int T, int n, int S, int inhomog, int pair_batched, unsigned options,
+int svae_lds_inference_is_lean(int B, int T, int n, int S, int inhomog, int keep_vjp, unsigned options);
+int svae_lds_inference_f64(int B, int T, int n, int S, int inhomog, int pair_batched, int keep_vjp, unsigned options,
                            const double* init_J, const double* init_h, const double* init_logZ,
                            const double* J11, const double* J12, const double* J22, const double* logZ_pair,
                            const double* node_J, const double* node_h, const double* node_logZ,

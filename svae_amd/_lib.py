@@ -57,8 +57,8 @@ SIGNATURES = {
     "svae_lds_estep_vjp_dense_f64": (ctypes.c_int, [ctypes.c_int] * 6 + [ctypes.c_uint] + [_c_double_p] * 14
                                      + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
                                         ctypes.c_void_p]),
-    "svae_lds_inference_is_lean": (ctypes.c_int, [ctypes.c_int] * 5 + [ctypes.c_uint]),
-    "svae_lds_inference_f64": (ctypes.c_int, [ctypes.c_int] * 6 + [ctypes.c_uint] + [_c_double_p] * 17
+    "svae_lds_inference_is_lean": (ctypes.c_int, [ctypes.c_int] * 6 + [ctypes.c_uint]),
+    "svae_lds_inference_f64": (ctypes.c_int, [ctypes.c_int] * 7 + [ctypes.c_uint] + [_c_double_p] * 17
                                + [_c_int_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "svae_lds_sample_f64": (ctypes.c_int, [ctypes.c_int] * 4 + [ctypes.c_uint] + [_c_double_p] * 2
                             + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),

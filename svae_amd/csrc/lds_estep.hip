@@ -21,7 +21,7 @@ extern "C" {
   int svae_lds_launch_forward_pair_n##NN(const svae::LdsArgs*, const svae::LdsArgs*, int, void*); \
   int svae_lds_sample_n##NN(const svae::SampleArgs*, void*);                   \
   int svae_lds_vjp_n##NN(const svae::VjpArgs*, void*);                         \
-  int svae_lds_infer_lean_n##NN(const svae::LdsArgs*, const svae::LeanSample*, void*); \
+  int svae_lds_infer_lean_n##NN(const svae::LdsArgs*, const svae::LeanSample*, int, void*); \
   int svae_lds_vjp_lean_n##NN(const svae::VjpArgs*, void*);
 #define SVAE_DECL(NN) SVAE_DECL_(NN)
 #ifdef SVAE_ONLY_N   /* experimental single-n builds (tools/build_variant.sh) */
@@ -128,16 +128,17 @@ int svae_hip_abi_version(void) { return SVAE_HIP_ABI_VERSION; }
 
 // Record format of svae_lds_inference_f64 (and of the svae_lds_estep_vjp_ex_f64 call that reads its workspace with
 // SVAE_OPT_INFER_RECORDS): a pure function of the arguments both calls share -- the library keeps no state.
-static bool lean_applies(int B, int T, int n, int S, int inhomog, unsigned options) {
-  if (inhomog || n > svae::LEAN_MAX_N || T < 2 || S < 0 || S > svae::LEAN_MAX_S) return false;
+static bool lean_applies(int B, int T, int n, int S, int inhomog, int keep_vjp, unsigned options) {
+  if (n > svae::LEAN_MAX_N || T < 2 || S < 0 || S > svae::LEAN_MAX_S) return false;
+  if (inhomog && keep_vjp) return false;          // per-step pair parameters: forward only (the VJP with statistics cotangents reads the full records)
   if ((long)T * svae::lean_rec_doubles(n) * 8 * 4 >= (1l << 31)) return false;     // 32-bit lane offsets inside a wavefront's records
   if (options & SVAE_OPT_LEAN_OFF) return false;
   if (options & SVAE_OPT_LEAN_ON) return true;
   if (options & (SVAE_OPT_LAYOUT_SPLIT | SVAE_OPT_PRODUCERS_ON)) return false;
   return B >= svae::LEAN_MIN_B;
 }
-int svae_lds_inference_is_lean(int B, int T, int n, int S, int inhomog, unsigned options) {
-  return lean_applies(B, T, n, S, inhomog, options) ? 1 : 0;
+int svae_lds_inference_is_lean(int B, int T, int n, int S, int inhomog, int keep_vjp, unsigned options) {
+  return lean_applies(B, T, n, S, inhomog, keep_vjp, options) ? 1 : 0;
 }
 
 // main region: the one-directional layout (lds_args.hpp), then -- n <= 10 -- the two-ended one (a launch that
@@ -468,7 +469,7 @@ extern "C" int svae_lds_sample_f64(int B, int T, int n, int S, unsigned options,
   return -3;
 }
 
-extern "C" int svae_lds_inference_f64(int B, int T, int n, int S, int inhomog, int pair_batched, unsigned options,
+extern "C" int svae_lds_inference_f64(int B, int T, int n, int S, int inhomog, int pair_batched, int keep_vjp, unsigned options,
                                       const double* init_J, const double* init_h, const double* init_logZ,
                                       const double* J11, const double* J12, const double* J22, const double* logZ_pair,
                                       const double* node_J, const double* node_h, const double* node_logZ,
@@ -478,10 +479,10 @@ extern "C" int svae_lds_inference_f64(int B, int T, int n, int S, int inhomog, i
                                       int32_t* info, void* workspace, size_t ws_bytes, void* stream) {
   if (n < 1 || n > SVAE_LDS_MAX_N) return -3;
   if (S < 0 || (S > 0 && (!eps || !samples))) return -4;
-  if (!lean_applies(B, T, n, S, inhomog, options)) {
-    // the general path: E-step keeping the hand-off, the factor and the cross moments, then the sampler
+  if (!lean_applies(B, T, n, S, inhomog, keep_vjp, options)) {
+    // the general path: E-step keeping the hand-off, the factor and (keep_vjp) the cross moments, then the sampler
     const unsigned o = options & SVAE_OPT_ALL;
-    const int rc = svae_lds_estep_f64(B, T, n, inhomog, pair_batched, 3, o, init_J, init_h, init_logZ, J11, J12, J22,
+    const int rc = svae_lds_estep_f64(B, T, n, inhomog, pair_batched, keep_vjp ? 3 : (S > 0 ? 1 : 0), o, init_J, init_h, init_logZ, J11, J12, J22,
                                       logZ_pair, node_J, node_h, node_logZ, lognorm, E_init, E_pair, E_node_diagxx,
                                       E_node_x, info, workspace, ws_bytes, stream);
     if (rc != 0 || S == 0 || B == 0) return rc;
@@ -493,6 +494,7 @@ extern "C" int svae_lds_inference_f64(int B, int T, int n, int S, int inhomog, i
   if (!init_h) return -7;
   if (!init_logZ) return -8;
   if (!J11 || !J12 || !J22 || !logZ_pair) return -9;
+  if (pair_batched && !inhomog) return -5;
   if (!node_J) return -13;
   if (!node_h) return -14;
   if (!lognorm) return -16;
@@ -515,15 +517,15 @@ extern "C" int svae_lds_inference_f64(int B, int T, int n, int S, int inhomog, i
   a.E_node_diagxx = E_node_diagxx; a.E_node_x = E_node_x;
   a.info = info; a.ws = (double*)workspace;        // lean records at the start of the main region
   a.ws2 = nullptr;
-  a.ws3 = (double*)workspace + main_ws_doubles(B, T, n) + factor_ws_doubles(B, T, n);   // cross moments: where the VJP looks
-  a.pair_seq_stride = 0;
+  a.ws3 = keep_vjp ? (double*)workspace + main_ws_doubles(B, T, n) + factor_ws_doubles(B, T, n) : nullptr;   // cross moments: where the VJP looks
+  a.pair_seq_stride = pair_batched ? (long)(T - 1) * n * n : 0;
   a.msg_Jp = a.msg_hp = a.msg_Jf = a.msg_hf = nullptr;
   a.mix_w = nullptr; a.mix_out = nullptr; a.seq_index = nullptr; a.mix_K = 0; a.lds_keep = 0;
   a.sig_out = nullptr;
   svae::LeanSample ls;
   ls.S = S; ls.eps = eps; ls.samples = samples;
   switch (n) {
-#define SVAE_CASE_(NN) case NN: return svae_lds_infer_lean_n##NN(&a, &ls, stream);
+#define SVAE_CASE_(NN) case NN: return svae_lds_infer_lean_n##NN(&a, &ls, inhomog, stream);
 #define SVAE_CASE(NN) SVAE_CASE_(NN)
 #ifdef SVAE_ONLY_N
     SVAE_CASE(SVAE_ONLY_N)
@@ -582,7 +584,7 @@ static int vjp_impl(int B, int T, int n, int S, int inhomog, int pair_batched, u
   a.adj = (double*)vjp_workspace;
   a.g_P = g_node_J_dense;
   if (g_node_J_dense) a.prod_max_b = 0;          /* the packed sweeps write it */
-  if ((options & SVAE_OPT_INFER_RECORDS) && lean_applies(B, T, n, S, inhomog, options)) {
+  if ((options & SVAE_OPT_INFER_RECORDS) && lean_applies(B, T, n, S, inhomog, 1, options)) {
     if (g_E_init || g_E_pair || g_node_J_dense) return -8;        /* lean records: cotangents of the node statistics, lognorm and samples */
     switch (n) {
 #define SVAE_CASE_(NN) case NN: return svae_lds_vjp_lean_n##NN(&a, stream);

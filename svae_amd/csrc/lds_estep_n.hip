@@ -68,6 +68,6 @@ extern "C" int SVAE_CAT(svae_lds_launch_filter_split_n, SVAE_N)(const svae::LdsA
 }
 
 // E-step + sampler in one launch on lean records (lds_lean_estep.hpp): homogeneous pair parameters, n <= LEAN_MAX_N
-extern "C" int SVAE_CAT(svae_lds_infer_lean_n, SVAE_N)(const svae::LdsArgs* a, const svae::LeanSample* ls, void* stream) {
-  return svae::launch_infer_lean<SVAE_N>(*a, *ls, (hipStream_t)stream);
+extern "C" int SVAE_CAT(svae_lds_infer_lean_n, SVAE_N)(const svae::LdsArgs* a, const svae::LeanSample* ls, int inhomog, void* stream) {
+  return svae::launch_infer_lean<SVAE_N>(*a, *ls, inhomog != 0, (hipStream_t)stream);
 }

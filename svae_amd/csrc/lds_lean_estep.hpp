@@ -24,7 +24,11 @@
 namespace svae {
 
 // SM: samples per sequence the instantiation holds registers for (0: no sampling; 1: the training step's S = 1; 2)
-template <int N, int SM>
+// INH: per-step pair parameters (T-1,n,n) / per-sequence (B,T-1,n,n) (a.pair_seq_stride), per-step pair statistics out --
+// the final pass of the SLDS's run_inference (slds_svae.py:289-310) on the mixed parameters of the converged mean field:
+// forward only (no cross-moment record: the VJP with statistics cotangents runs on the full records); J12_t is read a
+// second time in the backward half instead of (P^-1 J12)_t being stored and re-read.
+template <int N, int SM, bool INH = false>
 __global__ __launch_bounds__(64) void lds_infer_lean_kernel(const LdsArgs a, const LeanSample ls) {
   static_assert(N >= 1 && N <= LEAN_MAX_N, "lean records: n <= 10");
   constexpr int IL = SVAE_IL;
@@ -51,17 +55,25 @@ __global__ __launch_bounds__(64) void lds_infer_lean_kernel(const LdsArgs a, con
 
   // ---- pair parameters (info form: J = -2 natJ, J12 = -natJ12), column c per lane: as lds_estep_kernel ---------------
   double NJ12T[N], Cc[N];                   // (info-form J12 rows: re-read from L1 per step -- 20 registers)
-  static_for<0, N>([&](auto i) {
-    const double r12t = T > 1 ? a.J12[cc * N + i] : 0.0;
-    const double r22 = T > 1 ? a.J22[i * N + cc] : 0.0, r11 = T > 1 ? a.J11[i * N + cc] : 0.0;
-    NJ12T[i] = col ? r12t : 0.0;            // lane j of register k: nat J12[j][k] = -(info) J12[j][k]
-    Cc[i] = col ? -2.0 * (r22 + r11) : 0.0;
-  });
-  dpp_fence(NJ12T);
+  const double* pJ11 = a.J11 + (long)b * a.pair_seq_stride;
+  const double* pJ12 = a.J12 + (long)b * a.pair_seq_stride;
+  const double* pJ22 = a.J22 + (long)b * a.pair_seq_stride;
+  auto load_pair = [&](int t, bool with_next_J11) {   // pair t (and J11 of pair t+1): unconditional loads, selected afterwards
+    const long o = INH ? (long)t * N * N : 0;
+    const long o1 = INH ? (long)(t + 1) * N * N : 0;
+    static_for<0, N>([&](auto i) {
+      const double r12t = pJ12[o + cc * N + i], r22 = pJ22[o + i * N + cc];
+      const double r11 = with_next_J11 ? pJ11[o1 + i * N + cc] : 0.0;
+      NJ12T[i] = col ? r12t : 0.0;          // lane j of register k: nat J12[j][k] = -(info) J12[j][k]
+      Cc[i] = col ? -2.0 * (r22 + r11) : 0.0;
+    });
+  };
+  if (!INH && T > 1) { load_pair(0, true); dpp_fence(NJ12T); }
+  if (T == 1) static_for<0, N>([&](auto i) { NJ12T[i] = 0.0; Cc[i] = 0.0; });
 
   double An[N];
   static_for<0, N>([&](auto i) {
-    const double ij = a.init_J[i * N + cc], ih = a.init_h[i], j11 = T > 1 ? a.J11[i * N + cc] : 0.0;
+    const double ij = a.init_J[i * N + cc], ih = a.init_h[i], j11 = T > 1 ? pJ11[i * N + cc] : 0.0;
     An[i] = col ? -2.0 * (ij + j11) : ((c == N) ? ih : 0.0);
   });
 
@@ -99,13 +111,15 @@ __global__ __launch_bounds__(64) void lds_infer_lean_kernel(const LdsArgs a, con
       Jo_n = nJ[(long)(t + 1) * N];
       ho_n = nh[(long)(t + 1) * N];
     }
+    if (INH && !last) { load_pair(t, t + 1 < T - 1); dpp_fence(NJ12T); }
     double P[N], X[N];
     static_for<0, N>([&](auto i) { P[i] = __builtin_fma(Jo, E[i], An[i]); });
     if (last) {
       asm volatile("; last step: no pair potential, G = 0");   // keep this a branch
       static_for<0, N>([&](auto i) { X[i] = EN * An[i]; });
     } else {
-      static_for<0, N>([&](auto i) { const double r = a.J12[i * N + cc]; X[i] = __builtin_fma(EN, An[i], col ? -r : 0.0); });
+      const long o = INH ? (long)t * N * N : 0;
+      static_for<0, N>([&](auto i) { const double r = pJ12[o + i * N + cc]; X[i] = __builtin_fma(EN, An[i], col ? -r : 0.0); });
     }
     dpp_fence(ho);
     static_for<0, N>([&](auto i) { mac_bc<i>(X[i], ho, EN); });
@@ -140,9 +154,9 @@ __global__ __launch_bounds__(64) void lds_infer_lean_kernel(const LdsArgs a, con
 
     if (!last) {
       const bool next_last = (t + 1 == T - 1);
-      if (next_last) {
+      if (!INH && next_last) {
         asm volatile("; next step is the last: its pivot block has no J11 term");   // keep a branch
-        static_for<0, N>([&](auto i) { const double r = a.J22[i * N + cc]; An[i] = col ? -2.0 * r : 0.0; });
+        static_for<0, N>([&](auto i) { const double r = pJ22[i * N + cc]; An[i] = col ? -2.0 * r : 0.0; });
       } else {
         static_for<0, N>([&](auto i) { An[i] = Cc[i]; });
       }
@@ -158,9 +172,13 @@ __global__ __launch_bounds__(64) void lds_infer_lean_kernel(const LdsArgs a, con
     if (a.node_logZ) {
       for (int t = c; t < T; t += 16) z += a.node_logZ[(long)b * T + t];
     }
+    if (INH) {
+      const double* lz = a.logZ_pair + (a.pair_seq_stride ? (long)b * (T - 1) : 0);
+      for (int t = c; t < T - 1; t += 16) z += lz[t];
+    }
     double total = row_sum16(__builtin_fma(0.5, qacc * EN, z));
     total += a.init_logZ[0];
-    if (T > 1) total += (double)(T - 1) * a.logZ_pair[0];
+    if (!INH && T > 1) total += (double)(T - 1) * a.logZ_pair[0];
     total -= 0.5 * (::log(ldM) + (double)ldE * 0.6931471805599453094);
     if (valid && c == 0) a.lognorm[b] = total;
     const bool bad = !(pmin > 0.0) || !(total == total);
@@ -179,8 +197,9 @@ __global__ __launch_bounds__(64) void lds_infer_lean_kernel(const LdsArgs a, con
   static_for<0, N + 1>([&](auto i) { S_[i] = 0.0; });
   S_[N] = EN;
   dpp_fence(S_);
-  double sumA[N], sumW[N];
-  static_for<0, N>([&](auto i) { sumA[i] = 0.0; sumW[i] = 0.0; });
+  double sumA[INH ? 1 : N], sumW[INH ? 1 : N];
+  static_for<0, (INH ? 1 : N)>([&](auto i) { sumA[i] = 0.0; sumW[i] = 0.0; });
+  double* const oPair = INH ? a.E_pair + ((long)b * (T - 1)) * 3 * N * N + cc : nullptr;
   double Xs[SMAX];                              // x_{t+1}[c] per sample (lane = vector component)
   static_for<0, SMAX>([&](auto s) { Xs[s] = 0.0; });
   double M[N];                                  // M[k][c] = (c <= k): zeros of U' (lane c of register k holds U[c][k])
@@ -190,7 +209,9 @@ __global__ __launch_bounds__(64) void lds_infer_lean_kernel(const LdsArgs a, con
   const long dxx_delta = a.E_node_diagxx - a.E_node_x;               // (uniform: one per-lane pointer serves both outputs)
 
   // operands of a step, fetched one step ahead (raw: no arithmetic before their step; every load unconditional)
-  struct Ops { double Ur[N], Ut[N], cv, ep[SMAX]; };
+  struct Ops { double Ur[N], Ut[N], cv, ep[SMAX], Jt[INH ? N : 1]; };
+  const double* jp = INH ? pJ12 + (long)(T > 1 ? T - 2 : 0) * N * N + (long)cc * N : nullptr;   // J12_t[c][.] of the step's pair (t = T-1: unused)
+  int jleft = T - 2;                            // pair index the next load_ops fetches (clamped at 0)
   const unsigned lo_r = 8u * (rowoff + (unsigned)cc);                                 // row k of U: + 8 (row_off(k) - k)
   const unsigned lo_t = 8u * (rowoff + (unsigned)(lean_row_off(N, cc) - cc));         // U[c][k]:   + 8 k
   const char* rp = recs + (long)(T - 1) * (LR * 8);            // walking (uniform) record pointer: steps T-1, T-2, ..
@@ -201,14 +222,26 @@ __global__ __launch_bounds__(64) void lds_infer_lean_kernel(const LdsArgs a, con
       o.Ut[k] = *reinterpret_cast<const double*>(rp + lo_t + 8 * k);
     });
     o.cv = *reinterpret_cast<const double*>(rp + lo_r + 8 * TRI);
+    if constexpr (INH) {
+      static_for<0, N>([&](auto k) { o.Jt[k] = jp[k]; });
+    }
     if constexpr (SAMP) {
       static_for<0, SMAX>([&](auto s) { o.ep[s] = epp[(long)(s < S ? s : S - 1) * N]; });
       epp -= more * S * N;
     }
     rp -= more * (LR * 8);
   };
+  // (INH: the first record fetched is step T-1, which has no pair: it re-reads pair T-2; from then on step t reads pair t)
+  auto advance_pair = [&](int t_next) {         // called before the load_ops that fetches step t_next
+    if constexpr (INH) {
+      const int want = t_next < T - 1 ? t_next : T - 2;
+      jp += (long)((want > 0 ? want : 0) - (jleft > 0 ? jleft : 0)) * N * N;
+      jleft = want;
+    }
+  };
 
   auto step = [&](int t, Ops& cur, Ops& nxt) {
+    advance_pair(t > 0 ? t - 1 : 0);
     load_ops(nxt, t > 1 ? 1 : 0);               // unconditional prefetch of step t-1 (t = 0: re-reads record 0, unused)
     double Ut[N];
     static_for<0, N>([&](auto k) { Ut[k] = cur.Ut[k] * M[k]; });
@@ -233,9 +266,18 @@ __global__ __launch_bounds__(64) void lds_infer_lean_kernel(const LdsArgs a, con
     // H[k][c] = (P^-1 J12)[c][k] = sum_j J12[j][k] P^-1[j][c]  (k < N);  H[N] = (c', 1)
     double H[N + 1];
     static_for<0, N>([&](auto k) { H[k] = 0.0; });
-    static_for<0, N>([&](auto j) {
-      static_for<0, N>([&](auto k) { mac_bc<j, true>(H[k], NJ12T[k], Pi[j]); });
-    });
+    if constexpr (INH) {
+      double Jm[N];
+      static_for<0, N>([&](auto k) { Jm[k] = cur.Jt[k] * M[N - 1]; });           // lanes >= N: 0
+      dpp_fence(Jm);
+      static_for<0, N>([&](auto j) {
+        static_for<0, N>([&](auto k) { mac_bc<j, true>(H[k], Jm[k], Pi[j]); });
+      });
+    } else {
+      static_for<0, N>([&](auto j) {
+        static_for<0, N>([&](auto k) { mac_bc<j, true>(H[k], NJ12T[k], Pi[j]); });
+      });
+    }
     H[N] = cvm + EN;
 
     // W~ = S~_{t+1} G~'
@@ -252,7 +294,22 @@ __global__ __launch_bounds__(64) void lds_infer_lean_kernel(const LdsArgs a, con
     asm volatile("s_nop 1");   // block entry behind the conditional stores: two wait states before the DPP reads (audit rule)
     static_for<0, (N + 1 + IL - 1) / IL>([&](auto g) { rows_lane_bcast<IL, g * IL, N + 1, N>(S_, W, H); });
 
-    if (t < T - 1) static_for<0, N>([&](auto i) { sumA[i] += S_[i]; sumW[i] += W[i]; });
+    if constexpr (INH) {
+      // per-step pair blocks [E x_t x_t' | E x_t x_{t+1}' | E x_{t+1} x_{t+1}'] of pair t: S~_t completes pair t (first
+      // block) and pair t-1 (third block); W~ (t < T-1) is pair t, transposed by the addressing
+      if (st) {
+        if (t < T - 1) {
+          double* o = oPair + (long)t * 3 * N * N;
+          static_for<0, N>([&](auto i) { o[i * N] = S_[i]; });
+          double* o2 = a.E_pair + (((long)b * (T - 1) + t) * 3 + 1) * N * N + (long)cc * N;
+          static_for<0, N>([&](auto i) { o2[i] = W[i]; });
+        }
+        if (t > 0) {
+          double* o = oPair + ((long)(t - 1) * 3 + 2) * N * N;
+          static_for<0, N>([&](auto i) { o[i * N] = S_[i]; });
+        }
+      }
+    } else if (t < T - 1) static_for<0, N>([&](auto i) { sumA[i] += S_[i]; sumW[i] += W[i]; });
     else if (st) {                                                     // S~_{T-1} waits in its output slot
       double* const ep3 = a.E_pair + (long)b * 3 * N * N + 2 * N * N;
       static_for<0, N>([&](auto i) { ep3[i * N + cc] = S_[i]; });
@@ -289,7 +346,7 @@ __global__ __launch_bounds__(64) void lds_infer_lean_kernel(const LdsArgs a, con
 
   if (live) {
     Ops Ra, Rb;
-    load_ops(Ra, T > 1 ? 1 : 0);
+    load_ops(Ra, T > 1 ? 1 : 0);                // step T-1 (INH: with pair T-2, unused)
     int t = T - 1;
     for (; t >= 1; t -= 2) {          // two steps per trip: the prefetch buffers ping-pong
       step(t, Ra, Rb);
@@ -304,7 +361,7 @@ __global__ __launch_bounds__(64) void lds_infer_lean_kernel(const LdsArgs a, con
     static_for<0, N>([&](auto i) { ei[i * N + cc] = S_[i]; });   // E[x0 x0']
     ei[N * N + cc] = S_[N];                                      // E[x0]
     double* ep = a.E_pair + (long)b * 3 * N * N;
-    static_for<0, N>([&](auto i) {
+    if constexpr (!INH) static_for<0, N>([&](auto i) {
       ep[i * N + cc] = sumA[i];                               // sum_{t<T-1} E[x_t x_t']
       ep[N * N + cc * N + i] = sumW[i];                       // sum_t E[x_t x_{t+1}'] = (sum_t W_t)'
       const double sl = ep[2 * N * N + i * N + cc];
@@ -314,10 +371,15 @@ __global__ __launch_bounds__(64) void lds_infer_lean_kernel(const LdsArgs a, con
 }
 
 template <int N>
-static int launch_infer_lean(const LdsArgs& a, const LeanSample& ls, hipStream_t stream) {
+static int launch_infer_lean(const LdsArgs& a, const LeanSample& ls, bool inhomog, hipStream_t stream) {
   if constexpr (N <= LEAN_MAX_N) {
     dim3 grid((a.B + 3) / 4), block(64);
-    if (ls.S > 1) hipLaunchKernelGGL((lds_infer_lean_kernel<N, LEAN_MAX_S>), grid, block, 0, stream, a, ls);
+    if (inhomog) {
+      if (a.ws3) return -3;                     // (per-step parameters: forward only)
+      if (ls.S > 1) hipLaunchKernelGGL((lds_infer_lean_kernel<N, LEAN_MAX_S, true>), grid, block, 0, stream, a, ls);
+      else if (ls.S == 1) hipLaunchKernelGGL((lds_infer_lean_kernel<N, 1, true>), grid, block, 0, stream, a, ls);
+      else hipLaunchKernelGGL((lds_infer_lean_kernel<N, 0, true>), grid, block, 0, stream, a, ls);
+    } else if (ls.S > 1) hipLaunchKernelGGL((lds_infer_lean_kernel<N, LEAN_MAX_S>), grid, block, 0, stream, a, ls);
     else if (ls.S == 1) hipLaunchKernelGGL((lds_infer_lean_kernel<N, 1>), grid, block, 0, stream, a, ls);
     else hipLaunchKernelGGL((lds_infer_lean_kernel<N, 0>), grid, block, 0, stream, a, ls);
     return hipGetLastError() == hipSuccess ? 0 : -1000;

@@ -131,12 +131,13 @@ class LDSEStepPlan(object):
         self._pair_batched = bool(pair_batched)
 
     def infer(self, init_J, init_h, init_logZ, J11, J12, J22, logZ_pair, node_J, node_h, node_logZ=None,
-              pair_batched=False, eps=None, out=None):
+              pair_batched=False, eps=None, out=None, keep_vjp=True):
         """E-step + backward sampler in ONE call (svae_lds_inference_f64 = cython_natural_lds_inference_general,
         lds_inference.py:196-202), keeping what `vjp()` needs.  eps (B,T,S,n) or None (no sampling) -> samples or None.
         For large homogeneous batches (n <= 10, S <= 2, B > 2048, or OPT_LEAN_ON) the library keeps LEAN per-step
         records (csrc/lds_lean_estep.hpp): the same results with a fifth of the hand-off traffic; `sample()` cannot
-        follow such a launch (`self.lean`)."""
+        follow such a launch (`self.lean`).  keep_vjp=False: forward values only -- no cross-moment record, and lean
+        records then also serve per-step / per-sequence pair parameters; `vjp()` cannot follow."""
         if self.n > _lib.LDS_MAX_N:
             raise ValueError("infer(): latent dimension <= %d (the tile path runs its stages separately)" % _lib.LDS_MAX_N)
         p = _lib.ptr
@@ -150,16 +151,17 @@ class LDSEStepPlan(object):
             if out is None:
                 out = torch.empty_like(eps)
         rc = self.lib.svae_lds_inference_f64(
-            self.B, self.T, self.n, S, int(self.inhomog), int(pair_batched), self.options,
+            self.B, self.T, self.n, S, int(self.inhomog), int(pair_batched), int(bool(keep_vjp)), self.options,
             p(init_J), p(init_h), p(init_logZ), p(J11), p(J12), p(J22), p(logZ_pair),
             p(node_J), p(node_h), p(node_logZ), p(eps), p(out),
             p(self.lognorm), p(self.E_init), p(self.E_pair), p(self.E_node_diagxx), p(self.E_node_x),
             p(self.info), p(self.ws), self.ws_bytes, _lib.current_stream(self.device))
         _lib.check(rc, "svae_lds_inference_f64")
         self.epoch += 1
-        self.lean = bool(self.lib.svae_lds_inference_is_lean(self.B, self.T, self.n, S, int(self.inhomog), self.options))
-        self.has_factor = not self.lean
-        self.has_cross = True
+        self.lean = bool(self.lib.svae_lds_inference_is_lean(self.B, self.T, self.n, S, int(self.inhomog),
+                                                             int(bool(keep_vjp)), self.options))
+        self.has_factor = not self.lean and (bool(keep_vjp) or S > 0)
+        self.has_cross = bool(keep_vjp)
         self._infer_S = S
         self._J12 = J12
         self._pair_batched = bool(pair_batched)
@@ -468,7 +470,7 @@ def natural_lds_estep_general(natparam, node_params, plan=None, check=False, kee
     dev = plan.device
     if _infer_eps is not None:
         # (natural_lds_inference_general: E-step + sampler in one call -- lean records for large homogeneous batches)
-        plan._infer_samples = plan.infer(*q["args"], q["pair_batched"], _infer_eps)
+        plan._infer_samples = plan.infer(*q["args"], q["pair_batched"], _infer_eps, keep_vjp=False)
     else:
         plan.launch(*q["args"], q["pair_batched"], keep_factor)
     if check:

@@ -591,12 +591,16 @@ def optimize_local_meanfield_withlabels(global_natparam, node_potentials, labels
     return (hmm_stats, lds_stats), (None, (lds_init, lds_pair)), (torch.zeros_like(lds_vlb), lds_vlb.clone())
 
 
-def _lds_estep_batched_init(plan, lds_init, lds_pair, node, keep_factor=False, reference_compat=True):
+def _lds_estep_batched_init(plan, lds_init, lds_pair, node, keep_factor=False, reference_compat=True, eps=None,
+                            inplace=False):
     """LDS E-step with a PER-SEQUENCE init potential (the SLDS mixes K init potentials by E[z_0]):
     run the kernel with a zero shared init potential and add each sequence's (J0, h0) to its first
     node potential's dense block... the kernel's node potentials are diagonal, so instead the init
     potential is passed through the batched pair-parameter path: J11 of step 0 absorbs J0, and h0 is
-    added to node_h[:,0]; log-normaliser constants are added back on the host."""
+    added to node_h[:,0]; log-normaliser constants are added back on the host.
+    eps (B,T,S,n): E-step + backward sampler in ONE call (svae_lds_inference_f64, forward values only: lean records for
+    batches above 1024 sequences); the samples are left in plan._infer_samples.  inplace: J0 is added INTO the caller's
+    J11[:, 0] (the caller owns the per-step parameters and will not reuse them: saves a copy of (B,T-1,n,n))."""
     J0, h0, a0, b0 = lds_init                      # (B,n,n), (B,n), (B), (B)
     J11, J12, J22, lz = lds_pair                   # (B,T-1,...)
     B, T, n = node[1].shape
@@ -605,12 +609,13 @@ def _lds_estep_batched_init(plan, lds_init, lds_pair, node, keep_factor=False, r
     nh[:, 0] += h0
     zero = torch.zeros((), dtype=torch.float64, device=dev)
     if T > 1:
-        J11 = J11.clone()
+        if not (inplace and J11.is_contiguous()):
+            J11 = J11.clone()
         J11[:, 0] += J0                            # -1/2 x0' J0 x0 multiplies the same variable as J11[0]
         natparam = ((torch.zeros(n, n, dtype=torch.float64, device=dev), torch.zeros(n, dtype=torch.float64, device=dev), zero),
                     (J11.contiguous(), J12.contiguous(), J22.contiguous(), lz.contiguous()))
         lognorm, stats = natural_lds_estep_general(natparam, (nJ, nh) + tuple(node[2:]), plan=plan,
-                                                   keep_factor=keep_factor)
+                                                   keep_factor=keep_factor, _infer_eps=eps)
         return (lognorm + a0 if reference_compat else lognorm + a0 + b0), stats
     raise NotImplementedError("SLDS needs T > 1")
 
@@ -659,17 +664,25 @@ def run_inference(prior_natparam, global_natparam, nn_potentials, num_samples, i
     # (host copies of the global parameters for the prior term FIRST: made behind the kernels below, the device-to-host
     #  copies of device-resident parameters would wait for all of them and leave the host arithmetic of slds_prior_vlb,
     #  3.4 ms, for afterwards instead of next to the final pass)
-    host_params = (_slds_params_on_host(global_natparam), _slds_params_on_host(prior_natparam))
+    host_params = (_HostParamsLater(global_natparam), _HostParamsLater(prior_natparam))
     maps = global_to_local_maps(global_natparam, dev)
     (hmm_stats, _), (hmm_nat, (lds_init, lds_pair)), _, _ = optimize_local_meanfield(
         global_natparam, node, init_eps, tol, pair_stats=False, reference_compat=reference_compat, local_maps=maps)
     plan = LDSEStepPlan(B, T, n, dev, inhomog=True, pair_batched=True)
-    lognorm, (Ei, Ep, En) = _lds_estep_batched_init(plan, lds_init, lds_pair, node, keep_factor=True,
-                                                    reference_compat=reference_compat)
     S = int(num_samples)
     if eps is None:
         eps = torch.randn(B, T, S, n, dtype=torch.float64, device=dev, generator=generator)
-    samples = plan.sample(_dev64(eps, dev))
+    eps = _dev64(eps, dev)
+    if n <= _lib.LDS_MAX_N and S <= 16:
+        # final E-step + sampler in ONE call on the per-step parameters of the converged mean field (lean records above
+        # 1024 sequences: csrc/lds_lean_estep.hpp, INH), J0 added into the mixed J11 in place
+        lognorm, (Ei, Ep, En) = _lds_estep_batched_init(plan, lds_init, lds_pair, node, keep_factor=True,
+                                                        reference_compat=reference_compat, eps=eps, inplace=True)
+        samples = plan._infer_samples
+    else:
+        lognorm, (Ei, Ep, En) = _lds_estep_batched_init(plan, lds_init, lds_pair, node, keep_factor=True,
+                                                        reference_compat=reference_compat)
+        samples = plan.sample(eps)
     _, _, dense_init, dense_pair = maps
     fused = final_pass_contractions(dense_init, dense_pair, (Ei[0], Ei[1]), plan.E_pair, hmm_stats[2])
     node_hmm, pair_sums = fused if fused is not None else \
@@ -684,11 +697,54 @@ def run_inference(prior_natparam, global_natparam, nn_potentials, num_samples, i
 
 
 def _slds_params_on_host(natparam):
-    """A nested copy of SLDS global natural parameters on the host (device-resident ones: blocking device-to-host copies
-    -- to be made BEFORE the local step's kernels are queued, not behind them)."""
+    """A nested copy of SLDS global natural parameters on the host.  Host-resident parameters are used as they are; a
+    `_HostParamsLater` (device-resident ones on their way, below) is waited for here."""
+    if isinstance(natparam, _HostParamsLater):
+        return natparam.get()
     cpu = torch.device("cpu")
     (d, md), lds = natparam
     return (_dev64(d, cpu), _dev64(md, cpu)), [(_dev64(a, cpu), tuple(_dev64(y, cpu) for y in m)) for a, m in lds]
+
+
+class _HostParamsLater(object):
+    """Device-resident SLDS global parameters on their way to the host for the prior term (slds_prior_vlb is K small
+    matrices of host arithmetic): ONE device-side concatenation, ONE asynchronous copy into pinned memory and an event,
+    issued BEFORE the local step's kernels are queued -- the host goes on queueing and only waits when it needs the
+    values, by which time the copy has long landed.  (Round 5 made ~50 blocking device-to-host copies at this point:
+    0.6 ms during which nothing was queued; made behind the kernels they waited for all of them.)"""
+
+    def __init__(self, natparam):
+        (d, md), lds = natparam
+        self.leaves = [d, md] + [x for a, m in lds for x in (a,) + tuple(m)]
+        self.K = len(lds)
+        self.m_len = len(lds[0][1]) if lds else 0
+        self.pending = None
+        if all(isinstance(x, torch.Tensor) and x.is_cuda for x in self.leaves):
+            flat = torch.cat([x.detach().to(torch.float64).reshape(-1) for x in self.leaves])
+            self.host = torch.empty(flat.shape, dtype=torch.float64, device="cpu", pin_memory=True)
+            self.host.copy_(flat, non_blocking=True)
+            self.pending = torch.cuda.Event()
+            self.pending.record()
+            self._flat = flat                                   # (kept alive until the copy has completed)
+        else:
+            self.value = _slds_params_on_host(natparam)
+
+    def get(self):
+        if self.pending is not None:
+            self.pending.synchronize()
+            out, o = [], 0
+            for x in self.leaves:
+                k = x.numel()
+                out.append(self.host[o:o + k].reshape(x.shape).clone())
+                o += k
+            it = iter(out)
+            d, md = next(it), next(it)
+            lds = []
+            for _ in range(self.K):
+                a = next(it)
+                lds.append((a, tuple(next(it) for _ in range(self.m_len))))
+            self.value, self.pending, self._flat = ((d, md), lds), None, None
+        return self.value
 
 
 def slds_prior_vlb(global_natparam, prior_natparam, dev):
@@ -759,7 +815,7 @@ def run_inference_differentiable(prior_natparam, global_natparam, nn_potentials,
     B, T, n = node_d[1].shape
     if init_eps is None:
         init_eps = torch.randn(B, T, 1, n, dtype=torch.float64, device=dev, generator=generator)
-    host_params = (_slds_params_on_host(global_natparam), _slds_params_on_host(prior_natparam))
+    host_params = (_HostParamsLater(global_natparam), _HostParamsLater(prior_natparam))
     maps = global_to_local_maps(global_natparam, dev)
     (hmm_stats, _), (hmm_nat, lds_nat), _, _ = optimize_local_meanfield(
         global_natparam, node_d, init_eps, tol, pair_stats=False, reference_compat=reference_compat, local_maps=maps)

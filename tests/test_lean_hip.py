@@ -71,7 +71,7 @@ def test_lean_path_against_reference_compiled_code(n, T, B, S, with_samples):
             want_s[b] = smp
     plan = _plan(B, T, n, lean=True)
     lean = (not with_samples) or S <= 2            # at most two samples are drawn inside the smoother's loop
-    assert plan.lib.svae_lds_inference_is_lean(B, T, n, S if with_samples else 0, 0, plan.options) == int(lean)
+    assert plan.lib.svae_lds_inference_is_lean(B, T, n, S if with_samples else 0, 0, 1, plan.options) == int(lean)
     nJ, nh, nz = (t(x).requires_grad_(True) for x in node)
     lognorm, (dxx, ex), samples, (E_init, E_pair) = lds_inference_differentiable(
         (tuple(t(x) for x in init), tuple(t(x) for x in pair)), (nJ, nh, nz),
@@ -214,3 +214,62 @@ def test_lean_training_step_replays_as_one_hip_graph():
     torch.cuda.synchronize()
     for a, b in zip([smp, gJ, gh, plan.lognorm], ref_out):
         assert torch.equal(a, b)
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("n,T,B,S,batched", [(10, 30, 5, 1, True), (4, 9, 7, 2, False), (7, 2, 3, 1, True), (10, 3, 6, 0, True),
+                                             (3, 17, 9, 1, True)])
+def test_lean_forward_only_with_per_step_pair_parameters(n, T, B, S, batched):
+    """keep_vjp = 0 (forward values only): lean records also serve per-step (T-1,n,n) and per-sequence (B,T-1,n,n) pair
+    parameters -- the final pass of the SLDS's run_inference (slds_svae.py:289-310).  Against the reference's compiled
+    E-step and sampler on every sequence (per-step pair parameters: cython_lds_inference.pyx:17-26, 73; 1e-6, north_star
+    asks 1e-5) and against the full-record kernels of this library."""
+    from svae_amd import _lib
+    from svae_amd.lds.lds_inference import LDSEStepPlan
+    from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials
+    rng = np.random.default_rng(13 * n + T + B)
+    init = rand_lds_natparam(n, rng)[0]
+    sets = B if batched else 1
+    pairs = [[rand_lds_natparam(n, rng)[1] for _ in range(T - 1)] for _ in range(sets)]
+    pk = [np.stack([np.stack([np.asarray(p[i], float) for p in seq]) for seq in pairs]) for i in range(4)]   # (sets,T-1,..)
+    node = rand_node_potentials((B, T, n), rng, with_logZ=True)
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev).contiguous()
+    pd = [t(x if batched else x[0]) for x in pk]
+    args = [t(init[0]), t(init[1]), t(init[2]).reshape(1), pd[0], pd[1], pd[2], pd[3].reshape(-1),
+            t(node[0]), t(node[1]), t(node[2])]
+    eps_np = np.zeros((B, T, max(S, 1), n))
+    want = []
+    for b in range(B):
+        pb = tuple(x[b if batched else 0] for x in pk)
+        nb = tuple(x[b] for x in node)
+        ln, stats = ref.estep((init, pb), nb)
+        smp = None
+        if S:
+            smp, e = ref.sample_backward((init, pb), nb, S, seed=50 + b)
+            eps_np[b] = e
+        want.append((ln, stats, smp))
+    eps = t(eps_np) if S else None
+    out = {}
+    for name, opt in (("lean", _lib.OPT_LEAN_ON), ("full", _lib.OPT_LEAN_OFF)):
+        plan = LDSEStepPlan(B, T, n, dev, inhomog=True, pair_batched=batched, options=opt)
+        smp = plan.infer(*args, batched, eps, keep_vjp=False)
+        assert plan.lean == (name == "lean")
+        plan.check_info()
+        out[name] = [x.clone() for x in (plan.lognorm, plan.E_init, plan.E_pair, plan.E_node_diagxx, plan.E_node_x)] \
+            + ([smp.clone()] if S else [])
+        if name == "lean":
+            with pytest.raises(RuntimeError):
+                plan.vjp(torch.zeros(B, dtype=torch.float64, device=dev))
+    for a, b_ in zip(out["lean"], out["full"]):
+        assert _rel(a, b_.cpu().numpy()) < 1e-7      # (a fresh random pair per step: conditioning noise ~1e-8, as between the reference and either)
+    lognorm, E_init, E_pair, dxx, ex = out["lean"][:5]
+    for b in range(B):
+        ln, (oi, op, on), smp = want[b]
+        assert _rel(lognorm[b], ln) < 1e-6
+        assert _rel(E_init[b, :n * n].reshape(n, n), oi[0]) < 1e-6 and _rel(E_init[b, n * n:], oi[1]) < 1e-6
+        for i in range(3):
+            assert _rel(E_pair[b, :, i], np.asarray(op[i])) < 1e-6, "E_pair[%d]" % i
+        assert _rel(dxx[b], on[0]) < 1e-6 and _rel(ex[b], on[1]) < 1e-6
+        if S:
+            assert _rel(out["lean"][5][b], smp) < 1e-6, "samples"

@@ -656,3 +656,30 @@ def test_one_sequence_consumer_sweep_every_latent_dim_against_the_table_kernel(K
             for a, b in zip(out["default"], out["tables"]):
                 rel = float((a - b).abs().max()) / (float(b.abs().max()) + 1e-300)
                 assert rel < 1e-10, "K=%d n=%d T=%d: %.2e" % (K, n, T, rel)
+
+
+def test_run_inference_final_pass_on_lean_records_equals_the_full_record_path():
+    """Above 1024 sequences the final pass of run_inference (slds_svae.py:289-310: LDS E-step on the per-step parameters of the
+    converged mean field + backward sampler) runs as ONE launch on lean per-step records (csrc/lds_lean_estep.hpp, INH);
+    SVAE_OPT_LEAN_OFF sends it through the full-record E-step + sampler kernels: same samples, statistics and bounds."""
+    from svae_amd import _lib
+    from svae_amd.lds.lds_inference import set_default_options
+    from svae_amd.models import slds_svae
+    K, n, T, B = 4, 6, 12, 1100
+    rng = np.random.default_rng(77)
+    glob, prior = _globals(K, n, rng), _globals(K, n, rng)
+    J, h = _nodes(B, T, n, rng)
+    dev = torch.device("cuda:0")
+    node = (torch.as_tensor(J, device=dev), torch.as_tensor(h, device=dev))
+    init_eps = torch.as_tensor(rng.standard_normal((B, T, 1, n)), device=dev)
+    eps = torch.as_tensor(rng.standard_normal((B, T, 1, n)), device=dev)
+    outs = []
+    for opt in (_lib.OPT_DEFAULT, _lib.OPT_LEAN_OFF):
+        old = set_default_options(opt)
+        try:
+            samples, (hmm_g, (g_init, g_pair)), gv, lv = slds_svae.run_inference(prior, glob, node, 1, init_eps=init_eps, eps=eps)
+        finally:
+            set_default_options(old)
+        outs.append([samples, hmm_g[0], hmm_g[1], g_init[0], g_init[1], g_pair[0], g_pair[1], g_pair[2], lv.reshape(1), gv.reshape(1)])
+    for a, b in zip(*outs):
+        assert _err(a, _np(b)) < 1e-9
