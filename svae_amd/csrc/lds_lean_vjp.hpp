@@ -147,6 +147,7 @@ __global__ __launch_bounds__(64) void lds_vjp_sweep1_lean_kernel(const VjpArgs a
       // index are ever broadcast),  Lh from E' = sum_s eps_s z_s',  z = U' xhat
       double z[N], ET[N];
       static_for<0, N>([&](auto j) { z[j] = 0.0; ET[j] = 0.0; });
+      asm volatile("s_nop 1");     // block entry behind the sample loop: two wait states before the DPP reads (audit rule; n = 1)
       static_for<0, N>([&](auto i) {
         constexpr int ii = decltype(i)::value;
         static_for<ii, N>([&](auto j) { mac_bc<j>(z[j], Ur[ii], xh[ii]); });

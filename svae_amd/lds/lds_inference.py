@@ -130,6 +130,18 @@ class LDSEStepPlan(object):
         self._J12 = J12
         self._pair_batched = bool(pair_batched)
 
+    def fresh_outputs(self):
+        """New output tensors for the next launch (lognorm, E_init, E_pair, E_node_*): a caller that hands the outputs on
+        -- the autograd node below -- returns them as they are instead of copying them out of buffers the next launch
+        would overwrite (two of them are (B,T,n): 2 x 65 MB at 4096 x 200 x 10)."""
+        f64 = dict(dtype=torch.float64, device=self.device)
+        B, T, n = self.B, self.T, self.n
+        self.lognorm = torch.empty(B, **f64)
+        self.E_init = torch.empty(B, n * n + n, **f64)
+        self.E_pair = torch.empty(B, max(T - 1, 0), 3, n, n, **f64) if self.inhomog else torch.empty(B, 3, n, n, **f64)
+        self.E_node_diagxx = torch.empty(B, T, n, **f64)
+        self.E_node_x = torch.empty(B, T, n, **f64)
+
     def infer(self, init_J, init_h, init_logZ, J11, J12, J22, logZ_pair, node_J, node_h, node_logZ=None,
               pair_batched=False, eps=None, out=None, keep_vjp=True):
         """E-step + backward sampler in ONE call (svae_lds_inference_f64 = cython_natural_lds_inference_general,
@@ -681,6 +693,7 @@ class _LDSInference(torch.autograd.Function):
     @staticmethod
     def forward(ctx, node_J, node_h, node_logZ, eps, plan, params, pair_batched):
         init_J, init_h, init_logZ, J11, J12, J22, logZ_pair = params
+        plan.fresh_outputs()                    # (the outputs are handed to autograd as they are: no copies out of plan buffers)
         if eps is None or eps.shape[2] <= 16:
             # one call: E-step + sampler (lean per-step records for large homogeneous batches)
             samples = plan.infer(init_J, init_h, init_logZ, J11, J12, J22, logZ_pair, node_J, node_h, node_logZ,
@@ -695,11 +708,10 @@ class _LDSInference(torch.autograd.Function):
         ctx.epoch = plan.epoch
         ctx.set_materialize_grads(False)       # an output nobody differentiated arrives as None, not as zeros
         ctx.save_for_backward(eps if eps is not None else samples, samples)
-        E_init, E_pair = plan.E_init.clone(), plan.E_pair.clone()
+        E_init, E_pair = plan.E_init, plan.E_pair
         if not plan.inhomog:
             ctx.mark_non_differentiable(E_init, E_pair)
-        return (plan.lognorm.clone(), plan.E_node_diagxx.clone(), plan.E_node_x.clone(), samples,
-                E_init, E_pair)
+        return (plan.lognorm, plan.E_node_diagxx, plan.E_node_x, samples, E_init, E_pair)
 
     @staticmethod
     def backward(ctx, g_lognorm, g_dxx, g_x, g_samples, g_init, g_pair):
