@@ -11,6 +11,9 @@ for N in 2 8; do
      bench.py --gpus $N --steps 20 --warmup 3 > gpurun_out/r6_final/bench_gloo_${N}ranks_1gpu.json 2> gpurun_out/r6_final/bench_gloo_${N}ranks_1gpu.err
   echo "rehearsal N=$N rc=$? $(tail -c 300 gpurun_out/r6_final/bench_gloo_${N}ranks_1gpu.json | head -c 200)"
 done
+# round 6: `python bench.py --gpus 2` WITHOUT a launcher must bring up its own two ranks (gloo: one GPU on this box)
+SVAE_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 20 --warmup 3 --no-extra --no-cpu-baseline > gpurun_out/r6_final/bench_selflaunch_2ranks_1gpu.json 2> gpurun_out/r6_final/bench_selflaunch_2ranks_1gpu.err
+echo "self-launch N=2 rc=$? $(tail -c 400 gpurun_out/r6_final/bench_selflaunch_2ranks_1gpu.json | head -c 300)"
 timeout 900 bash tools/first_contact_8gpu.sh > gpurun_out/r6_final/first_contact.log 2>&1; echo "first contact rc=$?"; tail -6 gpurun_out/r6_final/first_contact.log
 timeout 900 python bench.py > gpurun_out/r6_final/bench.json 2> gpurun_out/r6_final/bench.err; echo "bench rc=$?"
 python - <<'PY'
