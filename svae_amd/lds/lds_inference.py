@@ -693,7 +693,14 @@ class _LDSInference(torch.autograd.Function):
     @staticmethod
     def forward(ctx, node_J, node_h, node_logZ, eps, plan, params, pair_batched):
         init_J, init_h, init_logZ, J11, J12, J22, logZ_pair = params
-        plan.fresh_outputs()                    # (the outputs are handed to autograd as they are: no copies out of plan buffers)
+        # Large batches, eager: the launch writes into FRESH output tensors that are handed to autograd as they are (the
+        # copies out of the plan's buffers are 0.3 ms of a 3 ms step at 4096 x 200 x 10).  Small batches and anything
+        # under stream capture keep the copies: a captured step must write into buffers that outlive the capture, and
+        # replacing the plan's buffers inside a capture of the whole make_gradfun step crashed hipStreamEndCapture
+        # (ROCm 7.2; bench.py extra[9]) -- there the copies are a few microseconds.
+        _copy_out = plan.B <= 1024 or torch.cuda.is_current_stream_capturing()
+        if not _copy_out:
+            plan.fresh_outputs()
         if eps is None or eps.shape[2] <= 16:
             # one call: E-step + sampler (lean per-step records for large homogeneous batches)
             samples = plan.infer(init_J, init_h, init_logZ, J11, J12, J22, logZ_pair, node_J, node_h, node_logZ,
@@ -709,8 +716,12 @@ class _LDSInference(torch.autograd.Function):
         ctx.set_materialize_grads(False)       # an output nobody differentiated arrives as None, not as zeros
         ctx.save_for_backward(eps if eps is not None else samples, samples)
         E_init, E_pair = plan.E_init, plan.E_pair
+        if _copy_out:
+            E_init, E_pair = E_init.clone(), E_pair.clone()
         if not plan.inhomog:
             ctx.mark_non_differentiable(E_init, E_pair)
+        if _copy_out:
+            return (plan.lognorm.clone(), plan.E_node_diagxx.clone(), plan.E_node_x.clone(), samples, E_init, E_pair)
         return (plan.lognorm, plan.E_node_diagxx, plan.E_node_x, samples, E_init, E_pair)
 
     @staticmethod
