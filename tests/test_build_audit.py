@@ -48,8 +48,11 @@ def test_generated_gauss_jordan_header_is_what_the_generator_emits():
 
 
 _ESTEP_NS = [2, 10, 12, 15]
-_OTHER_UNITS = [("lds_vjp_n.hip", 10, 3000), ("lds_estep_tile.hip", None, 2000), ("hmm_estep.hip", None, 200),
-                ("lds_chol_tile.hip", None, 2000)]
+# (lds_vjp_n.hip at n = 1: the smallest instantiation -- round 6's `make audit` found a block-entry rule there, in the lean
+#  sweep, that n = 10 does not show: the zero-initialisations that separate a branch join from the first DPP read at
+#  n = 10 are a single instruction at n = 1)
+_OTHER_UNITS = [("lds_vjp_n.hip", 10, 3000), ("lds_vjp_n.hip", 1, 100), ("lds_estep_tile.hip", None, 2000),
+                ("hmm_estep.hip", None, 200), ("lds_chol_tile.hip", None, 2000)]
 
 
 @pytest.fixture(scope="session")
