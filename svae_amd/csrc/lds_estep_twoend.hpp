@@ -826,9 +826,16 @@ __device__ __forceinline__ void lds_estep_twoend_body(const LdsArgs& a, const in
         });
       }
       // transposed, replicated copy through LDS: H[k][lane c] = G~[c][k]
+      // Lanes > N (zeros) store into their OWN row's padding column N + 1 (RSL >= N + 2).  At column c they would land in
+      // the rows behind (row i, lane c >= RSL = row i + 1, column c - RSL), correct only while those rows' own stores come
+      // later -- and per lane the J1 addresses differ, so the compiler may order them as it likes.  (Round 5's "n = 4
+      // only" failure of the ring consumer's two-steps-per-trip loop was exactly that: hipcc scheduled the store of rows
+      // 4 / 5 ahead of rows 0 .. 3, lane 10 of row 3 zeroed e_N[N], and the mean was gone from the second step on.  Found
+      // round 6 by dumping registers from patched ISA: docs/experiments/r6_ring_two_per_trip_reproducer.md.)
       double* tb = tab + dir * 16 * RSL;
+      const int cw = c <= N ? c : N + 1;
       __builtin_amdgcn_wave_barrier();
-      static_for<0, J1>([&](auto j) { tb[(2 * j + gl) * RSL + c] = Gc[j]; });
+      static_for<0, J1>([&](auto j) { tb[(2 * j + gl) * RSL + cw] = Gc[j]; });
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -995,11 +1002,13 @@ __device__ __forceinline__ void lds_estep_twoend_body(const LdsArgs& a, const in
     step(std::integral_constant<int, 1>{}, e, A, Bq);
     step(std::integral_constant<int, 2>{}, e - 1, Bq, A);
     int s = e - 2;
-    if constexpr (RING) {
-      // one step per trip, the stage copied.  (The two-steps-per-trip form below gave WRONG results from the second call
-      // site on for N = 4, and only N = 4, in this instantiation -- every other N, the same body without RING, and the
-      // row-per-chain consumer with the same structure are right; hipcc 7.2, not understood.  tools/slds_rpc_debug.py
-      // --sweep runs every N against the table kernel.)
+#ifndef SVAE_RING_TWO_PER_TRIP
+#define SVAE_RING_TWO_PER_TRIP 0      // 1: the ring consumer with the two-steps-per-trip loop as well (`make ring2`: the regression build)
+#endif
+    if constexpr (RING && !SVAE_RING_TWO_PER_TRIP) {
+      // one step per trip, the stage copied: same speed as two per trip here (0.51 ms at T = 500), half the code.  (Round 5
+      // chose it because the other form was WRONG at N = 4: the transposition-tile stores above, not the loop -- fixed in
+      // round 6; tests/test_slds_hip.py runs the two-per-trip build of N = 4 against the table kernel.)
       for (; s >= 1; --s) { step(GEN, s, A, Bq); A = Bq; }
     } else {
       for (; s >= 2; s -= 2) {          // two steps per trip: the prefetch buffers ping-pong

@@ -77,6 +77,7 @@ __device__ __forceinline__ void te_smooth4(const LdsArgs& a, const int b, const 
   const int c = lane & 15, r = lane >> 4;
   const bool col = c < N;
   const int cc = col ? c : 0;
+  const int cw = c <= N ? c : N + 1;      // column of this lane's transposition-tile stores
   const int T = a.T;
   const int e = te_elims(T);
   const bool oddT = (T & 1) != 0;
@@ -174,7 +175,8 @@ __device__ __forceinline__ void te_smooth4(const LdsArgs& a, const int b, const 
     }
     static_for<0, J1>([&](auto j) { p.PiZ[j] = __builtin_fma(-EN, pi.Pi[j], pi.Pi[j]); });
     __builtin_amdgcn_wave_barrier();
-    static_for<0, J1>([&](auto j) { tabw[(4 * j + r) * RSL + c] = p.Gc[j]; });
+    // (lanes > N: the row's padding column, see lds_estep_twoend.hpp -- a store at column c would land in the next rows)
+    static_for<0, J1>([&](auto j) { tabw[(4 * j + r) * RSL + cw] = p.Gc[j]; });
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

@@ -118,10 +118,10 @@ VALIDATED_HIPCC = "7.2.26015"     # HIP version the GPU suite (incl. the n = 1..
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 def test_toolchain_is_the_one_the_kernels_were_validated_with():
-    """Several kernels depend on what hipcc does around inline-asm DPP statements, and one (slds_meanfield_seq_kernel,
-    csrc/lds_estep_twoend.hpp) ships a loop form chosen because another was miscompiled or mis-scheduled at n = 4 with
-    THIS compiler.  A different hipcc is not an error of the product, but it voids that evidence: this
-    test fails until somebody has re-run `pytest -m gpu` (which includes the every-n sweep against the table kernel,
-    tests/test_slds_hip.py) and `make audit` with the new toolchain and updated VALIDATED_HIPCC."""
+    """Several kernels depend on what hipcc does around inline-asm DPP statements (hazards it cannot pad: `make audit`), and
+    round 5's "wrong at n = 4 only" finding turned out to hinge on the ORDER hipcc gives independent LDS stores (fixed in
+    round 6 by making the order irrelevant, csrc/lds_estep_twoend.hpp).  A different hipcc is not an error of the product, but
+    it voids that evidence: this test fails until somebody has re-run `pytest -m gpu` (the every-n sweep and the ring2
+    regression build, tests/test_slds_hip.py) and `make audit` with the new toolchain and updated VALIDATED_HIPCC."""
     out = subprocess.run([HIPCC, "--version"], capture_output=True, text=True).stdout
     assert "HIP version: " + VALIDATED_HIPCC in out, out[:300]

@@ -619,14 +619,9 @@ def test_final_pass_contractions_against_the_two_library_forms(K, n, T, B):
     assert slds_svae.final_pass_contractions(dense_init, dense_pair, init_stats, E_pair.cpu(), Es) is None
 
 
-@pytest.mark.parametrize("K", [1, 3, 8])
-def test_one_sequence_consumer_sweep_every_latent_dim_against_the_table_kernel(K):
-    """The default SLDS mean-field step for small launches (slds_meanfield_seq_kernel: one-sequence consumer + three
-    producer wavefronts) carries a workaround for a loop form that was wrong at n = 4 only (csrc/lds_estep_twoend.hpp,
-    "one step per trip"; cause not pinned: suspected compiler scheduling).  Until it is explained this sweep runs on
-    every GPU test pass: EVERY latent dimension 1..10, odd and even T, against the table kernel (a different
-    consumer, no ring, no producers), so that a toolchain change that re-opens it cannot pass silently
-    (tests/test_build_audit.py pins the hipcc version the sweep was last green on)."""
+def _consumer_sweep(K, ns=range(1, 11), Ts=(9, 12, 4)):
+    """default dispatch (one-sequence ring consumer + producer wavefronts for small launches) against the table kernel (a
+    different consumer: no ring, no producers); returns the worst relative distance and its case"""
     from svae_amd import _lib
     from svae_amd.models import slds_svae
     from svae_amd.lds.synthetic_data import rand_slds_global_natparam
@@ -634,8 +629,9 @@ def test_one_sequence_consumer_sweep_every_latent_dim_against_the_table_kernel(K
     B = 5
     d = lambda x: tuple(d(y) for y in x) if isinstance(x, (tuple, list)) else \
         torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev)
-    for n in range(1, 11):
-        for T in (9, 12, 4):
+    worst = (0.0, None)
+    for n in ns:
+        for T in Ts:
             rng = np.random.default_rng(100 * K + 10 * n + T)
             glob = rand_slds_global_natparam(K, n, rng)
             _, _, dense_init, dense_pair = slds_svae.global_to_local_maps(d(glob), dev)
@@ -655,7 +651,43 @@ def test_one_sequence_consumer_sweep_every_latent_dim_against_the_table_kernel(K
                                                  plan.hmm_nodeparams(dense_init, dense_pair))]
             for a, b in zip(out["default"], out["tables"]):
                 rel = float((a - b).abs().max()) / (float(b.abs().max()) + 1e-300)
-                assert rel < 1e-10, "K=%d n=%d T=%d: %.2e" % (K, n, T, rel)
+                if rel > worst[0]:
+                    worst = (rel, "K=%d n=%d T=%d" % (K, n, T))
+    return worst
+
+
+@pytest.mark.parametrize("K", [1, 3, 8])
+def test_one_sequence_consumer_sweep_every_latent_dim_against_the_table_kernel(K):
+    """The default SLDS mean-field step for small launches (slds_meanfield_seq_kernel: one-sequence consumer + three
+    producer wavefronts): EVERY latent dimension 1..10, odd and even T, against the table kernel.  Round 5 shipped the
+    consumer with a loop form chosen because the natural one was wrong at n = 4 only, cause unknown; round 6 found the
+    cause (order-dependent transposition-tile stores, csrc/lds_estep_twoend.hpp) and fixed it -- the sweep stays, and
+    test_ring_consumer_two_steps_per_trip_build_at_n4 runs the loop form that exposed it."""
+    rel, case = _consumer_sweep(K)
+    assert rel < 1e-10, "%s: %.2e" % (case, rel)
+
+
+def test_ring_consumer_two_steps_per_trip_build_at_n4():
+    """Regression build for the round-5 "wrong at n = 4 only" finding (docs/experiments/
+    r6_ring_two_per_trip_reproducer.md): tests/_variants/libsvae_hip_ring2.so (`make ring2`, made by __graft_entry__.build())
+    is the library with the n = 4 unit's ring consumer in its two-steps-per-trip loop form.  With the transposition-tile
+    stores as they were (every lane at its own column, lanes >= the row stride landing in the rows behind) hipcc
+    scheduled the last rows' store first and the mean was lost from the loop's second step on: x wrong by O(1).  With the
+    stores confined to their own rows the build must agree with the table kernel like the shipped one."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    variant = os.path.join(root, "tests", "_variants", "libsvae_hip_ring2.so")
+    if not os.path.exists(variant):
+        pytest.skip("tests/_variants/libsvae_hip_ring2.so not built (python __graft_entry__.py)")
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_slds_hip as m; "
+            "from svae_amd import _lib; assert _lib.LIB_PATH.endswith('libsvae_hip_ring2.so'), _lib.LIB_PATH; "
+            "w = max(m._consumer_sweep(K, ns=(4,), Ts=(9, 12, 13, 20, 4)) for K in (1, 3, 8)); print('WORST', w[0], w[1]); "
+            "assert w[0] < 1e-10, w" % (root, os.path.join(root, "tests")))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SVAE_AMD_LIB=variant), timeout=900,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_run_inference_final_pass_on_lean_records_equals_the_full_record_path():
