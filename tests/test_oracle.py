@@ -281,3 +281,17 @@ def test_oracle_dense_node_potentials_against_the_reference_python_path(name, go
             np.testing.assert_allclose(x, g[k][b], rtol=0, atol=1e-11)
         np.testing.assert_allclose(En[0], g["Enode_xx"][b], rtol=0, atol=1e-11)
         np.testing.assert_allclose(En[1], g["Enode_x"][b], rtol=0, atol=1e-11)
+
+
+def test_the_60_digit_arbiter_agrees_with_the_restatement_on_a_well_conditioned_model():
+    """oracle/lds_mp.py (block-tridiagonal solve in 60 digits: the arbiter of the conditioning tests) against
+    oracle/lds_numpy.py (the restatement of svae/lds/lds_inference.py:127-178, pinned above) where both are exact to fp64."""
+    from oracle import lds_numpy
+    from oracle.lds_mp import smoothed_means_mp
+    from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials
+    rng = np.random.default_rng(0)
+    n, T = 4, 9
+    init, pair = rand_lds_natparam(n, rng)
+    node = rand_node_potentials((1, T, n), rng, with_logZ=True)
+    _, (_, _, En) = lds_numpy.natural_lds_estep_general((init, pair), tuple(x[0] for x in node))
+    assert np.max(np.abs(np.asarray(En[1]) - smoothed_means_mp(init, pair, node[0][0], node[1][0]))) < 1e-13

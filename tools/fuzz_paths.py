@@ -1,0 +1,73 @@
+"""Random shapes through the parametrised GPU parity tests of the n <= 15 paths (E-step / sampler / filter / VJPs against the
+reference's compiled code, lean against full records, HMM two-ended and wide kernels, the SLDS consumer against the table
+kernel): the shapes the fixed parametrisations do not list.  Usage: python tools/fuzz_paths.py [seconds] [seed]"""
+import os, sys, time, traceback
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import pytest  # noqa: E402
+import test_lds_hip as tl, test_vjp_hip as tv, test_lean_hip as tn, test_hmm_hip as th, test_slds_hip as ts  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+ri = lambda a, b: int(rng.integers(a, b + 1))
+un = lambda f: getattr(f, "__wrapped__", f)
+
+
+def draw():
+    kind = ri(0, 9)
+    if kind == 0:
+        return "vjp_ref", un(tv.test_vjp_against_reference_compiled_vjps), (ri(1, 15), ri(1, 60), ri(1, 9), ri(1, 4), bool(ri(0, 1)))
+    if kind == 1:
+        return "vjp_inh", un(tv.test_vjp_inhomogeneous_with_statistics_cotangents), (ri(1, 15), ri(2, 40), ri(1, 6), ri(1, 3), bool(ri(0, 1)), bool(ri(0, 1)))
+    if kind == 2:
+        return "vjp_hom_sums", un(tv.test_vjp_homogeneous_summed_pair_statistics_cotangents), (ri(1, 15), ri(2, 40), ri(1, 6), ri(1, 3), bool(ri(0, 1)))
+    if kind == 3:
+        return "lean_vs_full", un(tn.test_lean_and_full_records_agree), (ri(1, 10), ri(2, 120), ri(1, 70), ri(1, 2), bool(ri(0, 1)))
+    if kind == 4:
+        return "lean_inh", un(tn.test_lean_forward_only_with_per_step_pair_parameters), (ri(1, 10), ri(2, 60), ri(1, 12), ri(0, 2), bool(ri(0, 1)))
+    if kind == 5:
+        return "sampler", un(tl.test_sampler_against_oracle), (ri(1, 15), ri(1, 40), ri(1, 20))
+    if kind == 6:
+        return "filter_msgs", un(tl.test_filter_messages_against_reference_build), (ri(1, 15), ri(1, 60), bool(ri(0, 1)))
+    if kind == 7:
+        return "smoother_on_msgs", un(tl.test_smoother_and_sampler_on_caller_supplied_messages), (ri(1, 15), ri(1, 60), bool(ri(0, 1)))
+    if kind == 8:
+        K = ri(1, 64)
+        f = th.test_hmm_estep_against_oracle_and_reference if K <= 16 else th.test_hmm_wide_kernel_against_oracle_and_reference
+        return "hmm", un(f), (ri(1, 40), ri(1, 300), K, float(rng.choice([1.0, 3.0, 10.0])))
+    return "slds_consumer", None, (ri(1, 8), ri(1, 10), ri(4, 90))
+
+
+# every module's _rel records what it measured, so that a failure can say by how much
+seen = []
+for m in (tl, tv, tn, th, ts):
+    if hasattr(m, "_rel"):
+        def wrap(f):
+            def g(*a, **k):
+                v = f(*a, **k)
+                seen.append(float(v))
+                return v
+            return g
+        m._rel = wrap(m._rel)
+
+t0, done, bad, worst = time.time(), {}, 0, {}
+while time.time() - t0 < budget:
+    name, fn, args = draw()
+    del seen[:]
+    try:
+        if fn is None:
+            rel, case = ts._consumer_sweep(args[0], ns=(args[1],), Ts=(args[2],))
+            assert rel < 1e-10, (case, rel)
+        else:
+            fn(*args)
+    except pytest.skip.Exception:
+        continue
+    except Exception:
+        bad += 1
+        big = max(seen) if seen else float("nan")
+        worst[name] = max(worst.get(name, 0.0), big)
+        print("FAIL %s %s  largest distance measured in the call: %.2e  (%s)" % (name, args, big, traceback.format_exc(limit=3).strip().splitlines()[-2].strip()[:110]), flush=True)
+    done[name] = done.get(name, 0) + 1
+print("cases", done, "failures", bad, "worst distance among failures", worst)
+sys.exit(1 if bad else 0)
