@@ -1,20 +1,45 @@
 """Random shapes through the parametrised GPU parity tests of the n <= 15 paths (E-step / sampler / filter / VJPs against the
 reference's compiled code, lean against full records, HMM two-ended and wide kernels, the SLDS consumer against the table
-kernel): the shapes the fixed parametrisations do not list.  Usage: python tools/fuzz_paths.py [seconds] [seed]"""
+kernel): the shapes the fixed parametrisations do not list.  Usage: python tools/fuzz_paths.py [seconds] [seed] [a|b]   (b: GMM, latent dimension 16 .. 64, dense node potentials)"""
 import os, sys, time, traceback
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import pytest  # noqa: E402
 import test_lds_hip as tl, test_vjp_hip as tv, test_lean_hip as tn, test_hmm_hip as th, test_slds_hip as ts  # noqa: E402
+import test_gmm_hip as tg, test_lds_tile_hip as tt, test_lds_dense_hip as td  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+group = sys.argv[3] if len(sys.argv) > 3 else "a"
 ri = lambda a, b: int(rng.integers(a, b + 1))
 un = lambda f: getattr(f, "__wrapped__", f)
 
 
+def draw_b():
+    kind = ri(0, 8)
+    if kind == 0:
+        return "gmm", un(tg.test_against_oracle), (ri(1, 3000), ri(1, 8), ri(1, 64), bool(ri(0, 1)))
+    if kind == 1:
+        return "gmm_global", un(tg.test_global_step_kernel_against_the_torch_maps), (ri(1, 64), ri(1, 8))
+    if kind == 2:
+        return "tile_oracle", un(tt.test_tile_estep_matches_oracle), (ri(16, 64), ri(1, 12))
+    if kind == 3:
+        return "tile_inh", un(tt.test_tile_estep_inhomogeneous_batched_pairs), (ri(16, 64), ri(2, 10), ri(1, 4))
+    if kind == 4:
+        return "tile_vjp_torch", un(tt.test_tile_vjp_kernels_match_the_torch_adjoint), (ri(16, 64), ri(1, 8), ri(1, 3), ri(0, 3), str(rng.choice(["homog", "inhomog", "batched"])))
+    if kind == 5:
+        return "tile_halves", un(tt.test_tile_estep_halves_equal_the_whole), (ri(16, 64), ri(1, 14), ri(1, 4))
+    if kind == 6:
+        return "tile_2wg", un(tt.test_tile_estep_two_workgroups_per_cu_instances), (ri(16, 64), ri(1, 8), bool(ri(0, 1)))
+    if kind == 7:
+        return "dense", un(td.test_dense_estep_filter_and_sampler_against_the_oracle), (ri(1, 15), ri(1, 40), ri(1, 6), bool(ri(0, 1)))
+    return "dense_grad", un(td.test_gradients_through_dense_node_potentials), (ri(1, 10), ri(2, 14), ri(1, 3), ri(1, 2), bool(ri(0, 1)))
+
+
 def draw():
+    if group == "b":
+        return draw_b()
     kind = ri(0, 9)
     if kind == 0:
         return "vjp_ref", un(tv.test_vjp_against_reference_compiled_vjps), (ri(1, 15), ri(1, 60), ri(1, 9), ri(1, 4), bool(ri(0, 1)))
@@ -41,7 +66,7 @@ def draw():
 
 # every module's _rel records what it measured, so that a failure can say by how much
 seen = []
-for m in (tl, tv, tn, th, ts):
+for m in (tl, tv, tn, th, ts, tg, tt, td):
     if hasattr(m, "_rel"):
         def wrap(f):
             def g(*a, **k):
