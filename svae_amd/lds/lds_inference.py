@@ -53,6 +53,22 @@ def set_default_options(options):
     return old
 
 
+def set_accurate_smoother(on=True):
+    """Plans created without an explicit `options` word take the kernels whose smoothed moments (and the gradients through
+    them) are accurate to cond * eps, like the reference's factor-and-solve, when `on`:
+      * E-step: FULL per-step hand-off records (SVAE_OPT_TWOEND_FULL) instead of the two-ended kernels' lean `[P^-1 | c]`
+        records, from which P^-1 J12 is rebuilt by multiplying with the explicit inverse every step (cond^2 * eps);
+        + 19 % per step at 512 sequences of n = 10, + 79 % at 4096;
+      * inference + VJP (n <= 10, <= 2 samples): the one-call kernels on `[chol(P)^-T | c]` records at EVERY batch size
+        (SVAE_OPT_LEAN_ON; the default from 1025 sequences) -- factors of balanced magnitude: cond * eps; 1.7 instead of
+        0.7 ms per forward + backward at 512 sequences.
+    On a model with cond(J22) = 7.8e7 (the worst of 400 draws of the reference's rand_lds): E[x] 1.4e-9 / 1.7e-9 from a
+    60-digit solve instead of 2.6e-4 / 7e-4, node gradients 3.5e-9 from the reference's instead of 1.2e-4; on well-conditioned
+    models 1e-12 either way ("Conditioning").  Returns the previous default word."""
+    acc = _lib.OPT_TWOEND_FULL | _lib.OPT_LEAN_ON
+    return set_default_options(((_default_options & ~_lib.OPT_LEAN_OFF) | acc) if on else (_default_options & ~acc))
+
+
 class LDSEStepPlan(object):
     """Pre-allocated buffers for repeated E-steps of one shape (B, T, n): the launch itself does no
     allocation, no host<->device copy and no synchronisation.  The sampler and the VJP read the

@@ -459,6 +459,22 @@ def test_smoothed_means_against_a_60_digit_solve(seed, lean_bound, accurate_boun
     assert dist(samples[0, :, 0].cpu().numpy()) < accurate_bound      # the sampler's recursion at zero noise
     lean = kernel_variant in ("twoend", "twoend_seq", "twoend_rpc")
     assert dist(En[1][0].cpu().numpy()) < (lean_bound if lean else accurate_bound), kernel_variant
+    if kernel_variant == "twoend":
+        # the training path (inference + VJP): set_accurate_smoother routes it through the [chol(P)^-T | c] records at this
+        # batch size too -- E[x] and the node gradients (against the reference's compiled VJPs) at cond * eps
+        from svae_amd.lds import lds_inference as li
+        g = np.random.default_rng(7).standard_normal((1, T, n))
+        (gJ, gh, _), _ = ref.estep_vjp((init, pair), tuple(x[0] for x in node), 0.0, (np.zeros((T, n)), g[0]), None, seed=1)
+        for accurate, bound in ((True, accurate_bound * 100), (False, lean_bound * 10)):
+            old = li.set_accurate_smoother(accurate)
+            try:
+                nJ, nh, nz = (t(x).requires_grad_(True) for x in node)
+                _, (_, ex), _, _ = lds_inference_differentiable(nat, (nJ, nh, nz), eps=torch.zeros((1, T, 1, n), dtype=torch.float64, device=dev))
+                (t(g) * ex).sum().backward()
+            finally:
+                li.set_default_options(old)
+            assert dist(ex[0].detach().cpu().numpy()) < bound, accurate
+            assert _rel(nJ.grad[0], gJ) < bound * 100 and _rel(nh.grad[0], gh) < bound * 100, accurate
 
 
 def test_sampler_moments_match_smoother():

@@ -78,3 +78,17 @@ def test_nnet_linear_matches_plain_matmul_and_its_gradients():
     assert torch.allclose(J, -0.5 * torch.log1p(torch.exp(out[..., :4])), rtol=1e-13, atol=1e-14)
     assert torch.allclose(h, out[..., 4:], rtol=1e-13, atol=1e-14) and torch.allclose(tanh_mlp(layers, x), out)
     assert all(g is not None for g in torch.autograd.grad((J.sum() + (h * h).sum()), [W1, b1, W2, b2]))
+
+
+def test_accurate_smoother_switch_sets_the_full_record_option():
+    """set_accurate_smoother: the documented way to the cond * eps kernels (full records for the E-step, the chol(P)^-T
+    records for inference + VJP at every batch size); host-side word only."""
+    from svae_amd import _lib
+    from svae_amd.lds import lds_inference as li
+    old = li.set_accurate_smoother(True)
+    try:
+        assert li._default_options & _lib.OPT_TWOEND_FULL and li._default_options & _lib.OPT_LEAN_ON
+        assert li.set_accurate_smoother(False) & _lib.OPT_TWOEND_FULL
+        assert not (li._default_options & (_lib.OPT_TWOEND_FULL | _lib.OPT_LEAN_ON))
+    finally:
+        li.set_default_options(old)
