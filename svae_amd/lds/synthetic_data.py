@@ -70,6 +70,8 @@ def rand_slds_global_natparam(K, n, rng):
         M = 0.95 * np.eye(n)
         if n >= 2:
             M[:2, :2] = 0.95 * np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
-        lds.append((expfam.niw_standard_to_natural(t(S), t(0.3 * rng.standard_normal(n)), t(0.5), t(nu)),
-                    expfam.mniw_standard_to_natural(t(nu), t(S), t(M), t(0.2 * np.eye(n)))))
+        # (contiguous leaves: mniw_standard_to_natural returns a transposed view as its first block, and every consumer
+        #  that packs the parameters -- the device maps, the host copy for the prior term -- would copy it per state per call)
+        lds.append((expfam.niw_standard_to_natural(t(S), t(0.3 * rng.standard_normal(n)), t(0.5), t(nu)).contiguous(),
+                    tuple(x.contiguous() for x in expfam.mniw_standard_to_natural(t(nu), t(S), t(M), t(0.2 * np.eye(n))))))
     return (t(rng.random(K) * 2.), t(rng.random((K, K)) * 2. + 3. * np.eye(K))), lds
