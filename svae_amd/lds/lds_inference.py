@@ -482,6 +482,10 @@ def natural_lds_estep_general(natparam, node_params, plan=None, check=False, kee
     Returns (lognorm, (E_init_stats, E_pair_stats, E_node_stats)) shaped like the reference's
     (cython_lds_inference.pyx:197-210); with a batch axis first when the nodes are batched.
 
+    Accuracy: lognorm is at cond * eps; the smoothed moments of the default kernels for n <= 15 at cond^2 * eps (1e-12 on
+    well-conditioned models, within 1e-5 of the reference up to cond(J22) ~ 1e7); set_accurate_smoother() (or a plan with
+    SVAE_OPT_TWOEND_FULL) selects the cond * eps kernels.
+
     Asynchronous like the reference is silent: no host synchronisation unless `check=True`, which reads
     the device-side status word and raises FloatingPointError for potentials that are not positive
     definite (the reference ignores LAPACK `info`, cython_gaussian_grads.pxd:54-76); `plan.check_info()`
