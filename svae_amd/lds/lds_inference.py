@@ -420,6 +420,34 @@ def _dense_stats(stats, info):
     return Ei, Ep, En
 
 
+# Homogeneous pair parameters that arrive as HOST data (NumPy arrays / CPU tensors: what a caller coming from the reference
+# passes) are looked at before they go to the device: beyond this condition number of J11 / J22 a plan made on the spot takes
+# the cond * eps kernels (set_accurate_smoother's option bits) for that call.  Two n x n SVDs on the host, no device
+# synchronisation; device-resident parameters -- the fast path -- are never inspected.  None switches the guard off.
+CONDITION_GUARD_THRESHOLD = 1e6
+
+
+def _host_condition_options(pair_params):
+    """option bits for a plan created on the spot: the accurate kernels when the pair blocks are host data and ill-conditioned"""
+    if CONDITION_GUARD_THRESHOLD is None:
+        return 0
+    blocks = []
+    for x in (pair_params[0], pair_params[2]):
+        if isinstance(x, torch.Tensor):
+            if x.is_cuda:
+                return 0
+            x = x.detach().numpy()
+        x = np.asarray(x, dtype=float)
+        if x.ndim != 2 or x.shape[0] != x.shape[1] or x.shape[0] > 15 or not np.all(np.isfinite(x)):
+            return 0
+        blocks.append(x)
+    try:
+        worst = max(float(np.linalg.cond(b)) for b in blocks)
+    except np.linalg.LinAlgError:
+        return 0
+    return (_lib.OPT_TWOEND_FULL | _lib.OPT_LEAN_ON) if worst > CONDITION_GUARD_THRESHOLD else 0
+
+
 def _prepare(natparam, node_params, plan):
     """Shape checks / canonical device tensors shared by the E-step, filter and sampler wrappers
     (`_canonical_node_params`, `_canonical_init_params`, lds_inference.py:59-82)."""
@@ -464,7 +492,9 @@ def _prepare(natparam, node_params, plan):
         raise ValueError("pair logZ must have one entry per step")
 
     if plan is None:
-        plan = LDSEStepPlan(B, T, n, dev, inhomog, pair_batched)
+        guard = 0 if inhomog else _host_condition_options(pair_params)
+        plan = LDSEStepPlan(B, T, n, dev, inhomog, pair_batched,
+                            options=((_default_options & ~_lib.OPT_LEAN_OFF) | guard) if guard else None)
     elif (plan.B, plan.T, plan.n, plan.inhomog) != (B, T, n, inhomog):
         raise ValueError("plan shape mismatch")
     return dict(plan=plan, batched=batched, B=B, T=T, n=n, inhomog=inhomog, pair_batched=pair_batched,
@@ -862,7 +892,9 @@ def lds_inference_differentiable(natparam, node_params, eps=None, plan=None, pai
         logZ_pair = logZ_pair.reshape(1).expand(max(T - 1, 0)).contiguous()
         inhomog = True
     if plan is None:
-        plan = LDSEStepPlan(B, T, n, dev, inhomog, pair_batched)
+        guard = 0 if np.ndim(pair_params[0]) != 2 else _host_condition_options(pair_params)
+        plan = LDSEStepPlan(B, T, n, dev, inhomog, pair_batched,
+                            options=((_default_options & ~_lib.OPT_LEAN_OFF) | guard) if guard else None)
     elif plan.inhomog != inhomog:
         raise ValueError("plan layout mismatch (pair_stats_grad=True needs a per-step plan: inhomog=True)")
     params = (init_J, init_h, init_logZ, J11, J12, J22, logZ_pair)

@@ -460,6 +460,11 @@ def test_smoothed_means_against_a_60_digit_solve(seed, lean_bound, accurate_boun
     lean = kernel_variant in ("twoend", "twoend_seq", "twoend_rpc")
     assert dist(En[1][0].cpu().numpy()) < (lean_bound if lean else accurate_bound), kernel_variant
     if kernel_variant == "twoend":
+        # parameters handed over as HOST arrays (the reference's calling convention) are looked at on the way in
+        # (lds_inference.CONDITION_GUARD_THRESHOLD): this model gets the accurate kernels without being asked
+        with torch.no_grad():
+            _, (_, _, En_host) = natural_lds_estep_general((init, pair), tuple(np.asarray(x) for x in node))
+        assert dist(En_host[1][0].cpu().numpy()) < accurate_bound
         # the training path (inference + VJP): set_accurate_smoother routes it through the [chol(P)^-T | c] records at this
         # batch size too -- E[x] and the node gradients (against the reference's compiled VJPs) at cond * eps
         from svae_amd.lds import lds_inference as li

@@ -92,3 +92,26 @@ def test_accurate_smoother_switch_sets_the_full_record_option():
         assert not (li._default_options & (_lib.OPT_TWOEND_FULL | _lib.OPT_LEAN_ON))
     finally:
         li.set_default_options(old)
+
+
+def test_host_condition_guard_picks_the_accurate_kernels_for_ill_conditioned_host_parameters():
+    """_host_condition_options: homogeneous pair blocks that arrive as host data (what a caller of the reference passes) and
+    are ill-conditioned -> the option bits of the cond * eps kernels for a plan made on the spot; well-conditioned blocks,
+    per-step parameters and anything that is not plain host data -> 0 (device tensors are never inspected)."""
+    import numpy as np
+    import torch
+    from svae_amd import _lib
+    from svae_amd.lds import lds_inference as li
+    from svae_amd.lds.synthetic_data import rand_lds_natparam
+    acc = _lib.OPT_TWOEND_FULL | _lib.OPT_LEAN_ON
+    good = rand_lds_natparam(7, np.random.default_rng(0))[1]       # cond(J22) 1e3
+    bad = rand_lds_natparam(7, np.random.default_rng(262))[1]      # cond(J22) 7.8e7
+    assert li._host_condition_options(good) == 0
+    assert li._host_condition_options(bad) == acc
+    assert li._host_condition_options(tuple(torch.as_tensor(np.asarray(x)) for x in bad)) == acc
+    assert li._host_condition_options(tuple(np.stack([np.asarray(x)] * 3) for x in bad[:3]) + (np.zeros(3),)) == 0
+    old, li.CONDITION_GUARD_THRESHOLD = li.CONDITION_GUARD_THRESHOLD, None
+    try:
+        assert li._host_condition_options(bad) == 0
+    finally:
+        li.CONDITION_GUARD_THRESHOLD = old
