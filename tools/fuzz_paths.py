@@ -1,6 +1,7 @@
 """Random shapes through the parametrised GPU parity tests of the n <= 15 paths (E-step / sampler / filter / VJPs against the
 reference's compiled code, lean against full records, HMM two-ended and wide kernels, the SLDS consumer against the table
-kernel): the shapes the fixed parametrisations do not list.  Usage: python tools/fuzz_paths.py [seconds] [seed] [a|b]   (b: GMM, latent dimension 16 .. 64, dense node potentials)"""
+kernel): the shapes the fixed parametrisations do not list.  Usage: python tools/fuzz_paths.py [seconds] [seed] [a|b|c]   (b: GMM, latent dimension 16 .. 64, dense node potentials; c: SLDS ascent and
+its glue kernels, model-level run_inference, GMM local step against autograd)"""
 import os, sys, time, traceback
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,6 +9,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import pytest  # noqa: E402
 import test_lds_hip as tl, test_vjp_hip as tv, test_lean_hip as tn, test_hmm_hip as th, test_slds_hip as ts  # noqa: E402
 import test_gmm_hip as tg, test_lds_tile_hip as tt, test_lds_dense_hip as td  # noqa: E402
+import test_models_hip as tm, test_svae_hip as tsv  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -37,9 +39,30 @@ def draw_b():
     return "dense_grad", un(td.test_gradients_through_dense_node_potentials), (ri(1, 10), ri(2, 14), ri(1, 3), ri(1, 2), bool(ri(0, 1)))
 
 
+def draw_c():
+    kind = ri(0, 7)
+    if kind == 0:
+        return "slds_ascent", un(ts.test_optimize_local_meanfield_matches_oracle), (ri(1, 8), ri(1, 10), ri(2, 40), ri(1, 6), bool(ri(0, 1)), bool(ri(0, 1)))
+    if kind == 1:
+        return "slds_contract", un(ts.test_contraction_kernels_against_the_dense_forms), (ri(1, 16), ri(1, 15), ri(2, 40), ri(1, 12))
+    if kind == 2:
+        return "slds_final_contract", un(ts.test_final_pass_contractions_against_the_two_library_forms), (ri(1, 8), ri(1, 10), ri(2, 60), ri(1, 40))
+    if kind == 3:
+        return "slds_init_path", un(ts.test_initial_sample_path_diagonal_kernel_equals_the_dense_filter_and_sampler), (ri(1, 80), ri(1, 60), ri(1, 10))
+    if kind == 4:
+        return "gmm_local_autograd", un(tsv.test_gmm_local_step_kernels_against_torch_autograd), (ri(1, 20), ri(1, 8), ri(1, 200), ri(1, 3))
+    if kind == 5:
+        return "lds_model", un(tm.test_lds_run_inference_against_oracle), (ri(1, 15), ri(1, 40), ri(1, 6), ri(1, 3))
+    if kind == 6:
+        return "global_step", un(tm.test_global_step_kernel_matches_the_exponential_family_maps), (ri(1, 64),)
+    return "slds_maps", un(tm.test_slds_global_maps_in_one_launch_equal_one_launch_per_state), (ri(1, 16), ri(1, 15))
+
+
 def draw():
     if group == "b":
         return draw_b()
+    if group == "c":
+        return draw_c()
     kind = ri(0, 9)
     if kind == 0:
         return "vjp_ref", un(tv.test_vjp_against_reference_compiled_vjps), (ri(1, 15), ri(1, 60), ri(1, 9), ri(1, 4), bool(ri(0, 1)))
@@ -66,7 +89,7 @@ def draw():
 
 # every module's _rel records what it measured, so that a failure can say by how much
 seen = []
-for m in (tl, tv, tn, th, ts, tg, tt, td):
+for m in (tl, tv, tn, th, ts, tg, tt, td, tm, tsv):
     if hasattr(m, "_rel"):
         def wrap(f):
             def g(*a, **k):
