@@ -1,7 +1,8 @@
 """Random shapes through the parametrised GPU parity tests of the n <= 15 paths (E-step / sampler / filter / VJPs against the
 reference's compiled code, lean against full records, HMM two-ended and wide kernels, the SLDS consumer against the table
 kernel): the shapes the fixed parametrisations do not list.  Usage: python tools/fuzz_paths.py [seconds] [seed] [a|b|c]   (b: GMM, latent dimension 16 .. 64, dense node potentials; c: SLDS ascent and
-its glue kernels, model-level run_inference, GMM local step against autograd)"""
+its glue kernels, model-level run_inference, GMM local step against autograd; d: batch sizes across the kernel-selection
+thresholds -- E-step against the reference on a few sequences, run-to-run bit equality, one-call inference against the E-step)"""
 import os, sys, time, traceback
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -58,9 +59,46 @@ def draw_c():
     return "slds_maps", un(tm.test_slds_global_maps_in_one_launch_equal_one_launch_per_state), (ri(1, 16), ri(1, 15))
 
 
+def _batch_case(n, T, B, S, seed):
+    """well-conditioned homogeneous model, B sequences: E-step vs the reference's compiled E-step on 5 of them, twice (bit
+    equality), and the one-call inference path's statistics against the E-step path's"""
+    import torch
+    from oracle import ref
+    from svae_amd.lds.lds_inference import natural_lds_estep_general, natural_lds_inference_general
+    from svae_amd.lds.synthetic_data import rand_lds_natparam, rand_node_potentials
+    r = np.random.default_rng(seed)
+    while True:
+        init, pair = rand_lds_natparam(n, r)
+        if max(np.linalg.cond(np.asarray(pair[0])), np.linalg.cond(np.asarray(pair[2]))) < 1e3:
+            break
+    node = rand_node_potentials((B, T, n), r, with_logZ=True)
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.as_tensor(np.asarray(x, float), dtype=torch.float64, device=dev)
+    nat = (tuple(t(x) for x in init), tuple(t(x) for x in pair))
+    nd = tuple(t(x) for x in node)
+    ln, (Ei, Ep, En) = natural_lds_estep_general(nat, nd)
+    ln2, (Ei2, Ep2, En2) = natural_lds_estep_general(nat, nd)
+    assert torch.equal(ln, ln2) and torch.equal(En[1], En2[1]) and torch.equal(Ep[1], Ep2[1]), "run-to-run"
+    for b in sorted(set(int(x) for x in r.integers(0, B, 5)) | {0, B - 1}):
+        wl, (wi, wp, wn) = ref.estep((init, pair), tuple(x[b] for x in node))
+        assert tl._rel(ln[b], wl) < 1e-7 and tl._rel(En[1][b], wn[1]) < 1e-7 and tl._rel(En[0][b], wn[0]) < 1e-7, ("estep", b)
+        assert tl._rel(Ei[0][b], wi[0]) < 1e-7 and all(tl._rel(Ep[k][b], wp[k]) < 1e-7 for k in range(3)), ("estep pair", b)
+    if S:
+        eps = torch.as_tensor(r.standard_normal((B, T, S, n)), device=dev)
+        samples, (Ei3, Ep3, En3), ln3 = natural_lds_inference_general(nat, nd, eps=eps)
+        assert tl._rel(ln3, ln.cpu().numpy()) < 1e-9 and tl._rel(En3[1], En[1].cpu().numpy()) < 1e-9, "inference vs estep"
+
+
+def draw_d():
+    B = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 63, 64, 65, 255, 256, 257, 511, 512, 513, 700, 1023, 1024, 1025, 1026, 1500, 2047, 2048, 2049, 3000, 4095, 4096, 4097, 4300]))
+    return "batch", _batch_case, (ri(1, 15), ri(1, 40), B, ri(0, 2), ri(0, 10 ** 6))
+
+
 def draw():
     if group == "b":
         return draw_b()
+    if group == "d":
+        return draw_d()
     if group == "c":
         return draw_c()
     kind = ri(0, 9)
